@@ -1,0 +1,272 @@
+"""Box algebra, NMS and detection metrics.
+
+Interface mirror of the hot-path part of the reference's ``utils/utils.py``: ``xyxy2xywh`` :98,
+``xywh2xyxy`` :108, ``scale_coords`` :138, ``clip_coords`` :154, ``ap_per_class`` :162,
+``compute_ap`` :225, ``bbox_iou`` :254, ``box_iou`` :300, ``wh_iou`` :325,
+``non_max_suppression`` :782-860.  Star-importing this module also provides the std names the
+reference scripts expect from it (``torch``, ``nn``, ``np``, ``os``, ``math``, ``glob`` ...).
+
+``non_max_suppression`` has two executions of the same algorithm:
+
+* CUDA tensor  -> the HIP kernels of ``csrc/nms.hip`` through ``engine.nms`` (candidate compaction,
+  IoU bit-mask matrix, greedy scan, merge).  No silent fallback: a missing library raises.
+* CPU tensor   -> the eager host path below (what runs in the CPU-only container and in host tests).
+
+``torchvision.ops.boxes.nms`` (the reference's call at utils.py:843) is not available in this image;
+its published contract is restated in ``nms_greedy``: order by score descending, keep a box unless an
+already-kept box overlaps it with IoU **>** threshold, return kept indices in score order.
+"""
+import glob
+import math
+import os
+import random
+import shutil
+import subprocess
+import time
+from pathlib import Path
+from sys import platform
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+try:  # tqdm is plumbing only
+    from tqdm import tqdm
+except Exception:  # pragma: no cover
+    def tqdm(x, *a, **k):
+        return x
+
+try:  # opencv is optional in this image; image I/O paths need it, tensor paths do not
+    import cv2
+    cv2.setNumThreads(0)
+except Exception:  # pragma: no cover
+    cv2 = None
+
+from . import torch_utils
+
+torch.set_printoptions(linewidth=320, precision=5, profile='long')
+np.set_printoptions(linewidth=320, formatter={'float_kind': '{:11.5g}'.format})
+
+MIN_WH, MAX_WH = 2, 4096  # NMS box-size window and the per-class coordinate offset (utils.py:790)
+
+
+def init_seeds(seed=0):
+    random.seed(seed)
+    np.random.seed(seed)
+    torch_utils.init_seeds(seed=seed)
+
+
+def load_classes(path):
+    with open(path, 'r') as fh:
+        return [n for n in fh.read().split('\n') if n]
+
+
+def coco80_to_coco91_class():
+    skipped = {12, 26, 29, 30, 45, 66, 68, 69, 71, 83}
+    return [i for i in range(1, 91) if i not in skipped]
+
+
+# ------------------------------------------------------------------------------------------------ boxes
+def _empty_like(x):
+    return torch.zeros_like(x) if isinstance(x, torch.Tensor) else np.zeros_like(x)
+
+
+def xyxy2xywh(x):
+    y = _empty_like(x)
+    y[:, 0] = (x[:, 0] + x[:, 2]) / 2
+    y[:, 1] = (x[:, 1] + x[:, 3]) / 2
+    y[:, 2] = x[:, 2] - x[:, 0]
+    y[:, 3] = x[:, 3] - x[:, 1]
+    return y
+
+
+def xywh2xyxy(x):
+    y = _empty_like(x)
+    y[:, 0] = x[:, 0] - x[:, 2] / 2
+    y[:, 1] = x[:, 1] - x[:, 3] / 2
+    y[:, 2] = x[:, 0] + x[:, 2] / 2
+    y[:, 3] = x[:, 1] + x[:, 3] / 2
+    return y
+
+
+def clip_coords(boxes, img_shape):
+    boxes[:, 0].clamp_(0, img_shape[1])
+    boxes[:, 1].clamp_(0, img_shape[0])
+    boxes[:, 2].clamp_(0, img_shape[1])
+    boxes[:, 3].clamp_(0, img_shape[0])
+
+
+def scale_coords(img1_shape, coords, img0_shape, ratio_pad=None):
+    """Map xyxy boxes from the letterboxed network input back to the original image, in place."""
+    if ratio_pad is None:
+        gain = max(img1_shape) / max(img0_shape)
+        pad = ((img1_shape[1] - img0_shape[1] * gain) / 2, (img1_shape[0] - img0_shape[0] * gain) / 2)
+    else:
+        gain, pad = ratio_pad[0][0], ratio_pad[1]
+    coords[:, [0, 2]] -= pad[0]
+    coords[:, [1, 3]] -= pad[1]
+    coords[:, :4] /= gain
+    clip_coords(coords, img0_shape)
+    return coords
+
+
+def box_iou(box1, box2):
+    """(N,4) x (M,4) xyxy -> (N,M) IoU."""
+    a1 = (box1[:, 2] - box1[:, 0]) * (box1[:, 3] - box1[:, 1])
+    a2 = (box2[:, 2] - box2[:, 0]) * (box2[:, 3] - box2[:, 1])
+    lt = torch.max(box1[:, None, :2], box2[:, :2])
+    rb = torch.min(box1[:, None, 2:], box2[:, 2:])
+    inter = (rb - lt).clamp(0).prod(2)
+    return inter / (a1[:, None] + a2 - inter)
+
+
+def wh_iou(wh1, wh2):
+    wh1 = wh1[:, None]
+    wh2 = wh2[None]
+    inter = torch.min(wh1, wh2).prod(2)
+    return inter / (wh1.prod(2) + wh2.prod(2) - inter)
+
+
+def bbox_iou(box1, box2, x1y1x2y2=True, GIoU=False, DIoU=False, CIoU=False):
+    """IoU (or G/D/C-IoU) of one box (4,) against n boxes (n,4)."""
+    box2 = box2.t()
+    if x1y1x2y2:
+        ax1, ay1, ax2, ay2 = box1[0], box1[1], box1[2], box1[3]
+        bx1, by1, bx2, by2 = box2[0], box2[1], box2[2], box2[3]
+    else:
+        ax1, ax2 = box1[0] - box1[2] / 2, box1[0] + box1[2] / 2
+        ay1, ay2 = box1[1] - box1[3] / 2, box1[1] + box1[3] / 2
+        bx1, bx2 = box2[0] - box2[2] / 2, box2[0] + box2[2] / 2
+        by1, by2 = box2[1] - box2[3] / 2, box2[1] + box2[3] / 2
+    inter = (torch.min(ax2, bx2) - torch.max(ax1, bx1)).clamp(0) * \
+            (torch.min(ay2, by2) - torch.max(ay1, by1)).clamp(0)
+    w1, h1 = ax2 - ax1, ay2 - ay1
+    w2, h2 = bx2 - bx1, by2 - by1
+    union = (w1 * h1 + 1e-16) + w2 * h2 - inter
+    iou = inter / union
+    if not (GIoU or DIoU or CIoU):
+        return iou
+    cw = torch.max(ax2, bx2) - torch.min(ax1, bx1)
+    ch = torch.max(ay2, by2) - torch.min(ay1, by1)
+    if GIoU:
+        hull = cw * ch + 1e-16
+        return iou - (hull - union) / hull
+    diag2 = cw ** 2 + ch ** 2 + 1e-16
+    rho2 = ((bx1 + bx2) - (ax1 + ax2)) ** 2 / 4 + ((by1 + by2) - (ay1 + ay2)) ** 2 / 4
+    if DIoU:
+        return iou - rho2 / diag2
+    v = (4 / math.pi ** 2) * torch.pow(torch.atan(w2 / h2) - torch.atan(w1 / h1), 2)
+    with torch.no_grad():
+        alpha = v / (1 - iou + v)
+    return iou - (rho2 / diag2 + v * alpha)
+
+
+# -------------------------------------------------------------------------------------------------- NMS
+def nms_greedy(boxes, scores, iou_thres):
+    """Host restatement of torchvision.ops.boxes.nms (see module docstring). Returns LongTensor."""
+    n = boxes.shape[0]
+    if n == 0:
+        return torch.zeros(0, dtype=torch.long, device=boxes.device)
+    order = torch.argsort(scores, descending=True, stable=True)
+    b = boxes[order]
+    iou = box_iou(b, b)
+    alive = torch.ones(n, dtype=torch.bool)
+    over = (iou > iou_thres).cpu()
+    keep = []
+    for i in range(n):
+        if alive[i]:
+            keep.append(i)
+            alive &= ~over[i]
+    return order[torch.tensor(keep, dtype=torch.long, device=boxes.device)]
+
+
+def _nms_one_image_host(x, conf_thres, iou_thres, multi_label, classes, agnostic):
+    """Reference algorithm for one image's (rows, 5+nc) prediction block; returns (n,6) or None."""
+    x = x[x[:, 4] > conf_thres]
+    wh = x[:, 2:4]
+    x = x[((wh > MIN_WH) & (wh < MAX_WH)).all(1)]
+    if x.shape[0] == 0:
+        return None
+    x[:, 5:] *= x[:, 4:5]
+    box = xywh2xyxy(x[:, :4])
+    if multi_label:
+        rows, cls = (x[:, 5:] > conf_thres).nonzero(as_tuple=False).t()
+        x = torch.cat((box[rows], x[rows, cls + 5].unsqueeze(1), cls.float().unsqueeze(1)), 1)
+    else:
+        conf, cls = x[:, 5:].max(1)
+        x = torch.cat((box, conf.unsqueeze(1), cls.float().unsqueeze(1)), 1)
+    if classes:
+        x = x[(cls.view(-1, 1) == torch.tensor(classes, device=cls.device)).any(1)]
+    finite = torch.isfinite(x).all(1)
+    if not finite.all():
+        x = x[finite]
+    n = x.shape[0]
+    if n == 0:
+        return None
+    offs = x[:, 5] * 0 if agnostic else x[:, 5]
+    boxes = x[:, :4].clone() + offs.view(-1, 1) * MAX_WH
+    scores = x[:, 4]
+    keep = nms_greedy(boxes, scores, iou_thres)
+    if 1 < n < 3000:  # merge-NMS: kept boxes become score-weighted means of what they suppress
+        w = (box_iou(boxes[keep], boxes) > iou_thres) * scores[None]
+        x[keep, :4] = torch.mm(w, x[:, :4]).float() / w.sum(1, keepdim=True)
+    return x[keep]
+
+
+def non_max_suppression(prediction, conf_thres=0.1, iou_thres=0.6, multi_label=True, classes=None, agnostic=False):
+    """(N, rows, 5+nc) decoded head output -> list of (n_i, 6) [x1,y1,x2,y2,conf,cls] or None."""
+    nc = prediction[0].shape[1] - 5
+    multi_label = bool(multi_label) and nc > 1
+    if isinstance(prediction, torch.Tensor) and prediction.is_cuda:
+        from engine import nms as hip_nms  # HIP path; raises if the library is missing
+        return hip_nms.non_max_suppression(prediction, conf_thres, iou_thres, multi_label, classes, agnostic)
+    out = [None] * len(prediction)
+    for k, x in enumerate(prediction):
+        out[k] = _nms_one_image_host(x, conf_thres, iou_thres, multi_label, classes, agnostic)
+    return out
+
+
+# ----------------------------------------------------------------------------------------------- metrics
+def compute_ap(recall, precision):
+    """101-point interpolated AP of one PR curve (COCO style)."""
+    mrec = np.concatenate(([0.], recall, [min(recall[-1] + 1E-3, 1.)]))
+    mpre = np.concatenate(([0.], precision, [0.]))
+    mpre = np.flip(np.maximum.accumulate(np.flip(mpre)))
+    x = np.linspace(0, 1, 101)
+    trapz = getattr(np, 'trapezoid', None) or np.trapz
+    return trapz(np.interp(x, mrec, mpre), x)
+
+
+def ap_per_class(tp, conf, pred_cls, target_cls):
+    """Per-class P, R, AP, F1 from per-detection TP flags (n, n_iou), scores and classes."""
+    order = np.argsort(-conf)
+    tp, conf, pred_cls = tp[order], conf[order], pred_cls[order]
+    unique_classes = np.unique(target_cls)
+    pr_score = 0.1
+    shape = [len(unique_classes), tp.shape[1]]
+    ap, p, r = np.zeros(shape), np.zeros(shape), np.zeros(shape)
+    for ci, c in enumerate(unique_classes):
+        sel = pred_cls == c
+        n_gt = (target_cls == c).sum()
+        if sel.sum() == 0 or n_gt == 0:
+            continue
+        fpc = (1 - tp[sel]).cumsum(0)
+        tpc = tp[sel].cumsum(0)
+        recall = tpc / (n_gt + 1e-16)
+        precision = tpc / (tpc + fpc)
+        r[ci] = np.interp(-pr_score, -conf[sel], recall[:, 0])
+        p[ci] = np.interp(-pr_score, -conf[sel], precision[:, 0])
+        for j in range(tp.shape[1]):
+            ap[ci, j] = compute_ap(recall[:, j], precision[:, j])
+    f1 = 2 * p * r / (p + r + 1e-16)
+    return p, r, ap, f1, unique_classes.astype('int32')
+
+
+def fitness(x):
+    w = [0.0, 0.0, 0.8, 0.2]  # weights for [P, R, mAP, F1]
+    return (x[:, :4] * w).sum(1)
+
+
+def get_yolo_layers(model):
+    return [i for i, d in enumerate(model.module_defs) if d['type'] == 'yolo']
