@@ -1,0 +1,144 @@
+#!/usr/bin/env python3
+"""Generate the committed golden fixtures by running the REFERENCE implementation on CPU.
+
+Run in the build container only (needs /root/reference; see tests/refharness.py for the two stubbed
+I/O imports):
+
+    python tests/golden/make_golden.py
+
+Writes ``tests/golden/*.npz``.  Each network fixture stores the recipe (cfg, size, seeds), a SHA-256
+of the seeded weights, a row subset of the reference's ``inf_out`` plus whole-tensor checksums, and
+per-head raw-output checksums; NMS fixtures store the full inputs' recipe and the reference outputs.
+"""
+import hashlib
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+import conftest  # noqa: F401  (puts the package on sys.path)
+import refharness
+import synth
+
+REFCFG = os.path.join(refharness.REF, 'cfg')
+
+NET_CASES = [
+    # name, cfg (relative to cfg/), size, batch, row stride of the stored subset
+    ('tiny_hand_416', 'yolov3tiny/yolov3-tiny-hand.cfg', 416, 2, 1),
+    ('yolov3_320', 'yolov3/yolov3.cfg', 320, 1, 16),
+    ('yolov4_320', 'yolov4/yolov4.cfg', 320, 1, 16),
+    ('yolov3_608', 'yolov3/yolov3.cfg', 608, 1, 64),
+]
+
+
+def state_digest(state):
+    h = hashlib.sha256()
+    for k, v in state.items():
+        h.update(k.encode())
+        h.update(v.detach().cpu().contiguous().numpy().tobytes())
+    return h.hexdigest()
+
+
+def checks(t):
+    t = t.detach().double()
+    return np.array([t.sum().item(), t.abs().sum().item(), t.abs().max().item()], dtype=np.float64)
+
+
+def build_reference(ref, rel, size):
+    torch.manual_seed(0)
+    model = ref.models.Darknet(os.path.join(REFCFG, rel), (size, size))
+    state = model.state_dict()
+    synth.randomize_bn_(state, seed=1)
+    model.load_state_dict(state)
+    return model.eval()
+
+
+def net_fixture(ref, name, rel, size, batch, row_stride):
+    model = build_reference(ref, rel, size)
+    x = synth.image_batch(batch, size, seed=0)
+    with torch.no_grad():
+        inf, raws, _ = model(x)
+        model.fuse()
+        inf_fused = model(x)[0]
+    out = dict(cfg=rel, size=size, batch=batch, row_stride=row_stride, weights_sha256=state_digest(model_state(ref, rel, size)),
+               inf_rows=inf[:, ::row_stride].numpy().astype(np.float32), inf_checks=checks(inf),
+               inf_shape=np.array(inf.shape), fused_vs_unfused_maxabs=(inf - inf_fused).abs().max().item())
+    for i, r in enumerate(raws):
+        out['raw%d_checks' % i] = checks(r)
+        out['raw%d_shape' % i] = np.array(r.shape)
+    np.savez_compressed(os.path.join(HERE, 'net_%s.npz' % name), **out)
+    print(name, tuple(inf.shape), 'fused-vs-unfused drift %.3g' % out['fused_vs_unfused_maxabs'])
+
+
+def model_state(ref, rel, size):
+    torch.manual_seed(0)
+    m = ref.models.Darknet(os.path.join(REFCFG, rel), (size, size))
+    return synth.randomize_bn_(m.state_dict(), seed=1)
+
+
+def nms_fixtures(ref):
+    cases = [
+        # name, n_img, rows, nc, seed, conf, iou, multi_label, agnostic
+        ('detect_80', 2, 600, 80, 11, 0.3, 0.6, False, False),
+        ('test_80', 2, 300, 80, 12, 0.001, 0.6, True, False),
+        ('single_class', 1, 500, 1, 13, 0.3, 0.6, True, False),
+        ('agnostic', 1, 400, 20, 14, 0.25, 0.45, False, True),
+        ('empty', 2, 64, 80, 15, 0.999, 0.6, False, False),
+        ('one_box', 1, 8, 3, 16, 0.9, 0.6, False, False),
+    ]
+    for name, n_img, rows, nc, seed, conf, iou, ml, agn in cases:
+        pred = synth.nms_candidates(n_img, rows, nc, seed)
+        res = ref.utils.non_max_suppression(pred.clone(), conf, iou, multi_label=ml, agnostic=agn)
+        out = dict(n_img=n_img, rows=rows, nc=nc, seed=seed, conf=conf, iou=iou, multi_label=ml, agnostic=agn,
+                   counts=np.array([0 if r is None else len(r) for r in res]))
+        for i, r in enumerate(res):
+            out['det%d' % i] = np.zeros((0, 6), np.float32) if r is None else r.numpy().astype(np.float32)
+        np.savez_compressed(os.path.join(HERE, 'nms_%s.npz' % name), **out)
+        print('nms', name, out['counts'])
+
+
+def fuse_fixture(ref):
+    torch.manual_seed(3)
+    conv = torch.nn.Conv2d(6, 10, 3, stride=2, padding=1, bias=False)
+    bn = torch.nn.BatchNorm2d(10)
+    g = torch.Generator().manual_seed(4)
+    bn.weight.data = torch.rand(10, generator=g) + 0.5
+    bn.bias.data = torch.randn(10, generator=g)
+    bn.running_mean = torch.randn(10, generator=g)
+    bn.running_var = torch.rand(10, generator=g) + 0.5
+    fused = ref.torch_utils.fuse_conv_and_bn(conv, bn.eval())
+    np.savez_compressed(os.path.join(HERE, 'fuse_conv_bn.npz'),
+                        w=conv.weight.detach().numpy(), gamma=bn.weight.detach().numpy(), beta=bn.bias.detach().numpy(),
+                        mean=bn.running_mean.numpy(), var=bn.running_var.numpy(), eps=bn.eps,
+                        fused_w=fused.weight.detach().numpy(), fused_b=fused.bias.detach().numpy())
+    print('fuse fixture ok')
+
+
+def decode_fixture(ref):
+    """YOLOLayer eval decode on a small seeded head map, both stride orders."""
+    g = torch.Generator().manual_seed(5)
+    anchors = np.array([[10, 13], [16, 30], [33, 23]], dtype=np.float64)
+    p = torch.randn(2, 3 * 9, 5, 7, generator=g)
+    layer = ref.models.YOLOLayer(anchors=anchors, nc=4, img_size=(224, 160), yolo_index=0, layers=[], stride=32,
+                                 quantizer_output=False).eval()
+    io, raw = layer(p.clone(), None)
+    np.savez_compressed(os.path.join(HERE, 'yolo_decode.npz'), p=p.numpy(), anchors=anchors, stride=32, nc=4,
+                        io=io.numpy(), raw=raw.numpy())
+    print('decode fixture ok', tuple(io.shape))
+
+
+def main():
+    ref = refharness.load()
+    torch.set_num_threads(8)
+    for case in NET_CASES:
+        net_fixture(ref, *case)
+    nms_fixtures(ref)
+    fuse_fixture(ref)
+    decode_fixture(ref)
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,75 @@
+"""Seeded synthetic weights / inputs / NMS candidates shared by the golden generator and the tests.
+
+Everything is derived from ``torch.Generator().manual_seed(seed)`` on the CPU so that the build
+container (where the reference is importable) and the GPU box produce identical tensors.
+"""
+import math
+
+import numpy as np
+import torch
+
+
+def randomize_bn_(state, seed=1):
+    """Make BN non-trivial in a state_dict, in key order: mean~N(0,.1) var~U(.5,1.5) g~U(.5,1.5) b~N(0,.1)."""
+    g = torch.Generator().manual_seed(seed)
+    for k, v in state.items():
+        if k.endswith('running_mean'):
+            v.copy_(torch.randn(v.shape, generator=g) * 0.1)
+        elif k.endswith('running_var'):
+            v.copy_(torch.rand(v.shape, generator=g) + 0.5)
+        elif k.endswith('BatchNorm2d.weight'):
+            v.copy_(torch.rand(v.shape, generator=g) + 0.5)
+        elif k.endswith('BatchNorm2d.bias'):
+            v.copy_(torch.randn(v.shape, generator=g) * 0.1)
+    return state
+
+
+def boost_heads_(state, module_defs, seed=2, frac=0.02, amount=6.0):
+    """Raise the objectness bias path so that a seeded subset of cells clears conf thresholds.
+
+    The smart-bias init puts obj logits near -4.5; adding ``amount`` to the obj *bias* would light up
+    every cell, so instead a sparse random set of head-conv weight rows gets a positive kick through
+    the bias of obj channels scaled by ``frac`` of anchors: obj bias += amount for one anchor per head.
+    """
+    g = torch.Generator().manual_seed(seed)
+    defs = [d for d in module_defs if d['type'] != 'net']
+    for i, d in enumerate(defs):
+        if d['type'] != 'yolo':
+            continue
+        key = 'module_list.%d.Conv2d.bias' % (i - 1)
+        no = int(d['classes']) + 5
+        b = state[key].view(len(d['mask']), no)
+        a = int(torch.randint(0, len(d['mask']), (1,), generator=g))
+        b[a, 4] += amount * frac * 10
+    return state
+
+
+def image_batch(n, size, seed=0, channels=3):
+    g = torch.Generator().manual_seed(seed)
+    return torch.rand(n, channels, size, size, generator=g)
+
+
+def nms_candidates(n_img, rows, nc, seed, n_clusters=12, img=608, hot=0.35):
+    """Decoded-head-like tensor (n_img, rows, 5+nc): clustered boxes, tied scores, tiny/huge boxes."""
+    g = torch.Generator().manual_seed(seed)
+    out = torch.zeros(n_img, rows, 5 + nc)
+    for b in range(n_img):
+        centers = torch.rand(n_clusters, 2, generator=g) * img
+        sizes = torch.rand(n_clusters, 2, generator=g) * 150 + 20
+        which = torch.randint(0, n_clusters, (rows,), generator=g)
+        out[b, :, 0:2] = centers[which] + torch.randn(rows, 2, generator=g) * 6
+        out[b, :, 2:4] = sizes[which] * (1 + torch.randn(rows, 2, generator=g) * 0.08)
+        obj = torch.rand(rows, generator=g)
+        obj = torch.where(torch.rand(rows, generator=g) < hot, obj, obj * 0.05)
+        obj = (obj * 64).round() / 64  # quantise -> plenty of exactly tied scores
+        out[b, :, 4] = obj
+        cls = torch.rand(rows, nc, generator=g)
+        fav = torch.randint(0, nc, (n_clusters,), generator=g)[which]
+        cls[torch.arange(rows), fav] = 0.9 + 0.1 * torch.rand(rows, generator=g)
+        out[b, :, 5:] = cls
+        if rows >= 8:  # degenerate rows: too small, too large, non-finite
+            out[b, 0, 2:4] = 1.0
+            out[b, 1, 2:4] = 5000.0
+            out[b, 2, 4] = 0.99
+            out[b, 2, 0] = float('inf')
+    return out
