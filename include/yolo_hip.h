@@ -1,0 +1,223 @@
+/*
+ * yolo_hip.h — C ABI of libyolo_hip.so, the MI355X (gfx950 / CDNA4) execution of the Darknet hot path.
+ *
+ * The reference (SpursLipu/YOLOv3v4-ModelCompression-MultidatasetTraining-Multibackbone) is pure
+ * Python: it has no FFI.  Its "operator interface" for this path is the set of torch.nn / ATen calls
+ * issued by models.py and utils/utils.py.  Every entry point below names the reference call it
+ * replaces (file:line relative to the reference root).  INTEGRATION.md shows the ctypes binding a
+ * maintainer of the reference would add.
+ *
+ * Conventions
+ *  - Plain pointers and sizes only; no torch types.  All pointers are DEVICE pointers unless a
+ *    parameter is documented as host.  The library never allocates or frees caller-visible memory and
+ *    keeps no reference to caller buffers after a call returns (plans keep the pointers they were
+ *    given; the caller keeps those buffers alive for the life of the plan).
+ *  - Activations are NHWC ("channels last"): element (n, y, x, c) of a tensor with row pitch `ld`
+ *    (in elements, ld >= C, ld % 8 == 0) lives at ((n*H + y)*W + x)*ld + c.  A pitch larger than C is
+ *    how route/concat is made zero-copy: producers write channel slices of a wider buffer.
+ *  - dtype selects the storage/compute type of activations and packed weights: YH_F16 computes on
+ *    MFMA f16 (v_mfma_f32_16x16x32_f16) with fp32 accumulation; YH_F32 computes on the exact-f32 MFMA
+ *    (v_mfma_f32_16x16x4_f32).  Bias, BN folding and the epilogue are always fp32.
+ *  - Every function is asynchronous on `stream` (a hipStream_t passed as void*), re-entrant, and
+ *    returns 0 on success, a negative YH_E* code for a rejected argument, or a positive hipError_t.
+ */
+#ifndef YOLO_HIP_H
+#define YOLO_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define YH_ABI_VERSION 1
+
+enum { YH_F16 = 0, YH_F32 = 1 };
+
+/* activation codes: models.py:102-113 (leaky 0.1 / 0.25, relu6, h_swish, relu, mish; else linear) */
+enum { YH_ACT_LINEAR = 0, YH_ACT_LEAKY = 1, YH_ACT_RELU = 2, YH_ACT_RELU6 = 3, YH_ACT_HSWISH = 4, YH_ACT_MISH = 5 };
+
+enum {
+    YH_OK = 0,
+    YH_EINVAL = -1,      /* bad size / null pointer / unsupported combination */
+    YH_EALIGN = -2,      /* pointer or pitch not aligned as documented */
+    YH_EUNSUPPORTED = -3,
+    YH_ENOMEM = -4,      /* host allocation inside a plan failed */
+    YH_ERANGE = -5       /* index out of range (plan op / slot) */
+};
+
+int yh_abi_version(void);
+const char* yh_error_string(int code);
+
+/* ---------------------------------------------------------------------------------------------------
+ * Weight packing.  Replaces the host-side BN folding of utils/torch_utils.py:65-89 (fuse_conv_and_bn)
+ * and produces the K-major, tile-padded weight image the conv kernels stream.
+ *
+ *   w          fp32 [cout][cin][kh][kw]   (nn.Conv2d.weight as stored in the state_dict)
+ *   conv_bias  fp32 [cout] or NULL        (present iff the block has no BN, models.py:98)
+ *   bn_*       fp32 [cout] or all NULL    (BatchNorm2d weight, bias, running_mean, running_var)
+ *   cin_map    int32 [cin] or NULL        physical input-channel index of each logical channel
+ *                                         (identity when NULL); lets a consumer read padded/concat
+ *                                         buffers whose logical channels are not contiguous
+ *   cin_k      padded per-tap reduction length: multiple of the K step (32 for f16, 16 for f32) and
+ *              > every cin_map entry
+ *   m_pad      rows of the packed image: multiple of 128, >= cout; rows >= cout are zero
+ *   packed     out, dtype [m_pad][kh*kw][cin_k]   W'[co][tap][map(ci)] = w * gamma/sqrt(var+eps)
+ *   bias_out   out, fp32 [m_pad]                  beta - gamma*mean/sqrt(var+eps) (+ scaled conv bias)
+ */
+int yh_conv_pack_weights(int dtype, const float* w, const float* conv_bias, const float* bn_gamma,
+                         const float* bn_beta, const float* bn_mean, const float* bn_var, float bn_eps,
+                         const int32_t* cin_map, int cout, int cin, int kh, int kw, int cin_k, int m_pad,
+                         void* packed, float* bias_out, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * Fused dense convolution block: y = act(conv(x, W') + b') [+ residual], optionally written 2x
+ * nearest-upsampled and/or into a channel slice of a wider buffer.
+ * Replaces nn.Sequential(Conv2d, BatchNorm2d, activation) (models.py:92-113) in eval mode, plus the
+ * following Shortcut add (utils/layers.py:52-72), the nn.Upsample(scale_factor=2) of models.py:225 and
+ * the torch.cat of FeatureConcat (utils/layers.py:35) when the planner fuses them.
+ * Implicit GEMM on MFMA: M = cout, N = n*ho*wo, K = kh*kw*cin_k.
+ */
+typedef struct yh_conv_desc {
+    const void* x;        /* dtype, NHWC, pitch ldx; channel offset already applied to the pointer      */
+    const void* w;        /* packed weights from yh_conv_pack_weights                                    */
+    const float* bias;    /* fp32 [m_pad]                                                                */
+    const void* res;      /* dtype residual added after the activation, pitch ldr; NULL for none         */
+    void* y;              /* out: dtype (or fp32 when out_f32), pitch ldy                                 */
+    int32_t n, h, w_in, cin;      /* input batch, height, width, physical channels reduced over (%8==0)  */
+    int32_t ho, wo, cout;         /* output height, width, physical channels stored (%4==0)              */
+    int32_t kh, kw, stride, pad;
+    int32_t ldx, ldr, ldy;        /* pitches in elements                                                 */
+    int32_t cin_k, m_pad;         /* as given to yh_conv_pack_weights                                    */
+    int32_t act;                  /* YH_ACT_*                                                            */
+    float slope;                  /* leaky slope                                                         */
+    int32_t ups;                  /* 1, or 2 = write every output pixel to its 2x2 upsampled block       */
+    int32_t out_f32;              /* store fp32 regardless of dtype (yolo head inputs)                   */
+    int32_t dtype;                /* YH_F16 / YH_F32                                                     */
+    int32_t tile;                 /* 0 = auto; else forces a tile config (bench/autotune only)           */
+} yh_conv_desc;
+
+int yh_conv2d_fwd(const yh_conv_desc* d, void* stream);
+
+/* First-layer convolution straight from the caller's NCHW fp32 image batch (cin <= 4): fuses the
+ * NCHW->NHWC relayout and the cast.  Replaces the first Sequential of models.py:92-113 as fed by
+ * detect.py:101 / test.py:95 (img / 256 stays with the caller, as in the reference).
+ *   x fp32 [n][cin][h][w];  w fp32 [kh*kw*cin][cout_pad] (tap-major, from yh_stem_pack_weights)    */
+typedef struct yh_stem_desc {
+    const float* x;
+    const float* w;
+    const float* bias;
+    void* y;
+    int32_t n, cin, h, w_in, ho, wo, cout, cout_pad, kh, kw, stride, pad, ldy, act;
+    float slope;
+    int32_t dtype;
+} yh_stem_desc;
+
+int yh_stem_pack_weights(const float* w, const float* conv_bias, const float* bn_gamma, const float* bn_beta,
+                         const float* bn_mean, const float* bn_var, float bn_eps, int cout, int cin, int kh,
+                         int kw, int cout_pad, float* packed, float* bias_out, void* stream);
+int yh_conv2d_stem_fwd(const yh_stem_desc* d, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * nn.MaxPool2d (models.py:207-215).  pad_lo cells of -inf are implied on the top/left, the window may
+ * run past the bottom/right edge: out-of-range taps read `edge_zero ? 0 : -inf` (edge_zero=1 reproduces
+ * the ZeroPad2d((0,1,0,1)) + MaxPool2d(2,1) pair of yolov3-tiny).                                       */
+typedef struct yh_pool_desc {
+    const void* x;
+    void* y;
+    int32_t n, h, w_in, c, ho, wo, k, stride, pad_lo, edge_zero, ldx, ldy, dtype;
+} yh_pool_desc;
+int yh_maxpool2d_fwd(const yh_pool_desc* d, void* stream);
+
+/* Channel-slice copy with optional nearest upsample by `ups` (1 or 2): the copying form of
+ * FeatureConcat (utils/layers.py:35,38) and nn.Upsample (models.py:225) for the cases the planner
+ * cannot make zero-copy.  y[n, y*ups+dy, x*ups+dx, 0:c] = x[n, y, x, 0:c].                              */
+typedef struct yh_copy_desc {
+    const void* x;
+    void* y;
+    int32_t n, h, w_in, c, ups, ldx, ldy, dtype;
+} yh_copy_desc;
+int yh_copy_channels(const yh_copy_desc* d, void* stream);
+
+/* Unfused Shortcut (utils/layers.py:52-72): y[..., 0:c] = a[..., 0:c] + b[..., 0:c] (c = min channels) */
+typedef struct yh_add_desc {
+    const void* a;
+    const void* b;
+    void* y;
+    int64_t pixels;
+    int32_t c, lda, ldb, ldy, dtype;
+} yh_add_desc;
+int yh_add_channels(const yh_add_desc* d, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * YOLO head decode, YOLOLayer.forward eval branch (models.py:406-418, grid :367-378, anchors :362):
+ *   raw[n][a][y][x][o] = p[n][y][x][a*no + o]
+ *   io: xy = (sigmoid(t) + cell) * stride, wh = (exp(t) * anchor) * stride, obj/cls = sigmoid(t)
+ * p is fp32 NHWC with pitch ldp (the head conv is run with out_f32).  io rows land at
+ * io[n][row_off + (a*ny + y)*nx + x][0:no] of an (n, rows_total, no) fp32 tensor, i.e. the torch.cat of
+ * models.py:554 is done in place.  raw may be NULL.                                                     */
+typedef struct yh_decode_desc {
+    const float* p;
+    float* io;
+    float* raw;
+    int32_t n, ny, nx, na, no, ldp, rows_total, row_off;
+    float stride;
+    float anchor_w[8], anchor_h[8];  /* cfg anchors[mask] / stride in fp32 (models.py:362), na <= 8 */
+} yh_decode_desc;
+int yh_yolo_decode(const yh_decode_desc* d, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * Non-maximum suppression, utils/utils.py:782-860, batched over the n images of one forward.
+ * Candidate records are 8 floats: x1, y1, x2, y2, score, cls, key (int32 bits), 0 — key = row*nc + cls
+ * is the position at which the reference would have emitted the candidate.  Buffers are laid out
+ * [n][cap][...] with one int32 count per image (counts above cap are clamped when read).
+ *
+ * 1 yh_nms_candidates  conf filter (:799), wh window (:802), cls*=obj (:809), xywh->xyxy (:812),
+ *                      best-class (:819-820) or multi-label expansion (:815-817), class allow-list
+ *                      (:823, class_mask uint8[nc] or NULL), finite filter (:827).  Appends records with
+ *                      an atomic cursor per image; with cand == NULL it only counts (sizing pass).
+ *                      pred fp32 [n][rows][5+nc]; count int32 [n], zeroed by the caller.
+ * 2 yh_nms_sort        orders every image's records by score descending, ties by ascending key (the
+ *                      stable order of the reference's emission sequence); rank-by-counting, O(m^2).
+ * 3 yh_nms_mask        bit j of mask[img][i][j/64] = IoU(box_i + off_i, box_j + off_j) > iou_thres for
+ *                      j > i, off = cls*4096 unless agnostic (:840-841); mask is [n][mmax][ceil(mmax/64)].
+ * 4 yh_nms_reduce      greedy scan in score order — the torchvision.ops.boxes.nms contract behind :843;
+ *                      writes kept indices (ascending = score order) and their number per image.
+ * 5 yh_nms_merge       out[img][k] = [merged box, score, cls] of kept box k.  For merge_lo < m < merge_hi
+ *                      (reference: 1 < n < 3000, :844-852) the box is sum_j w_j box_j / sum_j w_j with
+ *                      w_j = (IoU(kept_k, j) > thr) * score_j over all m records; otherwise the kept box.
+ *                      out fp32 [n][cap][6]; kmax >= max kept count (grid sizing).
+ * mmax >= max count over the batch (grid and mask sizing), mmax <= cap.                                  */
+int yh_nms_candidates(const float* pred, int n, int rows, int nc, float conf_thres, int multi_label,
+                      const uint8_t* class_mask, float* cand, int32_t* count, int cap, void* stream);
+int yh_nms_sort(const float* cand, const int32_t* count, int n, int cap, int mmax, float* sorted, void* stream);
+int yh_nms_mask(const float* sorted, const int32_t* count, int n, int cap, int mmax, float iou_thres, int agnostic,
+                uint64_t* mask, void* stream);
+int yh_nms_reduce(const uint64_t* mask, const int32_t* count, int n, int cap, int mmax, int32_t* keep_idx,
+                  int32_t* n_keep, void* stream);
+int yh_nms_merge(const float* sorted, const int32_t* count, const int32_t* keep_idx, const int32_t* n_keep, int n,
+                 int cap, int kmax, float iou_thres, int agnostic, int merge_lo, int merge_hi, float* out,
+                 void* stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * Plans: a recorded sequence of the launches above, replayed by one native call per forward (the
+ * replacement for the per-layer Python dispatch loop of models.py:524-545).  Pointers that change
+ * from call to call (network input, per-call outputs) are "slots": a fixup patches one pointer field
+ * of one recorded op with slot_base + byte_offset right before launch.                                  */
+typedef struct yh_plan yh_plan;
+enum { YH_OP_CONV = 1, YH_OP_STEM = 2, YH_OP_POOL = 3, YH_OP_COPY = 4, YH_OP_ADD = 5, YH_OP_DECODE = 6 };
+
+yh_plan* yh_plan_create(void);
+void yh_plan_destroy(yh_plan* p);
+int yh_plan_add(yh_plan* p, int op_kind, const void* desc, int desc_bytes); /* returns op index or <0 */
+int yh_plan_add_fixup(yh_plan* p, int op_index, int field_offset, int slot, int64_t byte_offset);
+int yh_plan_bind_slot(yh_plan* p, int slot, void* ptr);
+int yh_plan_num_ops(const yh_plan* p);
+int yh_plan_run(yh_plan* p, void* stream);
+/* run ops [first, last) only (profiling / per-layer tests) */
+int yh_plan_run_range(yh_plan* p, int first, int last, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* YOLO_HIP_H */

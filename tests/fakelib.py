@@ -1,0 +1,255 @@
+"""Host emulation of the libyolo_hip.so C ABI — TEST INFRASTRUCTURE ONLY.
+
+``FakeLib`` exposes the same entry points as the ctypes handle returned by ``engine.hiplib.load()`` and
+executes every descriptor on *host* memory with torch CPU ops, reading and writing the raw addresses in
+the descriptors exactly like the kernels do (pitches, channel offsets, padded weight images, slots and
+fix-ups).  Injecting it into ``DarknetEngine`` lets the CPU-only test tier validate the graph lowering
+(fusion decisions, zero-copy concat placement, channel maps, weight packing layout, plan replay) against
+the reference goldens without a GPU.  The kernels themselves are validated on the GPU tier against the
+same oracle.  Product code never imports this module.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from engine import hiplib
+from engine.hiplib import ConvDesc, StemDesc, PoolDesc, CopyDesc, AddDesc, DecodeDesc
+
+_NP = {hiplib.YH_F16: np.float16, hiplib.YH_F32: np.float32}
+_DESC = {hiplib.OP_CONV: ConvDesc, hiplib.OP_STEM: StemDesc, hiplib.OP_POOL: PoolDesc, hiplib.OP_COPY: CopyDesc,
+         hiplib.OP_ADD: AddDesc, hiplib.OP_DECODE: DecodeDesc}
+
+
+def _addr(p):
+    if p is None:
+        return 0
+    if isinstance(p, C.c_void_p):
+        return p.value or 0
+    return int(p)
+
+
+def flat(p, n, dtype):
+    """numpy view of n elements of dtype at host address p."""
+    a = _addr(p)
+    assert a != 0, 'null pointer dereferenced by the emulator'
+    itemsize = np.dtype(dtype).itemsize
+    buf = (C.c_char * (n * itemsize)).from_address(a)
+    return np.frombuffer(buf, dtype=dtype, count=n)
+
+
+def pitched(p, pixels, c, ld, dtype):
+    """[pixels, c] view with row pitch ld (elements) at host address p."""
+    base = flat(p, (pixels - 1) * ld + c, dtype)
+    es = base.itemsize
+    return np.lib.stride_tricks.as_strided(base, shape=(pixels, c), strides=(ld * es, es), writeable=True)
+
+
+def _act(v, act, slope):
+    if act == 1:
+        return torch.where(v > 0, v, v * slope)
+    if act == 2:
+        return v.clamp(min=0)
+    if act == 3:
+        return v.clamp(0, 6)
+    if act == 4:
+        return v * (v + 3).clamp(0, 6) / 6
+    if act == 5:
+        return v * torch.tanh(F.softplus(v))
+    return v
+
+
+class FakeLib:
+    def __init__(self):
+        self.plans = {}
+        self.next = 1
+        self.calls = []
+
+    # ---- misc
+    def yh_abi_version(self):
+        return 1
+
+    def yh_error_string(self, rc):
+        return ('fake error %d' % rc).encode()
+
+    # ---- packing
+    @staticmethod
+    def _fold(w, cb, g, be, mu, var, eps, cout):
+        scale = torch.ones(cout)
+        bias = torch.zeros(cout) if cb is None else cb.clone()
+        if g is not None:
+            sd = torch.sqrt(var + eps)
+            scale = g / sd
+            bias = (be - g * mu / sd) + bias * scale
+        return w * scale.view(-1, 1, 1, 1), bias
+
+    def yh_conv_pack_weights(self, dtype, w, cb, g, be, mu, var, eps, cmap, cout, cin, kh, kw, cin_k, m_pad, packed,
+                             bias_out, stream):
+        t = lambda p, n: None if not _addr(p) else torch.from_numpy(flat(p, n, np.float32).copy())
+        W = t(w, cout * cin * kh * kw).view(cout, cin, kh, kw)
+        Wf, b = self._fold(W, t(cb, cout), t(g, cout), t(be, cout), t(mu, cout), t(var, cout), eps, cout)
+        m = np.arange(cin) if not _addr(cmap) else flat(cmap, cin, np.int32).copy()
+        assert cin_k % (32 if dtype == hiplib.YH_F16 else 16) == 0 and m.max() < cin_k and m_pad % 128 == 0
+        img = torch.zeros(m_pad, kh * kw, cin_k)
+        img[:cout][:, :, torch.from_numpy(m).long()] = Wf.permute(0, 2, 3, 1).reshape(cout, kh * kw, cin)
+        flat(packed, m_pad * kh * kw * cin_k, _NP[dtype])[:] = img.reshape(-1).numpy().astype(_NP[dtype])
+        bo = flat(bias_out, m_pad, np.float32)
+        bo[:] = 0
+        bo[:cout] = b.numpy()
+        return 0
+
+    def yh_stem_pack_weights(self, w, cb, g, be, mu, var, eps, cout, cin, kh, kw, cout_pad, packed, bias_out, stream):
+        t = lambda p, n: None if not _addr(p) else torch.from_numpy(flat(p, n, np.float32).copy())
+        W = t(w, cout * cin * kh * kw).view(cout, cin, kh, kw)
+        Wf, b = self._fold(W, t(cb, cout), t(g, cout), t(be, cout), t(mu, cout), t(var, cout), eps, cout)
+        img = torch.zeros(kh * kw, cin, cout_pad)
+        img[:, :, :cout] = Wf.permute(2, 3, 1, 0).reshape(kh * kw, cin, cout)
+        flat(packed, kh * kw * cin * cout_pad, np.float32)[:] = img.reshape(-1).numpy()
+        bo = flat(bias_out, cout_pad, np.float32)
+        bo[:] = 0
+        bo[:cout] = b.numpy()
+        return 0
+
+    # ---- ops
+    def yh_conv2d_fwd(self, dref, stream):
+        d = dref._obj if hasattr(dref, '_obj') else dref
+        npdt = _NP[d.dtype]
+        vec, bk = (8, 32) if d.dtype == hiplib.YH_F16 else (4, 16)
+        assert d.cin % vec == 0 and d.ldx % vec == 0 and d.cin_k % bk == 0 and d.cout % 4 == 0 and d.ldy % 4 == 0
+        assert _addr(d.x) % 16 == 0 and _addr(d.w) % 16 == 0 and _addr(d.y) % 8 == 0
+        x = torch.from_numpy(pitched(d.x, d.n * d.h * d.w_in, d.cin, d.ldx, npdt).astype(np.float32))
+        x = x.view(d.n, d.h, d.w_in, d.cin).permute(0, 3, 1, 2)
+        taps = d.kh * d.kw
+        wimg = torch.from_numpy(flat(d.w, d.m_pad * taps * d.cin_k, npdt).astype(np.float32)).view(d.m_pad, d.kh, d.kw, d.cin_k)
+        w = wimg[:d.cout, :, :, :d.cin].permute(0, 3, 1, 2).contiguous()
+        assert wimg[:, :, :, d.cin:].abs().max().item() == 0 if d.cin_k > d.cin else True
+        b = torch.from_numpy(flat(d.bias, d.m_pad, np.float32)[:d.cout].copy())
+        y = F.conv2d(x, w, b, stride=d.stride, padding=d.pad)
+        assert y.shape[2] == d.ho and y.shape[3] == d.wo
+        y = _act(y, d.act, d.slope)
+        if _addr(d.res):
+            r = torch.from_numpy(pitched(d.res, d.n * d.ho * d.wo, d.cout, d.ldr, npdt).astype(np.float32))
+            y = y + r.view(d.n, d.ho, d.wo, d.cout).permute(0, 3, 1, 2)
+        if d.ups == 2:
+            y = y.repeat_interleave(2, 2).repeat_interleave(2, 3)
+        odt = np.float32 if d.out_f32 else npdt
+        out = pitched(d.y, d.n * y.shape[2] * y.shape[3], d.cout, d.ldy, odt)
+        out[:] = y.permute(0, 2, 3, 1).reshape(-1, d.cout).numpy().astype(odt)
+        return 0
+
+    def yh_conv2d_stem_fwd(self, dref, stream):
+        d = dref._obj if hasattr(dref, '_obj') else dref
+        npdt = _NP[d.dtype]
+        x = torch.from_numpy(flat(d.x, d.n * d.cin * d.h * d.w_in, np.float32).copy()).view(d.n, d.cin, d.h, d.w_in)
+        wimg = torch.from_numpy(flat(d.w, d.kh * d.kw * d.cin * d.cout_pad, np.float32).copy()).view(d.kh, d.kw, d.cin, d.cout_pad)
+        w = wimg[..., :d.cout].permute(3, 2, 0, 1).contiguous()
+        b = torch.from_numpy(flat(d.bias, d.cout_pad, np.float32)[:d.cout].copy())
+        y = _act(F.conv2d(x, w, b, stride=d.stride, padding=d.pad), d.act, d.slope)
+        assert y.shape[2] == d.ho and y.shape[3] == d.wo and d.cout % 8 == 0
+        out = pitched(d.y, d.n * d.ho * d.wo, d.cout, d.ldy, npdt)
+        out[:] = y.permute(0, 2, 3, 1).reshape(-1, d.cout).numpy().astype(npdt)
+        return 0
+
+    def yh_maxpool2d_fwd(self, dref, stream):
+        d = dref._obj if hasattr(dref, '_obj') else dref
+        npdt = _NP[d.dtype]
+        x = torch.from_numpy(pitched(d.x, d.n * d.h * d.w_in, d.c, d.ldx, npdt).astype(np.float32))
+        x = x.view(d.n, d.h, d.w_in, d.c).permute(0, 3, 1, 2)
+        if d.edge_zero:
+            need_h = (d.ho - 1) * d.stride + d.k - d.h
+            need_w = (d.wo - 1) * d.stride + d.k - d.w_in
+            y = F.max_pool2d(F.pad(x, (0, max(need_w, 0), 0, max(need_h, 0)), value=0.0), d.k, d.stride, 0)
+        else:
+            y = F.max_pool2d(x, d.k, d.stride, d.pad_lo)
+        assert y.shape[2] == d.ho and y.shape[3] == d.wo, (y.shape, d.ho, d.wo)
+        out = pitched(d.y, d.n * d.ho * d.wo, d.c, d.ldy, npdt)
+        out[:] = y.permute(0, 2, 3, 1).reshape(-1, d.c).numpy().astype(npdt)
+        return 0
+
+    def yh_copy_channels(self, dref, stream):
+        d = dref._obj if hasattr(dref, '_obj') else dref
+        npdt = _NP[d.dtype]
+        x = pitched(d.x, d.n * d.h * d.w_in, d.c, d.ldx, npdt).reshape(d.n, d.h, d.w_in, d.c)
+        if d.ups == 2:
+            x = x.repeat(2, axis=1).repeat(2, axis=2)
+        out = pitched(d.y, d.n * d.h * d.w_in * d.ups * d.ups, d.c, d.ldy, npdt)
+        out[:] = x.reshape(-1, d.c)
+        return 0
+
+    def yh_add_channels(self, dref, stream):
+        d = dref._obj if hasattr(dref, '_obj') else dref
+        npdt = _NP[d.dtype]
+        a = pitched(d.a, d.pixels, d.c, d.lda, npdt).astype(np.float32)
+        b = pitched(d.b, d.pixels, d.c, d.ldb, npdt).astype(np.float32)
+        pitched(d.y, d.pixels, d.c, d.ldy, npdt)[:] = (a + b).astype(npdt)
+        return 0
+
+    def yh_yolo_decode(self, dref, stream):
+        d = dref._obj if hasattr(dref, '_obj') else dref
+        c = d.na * d.no
+        p = torch.from_numpy(pitched(d.p, d.n * d.ny * d.nx, c, d.ldp, np.float32).copy())
+        raw = p.view(d.n, d.ny, d.nx, d.na, d.no).permute(0, 3, 1, 2, 4).contiguous()
+        io = raw.clone()
+        gx = torch.arange(d.nx, dtype=torch.float32).view(1, 1, 1, d.nx)
+        gy = torch.arange(d.ny, dtype=torch.float32).view(1, 1, d.ny, 1)
+        aw = torch.tensor(list(d.anchor_w)[:d.na]).view(1, d.na, 1, 1)
+        ah = torch.tensor(list(d.anchor_h)[:d.na]).view(1, d.na, 1, 1)
+        io[..., 0] = (torch.sigmoid(raw[..., 0]) + gx) * d.stride
+        io[..., 1] = (torch.sigmoid(raw[..., 1]) + gy) * d.stride
+        io[..., 2] = torch.exp(raw[..., 2]) * aw * d.stride
+        io[..., 3] = torch.exp(raw[..., 3]) * ah * d.stride
+        io[..., 4:] = torch.sigmoid(raw[..., 4:])
+        rows = d.na * d.ny * d.nx
+        out = flat(d.io, d.n * d.rows_total * d.no, np.float32).reshape(d.n, d.rows_total, d.no)
+        out[:, d.row_off:d.row_off + rows] = io.reshape(d.n, rows, d.no).numpy()
+        if _addr(d.raw):
+            flat(d.raw, raw.numel(), np.float32)[:] = raw.reshape(-1).numpy()
+        return 0
+
+    # ---- plans
+    def yh_plan_create(self):
+        h = self.next
+        self.next += 1
+        self.plans[h] = dict(ops=[], slots={})
+        return h
+
+    def yh_plan_destroy(self, h):
+        self.plans.pop(_addr(h), None)
+
+    def yh_plan_add(self, h, kind, dref, nbytes):
+        d = dref._obj if hasattr(dref, '_obj') else dref
+        cls = _DESC[kind]
+        assert nbytes == C.sizeof(cls) and isinstance(d, cls)
+        copy = cls.from_buffer_copy(bytes(d))
+        self.plans[_addr(h)]['ops'].append((kind, copy, []))
+        return len(self.plans[_addr(h)]['ops']) - 1
+
+    def yh_plan_add_fixup(self, h, op, field_offset, slot, byte_offset):
+        self.plans[_addr(h)]['ops'][op][2].append((field_offset, slot, byte_offset))
+        return 0
+
+    def yh_plan_bind_slot(self, h, slot, p):
+        self.plans[_addr(h)]['slots'][slot] = _addr(p)
+        return 0
+
+    def yh_plan_num_ops(self, h):
+        return len(self.plans[_addr(h)]['ops'])
+
+    def yh_plan_run(self, h, stream):
+        return self.yh_plan_run_range(h, 0, self.yh_plan_num_ops(h), stream)
+
+    def yh_plan_run_range(self, h, first, last, stream):
+        plan = self.plans[_addr(h)]
+        run = {hiplib.OP_CONV: self.yh_conv2d_fwd, hiplib.OP_STEM: self.yh_conv2d_stem_fwd,
+               hiplib.OP_POOL: self.yh_maxpool2d_fwd, hiplib.OP_COPY: self.yh_copy_channels,
+               hiplib.OP_ADD: self.yh_add_channels, hiplib.OP_DECODE: self.yh_yolo_decode}
+        for kind, desc, fixups in plan['ops'][first:last]:
+            d = type(desc).from_buffer_copy(bytes(desc))
+            for off, slot, boff in fixups:
+                C.c_void_p.from_address(C.addressof(d) + off).value = plan['slots'][slot] + boff
+            rc = run[kind](d, stream)
+            if rc:
+                return rc
+            self.calls.append(kind)
+        return 0

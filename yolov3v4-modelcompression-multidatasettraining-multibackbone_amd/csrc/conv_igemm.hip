@@ -1,0 +1,361 @@
+// Fused dense convolution block as an implicit GEMM on the CDNA4 matrix cores.
+//
+//   D[m][p] = sum_k  W'[m][k] * X[k][p]        m = output channel, p = (n, ho, wo) output pixel,
+//                                              k = (tap r,s ; input channel c)
+//   y = act(D + bias) (+ residual), stored NHWC (optionally 2x nearest-upsampled, optionally fp32)
+//
+// Operand roles are chosen for the NHWC epilogue: weights are the MFMA "A" operand (rows = channels),
+// activations the "B" operand (columns = pixels), so a lane's 4 accumulator registers are 4
+// *consecutive channels of one pixel* = one 8-byte (f16) or 16-byte (f32) store.
+//
+// Tiling: one workgroup = 4 waves computes a BM(channels) x BN(pixels) tile, K step BK = 4 "units" of
+// 16 bytes per row (32 f16 / 16 f32 channels of one filter tap).  Both operand tiles are staged
+// global -> VGPR -> LDS with the next K step's global loads issued before the current step's MFMAs
+// (double-buffered LDS, one barrier per step).  LDS image is [unit][row] in 16-byte cells:
+//   * a 16-row x 1-unit MFMA fragment read (ds_read_b128, lane = row) touches 16 consecutive cells:
+//     conflict free for every lane group of the instruction;
+//   * the staging store is arranged so every 8-lane group writes 8 consecutive cells (ds_write_b128).
+// The im2col gather is done by the loader: each thread owns fixed pixel rows and walks (r, s, c0) with
+// scalar counters; out-of-image taps and channel tails load zeros.
+//
+// Workgroup -> tile mapping is XCD-aware: the 8 XCDs each take a contiguous range of tiles, ordered so
+// that the channel tiles of one pixel tile are adjacent (the activation tile is fetched from HBM once
+// per XCD L2, weights are small and stay resident).
+#include <type_traits>
+
+#include "common.h"
+
+namespace yh {
+
+struct ConvArgs {
+    const void* x;
+    const void* w;
+    const float* bias;
+    const void* res;
+    void* y;
+    int N, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad;
+    int ldx, ldr, ldy;
+    int cin_k;       // padded per-tap K (multiple of BK)
+    int ktot;        // R*S*cin_k
+    long P;          // N*Ho*Wo
+    int m_tiles, p_tiles;
+    int act;
+    float slope;
+    int ups;
+};
+
+// compile-time unrolled loop: every array index below is a constant, so staging registers never
+// fall back to scratch (runtime-indexed private arrays do on this compiler)
+template <int N, typename F> __device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (N > 0) {
+        static_for<N - 1>(f);
+        f(std::integral_constant<int, N - 1>{});
+    }
+}
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));  // one 16-byte LDS cell / global vector
+
+template <typename T> struct Prec;
+template <> struct Prec<f16> {
+    static constexpr int VEC = 8;   // elements per 16-byte unit
+    static constexpr int BK = 32;
+};
+template <> struct Prec<float> {
+    static constexpr int VEC = 4;
+    static constexpr int BK = 16;
+};
+
+// One K step of MFMAs for a wave: TM x TN fragments of 16x16.
+template <typename T, int TM, int TN> struct MmaStep;
+
+template <int TM, int TN> struct MmaStep<f16, TM, TN> {
+    static __device__ __forceinline__ void run(const u32x4* As, const u32x4* Bs, int BM, int BN, int arow, int brow,
+                                               int lane, f32x4 (&acc)[TM][TN]) {
+        const int u = lane >> 4, r = lane & 15;
+        f16x8 a[TM], b[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            u32x4 v = As[u * BM + arow + i * 16 + r];
+            a[i] = *reinterpret_cast<f16x8*>(&v);
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            u32x4 v = Bs[u * BN + brow + j * 16 + r];
+            b[j] = *reinterpret_cast<f16x8*>(&v);
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+};
+
+template <int TM, int TN> struct MmaStep<float, TM, TN> {
+    static __device__ __forceinline__ void run(const u32x4* As, const u32x4* Bs, int BM, int BN, int arow, int brow,
+                                               int lane, f32x4 (&acc)[TM][TN]) {
+        const int kq = lane >> 4, r = lane & 15;
+        const float* Af = reinterpret_cast<const float*>(As);
+        const float* Bf = reinterpret_cast<const float*>(Bs);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {  // 4 units x 4 floats = K 16, one 16x16x4 MFMA per unit
+            float a[TM], b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[i] = Af[(u * BM + arow + i * 16 + r) * 4 + kq];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[j] = Bf[(u * BN + brow + j * 16 + r) * 4 + kq];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+    }
+};
+
+template <typename OutT> __device__ __forceinline__ void store4(OutT* p, float a, float b, float c, float d);
+template <> __device__ __forceinline__ void store4<f16>(f16* p, float a, float b, float c, float d) {
+    f16x4 v = {(f16)a, (f16)b, (f16)c, (f16)d};
+    *reinterpret_cast<f16x4*>(p) = v;
+}
+template <> __device__ __forceinline__ void store4<float>(float* p, float a, float b, float c, float d) {
+    f32x4 v = {a, b, c, d};
+    *reinterpret_cast<f32x4*>(p) = v;
+}
+
+template <typename T> __device__ __forceinline__ void load4(const T* p, float (&o)[4]);
+template <> __device__ __forceinline__ void load4<f16>(const f16* p, float (&o)[4]) {
+    f16x4 v = *reinterpret_cast<const f16x4*>(p);
+    o[0] = (float)v[0]; o[1] = (float)v[1]; o[2] = (float)v[2]; o[3] = (float)v[3];
+}
+template <> __device__ __forceinline__ void load4<float>(const float* p, float (&o)[4]) {
+    f32x4 v = *reinterpret_cast<const f32x4*>(p);
+    o[0] = v[0]; o[1] = v[1]; o[2] = v[2]; o[3] = v[3];
+}
+
+template <typename T, typename OutT, int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
+    constexpr int VEC = Prec<T>::VEC, BK = Prec<T>::BK, UNITS = 4;
+    constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
+    constexpr int APASS = (BM + 63) / 64, BPASS = (BN + 63) / 64;
+    static_assert(WM * WN == 4, "4 waves per workgroup");
+    static_assert(TM >= 1 && TN >= 1, "tile too small");
+
+    __shared__ u32x4 smem[2 * UNITS * (BM + BN)];
+    u32x4* const As = smem;                   // [2][UNITS][BM]
+    u32x4* const Bs = smem + 2 * UNITS * BM;  // [2][UNITS][BN]
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+
+    // ---- workgroup -> (pixel tile, channel tile); each XCD (blockIdx % 8) gets a contiguous range
+    int m_tile, p_tile;
+    {
+        const int nb = gridDim.x, bid = blockIdx.x;
+        const int q = nb >> 3, rr = nb & 7, xcd = bid & 7;
+        const int logical = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (bid >> 3);
+        p_tile = logical / a.m_tiles;
+        m_tile = logical - p_tile * a.m_tiles;
+    }
+    const int m0 = m_tile * BM;
+    const long p0 = (long)p_tile * BN;
+
+    // ---- loader coordinates: 64 rows x 4 units per pass over 256 threads
+    const int lu = (lane >> 3) & 3;
+    const int lrow = (wave << 4) + ((lane >> 5) << 3) + (lane & 7);
+
+    const T* const xg = reinterpret_cast<const T*>(a.x);
+    const T* wsrc[APASS];
+    static_for<APASS>([&](auto c) {
+        constexpr int ps = decltype(c)::value;
+        int row = lrow + ps * 64;
+        if (row >= BM) row = BM - 1;  // inactive lanes still hold a valid address
+        wsrc[ps] = reinterpret_cast<const T*>(a.w) + (long)(m0 + row) * a.ktot + lu * VEC;
+    });
+    long bbase[BPASS];
+    int bhi[BPASS], bwi[BPASS];
+    const int HoWo = a.Ho * a.Wo;
+    static_for<BPASS>([&](auto c) {
+        constexpr int ps = decltype(c)::value;
+        const int row = lrow + ps * 64;
+        const long p = p0 + row;
+        if (row < BN && p < a.P) {
+            const int n = (int)(p / HoWo);
+            const int rem = (int)(p - (long)n * HoWo);
+            const int ho = rem / a.Wo, wo = rem - ho * a.Wo;
+            bhi[ps] = ho * a.stride - a.pad;
+            bwi[ps] = wo * a.stride - a.pad;
+            bbase[ps] = (((long)n * a.H + bhi[ps]) * a.W + bwi[ps]) * a.ldx + lu * VEC;
+        } else {
+            bhi[ps] = -(1 << 28);
+            bwi[ps] = -(1 << 28);
+            bbase[ps] = 0;
+        }
+    });
+
+    u32x4 ra[APASS], rb[BPASS];
+    int kr = 0, ks = 0, kc = 0;  // filter tap (r, s) and channel offset of the K step being loaded
+    int kofs = 0;                // element offset of that K step inside a packed weight row
+
+    auto load_step = [&]() {
+        static_for<APASS>([&](auto c) {
+            constexpr int ps = decltype(c)::value;
+            if (BM % 64 == 0 || lrow + ps * 64 < BM) ra[ps] = *reinterpret_cast<const u32x4*>(wsrc[ps] + kofs);
+        });
+        const long tap = ((long)kr * a.W + ks) * a.ldx + kc;
+        const bool cok = kc + lu * VEC < a.Cin;
+        static_for<BPASS>([&](auto c) {
+            constexpr int ps = decltype(c)::value;
+            const bool ok = cok && (unsigned)(bhi[ps] + kr) < (unsigned)a.H && (unsigned)(bwi[ps] + ks) < (unsigned)a.W;
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (ok) v = *reinterpret_cast<const u32x4*>(xg + bbase[ps] + tap);
+            rb[ps] = v;
+        });
+    };
+    auto advance = [&]() {
+        kofs += BK;
+        kc += BK;
+        if (kc >= a.cin_k) {
+            kc = 0;
+            if (++ks == a.S) { ks = 0; ++kr; }
+        }
+    };
+    auto stash = [&](int buf) {
+        static_for<APASS>([&](auto c) {
+            constexpr int ps = decltype(c)::value;
+            const int row = lrow + ps * 64;
+            if (BM % 64 == 0 || row < BM) As[(buf * UNITS + lu) * BM + row] = ra[ps];
+        });
+        static_for<BPASS>([&](auto c) {
+            constexpr int ps = decltype(c)::value;
+            const int row = lrow + ps * 64;
+            if (BN % 64 == 0 || row < BN) Bs[(buf * UNITS + lu) * BN + row] = rb[ps];
+        });
+    };
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = a.ktot / BK;
+    load_step();
+    stash(0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        const bool more = kt + 1 < nk;
+        if (more) {
+            advance();
+            load_step();
+        }
+        MmaStep<T, TM, TN>::run(As + cur * UNITS * BM, Bs + cur * UNITS * BN, BM, BN, wm * TM * 16, wn * TN * 16, lane,
+                                acc);
+        if (more) stash(cur ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: lane holds channels m..m+3 of pixel p for each (i, j) fragment
+    const int mq = (lane >> 4) << 2, pc = lane & 15;
+    OutT* const yg = reinterpret_cast<OutT*>(a.y);
+    const T* const rg = reinterpret_cast<const T*>(a.res);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const long p = p0 + wn * TN * 16 + j * 16 + pc;
+        if (p >= a.P) continue;
+        long opix = p;  // output pixel index in the (possibly upsampled) destination
+        int wo2 = 0;
+        if (a.ups == 2) {
+            const int n = (int)(p / HoWo);
+            const int rem = (int)(p - (long)n * HoWo);
+            const int ho = rem / a.Wo, wo = rem - ho * a.Wo;
+            wo2 = 2 * a.Wo;
+            opix = ((long)n * 2 * a.Ho + 2 * ho) * wo2 + 2 * wo;
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int m = m0 + wm * TM * 16 + i * 16 + mq;
+            if (m >= a.Cout) continue;
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(a.bias + m);
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = activate(acc[i][j][e] + bv[e], a.act, a.slope);
+            if (rg != nullptr) {
+                float r4[4];
+                load4<T>(rg + p * a.ldr + m, r4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] += r4[e];
+            }
+            OutT* dst = yg + opix * a.ldy + m;
+            store4<OutT>(dst, v[0], v[1], v[2], v[3]);
+            if (a.ups == 2) {
+                store4<OutT>(dst + a.ldy, v[0], v[1], v[2], v[3]);
+                store4<OutT>(dst + (long)wo2 * a.ldy, v[0], v[1], v[2], v[3]);
+                store4<OutT>(dst + (long)(wo2 + 1) * a.ldy, v[0], v[1], v[2], v[3]);
+            }
+        }
+    }
+}
+
+template <typename T, typename OutT, int BM, int BN, int WM, int WN>
+static int launch(const ConvArgs& a0, hipStream_t stream) {
+    ConvArgs a = a0;
+    a.m_tiles = (a.Cout + BM - 1) / BM;
+    a.p_tiles = (int)((a.P + BN - 1) / BN);
+    const long blocks = (long)a.m_tiles * a.p_tiles;
+    if (blocks <= 0 || blocks > 0x7fffffffL) return YH_EINVAL;
+    hipLaunchKernelGGL((conv_igemm_kernel<T, OutT, BM, BN, WM, WN>), dim3((unsigned)blocks), dim3(256), 0, stream, a);
+    return check_launch();
+}
+
+template <typename T, typename OutT> static int dispatch_tile(const ConvArgs& a, int tile, hipStream_t s) {
+    // tile codes: 1 = 128x128, 2 = 64x256, 3 = 32x256, 4 = 64x128, 5 = 128x64
+    if (tile == 0) {
+        const int c = a.Cout;
+        const int w128 = ((c + 127) / 128) * 128, w64 = ((c + 63) / 64) * 64, w32 = ((c + 31) / 32) * 32;
+        tile = (w128 <= w64 && w128 <= w32) ? 1 : (w64 <= w32 ? 2 : 3);
+        // few pixels (deep 19x19 layers at small batch): prefer narrower pixel tiles for occupancy
+        if (tile == 1 && ((a.P + 127) / 128) * ((c + 127) / 128) < 256) tile = 5;
+        if (tile == 2 && ((a.P + 255) / 256) * ((c + 63) / 64) < 256) tile = 4;
+    }
+    switch (tile) {
+        case 1: return launch<T, OutT, 128, 128, 2, 2>(a, s);
+        case 2: return launch<T, OutT, 64, 256, 1, 4>(a, s);
+        case 3: return launch<T, OutT, 32, 256, 1, 4>(a, s);
+        case 4: return launch<T, OutT, 64, 128, 2, 2>(a, s);
+        case 5: return launch<T, OutT, 128, 64, 2, 2>(a, s);
+        default: return YH_EINVAL;
+    }
+}
+
+}  // namespace yh
+
+extern "C" int yh_conv2d_fwd(const yh_conv_desc* d, void* stream) {
+    using namespace yh;
+    if (!d || !d->x || !d->w || !d->bias || !d->y) return YH_EINVAL;
+    if (d->n <= 0 || d->h <= 0 || d->w_in <= 0 || d->cin <= 0 || d->ho <= 0 || d->wo <= 0 || d->cout <= 0) return YH_EINVAL;
+    if (d->kh <= 0 || d->kw <= 0 || d->stride <= 0 || d->pad < 0) return YH_EINVAL;
+    if (d->dtype != YH_F16 && d->dtype != YH_F32) return YH_EINVAL;
+    const int bk = d->dtype == YH_F16 ? 32 : 16, vec = d->dtype == YH_F16 ? 8 : 4;
+    if (d->cin % vec || d->ldx % vec || d->cin_k % bk || d->cin_k < d->cin || d->m_pad % 128 || d->m_pad < d->cout) return YH_EALIGN;
+    if (d->cout % 4 || d->ldy % 4 || (d->res && d->ldr % 4)) return YH_EALIGN;
+    if (!aligned16(d->x) || !aligned16(d->w) || !aligned16(d->bias) || (((uintptr_t)d->y) & 7u) || (((uintptr_t)d->res) & 7u)) return YH_EALIGN;
+    if (d->ups != 1 && d->ups != 2) return YH_EINVAL;
+    if (d->ho != (d->h + 2 * d->pad - d->kh) / d->stride + 1 || d->wo != (d->w_in + 2 * d->pad - d->kw) / d->stride + 1) return YH_EINVAL;
+
+    ConvArgs a;
+    a.x = d->x; a.w = d->w; a.bias = d->bias; a.res = d->res; a.y = d->y;
+    a.N = d->n; a.H = d->h; a.W = d->w_in; a.Cin = d->cin; a.Ho = d->ho; a.Wo = d->wo; a.Cout = d->cout;
+    a.R = d->kh; a.S = d->kw; a.stride = d->stride; a.pad = d->pad;
+    a.ldx = d->ldx; a.ldr = d->ldr; a.ldy = d->ldy;
+    a.cin_k = d->cin_k; a.ktot = d->kh * d->kw * d->cin_k;
+    a.P = (long)d->n * d->ho * d->wo;
+    a.m_tiles = a.p_tiles = 0;
+    a.act = d->act; a.slope = d->slope; a.ups = d->ups;
+    hipStream_t s = (hipStream_t)stream;
+    if (d->dtype == YH_F16) {
+        return d->out_f32 ? dispatch_tile<f16, float>(a, d->tile, s) : dispatch_tile<f16, f16>(a, d->tile, s);
+    }
+    return dispatch_tile<float, float>(a, d->tile, s);
+}

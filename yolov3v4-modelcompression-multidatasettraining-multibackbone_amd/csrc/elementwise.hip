@@ -1,0 +1,360 @@
+// HBM-bound pieces of the Darknet hot path: weight packing (BN folding), first-layer conv from the
+// caller's NCHW fp32 frames, max-pool, channel-slice copy / upsample, shortcut add, YOLO head decode.
+// All activations are NHWC with 16-byte vector accesses along the channel axis.
+#include "common.h"
+
+namespace yh {
+
+// ---------------------------------------------------------------------------------------- packing
+template <typename T>
+__global__ void pack_conv_weights_kernel(const float* __restrict__ w, const float* __restrict__ gamma,
+                                         const float* __restrict__ var, float eps, const int32_t* __restrict__ cin_map,
+                                         int cout, int cin, int taps, int cin_k, T* __restrict__ packed) {
+    const long total = (long)cout * cin * taps;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int tap = (int)(i % taps);
+        const long r = i / taps;
+        const int ci = (int)(r % cin), co = (int)(r / cin);
+        const float scale = gamma ? gamma[co] / sqrtf(var[co] + eps) : 1.f;
+        const int pc = cin_map ? cin_map[ci] : ci;
+        packed[((long)co * taps + tap) * cin_k + pc] = (T)(w[i] * scale);
+    }
+}
+
+__global__ void pack_bias_kernel(const float* __restrict__ conv_bias, const float* __restrict__ gamma,
+                                 const float* __restrict__ beta, const float* __restrict__ mean,
+                                 const float* __restrict__ var, float eps, int cout, float* __restrict__ out) {
+    const int co = blockIdx.x * blockDim.x + threadIdx.x;
+    if (co >= cout) return;
+    float b = conv_bias ? conv_bias[co] : 0.f;
+    if (gamma) {
+        const float sd = sqrtf(var[co] + eps);
+        b = (beta[co] - gamma[co] * mean[co] / sd) + b * (gamma[co] / sd);
+    }
+    out[co] = b;
+}
+
+// stem image: [tap][ci][cout_pad] fp32, tap = r*kw + s
+__global__ void pack_stem_weights_kernel(const float* __restrict__ w, const float* __restrict__ gamma,
+                                         const float* __restrict__ var, float eps, int cout, int cin, int taps,
+                                         int cout_pad, float* __restrict__ packed) {
+    const int total = cout * cin * taps;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int tap = i % taps;
+    const int r = i / taps;
+    const int ci = r % cin, co = r / cin;
+    const float scale = gamma ? gamma[co] / sqrtf(var[co] + eps) : 1.f;
+    packed[(tap * cin + ci) * cout_pad + co] = w[i] * scale;
+}
+
+// ------------------------------------------------------------------------------------- first layer
+template <typename T, int CO> struct StemStore;
+template <int CO> struct StemStore<f16, CO> {
+    static __device__ __forceinline__ void run(f16* dst, const float (&acc)[CO], int co0, int cout) {
+#pragma unroll
+        for (int g = 0; g < CO / 8; ++g) {
+            if (co0 + g * 8 >= cout) break;
+            f16x8 v;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (f16)acc[g * 8 + e];
+            *reinterpret_cast<f16x8*>(dst + g * 8) = v;
+        }
+    }
+};
+template <int CO> struct StemStore<float, CO> {
+    static __device__ __forceinline__ void run(float* dst, const float (&acc)[CO], int co0, int cout) {
+#pragma unroll
+        for (int g = 0; g < CO / 4; ++g) {
+            if (co0 + g * 4 >= cout) break;
+            f32x4 v = {acc[g * 4], acc[g * 4 + 1], acc[g * 4 + 2], acc[g * 4 + 3]};
+            *reinterpret_cast<f32x4*>(dst + g * 4) = v;
+        }
+    }
+};
+
+// one thread = one output pixel x CO output channels; weights/bias are wave-uniform (scalar loads)
+template <typename T, int CO>
+__global__ __launch_bounds__(256) void conv_stem_kernel(const yh_stem_desc d) {
+    const long P = (long)d.n * d.ho * d.wo;
+    const long p = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    const int co0 = blockIdx.y * CO;
+    if (p >= P) return;
+    const int hw = d.ho * d.wo;
+    const int n = (int)(p / hw);
+    const int rem = (int)(p - (long)n * hw);
+    const int ho = rem / d.wo, wo = rem - ho * d.wo;
+    const int hi0 = ho * d.stride - d.pad, wi0 = wo * d.stride - d.pad;
+    float acc[CO];
+#pragma unroll
+    for (int c = 0; c < CO; ++c) acc[c] = d.bias[co0 + c];
+    const float* xin = d.x + (long)n * d.cin * d.h * d.w_in;
+    for (int r = 0; r < d.kh; ++r) {
+        const int hi = hi0 + r;
+        for (int s = 0; s < d.kw; ++s) {
+            const int wi = wi0 + s;
+            const bool ok = (unsigned)hi < (unsigned)d.h && (unsigned)wi < (unsigned)d.w_in;
+            for (int ci = 0; ci < d.cin; ++ci) {
+                const float xv = ok ? xin[((long)ci * d.h + hi) * d.w_in + wi] : 0.f;
+                const float* wrow = d.w + ((r * d.kw + s) * d.cin + ci) * d.cout_pad + co0;
+#pragma unroll
+                for (int c = 0; c < CO; ++c) acc[c] = fmaf(xv, wrow[c], acc[c]);
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < CO; ++c) acc[c] = activate(acc[c], d.act, d.slope);
+    T* dst = reinterpret_cast<T*>(d.y) + p * d.ldy + co0;
+    StemStore<T, CO>::run(dst, acc, co0, d.cout);
+}
+
+// ---------------------------------------------------------------------------------------- max pool
+template <typename T> struct Vec16;
+template <> struct Vec16<f16> { typedef f16x8 type; static constexpr int N = 8; };
+template <> struct Vec16<float> { typedef f32x4 type; static constexpr int N = 4; };
+
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_kernel(const yh_pool_desc d) {
+    typedef typename Vec16<T>::type V;
+    constexpr int VN = Vec16<T>::N;
+    const int cg = d.c / VN;
+    const long total = (long)d.n * d.ho * d.wo * cg;
+    const T* x = reinterpret_cast<const T*>(d.x);
+    T* y = reinterpret_cast<T*>(d.y);
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int g = (int)(i % cg);
+        long r = i / cg;
+        const int wo = (int)(r % d.wo);
+        r /= d.wo;
+        const int ho = (int)(r % d.ho);
+        const int n = (int)(r / d.ho);
+        float m[VN];
+#pragma unroll
+        for (int e = 0; e < VN; ++e) m[e] = -INFINITY;
+        for (int dy = 0; dy < d.k; ++dy) {
+            const int hi = ho * d.stride - d.pad_lo + dy;
+            for (int dx = 0; dx < d.k; ++dx) {
+                const int wi = wo * d.stride - d.pad_lo + dx;
+                if ((unsigned)hi < (unsigned)d.h && (unsigned)wi < (unsigned)d.w_in) {
+                    const V v = *reinterpret_cast<const V*>(x + (((long)n * d.h + hi) * d.w_in + wi) * d.ldx + g * VN);
+#pragma unroll
+                    for (int e = 0; e < VN; ++e) m[e] = fmaxf(m[e], (float)v[e]);
+                } else if (d.edge_zero && hi >= 0 && wi >= 0) {
+#pragma unroll
+                    for (int e = 0; e < VN; ++e) m[e] = fmaxf(m[e], 0.f);
+                }
+            }
+        }
+        V o;
+#pragma unroll
+        for (int e = 0; e < VN; ++e) o[e] = (T)m[e];
+        *reinterpret_cast<V*>(y + (((long)n * d.ho + ho) * d.wo + wo) * d.ldy + g * VN) = o;
+    }
+}
+
+// ------------------------------------------------------------------------------ copy / upsample / add
+template <typename T>
+__global__ __launch_bounds__(256) void copy_channels_kernel(const yh_copy_desc d) {
+    typedef typename Vec16<T>::type V;
+    constexpr int VN = Vec16<T>::N;
+    const int cg = d.c / VN;
+    const long total = (long)d.n * d.h * d.w_in * cg;
+    const T* x = reinterpret_cast<const T*>(d.x);
+    T* y = reinterpret_cast<T*>(d.y);
+    const int u = d.ups;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int g = (int)(i % cg);
+        const long pix = i / cg;
+        const V v = *reinterpret_cast<const V*>(x + pix * d.ldx + g * VN);
+        if (u == 1) {
+            *reinterpret_cast<V*>(y + pix * d.ldy + g * VN) = v;
+        } else {
+            const int wi = (int)(pix % d.w_in);
+            const long r = pix / d.w_in;
+            const int hi = (int)(r % d.h);
+            const long n = r / d.h;
+            const long wo_n = (long)d.w_in * u;
+            for (int dy = 0; dy < u; ++dy)
+                for (int dx = 0; dx < u; ++dx) {
+                    const long opix = (n * d.h * u + (long)hi * u + dy) * wo_n + (long)wi * u + dx;
+                    *reinterpret_cast<V*>(y + opix * d.ldy + g * VN) = v;
+                }
+        }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void add_channels_kernel(const yh_add_desc d) {
+    typedef typename Vec16<T>::type V;
+    constexpr int VN = Vec16<T>::N;
+    const int cg = d.c / VN;
+    const long total = d.pixels * cg;
+    const T* a = reinterpret_cast<const T*>(d.a);
+    const T* b = reinterpret_cast<const T*>(d.b);
+    T* y = reinterpret_cast<T*>(d.y);
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int g = (int)(i % cg);
+        const long pix = i / cg;
+        const V va = *reinterpret_cast<const V*>(a + pix * d.lda + g * VN);
+        const V vb = *reinterpret_cast<const V*>(b + pix * d.ldb + g * VN);
+        V o;
+#pragma unroll
+        for (int e = 0; e < VN; ++e) o[e] = (T)((float)va[e] + (float)vb[e]);
+        *reinterpret_cast<V*>(y + pix * d.ldy + g * VN) = o;
+    }
+}
+
+// ------------------------------------------------------------------------------------- yolo decode
+__global__ __launch_bounds__(256) void yolo_decode_kernel(const yh_decode_desc d) {
+    const long total = (long)d.n * d.na * d.ny * d.nx * d.no;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int o = (int)(i % d.no);
+        long r = i / d.no;
+        const int x = (int)(r % d.nx);
+        r /= d.nx;
+        const int y = (int)(r % d.ny);
+        r /= d.ny;
+        const int a = (int)(r % d.na);
+        const int n = (int)(r / d.na);
+        const float v = d.p[(((long)n * d.ny + y) * d.nx + x) * d.ldp + a * d.no + o];
+        if (d.raw) d.raw[i] = v;
+        float out;
+        if (o < 2) {
+            const float sg = 1.f / (1.f + expf(-v));
+            out = (sg + (float)(o == 0 ? x : y)) * d.stride;
+        } else if (o < 4) {
+            out = (expf(v) * (o == 2 ? d.anchor_w[a] : d.anchor_h[a])) * d.stride;
+        } else {
+            out = 1.f / (1.f + expf(-v));
+        }
+        const long row = d.row_off + ((long)a * d.ny + y) * d.nx + x;
+        d.io[((long)n * d.rows_total + row) * d.no + o] = out;
+    }
+}
+
+static inline unsigned grid_for(long total, int block = 256, long cap = 256L * 16) {
+    long g = (total + block - 1) / block;
+    if (g > cap) g = cap;
+    if (g < 1) g = 1;
+    return (unsigned)g;
+}
+
+}  // namespace yh
+
+using namespace yh;
+
+extern "C" int yh_conv_pack_weights(int dtype, const float* w, const float* conv_bias, const float* bn_gamma,
+                                    const float* bn_beta, const float* bn_mean, const float* bn_var, float bn_eps,
+                                    const int32_t* cin_map, int cout, int cin, int kh, int kw, int cin_k, int m_pad,
+                                    void* packed, float* bias_out, void* stream) {
+    if (!w || !packed || !bias_out || cout <= 0 || cin <= 0 || kh <= 0 || kw <= 0) return YH_EINVAL;
+    if (dtype != YH_F16 && dtype != YH_F32) return YH_EINVAL;
+    const bool bn = bn_gamma != nullptr;
+    if (bn && (!bn_beta || !bn_mean || !bn_var)) return YH_EINVAL;
+    const int bk = dtype == YH_F16 ? 32 : 16;
+    if (cin_k % bk || m_pad % 128 || m_pad < cout) return YH_EALIGN;
+    hipStream_t s = (hipStream_t)stream;
+    const int taps = kh * kw;
+    const size_t esz = dtype == YH_F16 ? 2 : 4;
+    hipError_t e = hipMemsetAsync(packed, 0, (size_t)m_pad * taps * cin_k * esz, s);
+    if (e != hipSuccess) return (int)e;
+    e = hipMemsetAsync(bias_out, 0, (size_t)m_pad * sizeof(float), s);
+    if (e != hipSuccess) return (int)e;
+    const long total = (long)cout * cin * taps;
+    if (dtype == YH_F16)
+        hipLaunchKernelGGL(pack_conv_weights_kernel<f16>, dim3(grid_for(total)), dim3(256), 0, s, w, bn_gamma, bn_var, bn_eps,
+                           cin_map, cout, cin, taps, cin_k, (f16*)packed);
+    else
+        hipLaunchKernelGGL(pack_conv_weights_kernel<float>, dim3(grid_for(total)), dim3(256), 0, s, w, bn_gamma, bn_var,
+                           bn_eps, cin_map, cout, cin, taps, cin_k, (float*)packed);
+    hipLaunchKernelGGL(pack_bias_kernel, dim3((cout + 255) / 256), dim3(256), 0, s, conv_bias, bn_gamma, bn_beta, bn_mean,
+                       bn_var, bn_eps, cout, bias_out);
+    return check_launch();
+}
+
+extern "C" int yh_stem_pack_weights(const float* w, const float* conv_bias, const float* bn_gamma, const float* bn_beta,
+                                    const float* bn_mean, const float* bn_var, float bn_eps, int cout, int cin, int kh,
+                                    int kw, int cout_pad, float* packed, float* bias_out, void* stream) {
+    if (!w || !packed || !bias_out || cout <= 0 || cin <= 0 || kh <= 0 || kw <= 0) return YH_EINVAL;
+    if (cout_pad % 16 || cout_pad < cout) return YH_EALIGN;
+    const bool bn = bn_gamma != nullptr;
+    if (bn && (!bn_beta || !bn_mean || !bn_var)) return YH_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    const int taps = kh * kw;
+    hipError_t e = hipMemsetAsync(packed, 0, (size_t)taps * cin * cout_pad * sizeof(float), s);
+    if (e != hipSuccess) return (int)e;
+    e = hipMemsetAsync(bias_out, 0, (size_t)cout_pad * sizeof(float), s);
+    if (e != hipSuccess) return (int)e;
+    const int total = cout * cin * taps;
+    hipLaunchKernelGGL(pack_stem_weights_kernel, dim3((total + 255) / 256), dim3(256), 0, s, w, bn_gamma, bn_var, bn_eps, cout,
+                       cin, taps, cout_pad, packed);
+    hipLaunchKernelGGL(pack_bias_kernel, dim3((cout + 255) / 256), dim3(256), 0, s, conv_bias, bn_gamma, bn_beta, bn_mean,
+                       bn_var, bn_eps, cout, bias_out);
+    return check_launch();
+}
+
+extern "C" int yh_conv2d_stem_fwd(const yh_stem_desc* d, void* stream) {
+    if (!d || !d->x || !d->w || !d->bias || !d->y) return YH_EINVAL;
+    if (d->n <= 0 || d->cin <= 0 || d->cin > 4 || d->h <= 0 || d->w_in <= 0 || d->cout <= 0) return YH_EINVAL;
+    if (d->dtype != YH_F16 && d->dtype != YH_F32) return YH_EINVAL;
+    if (d->cout_pad % 16 || d->cout_pad < d->cout || d->cout % 8 || d->ldy % 8 || !aligned16(d->y)) return YH_EALIGN;
+    if (d->ho != (d->h + 2 * d->pad - d->kh) / d->stride + 1 || d->wo != (d->w_in + 2 * d->pad - d->kw) / d->stride + 1) return YH_EINVAL;
+    const long P = (long)d->n * d->ho * d->wo;
+    hipStream_t s = (hipStream_t)stream;
+    const bool wide = d->cout_pad % 32 == 0;
+    const dim3 grid((unsigned)((P + 255) / 256), (unsigned)(d->cout_pad / (wide ? 32 : 16)));
+    if (d->dtype == YH_F16) {
+        if (wide) hipLaunchKernelGGL((conv_stem_kernel<f16, 32>), grid, dim3(256), 0, s, *d);
+        else hipLaunchKernelGGL((conv_stem_kernel<f16, 16>), grid, dim3(256), 0, s, *d);
+    } else {
+        if (wide) hipLaunchKernelGGL((conv_stem_kernel<float, 32>), grid, dim3(256), 0, s, *d);
+        else hipLaunchKernelGGL((conv_stem_kernel<float, 16>), grid, dim3(256), 0, s, *d);
+    }
+    return check_launch();
+}
+
+static int vec_of(int dtype) { return dtype == YH_F16 ? 8 : 4; }
+
+extern "C" int yh_maxpool2d_fwd(const yh_pool_desc* d, void* stream) {
+    if (!d || !d->x || !d->y || d->n <= 0 || d->c <= 0 || d->k <= 0 || d->stride <= 0) return YH_EINVAL;
+    if (d->dtype != YH_F16 && d->dtype != YH_F32) return YH_EINVAL;
+    const int v = vec_of(d->dtype);
+    if (d->c % v || d->ldx % v || d->ldy % v || !aligned16(d->x) || !aligned16(d->y)) return YH_EALIGN;
+    const long total = (long)d->n * d->ho * d->wo * (d->c / v);
+    hipStream_t s = (hipStream_t)stream;
+    if (d->dtype == YH_F16) hipLaunchKernelGGL(maxpool_kernel<f16>, dim3(grid_for(total)), dim3(256), 0, s, *d);
+    else hipLaunchKernelGGL(maxpool_kernel<float>, dim3(grid_for(total)), dim3(256), 0, s, *d);
+    return check_launch();
+}
+
+extern "C" int yh_copy_channels(const yh_copy_desc* d, void* stream) {
+    if (!d || !d->x || !d->y || d->n <= 0 || d->c <= 0 || (d->ups != 1 && d->ups != 2)) return YH_EINVAL;
+    if (d->dtype != YH_F16 && d->dtype != YH_F32) return YH_EINVAL;
+    const int v = vec_of(d->dtype);
+    if (d->c % v || d->ldx % v || d->ldy % v || !aligned16(d->x) || !aligned16(d->y)) return YH_EALIGN;
+    const long total = (long)d->n * d->h * d->w_in * (d->c / v);
+    hipStream_t s = (hipStream_t)stream;
+    if (d->dtype == YH_F16) hipLaunchKernelGGL(copy_channels_kernel<f16>, dim3(grid_for(total)), dim3(256), 0, s, *d);
+    else hipLaunchKernelGGL(copy_channels_kernel<float>, dim3(grid_for(total)), dim3(256), 0, s, *d);
+    return check_launch();
+}
+
+extern "C" int yh_add_channels(const yh_add_desc* d, void* stream) {
+    if (!d || !d->a || !d->b || !d->y || d->pixels <= 0 || d->c <= 0) return YH_EINVAL;
+    if (d->dtype != YH_F16 && d->dtype != YH_F32) return YH_EINVAL;
+    const int v = vec_of(d->dtype);
+    if (d->c % v || d->lda % v || d->ldb % v || d->ldy % v || !aligned16(d->a) || !aligned16(d->b) || !aligned16(d->y)) return YH_EALIGN;
+    const long total = d->pixels * (d->c / v);
+    hipStream_t s = (hipStream_t)stream;
+    if (d->dtype == YH_F16) hipLaunchKernelGGL(add_channels_kernel<f16>, dim3(grid_for(total)), dim3(256), 0, s, *d);
+    else hipLaunchKernelGGL(add_channels_kernel<float>, dim3(grid_for(total)), dim3(256), 0, s, *d);
+    return check_launch();
+}
+
+extern "C" int yh_yolo_decode(const yh_decode_desc* d, void* stream) {
+    if (!d || !d->p || !d->io || d->n <= 0 || d->ny <= 0 || d->nx <= 0 || d->na <= 0 || d->na > 8 || d->no < 5) return YH_EINVAL;
+    if (d->ldp < d->na * d->no || d->row_off < 0 || d->row_off + d->na * d->ny * d->nx > d->rows_total) return YH_EINVAL;
+    const long total = (long)d->n * d->na * d->ny * d->nx * d->no;
+    hipLaunchKernelGGL(yolo_decode_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, *d);
+    return check_launch();
+}

@@ -1,0 +1,148 @@
+// Native replay of a recorded launch sequence: one call per forward instead of the reference's
+// per-layer Python dispatch (models.py:524-545).  Host-only code; compiled with the kernels so the
+// shared library is self-contained.
+#include <string.h>
+
+#include <new>
+#include <vector>
+
+#include "common.h"
+
+namespace {
+
+union AnyDesc {
+    yh_conv_desc conv;
+    yh_stem_desc stem;
+    yh_pool_desc pool;
+    yh_copy_desc copy;
+    yh_add_desc add;
+    yh_decode_desc decode;
+};
+
+struct Fixup {
+    int field_offset;
+    int slot;
+    int64_t byte_offset;
+};
+
+struct Op {
+    int kind;
+    AnyDesc d;
+    std::vector<Fixup> fixups;
+};
+
+size_t desc_size(int kind) {
+    switch (kind) {
+        case YH_OP_CONV: return sizeof(yh_conv_desc);
+        case YH_OP_STEM: return sizeof(yh_stem_desc);
+        case YH_OP_POOL: return sizeof(yh_pool_desc);
+        case YH_OP_COPY: return sizeof(yh_copy_desc);
+        case YH_OP_ADD: return sizeof(yh_add_desc);
+        case YH_OP_DECODE: return sizeof(yh_decode_desc);
+        default: return 0;
+    }
+}
+
+int launch(int kind, const AnyDesc& d, void* stream) {
+    switch (kind) {
+        case YH_OP_CONV: return yh_conv2d_fwd(&d.conv, stream);
+        case YH_OP_STEM: return yh_conv2d_stem_fwd(&d.stem, stream);
+        case YH_OP_POOL: return yh_maxpool2d_fwd(&d.pool, stream);
+        case YH_OP_COPY: return yh_copy_channels(&d.copy, stream);
+        case YH_OP_ADD: return yh_add_channels(&d.add, stream);
+        case YH_OP_DECODE: return yh_yolo_decode(&d.decode, stream);
+        default: return YH_EINVAL;
+    }
+}
+
+}  // namespace
+
+struct yh_plan {
+    std::vector<Op> ops;
+    std::vector<void*> slots;
+};
+
+extern "C" int yh_abi_version(void) { return YH_ABI_VERSION; }
+
+extern "C" const char* yh_error_string(int code) {
+    switch (code) {
+        case YH_OK: return "ok";
+        case YH_EINVAL: return "invalid argument";
+        case YH_EALIGN: return "misaligned pointer, pitch or channel count";
+        case YH_EUNSUPPORTED: return "unsupported configuration";
+        case YH_ENOMEM: return "out of host memory";
+        case YH_ERANGE: return "index out of range";
+        default: return code > 0 ? hipGetErrorString((hipError_t)code) : "unknown error";
+    }
+}
+
+extern "C" yh_plan* yh_plan_create(void) { return new (std::nothrow) yh_plan(); }
+
+extern "C" void yh_plan_destroy(yh_plan* p) { delete p; }
+
+extern "C" int yh_plan_add(yh_plan* p, int op_kind, const void* desc, int desc_bytes) {
+    if (!p || !desc) return YH_EINVAL;
+    const size_t want = desc_size(op_kind);
+    if (want == 0 || (size_t)desc_bytes != want) return YH_EINVAL;
+    Op op;
+    op.kind = op_kind;
+    memset(&op.d, 0, sizeof(op.d));
+    memcpy(&op.d, desc, want);
+    try {
+        p->ops.push_back(op);
+    } catch (...) {
+        return YH_ENOMEM;
+    }
+    return (int)p->ops.size() - 1;
+}
+
+extern "C" int yh_plan_add_fixup(yh_plan* p, int op_index, int field_offset, int slot, int64_t byte_offset) {
+    if (!p) return YH_EINVAL;
+    if (op_index < 0 || op_index >= (int)p->ops.size() || slot < 0 || slot >= 64) return YH_ERANGE;
+    Op& op = p->ops[op_index];
+    if (field_offset < 0 || (size_t)field_offset + sizeof(void*) > desc_size(op.kind) || field_offset % (int)sizeof(void*)) return YH_ERANGE;
+    try {
+        op.fixups.push_back(Fixup{field_offset, slot, byte_offset});
+        if ((int)p->slots.size() <= slot) p->slots.resize(slot + 1, nullptr);
+    } catch (...) {
+        return YH_ENOMEM;
+    }
+    return YH_OK;
+}
+
+extern "C" int yh_plan_bind_slot(yh_plan* p, int slot, void* ptr) {
+    if (!p) return YH_EINVAL;
+    if (slot < 0 || slot >= 64) return YH_ERANGE;
+    try {
+        if ((int)p->slots.size() <= slot) p->slots.resize(slot + 1, nullptr);
+    } catch (...) {
+        return YH_ENOMEM;
+    }
+    p->slots[slot] = ptr;
+    return YH_OK;
+}
+
+extern "C" int yh_plan_num_ops(const yh_plan* p) { return p ? (int)p->ops.size() : YH_EINVAL; }
+
+extern "C" int yh_plan_run_range(yh_plan* p, int first, int last, void* stream) {
+    if (!p) return YH_EINVAL;
+    if (first < 0 || last > (int)p->ops.size() || first > last) return YH_ERANGE;
+    for (int i = first; i < last; ++i) {
+        const Op& op = p->ops[i];
+        AnyDesc d = op.d;
+        for (const Fixup& f : op.fixups) {
+            void* base = p->slots[f.slot];
+            if (!base) return YH_EINVAL;
+            void* v = (char*)base + f.byte_offset;
+            memcpy((char*)&d + f.field_offset, &v, sizeof(void*));
+        }
+        const int rc = launch(op.kind, d, stream);
+        if (rc != YH_OK) return rc;
+    }
+    return YH_OK;
+}
+
+extern "C" int yh_plan_run(yh_plan* p, void* stream) {
+    if (!p) return YH_EINVAL;
+    return yh_plan_run_range(p, 0, (int)p->ops.size(), stream);
+}

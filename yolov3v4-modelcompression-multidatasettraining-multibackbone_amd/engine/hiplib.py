@@ -1,0 +1,144 @@
+"""ctypes binding of ``libyolo_hip.so`` (C ABI declared in ``include/yolo_hip.h``).
+
+There is deliberately no fallback: if the shared library is missing or an entry point cannot be
+resolved, importing the HIP path raises ``RuntimeError`` — GPU results never come from a silent eager
+substitute.  Build the library with ``make -C csrc`` (or ``python __graft_entry__.py``).
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), 'libyolo_hip.so')
+
+YH_F16, YH_F32 = 0, 1
+ACT_CODES = {'linear': 0, 'leaky': 1, 'relu': 2, 'relu6': 3, 'h_swish': 4, 'mish': 5}
+OP_CONV, OP_STEM, OP_POOL, OP_COPY, OP_ADD, OP_DECODE = 1, 2, 3, 4, 5, 6
+
+_i32, _f32, _vp, _i64 = C.c_int32, C.c_float, C.c_void_p, C.c_int64
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [('x', _vp), ('w', _vp), ('bias', _vp), ('res', _vp), ('y', _vp),
+                ('n', _i32), ('h', _i32), ('w_in', _i32), ('cin', _i32),
+                ('ho', _i32), ('wo', _i32), ('cout', _i32),
+                ('kh', _i32), ('kw', _i32), ('stride', _i32), ('pad', _i32),
+                ('ldx', _i32), ('ldr', _i32), ('ldy', _i32),
+                ('cin_k', _i32), ('m_pad', _i32),
+                ('act', _i32), ('slope', _f32), ('ups', _i32), ('out_f32', _i32), ('dtype', _i32), ('tile', _i32)]
+
+
+class StemDesc(C.Structure):
+    _fields_ = [('x', _vp), ('w', _vp), ('bias', _vp), ('y', _vp),
+                ('n', _i32), ('cin', _i32), ('h', _i32), ('w_in', _i32), ('ho', _i32), ('wo', _i32),
+                ('cout', _i32), ('cout_pad', _i32), ('kh', _i32), ('kw', _i32), ('stride', _i32), ('pad', _i32),
+                ('ldy', _i32), ('act', _i32), ('slope', _f32), ('dtype', _i32)]
+
+
+class PoolDesc(C.Structure):
+    _fields_ = [('x', _vp), ('y', _vp),
+                ('n', _i32), ('h', _i32), ('w_in', _i32), ('c', _i32), ('ho', _i32), ('wo', _i32), ('k', _i32),
+                ('stride', _i32), ('pad_lo', _i32), ('edge_zero', _i32), ('ldx', _i32), ('ldy', _i32), ('dtype', _i32)]
+
+
+class CopyDesc(C.Structure):
+    _fields_ = [('x', _vp), ('y', _vp),
+                ('n', _i32), ('h', _i32), ('w_in', _i32), ('c', _i32), ('ups', _i32), ('ldx', _i32), ('ldy', _i32),
+                ('dtype', _i32)]
+
+
+class AddDesc(C.Structure):
+    _fields_ = [('a', _vp), ('b', _vp), ('y', _vp), ('pixels', _i64),
+                ('c', _i32), ('lda', _i32), ('ldb', _i32), ('ldy', _i32), ('dtype', _i32)]
+
+
+class DecodeDesc(C.Structure):
+    _fields_ = [('p', _vp), ('io', _vp), ('raw', _vp),
+                ('n', _i32), ('ny', _i32), ('nx', _i32), ('na', _i32), ('no', _i32), ('ldp', _i32),
+                ('rows_total', _i32), ('row_off', _i32), ('stride', _f32),
+                ('anchor_w', _f32 * 8), ('anchor_h', _f32 * 8)]
+
+
+OP_KIND = {ConvDesc: OP_CONV, StemDesc: OP_STEM, PoolDesc: OP_POOL, CopyDesc: OP_COPY, AddDesc: OP_ADD,
+           DecodeDesc: OP_DECODE}
+
+_SIGNATURES = {
+    'yh_abi_version': (C.c_int, []),
+    'yh_error_string': (C.c_char_p, [C.c_int]),
+    'yh_conv_pack_weights': (C.c_int, [C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _f32, _vp, C.c_int, C.c_int, C.c_int,
+                                       C.c_int, C.c_int, C.c_int, _vp, _vp, _vp]),
+    'yh_conv2d_fwd': (C.c_int, [C.POINTER(ConvDesc), _vp]),
+    'yh_stem_pack_weights': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _f32, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                       _vp, _vp, _vp]),
+    'yh_conv2d_stem_fwd': (C.c_int, [C.POINTER(StemDesc), _vp]),
+    'yh_maxpool2d_fwd': (C.c_int, [C.POINTER(PoolDesc), _vp]),
+    'yh_copy_channels': (C.c_int, [C.POINTER(CopyDesc), _vp]),
+    'yh_add_channels': (C.c_int, [C.POINTER(AddDesc), _vp]),
+    'yh_yolo_decode': (C.c_int, [C.POINTER(DecodeDesc), _vp]),
+    'yh_nms_candidates': (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _f32, C.c_int, _vp, _vp, _vp, C.c_int, _vp]),
+    'yh_nms_sort': (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp]),
+    'yh_nms_mask': (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, _f32, C.c_int, _vp, _vp]),
+    'yh_nms_reduce': (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp]),
+    'yh_nms_merge': (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _f32, C.c_int, C.c_int, C.c_int, _vp, _vp]),
+    'yh_plan_create': (_vp, []),
+    'yh_plan_destroy': (None, [_vp]),
+    'yh_plan_add': (C.c_int, [_vp, C.c_int, _vp, C.c_int]),
+    'yh_plan_add_fixup': (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _i64]),
+    'yh_plan_bind_slot': (C.c_int, [_vp, C.c_int, _vp]),
+    'yh_plan_num_ops': (C.c_int, [_vp]),
+    'yh_plan_run': (C.c_int, [_vp, _vp]),
+    'yh_plan_run_range': (C.c_int, [_vp, C.c_int, C.c_int, _vp]),
+}
+
+EXPORTS = tuple(_SIGNATURES)
+ABI_VERSION = 1
+_lib = None
+
+
+class HipLibraryError(RuntimeError):
+    pass
+
+
+def load():
+    """Load (once) and return the ctypes handle; raises HipLibraryError when unavailable."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.isfile(LIB_PATH):
+        raise HipLibraryError('HIP library not built: %s is missing (run `make -C %s`). There is no eager '
+                              'fallback for CUDA tensors.' % (LIB_PATH, os.path.join(os.path.dirname(_HERE), 'csrc')))
+    try:
+        lib = C.CDLL(LIB_PATH)
+    except OSError as e:
+        raise HipLibraryError('cannot load %s: %s' % (LIB_PATH, e))
+    for name, (res, args) in _SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError:
+            raise HipLibraryError('%s does not export %s (stale build?)' % (LIB_PATH, name))
+        fn.restype = res
+        fn.argtypes = args
+    if lib.yh_abi_version() != ABI_VERSION:
+        raise HipLibraryError('ABI mismatch: library %d, binding %d' % (lib.yh_abi_version(), ABI_VERSION))
+    _lib = lib
+    return lib
+
+
+def check(rc, what=''):
+    if rc != 0:
+        msg = load().yh_error_string(rc)
+        raise RuntimeError('libyolo_hip %s failed: %s (code %d)' % (what, msg.decode() if msg else '?', rc))
+
+
+def ptr(t, elem_offset=0):
+    """Device address of a torch tensor (+ element offset) as an int usable for c_void_p fields."""
+    if t is None:
+        return None
+    return t.data_ptr() + elem_offset * t.element_size()
+
+
+def stream_ptr():
+    """Current torch HIP stream as a void* (NULL stream when torch has no GPU: host-emulation tests)."""
+    import torch
+    if not torch.cuda.is_available():
+        return None
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)

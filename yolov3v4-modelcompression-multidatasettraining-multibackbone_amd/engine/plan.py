@@ -1,0 +1,519 @@
+"""Lowering of a ``models.Darknet`` module to a replayable launch plan on ``libyolo_hip.so``.
+
+The reference executes the graph with a per-layer Python loop over ``nn.Module`` s
+(models.py:524-545) on NCHW tensors.  Here the same cfg graph is *compiled* once per input shape:
+
+1. **Values.**  Every block output that must exist in memory becomes a ``Value`` (NHWC, dtype fp16 or
+   fp32, channel pitch ``ld``).  Blocks that only re-label data produce no value: a single-layer
+   ``route`` is an alias, a ``shortcut`` following a conv is folded into that conv's epilogue as a
+   residual operand, an ``upsample`` following a conv makes the conv write each pixel to its 2x2
+   block, and a ``yolo`` block becomes a decode op writing straight into the concatenated output.
+2. **Placement.**  A multi-input ``route`` owns one wide buffer; each input that is not already placed
+   elsewhere is *produced directly into its channel slice* (zero-copy concat); consumers read slices
+   through the pitch.  Channel counts that are not multiples of 8 are padded per segment and the
+   consumer's packed weights get zero columns at the pad positions (``cin_map``), so pruned models
+   with arbitrary widths lower the same way.
+3. **Weights.**  BN is folded and weights are packed K-major by ``yh_conv_pack_weights`` on the device,
+   straight from the live ``nn.Parameter`` storage.  The cache is keyed on every source tensor's
+   ``(data_ptr, _version, shape)``; ``Darknet`` also drops the engine on ``load_state_dict`` /
+   ``load_darknet_weights`` / ``fuse`` / ``.to()`` / ``train()``.
+4. **Replay.**  ``yh_plan_run`` launches the recorded ops from native code; per-call pointers (input
+   frames, output tensors) are slots patched at launch.
+
+Nothing here computes activations with torch: torch supplies device memory and the stream.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import hiplib
+from .hiplib import ConvDesc, StemDesc, PoolDesc, CopyDesc, AddDesc, DecodeDesc
+
+SLOT_INPUT, SLOT_IO, SLOT_RAW0 = 0, 1, 2
+ALIGN_C = 8  # physical channel granularity of every NHWC buffer (16 bytes of fp16)
+
+
+def _round_up(a, b):
+    return (a + b - 1) // b * b
+
+
+class Value:
+    """A tensor that exists in device memory during the forward."""
+
+    def __init__(self, kind, C, H, W, block=None, **kw):
+        self.kind = kind  # input | conv | pool | copy | add | concat | slice
+        self.C, self.H, self.W = C, H, W
+        self.block = block
+        self.fp32 = False  # head convs store fp32 regardless of the engine precision
+        self.segs = [(0, C)]  # (physical start relative to c_off, logical length)
+        self.c_phys = _round_up(C, ALIGN_C)
+        self.parent = None  # concat value this one is produced into
+        self.storage = None
+        self.c_off = 0
+        self.ld = None
+        self.__dict__.update(kw)
+
+    def channel_map(self):
+        m = []
+        for start, length in self.segs:
+            m.extend(range(start, start + length))
+        return m
+
+    def is_dense(self):
+        return len(self.segs) == 1 and self.segs[0] == (0, self.C)
+
+
+class Head:
+    def __init__(self, block, src, module):
+        self.block, self.src = block, src
+        self.na, self.no, self.nc = module.na, module.no, module.nc
+        self.stride = float(module.stride)
+        self.anchor_vec = module.anchor_vec.detach().float().cpu().numpy()  # anchors / stride, fp32 (models.py:362)
+
+
+def _activation_of(block):
+    """(code, slope) of a conv block's activation child, by class name like the reference's scripts."""
+    for child in block.children():
+        name = child.__class__.__name__
+        if name == 'LeakyReLU':
+            return hiplib.ACT_CODES['leaky'], float(child.negative_slope)
+        if name == 'ReLU6':
+            return hiplib.ACT_CODES['relu6'], 0.0
+        if name == 'HardSwish':
+            return hiplib.ACT_CODES['h_swish'], 0.0
+        if name == 'ReLU':
+            return hiplib.ACT_CODES['relu'], 0.0
+        if name == 'Mish':
+            return hiplib.ACT_CODES['mish'], 0.0
+        if name in ('Swish', 'PReLU', 'Sigmoid'):
+            raise NotImplementedError('HIP engine: activation %s is not lowered' % name)
+    return hiplib.ACT_CODES['linear'], 0.0
+
+
+def _conv_parts(block):
+    kids = list(block.children())
+    conv = kids[0]
+    if not isinstance(conv, nn.Conv2d):
+        raise NotImplementedError('HIP engine: block starts with %s, not nn.Conv2d' % conv.__class__.__name__)
+    bn = None
+    for k in kids[1:]:
+        if isinstance(k, nn.modules.batchnorm.BatchNorm2d):
+            bn = k
+    return conv, bn
+
+
+class DarknetEngine:
+    def __init__(self, model, precision='fp16', lib=None):
+        if precision not in ('fp16', 'fp32'):
+            raise ValueError("precision must be 'fp16' or 'fp32'")
+        # ``lib`` is only ever passed by the CPU test tier (tests/fakelib.py emulates the C ABI on host
+        # memory to validate this lowering); the product path always loads the real library or raises.
+        self.lib = hiplib.load() if lib is None else lib
+        self.model = model
+        self.precision = precision
+        self.code = hiplib.YH_F16 if precision == 'fp16' else hiplib.YH_F32
+        self.dtype = torch.float16 if precision == 'fp16' else torch.float32
+        self.kstep = 32 if precision == 'fp16' else 16
+        self.want_raw = True
+        self.return_features = False
+        self._plans = {}
+        self._packed = {}  # block index -> dict(w=, b=, ...)
+        self._signature = None
+        self.device = None
+
+    # ------------------------------------------------------------------------------------ graph
+    def _build_values(self, N, Cin, H, W):
+        model = self.model
+        defs, mods, routs = model.module_defs, model.module_list, model.routs
+        L = len(mods)
+        x0 = Value('input', Cin, H, W)
+        values, heads = [x0], []
+        outs = [None] * L
+        cur = x0
+        skip = set()
+
+        def ref(i, l):
+            j = i + l if l < 0 else l
+            v = outs[j]
+            if v is None:
+                raise NotImplementedError('HIP engine: block %d reads block %d, which has no tensor' % (i, j))
+            return v
+
+        for i, (mdef, module) in enumerate(zip(defs, mods)):
+            kind = mdef['type']
+            cname = module.__class__.__name__
+            if i in skip:
+                outs[i] = cur
+                continue
+            hidden = False  # True when this block's own output is fused away into its follower
+            if kind in ('convolutional', 'depthwise'):
+                conv, bn = _conv_parts(module)
+                if conv.groups != 1:
+                    raise NotImplementedError('HIP engine: grouped/depthwise conv (block %d) not lowered yet' % i)
+                k, s, p = conv.kernel_size[0], conv.stride[0], conv.padding[0]
+                if conv.kernel_size[0] != conv.kernel_size[1] or conv.in_channels != cur.C:
+                    raise NotImplementedError('HIP engine: unsupported conv geometry at block %d' % i)
+                Ho, Wo = (cur.H + 2 * p - k) // s + 1, (cur.W + 2 * p - k) // s + 1
+                act, slope = _activation_of(module)
+                v = Value('conv', conv.out_channels, Ho, Wo, block=i, src=cur, conv=conv, bn=bn, k=k, stride=s, pad=p,
+                          act=act, slope=slope, res=None, ups=1)
+                nxt = defs[i + 1]['type'] if i + 1 < L else None
+                if nxt == 'shortcut' and not routs[i] and self._fusable_shortcut(i + 1, v, outs):
+                    v.res = ref(i + 1, mods[i + 1].layers[0])
+                    skip.add(i + 1)
+                    hidden = True
+                elif nxt == 'upsample' and not routs[i] and int(defs[i + 1]['stride']) == 2:
+                    v.ups = 2
+                    v.H, v.W = 2 * Ho, 2 * Wo
+                    v.Ho, v.Wo = Ho, Wo
+                    skip.add(i + 1)
+                    hidden = True
+                elif nxt == 'yolo':
+                    v.fp32 = True
+                if v.ups == 1:
+                    v.Ho, v.Wo = Ho, Wo
+                values.append(v)
+                cur = v
+            elif kind == 'maxpool':
+                k, s = int(mdef['size']), int(mdef['stride'])
+                if k == 2 and s == 1:
+                    Ho, Wo, pad_lo, edge_zero = cur.H, cur.W, 0, 1
+                else:
+                    pad_lo, edge_zero = (k - 1) // 2, 0
+                    Ho, Wo = (cur.H + 2 * pad_lo - k) // s + 1, (cur.W + 2 * pad_lo - k) // s + 1
+                v = Value('pool', cur.C, Ho, Wo, block=i, src=cur, k=k, stride=s, pad_lo=pad_lo, edge_zero=edge_zero)
+                v.segs, v.c_phys = list(cur.segs), cur.c_phys
+                values.append(v)
+                cur = v
+            elif kind == 'upsample':
+                s = int(mdef['stride'])
+                if s != 2:
+                    raise NotImplementedError('HIP engine: upsample stride %d' % s)
+                v = Value('copy', cur.C, cur.H * 2, cur.W * 2, block=i, src=cur, ups=2)
+                v.segs, v.c_phys = list(cur.segs), cur.c_phys
+                values.append(v)
+                cur = v
+            elif kind == 'route':
+                layers = module.layers
+                if len(layers) > 1:
+                    srcs = [ref(i, l) for l in layers]
+                    if any((s.H, s.W) != (srcs[0].H, srcs[0].W) for s in srcs):
+                        raise ValueError('route %d joins tensors of different spatial size' % i)
+                    v = Value('concat', sum(s.C for s in srcs), srcs[0].H, srcs[0].W, block=i, srcs=srcs)
+                    values.append(v)
+                    cur = v
+                elif getattr(module, 'groups', False):
+                    half = cur.C // 2
+                    if not cur.is_dense() or half % ALIGN_C or (cur.C - half) % ALIGN_C:
+                        raise NotImplementedError('HIP engine: unaligned group split at block %d' % i)
+                    v = Value('slice', cur.C - half, cur.H, cur.W, block=i, src=cur, first=half)
+                    values.append(v)
+                    cur = v
+                else:
+                    cur = ref(i, layers[0])
+            elif kind == 'shortcut':
+                if getattr(module, 'weight', False):
+                    raise NotImplementedError('HIP engine: weighted shortcut (block %d)' % i)
+                for l in module.layers:
+                    other = ref(i, l)
+                    c = min(cur.C, other.C)
+                    if c != cur.C or not cur.is_dense() or not other.is_dense():
+                        raise NotImplementedError('HIP engine: channel-mismatched shortcut (block %d)' % i)
+                    v = Value('add', cur.C, cur.H, cur.W, block=i, a=cur, b=other)
+                    values.append(v)
+                    cur = v
+            elif kind == 'yolo':
+                if not getattr(cur, 'fp32', False):
+                    raise NotImplementedError('HIP engine: yolo block %d is not fed by a conv block' % i)
+                heads.append(Head(i, cur, module))
+            elif kind == 'reorg3d':
+                pass
+            else:
+                raise NotImplementedError('HIP engine: block type %r (block %d) is not lowered' % (kind, i))
+            outs[i] = None if hidden else cur
+        if not heads:
+            raise ValueError('cfg has no yolo block')
+        return values, heads, outs
+
+    def _fusable_shortcut(self, j, conv_value, outs):
+        module = self.model.module_list[j]
+        if module.__class__.__name__ != 'Shortcut' or getattr(module, 'weight', False) or len(module.layers) != 1:
+            return False
+        l = module.layers[0]
+        other = outs[j + l if l < 0 else l]
+        return (other is not None and other.C == conv_value.C and (other.H, other.W) == (conv_value.H, conv_value.W)
+                and other.is_dense())
+
+    def _place(self, values):
+        """Decide which values are produced directly into a concat buffer's channel slice."""
+        for v in values:
+            if v.kind != 'concat':
+                continue
+            segs, off, seen = [], 0, set()
+            v.parts = []
+            for s in v.srcs:
+                if s.kind == 'input':
+                    raise NotImplementedError('HIP engine: route over the network input')
+                inplace = (s.kind in ('conv', 'pool', 'copy', 'add') and s.parent is None and id(s) not in seen
+                           and not s.fp32 and s.storage is None)
+                if inplace:
+                    s.parent, s.parent_off = v, off
+                seen.add(id(s))
+                v.parts.append((s, off, inplace))
+                segs.extend((off + st, ln) for st, ln in s.segs)
+                off += s.c_phys
+            v.segs, v.c_phys = segs, off
+
+    # ---------------------------------------------------------------------------------- weights
+    def _source_tensors(self):
+        out = []
+        for block in self.model.module_list:
+            if isinstance(block, nn.Sequential) and len(block) and isinstance(block[0], nn.Conv2d):
+                conv, bn = _conv_parts(block)
+                out.extend(t for t in (conv.weight, conv.bias) if t is not None)
+                if bn is not None:
+                    out.extend((bn.weight, bn.bias, bn.running_mean, bn.running_var))
+        return out
+
+    def _current_signature(self):
+        return tuple((t.data_ptr(), t._version, tuple(t.shape)) for t in self._source_tensors())
+
+    def _pack_conv(self, v):
+        """(Re)build the packed weight image of conv value ``v``; buffers are reused when shapes allow."""
+        conv, bn = v.conv, v.bn
+        dev = conv.weight.device
+        f32 = lambda t: None if t is None else t.detach().float().contiguous()
+        w = f32(conv.weight)
+        cb = f32(conv.bias)
+        g, be, mu, var = (f32(bn.weight), f32(bn.bias), f32(bn.running_mean), f32(bn.running_var)) if bn is not None \
+            else (None, None, None, None)
+        eps = float(bn.eps) if bn is not None else 0.0
+        keep = [w, cb, g, be, mu, var]
+        P = hiplib.ptr
+        slot = self._packed.get(v.block)
+        if v.src.kind == 'input':
+            cout_pad = _round_up(v.C, 32) if v.C % 32 == 0 else _round_up(v.C, 16)
+            taps = v.k * v.k
+            if slot is None or slot['w'].numel() != taps * v.src.C * cout_pad:
+                slot = dict(w=torch.empty(taps * v.src.C * cout_pad, device=dev, dtype=torch.float32),
+                            b=torch.empty(cout_pad, device=dev, dtype=torch.float32), cout_pad=cout_pad)
+            rc = self.lib.yh_stem_pack_weights(P(w), P(cb), P(g), P(be), P(mu), P(var), eps, v.C, v.src.C, v.k, v.k,
+                                               cout_pad, P(slot['w']), P(slot['b']), hiplib.stream_ptr())
+            hiplib.check(rc, 'yh_stem_pack_weights')
+        else:
+            cin_k = _round_up(v.src.c_phys, self.kstep)
+            m_pad = _round_up(_round_up(v.C, ALIGN_C), 128)
+            taps = v.k * v.k
+            cmap = None
+            if not v.src.is_dense():
+                cmap = torch.tensor(v.src.channel_map(), dtype=torch.int32, device=dev)
+                keep.append(cmap)
+            if slot is None or slot['w'].numel() != m_pad * taps * cin_k or slot['w'].dtype != self.dtype:
+                slot = dict(w=torch.empty(m_pad * taps * cin_k, device=dev, dtype=self.dtype),
+                            b=torch.empty(m_pad, device=dev, dtype=torch.float32), cin_k=cin_k, m_pad=m_pad)
+            rc = self.lib.yh_conv_pack_weights(self.code, P(w), P(cb), P(g), P(be), P(mu), P(var), eps, P(cmap), v.C,
+                                               conv.in_channels, v.k, v.k, cin_k, m_pad, P(slot['w']), P(slot['b']),
+                                               hiplib.stream_ptr())
+            hiplib.check(rc, 'yh_conv_pack_weights')
+        slot['keep'] = keep  # fp32 staging copies must outlive the async pack kernels
+        self._packed[v.block] = slot
+        return slot
+
+    # ------------------------------------------------------------------------------------- plan
+    def _alloc(self, N, H, W, C, fp32=False):
+        return torch.empty((N, H, W, C), device=self.device, dtype=torch.float32 if fp32 else self.dtype)
+
+    def _build_plan(self, N, Cin, H, W):
+        values, heads, outs = self._build_values(N, Cin, H, W)
+        self._place(values)
+        lib = self.lib
+        handle = lib.yh_plan_create()
+        if not handle:
+            raise MemoryError('yh_plan_create failed')
+        plan = dict(handle=handle, values=values, heads=heads, outs=outs, storages=[], N=N, ops=[])
+        P = hiplib.ptr
+
+        def add(desc, what):
+            idx = lib.yh_plan_add(handle, hiplib.OP_KIND[type(desc)], C.byref(desc), C.sizeof(desc))
+            if idx < 0:
+                hiplib.check(idx, 'yh_plan_add(%s)' % what)
+            plan['ops'].append((what, desc))
+            return idx
+
+        def fixup(op, desc_type, field, slot, byte_off=0):
+            hiplib.check(lib.yh_plan_add_fixup(handle, op, getattr(desc_type, field).offset, slot, byte_off), 'fixup')
+
+        def materialize(v):
+            """Give ``v`` an address: its own buffer, or a slice of its parent concat buffer."""
+            if v.storage is not None:
+                return
+            if v.parent is not None:
+                materialize(v.parent)
+                v.storage, v.c_off, v.ld = v.parent.storage, v.parent.c_off + v.parent_off, v.parent.ld
+            else:
+                v.storage = self._alloc(N, v.H, v.W, v.c_phys, v.fp32)
+                v.c_off, v.ld = 0, v.c_phys
+                plan['storages'].append(v.storage)
+
+        for v in values:
+            if v.kind == 'input':
+                continue
+            if v.kind == 'slice':
+                v.storage, v.c_off, v.ld = v.src.storage, v.src.c_off + v.first, v.src.ld
+                continue
+            materialize(v)
+            y = P(v.storage, v.c_off)
+            if v.kind == 'conv':
+                pk = self._packed.get(v.block) or self._pack_conv(v)
+                if v.src.kind == 'input':
+                    d = StemDesc(x=None, w=P(pk['w']), bias=P(pk['b']), y=y, n=N, cin=v.src.C, h=v.src.H, w_in=v.src.W,
+                                 ho=v.Ho, wo=v.Wo, cout=v.c_phys, cout_pad=pk['cout_pad'], kh=v.k, kw=v.k,
+                                 stride=v.stride, pad=v.pad, ldy=v.ld, act=v.act, slope=v.slope, dtype=self.code)
+                    if v.res is not None or v.ups != 1 or v.fp32:
+                        raise NotImplementedError('HIP engine: fused epilogue on the first conv')
+                    if v.c_phys > pk['cout_pad']:
+                        raise NotImplementedError('HIP engine: stem channel padding')
+                    op = add(d, 'stem%d' % v.block)
+                    fixup(op, StemDesc, 'x', SLOT_INPUT)
+                else:
+                    s = v.src
+                    if s.fp32 and self.code == hiplib.YH_F16:
+                        raise NotImplementedError('HIP engine: block %d consumes a yolo-head tensor' % v.block)
+                    d = ConvDesc(x=P(s.storage, s.c_off), w=P(pk['w']), bias=P(pk['b']),
+                                 res=None if v.res is None else P(v.res.storage, v.res.c_off), y=y,
+                                 n=N, h=s.H, w_in=s.W, cin=s.c_phys, ho=v.Ho, wo=v.Wo, cout=v.c_phys,
+                                 kh=v.k, kw=v.k, stride=v.stride, pad=v.pad, ldx=s.ld,
+                                 ldr=0 if v.res is None else v.res.ld, ldy=v.ld, cin_k=pk['cin_k'], m_pad=pk['m_pad'],
+                                 act=v.act, slope=v.slope, ups=v.ups, out_f32=1 if v.fp32 else 0, dtype=self.code, tile=0)
+                    add(d, 'conv%d' % v.block)
+            elif v.kind == 'pool':
+                s = v.src
+                add(PoolDesc(x=P(s.storage, s.c_off), y=y, n=N, h=s.H, w_in=s.W, c=s.c_phys, ho=v.H, wo=v.W, k=v.k,
+                             stride=v.stride, pad_lo=v.pad_lo, edge_zero=v.edge_zero, ldx=s.ld, ldy=v.ld,
+                             dtype=self.code), 'pool%d' % v.block)
+            elif v.kind == 'copy':
+                s = v.src
+                add(CopyDesc(x=P(s.storage, s.c_off), y=y, n=N, h=s.H, w_in=s.W, c=s.c_phys, ups=v.ups, ldx=s.ld,
+                             ldy=v.ld, dtype=self.code), 'ups%d' % v.block)
+            elif v.kind == 'add':
+                add(AddDesc(a=P(v.a.storage, v.a.c_off), b=P(v.b.storage, v.b.c_off), y=y, pixels=N * v.H * v.W,
+                            c=v.c_phys, lda=v.a.ld, ldb=v.b.ld, ldy=v.ld, dtype=self.code), 'add%d' % v.block)
+            elif v.kind == 'concat':
+                for s, off, inplace in v.parts:
+                    if inplace:
+                        continue  # its producer writes (or already wrote) the slice
+                    if s.fp32:
+                        raise NotImplementedError('HIP engine: route over a yolo-head tensor')
+                    add(CopyDesc(x=P(s.storage, s.c_off), y=P(v.storage, v.c_off + off), n=N, h=s.H, w_in=s.W,
+                                 c=s.c_phys, ups=1, ldx=s.ld, ldy=v.ld, dtype=self.code), 'cat%d' % v.block)
+
+        rows = sum(h.na * h.src.H * h.src.W for h in heads)
+        no = heads[0].no
+        off = 0
+        plan['raw_shapes'] = []
+        for k, h in enumerate(heads):
+            if h.no != no:
+                raise ValueError('yolo heads disagree on the class count')
+            s = h.src
+            d = DecodeDesc(p=P(s.storage, s.c_off), io=None, raw=None, n=N, ny=s.H, nx=s.W, na=h.na, no=h.no, ldp=s.ld,
+                           rows_total=rows, row_off=off, stride=h.stride)
+            for a in range(h.na):
+                d.anchor_w[a] = float(h.anchor_vec[a, 0])
+                d.anchor_h[a] = float(h.anchor_vec[a, 1])
+            op = add(d, 'yolo%d' % h.block)
+            fixup(op, DecodeDesc, 'io', SLOT_IO)
+            if self.want_raw:
+                fixup(op, DecodeDesc, 'raw', SLOT_RAW0 + k)
+            plan['raw_shapes'].append((N, h.na, s.H, s.W, h.no))
+            off += h.na * s.H * s.W
+        plan['rows'], plan['no'] = rows, no
+        return plan
+
+    # ---------------------------------------------------------------------------------- execute
+    def refresh_weights(self):
+        """Re-pack every conv from the live parameters (buffers are reused; plans stay valid)."""
+        for plan in self._plans.values():
+            for v in plan['values']:
+                if v.kind == 'conv':
+                    self._pack_conv(v)
+            break
+        self._signature = self._current_signature()
+
+    def __call__(self, x):
+        if x.dim() != 4:
+            raise ValueError('expected an (N, C, H, W) batch')
+        x = x.contiguous()
+        if x.dtype != torch.float32:
+            x = x.float()
+        if self.device is None:
+            self.device = x.device
+        elif self.device != x.device:
+            raise RuntimeError('engine was built on %s, input is on %s' % (self.device, x.device))
+        first = self.model.module_list[0]
+        w0 = first[0].weight if isinstance(first, nn.Sequential) and len(first) else None
+        if w0 is None or w0.device != x.device:
+            raise RuntimeError('model parameters must live on the input device %s' % x.device)
+
+        sig = self._current_signature()
+        if self._signature is None:
+            self._signature = sig
+        elif sig != self._signature:
+            old_shapes = [s[2] for s in self._signature]
+            if old_shapes != [s[2] for s in sig]:  # graph widths changed (pruning): start over
+                self._drop_plans()
+                self._packed = {}
+                self._signature = sig
+            else:
+                self._signature = sig
+                if self._plans:
+                    self.refresh_weights()
+
+        N, Cin, H, W = x.shape
+        key = (N, Cin, H, W)
+        plan = self._plans.get(key)
+        if plan is None:
+            plan = self._plans[key] = self._build_plan(N, Cin, H, W)
+
+        io = torch.empty((N, plan['rows'], plan['no']), device=x.device, dtype=torch.float32)
+        raws = [torch.empty(shape, device=x.device, dtype=torch.float32) for shape in plan['raw_shapes']] \
+            if self.want_raw else []
+        lib, handle = self.lib, plan['handle']
+        lib.yh_plan_bind_slot(handle, SLOT_INPUT, x.data_ptr())
+        lib.yh_plan_bind_slot(handle, SLOT_IO, io.data_ptr())
+        for k, r in enumerate(raws):
+            lib.yh_plan_bind_slot(handle, SLOT_RAW0 + k, r.data_ptr())
+        hiplib.check(lib.yh_plan_run(handle, hiplib.stream_ptr()), 'yh_plan_run')
+        feats = self._features(plan) if self.return_features else []
+        return io, tuple(raws), feats
+
+    def _features(self, plan):
+        """NCHW fp32 copies of the conv-block outputs the reference appends to ``feature_out``."""
+        feats = []
+        mods = self.model.module_list
+        for i, m in enumerate(mods):
+            if m.__class__.__name__ == 'Sequential' and i + 1 < len(mods) and \
+                    mods[i + 1].__class__.__name__ != 'YOLOLayer':
+                feats.append(self.block_output(plan, i))
+        return feats
+
+    def block_output(self, plan, i):
+        """Output of cfg block ``i`` as an NCHW fp32 tensor (debug / feature_out); None if fused away."""
+        v = plan['outs'][i]
+        if v is None or v.kind == 'input' or v.storage is None:
+            return None
+        t = v.storage[..., v.c_off:v.c_off + v.c_phys]
+        idx = torch.tensor(v.channel_map(), device=t.device)
+        return t.index_select(3, idx).permute(0, 3, 1, 2).float().contiguous()
+
+    def _drop_plans(self):
+        for plan in self._plans.values():
+            self.lib.yh_plan_destroy(plan['handle'])
+        self._plans = {}
+
+    def __del__(self):
+        try:
+            self._drop_plans()
+        except Exception:
+            pass
