@@ -216,6 +216,11 @@ int yh_plan_num_ops(const yh_plan* p);
 int yh_plan_run(yh_plan* p, void* stream);
 /* run ops [first, last) only (profiling / per-layer tests) */
 int yh_plan_run_range(yh_plan* p, int first, int last, void* stream);
+/* Per-op HIP-event timing on the launch stream: when enabled every replay brackets each op with a pair of
+ * events; after the caller has synchronised the stream, yh_plan_get_timings writes the last replay's
+ * per-op durations in milliseconds to the HOST array ms_out[n], n == yh_plan_num_ops.                    */
+int yh_plan_set_timing(yh_plan* p, int enable);
+int yh_plan_get_timings(yh_plan* p, float* ms_out, int n);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,129 @@
+"""Device-agnostic drivers for single C-ABI entry points (used by CPU emulator tests and GPU tests).
+
+Every helper takes torch tensors that live on the device the given ``lib`` executes on: the real
+``libyolo_hip.so`` with CUDA tensors, or ``fakelib.FakeLib`` with CPU tensors.
+"""
+import ctypes as C
+
+import torch
+
+from engine import hiplib
+from engine.hiplib import ConvDesc, StemDesc, PoolDesc, CopyDesc, AddDesc, DecodeDesc
+
+P = hiplib.ptr
+
+
+def round_up(a, b):
+    return (a + b - 1) // b * b
+
+
+def tdtype(code):
+    return torch.float16 if code == hiplib.YH_F16 else torch.float32
+
+
+def stream():
+    return hiplib.stream_ptr()
+
+
+def pack_conv(lib, code, w, cb=None, bn=None, eps=1e-5, cmap=None, cin_phys=None):
+    """w (cout,cin,k,k) fp32 on device; bn = (gamma, beta, mean, var) or None -> (packed, bias, cin_k, m_pad)."""
+    cout, cin, kh, kw = w.shape
+    kstep = 32 if code == hiplib.YH_F16 else 16
+    cin_phys = cin_phys or round_up(cin, 8)
+    cin_k = round_up(cin_phys, kstep)
+    m_pad = round_up(round_up(cout, 8), 128)
+    packed = torch.full((m_pad * kh * kw * cin_k,), 7.0, device=w.device, dtype=tdtype(code))
+    bias = torch.full((m_pad,), 7.0, device=w.device, dtype=torch.float32)
+    g, be, mu, var = bn if bn is not None else (None, None, None, None)
+    rc = lib.yh_conv_pack_weights(code, P(w), P(cb), P(g), P(be), P(mu), P(var), eps, P(cmap), cout, cin, kh, kw, cin_k,
+                                  m_pad, P(packed), P(bias), stream())
+    assert rc == 0, rc
+    return packed, bias, cin_k, m_pad
+
+
+def conv(lib, code, x, packed, bias, cin_k, m_pad, cout_phys, k, stride, pad, act=0, slope=0.1, res=None, ups=1,
+         out_f32=False, tile=0, cin=None, x_off=0, y=None, y_off=0, res_off=0):
+    """x: (N,H,W,ldx) NHWC buffer; reads channels [x_off, x_off+cin).  Returns the (N,Ho*ups,Wo*ups,ldy) output."""
+    N, H, W, ldx = x.shape
+    cin = cin if cin is not None else ldx - x_off
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    odt = torch.float32 if out_f32 else tdtype(code)
+    if y is None:
+        y = torch.full((N, Ho * ups, Wo * ups, cout_phys), 3.0, device=x.device, dtype=odt)
+    d = ConvDesc(x=P(x, x_off), w=P(packed), bias=P(bias), res=None if res is None else P(res, res_off), y=P(y, y_off),
+                 n=N, h=H, w_in=W, cin=cin, ho=Ho, wo=Wo, cout=cout_phys, kh=k, kw=k, stride=stride, pad=pad,
+                 ldx=ldx, ldr=0 if res is None else res.shape[3], ldy=y.shape[3], cin_k=cin_k, m_pad=m_pad, act=act,
+                 slope=slope, ups=ups, out_f32=1 if out_f32 else 0, dtype=code, tile=tile)
+    rc = lib.yh_conv2d_fwd(C.byref(d), stream())
+    assert rc == 0, 'yh_conv2d_fwd rc=%d' % rc
+    return y
+
+
+def stem(lib, code, x, w, cb=None, bn=None, eps=1e-5, stride=1, pad=1, act=1, slope=0.1):
+    cout, cin, kh, kw = w.shape
+    N, _, H, W = x.shape
+    cout_phys = round_up(cout, 8)
+    cout_pad = cout if cout % 32 == 0 else round_up(cout, 16)
+    packed = torch.empty(kh * kw * cin * cout_pad, device=x.device, dtype=torch.float32)
+    bias = torch.empty(cout_pad, device=x.device, dtype=torch.float32)
+    g, be, mu, var = bn if bn is not None else (None, None, None, None)
+    rc = lib.yh_stem_pack_weights(P(w), P(cb), P(g), P(be), P(mu), P(var), eps, cout, cin, kh, kw, cout_pad, P(packed),
+                                  P(bias), stream())
+    assert rc == 0, rc
+    Ho, Wo = (H + 2 * pad - kh) // stride + 1, (W + 2 * pad - kw) // stride + 1
+    y = torch.full((N, Ho, Wo, cout_phys), 3.0, device=x.device, dtype=tdtype(code))
+    d = StemDesc(x=P(x), w=P(packed), bias=P(bias), y=P(y), n=N, cin=cin, h=H, w_in=W, ho=Ho, wo=Wo, cout=cout_phys,
+                 cout_pad=cout_pad, kh=kh, kw=kw, stride=stride, pad=pad, ldy=cout_phys, act=act, slope=slope, dtype=code)
+    rc = lib.yh_conv2d_stem_fwd(C.byref(d), stream())
+    assert rc == 0, rc
+    return y
+
+
+def maxpool(lib, code, x, k, stride, c=None, x_off=0):
+    N, H, W, ldx = x.shape
+    c = c if c is not None else ldx - x_off
+    if k == 2 and stride == 1:
+        Ho, Wo, pad_lo, edge_zero = H, W, 0, 1
+    else:
+        pad_lo, edge_zero = (k - 1) // 2, 0
+        Ho, Wo = (H + 2 * pad_lo - k) // stride + 1, (W + 2 * pad_lo - k) // stride + 1
+    y = torch.full((N, Ho, Wo, c), 3.0, device=x.device, dtype=x.dtype)
+    d = PoolDesc(x=P(x, x_off), y=P(y), n=N, h=H, w_in=W, c=c, ho=Ho, wo=Wo, k=k, stride=stride, pad_lo=pad_lo,
+                 edge_zero=edge_zero, ldx=ldx, ldy=c, dtype=code)
+    rc = lib.yh_maxpool2d_fwd(C.byref(d), stream())
+    assert rc == 0, rc
+    return y
+
+
+def copy_channels(lib, code, x, y, c, ups=1, x_off=0, y_off=0):
+    N, H, W, ldx = x.shape
+    d = CopyDesc(x=P(x, x_off), y=P(y, y_off), n=N, h=H, w_in=W, c=c, ups=ups, ldx=ldx, ldy=y.shape[3], dtype=code)
+    rc = lib.yh_copy_channels(C.byref(d), stream())
+    assert rc == 0, rc
+    return y
+
+
+def add_channels(lib, code, a, b, c):
+    N, H, W, lda = a.shape
+    y = torch.full((N, H, W, c), 3.0, device=a.device, dtype=a.dtype)
+    d = AddDesc(a=P(a), b=P(b), y=P(y), pixels=N * H * W, c=c, lda=lda, ldb=b.shape[3], ldy=c, dtype=code)
+    rc = lib.yh_add_channels(C.byref(d), stream())
+    assert rc == 0, rc
+    return y
+
+
+def decode(lib, p, na, no, stride, anchor_vec, rows_total=None, row_off=0, want_raw=True):
+    """p: (N,ny,nx,ldp) fp32 head map."""
+    N, ny, nx, ldp = p.shape
+    rows = na * ny * nx
+    rows_total = rows_total or rows
+    io = torch.full((N, rows_total, no), -1.0, device=p.device, dtype=torch.float32)
+    raw = torch.full((N, na, ny, nx, no), -1.0, device=p.device, dtype=torch.float32) if want_raw else None
+    d = DecodeDesc(p=P(p), io=P(io), raw=P(raw), n=N, ny=ny, nx=nx, na=na, no=no, ldp=ldp, rows_total=rows_total,
+                   row_off=row_off, stride=float(stride))
+    for a in range(na):
+        d.anchor_w[a] = float(anchor_vec[a][0])
+        d.anchor_h[a] = float(anchor_vec[a][1])
+    rc = lib.yh_yolo_decode(C.byref(d), stream())
+    assert rc == 0, rc
+    return io, raw

@@ -1,0 +1,179 @@
+"""GPU tier: every HIP kernel against the host emulation of its C-ABI descriptor (torch fp32 math).
+
+Each case builds the same descriptor twice — CUDA tensors for libyolo_hip.so, CPU copies for
+tests/fakelib.py — and compares the outputs.  fp32 mode must agree to fp32 round-off; fp16 mode to the
+rounding of one fp16 store (accumulation is fp32 on both sides).
+"""
+import numpy as np
+import pytest
+import torch
+
+import fakelib
+import ops_harness as oh
+from engine import hiplib
+
+pytestmark = pytest.mark.gpu
+
+F16, F32 = hiplib.YH_F16, hiplib.YH_F32
+
+
+import os
+DRY = bool(os.environ.get('YOLO_TEST_DRY_GPU'))  # vet the test code itself on a CPU-only machine (emulator twice)
+GPU = 'cpu' if DRY else 'cuda'
+
+
+@pytest.fixture(scope='module')
+def libs():
+    if DRY:
+        return fakelib.FakeLib(), fakelib.FakeLib()
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU')
+    return hiplib.load(), fakelib.FakeLib()
+
+
+def _rand(g, *shape, scale=1.0):
+    return (torch.randn(*shape, generator=g) * scale)
+
+
+def _bn(g, c):
+    return (torch.rand(c, generator=g) + 0.5, torch.randn(c, generator=g) * 0.1, torch.randn(c, generator=g) * 0.1,
+            torch.rand(c, generator=g) + 0.5)
+
+
+CONV_CASES = [
+    # N, H, W, cin, cout, k, s, act, res, ups, out_f32, tile, ldx_extra, ldy_extra
+    (2, 16, 16, 64, 128, 1, 1, 1, False, 1, False, 0, 0, 0),
+    (2, 20, 20, 32, 64, 3, 1, 1, False, 1, False, 0, 0, 0),
+    (1, 33, 31, 64, 128, 3, 2, 1, False, 1, False, 0, 0, 0),
+    (3, 19, 19, 128, 255, 1, 1, 0, False, 1, True, 0, 0, 0),     # head: linear, fp32 out, cout 255 -> 256
+    (2, 13, 13, 256, 18, 1, 1, 0, False, 1, True, 0, 0, 0),      # tiny head: cout 18 -> 24
+    (2, 24, 24, 24, 40, 3, 1, 5, False, 1, False, 0, 0, 0),      # cin 24 (K tail), mish
+    (2, 16, 16, 128, 128, 3, 1, 1, True, 1, False, 0, 0, 0),     # residual epilogue
+    (2, 10, 10, 256, 128, 1, 1, 1, False, 2, False, 0, 0, 64),   # 2x upsample into a wider buffer slice
+    (2, 12, 12, 96, 64, 3, 1, 4, False, 1, False, 0, 32, 16),    # reads a slice, writes a slice, h_swish
+    (1, 10, 10, 512, 1024, 3, 1, 1, False, 1, False, 0, 0, 0),   # deep K = 4608
+    (2, 40, 40, 64, 32, 1, 1, 3, False, 1, False, 0, 0, 0),      # cout 32 tile
+    (4, 32, 32, 32, 128, 3, 1, 1, True, 1, False, 1, 0, 0),      # forced tiles
+    (4, 32, 32, 32, 64, 3, 1, 1, True, 1, False, 2, 0, 0),
+    (4, 32, 32, 32, 32, 3, 1, 2, False, 1, False, 3, 0, 0),
+    (4, 32, 32, 32, 64, 3, 2, 1, False, 1, False, 4, 0, 0),
+    (4, 32, 32, 32, 128, 3, 1, 1, False, 1, False, 5, 0, 0),
+]
+
+
+@pytest.mark.parametrize('code', [F32, F16], ids=['fp32', 'fp16'])
+@pytest.mark.parametrize('case', CONV_CASES, ids=lambda c: 'n%d_%dx%d_c%d-%d_k%ds%d_a%d_r%d_u%d_f%d_t%d_x%d_y%d' % c)
+def test_conv_matches_emulation(libs, code, case):
+    lib, fake = libs
+    N, H, W, cin, cout, k, s, act, use_res, ups, out_f32, tile, xe, ye = case
+    g = torch.Generator().manual_seed(hash(case) % (2 ** 31))
+    dt = oh.tdtype(code)
+    cin_phys, cout_phys = oh.round_up(cin, 8), oh.round_up(cout, 8)
+    pad = (k - 1) // 2
+    w = _rand(g, cout, cin, k, k, scale=(cin * k * k) ** -0.5)
+    bn = _bn(g, cout) if act != 0 else None
+    cb = None if bn is not None else _rand(g, cout)
+    x = _rand(g, N, H, W, cin_phys + xe).to(dt)
+    x_off = xe
+    if cin_phys > cin:
+        x[..., x_off + cin:x_off + cin_phys] = 0
+    Ho, Wo = (H + 2 * pad - k) // s + 1, (W + 2 * pad - k) // s + 1
+    res = _rand(g, N, Ho, Wo, cout_phys).to(dt) if use_res else None
+    outs = []
+    for L, dev in ((lib, GPU), (fake, 'cpu')):
+        mv = lambda t: None if t is None else t.to(dev)
+        packed, bias, cin_k, m_pad = oh.pack_conv(L, code, mv(w), mv(cb), None if bn is None else tuple(mv(t) for t in bn),
+                                                  cin_phys=cin_phys)
+        odt = torch.float32 if out_f32 else dt
+        y = torch.full((N, Ho * ups, Wo * ups, cout_phys + ye), 3.0, device=dev, dtype=odt)
+        oh.conv(L, code, mv(x), packed, bias, cin_k, m_pad, cout_phys, k, s, pad, act=act, slope=0.1, res=mv(res), ups=ups,
+                out_f32=out_f32, tile=tile, cin=cin_phys, x_off=x_off, y=y, y_off=ye)
+        if dev == 'cuda':
+            torch.cuda.synchronize()
+        outs.append((y.float().cpu(), packed.float().cpu(), bias.cpu()))
+    (yg, pg, bg), (yc, pc, bc) = outs
+    assert torch.equal(pg, pc) or (pg - pc).abs().max() <= (0 if code == F32 else 1e-3) * pc.abs().max(), 'packed weights differ'
+    np.testing.assert_allclose(bg.numpy(), bc.numpy(), rtol=1e-6, atol=1e-6)
+    if ye:
+        assert torch.equal(yg[..., :ye], torch.full_like(yg[..., :ye], 3.0)), 'kernel wrote outside its channel slice'
+    scale = yc.abs().max().item() + 1e-6
+    tol = 2e-5 if (code == F32) else (2e-4 if out_f32 else 2.5e-3)
+    err = (yg - yc).abs().max().item()
+    assert err <= tol * scale, 'max err %g (scale %g)' % (err, scale)
+
+
+def test_conv_f16_exact_on_small_integers(libs):
+    """Integer-valued operands make every product and partial sum exact: the MFMA path must be bit-exact."""
+    lib, fake = libs
+    g = torch.Generator().manual_seed(3)
+    N, H, W, cin, cout, k = 2, 14, 14, 64, 128, 3
+    w = torch.randint(-2, 3, (cout, cin, k, k), generator=g).float()
+    x = torch.randint(-3, 4, (N, H, W, cin), generator=g).to(torch.float16)
+    cb = torch.randint(-5, 6, (cout,), generator=g).float()
+    ys = []
+    for L, dev in ((lib, GPU), (fake, 'cpu')):
+        packed, bias, cin_k, m_pad = oh.pack_conv(L, F16, w.to(dev), cb.to(dev))
+        ys.append(oh.conv(L, F16, x.to(dev), packed, bias, cin_k, m_pad, cout, k, 1, 1, act=0, out_f32=True).cpu())
+    assert torch.equal(ys[0], ys[1])
+
+
+@pytest.mark.parametrize('code', [F32, F16], ids=['fp32', 'fp16'])
+@pytest.mark.parametrize('shape', [(2, 3, 40, 56, 32, 1), (1, 3, 33, 33, 16, 2), (2, 1, 20, 20, 24, 1)])
+def test_stem_matches_emulation(libs, code, shape):
+    lib, fake = libs
+    N, cin, H, W, cout, s = shape
+    g = torch.Generator().manual_seed(11)
+    x = torch.rand(N, cin, H, W, generator=g)
+    w = _rand(g, cout, cin, 3, 3, scale=0.3)
+    bn = _bn(g, cout)
+    ys = [oh.stem(L, code, x.to(dev), w.to(dev), None, tuple(t.to(dev) for t in bn), stride=s).float().cpu()
+          for L, dev in ((lib, GPU), (fake, 'cpu'))]
+    tol = 1e-5 if code == F32 else 2e-3
+    assert (ys[0] - ys[1]).abs().max().item() <= tol * (ys[1].abs().max().item() + 1e-6)
+
+
+@pytest.mark.parametrize('code', [F32, F16], ids=['fp32', 'fp16'])
+@pytest.mark.parametrize('k,s,H', [(2, 2, 26), (2, 2, 13), (2, 1, 13), (5, 1, 19), (9, 1, 19), (13, 1, 20), (3, 2, 17)])
+def test_maxpool_matches_emulation(libs, code, k, s, H):
+    lib, fake = libs
+    g = torch.Generator().manual_seed(12)
+    x = _rand(g, 2, H, H + 3, 48).to(oh.tdtype(code))
+    ys = [oh.maxpool(L, code, x.to(dev), k, s, c=32, x_off=8).float().cpu() for L, dev in ((lib, GPU), (fake, 'cpu'))]
+    assert torch.equal(ys[0], ys[1])
+
+
+@pytest.mark.parametrize('code', [F32, F16], ids=['fp32', 'fp16'])
+@pytest.mark.parametrize('ups', [1, 2])
+def test_copy_and_add_match_emulation(libs, code, ups):
+    lib, fake = libs
+    g = torch.Generator().manual_seed(13)
+    dt = oh.tdtype(code)
+    x = _rand(g, 2, 9, 11, 40).to(dt)
+    b = _rand(g, 2, 9, 11, 24).to(dt)
+    res = []
+    for L, dev in ((lib, GPU), (fake, 'cpu')):
+        y = torch.full((2, 9 * ups, 11 * ups, 64), 3.0, device=dev, dtype=dt)
+        oh.copy_channels(L, code, x.to(dev), y, c=24, ups=ups, x_off=8, y_off=16)
+        s = oh.add_channels(L, code, x.to(dev), b.to(dev), c=24)
+        res.append((y.float().cpu(), s.float().cpu()))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+
+
+def test_decode_matches_emulation_and_oracle(libs):
+    from oracle import darknet_oracle as oracle
+    lib, fake = libs
+    g = torch.Generator().manual_seed(14)
+    N, ny, nx, na, nc = 2, 7, 5, 3, 4
+    no = nc + 5
+    anchors = np.array([[10., 13.], [16., 30.], [33., 23.]], dtype=np.float32)
+    p = torch.zeros(N, ny, nx, 32)
+    p[..., :na * no] = torch.randn(N, ny, nx, na * no, generator=g)
+    avec = (torch.from_numpy(anchors) / 16.0).numpy()
+    outs = [oh.decode(L, p.to(dev), na, no, 16.0, avec, rows_total=na * ny * nx + 10, row_off=6)
+            for L, dev in ((lib, GPU), (fake, 'cpu'))]
+    (iog, rawg), (ioc, rawc) = [(a.cpu(), b.cpu()) for a, b in outs]
+    assert torch.equal(rawg, rawc)
+    np.testing.assert_allclose(iog.numpy(), ioc.numpy(), rtol=2e-6, atol=2e-5)
+    io_o, raw_o = oracle.yolo_decode(p[..., :na * no].permute(0, 3, 1, 2).contiguous(), anchors, 16.0, nc)
+    np.testing.assert_allclose(iog[:, 6:6 + na * ny * nx].numpy(), io_o.numpy(), rtol=2e-6, atol=2e-5)
+    assert torch.equal(iog[:, :6], torch.full_like(iog[:, :6], -1.0))

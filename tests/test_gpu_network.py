@@ -1,0 +1,126 @@
+"""GPU tier: whole-graph parity of the HIP path (models.Darknet on CUDA -> libyolo_hip.so).
+
+* vs the reference-generated goldens (fp32 engine: boxes within 1e-3 px, conf within 1e-5 — the
+  tolerance BASELINE.json's north star states; fp16 engine: bounded drift + the synthetic mAP@0.5
+  protocol of SURVEY.md §8d, |mAP - 1| <= 0.002);
+* vs the CPU oracle on the same seeded inputs (every tensor, not only the stored rows);
+* size-independent properties at the BASELINE size (608): batch-permutation equivariance and
+  run-to-run determinism.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import synth
+from map_protocol import map50
+from oracle import darknet_oracle as oracle
+from test_oracle_golden import GOLD, build_mirror
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module', autouse=True)
+def _need_gpu():
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU')
+
+
+def _hip_forward(model, x, precision):
+    model.hip_precision = precision
+    with torch.no_grad():
+        out = model(x.cuda())
+    torch.cuda.synchronize()
+    assert model.__dict__['_hip_engine'] is not None, 'HIP engine did not run'
+    return out
+
+
+@pytest.mark.parametrize('name', ['tiny_hand_416', 'yolov3_320', 'yolov4_320', 'yolov3_608'])
+def test_fp32_engine_matches_reference_golden_and_oracle(name, cfg_dir):
+    fx = np.load(os.path.join(GOLD, 'net_%s.npz' % name))
+    rel, size, batch, rs = str(fx['cfg']), int(fx['size']), int(fx['batch']), int(fx['row_stride'])
+    model = build_mirror(cfg_dir, rel, size)
+    x = synth.image_batch(batch, size, seed=0)
+    inf_o, raws_o = oracle.forward(model.module_defs, model.state_dict(), x, fold=True)
+    model.cuda()
+    inf, raws, _ = _hip_forward(model, x, 'fp32')
+    inf = inf.cpu()
+    ref_rows = torch.from_numpy(fx['inf_rows'])
+    d = (inf[:, ::rs] - ref_rows).abs()
+    assert d[..., :4].max().item() <= 1e-3, 'box drift vs reference %g px' % d[..., :4].max().item()
+    assert d[..., 4:].max().item() <= 1e-5, 'conf drift vs reference %g' % d[..., 4:].max().item()
+    do = (inf - inf_o).abs()
+    assert do[..., :4].max().item() <= 1e-3 and do[..., 4:].max().item() <= 1e-5
+    for r, ro in zip(raws, raws_o):
+        assert r.shape == ro.shape
+        assert (r.cpu() - ro).abs().max().item() <= 5e-4
+
+
+@pytest.mark.parametrize('name', ['tiny_hand_416', 'yolov3_320', 'yolov4_320'])
+def test_fp16_engine_bounded_drift(name, cfg_dir):
+    fx = np.load(os.path.join(GOLD, 'net_%s.npz' % name))
+    rel, size, batch, rs = str(fx['cfg']), int(fx['size']), int(fx['batch']), int(fx['row_stride'])
+    model = build_mirror(cfg_dir, rel, size).cuda()
+    x = synth.image_batch(batch, size, seed=0)
+    inf, raws, _ = _hip_forward(model, x, 'fp16')
+    d = (inf.cpu()[:, ::rs] - torch.from_numpy(fx['inf_rows'])).abs()
+    assert d[..., :4].max().item() <= 0.5, 'fp16 box drift %g px' % d[..., :4].max().item()
+    assert d[..., 4:].max().item() <= 5e-3, 'fp16 conf drift %g' % d[..., 4:].max().item()
+
+
+@pytest.mark.parametrize('rel,size,batch', [('yolov3tiny/yolov3-tiny-hand.cfg', 416, 4), ('yolov3/yolov3.cfg', 320, 4)])
+@pytest.mark.parametrize('precision', ['fp32', 'fp16'])
+def test_synthetic_map_protocol(rel, size, batch, precision, cfg_dir):
+    """mAP@0.5 of the HIP path against the CPU fp32 oracle's detections (must stay within 0.2 pt of 1.0)."""
+    from utils.utils import non_max_suppression
+    model = build_mirror(cfg_dir, rel, size)
+    state = synth.trained_like_heads_(model.state_dict(), model.module_defs)
+    model.load_state_dict(state)
+    x = synth.image_batch(batch, size, seed=21)
+    inf_o, _ = oracle.forward(model.module_defs, model.state_dict(), x, fold=True)
+    conf = float(torch.quantile(inf_o[..., 4].flatten(), 0.985))  # ~1.5 % of the cells become ground truth
+    gt = oracle.non_max_suppression(inf_o.numpy(), conf, 0.6, multi_label=False)
+    gt = [None if g is None else torch.from_numpy(g) for g in gt]
+    assert sum(0 if g is None else len(g) for g in gt) >= 20 * batch
+    model.cuda()
+    inf, _, _ = _hip_forward(model, x, precision)
+    det = non_max_suppression(inf, conf * 0.9, 0.6, multi_label=False)   # HIP NMS (CUDA tensor)
+    score = map50(gt, det)
+    assert score >= 0.998, 'synthetic mAP@0.5 = %.4f' % score
+
+
+def test_properties_at_baseline_size(cfg_dir):
+    """YOLOv3-608 fp16: determinism and batch-permutation equivariance (no oracle needed at this size)."""
+    model = build_mirror(cfg_dir, 'yolov3/yolov3.cfg', 608).cuda()
+    x = synth.image_batch(4, 608, seed=31)
+    a = _hip_forward(model, x, 'fp16')[0].clone()
+    b = _hip_forward(model, x, 'fp16')[0].clone()
+    assert torch.equal(a, b), 'forward is not deterministic'
+    perm = torch.tensor([2, 0, 3, 1])
+    c = _hip_forward(model, x[perm], 'fp16')[0]
+    assert torch.equal(c, a[perm.cuda()]), 'batch entries influence each other'
+    assert torch.isfinite(a).all()
+    assert tuple(a.shape) == (4, 22743, 85)
+
+
+def test_cuda_path_fails_loudly_without_library(cfg_dir, monkeypatch):
+    from engine import hiplib
+    model = build_mirror(cfg_dir, 'yolov3tiny/yolov3-tiny-hand.cfg', 416).cuda()
+    monkeypatch.setattr(hiplib, '_lib', None)
+    monkeypatch.setattr(hiplib, 'LIB_PATH', '/nonexistent/libyolo_hip.so')
+    with pytest.raises(hiplib.HipLibraryError):
+        model(synth.image_batch(1, 416).cuda())
+
+
+def test_train_mode_and_weight_updates(cfg_dir):
+    """After an in-place weight update the next eval forward must use the new weights."""
+    model = build_mirror(cfg_dir, 'yolov3tiny/yolov3-tiny-hand.cfg', 416).cuda()
+    x = synth.image_batch(2, 416, seed=41)
+    a = _hip_forward(model, x, 'fp32')[0].clone()
+    with torch.no_grad():
+        model.module_list[12][0].weight.mul_(1.5)
+    b = _hip_forward(model, x, 'fp32')[0].clone()
+    inf_o, _ = oracle.forward(model.module_defs, {k: v.cpu() for k, v in model.state_dict().items()}, x, fold=True)
+    assert (a - b).abs().max().item() > 1e-3
+    assert (b.cpu() - inf_o)[..., :4].abs().max().item() <= 1e-3

@@ -1,0 +1,116 @@
+"""CPU tier: the graph lowering (engine/plan.py) replayed through the host emulation of the C ABI.
+
+Validates fusion decisions, zero-copy concat placement, channel padding maps, the packed weight layout
+and plan replay against (a) the reference-generated goldens and (b) the eager mirror, without a GPU.
+The HIP kernels themselves are checked on the GPU tier (tests/test_gpu_*.py).
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import fakelib
+import synth
+from engine.plan import DarknetEngine
+from test_oracle_golden import GOLD, build_mirror
+
+CASES = ['tiny_hand_416', 'yolov3_320', 'yolov4_320']
+
+
+@pytest.mark.parametrize('name', CASES)
+@pytest.mark.parametrize('prec', ['fp32', 'fp16'])
+def test_lowered_network_matches_reference_golden(name, prec, cfg_dir):
+    fx = np.load(os.path.join(GOLD, 'net_%s.npz' % name))
+    rel, size, batch, rs = str(fx['cfg']), int(fx['size']), int(fx['batch']), int(fx['row_stride'])
+    model = build_mirror(cfg_dir, rel, size)
+    x = synth.image_batch(batch, size, seed=0)
+    eng = DarknetEngine(model, precision=prec, lib=fakelib.FakeLib())
+    io, raws, feats = eng(x)
+    assert feats == [] and tuple(io.shape) == tuple(fx['inf_shape'])
+    d = (io[:, ::rs] - torch.from_numpy(fx['inf_rows'])).abs()
+    box_tol, conf_tol = (1e-3, 1e-5) if prec == 'fp32' else (0.25, 2e-3)
+    assert d[..., :4].max().item() <= box_tol and d[..., 4:].max().item() <= conf_tol
+    with torch.no_grad():
+        _, raws_ref, _ = model(x)  # eager mirror == reference (test_oracle_golden)
+    for r, rr in zip(raws, raws_ref):
+        assert r.shape == rr.shape and r.is_contiguous()
+        assert (r - rr).abs().max().item() <= (2e-4 if prec == 'fp32' else 0.05)
+    plan = next(iter(eng._plans.values()))
+    kinds = {''.join(c for c in what if not c.isdigit()) for what, _ in plan['ops']}
+    assert kinds <= {'stem', 'conv', 'pool', 'yolo'}, 'shortcut/route/upsample must all be fused: %s' % kinds
+
+
+def _odd_cfg():
+    """Widths that are not multiples of 8, a tensor routed twice, an unfusable shortcut, a lone upsample."""
+    net = {'type': 'net', 'width': 64, 'height': 64, 'channels': 3}
+    conv = lambda f, k, s=1, act='leaky', bn=1: {'type': 'convolutional', 'batch_normalize': bn, 'filters': f, 'size': k,
+                                                 'stride': s, 'pad': 1, 'activation': act}
+    anchors = np.array([[10., 13.], [16., 30.], [33., 23.]])
+    return [net,
+            conv(13, 3),                      # 0  stem, 13 channels -> padded to 16
+            conv(21, 3, 2, 'mish'),           # 1
+            conv(10, 1, 1, 'relu6'),          # 2
+            {'type': 'route', 'layers': [-1, -2]},   # 3  concat 10 + 21 (padded segments)
+            conv(21, 3, 1, 'h_swish'),        # 4
+            {'type': 'shortcut', 'from': [-4], 'activation': 'linear'},   # 5  fused into conv 4
+            conv(21, 1, 1, 'relu'),           # 6  routed below -> its shortcut cannot be fused
+            {'type': 'shortcut', 'from': [-2], 'activation': 'linear'},   # 7  explicit add
+            {'type': 'route', 'layers': [6, 3]},     # 8  conv 6 and the earlier concat (nested -> copy)
+            {'type': 'maxpool', 'size': 2, 'stride': 2},   # 9
+            {'type': 'upsample', 'stride': 2},       # 10 lone upsample (input is a pool)
+            {'type': 'route', 'layers': [-1, 7]},    # 11
+            {'type': 'maxpool', 'size': 5, 'stride': 1},   # 12
+            conv(24, 1, 1, 'linear', 0),      # 13 head (3 * (3 + 5))
+            {'type': 'yolo', 'mask': [0, 1, 2], 'anchors': anchors, 'classes': 3, 'num': 3}]
+
+
+@pytest.mark.parametrize('prec', ['fp32', 'fp16'])
+def test_odd_widths_and_unfused_paths(prec):
+    import models
+    torch.manual_seed(5)
+    model = models.Darknet(_odd_cfg(), (64, 64))
+    model.load_state_dict(synth.randomize_bn_(model.state_dict(), seed=6))
+    model.eval()
+    x = synth.image_batch(2, 64, seed=7)
+    with torch.no_grad():
+        ref, raws_ref, _ = model(x)
+    eng = DarknetEngine(model, precision=prec, lib=fakelib.FakeLib())
+    io, raws, _ = eng(x)
+    tol = 2e-4 if prec == 'fp32' else 0.08
+    assert (io - ref).abs().max().item() <= tol
+    assert (raws[0] - raws_ref[0]).abs().max().item() <= tol
+    plan = next(iter(eng._plans.values()))
+    kinds = [''.join(c for c in what if not c.isdigit()) for what, _ in plan['ops']]
+    assert 'add' in kinds and 'ups' in kinds and 'cat' in kinds  # the non-fused forms were exercised
+
+
+def test_weight_edits_are_picked_up():
+    """In-place parameter updates (optimizer step, prune script) must reach the packed weights."""
+    import models
+    torch.manual_seed(5)
+    model = models.Darknet(_odd_cfg(), (64, 64)).eval()
+    x = synth.image_batch(1, 64, seed=8)
+    eng = DarknetEngine(model, precision='fp32', lib=fakelib.FakeLib())
+    a = eng(x)[0].clone()
+    with torch.no_grad():
+        model.module_list[4][0].weight.mul_(0.5)          # version bump
+        model.module_list[6][1].bias.data = model.module_list[6][1].bias.data + 1.0   # rebinding .data
+    b = eng(x)[0]
+    with torch.no_grad():
+        ref = model(x)[0]
+    assert (a - b).abs().max().item() > 1e-3
+    assert (b - ref).abs().max().item() <= 2e-4
+
+
+def test_batch_and_shape_change_build_new_plans():
+    import models
+    torch.manual_seed(5)
+    model = models.Darknet(_odd_cfg(), (64, 64)).eval()
+    eng = DarknetEngine(model, precision='fp32', lib=fakelib.FakeLib())
+    for n, s in ((1, 64), (3, 96), (1, 64)):
+        x = synth.image_batch(n, s, seed=9)
+        with torch.no_grad():
+            ref = model(x)[0]
+        assert (eng(x)[0] - ref).abs().max().item() <= 2e-4
+    assert len(eng._plans) == 2

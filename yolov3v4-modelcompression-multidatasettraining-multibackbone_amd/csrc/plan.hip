@@ -60,6 +60,12 @@ int launch(int kind, const AnyDesc& d, void* stream) {
 struct yh_plan {
     std::vector<Op> ops;
     std::vector<void*> slots;
+    // optional per-op HIP-event timing (bench.py roofline leg): events[2*i], events[2*i+1] bracket op i
+    bool timing = false;
+    std::vector<hipEvent_t> events;
+    ~yh_plan() {
+        for (hipEvent_t e : events) (void)hipEventDestroy(e);
+    }
 };
 
 extern "C" int yh_abi_version(void) { return YH_ABI_VERSION; }
@@ -136,8 +142,39 @@ extern "C" int yh_plan_run_range(yh_plan* p, int first, int last, void* stream) 
             void* v = (char*)base + f.byte_offset;
             memcpy((char*)&d + f.field_offset, &v, sizeof(void*));
         }
+        if (p->timing) (void)hipEventRecord(p->events[2 * i], (hipStream_t)stream);
         const int rc = launch(op.kind, d, stream);
+        if (p->timing) (void)hipEventRecord(p->events[2 * i + 1], (hipStream_t)stream);
         if (rc != YH_OK) return rc;
+    }
+    return YH_OK;
+}
+
+extern "C" int yh_plan_set_timing(yh_plan* p, int enable) {
+    if (!p) return YH_EINVAL;
+    if (enable && p->events.size() < 2 * p->ops.size()) {
+        try {
+            p->events.reserve(2 * p->ops.size());
+        } catch (...) {
+            return YH_ENOMEM;
+        }
+        while (p->events.size() < 2 * p->ops.size()) {
+            hipEvent_t e;
+            const hipError_t rc = hipEventCreate(&e);
+            if (rc != hipSuccess) return (int)rc;
+            p->events.push_back(e);
+        }
+    }
+    p->timing = enable != 0;
+    return YH_OK;
+}
+
+extern "C" int yh_plan_get_timings(yh_plan* p, float* ms_out, int n) {
+    if (!p || !ms_out) return YH_EINVAL;
+    if (n != (int)p->ops.size() || p->events.size() < 2 * p->ops.size()) return YH_ERANGE;
+    for (int i = 0; i < n; ++i) {
+        const hipError_t rc = hipEventElapsedTime(&ms_out[i], p->events[2 * i], p->events[2 * i + 1]);
+        if (rc != hipSuccess) return (int)rc;
     }
     return YH_OK;
 }

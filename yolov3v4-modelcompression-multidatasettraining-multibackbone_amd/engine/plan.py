@@ -202,6 +202,14 @@ class DarknetEngine:
                     if any((s.H, s.W) != (srcs[0].H, srcs[0].W) for s in srcs):
                         raise ValueError('route %d joins tensors of different spatial size' % i)
                     v = Value('concat', sum(s.C for s in srcs), srcs[0].H, srcs[0].W, block=i, srcs=srcs)
+                    # physical layout is fixed here (later pool/copy/add values inherit it): every source
+                    # keeps its own padded span, logical channels map through the per-source segments
+                    v.segs, v.offsets, off = [], [], 0
+                    for s in srcs:
+                        v.offsets.append(off)
+                        v.segs.extend((off + st, ln) for st, ln in s.segs)
+                        off += s.c_phys
+                    v.c_phys = off
                     values.append(v)
                     cur = v
                 elif getattr(module, 'groups', False):
@@ -251,9 +259,9 @@ class DarknetEngine:
         for v in values:
             if v.kind != 'concat':
                 continue
-            segs, off, seen = [], 0, set()
+            seen = set()
             v.parts = []
-            for s in v.srcs:
+            for s, off in zip(v.srcs, v.offsets):
                 if s.kind == 'input':
                     raise NotImplementedError('HIP engine: route over the network input')
                 inplace = (s.kind in ('conv', 'pool', 'copy', 'add') and s.parent is None and id(s) not in seen
@@ -262,9 +270,6 @@ class DarknetEngine:
                     s.parent, s.parent_off = v, off
                 seen.add(id(s))
                 v.parts.append((s, off, inplace))
-                segs.extend((off + st, ln) for st, ln in s.segs)
-                off += s.c_phys
-            v.segs, v.c_phys = segs, off
 
     # ---------------------------------------------------------------------------------- weights
     def _source_tensors(self):
