@@ -1,0 +1,230 @@
+#!/usr/bin/env python3
+"""Benchmark of the Darknet hot path on MI355X: YOLOv3-608 fp16 detection (BASELINE.json configs[1]).
+
+    python bench.py --gpus N --steps K --warmup W
+
+One *step* = one pass of the hot path over one batch of synthetic 608x608 frames already resident in
+HBM: Darknet forward (75 fused conv blocks, 23 residual adds, 2 routes/upsamples, 3-scale YOLO decode)
+through libyolo_hip.so + NMS at detect.py's settings (conf 0.3, iou 0.6, best class).  Weights are
+random-init YOLOv3 with non-trivial BN statistics (no network access for checkpoints).
+
+N > 1 (launched by torch.distributed.run, one process per GPU): inference does not exchange data, so
+every rank runs the same per-GPU batch ("replicas only", weak scaling); ranks are only synchronised by
+the barrier that brackets the timed region, and the slowest rank's time is used.
+
+Rank 0 prints ONE JSON line.  Besides the driver contract it carries
+  roofline      the dominant kernel (the MFMA implicit-GEMM conv instantiation with the largest total
+                time), algorithmic conv FLOPs of the layers it ran / its summed duration measured with HIP
+                events on the launch stream (yh_plan_set_timing), against the 2.5 PFLOP/s fp16 dense peak;
+  roofline_net  whole-network conv FLOPs/s from the un-instrumented timed region;
+  cpu_baseline  the CPU oracle (torch fp32 restatement of the reference path) timed on this host's cores
+                on a bounded sample of the same workload (N = 1 only).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.join(REPO, 'yolov3v4-modelcompression-multidatasettraining-multibackbone_amd')
+for p in (PKG, REPO):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch  # noqa: E402
+
+PEAK_TFLOPS = {'fp16': 2500.0, 'fp32': 157.3}  # dense MFMA peaks, MI355X_MICROARCH.md
+TILE_NAMES = {1: '128x128', 2: '64x256', 3: '32x256', 4: '64x128', 5: '128x64'}
+
+
+def build_model(cfg, size, precision, device):
+    import models
+    torch.manual_seed(0)
+    model = models.Darknet(cfg, (size, size))
+    g = torch.Generator().manual_seed(1)
+    state = model.state_dict()
+    for k, v in state.items():
+        if k.endswith('running_var') or k.endswith('BatchNorm2d.weight'):
+            v.copy_(torch.rand(v.shape, generator=g) + 0.5)
+        elif k.endswith('running_mean') or k.endswith('BatchNorm2d.bias'):
+            v.copy_(torch.randn(v.shape, generator=g) * 0.1)
+    model.load_state_dict(state)
+    model.hip_precision = precision
+    return model.to(device).eval()
+
+
+def conv_flops(plan):
+    """Algorithmic FLOPs (2 x MACs on logical channels) of every conv op of a built plan, by op index."""
+    flops = {}
+    values = {('conv%d' % v.block if v.src.kind != 'input' else 'stem%d' % v.block): v
+              for v in plan['values'] if v.kind == 'conv'}
+    for idx, (what, desc) in enumerate(plan['ops']):
+        v = values.get(what)
+        if v is not None:
+            flops[idx] = 2.0 * plan['N'] * v.Ho * v.Wo * v.C * v.k * v.k * v.src.C
+    return flops
+
+
+def roofline_leg(model, x, steps, precision):
+    from engine import hiplib
+    eng = model.__dict__['_hip_engine']
+    plan = eng._plans[tuple(x.shape)]
+    lib, handle = eng.lib, plan['handle']
+    n_ops = lib.yh_plan_num_ops(handle)
+    hiplib.check(lib.yh_plan_set_timing(handle, 1), 'set_timing')
+    buf = (C.c_float * n_ops)()
+    total = [0.0] * n_ops
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        with torch.no_grad():
+            model(x)
+        torch.cuda.synchronize()
+        hiplib.check(lib.yh_plan_get_timings(handle, buf, n_ops), 'get_timings')
+        for i in range(n_ops):
+            total[i] += buf[i]
+    wall = (time.perf_counter() - t0) / steps
+    hiplib.check(lib.yh_plan_set_timing(handle, 0), 'set_timing')
+    flops = conv_flops(plan)
+    groups = {}
+    for idx, (what, desc) in enumerate(plan['ops']):
+        ms = total[idx] / steps
+        if isinstance(desc, hiplib.ConvDesc):
+            name = 'conv_igemm_%s_%s' % (precision, TILE_NAMES[lib.yh_conv2d_tile(C.byref(desc))])
+        else:
+            name = ''.join(c for c in what if not c.isdigit())
+        g = groups.setdefault(name, dict(ms=0.0, flops=0.0, launches=0))
+        g['ms'] += ms
+        g['flops'] += flops.get(idx, 0.0)
+        g['launches'] += 1
+    dom_name = max((n for n in groups if n.startswith('conv_igemm')), key=lambda n: groups[n]['ms'])
+    dom = groups[dom_name]
+    achieved = dom['flops'] / (dom['ms'] * 1e-3) / 1e12
+    peak = PEAK_TFLOPS[precision]
+    breakdown = {n: dict(ms=round(g['ms'], 4), launches=g['launches'],
+                         tflops=round(g['flops'] / (g['ms'] * 1e-3) / 1e12, 1) if g['flops'] else None)
+                 for n, g in sorted(groups.items(), key=lambda kv: -kv[1]['ms'])}
+    return dict(bound='mfma', kernel=dom_name, achieved=round(achieved, 2), peak=peak, unit='TFLOP/s',
+                frac=round(achieved / peak, 4), traffic=None, launches_per_step=dom['launches'],
+                avg_launch_ms=round(dom['ms'] / dom['launches'], 5),
+                gflop_per_launch=round(dom['flops'] / dom['launches'] / 1e9, 3),
+                gpu_ms_per_step_all_kernels=round(sum(g['ms'] for g in groups.values()), 4),
+                instrumented_ms_per_step=round(wall * 1e3, 4), kernels=breakdown)
+
+
+def cpu_baseline(cfg, size, budget_s):
+    """The oracle (CPU port of the reference path) on this host: YOLOv3-608, batch 1, fp32, BN folded."""
+    import models
+    from oracle import darknet_oracle as oracle
+    torch.manual_seed(0)
+    m = models.Darknet(cfg, (size, size)).eval()
+    state = m.state_dict()
+    x = torch.rand(1, 3, size, size)
+    torch.set_num_threads(os.cpu_count() or 1)
+    with torch.no_grad():
+        oracle.forward(m.module_defs, state, x)  # warm-up (page-in, thread pool)
+        n, t0 = 0, time.perf_counter()
+        while True:
+            oracle.forward(m.module_defs, state, x)
+            n += 1
+            dt = time.perf_counter() - t0
+            if dt >= budget_s or n >= 64:
+                break
+    return dict(value=round(n / dt, 3), unit='images/s', cores=torch.get_num_threads(), kind='port',
+                sample='%d images of YOLOv3-%d, batch 1, fp32, oracle.forward (BN folded), %.1f s' % (n, size, dt))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--batch', type=int, default=32, help='frames per GPU per step')
+    ap.add_argument('--size', type=int, default=608)
+    ap.add_argument('--precision', default='fp16', choices=['fp16', 'fp32'])
+    ap.add_argument('--cfg', default=os.path.join(PKG, 'cfg', 'yolov3', 'yolov3.cfg'))
+    ap.add_argument('--no-nms', action='store_true')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-seconds', type=float, default=12.0)
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit('launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)' % (args.gpus, world))
+    assert torch.cuda.is_available(), 'bench.py needs a GPU'
+    torch.cuda.set_device(local_rank)
+    device = torch.device('cuda', local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=device)
+
+    from utils.utils import non_max_suppression
+    model = build_model(args.cfg, args.size, args.precision, device)
+    g = torch.Generator().manual_seed(100 + rank)
+    x = torch.rand(args.batch, 3, args.size, args.size, generator=g).to(device)  # resident in HBM before timing
+
+    def step():
+        with torch.no_grad():
+            inf, _, _ = model(x)
+        if not args.no_nms:
+            non_max_suppression(inf, conf_thres=0.3, iou_thres=0.6, multi_label=False)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        images = world * args.batch * args.steps
+        value = images / elapsed
+        flops = conv_flops(model.__dict__['_hip_engine']._plans[tuple(x.shape)])
+        gflop_img = sum(flops.values()) / args.batch / 1e9
+        peak = PEAK_TFLOPS[args.precision]
+        net_tflops = value / world * gflop_img / 1e3
+        out = {
+            'metric': 'images/sec YOLOv3-608 detect fp16 (forward + NMS)', 'value': round(value, 2), 'unit': 'images/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(elapsed / args.steps * 1e3, 4),
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f16' if args.precision == 'fp16' else 'f32', 'data': 'synthetic',
+            'config': {'workload': 'YOLOv3 Darknet-53 %d COCO (80 classes) %s inference, batch %d/GPU, %s'
+                                   % (args.size, args.precision, args.batch,
+                                      'forward only' if args.no_nms else 'forward + NMS conf 0.3 iou 0.6'),
+                       'global_batch': world * args.batch, 'parallelism': 'replicas x%d' % world,
+                       'gflop_per_image': round(gflop_img, 3)},
+            'roofline_net': {'bound': 'mfma', 'achieved': round(net_tflops, 2), 'peak': peak, 'unit': 'TFLOP/s',
+                             'frac': round(net_tflops / peak, 4), 'per': 'GPU, whole step incl. NMS and host gaps'},
+        }
+        out['roofline'] = roofline_leg(model, x, max(3, min(args.steps, 10)), args.precision)
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(args.cfg, args.size, args.cpu_seconds)
+        else:
+            out['cpu_baseline'] = None
+        print(json.dumps(out))
+    barrier()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

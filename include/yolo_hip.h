@@ -98,6 +98,9 @@ typedef struct yh_conv_desc {
 } yh_conv_desc;
 
 int yh_conv2d_fwd(const yh_conv_desc* d, void* stream);
+/* Tile configuration yh_conv2d_fwd will use for this descriptor (1 = 128x128, 2 = 64x256, 3 = 32x256,
+ * 4 = 64x128, 5 = 128x64, channels x pixels): lets a profiler attribute time to kernel instantiations. */
+int yh_conv2d_tile(const yh_conv_desc* d);
 
 /* First-layer convolution straight from the caller's NCHW fp32 image batch (cin <= 4): fuses the
  * NCHW->NHWC relayout and the cast.  Replaces the first Sequential of models.py:92-113 as fed by

@@ -309,16 +309,19 @@ static int launch(const ConvArgs& a0, hipStream_t stream) {
     return check_launch();
 }
 
+// tile codes: 1 = 128x128, 2 = 64x256, 3 = 32x256, 4 = 64x128, 5 = 128x64 (channels x pixels)
+static int pick_tile(int cout, long P) {
+    const int c = cout;
+    const int w128 = ((c + 127) / 128) * 128, w64 = ((c + 63) / 64) * 64, w32 = ((c + 31) / 32) * 32;
+    int tile = (w128 <= w64 && w128 <= w32) ? 1 : (w64 <= w32 ? 2 : 3);
+    // few pixels (deep 19x19 layers at small batch): prefer narrower pixel tiles for occupancy
+    if (tile == 1 && ((P + 127) / 128) * ((c + 127) / 128) < 256) tile = 5;
+    if (tile == 2 && ((P + 255) / 256) * ((c + 63) / 64) < 256) tile = 4;
+    return tile;
+}
+
 template <typename T, typename OutT> static int dispatch_tile(const ConvArgs& a, int tile, hipStream_t s) {
-    // tile codes: 1 = 128x128, 2 = 64x256, 3 = 32x256, 4 = 64x128, 5 = 128x64
-    if (tile == 0) {
-        const int c = a.Cout;
-        const int w128 = ((c + 127) / 128) * 128, w64 = ((c + 63) / 64) * 64, w32 = ((c + 31) / 32) * 32;
-        tile = (w128 <= w64 && w128 <= w32) ? 1 : (w64 <= w32 ? 2 : 3);
-        // few pixels (deep 19x19 layers at small batch): prefer narrower pixel tiles for occupancy
-        if (tile == 1 && ((a.P + 127) / 128) * ((c + 127) / 128) < 256) tile = 5;
-        if (tile == 2 && ((a.P + 255) / 256) * ((c + 63) / 64) < 256) tile = 4;
-    }
+    if (tile == 0) tile = pick_tile(a.Cout, a.P);
     switch (tile) {
         case 1: return launch<T, OutT, 128, 128, 2, 2>(a, s);
         case 2: return launch<T, OutT, 64, 256, 1, 4>(a, s);
@@ -330,6 +333,12 @@ template <typename T, typename OutT> static int dispatch_tile(const ConvArgs& a,
 }
 
 }  // namespace yh
+
+extern "C" int yh_conv2d_tile(const yh_conv_desc* d) {
+    if (!d) return YH_EINVAL;
+    if (d->tile != 0) return d->tile;
+    return yh::pick_tile(d->cout, (long)d->n * d->ho * d->wo);
+}
 
 extern "C" int yh_conv2d_fwd(const yh_conv_desc* d, void* stream) {
     using namespace yh;

@@ -67,6 +67,7 @@ _SIGNATURES = {
     'yh_conv_pack_weights': (C.c_int, [C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _f32, _vp, C.c_int, C.c_int, C.c_int,
                                        C.c_int, C.c_int, C.c_int, _vp, _vp, _vp]),
     'yh_conv2d_fwd': (C.c_int, [C.POINTER(ConvDesc), _vp]),
+    'yh_conv2d_tile': (C.c_int, [C.POINTER(ConvDesc)]),
     'yh_stem_pack_weights': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _f32, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                        _vp, _vp, _vp]),
     'yh_conv2d_stem_fwd': (C.c_int, [C.POINTER(StemDesc), _vp]),

@@ -442,6 +442,27 @@ class Darknet(nn.Module):
     def info(self, verbose=False):
         torch_utils.model_info(self, verbose)
 
+    # -- keep the packed-weight cache honest ---------------------------------------------------------
+    def hip_refresh(self):
+        """Drop the HIP engine; the next CUDA eval forward re-packs from the live parameters.
+
+        The engine already notices optimizer steps and ``param.data = ...`` rebinding (tensor version /
+        address); call this after editing weights through ``param.data`` views in place."""
+        self.__dict__['_hip_engine'] = None
+
+    def _apply(self, fn, *args, **kwargs):
+        self.__dict__['_hip_engine'] = None
+        return super()._apply(fn, *args, **kwargs)
+
+    def load_state_dict(self, *args, **kwargs):
+        self.__dict__['_hip_engine'] = None
+        return super().load_state_dict(*args, **kwargs)
+
+    def train(self, mode=True):
+        if mode:
+            self.__dict__['_hip_engine'] = None
+        return super().train(mode)
+
     def __deepcopy__(self, memo):
         # the engine holds raw device pointers and ctypes handles: never copy it with the module
         cls = self.__class__
