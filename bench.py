@@ -121,7 +121,9 @@ def cpu_baseline(cfg, size, budget_s):
     m = models.Darknet(cfg, (size, size)).eval()
     state = m.state_dict()
     x = torch.rand(1, 3, size, size)
-    torch.set_num_threads(os.cpu_count() or 1)
+    # one thread per physical core up to 64: batch-1 oneDNN convolutions get slower, not faster, when every
+    # SMT sibling of a 2-socket host joins in (measured: 256 threads -> 80 s/image on the GPU node)
+    torch.set_num_threads(max(1, min((os.cpu_count() or 2) // 2, 64)))
     with torch.no_grad():
         oracle.forward(m.module_defs, state, x)  # warm-up (page-in, thread pool)
         n, t0 = 0, time.perf_counter()

@@ -92,7 +92,8 @@ def test_conv_matches_emulation(libs, code, case):
             torch.cuda.synchronize()
         outs.append((y.float().cpu(), packed.float().cpu(), bias.cpu()))
     (yg, pg, bg), (yc, pc, bc) = outs
-    assert torch.equal(pg, pc) or (pg - pc).abs().max() <= (0 if code == F32 else 1e-3) * pc.abs().max(), 'packed weights differ'
+    # BN folding uses the device's sqrt/divide: allow 2 ulp in fp32, one fp16 rounding in fp16
+    assert (pg - pc).abs().max() <= (3e-7 if code == F32 else 1e-3) * pc.abs().max(), 'packed weights differ'
     np.testing.assert_allclose(bg.numpy(), bc.numpy(), rtol=1e-6, atol=1e-6)
     if ye:
         assert torch.equal(yg[..., :ye], torch.full_like(yg[..., :ye], 3.0)), 'kernel wrote outside its channel slice'

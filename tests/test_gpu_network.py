@@ -87,7 +87,10 @@ def test_synthetic_map_protocol(rel, size, batch, precision, cfg_dir):
     inf, _, _ = _hip_forward(model, x, precision)
     det = non_max_suppression(inf, conf * 0.9, 0.6, multi_label=False)   # HIP NMS (CUDA tensor)
     score = map50(gt, det)
-    assert score >= 0.998, 'synthetic mAP@0.5 = %.4f' % score
+    # the reference's 101-point AP (utils.py:243-246) scores a perfect detector 0.995, not 1.0: compare with
+    # the score the reference detections obtain against themselves; north star: within 0.2 pt
+    perfect = map50(gt, gt)
+    assert abs(score - perfect) <= 0.002, 'synthetic mAP@0.5 = %.4f vs %.4f for the reference itself' % (score, perfect)
 
 
 def test_properties_at_baseline_size(cfg_dir):

@@ -23,6 +23,7 @@ The reference executes the graph with a per-layer Python loop over ``nn.Module``
 Nothing here computes activations with torch: torch supplies device memory and the stream.
 """
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -118,6 +119,7 @@ class DarknetEngine:
         self.kstep = 32 if precision == 'fp16' else 16
         self.want_raw = True
         self.return_features = False
+        self.force_tile = int(os.environ.get('YOLO_HIP_TILE', '0'))  # A/B profiling knob; 0 = library heuristic
         self._plans = {}
         self._packed = {}  # block index -> dict(w=, b=, ...)
         self._signature = None
@@ -391,7 +393,7 @@ class DarknetEngine:
                                  n=N, h=s.H, w_in=s.W, cin=s.c_phys, ho=v.Ho, wo=v.Wo, cout=v.c_phys,
                                  kh=v.k, kw=v.k, stride=v.stride, pad=v.pad, ldx=s.ld,
                                  ldr=0 if v.res is None else v.res.ld, ldy=v.ld, cin_k=pk['cin_k'], m_pad=pk['m_pad'],
-                                 act=v.act, slope=v.slope, ups=v.ups, out_f32=1 if v.fp32 else 0, dtype=self.code, tile=0)
+                                 act=v.act, slope=v.slope, ups=v.ups, out_f32=1 if v.fp32 else 0, dtype=self.code, tile=self.force_tile)
                     add(d, 'conv%d' % v.block)
             elif v.kind == 'pool':
                 s = v.src
