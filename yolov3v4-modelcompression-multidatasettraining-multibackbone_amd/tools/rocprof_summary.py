@@ -1,0 +1,52 @@
+#!/usr/bin/env python3
+"""Text summaries of rocprofv3 result databases (rocpd sqlite): kernel stats and PMC sums per kernel.
+
+    python tools/rocprof_summary.py stats  <results.db>              # like --stats: calls, total, avg, %
+    python tools/rocprof_summary.py pmc    <results.db> [<more.db>]  # per kernel: sum / per-dispatch mean of every counter
+"""
+import sqlite3
+import sys
+
+
+def short(name):
+    import re
+    m = re.match(r'_ZN2yh17conv_igemm_kernelI(DF16_|f)(DF16_|f)Li(\d+)ELi(\d+)E', name)
+    if m:
+        return 'conv_igemm<%s,%s,%sx%s>' % ('f16' if m.group(1) != 'f' else 'f32', 'f16' if m.group(2) != 'f' else 'f32',
+                                           m.group(3), m.group(4))
+    m = re.match(r'_ZN2yh(\d+)([a-z_0-9]+)', name)
+    if m:
+        return m.group(2)[:int(m.group(1))]
+    return name.split('(')[0][:60]
+
+
+def stats(db):
+    c = sqlite3.connect(db)
+    rows = list(c.execute('select name, total_calls, total_duration, average, percentage from top_kernels'))
+    print('%-44s %8s %14s %12s %7s' % ('kernel', 'calls', 'total_us', 'avg_us', '%'))
+    for name, calls, total, avg, pct in rows:
+        print('%-44s %8d %14.1f %12.3f %6.2f%%' % (short(name), calls, total / 1e3, avg / 1e3, pct))
+
+
+def pmc(dbs):
+    agg = {}
+    for db in dbs:
+        c = sqlite3.connect(db)
+        q = 'select kernel_name, counter_name, sum(value), count(*), sum(duration) from counters_collection group by kernel_name, counter_name'
+        for k, cn, s, n, dur in c.execute(q):
+            agg.setdefault(short(k), {})[cn] = (s, n, dur)
+    names = sorted({cn for v in agg.values() for cn in v})
+    for k, v in sorted(agg.items(), key=lambda kv: -max(x[2] for x in kv[1].values())):
+        n = max(x[1] for x in v.values())
+        print('%s  (dispatches %d)' % (k, n))
+        for cn in names:
+            if cn in v:
+                s, cnt, dur = v[cn]
+                print('    %-28s sum %.6g   per-dispatch %.6g   (profiled us/dispatch %.2f)' % (cn, s, s / cnt, dur / cnt / 1e3))
+
+
+if __name__ == '__main__':
+    if sys.argv[1] == 'stats':
+        stats(sys.argv[2])
+    else:
+        pmc(sys.argv[2:])
