@@ -58,6 +58,26 @@ CONV_CASES = [
     (4, 32, 32, 32, 32, 3, 1, 2, False, 1, False, 3, 0, 0),
     (4, 32, 32, 32, 64, 3, 2, 1, False, 1, False, 4, 0, 0),
     (4, 32, 32, 32, 128, 3, 1, 1, False, 1, False, 5, 0, 0),
+    (2, 24, 24, 64, 256, 3, 1, 1, True, 1, False, 6, 0, 0),      # 256x128 tile, 8 waves
+    (2, 24, 24, 64, 128, 3, 1, 1, True, 1, False, 11, 0, 0),     # 8-unit K step variants
+    (2, 24, 24, 128, 64, 3, 1, 5, False, 1, False, 12, 0, 0),
+    (2, 24, 24, 64, 64, 1, 1, 1, False, 1, False, 14, 0, 0),
+    (2, 13, 13, 192, 255, 1, 1, 0, False, 1, True, 15, 0, 0),
+    (2, 24, 24, 128, 256, 3, 2, 1, False, 1, False, 16, 0, 0),
+    (1, 19, 19, 64, 320, 3, 1, 1, True, 2, False, 16, 0, 64),
+    # LDS-DMA ring kernels (3 and 4 stages), incl. short K loops (nk < stages), tails, slices
+    (2, 24, 24, 64, 128, 3, 1, 1, True, 1, False, 21, 0, 0),
+    (2, 24, 24, 32, 128, 1, 1, 1, False, 1, False, 21, 0, 0),     # nk = 1
+    (2, 24, 24, 64, 128, 1, 1, 5, False, 1, False, 31, 0, 0),     # nk = 2 < stages
+    (1, 33, 31, 96, 255, 3, 2, 0, False, 1, True, 21, 32, 0),     # K tail per tap (cin 96), fp32 head, slice in
+    (2, 20, 20, 128, 64, 3, 1, 1, False, 1, False, 22, 0, 0),
+    (2, 20, 20, 128, 64, 3, 1, 4, True, 1, False, 24, 0, 16),
+    (3, 19, 19, 256, 255, 1, 1, 0, False, 1, True, 25, 0, 0),
+    (2, 24, 24, 128, 256, 3, 1, 1, True, 1, False, 26, 0, 0),
+    (2, 10, 10, 256, 128, 1, 1, 1, False, 2, False, 31, 0, 64),
+    (2, 20, 20, 24, 64, 3, 1, 3, False, 1, False, 32, 0, 0),      # cin 24: channel tail inside the first K step
+    (2, 20, 20, 128, 64, 3, 2, 1, False, 1, False, 34, 0, 0),
+    (1, 10, 10, 512, 1024, 3, 1, 1, True, 1, False, 35, 0, 0),
 ]
 
 

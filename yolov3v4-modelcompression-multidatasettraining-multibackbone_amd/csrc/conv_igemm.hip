@@ -39,6 +39,7 @@ struct ConvArgs {
     int ktot;        // R*S*cin_k
     long P;          // N*Ho*Wo
     int m_tiles, p_tiles;
+    int m_pad;
     int act;
     float slope;
     int ups;
@@ -58,47 +59,49 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));  // one 16-byte 
 template <typename T> struct Prec;
 template <> struct Prec<f16> {
     static constexpr int VEC = 8;   // elements per 16-byte unit
-    static constexpr int BK = 32;
 };
 template <> struct Prec<float> {
     static constexpr int VEC = 4;
-    static constexpr int BK = 16;
 };
 
-// One K step of MFMAs for a wave: TM x TN fragments of 16x16.
-template <typename T, int TM, int TN> struct MmaStep;
+// One K step (KU units of 16 bytes per row) of MFMAs for a wave: TM x TN fragments of 16x16.
+template <typename T, int TM, int TN, int KU> struct MmaStep;
 
-template <int TM, int TN> struct MmaStep<f16, TM, TN> {
+template <int TM, int TN, int KU> struct MmaStep<f16, TM, TN, KU> {
     static __device__ __forceinline__ void run(const u32x4* As, const u32x4* Bs, int BM, int BN, int arow, int brow,
                                                int lane, f32x4 (&acc)[TM][TN]) {
-        const int u = lane >> 4, r = lane & 15;
-        f16x8 a[TM], b[TN];
+        const int r = lane & 15;
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            u32x4 v = As[u * BM + arow + i * 16 + r];
-            a[i] = *reinterpret_cast<f16x8*>(&v);
+        for (int h = 0; h < KU / 4; ++h) {  // 4 units x 8 halfs = K 32 per 16x16x32 MFMA
+            const int u = h * 4 + (lane >> 4);
+            f16x8 a[TM], b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                u32x4 v = As[u * BM + arow + i * 16 + r];
+                a[i] = *reinterpret_cast<f16x8*>(&v);
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                u32x4 v = Bs[u * BN + brow + j * 16 + r];
+                b[j] = *reinterpret_cast<f16x8*>(&v);
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i], b[j], acc[i][j], 0, 0, 0);
         }
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            u32x4 v = Bs[u * BN + brow + j * 16 + r];
-            b[j] = *reinterpret_cast<f16x8*>(&v);
-        }
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i], b[j], acc[i][j], 0, 0, 0);
     }
 };
 
-template <int TM, int TN> struct MmaStep<float, TM, TN> {
+template <int TM, int TN, int KU> struct MmaStep<float, TM, TN, KU> {
     static __device__ __forceinline__ void run(const u32x4* As, const u32x4* Bs, int BM, int BN, int arow, int brow,
                                                int lane, f32x4 (&acc)[TM][TN]) {
         const int kq = lane >> 4, r = lane & 15;
         const float* Af = reinterpret_cast<const float*>(As);
         const float* Bf = reinterpret_cast<const float*>(Bs);
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {  // 4 units x 4 floats = K 16, one 16x16x4 MFMA per unit
+        for (int u = 0; u < KU; ++u) {  // one unit = 4 floats = one 16x16x4 MFMA
             float a[TM], b[TN];
 #pragma unroll
             for (int i = 0; i < TM; ++i) a[i] = Af[(u * BM + arow + i * 16 + r) * 4 + kq];
@@ -133,12 +136,15 @@ template <> __device__ __forceinline__ void load4<float>(const float* p, float (
     o[0] = v[0]; o[1] = v[1]; o[2] = v[2]; o[3] = v[3];
 }
 
-template <typename T, typename OutT, int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
-    constexpr int VEC = Prec<T>::VEC, BK = Prec<T>::BK, UNITS = 4;
+template <typename T, typename OutT, int BM, int BN, int WM, int WN, int KU>
+__global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm_kernel(const ConvArgs a) {
+    constexpr int VEC = Prec<T>::VEC, BK = VEC * KU, UNITS = KU;
+    constexpr int NW = WM * WN;              // waves per workgroup
+    constexpr int RPW = 64 / KU;             // tile rows one wave stages per pass (64 lanes = RPW rows x KU units)
+    constexpr int RPP = NW * RPW;            // rows per pass of the whole workgroup
     constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
-    constexpr int APASS = (BM + 63) / 64, BPASS = (BN + 63) / 64;
-    static_assert(WM * WN == 4, "4 waves per workgroup");
+    constexpr int APASS = (BM + RPP - 1) / RPP, BPASS = (BN + RPP - 1) / RPP;
+    static_assert(KU == 4 || KU == 8, "K step is 4 or 8 units");
     static_assert(TM >= 1 && TN >= 1, "tile too small");
 
     __shared__ u32x4 smem[2 * UNITS * (BM + BN)];
@@ -160,24 +166,25 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
     const int m0 = m_tile * BM;
     const long p0 = (long)p_tile * BN;
 
-    // ---- loader coordinates: 64 rows x 4 units per pass over 256 threads
-    const int lu = (lane >> 3) & 3;
-    const int lrow = (wave << 4) + ((lane >> 5) << 3) + (lane & 7);
+    // ---- loader coordinates: every 8-lane group stages 8 consecutive rows of one unit
+    const int lu = (lane >> 3) % KU;
+    const int lrow = wave * RPW + ((lane >> 3) / KU) * 8 + (lane & 7);
 
     const T* const xg = reinterpret_cast<const T*>(a.x);
     const T* wsrc[APASS];
     static_for<APASS>([&](auto c) {
         constexpr int ps = decltype(c)::value;
-        int row = lrow + ps * 64;
+        int row = lrow + ps * RPP;
         if (row >= BM) row = BM - 1;  // inactive lanes still hold a valid address
-        wsrc[ps] = reinterpret_cast<const T*>(a.w) + (long)(m0 + row) * a.ktot + lu * VEC;
+        row = min(m0 + row, a.m_pad - 1);  // tiles taller than the packed image's 128-row padding
+        wsrc[ps] = reinterpret_cast<const T*>(a.w) + (long)row * a.ktot + lu * VEC;
     });
     long bbase[BPASS];
     int bhi[BPASS], bwi[BPASS];
     const int HoWo = a.Ho * a.Wo;
     static_for<BPASS>([&](auto c) {
         constexpr int ps = decltype(c)::value;
-        const int row = lrow + ps * 64;
+        const int row = lrow + ps * RPP;
         const long p = p0 + row;
         if (row < BN && p < a.P) {
             const int n = (int)(p / HoWo);
@@ -200,7 +207,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
     auto load_step = [&]() {
         static_for<APASS>([&](auto c) {
             constexpr int ps = decltype(c)::value;
-            if (BM % 64 == 0 || lrow + ps * 64 < BM) ra[ps] = *reinterpret_cast<const u32x4*>(wsrc[ps] + kofs);
+            if (BM % RPP == 0 || lrow + ps * RPP < BM) ra[ps] = *reinterpret_cast<const u32x4*>(wsrc[ps] + kofs);
         });
         const long tap = ((long)kr * a.W + ks) * a.ldx + kc;
         const bool cok = kc + lu * VEC < a.Cin;
@@ -223,13 +230,13 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
     auto stash = [&](int buf) {
         static_for<APASS>([&](auto c) {
             constexpr int ps = decltype(c)::value;
-            const int row = lrow + ps * 64;
-            if (BM % 64 == 0 || row < BM) As[(buf * UNITS + lu) * BM + row] = ra[ps];
+            const int row = lrow + ps * RPP;
+            if (BM % RPP == 0 || row < BM) As[(buf * UNITS + lu) * BM + row] = ra[ps];
         });
         static_for<BPASS>([&](auto c) {
             constexpr int ps = decltype(c)::value;
-            const int row = lrow + ps * 64;
-            if (BN % 64 == 0 || row < BN) Bs[(buf * UNITS + lu) * BN + row] = rb[ps];
+            const int row = lrow + ps * RPP;
+            if (BN % RPP == 0 || row < BN) Bs[(buf * UNITS + lu) * BN + row] = rb[ps];
         });
     };
 
@@ -250,7 +257,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
             advance();
             load_step();
         }
-        MmaStep<T, TM, TN>::run(As + cur * UNITS * BM, Bs + cur * UNITS * BN, BM, BN, wm * TM * 16, wn * TN * 16, lane,
+        MmaStep<T, TM, TN, KU>::run(As + cur * UNITS * BM, Bs + cur * UNITS * BN, BM, BN, wm * TM * 16, wn * TN * 16, lane,
                                 acc);
         if (more) stash(cur ^ 1);
         __syncthreads();
@@ -298,36 +305,302 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
     }
 }
 
-template <typename T, typename OutT, int BM, int BN, int WM, int WN>
-static int launch(const ConvArgs& a0, hipStream_t stream) {
+
+// ---------------------------------------------------------------------------------------------------
+// LDS-DMA variant: operand tiles go global -> LDS directly (global_load_lds_dwordx4), STAGES K steps deep.
+//
+// Why: the register-staged kernel above is latency bound (rocprofv3: waves parked 64 % of their cycles,
+// MFMA pipe 17 % busy) — its prefetch distance is one K step and every staged byte costs VGPRs and a
+// ds_write.  LDS-DMA needs neither, so the ring can be 3-4 stages deep at higher occupancy.
+//
+// An LDS-DMA wave instruction writes 64 lanes x 16 B to *consecutive* LDS cells (M0 base + lane*16), so
+// the tile image is row-major here: row = 4 cells (one 64-byte K step of f16), 16 rows per instruction,
+// which keeps the global side at 64 contiguous bytes per row.  Bank conflicts on the fragment reads are
+// removed by permuting the 4 cells of a row with f[(row >> 2) & 3], f = {0,2,3,1}: the *source* unit a
+// lane fetches is (lane & 3) ^ f, the reader looks unit u up at cell u ^ f (both sides, same involution).
+// Out-of-image taps and channel tails read a 16-byte zero page instead of branching.
+__device__ __attribute__((aligned(16))) unsigned int g_zero_page[4];
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() {
+    // counted wait on this wave's vector-memory queue (LDS-DMA included); literal operand, compiler barrier
+#define YH_VMCNT_CASE(K) else if constexpr (N == K) asm volatile("s_waitcnt vmcnt(" #K ")" ::: "memory")
+    if constexpr (N < 0) {}
+    YH_VMCNT_CASE(0); YH_VMCNT_CASE(1); YH_VMCNT_CASE(2); YH_VMCNT_CASE(3); YH_VMCNT_CASE(4); YH_VMCNT_CASE(5);
+    YH_VMCNT_CASE(6); YH_VMCNT_CASE(7); YH_VMCNT_CASE(8); YH_VMCNT_CASE(9); YH_VMCNT_CASE(10); YH_VMCNT_CASE(11);
+    YH_VMCNT_CASE(12); YH_VMCNT_CASE(13); YH_VMCNT_CASE(14); YH_VMCNT_CASE(15); YH_VMCNT_CASE(16); YH_VMCNT_CASE(18);
+    YH_VMCNT_CASE(20); YH_VMCNT_CASE(24);
+    else static_assert(N < 0, "add the literal");
+#undef YH_VMCNT_CASE
+}
+
+__device__ __forceinline__ int swz_f(int g) { return (0x78 >> (2 * (g & 3))) & 3; }  // {0,2,3,1}
+
+template <typename T, int TM, int TN> struct MmaStepRM;  // row-major swizzled image, 4 units per row
+template <int TM, int TN> struct MmaStepRM<f16, TM, TN> {
+    static __device__ __forceinline__ void run(const u32x4* As, const u32x4* Bs, int arow, int brow, int lane,
+                                               f32x4 (&acc)[TM][TN]) {
+        const int r = lane & 15;
+        const int off = r * 4 + ((lane >> 4) ^ swz_f(r >> 2));
+        f16x8 a[TM], b[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            u32x4 v = As[(arow + i * 16) * 4 + off];
+            a[i] = *reinterpret_cast<f16x8*>(&v);
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            u32x4 v = Bs[(brow + j * 16) * 4 + off];
+            b[j] = *reinterpret_cast<f16x8*>(&v);
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+};
+template <int TM, int TN> struct MmaStepRM<float, TM, TN> {
+    static __device__ __forceinline__ void run(const u32x4* As, const u32x4* Bs, int arow, int brow, int lane,
+                                               f32x4 (&acc)[TM][TN]) {
+        const int r = lane & 15, kq = lane >> 4, fr = swz_f(r >> 2);
+        const float* Af = reinterpret_cast<const float*>(As);
+        const float* Bf = reinterpret_cast<const float*>(Bs);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int off = (r * 4 + (u ^ fr)) * 4 + kq;
+            float a[TM], b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[i] = Af[(arow + i * 16) * 16 + off];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[j] = Bf[(brow + j * 16) * 16 + off];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+    }
+};
+
+template <typename T, typename OutT, int BM, int BN, int WM, int WN, int STAGES>
+__global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm_glds_kernel(const ConvArgs a) {
+    constexpr int VEC = Prec<T>::VEC, BK = VEC * 4;
+    constexpr int NW = WM * WN;
+    constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
+    constexpr int GA = BM / 16, GB = BN / 16;        // 16-row groups (one LDS-DMA instruction each) per tile
+    constexpr int GPW = (GA + GB) / NW;               // groups per wave per K step
+    constexpr int GAW = GA / NW;                      // of which weight groups
+    static_assert(GA % NW == 0 && GB % NW == 0, "tile rows must split evenly over the waves");
+    static_assert(STAGES == 3 || STAGES == 4, "3 or 4 stage ring");
+
+    __shared__ u32x4 smem[STAGES * 4 * (BM + BN)];    // one array only: [stage][A rows*4 | B rows*4]
+    constexpr int STAGE_CELLS = 4 * (BM + BN);
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+
+    int m_tile, p_tile;
+    {
+        const int nb = gridDim.x, bid = blockIdx.x;
+        const int q = nb >> 3, rr = nb & 7, xcd = bid & 7;
+        const int logical = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (bid >> 3);
+        p_tile = logical / a.m_tiles;
+        m_tile = logical - p_tile * a.m_tiles;
+    }
+    const int m0 = m_tile * BM;
+    const long p0 = (long)p_tile * BN;
+
+    // loader: lane -> (row within its 16-row group, source unit)
+    const int lrow = lane >> 2;
+    const int lu = (lane & 3) ^ swz_f(lane >> 4);
+    const T* const xg = reinterpret_cast<const T*>(a.x);
+    const T* const zero = reinterpret_cast<const T*>(g_zero_page);
+
+    const T* wsrc[GAW > 0 ? GAW : 1];
+    static_for<GAW>([&](auto c) {
+        constexpr int i = decltype(c)::value;
+        const int row = (wave + i * NW) * 16 + lrow;
+        wsrc[i] = reinterpret_cast<const T*>(a.w) + (long)(m0 + row) * a.ktot + lu * VEC;
+    });
+    constexpr int GBW = GPW - GAW;
+    long bbase[GBW];
+    int bhi[GBW], bwi[GBW];
+    const int HoWo = a.Ho * a.Wo;
+    static_for<GBW>([&](auto c) {
+        constexpr int i = decltype(c)::value;
+        const int row = (wave + i * NW) * 16 + lrow;
+        const long p = p0 + row;
+        if (p < a.P) {
+            const int n = (int)(p / HoWo);
+            const int rem = (int)(p - (long)n * HoWo);
+            const int ho = rem / a.Wo, wo = rem - ho * a.Wo;
+            bhi[i] = ho * a.stride - a.pad;
+            bwi[i] = wo * a.stride - a.pad;
+            bbase[i] = (((long)n * a.H + bhi[i]) * a.W + bwi[i]) * a.ldx + lu * VEC;
+        } else {
+            bhi[i] = -(1 << 28);
+            bwi[i] = -(1 << 28);
+            bbase[i] = 0;
+        }
+    });
+
+    int kr = 0, ks = 0, kc = 0, kofs = 0;
+    auto issue = [&](int st) {  // LDS-DMA of the K step (kr, ks, kc) into ring slot st, then advance the step
+        u32x4* const base = smem + st * STAGE_CELLS;
+        static_for<GAW>([&](auto c) {
+            constexpr int i = decltype(c)::value;
+            u32x4* dst = base + (wave + i * NW) * 64;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc[i] + kofs),
+                                             (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+        });
+        const long tap = ((long)kr * a.W + ks) * a.ldx + kc;
+        const bool cok = kc + lu * VEC < a.Cin;
+        static_for<GBW>([&](auto c) {
+            constexpr int i = decltype(c)::value;
+            const bool ok = cok && (unsigned)(bhi[i] + kr) < (unsigned)a.H && (unsigned)(bwi[i] + ks) < (unsigned)a.W;
+            const T* src = ok ? xg + bbase[i] + tap : zero;
+            u32x4* dst = base + 4 * BM + (wave + i * NW) * 64;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+        });
+        kofs += BK;
+        kc += BK;
+        if (kc >= a.cin_k) {
+            kc = 0;
+            if (++ks == a.S) { ks = 0; ++kr; }
+        }
+    };
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = a.ktot / BK;
+#pragma unroll
+    for (int s = 0; s < STAGES - 1; ++s)
+        if (s < nk) issue(s);
+    int st_read = 0, st_write = STAGES - 1;
+    for (int kt = 0; kt < nk; ++kt) {
+        // this wave's share of step kt has landed once at most `ahead` later steps are still in flight
+        const int ahead = min(STAGES - 2, nk - 1 - kt);
+        if (ahead >= 2) wait_vmcnt<2 * GPW>();
+        else if (ahead == 1) wait_vmcnt<GPW>();
+        else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();  // everyone's share landed; everyone is done reading slot st_write
+        if (kt + STAGES - 1 < nk) issue(st_write);
+        const u32x4* As = smem + st_read * STAGE_CELLS;
+        MmaStepRM<T, TM, TN>::run(As, As + 4 * BM, wm * TM * 16, wn * TN * 16, lane, acc);
+        st_read = st_read + 1 == STAGES ? 0 : st_read + 1;
+        st_write = st_write + 1 == STAGES ? 0 : st_write + 1;
+    }
+
+    // ---- epilogue (same mapping as the register-staged kernel)
+    const int mq = (lane >> 4) << 2, pc = lane & 15;
+    OutT* const yg = reinterpret_cast<OutT*>(a.y);
+    const T* const rg = reinterpret_cast<const T*>(a.res);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const long p = p0 + wn * TN * 16 + j * 16 + pc;
+        if (p >= a.P) continue;
+        long opix = p;
+        int wo2 = 0;
+        if (a.ups == 2) {
+            const int n = (int)(p / HoWo);
+            const int rem = (int)(p - (long)n * HoWo);
+            const int ho = rem / a.Wo, wo = rem - ho * a.Wo;
+            wo2 = 2 * a.Wo;
+            opix = ((long)n * 2 * a.Ho + 2 * ho) * wo2 + 2 * wo;
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int m = m0 + wm * TM * 16 + i * 16 + mq;
+            if (m >= a.Cout) continue;
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(a.bias + m);
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = activate(acc[i][j][e] + bv[e], a.act, a.slope);
+            if (rg != nullptr) {
+                float r4[4];
+                load4<T>(rg + p * a.ldr + m, r4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] += r4[e];
+            }
+            OutT* dst = yg + opix * a.ldy + m;
+            store4<OutT>(dst, v[0], v[1], v[2], v[3]);
+            if (a.ups == 2) {
+                store4<OutT>(dst + a.ldy, v[0], v[1], v[2], v[3]);
+                store4<OutT>(dst + (long)wo2 * a.ldy, v[0], v[1], v[2], v[3]);
+                store4<OutT>(dst + (long)(wo2 + 1) * a.ldy, v[0], v[1], v[2], v[3]);
+            }
+        }
+    }
+}
+
+template <typename T, typename OutT, int BM, int BN, int WM, int WN, int STAGES>
+static int launch_glds(const ConvArgs& a0, hipStream_t stream) {
     ConvArgs a = a0;
     a.m_tiles = (a.Cout + BM - 1) / BM;
     a.p_tiles = (int)((a.P + BN - 1) / BN);
     const long blocks = (long)a.m_tiles * a.p_tiles;
     if (blocks <= 0 || blocks > 0x7fffffffL) return YH_EINVAL;
-    hipLaunchKernelGGL((conv_igemm_kernel<T, OutT, BM, BN, WM, WN>), dim3((unsigned)blocks), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL((conv_igemm_glds_kernel<T, OutT, BM, BN, WM, WN, STAGES>), dim3((unsigned)blocks), dim3(WM * WN * 64), 0,
+                       stream, a);
     return check_launch();
 }
 
-// tile codes: 1 = 128x128, 2 = 64x256, 3 = 32x256, 4 = 64x128, 5 = 128x64 (channels x pixels)
-static int pick_tile(int cout, long P) {
+template <typename T, typename OutT, int BM, int BN, int WM, int WN, int KU>
+static int launch(const ConvArgs& a0, hipStream_t stream) {
+    ConvArgs a = a0;
+    if (a.cin_k % (Prec<T>::VEC * KU)) return YH_EALIGN;
+    a.m_tiles = (a.Cout + BM - 1) / BM;
+    a.p_tiles = (int)((a.P + BN - 1) / BN);
+    const long blocks = (long)a.m_tiles * a.p_tiles;
+    if (blocks <= 0 || blocks > 0x7fffffffL) return YH_EINVAL;
+    hipLaunchKernelGGL((conv_igemm_kernel<T, OutT, BM, BN, WM, WN, KU>), dim3((unsigned)blocks), dim3(WM * WN * 64), 0, stream,
+                       a);
+    return check_launch();
+}
+
+// Tile codes (channels x pixels): 1 = 128x128, 2 = 64x256, 3 = 32x256, 4 = 64x128, 5 = 128x64, 6 = 256x128 (8 waves);
+// +10 selects the 8-unit K step (BK = 64 f16 / 32 f32) and needs cin_k to be a multiple of it.
+static int pick_tile(int cout, long P, int cin_k, int vec) {
     const int c = cout;
     const int w128 = ((c + 127) / 128) * 128, w64 = ((c + 63) / 64) * 64, w32 = ((c + 31) / 32) * 32;
     int tile = (w128 <= w64 && w128 <= w32) ? 1 : (w64 <= w32 ? 2 : 3);
     // few pixels (deep 19x19 layers at small batch): prefer narrower pixel tiles for occupancy
     if (tile == 1 && ((P + 127) / 128) * ((c + 127) / 128) < 256) tile = 5;
     if (tile == 2 && ((P + 255) / 256) * ((c + 63) / 64) < 256) tile = 4;
+    (void)cin_k; (void)vec;
     return tile;
 }
 
 template <typename T, typename OutT> static int dispatch_tile(const ConvArgs& a, int tile, hipStream_t s) {
-    if (tile == 0) tile = pick_tile(a.Cout, a.P);
+    if (tile == 0) tile = pick_tile(a.Cout, a.P, a.cin_k, Prec<T>::VEC);
     switch (tile) {
-        case 1: return launch<T, OutT, 128, 128, 2, 2>(a, s);
-        case 2: return launch<T, OutT, 64, 256, 1, 4>(a, s);
-        case 3: return launch<T, OutT, 32, 256, 1, 4>(a, s);
-        case 4: return launch<T, OutT, 64, 128, 2, 2>(a, s);
-        case 5: return launch<T, OutT, 128, 64, 2, 2>(a, s);
+        case 1: return launch<T, OutT, 128, 128, 2, 2, 4>(a, s);
+        case 2: return launch<T, OutT, 64, 256, 1, 4, 4>(a, s);
+        case 3: return launch<T, OutT, 32, 256, 1, 4, 4>(a, s);
+        case 4: return launch<T, OutT, 64, 128, 2, 2, 4>(a, s);
+        case 5: return launch<T, OutT, 128, 64, 2, 2, 4>(a, s);
+        case 6: return launch<T, OutT, 256, 128, 4, 2, 4>(a, s);
+        case 11: return launch<T, OutT, 128, 128, 2, 2, 8>(a, s);
+        case 12: return launch<T, OutT, 64, 256, 1, 4, 8>(a, s);
+        case 14: return launch<T, OutT, 64, 128, 2, 2, 8>(a, s);
+        case 15: return launch<T, OutT, 128, 64, 2, 2, 8>(a, s);
+        case 16: return launch<T, OutT, 256, 128, 4, 2, 8>(a, s);
+        // LDS-DMA ring kernels: 2x = 3 stages, 3x = 4 stages
+        case 21: return launch_glds<T, OutT, 128, 128, 2, 2, 3>(a, s);
+        case 22: return launch_glds<T, OutT, 64, 256, 1, 4, 3>(a, s);
+        case 24: return launch_glds<T, OutT, 64, 128, 2, 2, 3>(a, s);
+        case 25: return launch_glds<T, OutT, 128, 64, 2, 2, 3>(a, s);
+        case 26: return launch_glds<T, OutT, 256, 128, 4, 2, 3>(a, s);
+        case 31: return launch_glds<T, OutT, 128, 128, 2, 2, 4>(a, s);
+        case 32: return launch_glds<T, OutT, 64, 256, 1, 4, 4>(a, s);
+        case 34: return launch_glds<T, OutT, 64, 128, 2, 2, 4>(a, s);
+        case 35: return launch_glds<T, OutT, 128, 64, 2, 2, 4>(a, s);
         default: return YH_EINVAL;
     }
 }
@@ -337,7 +610,7 @@ template <typename T, typename OutT> static int dispatch_tile(const ConvArgs& a,
 extern "C" int yh_conv2d_tile(const yh_conv_desc* d) {
     if (!d) return YH_EINVAL;
     if (d->tile != 0) return d->tile;
-    return yh::pick_tile(d->cout, (long)d->n * d->ho * d->wo);
+    return yh::pick_tile(d->cout, (long)d->n * d->ho * d->wo, d->cin_k, d->dtype == YH_F16 ? 8 : 4);
 }
 
 extern "C" int yh_conv2d_fwd(const yh_conv_desc* d, void* stream) {
@@ -361,6 +634,7 @@ extern "C" int yh_conv2d_fwd(const yh_conv_desc* d, void* stream) {
     a.cin_k = d->cin_k; a.ktot = d->kh * d->kw * d->cin_k;
     a.P = (long)d->n * d->ho * d->wo;
     a.m_tiles = a.p_tiles = 0;
+    a.m_pad = d->m_pad;
     a.act = d->act; a.slope = d->slope; a.ups = d->ups;
     hipStream_t s = (hipStream_t)stream;
     if (d->dtype == YH_F16) {

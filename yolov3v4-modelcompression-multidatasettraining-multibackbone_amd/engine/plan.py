@@ -388,12 +388,15 @@ class DarknetEngine:
                     s = v.src
                     if s.fp32 and self.code == hiplib.YH_F16:
                         raise NotImplementedError('HIP engine: block %d consumes a yolo-head tensor' % v.block)
+                    tile = self.force_tile
+                    if 10 <= tile < 20 and pk['cin_k'] % (2 * self.kstep):
+                        tile -= 10  # the 8-unit K step needs cin_k to be a multiple of it
                     d = ConvDesc(x=P(s.storage, s.c_off), w=P(pk['w']), bias=P(pk['b']),
                                  res=None if v.res is None else P(v.res.storage, v.res.c_off), y=y,
                                  n=N, h=s.H, w_in=s.W, cin=s.c_phys, ho=v.Ho, wo=v.Wo, cout=v.c_phys,
                                  kh=v.k, kw=v.k, stride=v.stride, pad=v.pad, ldx=s.ld,
                                  ldr=0 if v.res is None else v.res.ld, ldy=v.ld, cin_k=pk['cin_k'], m_pad=pk['m_pad'],
-                                 act=v.act, slope=v.slope, ups=v.ups, out_f32=1 if v.fp32 else 0, dtype=self.code, tile=self.force_tile)
+                                 act=v.act, slope=v.slope, ups=v.ups, out_f32=1 if v.fp32 else 0, dtype=self.code, tile=tile)
                     add(d, 'conv%d' % v.block)
             elif v.kind == 'pool':
                 s = v.src
