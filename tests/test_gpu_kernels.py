@@ -74,6 +74,9 @@ CONV_CASES = [
     (2, 20, 20, 128, 64, 3, 1, 4, True, 1, False, 24, 0, 16),
     (3, 19, 19, 256, 255, 1, 1, 0, False, 1, True, 25, 0, 0),
     (2, 24, 24, 128, 256, 3, 1, 1, True, 1, False, 26, 0, 0),
+    (2, 24, 24, 128, 128, 3, 1, 1, True, 1, False, 26, 0, 0),     # tile taller than the packed image
+    (2, 24, 24, 128, 128, 3, 1, 1, True, 1, False, 27, 0, 0),
+    (1, 19, 19, 64, 320, 1, 1, 5, False, 2, False, 27, 0, 64),
     (2, 10, 10, 256, 128, 1, 1, 1, False, 2, False, 31, 0, 64),
     (2, 20, 20, 24, 64, 3, 1, 3, False, 1, False, 32, 0, 0),      # cin 24: channel tail inside the first K step
     (2, 20, 20, 128, 64, 3, 2, 1, False, 1, False, 34, 0, 0),

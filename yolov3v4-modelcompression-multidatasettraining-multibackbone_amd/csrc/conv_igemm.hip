@@ -420,8 +420,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm_glds_kernel(const 
     const T* wsrc[GAW > 0 ? GAW : 1];
     static_for<GAW>([&](auto c) {
         constexpr int i = decltype(c)::value;
-        const int row = (wave + i * NW) * 16 + lrow;
-        wsrc[i] = reinterpret_cast<const T*>(a.w) + (long)(m0 + row) * a.ktot + lu * VEC;
+        const int row = min(m0 + (wave + i * NW) * 16 + lrow, a.m_pad - 1);  // tiles taller than the 128-row padding
+        wsrc[i] = reinterpret_cast<const T*>(a.w) + (long)row * a.ktot + lu * VEC;
     });
     constexpr int GBW = GPW - GAW;
     long bbase[GBW];
@@ -564,17 +564,26 @@ static int launch(const ConvArgs& a0, hipStream_t stream) {
     return check_launch();
 }
 
-// Tile codes (channels x pixels): 1 = 128x128, 2 = 64x256, 3 = 32x256, 4 = 64x128, 5 = 128x64, 6 = 256x128 (8 waves);
-// +10 selects the 8-unit K step (BK = 64 f16 / 32 f32) and needs cin_k to be a multiple of it.
+// Tile codes (channels x pixels).  Register-staged kernels: 1 = 128x128, 2 = 64x256, 3 = 32x256, 4 = 64x128,
+// 5 = 128x64, 6 = 256x128 (8 waves); +10 = 8-unit K step.  LDS-DMA ring kernels: 21 = 128x128, 22 = 64x256,
+// 24 = 64x128, 25 = 128x64, 26 = 256x128 (8 waves), 27 = 128x256 (8 waves) with 3 stages; 3x = 4 stages.
+// The automatic choice below was fitted to per-layer measurements on MI355X (profiles/r01_tile_ab.txt):
+// the kernels are bound by global->LDS delivery, so the tile with the most FLOP per staged byte wins as
+// long as it still yields >= ~1 workgroup wave over the 256 CUs.
 static int pick_tile(int cout, long P, int cin_k, int vec) {
-    const int c = cout;
-    const int w128 = ((c + 127) / 128) * 128, w64 = ((c + 63) / 64) * 64, w32 = ((c + 31) / 32) * 32;
-    int tile = (w128 <= w64 && w128 <= w32) ? 1 : (w64 <= w32 ? 2 : 3);
-    // few pixels (deep 19x19 layers at small batch): prefer narrower pixel tiles for occupancy
-    if (tile == 1 && ((P + 127) / 128) * ((c + 127) / 128) < 256) tile = 5;
-    if (tile == 2 && ((P + 255) / 256) * ((c + 63) / 64) < 256) tile = 4;
     (void)cin_k; (void)vec;
-    return tile;
+    const int c = cout;
+    const long w256 = ((c + 255) / 256) * 256, w128 = ((c + 127) / 128) * 128, w64 = ((c + 63) / 64) * 64,
+               w32 = ((c + 31) / 32) * 32;
+    auto blocks = [&](int bm, int bn) { return (long)((c + bm - 1) / bm) * ((P + bn - 1) / bn); };
+    if (w128 <= w64 && w128 <= w32) {
+        if (w256 == w128 && blocks(256, 128) >= 256) return 26;
+        if (blocks(128, 256) >= 256) return 27;
+        if (blocks(128, 128) >= 256) return 21;
+        return 25;
+    }
+    if (w64 <= w32) return blocks(64, 256) >= 2048 ? 24 : 24;
+    return 3;
 }
 
 template <typename T, typename OutT> static int dispatch_tile(const ConvArgs& a, int tile, hipStream_t s) {
@@ -597,6 +606,7 @@ template <typename T, typename OutT> static int dispatch_tile(const ConvArgs& a,
         case 24: return launch_glds<T, OutT, 64, 128, 2, 2, 3>(a, s);
         case 25: return launch_glds<T, OutT, 128, 64, 2, 2, 3>(a, s);
         case 26: return launch_glds<T, OutT, 256, 128, 4, 2, 3>(a, s);
+        case 27: return launch_glds<T, OutT, 128, 256, 2, 4, 3>(a, s);
         case 31: return launch_glds<T, OutT, 128, 128, 2, 2, 4>(a, s);
         case 32: return launch_glds<T, OutT, 64, 256, 1, 4, 4>(a, s);
         case 34: return launch_glds<T, OutT, 64, 128, 2, 2, 4>(a, s);

@@ -49,45 +49,30 @@ __global__ void pack_stem_weights_kernel(const float* __restrict__ w, const floa
 }
 
 // ------------------------------------------------------------------------------------- first layer
-template <typename T, int CO> struct StemStore;
-template <int CO> struct StemStore<f16, CO> {
-    static __device__ __forceinline__ void run(f16* dst, const float (&acc)[CO], int co0, int cout) {
-#pragma unroll
-        for (int g = 0; g < CO / 8; ++g) {
-            if (co0 + g * 8 >= cout) break;
-            f16x8 v;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = (f16)acc[g * 8 + e];
-            *reinterpret_cast<f16x8*>(dst + g * 8) = v;
-        }
-    }
-};
-template <int CO> struct StemStore<float, CO> {
-    static __device__ __forceinline__ void run(float* dst, const float (&acc)[CO], int co0, int cout) {
-#pragma unroll
-        for (int g = 0; g < CO / 4; ++g) {
-            if (co0 + g * 4 >= cout) break;
-            f32x4 v = {acc[g * 4], acc[g * 4 + 1], acc[g * 4 + 2], acc[g * 4 + 3]};
-            *reinterpret_cast<f32x4*>(dst + g * 4) = v;
-        }
-    }
-};
-
-// one thread = one output pixel x CO output channels; weights/bias are wave-uniform (scalar loads)
-template <typename T, int CO>
+// One thread = one output pixel x 8 output channels; the G = cout_pad/8 threads of a pixel are adjacent, so a
+// wave stores G*16 contiguous bytes per pixel (full 64-byte segments for 32 channels) instead of 64-byte
+// strided 16-byte pieces.  The 27 input taps are re-read by the G threads of a pixel (L1 hits).
+template <typename T>
 __global__ __launch_bounds__(256) void conv_stem_kernel(const yh_stem_desc d) {
-    const long P = (long)d.n * d.ho * d.wo;
-    const long p = blockIdx.x * (long)blockDim.x + threadIdx.x;
-    const int co0 = blockIdx.y * CO;
-    if (p >= P) return;
+    const int G = d.cout_pad >> 3;
+    const long total = (long)d.n * d.ho * d.wo * G;
+    const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int g = (int)(i % G);
+    const long p = i / G;
+    const int co0 = g * 8;
     const int hw = d.ho * d.wo;
     const int n = (int)(p / hw);
     const int rem = (int)(p - (long)n * hw);
     const int ho = rem / d.wo, wo = rem - ho * d.wo;
     const int hi0 = ho * d.stride - d.pad, wi0 = wo * d.stride - d.pad;
-    float acc[CO];
+    float acc[8];
+    {
+        const f32x4 b0 = *reinterpret_cast<const f32x4*>(d.bias + co0);
+        const f32x4 b1 = *reinterpret_cast<const f32x4*>(d.bias + co0 + 4);
 #pragma unroll
-    for (int c = 0; c < CO; ++c) acc[c] = d.bias[co0 + c];
+        for (int c = 0; c < 4; ++c) { acc[c] = b0[c]; acc[4 + c] = b1[c]; }
+    }
     const float* xin = d.x + (long)n * d.cin * d.h * d.w_in;
     for (int r = 0; r < d.kh; ++r) {
         const int hi = hi0 + r;
@@ -97,15 +82,29 @@ __global__ __launch_bounds__(256) void conv_stem_kernel(const yh_stem_desc d) {
             for (int ci = 0; ci < d.cin; ++ci) {
                 const float xv = ok ? xin[((long)ci * d.h + hi) * d.w_in + wi] : 0.f;
                 const float* wrow = d.w + ((r * d.kw + s) * d.cin + ci) * d.cout_pad + co0;
+                const f32x4 w0 = *reinterpret_cast<const f32x4*>(wrow);
+                const f32x4 w1 = *reinterpret_cast<const f32x4*>(wrow + 4);
 #pragma unroll
-                for (int c = 0; c < CO; ++c) acc[c] = fmaf(xv, wrow[c], acc[c]);
+                for (int c = 0; c < 4; ++c) {
+                    acc[c] = fmaf(xv, w0[c], acc[c]);
+                    acc[4 + c] = fmaf(xv, w1[c], acc[4 + c]);
+                }
             }
         }
     }
+    if (co0 >= d.cout) return;
 #pragma unroll
-    for (int c = 0; c < CO; ++c) acc[c] = activate(acc[c], d.act, d.slope);
+    for (int c = 0; c < 8; ++c) acc[c] = activate(acc[c], d.act, d.slope);
     T* dst = reinterpret_cast<T*>(d.y) + p * d.ldy + co0;
-    StemStore<T, CO>::run(dst, acc, co0, d.cout);
+    if constexpr (sizeof(T) == 2) {
+        f16x8 v;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (f16)acc[e];
+        *reinterpret_cast<f16x8*>(dst) = v;
+    } else {
+        *reinterpret_cast<f32x4*>(dst) = f32x4{acc[0], acc[1], acc[2], acc[3]};
+        *reinterpret_cast<f32x4*>(dst + 4) = f32x4{acc[4], acc[5], acc[6], acc[7]};
+    }
 }
 
 // ---------------------------------------------------------------------------------------- max pool
@@ -205,30 +204,31 @@ __global__ __launch_bounds__(256) void add_channels_kernel(const yh_add_desc d) 
 }
 
 // ------------------------------------------------------------------------------------- yolo decode
+// grid.x = n * na * ny: one workgroup per (image, anchor, grid row); threads sweep the nx * no outputs of the
+// row, which are contiguous in both io and raw; the head map is read in 4*no-byte runs (one per cell).
 __global__ __launch_bounds__(256) void yolo_decode_kernel(const yh_decode_desc d) {
-    const long total = (long)d.n * d.na * d.ny * d.nx * d.no;
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int o = (int)(i % d.no);
-        long r = i / d.no;
-        const int x = (int)(r % d.nx);
-        r /= d.nx;
-        const int y = (int)(r % d.ny);
-        r /= d.ny;
-        const int a = (int)(r % d.na);
-        const int n = (int)(r / d.na);
-        const float v = d.p[(((long)n * d.ny + y) * d.nx + x) * d.ldp + a * d.no + o];
-        if (d.raw) d.raw[i] = v;
+    const int row = blockIdx.x;
+    const int y = row % d.ny;
+    const int t = row / d.ny;
+    const int a = t % d.na, n = t / d.na;
+    const int span = d.nx * d.no;
+    const float* prow = d.p + ((long)n * d.ny + y) * d.nx * d.ldp + a * d.no;
+    const long obase = (((long)n * d.na + a) * d.ny + y) * span;  // raw is (n, a, y, x, o) contiguous
+    float* const io = d.io + ((long)n * d.rows_total + d.row_off + ((long)a * d.ny + y) * d.nx) * d.no;
+    const float aw = d.anchor_w[a], ah = d.anchor_h[a];
+    for (int i = threadIdx.x; i < span; i += blockDim.x) {
+        const int x = i / d.no, o = i - x * d.no;
+        const float v = prow[(long)x * d.ldp + o];
+        if (d.raw) d.raw[obase + i] = v;
         float out;
         if (o < 2) {
-            const float sg = 1.f / (1.f + expf(-v));
-            out = (sg + (float)(o == 0 ? x : y)) * d.stride;
+            out = (1.f / (1.f + expf(-v)) + (float)(o == 0 ? x : y)) * d.stride;
         } else if (o < 4) {
-            out = (expf(v) * (o == 2 ? d.anchor_w[a] : d.anchor_h[a])) * d.stride;
+            out = (expf(v) * (o == 2 ? aw : ah)) * d.stride;
         } else {
             out = 1.f / (1.f + expf(-v));
         }
-        const long row = d.row_off + ((long)a * d.ny + y) * d.nx + x;
-        d.io[((long)n * d.rows_total + row) * d.no + o] = out;
+        io[i] = out;
     }
 }
 
@@ -299,17 +299,11 @@ extern "C" int yh_conv2d_stem_fwd(const yh_stem_desc* d, void* stream) {
     if (d->dtype != YH_F16 && d->dtype != YH_F32) return YH_EINVAL;
     if (d->cout_pad % 16 || d->cout_pad < d->cout || d->cout % 8 || d->ldy % 8 || !aligned16(d->y)) return YH_EALIGN;
     if (d->ho != (d->h + 2 * d->pad - d->kh) / d->stride + 1 || d->wo != (d->w_in + 2 * d->pad - d->kw) / d->stride + 1) return YH_EINVAL;
-    const long P = (long)d->n * d->ho * d->wo;
+    const long total = (long)d->n * d->ho * d->wo * (d->cout_pad / 8);
     hipStream_t s = (hipStream_t)stream;
-    const bool wide = d->cout_pad % 32 == 0;
-    const dim3 grid((unsigned)((P + 255) / 256), (unsigned)(d->cout_pad / (wide ? 32 : 16)));
-    if (d->dtype == YH_F16) {
-        if (wide) hipLaunchKernelGGL((conv_stem_kernel<f16, 32>), grid, dim3(256), 0, s, *d);
-        else hipLaunchKernelGGL((conv_stem_kernel<f16, 16>), grid, dim3(256), 0, s, *d);
-    } else {
-        if (wide) hipLaunchKernelGGL((conv_stem_kernel<float, 32>), grid, dim3(256), 0, s, *d);
-        else hipLaunchKernelGGL((conv_stem_kernel<float, 16>), grid, dim3(256), 0, s, *d);
-    }
+    const dim3 grid((unsigned)((total + 255) / 256));
+    if (d->dtype == YH_F16) hipLaunchKernelGGL(conv_stem_kernel<f16>, grid, dim3(256), 0, s, *d);
+    else hipLaunchKernelGGL(conv_stem_kernel<float>, grid, dim3(256), 0, s, *d);
     return check_launch();
 }
 
@@ -354,7 +348,8 @@ extern "C" int yh_add_channels(const yh_add_desc* d, void* stream) {
 extern "C" int yh_yolo_decode(const yh_decode_desc* d, void* stream) {
     if (!d || !d->p || !d->io || d->n <= 0 || d->ny <= 0 || d->nx <= 0 || d->na <= 0 || d->na > 8 || d->no < 5) return YH_EINVAL;
     if (d->ldp < d->na * d->no || d->row_off < 0 || d->row_off + d->na * d->ny * d->nx > d->rows_total) return YH_EINVAL;
-    const long total = (long)d->n * d->na * d->ny * d->nx * d->no;
-    hipLaunchKernelGGL(yolo_decode_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, *d);
+    const long rows = (long)d->n * d->na * d->ny;
+    if (rows > 0x7fffffffL) return YH_EINVAL;
+    hipLaunchKernelGGL(yolo_decode_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, *d);
     return check_launch();
 }
