@@ -81,6 +81,15 @@ CONV_CASES = [
     (2, 20, 20, 24, 64, 3, 1, 3, False, 1, False, 32, 0, 0),      # cin 24: channel tail inside the first K step
     (2, 20, 20, 128, 64, 3, 2, 1, False, 1, False, 34, 0, 0),
     (1, 10, 10, 512, 1024, 3, 1, 1, True, 1, False, 35, 0, 0),
+    # 3x3 halo kernels (virtual padded pixel space): several widths, batch boundaries, tails, fused epilogues
+    (2, 19, 19, 64, 128, 3, 1, 1, True, 1, False, 41, 0, 0),
+    (3, 38, 38, 32, 128, 3, 1, 1, False, 1, False, 41, 0, 0),      # single chunk (nk = 9)
+    (1, 76, 76, 128, 255, 3, 1, 0, False, 1, True, 41, 0, 0),      # fp32 head-style output, cout 255
+    (2, 13, 17, 96, 64, 3, 1, 5, False, 1, False, 41, 32, 16),     # non-square, cin 96, slices, cout < tile
+    (2, 20, 20, 24, 128, 3, 1, 4, True, 2, False, 41, 0, 64),      # channel tail inside the chunk, upsample
+    (5, 7, 5, 64, 256, 3, 1, 1, True, 1, False, 41, 0, 0),         # tiny images: many images per tile
+    (2, 19, 19, 64, 256, 3, 1, 1, True, 1, False, 42, 0, 0),
+    (1, 40, 40, 128, 512, 3, 1, 1, False, 1, False, 42, 0, 0),
 ]
 
 

@@ -551,6 +551,262 @@ static int launch_glds(const ConvArgs& a0, hipStream_t stream) {
     return check_launch();
 }
 
+
+// ---------------------------------------------------------------------------------------------------
+// 3x3 / stride 1 / pad 1 "halo" kernel: the im2col gather is done from LDS instead of from L2.
+//
+// rocprofv3 on the LDS-DMA im2col kernels: L2 (TCC) busy 80 %, MFMA pipe ~30 % — every activation row is
+// fetched from L2 once per filter tap (9x).  Here a workgroup stages, once per 32-channel chunk, the rows of
+// all input pixels its 256 output pixels touch (the tile plus one image row and one pixel on either side)
+// and produces the nine shifted operand tiles as *views* of that LDS image: global traffic per K step drops
+// from BM+256 rows to BM + ~(256 + 2W)/9 rows.
+//
+// To make every tap a constant row offset, output pixels are indexed in a virtual space with padding built
+// in: image n, row y, column x  <->  v = n*(H+1)*(W+2) + (y+1)*(W+2) + (x+1); one zero row is shared between
+// consecutive images, two zero columns end every row.  Output tile = 256 consecutive v; its inputs are the
+// consecutive range [v0 - (W+2) - 1, v0 + 256 + (W+2) + 1); tap (r, s) of output v sits (r*(W+2) + s) rows
+// further into the staged image.  Virtual positions that are padding are loaded from the zero page and their
+// (garbage) outputs are not stored: (H+1)(W+2)/(HW) - 1 of the MFMA work is wasted (4 % at 76x76, 16 % at 19x19).
+//
+// Pipeline per K step (one tap of one chunk): weights stream through a 3-deep LDS-DMA ring exactly like the
+// im2col kernel; the next chunk's halo image is fetched into the second halo buffer right after tap 0.
+template <typename T, typename OutT, int BM, int LB>
+__global__ __launch_bounds__(512, (BM <= 128 ? 4 : 2)) void conv3x3_halo_kernel(const ConvArgs a, const int rows_h) {
+    constexpr int VEC = Prec<T>::VEC, BK = VEC * 4, BN = 256, NW = 8, WN = 4, STAGES = 3;
+    constexpr int WM = NW / WN;
+    constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
+    constexpr int GAW = BM / 16 / NW;  // weight groups (16 rows) per wave per K step
+    static_assert(BM % (16 * NW) == 0, "weight tile must split over 8 waves");
+    constexpr int LA = GAW;
+
+    extern __shared__ __attribute__((aligned(16))) u32x4 dsm[];
+    u32x4* const Aring = dsm;                                  // [STAGES][BM*4]
+    u32x4* const Bbuf0 = dsm + STAGES * BM * 4;                 // [2][rows_h*4]
+    u32x4* const dummy = Bbuf0 + 2 * rows_h * 4;                // [64] sink for padding loads
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+
+    int m_tile, p_tile;
+    {
+        const int nb = gridDim.x, bid = blockIdx.x;
+        const int q = nb >> 3, rr = nb & 7, xcd = bid & 7;
+        const int logical = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (bid >> 3);
+        p_tile = logical / a.m_tiles;
+        m_tile = logical - p_tile * a.m_tiles;
+    }
+    const int m0 = m_tile * BM;
+    const long q0 = (long)p_tile * BN;  // first virtual output position of this tile
+    const int Wp = a.W + 2;
+    const long IMG = (long)(a.H + 1) * Wp;
+
+    const int lrow = lane >> 2;
+    const int lu = (lane & 3) ^ (((lane >> 4) & 1) << 1);  // source unit of this lane (swizzle f = 2*((row>>2)&1))
+    const T* const xg = reinterpret_cast<const T*>(a.x);
+    const T* const zero = reinterpret_cast<const T*>(g_zero_page);
+
+    const T* wsrc[GAW];
+    static_for<GAW>([&](auto c) {
+        constexpr int i = decltype(c)::value;
+        const int row = min(m0 + (wave + i * NW) * 16 + lrow, a.m_pad - 1);
+        wsrc[i] = reinterpret_cast<const T*>(a.w) + (long)row * a.ktot + lu * VEC;
+    });
+    // halo rows owned by this lane: group g = wave + i*NW, row j = g*16 + lrow, input position v = v0 + j
+    const long v0 = q0 - Wp - 1;
+    const T* bsrc[LB];
+    static_for<LB>([&](auto c) {
+        constexpr int i = decltype(c)::value;
+        const int j = (wave + i * NW) * 16 + lrow;
+        const long v = v0 + j;
+        const T* ptr = nullptr;
+        if (j < rows_h && v >= 0) {
+            const long n = v / IMG;
+            const int rem = (int)(v - n * IMG);
+            const int yy = rem / Wp - 1, xx = rem - (rem / Wp) * Wp - 1;
+            if (n < a.N && yy >= 0 && xx >= 0 && xx < a.W)  // yy < H always: IMG has H+1 rows, row 0 is the pad row
+                ptr = xg + ((n * a.H + yy) * (long)a.W + xx) * a.ldx + lu * VEC;
+        }
+        bsrc[i] = ptr;
+    });
+
+    auto issue_a = [&](int st, int tap, int kc) {
+        static_for<GAW>([&](auto c) {
+            constexpr int i = decltype(c)::value;
+            u32x4* dst = Aring + st * (BM * 4) + (wave + i * NW) * 64;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc[i] + tap * a.cin_k + kc),
+                                             (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+        });
+    };
+    auto issue_b = [&](int buf, int kc) {
+        const bool cok = kc + lu * VEC < a.Cin;
+        static_for<LB>([&](auto c) {
+            constexpr int i = decltype(c)::value;
+            const int g = wave + i * NW;  // wave-uniform
+            const T* src = (cok && bsrc[i] != nullptr) ? bsrc[i] + kc : zero;
+            u32x4* dst = (g * 16 < rows_h) ? Bbuf0 + buf * (rows_h * 4) + g * 64 : dummy;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+        });
+    };
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nchunks = a.cin_k / BK;
+    const int nk = 9 * nchunks;
+    // prologue: halo image of chunk 0, then weights of steps 0 and 1
+    issue_b(0, 0);
+    issue_a(0, 0, 0);
+    issue_a(1, 1, 0);  // nk >= 9 always
+    int tap = 0, chunk = 0;        // the step being computed
+    int ptap = 2, pkc = 0;         // tap / channel offset of the next weight tile to prefetch (step k+2)
+    int st_read = 0, st_write = 2;
+    const int r16 = lane & 15;
+    for (int kt = 0; kt < nk; ++kt) {
+        const bool more_a = kt + 1 < nk;                          // A(k+1) still in flight behind A(k)
+        const bool b_behind = (tap == 1 || tap == 2) && chunk + 1 < nchunks;  // next halo image issued after A(k)
+        if (more_a) { if (b_behind) wait_vmcnt<LA + LB>(); else wait_vmcnt<LA>(); }
+        else        { if (b_behind) wait_vmcnt<LB>(); else wait_vmcnt<0>(); }
+        __builtin_amdgcn_s_barrier();
+        if (kt + 2 < nk) issue_a(st_write, ptap, pkc);
+        if (tap == 0 && chunk + 1 < nchunks) issue_b((chunk + 1) & 1, (chunk + 1) * BK);
+        if (++ptap == 9) { ptap = 0; pkc += BK; }
+
+        // ---- MFMAs of this tap: weights from the ring slot, activations = halo image shifted by the tap
+        {
+            const u32x4* As = Aring + st_read * (BM * 4);
+            const u32x4* Bs = Bbuf0 + (chunk & 1) * (rows_h * 4);
+            const int tapoff = (tap / 3) * Wp + (tap % 3);
+            if constexpr (sizeof(T) == 2) {
+                const int u = lane >> 4;
+                f16x8 fa[TM], fb[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const int row = wm * TM * 16 + i * 16 + r16;
+                    u32x4 v = As[row * 4 + (u ^ (((row >> 2) & 1) << 1))];
+                    fa[i] = *reinterpret_cast<f16x8*>(&v);
+                }
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int row = wn * TN * 16 + j * 16 + r16 + tapoff;
+                    u32x4 v = Bs[row * 4 + (u ^ (((row >> 2) & 1) << 1))];
+                    fb[j] = *reinterpret_cast<f16x8*>(&v);
+                }
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+            } else {
+                const int kq = lane >> 4;
+                const float* Af = reinterpret_cast<const float*>(As);
+                const float* Bf = reinterpret_cast<const float*>(Bs);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    float fa[TM], fb[TN];
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) {
+                        const int row = wm * TM * 16 + i * 16 + r16;
+                        fa[i] = Af[(row * 4 + (u ^ (((row >> 2) & 1) << 1))) * 4 + kq];
+                    }
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        const int row = wn * TN * 16 + j * 16 + r16 + tapoff;
+                        fb[j] = Bf[(row * 4 + (u ^ (((row >> 2) & 1) << 1))) * 4 + kq];
+                    }
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
+                }
+            }
+        }
+        st_read = st_read + 1 == STAGES ? 0 : st_read + 1;
+        st_write = st_write + 1 == STAGES ? 0 : st_write + 1;
+        if (++tap == 9) { tap = 0; ++chunk; }
+    }
+
+    // ---- epilogue: virtual position -> real pixel (padding positions are dropped)
+    const int mq = (lane >> 4) << 2;
+    OutT* const yg = reinterpret_cast<OutT*>(a.y);
+    const T* const rg = reinterpret_cast<const T*>(a.res);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const long q = q0 + wn * TN * 16 + j * 16 + r16;
+        const long n = q / IMG;
+        const int rem = (int)(q - n * IMG);
+        const int yy = rem / Wp - 1, xx = rem - (rem / Wp) * Wp - 1;
+        if (n >= a.N || yy < 0 || xx < 0 || xx >= a.W) continue;
+        const long p = (n * a.H + yy) * (long)a.W + xx;
+        long opix = p;
+        int wo2 = 0;
+        if (a.ups == 2) {
+            wo2 = 2 * a.W;
+            opix = (n * 2 * a.H + 2 * yy) * (long)wo2 + 2 * xx;
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int m = m0 + wm * TM * 16 + i * 16 + mq;
+            if (m >= a.Cout) continue;
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(a.bias + m);
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = activate(acc[i][j][e] + bv[e], a.act, a.slope);
+            if (rg != nullptr) {
+                float r4[4];
+                load4<T>(rg + p * a.ldr + m, r4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] += r4[e];
+            }
+            OutT* dst = yg + opix * a.ldy + m;
+            store4<OutT>(dst, v[0], v[1], v[2], v[3]);
+            if (a.ups == 2) {
+                store4<OutT>(dst + a.ldy, v[0], v[1], v[2], v[3]);
+                store4<OutT>(dst + (long)wo2 * a.ldy, v[0], v[1], v[2], v[3]);
+                store4<OutT>(dst + (long)(wo2 + 1) * a.ldy, v[0], v[1], v[2], v[3]);
+            }
+        }
+    }
+}
+
+template <typename T, typename OutT, int BM> static int launch_halo(const ConvArgs& a0, hipStream_t stream) {
+    ConvArgs a = a0;
+    if (a.R != 3 || a.S != 3 || a.stride != 1 || a.pad != 1) return YH_EUNSUPPORTED;
+    const int Wp = a.W + 2;
+    const int rows_h = ((256 + 2 * Wp + 2 + 15) / 16) * 16;
+    const int groups = rows_h / 16;
+    const int lb = (groups + 7) / 8;
+    if (lb > 5) return YH_EUNSUPPORTED;  // halo image too large for LDS (W > ~190)
+    a.m_tiles = (a.Cout + BM - 1) / BM;
+    const long Q = (long)a.N * (a.H + 1) * Wp;
+    a.p_tiles = (int)((Q + 255) / 256);
+    const long blocks = (long)a.m_tiles * a.p_tiles;
+    if (blocks <= 0 || blocks > 0x7fffffffL) return YH_EINVAL;
+    const size_t lds = ((size_t)3 * BM * 4 + (size_t)2 * rows_h * 4 + 64) * 16;
+    if (lds > 160 * 1024) return YH_EUNSUPPORTED;
+#define YH_HALO_CASE(LBV)                                                                                             \
+    case LBV: {                                                                                                       \
+        auto kern = conv3x3_halo_kernel<T, OutT, BM, LBV>;                                                            \
+        if (lds > 64 * 1024) {                                                                                        \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            if (e != hipSuccess) return (int)e;                                                                       \
+        }                                                                                                             \
+        hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(512), lds, stream, a, rows_h);                          \
+        break;                                                                                                        \
+    }
+    switch (lb) {
+        YH_HALO_CASE(1) YH_HALO_CASE(2) YH_HALO_CASE(3) YH_HALO_CASE(4) YH_HALO_CASE(5)
+        default: return YH_EUNSUPPORTED;
+    }
+#undef YH_HALO_CASE
+    return check_launch();
+}
+
 template <typename T, typename OutT, int BM, int BN, int WM, int WN, int KU>
 static int launch(const ConvArgs& a0, hipStream_t stream) {
     ConvArgs a = a0;
@@ -607,6 +863,8 @@ template <typename T, typename OutT> static int dispatch_tile(const ConvArgs& a,
         case 25: return launch_glds<T, OutT, 128, 64, 2, 2, 3>(a, s);
         case 26: return launch_glds<T, OutT, 256, 128, 4, 2, 3>(a, s);
         case 27: return launch_glds<T, OutT, 128, 256, 2, 4, 3>(a, s);
+        case 41: return launch_halo<T, OutT, 128>(a, s);   // 3x3 s1 halo kernel, 128 channels x 256 virtual pixels
+        case 42: return launch_halo<T, OutT, 256>(a, s);
         case 31: return launch_glds<T, OutT, 128, 128, 2, 2, 4>(a, s);
         case 32: return launch_glds<T, OutT, 64, 256, 1, 4, 4>(a, s);
         case 34: return launch_glds<T, OutT, 64, 128, 2, 2, 4>(a, s);

@@ -391,6 +391,8 @@ class DarknetEngine:
                     tile = self.force_tile
                     if 10 <= tile < 20 and pk['cin_k'] % (2 * self.kstep):
                         tile -= 10  # the 8-unit K step needs cin_k to be a multiple of it
+                    if tile >= 40 and not (v.k == 3 and v.stride == 1 and v.pad == 1 and s.W <= 160):
+                        tile = 0    # halo kernels are 3x3 / stride 1 only
                     d = ConvDesc(x=P(s.storage, s.c_off), w=P(pk['w']), bias=P(pk['b']),
                                  res=None if v.res is None else P(v.res.storage, v.res.c_off), y=y,
                                  n=N, h=s.H, w_in=s.W, cin=s.c_phys, ho=v.Ho, wo=v.Wo, cout=v.c_phys,
