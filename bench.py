@@ -38,7 +38,7 @@ import torch  # noqa: E402
 PEAK_TFLOPS = {'fp16': 2500.0, 'fp32': 157.3}  # dense MFMA peaks, MI355X_MICROARCH.md
 TILE_NAMES = {1: '128x128', 2: '64x256', 3: '32x256', 4: '64x128', 5: '128x64', 6: '256x128', 11: '128x128k8', 12: '64x256k8',
               14: '64x128k8', 15: '128x64k8', 16: '256x128k8', 21: 'dma3_128x128', 22: 'dma3_64x256', 24: 'dma3_64x128',
-              25: 'dma3_128x64', 26: 'dma3_256x128', 27: 'dma3_128x256', 41: 'halo_128x256', 42: 'halo_256x256', 31: 'dma4_128x128', 32: 'dma4_64x256', 34: 'dma4_64x128',
+              25: 'dma3_128x64', 26: 'dma3_256x128', 27: 'dma3_128x256', 41: 'halo_128x256', 51: 'abl_noload', 52: 'abl_nomfma', 42: 'halo_256x256', 31: 'dma4_128x128', 32: 'dma4_64x256', 34: 'dma4_64x128',
               35: 'dma4_128x64'}
 
 
@@ -145,7 +145,7 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=5)
-    ap.add_argument('--batch', type=int, default=32, help='frames per GPU per step')
+    ap.add_argument('--batch', type=int, default=64, help='frames per GPU per step (BASELINE: batch 64/GPU)')
     ap.add_argument('--size', type=int, default=608)
     ap.add_argument('--precision', default='fp16', choices=['fp16', 'fp32'])
     ap.add_argument('--cfg', default=os.path.join(PKG, 'cfg', 'yolov3', 'yolov3.cfg'))

@@ -382,7 +382,8 @@ template <int TM, int TN> struct MmaStepRM<float, TM, TN> {
     }
 };
 
-template <typename T, typename OutT, int BM, int BN, int WM, int WN, int STAGES>
+// ABL: ablation switch for profiling only (0 = normal, 1 = skip the LDS-DMA loads, 2 = skip the MFMAs)
+template <typename T, typename OutT, int BM, int BN, int WM, int WN, int STAGES, int ABL = 0>
 __global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm_glds_kernel(const ConvArgs a) {
     constexpr int VEC = Prec<T>::VEC, BK = VEC * 4;
     constexpr int NW = WM * WN;
@@ -448,7 +449,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm_glds_kernel(const 
     int kr = 0, ks = 0, kc = 0, kofs = 0;
     auto issue = [&](int st) {  // LDS-DMA of the K step (kr, ks, kc) into ring slot st, then advance the step
         u32x4* const base = smem + st * STAGE_CELLS;
-        static_for<GAW>([&](auto c) {
+        if constexpr (ABL != 1) static_for<GAW>([&](auto c) {
             constexpr int i = decltype(c)::value;
             u32x4* dst = base + (wave + i * NW) * 64;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc[i] + kofs),
@@ -456,7 +457,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm_glds_kernel(const 
         });
         const long tap = ((long)kr * a.W + ks) * a.ldx + kc;
         const bool cok = kc + lu * VEC < a.Cin;
-        static_for<GBW>([&](auto c) {
+        if constexpr (ABL != 1) static_for<GBW>([&](auto c) {
             constexpr int i = decltype(c)::value;
             const bool ok = cok && (unsigned)(bhi[i] + kr) < (unsigned)a.H && (unsigned)(bwi[i] + ks) < (unsigned)a.W;
             const T* src = ok ? xg + bbase[i] + tap : zero;
@@ -492,7 +493,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm_glds_kernel(const 
         __builtin_amdgcn_s_barrier();  // everyone's share landed; everyone is done reading slot st_write
         if (kt + STAGES - 1 < nk) issue(st_write);
         const u32x4* As = smem + st_read * STAGE_CELLS;
-        MmaStepRM<T, TM, TN>::run(As, As + 4 * BM, wm * TM * 16, wn * TN * 16, lane, acc);
+        if constexpr (ABL != 2) MmaStepRM<T, TM, TN>::run(As, As + 4 * BM, wm * TM * 16, wn * TN * 16, lane, acc);
         st_read = st_read + 1 == STAGES ? 0 : st_read + 1;
         st_write = st_write + 1 == STAGES ? 0 : st_write + 1;
     }
@@ -539,15 +540,15 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm_glds_kernel(const 
     }
 }
 
-template <typename T, typename OutT, int BM, int BN, int WM, int WN, int STAGES>
+template <typename T, typename OutT, int BM, int BN, int WM, int WN, int STAGES, int ABL = 0>
 static int launch_glds(const ConvArgs& a0, hipStream_t stream) {
     ConvArgs a = a0;
     a.m_tiles = (a.Cout + BM - 1) / BM;
     a.p_tiles = (int)((a.P + BN - 1) / BN);
     const long blocks = (long)a.m_tiles * a.p_tiles;
     if (blocks <= 0 || blocks > 0x7fffffffL) return YH_EINVAL;
-    hipLaunchKernelGGL((conv_igemm_glds_kernel<T, OutT, BM, BN, WM, WN, STAGES>), dim3((unsigned)blocks), dim3(WM * WN * 64), 0,
-                       stream, a);
+    hipLaunchKernelGGL((conv_igemm_glds_kernel<T, OutT, BM, BN, WM, WN, STAGES, ABL>), dim3((unsigned)blocks),
+                       dim3(WM * WN * 64), 0, stream, a);
     return check_launch();
 }
 
@@ -863,6 +864,8 @@ template <typename T, typename OutT> static int dispatch_tile(const ConvArgs& a,
         case 25: return launch_glds<T, OutT, 128, 64, 2, 2, 3>(a, s);
         case 26: return launch_glds<T, OutT, 256, 128, 4, 2, 3>(a, s);
         case 27: return launch_glds<T, OutT, 128, 256, 2, 4, 3>(a, s);
+        case 51: return launch_glds<T, OutT, 256, 128, 4, 2, 3, 1>(a, s);  // ablation: no loads (results are garbage)
+        case 52: return launch_glds<T, OutT, 256, 128, 4, 2, 3, 2>(a, s);  // ablation: no MFMAs (results are garbage)
         case 41: return launch_halo<T, OutT, 128>(a, s);   // 3x3 s1 halo kernel, 128 channels x 256 virtual pixels
         case 42: return launch_halo<T, OutT, 256>(a, s);
         case 31: return launch_glds<T, OutT, 128, 128, 2, 2, 4>(a, s);
