@@ -109,11 +109,29 @@ def roofline_leg(model, x, steps, precision):
                          tflops=round(g['flops'] / (g['ms'] * 1e-3) / 1e12, 1) if g['flops'] else None)
                  for n, g in sorted(groups.items(), key=lambda kv: -kv[1]['ms'])}
     return dict(bound='mfma', kernel=dom_name, achieved=round(achieved, 2), peak=peak, unit='TFLOP/s',
-                frac=round(achieved / peak, 4), traffic=None, launches_per_step=dom['launches'],
+                frac=round(achieved / peak, 4), traffic=hbm_traffic(dom_name, x.shape[0]), launches_per_step=dom['launches'],
                 avg_launch_ms=round(dom['ms'] / dom['launches'], 5),
                 gflop_per_launch=round(dom['flops'] / dom['launches'] / 1e9, 3),
                 gpu_ms_per_step_all_kernels=round(sum(g['ms'] for g in groups.values()), 4),
                 instrumented_ms_per_step=round(wall * 1e3, 4), kernels=breakdown)
+
+
+def hbm_traffic(kernel, batch):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes, or None.
+
+    PMC counters cannot be read from inside this process; they are collected with separate
+    `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of this same command and reduced by
+    tools/rocprof_summary.py traffic (gfx950 correction: read side doubled) into profiles/hbm_traffic.json."""
+    path = os.path.join(REPO, 'profiles', 'hbm_traffic.json')
+    try:
+        table = json.load(open(path))
+    except Exception:
+        return None
+    m = {'dma3_256x128': 'conv_igemm_glds<f16,f16,256x128,S3>', 'dma3_128x256': 'conv_igemm_glds<f16,f16,128x256,S3>',
+         'dma3_128x128': 'conv_igemm_glds<f16,f16,128x128,S3>'}
+    key = m.get(kernel.replace('conv_igemm_fp16_', ''))
+    ent = table.get('batch%d' % batch, {}).get(key) if key else None
+    return None if ent is None else {'hbm_bytes_per_launch': ent['hbm_bytes_per_dispatch'], 'source': 'profiles/hbm_traffic.json'}
 
 
 def cpu_baseline(cfg, size, budget_s):
