@@ -197,26 +197,15 @@ def main():
         if not args.no_nms:
             non_max_suppression(inf, conf_thres=0.3, iou_thres=0.6, multi_label=False)
 
+    from engine import distutil
+
     def barrier():
-        if dist is not None:
-            dist.barrier()
+        distutil.barrier(dist)
 
     for _ in range(args.warmup):
         step()
-    torch.cuda.synchronize()
-    barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    # barrier + synchronize on both sides of exactly K steps; MAX over ranks (engine/distutil.py)
+    elapsed = distutil.timed_region(step, args.steps, dist, device)
 
     if rank == 0:
         images = world * args.batch * args.steps

@@ -122,6 +122,41 @@ int yh_stem_pack_weights(const float* w, const float* conv_bias, const float* bn
 int yh_conv2d_stem_fwd(const yh_stem_desc* d, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------
+ * Depthwise block: y = act(dwconv(x, W') + b'), one k x k filter per channel (k = 3 or 5 in the MobilenetV3 /
+ * GhostNet cfgs).  Replaces nn.Sequential(DepthWise2d, BatchNorm2d, activation) (models.py:176-197) and the
+ * groups == channels form of models.py:92-98.  HBM-bound: 16-byte channel vectors, weights stay in L1/L2.
+ *   yh_dw_pack_weights: w fp32 [c][1][k][k] (+ optional conv bias / BN as in yh_conv_pack_weights); ch_map maps
+ *   logical to physical channel (NULL = identity); packed out is dtype [k*k][c_phys], bias_out fp32 [c_phys].   */
+typedef struct yh_dw_desc {
+    const void* x;
+    const void* w;
+    const float* bias;
+    void* y;
+    int32_t n, h, w_in, c, ho, wo, k, stride, pad, ldx, ldy, act;
+    float slope;
+    int32_t dtype;
+} yh_dw_desc;
+int yh_dw_pack_weights(int dtype, const float* w, const float* conv_bias, const float* bn_gamma, const float* bn_beta,
+                       const float* bn_mean, const float* bn_var, float bn_eps, const int32_t* ch_map, int c, int k,
+                       int c_phys, void* packed, float* bias_out, void* stream);
+int yh_dwconv2d_fwd(const yh_dw_desc* d, void* stream);
+
+/* Squeeze-excite, SE.forward (utils/layers.py:188-192): y = x * hsigmoid(W2 relu(W1 avgpool(x))), both Linear
+ * layers bias-free.  w1 fp32 [cr][c], w2 fp32 [c][cr] (nn.Linear.weight layout, logical channels); pooled and
+ * gate are caller-provided fp32 scratch [n][c_phys]; ch_map as above.  Three launches: pool, FC pair, scale.   */
+typedef struct yh_se_desc {
+    const void* x;
+    void* y;
+    const float* w1;
+    const float* w2;
+    float* pooled;
+    float* gate;
+    const int32_t* ch_map;
+    int32_t n, h, w_in, c, c_phys, cr, ldx, ldy, dtype;
+} yh_se_desc;
+int yh_se_fwd(const yh_se_desc* d, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------
  * nn.MaxPool2d (models.py:207-215).  pad_lo cells of -inf are implied on the top/left, the window may
  * run past the bottom/right edge: out-of-range taps read `edge_zero ? 0 : -inf` (edge_zero=1 reproduces
  * the ZeroPad2d((0,1,0,1)) + MaxPool2d(2,1) pair of yolov3-tiny).                                       */
@@ -208,7 +243,8 @@ int yh_nms_merge(const float* sorted, const int32_t* count, const int32_t* keep_
  * from call to call (network input, per-call outputs) are "slots": a fixup patches one pointer field
  * of one recorded op with slot_base + byte_offset right before launch.                                  */
 typedef struct yh_plan yh_plan;
-enum { YH_OP_CONV = 1, YH_OP_STEM = 2, YH_OP_POOL = 3, YH_OP_COPY = 4, YH_OP_ADD = 5, YH_OP_DECODE = 6 };
+enum { YH_OP_CONV = 1, YH_OP_STEM = 2, YH_OP_POOL = 3, YH_OP_COPY = 4, YH_OP_ADD = 5, YH_OP_DECODE = 6, YH_OP_DW = 7,
+       YH_OP_SE = 8 };
 
 yh_plan* yh_plan_create(void);
 void yh_plan_destroy(yh_plan* p);

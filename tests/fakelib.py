@@ -15,11 +15,11 @@ import torch
 import torch.nn.functional as F
 
 from engine import hiplib
-from engine.hiplib import ConvDesc, StemDesc, PoolDesc, CopyDesc, AddDesc, DecodeDesc
+from engine.hiplib import ConvDesc, StemDesc, PoolDesc, CopyDesc, AddDesc, DecodeDesc, DwDesc, SeDesc
 
 _NP = {hiplib.YH_F16: np.float16, hiplib.YH_F32: np.float32}
 _DESC = {hiplib.OP_CONV: ConvDesc, hiplib.OP_STEM: StemDesc, hiplib.OP_POOL: PoolDesc, hiplib.OP_COPY: CopyDesc,
-         hiplib.OP_ADD: AddDesc, hiplib.OP_DECODE: DecodeDesc}
+         hiplib.OP_ADD: AddDesc, hiplib.OP_DECODE: DecodeDesc, hiplib.OP_DW: DwDesc, hiplib.OP_SE: SeDesc}
 
 
 def _addr(p):
@@ -111,7 +111,50 @@ class FakeLib:
         bo[:cout] = b.numpy()
         return 0
 
+    def yh_dw_pack_weights(self, dtype, w, cb, g, be, mu, var, eps, cmap, c, k, c_phys, packed, bias_out, stream):
+        t = lambda p, n: None if not _addr(p) else torch.from_numpy(flat(p, n, np.float32).copy())
+        W = t(w, c * k * k).view(c, 1, k, k)
+        Wf, b = self._fold(W, t(cb, c), t(g, c), t(be, c), t(mu, c), t(var, c), eps, c)
+        m = torch.arange(c) if not _addr(cmap) else torch.from_numpy(flat(cmap, c, np.int32).copy()).long()
+        img = torch.zeros(k * k, c_phys)
+        img[:, m] = Wf.view(c, k * k).t()
+        flat(packed, k * k * c_phys, _NP[dtype])[:] = img.reshape(-1).numpy().astype(_NP[dtype])
+        bo = flat(bias_out, c_phys, np.float32)
+        bo[:] = 0
+        bo[m.numpy()] = b.numpy()
+        return 0
+
     # ---- ops
+    def yh_dwconv2d_fwd(self, dref, stream):
+        d = dref._obj if hasattr(dref, '_obj') else dref
+        npdt = _NP[d.dtype]
+        x = torch.from_numpy(pitched(d.x, d.n * d.h * d.w_in, d.c, d.ldx, npdt).astype(np.float32))
+        x = x.view(d.n, d.h, d.w_in, d.c).permute(0, 3, 1, 2)
+        w = torch.from_numpy(flat(d.w, d.k * d.k * d.c, npdt).astype(np.float32)).view(d.k, d.k, d.c).permute(2, 0, 1)
+        b = torch.from_numpy(flat(d.bias, d.c, np.float32).copy())
+        y = _act(F.conv2d(x, w.unsqueeze(1).contiguous(), b, stride=d.stride, padding=d.pad, groups=d.c), d.act, d.slope)
+        assert y.shape[2] == d.ho and y.shape[3] == d.wo
+        pitched(d.y, d.n * d.ho * d.wo, d.c, d.ldy, npdt)[:] = y.permute(0, 2, 3, 1).reshape(-1, d.c).numpy().astype(npdt)
+        return 0
+
+    def yh_se_fwd(self, dref, stream):
+        d = dref._obj if hasattr(dref, '_obj') else dref
+        npdt = _NP[d.dtype]
+        hw = d.h * d.w_in
+        x = torch.from_numpy(pitched(d.x, d.n * hw, d.c_phys, d.ldx, npdt).astype(np.float32)).view(d.n, hw, d.c_phys)
+        m = torch.arange(d.c) if not _addr(d.ch_map) else torch.from_numpy(flat(d.ch_map, d.c, np.int32).copy()).long()
+        w1 = torch.from_numpy(flat(d.w1, d.cr * d.c, np.float32).copy()).view(d.cr, d.c)
+        w2 = torch.from_numpy(flat(d.w2, d.c * d.cr, np.float32).copy()).view(d.c, d.cr)
+        pooled = x.mean(1)
+        hidden = (pooled[:, m] @ w1.t()).clamp(min=0)
+        gate = torch.zeros(d.n, d.c_phys)
+        gate[:, m] = ((hidden @ w2.t()) + 3).clamp(0, 6) / 6
+        flat(d.pooled, d.n * d.c_phys, np.float32)[:] = pooled.reshape(-1).numpy()
+        flat(d.gate, d.n * d.c_phys, np.float32)[:] = gate.reshape(-1).numpy()
+        y = x * gate[:, None, :]
+        pitched(d.y, d.n * hw, d.c_phys, d.ldy, npdt)[:] = y.reshape(-1, d.c_phys).numpy().astype(npdt)
+        return 0
+
     def yh_conv2d_fwd(self, dref, stream):
         d = dref._obj if hasattr(dref, '_obj') else dref
         npdt = _NP[d.dtype]
@@ -243,7 +286,8 @@ class FakeLib:
         plan = self.plans[_addr(h)]
         run = {hiplib.OP_CONV: self.yh_conv2d_fwd, hiplib.OP_STEM: self.yh_conv2d_stem_fwd,
                hiplib.OP_POOL: self.yh_maxpool2d_fwd, hiplib.OP_COPY: self.yh_copy_channels,
-               hiplib.OP_ADD: self.yh_add_channels, hiplib.OP_DECODE: self.yh_yolo_decode}
+               hiplib.OP_ADD: self.yh_add_channels, hiplib.OP_DECODE: self.yh_yolo_decode,
+               hiplib.OP_DW: self.yh_dwconv2d_fwd, hiplib.OP_SE: self.yh_se_fwd}
         for kind, desc, fixups in plan['ops'][first:last]:
             d = type(desc).from_buffer_copy(bytes(desc))
             for off, slot, boff in fixups:

@@ -31,6 +31,7 @@ NET_CASES = [
     ('yolov3_320', 'yolov3/yolov3.cfg', 320, 1, 16),
     ('yolov4_320', 'yolov4/yolov4.cfg', 320, 1, 16),
     ('yolov3_608', 'yolov3/yolov3.cfg', 608, 1, 64),
+    ('mobilenet_224', 'yolov3-mobilenet/yolov3-mobilenet-coco.cfg', 224, 2, 4),
 ]
 
 
@@ -133,8 +134,13 @@ def decode_fixture(ref):
 def main():
     ref = refharness.load()
     torch.set_num_threads(8)
+    only = sys.argv[1:]
     for case in NET_CASES:
+        if only and case[0] not in only:
+            continue
         net_fixture(ref, *case)
+    if only:
+        return
     nms_fixtures(ref)
     fuse_fixture(ref)
     decode_fixture(ref)

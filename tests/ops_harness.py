@@ -8,7 +8,7 @@ import ctypes as C
 import torch
 
 from engine import hiplib
-from engine.hiplib import ConvDesc, StemDesc, PoolDesc, CopyDesc, AddDesc, DecodeDesc
+from engine.hiplib import ConvDesc, StemDesc, PoolDesc, CopyDesc, AddDesc, DecodeDesc, DwDesc, SeDesc
 
 P = hiplib.ptr
 
@@ -127,3 +127,37 @@ def decode(lib, p, na, no, stride, anchor_vec, rows_total=None, row_off=0, want_
     rc = lib.yh_yolo_decode(C.byref(d), stream())
     assert rc == 0, rc
     return io, raw
+
+
+def dwconv(lib, code, x, w, bn=None, cb=None, eps=1e-5, stride=1, act=3, slope=0.1, cmap=None, c_phys=None, x_off=0):
+    """x: (N,H,W,ldx) NHWC; w: (C,1,k,k) fp32 on the same device; depthwise over channels [x_off, x_off + c_phys)."""
+    N, H, W, ldx = x.shape
+    c, _, k, _ = w.shape
+    c_phys = c_phys or round_up(c, 8)
+    pad = (k - 1) // 2
+    packed = torch.full((k * k * c_phys,), 7.0, device=x.device, dtype=tdtype(code))
+    bias = torch.full((c_phys,), 7.0, device=x.device, dtype=torch.float32)
+    g, be, mu, var = bn if bn is not None else (None, None, None, None)
+    rc = lib.yh_dw_pack_weights(code, P(w), P(cb), P(g), P(be), P(mu), P(var), eps, P(cmap), c, k, c_phys, P(packed), P(bias),
+                                stream())
+    assert rc == 0, rc
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    y = torch.full((N, Ho, Wo, c_phys), 3.0, device=x.device, dtype=x.dtype)
+    d = DwDesc(x=P(x, x_off), w=P(packed), bias=P(bias), y=P(y), n=N, h=H, w_in=W, c=c_phys, ho=Ho, wo=Wo, k=k, stride=stride,
+               pad=pad, ldx=ldx, ldy=c_phys, act=act, slope=slope, dtype=code)
+    rc = lib.yh_dwconv2d_fwd(C.byref(d), stream())
+    assert rc == 0, rc
+    return y, packed, bias
+
+
+def se(lib, code, x, w1, w2, c, cmap=None):
+    """x: (N,H,W,c_phys) NHWC; w1 (cr,c), w2 (c,cr) fp32."""
+    N, H, W, c_phys = x.shape
+    pooled = torch.empty((N, c_phys), device=x.device, dtype=torch.float32)
+    gate = torch.empty((N, c_phys), device=x.device, dtype=torch.float32)
+    y = torch.full_like(x, 3.0)
+    d = SeDesc(x=P(x), y=P(y), w1=P(w1), w2=P(w2), pooled=P(pooled), gate=P(gate), ch_map=P(cmap), n=N, h=H, w_in=W, c=c,
+               c_phys=c_phys, cr=w1.shape[0], ldx=c_phys, ldy=c_phys, dtype=code)
+    rc = lib.yh_se_fwd(C.byref(d), stream())
+    assert rc == 0, rc
+    return y, gate

@@ -210,3 +210,44 @@ def test_decode_matches_emulation_and_oracle(libs):
     io_o, raw_o = oracle.yolo_decode(p[..., :na * no].permute(0, 3, 1, 2).contiguous(), anchors, 16.0, nc)
     np.testing.assert_allclose(iog[:, 6:6 + na * ny * nx].numpy(), io_o.numpy(), rtol=2e-6, atol=2e-5)
     assert torch.equal(iog[:, :6], torch.full_like(iog[:, :6], -1.0))
+
+
+@pytest.mark.parametrize('code', [F32, F16], ids=['fp32', 'fp16'])
+@pytest.mark.parametrize('c,k,s,H,act', [(72, 3, 1, 20, 3), (64, 3, 2, 21, 3), (120, 5, 1, 14, 3), (72, 5, 2, 26, 4), (960, 5, 1, 7, 4),
+                                        (20, 3, 1, 9, 1)])
+def test_depthwise_matches_emulation(libs, code, c, k, s, H, act):
+    lib, fake = libs
+    g = torch.Generator().manual_seed(15)
+    dt = oh.tdtype(code)
+    c_phys = oh.round_up(c, 8)
+    x = _rand(g, 2, H, H + 2, c_phys + 8).to(dt)
+    w = _rand(g, c, 1, k, k, scale=0.4)
+    bn = _bn(g, c)
+    res = []
+    for L, dev in ((lib, GPU), (fake, 'cpu')):
+        y, pk, b = oh.dwconv(L, code, x.to(dev), w.to(dev), tuple(t.to(dev) for t in bn), stride=s, act=act, x_off=8)
+        res.append((y.float().cpu(), pk.float().cpu(), b.cpu()))
+    (yg, pg, bg), (yc, pc, bc) = res
+    assert (pg - pc).abs().max() <= (3e-7 if code == F32 else 1e-3) * pc.abs().max()
+    tol = 2e-5 if code == F32 else 2.5e-3
+    assert (yg - yc).abs().max().item() <= tol * (yc.abs().max().item() + 1e-6)
+    if c_phys > c:
+        assert torch.equal(yg[..., c:], torch.zeros_like(yg[..., c:])), 'pad channels must stay exactly zero'
+
+
+@pytest.mark.parametrize('code', [F32, F16], ids=['fp32', 'fp16'])
+@pytest.mark.parametrize('c,H', [(72, 26), (480, 13), (960, 7), (20, 5)])
+def test_squeeze_excite_matches_emulation(libs, code, c, H):
+    lib, fake = libs
+    g = torch.Generator().manual_seed(16)
+    dt = oh.tdtype(code)
+    c_phys = oh.round_up(c, 8)
+    x = _rand(g, 3, H, H + 1, c_phys).to(dt)
+    x[..., c:] = 0
+    w1 = _rand(g, c // 4, c, scale=c ** -0.5 * 4)
+    w2 = _rand(g, c, c // 4, scale=(c // 4) ** -0.5 * 4)
+    res = [tuple(t.float().cpu() for t in oh.se(L, code, x.to(dev), w1.to(dev), w2.to(dev), c)) for L, dev in ((lib, GPU), (fake, 'cpu'))]
+    (yg, gg), (yc, gc) = res
+    assert (gg - gc).abs().max().item() <= 2e-5
+    tol = 2e-5 if code == F32 else 2.5e-3
+    assert (yg - yc).abs().max().item() <= tol * (yc.abs().max().item() + 1e-6)

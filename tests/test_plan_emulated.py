@@ -15,7 +15,7 @@ import synth
 from engine.plan import DarknetEngine
 from test_oracle_golden import GOLD, build_mirror
 
-CASES = ['tiny_hand_416', 'yolov3_320', 'yolov4_320']
+CASES = ['tiny_hand_416', 'yolov3_320', 'yolov4_320', 'mobilenet_224']
 
 
 @pytest.mark.parametrize('name', CASES)
@@ -38,7 +38,7 @@ def test_lowered_network_matches_reference_golden(name, prec, cfg_dir):
         assert (r - rr).abs().max().item() <= (2e-4 if prec == 'fp32' else 0.05)
     plan = next(iter(eng._plans.values()))
     kinds = {''.join(c for c in what if not c.isdigit()) for what, _ in plan['ops']}
-    assert kinds <= {'stem', 'conv', 'pool', 'yolo'}, 'shortcut/route/upsample must all be fused: %s' % kinds
+    assert kinds <= {'stem', 'conv', 'pool', 'yolo', 'dw', 'se'}, 'shortcut/route/upsample must all be fused: %s' % kinds
 
 
 def _odd_cfg():
@@ -83,6 +83,36 @@ def test_odd_widths_and_unfused_paths(prec):
     plan = next(iter(eng._plans.values()))
     kinds = [''.join(c for c in what if not c.isdigit()) for what, _ in plan['ops']]
     assert 'add' in kinds and 'ups' in kinds and 'cat' in kinds  # the non-fused forms were exercised
+
+
+def _odd_mobile_cfg():
+    """Depthwise + squeeze-excite on channel counts that need padding (13, 20) and a 5x5 kernel."""
+    net = {'type': 'net', 'width': 64, 'height': 64, 'channels': 3}
+    conv = lambda f, k, s=1, act='leaky', bn=1: {'type': 'convolutional', 'batch_normalize': bn, 'filters': f, 'size': k,
+                                                 'stride': s, 'pad': 1, 'activation': act}
+    dw = lambda f, k, s, act: {'type': 'depthwise', 'batch_normalize': 1, 'filters': f, 'size': k, 'stride': s, 'pad': 1,
+                                'activation': act}
+    anchors = np.array([[10., 13.], [16., 30.], [33., 23.]])
+    return [net, conv(13, 3, 2, 'h_swish'), conv(20, 1, 1, 'relu6'), dw(20, 5, 1, 'relu6'), {'type': 'se', 'filters': 20},
+            conv(13, 1, 1, 'linear'), {'type': 'shortcut', 'from': [-5], 'activation': 'linear'},
+            conv(24, 1, 1, 'h_swish'), dw(24, 3, 2, 'h_swish'), {'type': 'route', 'layers': [-1, -1]},
+            conv(24, 1, 1, 'linear', 0), {'type': 'yolo', 'mask': [0, 1, 2], 'anchors': anchors, 'classes': 3, 'num': 3}]
+
+
+@pytest.mark.parametrize('prec', ['fp32', 'fp16'])
+def test_depthwise_and_se_on_padded_channels(prec):
+    import models
+    torch.manual_seed(11)
+    model = models.Darknet(_odd_mobile_cfg(), (64, 64))
+    model.load_state_dict(synth.randomize_bn_(model.state_dict(), seed=12))
+    model.eval()
+    x = synth.image_batch(2, 64, seed=13)
+    with torch.no_grad():
+        ref, raws_ref, _ = model(x)
+    eng = DarknetEngine(model, precision=prec, lib=fakelib.FakeLib())
+    io, raws, _ = eng(x)
+    tol = 2e-4 if prec == 'fp32' else 0.08
+    assert (io - ref).abs().max().item() <= tol
 
 
 def test_weight_edits_are_picked_up():

@@ -17,6 +17,8 @@ union AnyDesc {
     yh_copy_desc copy;
     yh_add_desc add;
     yh_decode_desc decode;
+    yh_dw_desc dw;
+    yh_se_desc se;
 };
 
 struct Fixup {
@@ -39,6 +41,8 @@ size_t desc_size(int kind) {
         case YH_OP_COPY: return sizeof(yh_copy_desc);
         case YH_OP_ADD: return sizeof(yh_add_desc);
         case YH_OP_DECODE: return sizeof(yh_decode_desc);
+        case YH_OP_DW: return sizeof(yh_dw_desc);
+        case YH_OP_SE: return sizeof(yh_se_desc);
         default: return 0;
     }
 }
@@ -51,6 +55,8 @@ int launch(int kind, const AnyDesc& d, void* stream) {
         case YH_OP_COPY: return yh_copy_channels(&d.copy, stream);
         case YH_OP_ADD: return yh_add_channels(&d.add, stream);
         case YH_OP_DECODE: return yh_yolo_decode(&d.decode, stream);
+        case YH_OP_DW: return yh_dwconv2d_fwd(&d.dw, stream);
+        case YH_OP_SE: return yh_se_fwd(&d.se, stream);
         default: return YH_EINVAL;
     }
 }

@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(os.path.dirname(_HERE), 'libyolo_hip.so')
 
 YH_F16, YH_F32 = 0, 1
 ACT_CODES = {'linear': 0, 'leaky': 1, 'relu': 2, 'relu6': 3, 'h_swish': 4, 'mish': 5}
-OP_CONV, OP_STEM, OP_POOL, OP_COPY, OP_ADD, OP_DECODE = 1, 2, 3, 4, 5, 6
+OP_CONV, OP_STEM, OP_POOL, OP_COPY, OP_ADD, OP_DECODE, OP_DW, OP_SE = 1, 2, 3, 4, 5, 6, 7, 8
 
 _i32, _f32, _vp, _i64 = C.c_int32, C.c_float, C.c_void_p, C.c_int64
 
@@ -58,8 +58,21 @@ class DecodeDesc(C.Structure):
                 ('anchor_w', _f32 * 8), ('anchor_h', _f32 * 8)]
 
 
+class DwDesc(C.Structure):
+    _fields_ = [('x', _vp), ('w', _vp), ('bias', _vp), ('y', _vp),
+                ('n', _i32), ('h', _i32), ('w_in', _i32), ('c', _i32), ('ho', _i32), ('wo', _i32), ('k', _i32),
+                ('stride', _i32), ('pad', _i32), ('ldx', _i32), ('ldy', _i32), ('act', _i32), ('slope', _f32),
+                ('dtype', _i32)]
+
+
+class SeDesc(C.Structure):
+    _fields_ = [('x', _vp), ('y', _vp), ('w1', _vp), ('w2', _vp), ('pooled', _vp), ('gate', _vp), ('ch_map', _vp),
+                ('n', _i32), ('h', _i32), ('w_in', _i32), ('c', _i32), ('c_phys', _i32), ('cr', _i32), ('ldx', _i32),
+                ('ldy', _i32), ('dtype', _i32)]
+
+
 OP_KIND = {ConvDesc: OP_CONV, StemDesc: OP_STEM, PoolDesc: OP_POOL, CopyDesc: OP_COPY, AddDesc: OP_ADD,
-           DecodeDesc: OP_DECODE}
+           DecodeDesc: OP_DECODE, DwDesc: OP_DW, SeDesc: OP_SE}
 
 _SIGNATURES = {
     'yh_abi_version': (C.c_int, []),
@@ -71,6 +84,9 @@ _SIGNATURES = {
     'yh_stem_pack_weights': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _f32, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                        _vp, _vp, _vp]),
     'yh_conv2d_stem_fwd': (C.c_int, [C.POINTER(StemDesc), _vp]),
+    'yh_dw_pack_weights': (C.c_int, [C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _f32, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp]),
+    'yh_dwconv2d_fwd': (C.c_int, [C.POINTER(DwDesc), _vp]),
+    'yh_se_fwd': (C.c_int, [C.POINTER(SeDesc), _vp]),
     'yh_maxpool2d_fwd': (C.c_int, [C.POINTER(PoolDesc), _vp]),
     'yh_copy_channels': (C.c_int, [C.POINTER(CopyDesc), _vp]),
     'yh_add_channels': (C.c_int, [C.POINTER(AddDesc), _vp]),

@@ -30,7 +30,7 @@ import torch
 import torch.nn as nn
 
 from . import hiplib
-from .hiplib import ConvDesc, StemDesc, PoolDesc, CopyDesc, AddDesc, DecodeDesc
+from .hiplib import ConvDesc, StemDesc, PoolDesc, CopyDesc, AddDesc, DecodeDesc, DwDesc, SeDesc
 
 SLOT_INPUT, SLOT_IO, SLOT_RAW0 = 0, 1, 2
 ALIGN_C = 8  # physical channel granularity of every NHWC buffer (16 bytes of fp16)
@@ -152,9 +152,19 @@ class DarknetEngine:
             hidden = False  # True when this block's own output is fused away into its follower
             if kind in ('convolutional', 'depthwise'):
                 conv, bn = _conv_parts(module)
-                if conv.groups != 1:
-                    raise NotImplementedError('HIP engine: grouped/depthwise conv (block %d) not lowered yet' % i)
                 k, s, p = conv.kernel_size[0], conv.stride[0], conv.padding[0]
+                if conv.groups != 1:
+                    if not (conv.groups == conv.in_channels == conv.out_channels == cur.C) or cur.kind == 'input':
+                        raise NotImplementedError('HIP engine: grouped conv with groups != channels (block %d)' % i)
+                    Ho, Wo = (cur.H + 2 * p - k) // s + 1, (cur.W + 2 * p - k) // s + 1
+                    act, slope = _activation_of(module)
+                    v = Value('dw', cur.C, Ho, Wo, block=i, src=cur, conv=conv, bn=bn, k=k, stride=s, pad=p, act=act,
+                              slope=slope)
+                    v.segs, v.c_phys = list(cur.segs), cur.c_phys
+                    values.append(v)
+                    cur = v
+                    outs[i] = cur
+                    continue
                 if conv.kernel_size[0] != conv.kernel_size[1] or conv.in_channels != cur.C:
                     raise NotImplementedError('HIP engine: unsupported conv geometry at block %d' % i)
                 Ho, Wo = (cur.H + 2 * p - k) // s + 1, (cur.W + 2 * p - k) // s + 1
@@ -186,6 +196,15 @@ class DarknetEngine:
                     pad_lo, edge_zero = (k - 1) // 2, 0
                     Ho, Wo = (cur.H + 2 * pad_lo - k) // s + 1, (cur.W + 2 * pad_lo - k) // s + 1
                 v = Value('pool', cur.C, Ho, Wo, block=i, src=cur, k=k, stride=s, pad_lo=pad_lo, edge_zero=edge_zero)
+                v.segs, v.c_phys = list(cur.segs), cur.c_phys
+                values.append(v)
+                cur = v
+            elif kind == 'se':
+                se = module[0] if isinstance(module, nn.Sequential) else module
+                fc1, fc2 = se.fc[0], se.fc[2]
+                if fc1.in_features != cur.C or fc2.out_features != cur.C or fc1.bias is not None or fc2.bias is not None:
+                    raise NotImplementedError('HIP engine: unsupported SE geometry at block %d' % i)
+                v = Value('se', cur.C, cur.H, cur.W, block=i, src=cur, fc1=fc1, fc2=fc2)
                 v.segs, v.c_phys = list(cur.segs), cur.c_phys
                 values.append(v)
                 cur = v
@@ -266,7 +285,7 @@ class DarknetEngine:
             for s, off in zip(v.srcs, v.offsets):
                 if s.kind == 'input':
                     raise NotImplementedError('HIP engine: route over the network input')
-                inplace = (s.kind in ('conv', 'pool', 'copy', 'add') and s.parent is None and id(s) not in seen
+                inplace = (s.kind in ('conv', 'pool', 'copy', 'add', 'dw', 'se') and s.parent is None and id(s) not in seen
                            and not s.fp32 and s.storage is None)
                 if inplace:
                     s.parent, s.parent_off = v, off
@@ -282,6 +301,8 @@ class DarknetEngine:
                 out.extend(t for t in (conv.weight, conv.bias) if t is not None)
                 if bn is not None:
                     out.extend((bn.weight, bn.bias, bn.running_mean, bn.running_var))
+            elif isinstance(block, nn.Sequential) and len(block) and block[0].__class__.__name__ == 'SE':
+                out.extend((block[0].fc[0].weight, block[0].fc[2].weight))
         return out
 
     def _current_signature(self):
@@ -325,6 +346,46 @@ class DarknetEngine:
                                                hiplib.stream_ptr())
             hiplib.check(rc, 'yh_conv_pack_weights')
         slot['keep'] = keep  # fp32 staging copies must outlive the async pack kernels
+        self._packed[v.block] = slot
+        return slot
+
+    def _pack_dw(self, v):
+        conv, bn = v.conv, v.bn
+        dev = conv.weight.device
+        f32 = lambda t: None if t is None else t.detach().float().contiguous()
+        w, cb = f32(conv.weight), f32(conv.bias)
+        g, be, mu, var = (f32(bn.weight), f32(bn.bias), f32(bn.running_mean), f32(bn.running_var)) if bn is not None \
+            else (None, None, None, None)
+        eps = float(bn.eps) if bn is not None else 0.0
+        keep = [w, cb, g, be, mu, var]
+        cmap = None
+        if not v.src.is_dense():
+            cmap = torch.tensor(v.src.channel_map(), dtype=torch.int32, device=dev)
+            keep.append(cmap)
+        P = hiplib.ptr
+        slot = self._packed.get(v.block)
+        taps = v.k * v.k
+        if slot is None or slot['w'].numel() != taps * v.c_phys or slot['w'].dtype != self.dtype:
+            slot = dict(w=torch.empty(taps * v.c_phys, device=dev, dtype=self.dtype),
+                        b=torch.empty(v.c_phys, device=dev, dtype=torch.float32))
+        rc = self.lib.yh_dw_pack_weights(self.code, P(w), P(cb), P(g), P(be), P(mu), P(var), eps, P(cmap), v.C, v.k, v.c_phys,
+                                         P(slot['w']), P(slot['b']), hiplib.stream_ptr())
+        hiplib.check(rc, 'yh_dw_pack_weights')
+        slot['keep'] = keep
+        self._packed[v.block] = slot
+        return slot
+
+    def _pack_se(self, v, N):
+        dev = v.fc1.weight.device
+        slot = self._packed.get(v.block)
+        w1 = v.fc1.weight.detach().float().contiguous()
+        w2 = v.fc2.weight.detach().float().contiguous()
+        if slot is None or slot['w1'].shape != w1.shape:
+            slot = dict(w1=torch.empty_like(w1), w2=torch.empty_like(w2), cmap=None)
+            if not v.src.is_dense():
+                slot['cmap'] = torch.tensor(v.src.channel_map(), dtype=torch.int32, device=dev)
+        slot['w1'].copy_(w1)
+        slot['w2'].copy_(w2)
         self._packed[v.block] = slot
         return slot
 
@@ -400,6 +461,21 @@ class DarknetEngine:
                                  ldr=0 if v.res is None else v.res.ld, ldy=v.ld, cin_k=pk['cin_k'], m_pad=pk['m_pad'],
                                  act=v.act, slope=v.slope, ups=v.ups, out_f32=1 if v.fp32 else 0, dtype=self.code, tile=tile)
                     add(d, 'conv%d' % v.block)
+            elif v.kind == 'dw':
+                pk = self._packed.get(v.block) or self._pack_dw(v)
+                s = v.src
+                add(DwDesc(x=P(s.storage, s.c_off), w=P(pk['w']), bias=P(pk['b']), y=y, n=N, h=s.H, w_in=s.W, c=s.c_phys,
+                           ho=v.H, wo=v.W, k=v.k, stride=v.stride, pad=v.pad, ldx=s.ld, ldy=v.ld, act=v.act, slope=v.slope,
+                           dtype=self.code), 'dw%d' % v.block)
+            elif v.kind == 'se':
+                pk = self._packed.get(v.block) or self._pack_se(v, N)
+                s = v.src
+                pooled = torch.empty((N, v.c_phys), device=self.device, dtype=torch.float32)
+                gate = torch.empty((N, v.c_phys), device=self.device, dtype=torch.float32)
+                plan['storages'].extend((pooled, gate))
+                add(SeDesc(x=P(s.storage, s.c_off), y=y, w1=P(pk['w1']), w2=P(pk['w2']), pooled=P(pooled), gate=P(gate),
+                           ch_map=P(pk['cmap']), n=N, h=s.H, w_in=s.W, c=v.C, c_phys=v.c_phys, cr=pk['w1'].shape[0],
+                           ldx=s.ld, ldy=v.ld, dtype=self.code), 'se%d' % v.block)
             elif v.kind == 'pool':
                 s = v.src
                 add(PoolDesc(x=P(s.storage, s.c_off), y=y, n=N, h=s.H, w_in=s.W, c=s.c_phys, ho=v.H, wo=v.W, k=v.k,
@@ -450,6 +526,10 @@ class DarknetEngine:
             for v in plan['values']:
                 if v.kind == 'conv':
                     self._pack_conv(v)
+                elif v.kind == 'dw':
+                    self._pack_dw(v)
+                elif v.kind == 'se':
+                    self._pack_se(v, plan['N'])
             break
         self._signature = self._current_signature()
 

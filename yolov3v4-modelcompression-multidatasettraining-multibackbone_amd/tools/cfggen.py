@@ -40,6 +40,12 @@ class CfgWriter:
         kv.update(filters=filters, size=size, stride=stride, pad=1, activation=act)
         return self.block('convolutional', **kv)
 
+    def depthwise(self, filters, size, stride=1, act='relu6'):
+        return self.block('depthwise', batch_normalize=1, filters=filters, size=size, stride=stride, pad=1, activation=act)
+
+    def se(self, filters):
+        return self.block('se', filters=filters)
+
     def shortcut(self, frm=-3):
         return self.block('shortcut', from_=frm, activation='linear')
 
@@ -202,7 +208,52 @@ def yolov4(classes=80, size=608, anchors=COCO_ANCHORS_V4):
     return w.text()
 
 
+# MobileNetV3-large bottlenecks: kernel, expansion, out, squeeze-excite, nonlinearity, stride
+MBV3_LARGE = [(3, 16, 16, 0, 'relu6', 1), (3, 64, 24, 0, 'relu6', 2), (3, 72, 24, 0, 'relu6', 1), (5, 72, 40, 1, 'relu6', 2),
+              (5, 120, 40, 1, 'relu6', 1), (5, 120, 40, 1, 'relu6', 1), (3, 240, 80, 0, 'h_swish', 2),
+              (3, 200, 80, 0, 'h_swish', 1), (3, 184, 80, 0, 'h_swish', 1), (3, 184, 80, 0, 'h_swish', 1),
+              (3, 480, 112, 1, 'h_swish', 1), (3, 672, 112, 1, 'h_swish', 1), (5, 672, 160, 1, 'h_swish', 2),
+              (5, 960, 160, 1, 'h_swish', 1), (5, 960, 160, 1, 'h_swish', 1)]
+
+
+def yolov3_mobilenet(classes=80, size=416, anchors=COCO_ANCHORS_V3):
+    """MobileNetV3-large backbone (depthwise + squeeze-excite bottlenecks) under the YOLOv3 neck and heads."""
+    w = CfgWriter()
+    _net_v3(w, size)
+    head_filters = 3 * (classes + 5)
+    w.conv(16, 3, stride=2, act='h_swish')
+    cin, taps = 16, {}
+    for k, exp, out, se, nl, stride in MBV3_LARGE:
+        w.conv(exp, 1, act=nl)
+        w.depthwise(exp, k, stride, act=nl)
+        if se:
+            w.se(exp)
+        w.conv(out, 1, act='linear')
+        if stride == 1 and cin == out:
+            w.shortcut(-5 if se else -4)
+        taps[out] = w.n
+        cin = out
+    w.conv(1024, 1, act='h_swish')
+
+    def head(width, mask):
+        for _ in range(3):
+            w.conv(width, 1)
+            w.conv(width * 2, 3)
+        w.conv(head_filters, 1, act='linear', bn=0)
+        w.yolo(mask, anchors, classes, 9, random=1)
+
+    head(512, (6, 7, 8))
+    for width, mask, skip in ((256, (3, 4, 5), taps[112]), (128, (0, 1, 2), taps[40])):
+        w.route(-4)
+        w.conv(width, 1)
+        w.upsample(2)
+        w.route(-1, skip)
+        head(width, mask)
+    return w.text()
+
+
 GENERATED = {
+    'yolov3-mobilenet/yolov3-mobilenet-coco.cfg': lambda: yolov3_mobilenet(80, 416),
     'yolov3/yolov3.cfg': lambda: yolov3(80, 416),
     'yolov3tiny/yolov3-tiny.cfg': lambda: yolov3_tiny(80, 416),
     'yolov3tiny/yolov3-tiny-hand.cfg': lambda: yolov3_tiny(1, 416, TINY_HAND_ANCHORS, '15,25,60,99,150,160,180',
