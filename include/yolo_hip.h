@@ -32,7 +32,7 @@ extern "C" {
 
 #define YH_ABI_VERSION 1
 
-enum { YH_F16 = 0, YH_F32 = 1 };
+enum { YH_F16 = 0, YH_F32 = 1, YH_I8 = 2 };  /* YH_I8: PTQ eval path on v_mfma_i32_16x16x64_i8 (conv, stem out, pool, copy, qadd) */
 
 /* activation codes: models.py:102-113 (leaky 0.1 / 0.25, relu6, h_swish, relu, mish; else linear) */
 enum { YH_ACT_LINEAR = 0, YH_ACT_LEAKY = 1, YH_ACT_RELU = 2, YH_ACT_RELU6 = 3, YH_ACT_HSWISH = 4, YH_ACT_MISH = 5 };
@@ -95,9 +95,19 @@ typedef struct yh_conv_desc {
     int32_t out_f32;              /* store fp32 regardless of dtype (yolo head inputs)                   */
     int32_t dtype;                /* YH_F16 / YH_F32                                                     */
     int32_t tile;                 /* 0 = auto; else forces a tile config (bench/autotune only)           */
+    float acc_scale;              /* YH_I8 only: s_w * s_x, turns the int32 accumulator into real units   */
+    float out_scale;              /* YH_I8 only: s_a of the block's activation quantizer                  */
 } yh_conv_desc;
 
 int yh_conv2d_fwd(const yh_conv_desc* d, void* stream);
+/* YH_I8 form of the block = eval branch of BNFold_COSPTQuantizedConv2d_For_FPGA.forward
+ * (utils/quantized/quantized_ptq_cos.py:193-212,288-296,543-567,717): x and w hold the int8 grid values
+ * (x = round(x_real/s_x), w = clamp(round(W'/s_w))), bias holds q_bias in real units (int grid * s_b);
+ *   y_real = act(acc_i32 * acc_scale + bias);  y_q = clamp(round_half_away(y_real / out_scale), -128, 127)
+ * stored as int8, or as fp32 y_q * out_scale when out_f32 (yolo head inputs).  cin % 16, cin_k % 64, no residual.
+ * yh_qconv_pack_weights builds the int8 image from the module's q_weight buffer (real units) and its scale.  */
+int yh_qconv_pack_weights(const float* q_weight, float w_scale, const int32_t* cin_map, int cout, int cin, int kh, int kw,
+                          int cin_k, int m_pad, void* packed, void* stream);
 /* Tile configuration yh_conv2d_fwd will use for this descriptor (1 = 128x128, 2 = 64x256, 3 = 32x256,
  * 4 = 64x128, 5 = 128x64, channels x pixels): lets a profiler attribute time to kernel instantiations. */
 int yh_conv2d_tile(const yh_conv_desc* d);
@@ -114,6 +124,7 @@ typedef struct yh_stem_desc {
     int32_t n, cin, h, w_in, ho, wo, cout, cout_pad, kh, kw, stride, pad, ldy, act;
     float slope;
     int32_t dtype;
+    float out_scale;   /* YH_I8 only: the output is quantised, y_q = clamp(round_half_away(y / out_scale)) stored int8 */
 } yh_stem_desc;
 
 int yh_stem_pack_weights(const float* w, const float* conv_bias, const float* bn_gamma, const float* bn_beta,
@@ -188,6 +199,34 @@ typedef struct yh_add_desc {
 int yh_add_channels(const yh_add_desc* d, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------
+ * int8 (PTQ eval) forms of the data-movement blocks.  Tensors are int8 grid values with one power-of-two scale
+ * per tensor kept by the caller; c % 16 == 0, pitches % 16 == 0.
+ *  yh_qcopy   y = clamp(round_half_away(x * ratio)) with optional 2x nearest upsample.  ratio = s_in / s_out:
+ *             1 for a plain slice copy / upsample, otherwise the re-quantisation COSPTQuantizedFeatureConcat
+ *             applies to every routed input (quantized_ptq_cos.py:1540-1545).
+ *  yh_qpool   nn.MaxPool2d on grid values (max commutes with the positive scale); same geometry as yh_pool_desc.
+ *  yh_qadd    COSPTQuantizedShortcut_min/_max eval (quantized_ptq_cos.py:877-912,1029):
+ *               xq = round(x * rx), aq = round(a * ra)            (no clamp; rx = s_x_in / scale_x, ra = s_a_in / scale_a)
+ *               y  = clamp(round((xq * scale_x + aq * scale_a) / scale_sum))                                   */
+typedef struct yh_qcopy_desc {
+    const void* x;
+    void* y;
+    int32_t n, h, w_in, c, ups, ldx, ldy;
+    float ratio;
+} yh_qcopy_desc;
+int yh_qcopy(const yh_qcopy_desc* d, void* stream);
+int yh_qpool(const yh_pool_desc* d, void* stream);   /* dtype field must be YH_I8 */
+typedef struct yh_qadd_desc {
+    const void* x;
+    const void* a;
+    void* y;
+    int64_t pixels;
+    int32_t c, ldx, lda, ldy;
+    float rx, ra, scale_x, scale_a, inv_scale_sum;
+} yh_qadd_desc;
+int yh_qadd(const yh_qadd_desc* d, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------
  * YOLO head decode, YOLOLayer.forward eval branch (models.py:406-418, grid :367-378, anchors :362):
  *   raw[n][a][y][x][o] = p[n][y][x][a*no + o]
  *   io: xy = (sigmoid(t) + cell) * stride, wh = (exp(t) * anchor) * stride, obj/cls = sigmoid(t)
@@ -244,7 +283,7 @@ int yh_nms_merge(const float* sorted, const int32_t* count, const int32_t* keep_
  * of one recorded op with slot_base + byte_offset right before launch.                                  */
 typedef struct yh_plan yh_plan;
 enum { YH_OP_CONV = 1, YH_OP_STEM = 2, YH_OP_POOL = 3, YH_OP_COPY = 4, YH_OP_ADD = 5, YH_OP_DECODE = 6, YH_OP_DW = 7,
-       YH_OP_SE = 8 };
+       YH_OP_SE = 8, YH_OP_QCOPY = 9, YH_OP_QPOOL = 10, YH_OP_QADD = 11 };
 
 yh_plan* yh_plan_create(void);
 void yh_plan_destroy(yh_plan* p);

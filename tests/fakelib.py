@@ -15,11 +15,13 @@ import torch
 import torch.nn.functional as F
 
 from engine import hiplib
-from engine.hiplib import ConvDesc, StemDesc, PoolDesc, CopyDesc, AddDesc, DecodeDesc, DwDesc, SeDesc
+from engine.hiplib import (ConvDesc, StemDesc, PoolDesc, CopyDesc, AddDesc, DecodeDesc, DwDesc, SeDesc, QCopyDesc, QPoolDesc,
+                           QAddDesc)
 
-_NP = {hiplib.YH_F16: np.float16, hiplib.YH_F32: np.float32}
+_NP = {hiplib.YH_F16: np.float16, hiplib.YH_F32: np.float32, hiplib.YH_I8: np.int8}
 _DESC = {hiplib.OP_CONV: ConvDesc, hiplib.OP_STEM: StemDesc, hiplib.OP_POOL: PoolDesc, hiplib.OP_COPY: CopyDesc,
-         hiplib.OP_ADD: AddDesc, hiplib.OP_DECODE: DecodeDesc, hiplib.OP_DW: DwDesc, hiplib.OP_SE: SeDesc}
+         hiplib.OP_ADD: AddDesc, hiplib.OP_DECODE: DecodeDesc, hiplib.OP_DW: DwDesc, hiplib.OP_SE: SeDesc,
+         hiplib.OP_QCOPY: QCopyDesc, hiplib.OP_QPOOL: QPoolDesc, hiplib.OP_QADD: QAddDesc}
 
 
 def _addr(p):
@@ -44,6 +46,11 @@ def pitched(p, pixels, c, ld, dtype):
     base = flat(p, (pixels - 1) * ld + c, dtype)
     es = base.itemsize
     return np.lib.stride_tricks.as_strided(base, shape=(pixels, c), strides=(ld * es, es), writeable=True)
+
+
+def rnd_away(t):
+    """PTQ rounding: half away from zero (quantized_ptq_cos.py:14-20)."""
+    return torch.sign(t) * torch.floor(torch.abs(t) + 0.5)
 
 
 def _act(v, act, slope):
@@ -155,8 +162,74 @@ class FakeLib:
         pitched(d.y, d.n * hw, d.c_phys, d.ldy, npdt)[:] = y.reshape(-1, d.c_phys).numpy().astype(npdt)
         return 0
 
+    def yh_qconv_pack_weights(self, qw, w_scale, cmap, cout, cin, kh, kw, cin_k, m_pad, packed, stream):
+        W = torch.from_numpy(flat(qw, cout * cin * kh * kw, np.float32).copy()).view(cout, cin, kh, kw)
+        q = rnd_away(W / w_scale).clamp(-128, 127)
+        m = np.arange(cin) if not _addr(cmap) else flat(cmap, cin, np.int32).copy()
+        assert cin_k % 64 == 0 and m_pad % 128 == 0
+        img = torch.zeros(m_pad, kh * kw, cin_k)
+        img[:cout][:, :, torch.from_numpy(m).long()] = q.permute(0, 2, 3, 1).reshape(cout, kh * kw, cin)
+        flat(packed, m_pad * kh * kw * cin_k, np.int8)[:] = img.reshape(-1).numpy().astype(np.int8)
+        return 0
+
+    def _qconv(self, d):
+        assert d.cin % 16 == 0 and d.ldx % 16 == 0 and d.cin_k % 64 == 0 and not _addr(d.res)
+        x = torch.from_numpy(pitched(d.x, d.n * d.h * d.w_in, d.cin, d.ldx, np.int8).astype(np.float64))
+        x = x.view(d.n, d.h, d.w_in, d.cin).permute(0, 3, 1, 2)
+        taps = d.kh * d.kw
+        wimg = torch.from_numpy(flat(d.w, d.m_pad * taps * d.cin_k, np.int8).astype(np.float64)).view(d.m_pad, d.kh, d.kw, d.cin_k)
+        w = wimg[:d.cout, :, :, :d.cin].permute(0, 3, 1, 2).contiguous()
+        b = torch.from_numpy(flat(d.bias, d.m_pad, np.float32)[:d.cout].copy())
+        acc = F.conv2d(x, w, None, stride=d.stride, padding=d.pad)  # exact integer sums in fp64
+        y = (acc.float() * d.acc_scale + b.view(1, -1, 1, 1))
+        y = _act(y, d.act, d.slope)
+        q = rnd_away(y / d.out_scale).clamp(-128, 127)
+        if d.ups == 2:
+            q = q.repeat_interleave(2, 2).repeat_interleave(2, 3)
+        if d.out_f32:
+            out = pitched(d.y, d.n * q.shape[2] * q.shape[3], d.cout, d.ldy, np.float32)
+            out[:] = (q * d.out_scale).permute(0, 2, 3, 1).reshape(-1, d.cout).numpy()
+        else:
+            out = pitched(d.y, d.n * q.shape[2] * q.shape[3], d.cout, d.ldy, np.int8)
+            out[:] = q.permute(0, 2, 3, 1).reshape(-1, d.cout).numpy().astype(np.int8)
+        return 0
+
+    def yh_qcopy(self, dref, stream):
+        d = dref._obj if hasattr(dref, '_obj') else dref
+        x = torch.from_numpy(pitched(d.x, d.n * d.h * d.w_in, d.c, d.ldx, np.int8).astype(np.float32))
+        if d.ratio != 1.0:
+            x = rnd_away(x * d.ratio).clamp(-128, 127)
+        x = x.view(d.n, d.h, d.w_in, d.c)
+        if d.ups == 2:
+            x = x.repeat_interleave(2, 1).repeat_interleave(2, 2)
+        pitched(d.y, d.n * d.h * d.w_in * d.ups * d.ups, d.c, d.ldy, np.int8)[:] = x.reshape(-1, d.c).numpy().astype(np.int8)
+        return 0
+
+    def yh_qpool(self, dref, stream):
+        d = dref._obj if hasattr(dref, '_obj') else dref
+        x = torch.from_numpy(pitched(d.x, d.n * d.h * d.w_in, d.c, d.ldx, np.int8).astype(np.float32))
+        x = x.view(d.n, d.h, d.w_in, d.c).permute(0, 3, 1, 2)
+        if d.edge_zero:
+            need_h = (d.ho - 1) * d.stride + d.k - d.h
+            need_w = (d.wo - 1) * d.stride + d.k - d.w_in
+            y = F.max_pool2d(F.pad(x, (0, max(need_w, 0), 0, max(need_h, 0)), value=0.0), d.k, d.stride, 0)
+        else:
+            y = F.max_pool2d(x, d.k, d.stride, d.pad_lo)
+        pitched(d.y, d.n * d.ho * d.wo, d.c, d.ldy, np.int8)[:] = y.permute(0, 2, 3, 1).reshape(-1, d.c).numpy().astype(np.int8)
+        return 0
+
+    def yh_qadd(self, dref, stream):
+        d = dref._obj if hasattr(dref, '_obj') else dref
+        x = torch.from_numpy(pitched(d.x, d.pixels, d.c, d.ldx, np.int8).astype(np.float32))
+        a = torch.from_numpy(pitched(d.a, d.pixels, d.c, d.lda, np.int8).astype(np.float32))
+        s = rnd_away(x * d.rx) * d.scale_x + rnd_away(a * d.ra) * d.scale_a
+        pitched(d.y, d.pixels, d.c, d.ldy, np.int8)[:] = rnd_away(s * d.inv_scale_sum).clamp(-128, 127).numpy().astype(np.int8)
+        return 0
+
     def yh_conv2d_fwd(self, dref, stream):
         d = dref._obj if hasattr(dref, '_obj') else dref
+        if d.dtype == hiplib.YH_I8:
+            return self._qconv(d)
         npdt = _NP[d.dtype]
         vec, bk = (8, 32) if d.dtype == hiplib.YH_F16 else (4, 16)
         assert d.cin % vec == 0 and d.ldx % vec == 0 and d.cin_k % bk == 0 and d.cout % 4 == 0 and d.ldy % 4 == 0
@@ -190,6 +263,8 @@ class FakeLib:
         b = torch.from_numpy(flat(d.bias, d.cout_pad, np.float32)[:d.cout].copy())
         y = _act(F.conv2d(x, w, b, stride=d.stride, padding=d.pad), d.act, d.slope)
         assert y.shape[2] == d.ho and y.shape[3] == d.wo and d.cout % 8 == 0
+        if d.dtype == hiplib.YH_I8:
+            y = rnd_away(y / d.out_scale).clamp(-128, 127)
         out = pitched(d.y, d.n * d.ho * d.wo, d.cout, d.ldy, npdt)
         out[:] = y.permute(0, 2, 3, 1).reshape(-1, d.cout).numpy().astype(npdt)
         return 0
@@ -287,7 +362,8 @@ class FakeLib:
         run = {hiplib.OP_CONV: self.yh_conv2d_fwd, hiplib.OP_STEM: self.yh_conv2d_stem_fwd,
                hiplib.OP_POOL: self.yh_maxpool2d_fwd, hiplib.OP_COPY: self.yh_copy_channels,
                hiplib.OP_ADD: self.yh_add_channels, hiplib.OP_DECODE: self.yh_yolo_decode,
-               hiplib.OP_DW: self.yh_dwconv2d_fwd, hiplib.OP_SE: self.yh_se_fwd}
+               hiplib.OP_DW: self.yh_dwconv2d_fwd, hiplib.OP_SE: self.yh_se_fwd, hiplib.OP_QCOPY: self.yh_qcopy,
+               hiplib.OP_QPOOL: self.yh_qpool, hiplib.OP_QADD: self.yh_qadd}
         for kind, desc, fixups in plan['ops'][first:last]:
             d = type(desc).from_buffer_copy(bytes(desc))
             for off, slot, boff in fixups:

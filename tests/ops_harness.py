@@ -8,7 +8,7 @@ import ctypes as C
 import torch
 
 from engine import hiplib
-from engine.hiplib import ConvDesc, StemDesc, PoolDesc, CopyDesc, AddDesc, DecodeDesc, DwDesc, SeDesc
+from engine.hiplib import ConvDesc, StemDesc, PoolDesc, CopyDesc, AddDesc, DecodeDesc, DwDesc, SeDesc, QCopyDesc, QAddDesc
 
 P = hiplib.ptr
 
@@ -161,3 +161,63 @@ def se(lib, code, x, w1, w2, c, cmap=None):
     rc = lib.yh_se_fwd(C.byref(d), stream())
     assert rc == 0, rc
     return y, gate
+
+
+# ------------------------------------------------------------------------------------------------ int8 (PTQ eval)
+def qconv(lib, x, qw, w_scale, qbias, acc_scale, out_scale, k, stride, pad, act=1, slope=0.1, ups=1, out_f32=False, tile=0,
+          cin=None, x_off=0, y=None, y_off=0):
+    """x int8 (N,H,W,ldx); qw fp32 (cout,cin,k,k) = int grid * w_scale; qbias fp32 (cout,) real units."""
+    N, H, W, ldx = x.shape
+    cout, cin_l = qw.shape[0], qw.shape[1]
+    cin = cin if cin is not None else ldx - x_off
+    cin_k = round_up(cin, 64)
+    cout_phys = round_up(cout, 16)
+    m_pad = round_up(cout_phys, 128)
+    packed = torch.full((m_pad * k * k * cin_k,), 7, device=x.device, dtype=torch.int8)
+    rc = lib.yh_qconv_pack_weights(P(qw), float(w_scale), None, cout, cin_l, k, k, cin_k, m_pad, P(packed), stream())
+    assert rc == 0, rc
+    bias = torch.zeros(m_pad, device=x.device, dtype=torch.float32)
+    bias[:cout] = qbias
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    if y is None:
+        y = torch.full((N, Ho * ups, Wo * ups, cout_phys), 3, device=x.device, dtype=torch.float32 if out_f32 else torch.int8)
+    d = ConvDesc(x=P(x, x_off), w=P(packed), bias=P(bias), res=None, y=P(y, y_off), n=N, h=H, w_in=W, cin=cin, ho=Ho, wo=Wo,
+                 cout=cout_phys, kh=k, kw=k, stride=stride, pad=pad, ldx=ldx, ldr=0, ldy=y.shape[3], cin_k=cin_k, m_pad=m_pad,
+                 act=act, slope=slope, ups=ups, out_f32=1 if out_f32 else 0, dtype=hiplib.YH_I8, tile=tile,
+                 acc_scale=float(acc_scale), out_scale=float(out_scale))
+    rc = lib.yh_conv2d_fwd(C.byref(d), stream())
+    assert rc == 0, 'yh_conv2d_fwd(i8) rc=%d' % rc
+    return y, packed
+
+
+def qcopy(lib, x, y, c, ratio=1.0, ups=1, x_off=0, y_off=0):
+    N, H, W, ldx = x.shape
+    d = QCopyDesc(x=P(x, x_off), y=P(y, y_off), n=N, h=H, w_in=W, c=c, ups=ups, ldx=ldx, ldy=y.shape[3], ratio=float(ratio))
+    rc = lib.yh_qcopy(C.byref(d), stream())
+    assert rc == 0, rc
+    return y
+
+
+def qpool(lib, x, k, stride):
+    N, H, W, c = x.shape
+    if k == 2 and stride == 1:
+        Ho, Wo, pad_lo, edge_zero = H, W, 0, 1
+    else:
+        pad_lo, edge_zero = (k - 1) // 2, 0
+        Ho, Wo = (H + 2 * pad_lo - k) // stride + 1, (W + 2 * pad_lo - k) // stride + 1
+    y = torch.full((N, Ho, Wo, c), 3, device=x.device, dtype=torch.int8)
+    d = PoolDesc(x=P(x), y=P(y), n=N, h=H, w_in=W, c=c, ho=Ho, wo=Wo, k=k, stride=stride, pad_lo=pad_lo, edge_zero=edge_zero,
+                 ldx=c, ldy=c, dtype=hiplib.YH_I8)
+    rc = lib.yh_qpool(C.byref(d), stream())
+    assert rc == 0, rc
+    return y
+
+
+def qadd(lib, x, a, rx, ra, scale_x, scale_a, scale_sum):
+    N, H, W, c = x.shape
+    y = torch.full((N, H, W, c), 3, device=x.device, dtype=torch.int8)
+    d = QAddDesc(x=P(x), a=P(a), y=P(y), pixels=N * H * W, c=c, ldx=c, lda=a.shape[3], ldy=c, rx=float(rx), ra=float(ra),
+                 scale_x=float(scale_x), scale_a=float(scale_a), inv_scale_sum=float(1.0 / scale_sum))
+    rc = lib.yh_qadd(C.byref(d), stream())
+    assert rc == 0, rc
+    return y

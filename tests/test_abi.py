@@ -33,7 +33,9 @@ def test_library_loads_and_exports_every_declared_symbol():
 def test_struct_layout_matches_c_compiler(tmp_path):
     """ctypes mirrors must have the C compiler's sizeof/offsetof (gcc, no GPU needed)."""
     structs = {'yh_conv_desc': hiplib.ConvDesc, 'yh_stem_desc': hiplib.StemDesc, 'yh_pool_desc': hiplib.PoolDesc,
-               'yh_copy_desc': hiplib.CopyDesc, 'yh_add_desc': hiplib.AddDesc, 'yh_decode_desc': hiplib.DecodeDesc}
+               'yh_copy_desc': hiplib.CopyDesc, 'yh_add_desc': hiplib.AddDesc, 'yh_decode_desc': hiplib.DecodeDesc,
+               'yh_dw_desc': hiplib.DwDesc, 'yh_se_desc': hiplib.SeDesc, 'yh_qcopy_desc': hiplib.QCopyDesc,
+               'yh_qadd_desc': hiplib.QAddDesc}
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "yolo_hip.h"', 'int main(void){']
     for cname, cls in structs.items():
         lines.append('printf("%s %%zu\\n", sizeof(%s));' % (cname, cname))

@@ -251,3 +251,85 @@ def test_squeeze_excite_matches_emulation(libs, code, c, H):
     assert (gg - gc).abs().max().item() <= 2e-5
     tol = 2e-5 if code == F32 else 2.5e-3
     assert (yg - yc).abs().max().item() <= tol * (yc.abs().max().item() + 1e-6)
+
+
+# ------------------------------------------------------------------------------------------------ int8 (PTQ eval, row Q/Q2)
+QCONV_CASES = [
+    # N, H, W, cin, cout, k, s, act, ups, out_f32, tile
+    (2, 20, 20, 64, 128, 3, 1, 1, 1, False, 0),
+    (2, 19, 19, 128, 255, 1, 1, 0, 1, True, 0),       # head: linear, dequantised fp32 output
+    (1, 33, 31, 32, 64, 3, 2, 1, 1, False, 0),        # cin 32 -> K tail of the 64-wide step
+    (2, 16, 16, 256, 128, 1, 1, 5, 2, False, 21),     # mish, upsampled
+    (2, 24, 24, 64, 64, 3, 1, 1, 1, False, 24),
+    (3, 13, 13, 192, 256, 3, 1, 1, 1, False, 26),
+    (2, 24, 24, 128, 128, 1, 1, 3, 1, False, 27),
+    (1, 10, 10, 512, 1024, 3, 1, 1, 1, False, 25),    # K = 4608: |acc| stays below 2^24
+]
+
+
+@pytest.mark.parametrize('case', QCONV_CASES, ids=lambda c: 'q_n%d_%dx%d_c%d-%d_k%ds%d_a%d_u%d_f%d_t%d' % c)
+def test_int8_conv_matches_emulation(libs, case):
+    """MFMA-i8 conv block: integer accumulation is exact, so outputs must be equal on the int8 grid."""
+    lib, fake = libs
+    N, H, W, cin, cout, k, s, act, ups, out_f32, tile = case
+    g = torch.Generator().manual_seed(hash(case) % (2 ** 31))
+    w_scale, x_scale, out_scale = 2.0 ** -9, 2.0 ** -5, 2.0 ** -4
+    qw = torch.randint(-127, 128, (cout, cin, k, k), generator=g).float() * (torch.rand(cout, cin, k, k, generator=g) < 0.5) * w_scale
+    x = torch.randint(-128, 128, (N, H, W, cin), generator=g).to(torch.int8)
+    qb = torch.randint(-128, 128, (cout,), generator=g).float() * 2.0 ** -6
+    pad = (k - 1) // 2
+    ys = []
+    for L, dev in ((lib, GPU), (fake, 'cpu')):
+        y, pk = oh.qconv(L, x.to(dev), qw.to(dev), w_scale, qb.to(dev), w_scale * x_scale, out_scale, k, s, pad, act=act, ups=ups,
+                         out_f32=out_f32, tile=tile)
+        ys.append((y.float().cpu(), pk.cpu()))
+    (yg, pg), (yc, pc) = ys
+    assert torch.equal(pg, pc), 'int8 weight image differs'
+    diff = (yg - yc).abs() / (out_scale if out_f32 else 1.0)
+    # identical integer sums; a result can only differ by one grid step when the real value sits on a rounding tie
+    assert diff.max().item() <= 1.0 and (diff > 0).float().mean().item() <= 1e-4, (diff.max().item(), (diff > 0).float().mean().item())
+
+
+def test_int8_movement_ops_match_emulation(libs):
+    lib, fake = libs
+    g = torch.Generator().manual_seed(17)
+    x = torch.randint(-128, 128, (2, 9, 11, 48), generator=g).to(torch.int8)
+    a = torch.randint(-128, 128, (2, 9, 11, 32), generator=g).to(torch.int8)
+    res = []
+    for L, dev in ((lib, GPU), (fake, 'cpu')):
+        y1 = torch.full((2, 18, 22, 64), 3, device=dev, dtype=torch.int8)
+        oh.qcopy(L, x.to(dev), y1, c=32, ratio=0.5, ups=2, x_off=16, y_off=16)
+        y2 = torch.full((2, 9, 11, 64), 3, device=dev, dtype=torch.int8)
+        oh.qcopy(L, x.to(dev), y2, c=48, ratio=1.0, ups=1, y_off=16)
+        y3 = oh.qcopy(L, x.to(dev), torch.full((2, 9, 11, 48), 3, device=dev, dtype=torch.int8), c=48, ratio=4.0)
+        p5 = oh.qpool(L, x.to(dev), 5, 1)
+        p2 = oh.qpool(L, x.to(dev), 2, 2)
+        p21 = oh.qpool(L, x.to(dev), 2, 1)
+        s = oh.qadd(L, a.to(dev), x.to(dev)[..., :32].contiguous(), 0.5, 2.0, 2.0 ** -4, 2.0 ** -6, 2.0 ** -3)
+        res.append([t.cpu() for t in (y1, y2, y3, p5, p2, p21, s)])
+    for tg, tc in zip(*res):
+        assert torch.equal(tg, tc)
+
+
+def test_int8_stem_matches_emulation(libs):
+    lib, fake = libs
+    g = torch.Generator().manual_seed(18)
+    x = torch.rand(2, 3, 40, 56, generator=g)
+    qw = torch.randint(-127, 128, (32, 3, 3, 3), generator=g).float() * 2.0 ** -8
+    qb = torch.randint(-128, 128, (32,), generator=g).float() * 2.0 ** -7
+    ys = []
+    for L, dev in ((lib, GPU), (fake, 'cpu')):
+        N, _, H, W = x.shape
+        packed = torch.empty(27 * 32, device=dev, dtype=torch.float32)
+        bias = torch.empty(32, device=dev, dtype=torch.float32)
+        assert L.yh_stem_pack_weights(oh.P(qw.to(dev)), oh.P(qb.to(dev)), None, None, None, None, 0.0, 32, 3, 3, 3, 32, oh.P(packed),
+                                      oh.P(bias), oh.stream()) == 0
+        y = torch.full((N, H, W, 32), 3, device=dev, dtype=torch.int8)
+        d = hiplib.StemDesc(x=oh.P(x.to(dev)), w=oh.P(packed), bias=oh.P(bias), y=oh.P(y), n=N, cin=3, h=H, w_in=W, ho=H, wo=W,
+                            cout=32, cout_pad=32, kh=3, kw=3, stride=1, pad=1, ldy=32, act=1, slope=0.1, dtype=hiplib.YH_I8,
+                            out_scale=2.0 ** -5)
+        import ctypes as C
+        assert L.yh_conv2d_stem_fwd(C.byref(d), oh.stream()) == 0
+        ys.append(y.float().cpu())
+    diff = (ys[0] - ys[1]).abs()
+    assert diff.max().item() <= 1.0 and (diff > 0).float().mean().item() <= 2e-3  # fp32 sums differ in the last bit -> rare ties

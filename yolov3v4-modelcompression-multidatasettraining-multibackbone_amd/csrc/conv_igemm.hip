@@ -40,6 +40,7 @@ struct ConvArgs {
     long P;          // N*Ho*Wo
     int m_tiles, p_tiles;
     int m_pad;
+    float acc_scale, out_scale, inv_out_scale;  // int8 path: s_w*s_x, s_a, 1/s_a (all powers of two)
     int act;
     float slope;
     int ups;
@@ -63,6 +64,19 @@ template <> struct Prec<f16> {
 template <> struct Prec<float> {
     static constexpr int VEC = 4;
 };
+template <> struct Prec<int8_t> {
+    static constexpr int VEC = 16;  // int8 PTQ path: 64 channels per K step on v_mfma_i32_16x16x64_i8
+};
+
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+template <typename T> struct AccOf { typedef f32x4 type; };
+template <> struct AccOf<int8_t> { typedef i32x4 type; };
+
+// PTQ rounding (utils/quantized/quantized_ptq_cos.py:14-20): half away from zero, then clamp to int8
+__device__ __forceinline__ float round_clamp_i8(float t) {
+    const float r = copysignf(floorf(fabsf(t) + 0.5f), t);
+    return fminf(fmaxf(r, -128.f), 127.f);
+}
 
 // One K step (KU units of 16 bytes per row) of MFMAs for a wave: TM x TN fragments of 16x16.
 template <typename T, int TM, int TN, int KU> struct MmaStep;
@@ -126,10 +140,21 @@ template <> __device__ __forceinline__ void store4<float>(float* p, float a, flo
     *reinterpret_cast<f32x4*>(p) = v;
 }
 
+template <> __device__ __forceinline__ void store4<int8_t>(int8_t* p, float a, float b, float c, float d) {
+    const unsigned v = ((unsigned)(int)a & 0xffu) | (((unsigned)(int)b & 0xffu) << 8) | (((unsigned)(int)c & 0xffu) << 16) |
+                       (((unsigned)(int)d & 0xffu) << 24);
+    *reinterpret_cast<unsigned*>(p) = v;
+}
+
 template <typename T> __device__ __forceinline__ void load4(const T* p, float (&o)[4]);
 template <> __device__ __forceinline__ void load4<f16>(const f16* p, float (&o)[4]) {
     f16x4 v = *reinterpret_cast<const f16x4*>(p);
     o[0] = (float)v[0]; o[1] = (float)v[1]; o[2] = (float)v[2]; o[3] = (float)v[3];
+}
+template <> __device__ __forceinline__ void load4<int8_t>(const int8_t* p, float (&o)[4]) {
+    const unsigned v = *reinterpret_cast<const unsigned*>(p);
+    o[0] = (float)(int8_t)(v & 0xff); o[1] = (float)(int8_t)((v >> 8) & 0xff);
+    o[2] = (float)(int8_t)((v >> 16) & 0xff); o[3] = (float)(int8_t)(v >> 24);
 }
 template <> __device__ __forceinline__ void load4<float>(const float* p, float (&o)[4]) {
     f32x4 v = *reinterpret_cast<const f32x4*>(p);
@@ -383,6 +408,30 @@ template <int TM, int TN> struct MmaStepRM<float, TM, TN> {
 };
 
 // ABL: ablation switch for profiling only (0 = normal, 1 = skip the LDS-DMA loads, 2 = skip the MFMAs)
+template <int TM, int TN> struct MmaStepRM<int8_t, TM, TN> {
+    static __device__ __forceinline__ void run(const u32x4* As, const u32x4* Bs, int arow, int brow, int lane,
+                                               i32x4 (&acc)[TM][TN]) {
+        const int r = lane & 15;
+        const int off = r * 4 + ((lane >> 4) ^ swz_f(r >> 2));
+        i32x4 a[TM], b[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            u32x4 v = As[(arow + i * 16) * 4 + off];
+            a[i] = *reinterpret_cast<i32x4*>(&v);
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            u32x4 v = Bs[(brow + j * 16) * 4 + off];
+            b[j] = *reinterpret_cast<i32x4*>(&v);
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+};
+
 template <typename T, typename OutT, int BM, int BN, int WM, int WN, int STAGES, int ABL = 0>
 __global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm_glds_kernel(const ConvArgs a) {
     constexpr int VEC = Prec<T>::VEC, BK = VEC * 4;
@@ -473,11 +522,12 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm_glds_kernel(const 
         }
     };
 
-    f32x4 acc[TM][TN];
+    typedef typename AccOf<T>::type acc_t;
+    acc_t acc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < TN; ++j) acc[i][j] = acc_t{0, 0, 0, 0};
 
     const int nk = a.ktot / BK;
 #pragma unroll
@@ -521,13 +571,24 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm_glds_kernel(const 
             if (m >= a.Cout) continue;
             const f32x4 bv = *reinterpret_cast<const f32x4*>(a.bias + m);
             float v[4];
+            if constexpr (sizeof(T) == 1) {
+                // PTQ eval arithmetic (quantized_ptq_cos.py:288-296,543-567,717): dequantised conv + quantised bias,
+                // activation in fp32, then round-half-away/clamp onto the activation grid
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = activate(acc[i][j][e] + bv[e], a.act, a.slope);
-            if (rg != nullptr) {
-                float r4[4];
-                load4<T>(rg + p * a.ldr + m, r4);
+                for (int e = 0; e < 4; ++e) {
+                    const float y = activate((float)acc[i][j][e] * a.acc_scale + bv[e], a.act, a.slope);
+                    const float q = round_clamp_i8(y * a.inv_out_scale);
+                    v[e] = sizeof(OutT) == 1 ? q : q * a.out_scale;
+                }
+            } else {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] += r4[e];
+                for (int e = 0; e < 4; ++e) v[e] = activate((float)acc[i][j][e] + bv[e], a.act, a.slope);
+                if (rg != nullptr) {
+                    float r4[4];
+                    load4<T>(rg + p * a.ldr + m, r4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] += r4[e];
+                }
             }
             OutT* dst = yg + opix * a.ldy + m;
             store4<OutT>(dst, v[0], v[1], v[2], v[3]);
@@ -876,12 +937,56 @@ template <typename T, typename OutT> static int dispatch_tile(const ConvArgs& a,
     }
 }
 
+template <typename OutT> static int dispatch_tile_i8(const ConvArgs& a, int tile, hipStream_t s) {
+    if (tile == 0) {
+        tile = pick_tile(a.Cout, a.P, a.cin_k, 16);
+        if (tile == 3) tile = 24;  // no 32-channel LDS-DMA tile: use 64x128
+    }
+    switch (tile) {
+        case 21: return launch_glds<int8_t, OutT, 128, 128, 2, 2, 3>(a, s);
+        case 24: return launch_glds<int8_t, OutT, 64, 128, 2, 2, 3>(a, s);
+        case 25: return launch_glds<int8_t, OutT, 128, 64, 2, 2, 3>(a, s);
+        case 26: return launch_glds<int8_t, OutT, 256, 128, 4, 2, 3>(a, s);
+        case 27: return launch_glds<int8_t, OutT, 128, 256, 2, 4, 3>(a, s);
+        default: return YH_EINVAL;
+    }
+}
+
+__global__ void pack_qconv_weights_kernel(const float* __restrict__ qw, float inv_scale, const int32_t* __restrict__ cin_map,
+                                          int cout, int cin, int taps, int cin_k, int8_t* __restrict__ packed) {
+    const long total = (long)cout * cin * taps;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int tap = (int)(i % taps);
+        const long r = i / taps;
+        const int ci = (int)(r % cin), co = (int)(r / cin);
+        const int pc = cin_map ? cin_map[ci] : ci;
+        packed[((long)co * taps + tap) * cin_k + pc] = (int8_t)(int)round_clamp_i8(qw[i] * inv_scale);
+    }
+}
+
 }  // namespace yh
+
+extern "C" int yh_qconv_pack_weights(const float* q_weight, float w_scale, const int32_t* cin_map, int cout, int cin, int kh,
+                                     int kw, int cin_k, int m_pad, void* packed, void* stream) {
+    using namespace yh;
+    if (!q_weight || !packed || cout <= 0 || cin <= 0 || kh <= 0 || kw <= 0 || !(w_scale > 0.f)) return YH_EINVAL;
+    if (cin_k % 64 || m_pad % 128 || m_pad < cout) return YH_EALIGN;
+    hipStream_t s = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(packed, 0, (size_t)m_pad * kh * kw * cin_k, s);
+    if (e != hipSuccess) return (int)e;
+    const long total = (long)cout * cin * kh * kw;
+    long g = (total + 255) / 256;
+    if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(pack_qconv_weights_kernel, dim3((unsigned)g), dim3(256), 0, s, q_weight, 1.f / w_scale, cin_map, cout, cin,
+                       kh * kw, cin_k, (int8_t*)packed);
+    return check_launch();
+}
 
 extern "C" int yh_conv2d_tile(const yh_conv_desc* d) {
     if (!d) return YH_EINVAL;
     if (d->tile != 0) return d->tile;
-    return yh::pick_tile(d->cout, (long)d->n * d->ho * d->wo, d->cin_k, d->dtype == YH_F16 ? 8 : 4);
+    const int t = yh::pick_tile(d->cout, (long)d->n * d->ho * d->wo, d->cin_k, d->dtype == YH_F16 ? 8 : 4);
+    return (d->dtype == YH_I8 && t == 3) ? 24 : t;
 }
 
 extern "C" int yh_conv2d_fwd(const yh_conv_desc* d, void* stream) {
@@ -889,8 +994,9 @@ extern "C" int yh_conv2d_fwd(const yh_conv_desc* d, void* stream) {
     if (!d || !d->x || !d->w || !d->bias || !d->y) return YH_EINVAL;
     if (d->n <= 0 || d->h <= 0 || d->w_in <= 0 || d->cin <= 0 || d->ho <= 0 || d->wo <= 0 || d->cout <= 0) return YH_EINVAL;
     if (d->kh <= 0 || d->kw <= 0 || d->stride <= 0 || d->pad < 0) return YH_EINVAL;
-    if (d->dtype != YH_F16 && d->dtype != YH_F32) return YH_EINVAL;
-    const int bk = d->dtype == YH_F16 ? 32 : 16, vec = d->dtype == YH_F16 ? 8 : 4;
+    if (d->dtype != YH_F16 && d->dtype != YH_F32 && d->dtype != YH_I8) return YH_EINVAL;
+    const int bk = d->dtype == YH_F16 ? 32 : (d->dtype == YH_I8 ? 64 : 16), vec = d->dtype == YH_F16 ? 8 : (d->dtype == YH_I8 ? 16 : 4);
+    if (d->dtype == YH_I8 && (d->res || !(d->acc_scale > 0.f) || !(d->out_scale > 0.f))) return YH_EINVAL;
     if (d->cin % vec || d->ldx % vec || d->cin_k % bk || d->cin_k < d->cin || d->m_pad % 128 || d->m_pad < d->cout) return YH_EALIGN;
     if (d->cout % 4 || d->ldy % 4 || (d->res && d->ldr % 4)) return YH_EALIGN;
     if (!aligned16(d->x) || !aligned16(d->w) || !aligned16(d->bias) || (((uintptr_t)d->y) & 7u) || (((uintptr_t)d->res) & 7u)) return YH_EALIGN;
@@ -906,10 +1012,14 @@ extern "C" int yh_conv2d_fwd(const yh_conv_desc* d, void* stream) {
     a.P = (long)d->n * d->ho * d->wo;
     a.m_tiles = a.p_tiles = 0;
     a.m_pad = d->m_pad;
+    a.acc_scale = d->acc_scale; a.out_scale = d->out_scale; a.inv_out_scale = d->out_scale > 0.f ? 1.f / d->out_scale : 0.f;
     a.act = d->act; a.slope = d->slope; a.ups = d->ups;
     hipStream_t s = (hipStream_t)stream;
     if (d->dtype == YH_F16) {
         return d->out_f32 ? dispatch_tile<f16, float>(a, d->tile, s) : dispatch_tile<f16, f16>(a, d->tile, s);
+    }
+    if (d->dtype == YH_I8) {
+        return d->out_f32 ? dispatch_tile_i8<float>(a, d->tile, s) : dispatch_tile_i8<int8_t>(a, d->tile, s);
     }
     return dispatch_tile<float, float>(a, d->tile, s);
 }

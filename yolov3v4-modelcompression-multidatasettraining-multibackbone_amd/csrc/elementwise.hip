@@ -77,6 +77,24 @@ template <int CO> struct StemStore<float, CO> {
     }
 };
 
+template <int CO> struct StemStore<int8_t, CO> {
+    static __device__ __forceinline__ void run(int8_t* dst, const float (&acc)[CO], int co0, int cout) {
+#pragma unroll
+        for (int g = 0; g < CO / 16; ++g) {
+            if (co0 + g * 16 >= cout) break;
+            unsigned w[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                unsigned v = 0;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v |= ((unsigned)(int)acc[g * 16 + q * 4 + e] & 0xffu) << (8 * e);
+                w[q] = v;
+            }
+            *reinterpret_cast<uint4*>(dst + g * 16) = make_uint4(w[0], w[1], w[2], w[3]);
+        }
+    }
+};
+
 template <typename T, int CO>
 __global__ __launch_bounds__(256) void conv_stem_kernel(const yh_stem_desc d) {
     const long P = (long)d.n * d.ho * d.wo;
@@ -107,6 +125,14 @@ __global__ __launch_bounds__(256) void conv_stem_kernel(const yh_stem_desc d) {
     }
 #pragma unroll
     for (int c = 0; c < CO; ++c) acc[c] = activate(acc[c], d.act, d.slope);
+    if constexpr (sizeof(T) == 1) {  // PTQ: quantise onto the activation grid (round half away, clamp)
+        const float inv = 1.f / d.out_scale;
+#pragma unroll
+        for (int c = 0; c < CO; ++c) {
+            const float t = acc[c] * inv;
+            acc[c] = fminf(fmaxf(copysignf(floorf(fabsf(t) + 0.5f), t), -128.f), 127.f);
+        }
+    }
     T* dst = reinterpret_cast<T*>(d.y) + p * d.ldy + co0;
     StemStore<T, CO>::run(dst, acc, co0, d.cout);
 }
@@ -300,7 +326,8 @@ extern "C" int yh_stem_pack_weights(const float* w, const float* conv_bias, cons
 extern "C" int yh_conv2d_stem_fwd(const yh_stem_desc* d, void* stream) {
     if (!d || !d->x || !d->w || !d->bias || !d->y) return YH_EINVAL;
     if (d->n <= 0 || d->cin <= 0 || d->cin > 4 || d->h <= 0 || d->w_in <= 0 || d->cout <= 0) return YH_EINVAL;
-    if (d->dtype != YH_F16 && d->dtype != YH_F32) return YH_EINVAL;
+    if (d->dtype != YH_F16 && d->dtype != YH_F32 && d->dtype != YH_I8) return YH_EINVAL;
+    if (d->dtype == YH_I8 && (!(d->out_scale > 0.f) || d->cout % 16 || d->ldy % 16)) return YH_EALIGN;
     if (d->cout_pad % 16 || d->cout_pad < d->cout || d->cout % 8 || d->ldy % 8 || !aligned16(d->y)) return YH_EALIGN;
     if (d->ho != (d->h + 2 * d->pad - d->kh) / d->stride + 1 || d->wo != (d->w_in + 2 * d->pad - d->kw) / d->stride + 1) return YH_EINVAL;
     const long P = (long)d->n * d->ho * d->wo;
@@ -310,6 +337,9 @@ extern "C" int yh_conv2d_stem_fwd(const yh_stem_desc* d, void* stream) {
     if (d->dtype == YH_F16) {
         if (wide) hipLaunchKernelGGL((conv_stem_kernel<f16, 32>), grid, dim3(256), 0, s, *d);
         else hipLaunchKernelGGL((conv_stem_kernel<f16, 16>), grid, dim3(256), 0, s, *d);
+    } else if (d->dtype == YH_I8) {
+        if (wide) hipLaunchKernelGGL((conv_stem_kernel<int8_t, 32>), grid, dim3(256), 0, s, *d);
+        else hipLaunchKernelGGL((conv_stem_kernel<int8_t, 16>), grid, dim3(256), 0, s, *d);
     } else {
         if (wide) hipLaunchKernelGGL((conv_stem_kernel<float, 32>), grid, dim3(256), 0, s, *d);
         else hipLaunchKernelGGL((conv_stem_kernel<float, 16>), grid, dim3(256), 0, s, *d);

@@ -19,6 +19,8 @@ union AnyDesc {
     yh_decode_desc decode;
     yh_dw_desc dw;
     yh_se_desc se;
+    yh_qcopy_desc qcopy;
+    yh_qadd_desc qadd;
 };
 
 struct Fixup {
@@ -43,6 +45,9 @@ size_t desc_size(int kind) {
         case YH_OP_DECODE: return sizeof(yh_decode_desc);
         case YH_OP_DW: return sizeof(yh_dw_desc);
         case YH_OP_SE: return sizeof(yh_se_desc);
+        case YH_OP_QCOPY: return sizeof(yh_qcopy_desc);
+        case YH_OP_QPOOL: return sizeof(yh_pool_desc);
+        case YH_OP_QADD: return sizeof(yh_qadd_desc);
         default: return 0;
     }
 }
@@ -57,6 +62,9 @@ int launch(int kind, const AnyDesc& d, void* stream) {
         case YH_OP_DECODE: return yh_yolo_decode(&d.decode, stream);
         case YH_OP_DW: return yh_dwconv2d_fwd(&d.dw, stream);
         case YH_OP_SE: return yh_se_fwd(&d.se, stream);
+        case YH_OP_QCOPY: return yh_qcopy(&d.qcopy, stream);
+        case YH_OP_QPOOL: return yh_qpool(&d.pool, stream);
+        case YH_OP_QADD: return yh_qadd(&d.qadd, stream);
         default: return YH_EINVAL;
     }
 }

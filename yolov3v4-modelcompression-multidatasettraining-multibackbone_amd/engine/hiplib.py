@@ -10,9 +10,9 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), 'libyolo_hip.so')
 
-YH_F16, YH_F32 = 0, 1
+YH_F16, YH_F32, YH_I8 = 0, 1, 2
 ACT_CODES = {'linear': 0, 'leaky': 1, 'relu': 2, 'relu6': 3, 'h_swish': 4, 'mish': 5}
-OP_CONV, OP_STEM, OP_POOL, OP_COPY, OP_ADD, OP_DECODE, OP_DW, OP_SE = 1, 2, 3, 4, 5, 6, 7, 8
+OP_CONV, OP_STEM, OP_POOL, OP_COPY, OP_ADD, OP_DECODE, OP_DW, OP_SE, OP_QCOPY, OP_QPOOL, OP_QADD = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11
 
 _i32, _f32, _vp, _i64 = C.c_int32, C.c_float, C.c_void_p, C.c_int64
 
@@ -24,14 +24,15 @@ class ConvDesc(C.Structure):
                 ('kh', _i32), ('kw', _i32), ('stride', _i32), ('pad', _i32),
                 ('ldx', _i32), ('ldr', _i32), ('ldy', _i32),
                 ('cin_k', _i32), ('m_pad', _i32),
-                ('act', _i32), ('slope', _f32), ('ups', _i32), ('out_f32', _i32), ('dtype', _i32), ('tile', _i32)]
+                ('act', _i32), ('slope', _f32), ('ups', _i32), ('out_f32', _i32), ('dtype', _i32), ('tile', _i32),
+                ('acc_scale', _f32), ('out_scale', _f32)]
 
 
 class StemDesc(C.Structure):
     _fields_ = [('x', _vp), ('w', _vp), ('bias', _vp), ('y', _vp),
                 ('n', _i32), ('cin', _i32), ('h', _i32), ('w_in', _i32), ('ho', _i32), ('wo', _i32),
                 ('cout', _i32), ('cout_pad', _i32), ('kh', _i32), ('kw', _i32), ('stride', _i32), ('pad', _i32),
-                ('ldy', _i32), ('act', _i32), ('slope', _f32), ('dtype', _i32)]
+                ('ldy', _i32), ('act', _i32), ('slope', _f32), ('dtype', _i32), ('out_scale', _f32)]
 
 
 class PoolDesc(C.Structure):
@@ -71,8 +72,24 @@ class SeDesc(C.Structure):
                 ('ldy', _i32), ('dtype', _i32)]
 
 
+class QCopyDesc(C.Structure):
+    _fields_ = [('x', _vp), ('y', _vp),
+                ('n', _i32), ('h', _i32), ('w_in', _i32), ('c', _i32), ('ups', _i32), ('ldx', _i32), ('ldy', _i32),
+                ('ratio', _f32)]
+
+
+class QAddDesc(C.Structure):
+    _fields_ = [('x', _vp), ('a', _vp), ('y', _vp), ('pixels', _i64),
+                ('c', _i32), ('ldx', _i32), ('lda', _i32), ('ldy', _i32),
+                ('rx', _f32), ('ra', _f32), ('scale_x', _f32), ('scale_a', _f32), ('inv_scale_sum', _f32)]
+
+
+class QPoolDesc(PoolDesc):
+    """Same layout as PoolDesc; a distinct Python type so plans record it as YH_OP_QPOOL."""
+
+
 OP_KIND = {ConvDesc: OP_CONV, StemDesc: OP_STEM, PoolDesc: OP_POOL, CopyDesc: OP_COPY, AddDesc: OP_ADD,
-           DecodeDesc: OP_DECODE, DwDesc: OP_DW, SeDesc: OP_SE}
+           DecodeDesc: OP_DECODE, DwDesc: OP_DW, SeDesc: OP_SE, QCopyDesc: OP_QCOPY, QPoolDesc: OP_QPOOL, QAddDesc: OP_QADD}
 
 _SIGNATURES = {
     'yh_abi_version': (C.c_int, []),
@@ -81,6 +98,7 @@ _SIGNATURES = {
                                        C.c_int, C.c_int, C.c_int, _vp, _vp, _vp]),
     'yh_conv2d_fwd': (C.c_int, [C.POINTER(ConvDesc), _vp]),
     'yh_conv2d_tile': (C.c_int, [C.POINTER(ConvDesc)]),
+    'yh_qconv_pack_weights': (C.c_int, [_vp, _f32, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp]),
     'yh_stem_pack_weights': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _f32, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                        _vp, _vp, _vp]),
     'yh_conv2d_stem_fwd': (C.c_int, [C.POINTER(StemDesc), _vp]),
@@ -88,6 +106,9 @@ _SIGNATURES = {
     'yh_dwconv2d_fwd': (C.c_int, [C.POINTER(DwDesc), _vp]),
     'yh_se_fwd': (C.c_int, [C.POINTER(SeDesc), _vp]),
     'yh_maxpool2d_fwd': (C.c_int, [C.POINTER(PoolDesc), _vp]),
+    'yh_qcopy': (C.c_int, [C.POINTER(QCopyDesc), _vp]),
+    'yh_qpool': (C.c_int, [C.POINTER(PoolDesc), _vp]),
+    'yh_qadd': (C.c_int, [C.POINTER(QAddDesc), _vp]),
     'yh_copy_channels': (C.c_int, [C.POINTER(CopyDesc), _vp]),
     'yh_add_channels': (C.c_int, [C.POINTER(AddDesc), _vp]),
     'yh_yolo_decode': (C.c_int, [C.POINTER(DecodeDesc), _vp]),
