@@ -30,7 +30,8 @@ import torch
 import torch.nn as nn
 
 from . import hiplib
-from .hiplib import ConvDesc, StemDesc, PoolDesc, CopyDesc, AddDesc, DecodeDesc, DwDesc, SeDesc
+from .hiplib import (ConvDesc, StemDesc, PoolDesc, CopyDesc, AddDesc, DecodeDesc, DwDesc, SeDesc, QCopyDesc, QPoolDesc,
+                     QAddDesc)
 
 SLOT_INPUT, SLOT_IO, SLOT_RAW0 = 0, 1, 2
 ALIGN_C = 8  # physical channel granularity of every NHWC buffer (16 bytes of fp16)
@@ -43,13 +44,16 @@ def _round_up(a, b):
 class Value:
     """A tensor that exists in device memory during the forward."""
 
+    ALIGN = ALIGN_C  # physical channel granularity; the engine raises it to 16 for int8 tensors
+
     def __init__(self, kind, C, H, W, block=None, **kw):
         self.kind = kind  # input | conv | pool | copy | add | concat | slice
         self.C, self.H, self.W = C, H, W
         self.block = block
         self.fp32 = False  # head convs store fp32 regardless of the engine precision
         self.segs = [(0, C)]  # (physical start relative to c_off, logical length)
-        self.c_phys = _round_up(C, ALIGN_C)
+        self.c_phys = _round_up(C, Value.ALIGN)
+        self.scale = None  # int8 engines: real value = grid value * scale (power of two)
         self.parent = None  # concat value this one is produced into
         self.storage = None
         self.c_off = 0
@@ -93,6 +97,20 @@ def _activation_of(block):
     return hiplib.ACT_CODES['linear'], 0.0
 
 
+_ACT_BY_NAME = {'leaky': 'leaky', 'relu6': 'relu6', 'h_swish': 'h_swish', 'relu': 'relu', 'mish': 'mish', 'linear': 'linear'}
+
+
+def _quant_conv_info(conv):
+    """(act code, slope, s_w, s_a) of a calibrated BNFold_COSPTQuantizedConv2d_For_FPGA (duck-typed)."""
+    if not getattr(conv, 'quantized', False):
+        raise RuntimeError('HIP int8 engine: quantised conv has not been calibrated (run the PTQ calibration first)')
+    name = _ACT_BY_NAME.get(conv.activate)
+    if name is None:
+        raise NotImplementedError('HIP int8 engine: activation %r' % conv.activate)
+    slope = 0.25 if getattr(conv, 'maxabsscaler', False) else 0.1
+    return hiplib.ACT_CODES[name], slope, float(conv.weight_quantizer.scale), float(conv.activation_quantizer.scale)
+
+
 def _conv_parts(block):
     kids = list(block.children())
     conv = kids[0]
@@ -107,16 +125,18 @@ def _conv_parts(block):
 
 class DarknetEngine:
     def __init__(self, model, precision='fp16', lib=None):
-        if precision not in ('fp16', 'fp32'):
-            raise ValueError("precision must be 'fp16' or 'fp32'")
+        if precision not in ('fp16', 'fp32', 'int8'):
+            raise ValueError("precision must be 'fp16', 'fp32' or 'int8'")
         # ``lib`` is only ever passed by the CPU test tier (tests/fakelib.py emulates the C ABI on host
         # memory to validate this lowering); the product path always loads the real library or raises.
         self.lib = hiplib.load() if lib is None else lib
         self.model = model
         self.precision = precision
-        self.code = hiplib.YH_F16 if precision == 'fp16' else hiplib.YH_F32
-        self.dtype = torch.float16 if precision == 'fp16' else torch.float32
-        self.kstep = 32 if precision == 'fp16' else 16
+        self.code = {'fp16': hiplib.YH_F16, 'fp32': hiplib.YH_F32, 'int8': hiplib.YH_I8}[precision]
+        self.dtype = {'fp16': torch.float16, 'fp32': torch.float32, 'int8': torch.int8}[precision]
+        self.kstep = {'fp16': 32, 'fp32': 16, 'int8': 64}[precision]
+        self.align = 16 if precision == 'int8' else ALIGN_C
+        self.q = precision == 'int8'  # PTQ eval graph: modules are the reference's COSPTQuantized* classes
         self.want_raw = True
         self.return_features = False
         self.force_tile = int(os.environ.get('YOLO_HIP_TILE', '0'))  # A/B profiling knob; 0 = library heuristic
@@ -130,6 +150,7 @@ class DarknetEngine:
         model = self.model
         defs, mods, routs = model.module_defs, model.module_list, model.routs
         L = len(mods)
+        Value.ALIGN = self.align
         x0 = Value('input', Cin, H, W)
         values, heads = [x0], []
         outs = [None] * L
@@ -168,9 +189,16 @@ class DarknetEngine:
                 if conv.kernel_size[0] != conv.kernel_size[1] or conv.in_channels != cur.C:
                     raise NotImplementedError('HIP engine: unsupported conv geometry at block %d' % i)
                 Ho, Wo = (cur.H + 2 * p - k) // s + 1, (cur.W + 2 * p - k) // s + 1
-                act, slope = _activation_of(module)
+                if self.q:
+                    if conv.__class__.__name__ != 'BNFold_COSPTQuantizedConv2d_For_FPGA':
+                        raise NotImplementedError('HIP int8 engine: block %d is not a COS-PTQ quantised conv' % i)
+                    act, slope, s_w, s_a = _quant_conv_info(conv)
+                else:
+                    act, slope = _activation_of(module)
                 v = Value('conv', conv.out_channels, Ho, Wo, block=i, src=cur, conv=conv, bn=bn, k=k, stride=s, pad=p,
                           act=act, slope=slope, res=None, ups=1)
+                if self.q:
+                    v.s_w, v.scale = s_w, s_a
                 nxt = defs[i + 1]['type'] if i + 1 < L else None
                 if nxt == 'shortcut' and not routs[i] and self._fusable_shortcut(i + 1, v, outs):
                     v.res = ref(i + 1, mods[i + 1].layers[0])
@@ -196,7 +224,7 @@ class DarknetEngine:
                     pad_lo, edge_zero = (k - 1) // 2, 0
                     Ho, Wo = (cur.H + 2 * pad_lo - k) // s + 1, (cur.W + 2 * pad_lo - k) // s + 1
                 v = Value('pool', cur.C, Ho, Wo, block=i, src=cur, k=k, stride=s, pad_lo=pad_lo, edge_zero=edge_zero)
-                v.segs, v.c_phys = list(cur.segs), cur.c_phys
+                v.segs, v.c_phys, v.scale = list(cur.segs), cur.c_phys, cur.scale
                 values.append(v)
                 cur = v
             elif kind == 'se':
@@ -213,7 +241,7 @@ class DarknetEngine:
                 if s != 2:
                     raise NotImplementedError('HIP engine: upsample stride %d' % s)
                 v = Value('copy', cur.C, cur.H * 2, cur.W * 2, block=i, src=cur, ups=2)
-                v.segs, v.c_phys = list(cur.segs), cur.c_phys
+                v.segs, v.c_phys, v.scale = list(cur.segs), cur.c_phys, cur.scale
                 values.append(v)
                 cur = v
             elif kind == 'route':
@@ -231,17 +259,34 @@ class DarknetEngine:
                         v.segs.extend((off + st, ln) for st, ln in s.segs)
                         off += s.c_phys
                     v.c_phys = off
+                    if self.q:  # COSPTQuantizedFeatureConcat: every input is re-quantised to one shared scale
+                        v.scale = float(module.scale)
+                        if not v.scale > 0:
+                            raise RuntimeError('HIP int8 engine: route %d has no calibrated scale' % i)
                     values.append(v)
                     cur = v
                 elif getattr(module, 'groups', False):
                     half = cur.C // 2
-                    if not cur.is_dense() or half % ALIGN_C or (cur.C - half) % ALIGN_C:
+                    if not cur.is_dense() or half % self.align or (cur.C - half) % self.align:
                         raise NotImplementedError('HIP engine: unaligned group split at block %d' % i)
                     v = Value('slice', cur.C - half, cur.H, cur.W, block=i, src=cur, first=half)
+                    v.scale = cur.scale
                     values.append(v)
                     cur = v
                 else:
                     cur = ref(i, layers[0])
+            elif kind == 'shortcut' and self.q:
+                if cname not in ('COSPTQuantizedShortcut_min', 'COSPTQuantizedShortcut_max') or getattr(module, 'weight', False) \
+                        or len(module.layers) != 1:
+                    raise NotImplementedError('HIP int8 engine: shortcut form at block %d' % i)
+                other = ref(i, module.layers[0])
+                if other.C != cur.C or not cur.is_dense() or not other.is_dense():
+                    raise NotImplementedError('HIP int8 engine: channel-mismatched shortcut (block %d)' % i)
+                v = Value('qadd', cur.C, cur.H, cur.W, block=i, a=cur, b=other, scale_x=float(module.scale_x),
+                          scale_a=float(module.scale_a))
+                v.scale = float(module.scale_sum)
+                values.append(v)
+                cur = v
             elif kind == 'shortcut':
                 if getattr(module, 'weight', False):
                     raise NotImplementedError('HIP engine: weighted shortcut (block %d)' % i)
@@ -285,8 +330,9 @@ class DarknetEngine:
             for s, off in zip(v.srcs, v.offsets):
                 if s.kind == 'input':
                     raise NotImplementedError('HIP engine: route over the network input')
-                inplace = (s.kind in ('conv', 'pool', 'copy', 'add', 'dw', 'se') and s.parent is None and id(s) not in seen
-                           and not s.fp32 and s.storage is None)
+                inplace = (s.kind in ('conv', 'pool', 'copy', 'add', 'dw', 'se', 'qadd') and s.parent is None
+                           and id(s) not in seen and not s.fp32 and s.storage is None
+                           and (not self.q or s.scale == v.scale))  # int8: zero-copy only when no re-quantisation is due
                 if inplace:
                     s.parent, s.parent_off = v, off
                 seen.add(id(s))
@@ -296,7 +342,14 @@ class DarknetEngine:
     def _source_tensors(self):
         out = []
         for block in self.model.module_list:
-            if isinstance(block, nn.Sequential) and len(block) and isinstance(block[0], nn.Conv2d):
+            if self.q and isinstance(block, nn.Sequential) and len(block) and hasattr(block[0], 'q_weight'):
+                c = block[0]
+                out.extend((c.q_weight, c.q_bias, c.weight_quantizer.scale, c.activation_quantizer.scale))
+            elif self.q and hasattr(block, 'scale_sum'):
+                out.extend((block.scale_x, block.scale_a, block.scale_sum))
+            elif self.q and hasattr(block, 'float_max_list'):
+                out.append(block.scale)
+            elif isinstance(block, nn.Sequential) and len(block) and isinstance(block[0], nn.Conv2d):
                 conv, bn = _conv_parts(block)
                 out.extend(t for t in (conv.weight, conv.bias) if t is not None)
                 if bn is not None:
@@ -313,6 +366,8 @@ class DarknetEngine:
         conv, bn = v.conv, v.bn
         dev = conv.weight.device
         f32 = lambda t: None if t is None else t.detach().float().contiguous()
+        if self.q:
+            return self._pack_qconv(v)
         w = f32(conv.weight)
         cb = f32(conv.bias)
         g, be, mu, var = (f32(bn.weight), f32(bn.bias), f32(bn.running_mean), f32(bn.running_var)) if bn is not None \
@@ -346,6 +401,43 @@ class DarknetEngine:
                                                hiplib.stream_ptr())
             hiplib.check(rc, 'yh_conv_pack_weights')
         slot['keep'] = keep  # fp32 staging copies must outlive the async pack kernels
+        self._packed[v.block] = slot
+        return slot
+
+    def _pack_qconv(self, v):
+        """int8 image of a calibrated COS-PTQ conv: grid weights from q_weight / s_w, bias = q_bias in real units."""
+        conv = v.conv
+        dev = conv.q_weight.device
+        qw = conv.q_weight.detach().float().contiguous()
+        qb = conv.q_bias.detach().float().contiguous()
+        P = hiplib.ptr
+        slot = self._packed.get(v.block)
+        if v.src.kind == 'input':  # float frames in: the stem kernel multiplies real-valued (de-quantised) weights
+            cout_pad = v.C if v.C % 32 == 0 else _round_up(v.C, 16)
+            taps = v.k * v.k
+            if slot is None or slot['w'].numel() != taps * v.src.C * cout_pad:
+                slot = dict(w=torch.empty(taps * v.src.C * cout_pad, device=dev, dtype=torch.float32),
+                            b=torch.empty(cout_pad, device=dev, dtype=torch.float32), cout_pad=cout_pad)
+            rc = self.lib.yh_stem_pack_weights(P(qw), P(qb), None, None, None, None, 0.0, v.C, v.src.C, v.k, v.k, cout_pad,
+                                               P(slot['w']), P(slot['b']), hiplib.stream_ptr())
+            hiplib.check(rc, 'yh_stem_pack_weights')
+        else:
+            cin_k = _round_up(v.src.c_phys, self.kstep)
+            m_pad = _round_up(_round_up(v.C, self.align), 128)
+            taps = v.k * v.k
+            cmap = None
+            if not v.src.is_dense():
+                cmap = torch.tensor(v.src.channel_map(), dtype=torch.int32, device=dev)
+            if slot is None or slot['w'].numel() != m_pad * taps * cin_k or slot['w'].dtype != torch.int8:
+                slot = dict(w=torch.empty(m_pad * taps * cin_k, device=dev, dtype=torch.int8),
+                            b=torch.zeros(m_pad, device=dev, dtype=torch.float32), cin_k=cin_k, m_pad=m_pad)
+            rc = self.lib.yh_qconv_pack_weights(P(qw), v.s_w, P(cmap), v.C, conv.in_channels, v.k, v.k, cin_k, m_pad, P(slot['w']),
+                                                hiplib.stream_ptr())
+            hiplib.check(rc, 'yh_qconv_pack_weights')
+            slot['b'].zero_()
+            slot['b'][:v.C].copy_(qb)
+            slot['cmap'] = cmap
+        slot['keep'] = [qw, qb]
         self._packed[v.block] = slot
         return slot
 
@@ -438,7 +530,8 @@ class DarknetEngine:
                 if v.src.kind == 'input':
                     d = StemDesc(x=None, w=P(pk['w']), bias=P(pk['b']), y=y, n=N, cin=v.src.C, h=v.src.H, w_in=v.src.W,
                                  ho=v.Ho, wo=v.Wo, cout=v.c_phys, cout_pad=pk['cout_pad'], kh=v.k, kw=v.k,
-                                 stride=v.stride, pad=v.pad, ldy=v.ld, act=v.act, slope=v.slope, dtype=self.code)
+                                 stride=v.stride, pad=v.pad, ldy=v.ld, act=v.act, slope=v.slope, dtype=self.code,
+                                 out_scale=v.scale if self.q else 0.0)
                     if v.res is not None or v.ups != 1 or v.fp32:
                         raise NotImplementedError('HIP engine: fused epilogue on the first conv')
                     if v.c_phys > pk['cout_pad']:
@@ -459,7 +552,8 @@ class DarknetEngine:
                                  n=N, h=s.H, w_in=s.W, cin=s.c_phys, ho=v.Ho, wo=v.Wo, cout=v.c_phys,
                                  kh=v.k, kw=v.k, stride=v.stride, pad=v.pad, ldx=s.ld,
                                  ldr=0 if v.res is None else v.res.ld, ldy=v.ld, cin_k=pk['cin_k'], m_pad=pk['m_pad'],
-                                 act=v.act, slope=v.slope, ups=v.ups, out_f32=1 if v.fp32 else 0, dtype=self.code, tile=tile)
+                                 act=v.act, slope=v.slope, ups=v.ups, out_f32=1 if v.fp32 else 0, dtype=self.code, tile=tile,
+                                 acc_scale=(v.s_w * s.scale) if self.q else 0.0, out_scale=v.scale if self.q else 0.0)
                     add(d, 'conv%d' % v.block)
             elif v.kind == 'dw':
                 pk = self._packed.get(v.block) or self._pack_dw(v)
@@ -478,9 +572,18 @@ class DarknetEngine:
                            ldx=s.ld, ldy=v.ld, dtype=self.code), 'se%d' % v.block)
             elif v.kind == 'pool':
                 s = v.src
-                add(PoolDesc(x=P(s.storage, s.c_off), y=y, n=N, h=s.H, w_in=s.W, c=s.c_phys, ho=v.H, wo=v.W, k=v.k,
-                             stride=v.stride, pad_lo=v.pad_lo, edge_zero=v.edge_zero, ldx=s.ld, ldy=v.ld,
-                             dtype=self.code), 'pool%d' % v.block)
+                cls = QPoolDesc if self.q else PoolDesc
+                add(cls(x=P(s.storage, s.c_off), y=y, n=N, h=s.H, w_in=s.W, c=s.c_phys, ho=v.H, wo=v.W, k=v.k,
+                        stride=v.stride, pad_lo=v.pad_lo, edge_zero=v.edge_zero, ldx=s.ld, ldy=v.ld,
+                        dtype=self.code), 'pool%d' % v.block)
+            elif v.kind == 'copy' and self.q:
+                s = v.src
+                add(QCopyDesc(x=P(s.storage, s.c_off), y=y, n=N, h=s.H, w_in=s.W, c=s.c_phys, ups=v.ups, ldx=s.ld, ldy=v.ld,
+                              ratio=1.0), 'ups%d' % v.block)
+            elif v.kind == 'qadd':
+                add(QAddDesc(x=P(v.a.storage, v.a.c_off), a=P(v.b.storage, v.b.c_off), y=y, pixels=N * v.H * v.W, c=v.c_phys,
+                             ldx=v.a.ld, lda=v.b.ld, ldy=v.ld, rx=v.a.scale / v.scale_x, ra=v.b.scale / v.scale_a,
+                             scale_x=v.scale_x, scale_a=v.scale_a, inv_scale_sum=1.0 / v.scale), 'qadd%d' % v.block)
             elif v.kind == 'copy':
                 s = v.src
                 add(CopyDesc(x=P(s.storage, s.c_off), y=y, n=N, h=s.H, w_in=s.W, c=s.c_phys, ups=v.ups, ldx=s.ld,
@@ -494,6 +597,10 @@ class DarknetEngine:
                         continue  # its producer writes (or already wrote) the slice
                     if s.fp32:
                         raise NotImplementedError('HIP engine: route over a yolo-head tensor')
+                    if self.q:
+                        add(QCopyDesc(x=P(s.storage, s.c_off), y=P(v.storage, v.c_off + off), n=N, h=s.H, w_in=s.W, c=s.c_phys,
+                                      ups=1, ldx=s.ld, ldy=v.ld, ratio=s.scale / v.scale), 'cat%d' % v.block)
+                        continue
                     add(CopyDesc(x=P(s.storage, s.c_off), y=P(v.storage, v.c_off + off), n=N, h=s.H, w_in=s.W,
                                  c=s.c_phys, ups=1, ldx=s.ld, ldy=v.ld, dtype=self.code), 'cat%d' % v.block)
 

@@ -371,7 +371,9 @@ class Darknet(nn.Module):
         return torch.cat(y, 1), None
 
     def _use_hip(self, x):
-        return x.is_cuda and not self.training and self.quantized == -1
+        # float graphs and the calibrated COS-PTQ graph (quantized == 3, eval) are lowered; the QAT research
+        # quantisers (1, 2) stay on the eager modules
+        return x.is_cuda and not self.training and self.quantized in (-1, 3)
 
     def forward_once(self, x, augment=False, verbose=False):
         if self._use_hip(x) and not verbose and not augment:
@@ -381,8 +383,9 @@ class Darknet(nn.Module):
     def _forward_hip(self, x):
         from engine.plan import DarknetEngine  # raises if libyolo_hip.so is missing: no fallback
         eng = self.__dict__.get('_hip_engine')
-        if eng is None or eng.precision != self.hip_precision:
-            eng = DarknetEngine(self, precision=self.hip_precision)
+        precision = 'int8' if self.quantized == 3 else self.hip_precision
+        if eng is None or eng.precision != precision:
+            eng = DarknetEngine(self, precision=precision)
             self.__dict__['_hip_engine'] = eng
         return eng(x)
 
