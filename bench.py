@@ -35,7 +35,7 @@ for p in (PKG, REPO):
 
 import torch  # noqa: E402
 
-PEAK_TFLOPS = {'fp16': 2500.0, 'fp32': 157.3}  # dense MFMA peaks, MI355X_MICROARCH.md
+PEAK_TFLOPS = {'fp16': 2500.0, 'fp32': 157.3, 'int8': 5000.0}  # dense MFMA peaks (int8: TOP/s), MI355X_MICROARCH.md
 TILE_NAMES = {1: '128x128', 2: '64x256', 3: '32x256', 4: '64x128', 5: '128x64', 6: '256x128', 11: '128x128k8', 12: '64x256k8',
               14: '64x128k8', 15: '128x64k8', 16: '256x128k8', 21: 'dma3_128x128', 22: 'dma3_64x256', 24: 'dma3_64x128',
               25: 'dma3_128x64', 26: 'dma3_256x128', 27: 'dma3_128x256', 41: 'halo_128x256', 51: 'abl_noload', 52: 'abl_nomfma', 42: 'halo_256x256', 31: 'dma4_128x128', 32: 'dma4_64x256', 34: 'dma4_64x128',
@@ -56,6 +56,51 @@ def build_model(cfg, size, precision, device):
     model.load_state_dict(state)
     model.hip_precision = precision
     return model.to(device).eval()
+
+
+def build_qmodel_synthetic(cfg, size, device):
+    """A COS-PTQ graph (Darknet(quantized=3)) with a synthetic calibrated state, for int8 *timing* only.
+
+    Weight/bias grids come from the BN-folded seeded float weights with power-of-two max-abs scales; every
+    activation, shortcut and concat scale is a fixed power of two.  The module classes are the reference's
+    utils/quantized/quantized_ptq_cos.py when a reference checkout is present, otherwise the eval stand-ins of
+    tests/ptq_standin.py (same names, buffers and eval arithmetic; pinned to the reference in tests/test_ptq.py).
+    Only the HIP int8 engine is timed."""
+    import math
+    import models
+    from utils.torch_utils import fold_bn
+    try:
+        import utils.quantized.quantized_ptq_cos  # noqa: F401
+    except Exception:
+        sys.path.insert(0, os.path.join(REPO, 'tests'))
+        import ptq_standin
+        ptq_standin.install()
+    fm = build_model(cfg, size, 'fp16', 'cpu')
+    torch.manual_seed(0)
+    qm = models.Darknet(cfg, (size, size), quantized=3, a_bit=8, w_bit=8, shortcut_way=1)
+    pow2 = lambda t: 2.0 ** math.ceil(math.log2(max(float(t), 1e-12) / 127.0))
+    with torch.no_grad():
+        for f, q in zip(fm.module_list, qm.module_list):
+            name = q.__class__.__name__
+            if isinstance(f, torch.nn.Sequential) and len(f) and isinstance(f[0], torch.nn.Conv2d):
+                conv, bn = f[0], (f[1] if len(f) > 1 and isinstance(f[1], torch.nn.BatchNorm2d) else None)
+                w, b = (conv.weight, conv.bias) if bn is None else fold_bn(conv.weight, conv.bias, bn.weight, bn.bias,
+                                                                           bn.running_mean, bn.running_var, bn.eps)
+                qc = q[0]
+                sw, sb = pow2(w.abs().max()), pow2(b.abs().max())
+                qc.weight_quantizer.scale.fill_(sw)
+                qc.bias_quantizer.scale.fill_(sb)
+                qc.activation_quantizer.scale.fill_(2.0 ** -4)
+                qc.q_weight.copy_((torch.sign(w) * torch.floor(w.abs() / sw + 0.5)).clamp(-128, 127) * sw)
+                qc.q_bias.copy_((torch.sign(b) * torch.floor(b.abs() / sb + 0.5)).clamp(-128, 127) * sb)
+                qc.quantized = True
+            elif name.startswith('COSPTQuantizedShortcut'):
+                q.scale_x.fill_(2.0 ** -4)
+                q.scale_a.fill_(2.0 ** -4)
+                q.scale_sum.fill_(2.0 ** -3)
+            elif name == 'COSPTQuantizedFeatureConcat':
+                q.scale.fill_(2.0 ** -4)
+    return qm.to(device).eval()
 
 
 def conv_flops(plan):
@@ -165,7 +210,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--batch', type=int, default=64, help='frames per GPU per step (BASELINE: batch 64/GPU)')
     ap.add_argument('--size', type=int, default=608)
-    ap.add_argument('--precision', default='fp16', choices=['fp16', 'fp32'])
+    ap.add_argument('--precision', default='fp16', choices=['fp16', 'fp32', 'int8'])
     ap.add_argument('--cfg', default=os.path.join(PKG, 'cfg', 'yolov3', 'yolov3.cfg'))
     ap.add_argument('--no-nms', action='store_true')
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -187,7 +232,8 @@ def main():
         dist.init_process_group('nccl', device_id=device)
 
     from utils.utils import non_max_suppression
-    model = build_model(args.cfg, args.size, args.precision, device)
+    model = build_qmodel_synthetic(args.cfg, args.size, device) if args.precision == 'int8' else \
+        build_model(args.cfg, args.size, args.precision, device)
     g = torch.Generator().manual_seed(100 + rank)
     x = torch.rand(args.batch, 3, args.size, args.size, generator=g).to(device)  # resident in HBM before timing
 
@@ -215,10 +261,10 @@ def main():
         peak = PEAK_TFLOPS[args.precision]
         net_tflops = value / world * gflop_img / 1e3
         out = {
-            'metric': 'images/sec YOLOv3-608 detect fp16 (forward + NMS)', 'value': round(value, 2), 'unit': 'images/s',
+            'metric': 'images/sec YOLOv3-608 detect %s (forward + NMS)' % args.precision, 'value': round(value, 2), 'unit': 'images/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(elapsed / args.steps * 1e3, 4),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'f16' if args.precision == 'fp16' else 'f32', 'data': 'synthetic',
+            'dtype': {'fp16': 'f16', 'fp32': 'f32', 'int8': 'i8'}[args.precision], 'data': 'synthetic',
             'config': {'workload': 'YOLOv3 Darknet-53 %d COCO (80 classes) %s inference, batch %d/GPU, %s'
                                    % (args.size, args.precision, args.batch,
                                       'forward only' if args.no_nms else 'forward + NMS conf 0.3 iou 0.6'),

@@ -81,7 +81,9 @@ def test_hip_int8_engine_matches_reference_eval():
     assert mx <= 1.5 and frac <= 0.02, (mx, frac)
     mx, frac = _grid_mismatch(io[..., 4:], ref[..., 4:], 2e-3)
     assert mx <= 0.05 and frac <= 0.02, (mx, frac)
-    conf = float(torch.quantile(ref[..., 4].flatten(), 0.97))
+    # objectness lives on the int8 grid (many ties): put the threshold just below a grid level that keeps ~3 %
+    conf = float(torch.quantile(ref[..., 4].flatten(), 0.97)) * 0.999
     gt = non_max_suppression(ref.clone(), conf, 0.6, multi_label=False)
+    assert sum(0 if g is None else len(g) for g in gt) >= 10
     det = non_max_suppression(io.cuda(), conf * 0.9, 0.6, multi_label=False)
     assert abs(map50(gt, det) - map50(gt, gt)) <= 0.002

@@ -24,7 +24,7 @@ TILE = {1: '128x128', 2: '64x256', 3: '32x256', 4: '64x128', 5: '128x64', 6: '25
 
 
 def main():
-    from bench import build_model
+    from bench import build_model, build_qmodel_synthetic
     from engine import hiplib
     ap = argparse.ArgumentParser()
     ap.add_argument('--cfg', default=os.path.join(PKG, 'cfg', 'yolov3', 'yolov3.cfg'))
@@ -35,7 +35,8 @@ def main():
     ap.add_argument('--tile', type=int, default=0, help='force one conv tile code for every layer (A/B runs)')
     args = ap.parse_args()
     dev = torch.device('cuda', 0)
-    model = build_model(args.cfg, args.size, args.precision, dev)
+    model = build_qmodel_synthetic(args.cfg, args.size, dev) if args.precision == 'int8' else \
+        build_model(args.cfg, args.size, args.precision, dev)
     x = torch.rand(args.batch, 3, args.size, args.size, device=dev)
     with torch.no_grad():
         model(x)
@@ -54,7 +55,7 @@ def main():
         if it:
             for i in range(n):
                 tot[i] += buf[i] / args.iters
-    esz = 2 if args.precision == 'fp16' else 4
+    esz = {'fp16': 2, 'fp32': 4, 'int8': 1}[args.precision]
     vals = {('conv%d' % v.block if v.src.kind != 'input' else 'stem%d' % v.block): v for v in plan['values'] if v.kind == 'conv'}
     fam = {}
     print('%-8s %-18s %-34s %9s %9s %9s' % ('op', 'kernel', 'shape', 'ms', 'TFLOP/s', 'GB/s'))
