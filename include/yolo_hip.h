@@ -299,6 +299,12 @@ int yh_plan_run_range(yh_plan* p, int first, int last, void* stream);
  * per-op durations in milliseconds to the HOST array ms_out[n], n == yh_plan_num_ops.                    */
 int yh_plan_set_timing(yh_plan* p, int enable);
 int yh_plan_get_timings(yh_plan* p, float* ms_out, int n);
+/* hipGraph replay for launch-bound (small batch) forwards: capture records one replay with the currently bound
+ * slot pointers on a non-null stream; launch replays it with a single graph launch; reset drops the graph (needed
+ * before slot pointers or recorded ops change).  Weights may be re-packed in place between launches.          */
+int yh_plan_graph_capture(yh_plan* p, void* stream);
+int yh_plan_graph_launch(yh_plan* p, void* stream);
+int yh_plan_graph_reset(yh_plan* p);
 
 #ifdef __cplusplus
 }

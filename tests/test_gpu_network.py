@@ -127,3 +127,31 @@ def test_train_mode_and_weight_updates(cfg_dir):
     inf_o, _ = oracle.forward(model.module_defs, {k: v.cpu() for k, v in model.state_dict().items()}, x, fold=True)
     assert (a - b).abs().max().item() > 1e-3
     assert (b.cpu() - inf_o)[..., :4].abs().max().item() <= 1e-3
+
+
+def test_graph_replay_equals_direct_replay(cfg_dir):
+    """Small batches replay through a captured hipGraph; results must equal the launch-by-launch replay."""
+    model = build_mirror(cfg_dir, 'yolov3/yolov3.cfg', 320).cuda()
+    x = synth.image_batch(2, 320, seed=51)
+    outs = {}
+    for mode in (0, 8):
+        model.hip_refresh()
+        model.hip_precision = 'fp16'
+        with torch.no_grad():
+            model(x.cuda())
+        eng = model.__dict__['_hip_engine']
+        eng.graph_max_batch = mode
+        res = []
+        for k in range(3):  # several launches of the same captured graph, with a changing frame
+            with torch.no_grad():
+                inf, raws, _ = model((x + 0.01 * k).clamp(0, 1).cuda())
+            res.append((inf.clone(), [r.clone() for r in raws]))
+        outs[mode] = res
+        if mode:
+            plan = next(iter(eng._plans.values()))
+            assert plan.get('graph') is not None, 'graph path did not engage'
+    for (a, ra), (b, rb) in zip(outs[0], outs[8]):
+        assert torch.equal(a, b)
+        for p, q in zip(ra, rb):
+            assert torch.equal(p, q)
+    assert not torch.equal(outs[8][0][0], outs[8][1][0]), 'graph must see the new frame'

@@ -77,8 +77,18 @@ struct yh_plan {
     // optional per-op HIP-event timing (bench.py roofline leg): events[2*i], events[2*i+1] bracket op i
     bool timing = false;
     std::vector<hipEvent_t> events;
+    // optional hipGraph of one replay (launch-bound small batches): valid for the slot pointers bound at capture
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t graph_exec = nullptr;
+    void drop_graph() {
+        if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
+        if (graph) (void)hipGraphDestroy(graph);
+        graph_exec = nullptr;
+        graph = nullptr;
+    }
     ~yh_plan() {
         for (hipEvent_t e : events) (void)hipEventDestroy(e);
+        drop_graph();
     }
 };
 
@@ -196,4 +206,39 @@ extern "C" int yh_plan_get_timings(yh_plan* p, float* ms_out, int n) {
 extern "C" int yh_plan_run(yh_plan* p, void* stream) {
     if (!p) return YH_EINVAL;
     return yh_plan_run_range(p, 0, (int)p->ops.size(), stream);
+}
+
+
+// ---- hipGraph replay -----------------------------------------------------------------------------------
+// Captures one replay of the plan (with the currently bound slot pointers) on `stream` into an executable
+// graph; yh_plan_graph_launch then costs one graph launch instead of ~100 kernel launches.  The caller keeps
+// the slot buffers static between capture and launches (engine/plan.py stages the frame into a fixed buffer).
+extern "C" int yh_plan_graph_capture(yh_plan* p, void* stream) {
+    if (!p || !stream) return YH_EINVAL;  // capture needs a real (non-null) stream
+    p->drop_graph();
+    const bool was_timing = p->timing;
+    p->timing = false;
+    hipStream_t s = (hipStream_t)stream;
+    hipError_t e = hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed);
+    if (e != hipSuccess) { p->timing = was_timing; return (int)e; }
+    const int rc = yh_plan_run_range(p, 0, (int)p->ops.size(), stream);
+    e = hipStreamEndCapture(s, &p->graph);
+    p->timing = was_timing;
+    if (rc != YH_OK) { p->drop_graph(); return rc; }
+    if (e != hipSuccess) { p->drop_graph(); return (int)e; }
+    e = hipGraphInstantiate(&p->graph_exec, p->graph, nullptr, nullptr, 0);
+    if (e != hipSuccess) { p->drop_graph(); return (int)e; }
+    return YH_OK;
+}
+
+extern "C" int yh_plan_graph_launch(yh_plan* p, void* stream) {
+    if (!p || !p->graph_exec) return YH_EINVAL;
+    const hipError_t e = hipGraphLaunch(p->graph_exec, (hipStream_t)stream);
+    return e == hipSuccess ? YH_OK : (int)e;
+}
+
+extern "C" int yh_plan_graph_reset(yh_plan* p) {
+    if (!p) return YH_EINVAL;
+    p->drop_graph();
+    return YH_OK;
 }

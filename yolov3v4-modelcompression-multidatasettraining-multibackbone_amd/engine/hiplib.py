@@ -127,6 +127,9 @@ _SIGNATURES = {
     'yh_plan_run_range': (C.c_int, [_vp, C.c_int, C.c_int, _vp]),
     'yh_plan_set_timing': (C.c_int, [_vp, C.c_int]),
     'yh_plan_get_timings': (C.c_int, [_vp, C.POINTER(C.c_float), C.c_int]),
+    'yh_plan_graph_capture': (C.c_int, [_vp, _vp]),
+    'yh_plan_graph_launch': (C.c_int, [_vp, _vp]),
+    'yh_plan_graph_reset': (C.c_int, [_vp]),
 }
 
 EXPORTS = tuple(_SIGNATURES)

@@ -140,6 +140,9 @@ class DarknetEngine:
         self.want_raw = True
         self.return_features = False
         self.force_tile = int(os.environ.get('YOLO_HIP_TILE', '0'))  # A/B profiling knob; 0 = library heuristic
+        # batches up to this size replay through a captured hipGraph (one launch instead of ~100: detect.py's
+        # frame-at-a-time loop is launch-bound); 0 disables.  Frames are staged into a fixed input buffer.
+        self.graph_max_batch = int(os.environ.get('YOLO_HIP_GRAPH_BATCH', '8'))
         self._plans = {}
         self._packed = {}  # block index -> dict(w=, b=, ...)
         self._signature = None
@@ -675,17 +678,42 @@ class DarknetEngine:
         if plan is None:
             plan = self._plans[key] = self._build_plan(N, Cin, H, W)
 
-        io = torch.empty((N, plan['rows'], plan['no']), device=x.device, dtype=torch.float32)
-        raws = [torch.empty(shape, device=x.device, dtype=torch.float32) for shape in plan['raw_shapes']] \
-            if self.want_raw else []
         lib, handle = self.lib, plan['handle']
-        lib.yh_plan_bind_slot(handle, SLOT_INPUT, x.data_ptr())
-        lib.yh_plan_bind_slot(handle, SLOT_IO, io.data_ptr())
-        for k, r in enumerate(raws):
-            lib.yh_plan_bind_slot(handle, SLOT_RAW0 + k, r.data_ptr())
-        hiplib.check(lib.yh_plan_run(handle, hiplib.stream_ptr()), 'yh_plan_run')
+        if 0 < N <= self.graph_max_batch and x.is_cuda and hasattr(lib, 'yh_plan_graph_launch'):
+            io, raws = self._run_graph(plan, x)
+        else:
+            io = torch.empty((N, plan['rows'], plan['no']), device=x.device, dtype=torch.float32)
+            raws = [torch.empty(shape, device=x.device, dtype=torch.float32) for shape in plan['raw_shapes']] \
+                if self.want_raw else []
+            lib.yh_plan_bind_slot(handle, SLOT_INPUT, x.data_ptr())
+            lib.yh_plan_bind_slot(handle, SLOT_IO, io.data_ptr())
+            for k, r in enumerate(raws):
+                lib.yh_plan_bind_slot(handle, SLOT_RAW0 + k, r.data_ptr())
+            hiplib.check(lib.yh_plan_run(handle, hiplib.stream_ptr()), 'yh_plan_run')
         feats = self._features(plan) if self.return_features else []
         return io, tuple(raws), feats
+
+    def _run_graph(self, plan, x):
+        """Small-batch path: static I/O buffers + one hipGraph launch; results are copied out (fresh tensors)."""
+        lib, handle = self.lib, plan['handle']
+        g = plan.get('graph')
+        stream = hiplib.stream_ptr()
+        if g is None or g['want_raw'] != self.want_raw or g['stream'] != torch.cuda.current_stream().cuda_stream:
+            dev = x.device
+            g = dict(x=torch.empty_like(x), io=torch.empty((x.shape[0], plan['rows'], plan['no']), device=dev, dtype=torch.float32),
+                     raws=[torch.empty(sh, device=dev, dtype=torch.float32) for sh in plan['raw_shapes']] if self.want_raw else [],
+                     want_raw=self.want_raw, stream=torch.cuda.current_stream().cuda_stream)
+            lib.yh_plan_bind_slot(handle, SLOT_INPUT, g['x'].data_ptr())
+            lib.yh_plan_bind_slot(handle, SLOT_IO, g['io'].data_ptr())
+            for k, r in enumerate(g['raws']):
+                lib.yh_plan_bind_slot(handle, SLOT_RAW0 + k, r.data_ptr())
+            g['x'].copy_(x)
+            hiplib.check(lib.yh_plan_run(handle, stream), 'yh_plan_run')   # warm (lazy kernel loads) before capturing
+            hiplib.check(lib.yh_plan_graph_capture(handle, stream), 'yh_plan_graph_capture')
+            plan['graph'] = g
+        g['x'].copy_(x)
+        hiplib.check(lib.yh_plan_graph_launch(handle, stream), 'yh_plan_graph_launch')
+        return g['io'].clone(), [r.clone() for r in g['raws']]
 
     def _features(self, plan):
         """NCHW fp32 copies of the conv-block outputs the reference appends to ``feature_out``."""
