@@ -694,26 +694,41 @@ class DarknetEngine:
         return io, tuple(raws), feats
 
     def _run_graph(self, plan, x):
-        """Small-batch path: static I/O buffers + one hipGraph launch; results are copied out (fresh tensors)."""
+        """Small-batch path: static I/O buffers + one hipGraph launch; results are copied out (fresh tensors).
+
+        Stream capture is not allowed on the legacy default stream, so the graph lives on an engine-owned
+        side stream that is ordered against the caller's current stream on both sides."""
         lib, handle = self.lib, plan['handle']
-        g = plan.get('graph')
-        stream = hiplib.stream_ptr()
-        if g is None or g['want_raw'] != self.want_raw or g['stream'] != torch.cuda.current_stream().cuda_stream:
-            dev = x.device
-            g = dict(x=torch.empty_like(x), io=torch.empty((x.shape[0], plan['rows'], plan['no']), device=dev, dtype=torch.float32),
-                     raws=[torch.empty(sh, device=dev, dtype=torch.float32) for sh in plan['raw_shapes']] if self.want_raw else [],
-                     want_raw=self.want_raw, stream=torch.cuda.current_stream().cuda_stream)
-            lib.yh_plan_bind_slot(handle, SLOT_INPUT, g['x'].data_ptr())
-            lib.yh_plan_bind_slot(handle, SLOT_IO, g['io'].data_ptr())
-            for k, r in enumerate(g['raws']):
-                lib.yh_plan_bind_slot(handle, SLOT_RAW0 + k, r.data_ptr())
+        cur = torch.cuda.current_stream()
+        gs = self.__dict__.get('_graph_stream')
+        if gs is None:
+            gs = self._graph_stream = torch.cuda.Stream(device=x.device)
+        gs.wait_stream(cur)
+        with torch.cuda.stream(gs):
+            sp = C.c_void_p(gs.cuda_stream)
+            g = plan.get('graph')
+            if g is None or g['want_raw'] != self.want_raw:
+                dev = x.device
+                g = dict(x=torch.empty_like(x),
+                         io=torch.empty((x.shape[0], plan['rows'], plan['no']), device=dev, dtype=torch.float32),
+                         raws=[torch.empty(sh, device=dev, dtype=torch.float32) for sh in plan['raw_shapes']]
+                         if self.want_raw else [], want_raw=self.want_raw)
+                lib.yh_plan_bind_slot(handle, SLOT_INPUT, g['x'].data_ptr())
+                lib.yh_plan_bind_slot(handle, SLOT_IO, g['io'].data_ptr())
+                for k, r in enumerate(g['raws']):
+                    lib.yh_plan_bind_slot(handle, SLOT_RAW0 + k, r.data_ptr())
+                g['x'].copy_(x)
+                hiplib.check(lib.yh_plan_run(handle, sp), 'yh_plan_run')   # warm (lazy code loads) before capturing
+                hiplib.check(lib.yh_plan_graph_capture(handle, sp), 'yh_plan_graph_capture')
+                plan['graph'] = g
             g['x'].copy_(x)
-            hiplib.check(lib.yh_plan_run(handle, stream), 'yh_plan_run')   # warm (lazy kernel loads) before capturing
-            hiplib.check(lib.yh_plan_graph_capture(handle, stream), 'yh_plan_graph_capture')
-            plan['graph'] = g
-        g['x'].copy_(x)
-        hiplib.check(lib.yh_plan_graph_launch(handle, stream), 'yh_plan_graph_launch')
-        return g['io'].clone(), [r.clone() for r in g['raws']]
+            hiplib.check(lib.yh_plan_graph_launch(handle, sp), 'yh_plan_graph_launch')
+            io = g['io'].clone()
+            raws = [r.clone() for r in g['raws']]
+        cur.wait_stream(gs)
+        for t in [io] + raws:
+            t.record_stream(cur)
+        return io, raws
 
     def _features(self, plan):
         """NCHW fp32 copies of the conv-block outputs the reference appends to ``feature_out``."""
