@@ -140,9 +140,10 @@ class DarknetEngine:
         self.want_raw = True
         self.return_features = False
         self.force_tile = int(os.environ.get('YOLO_HIP_TILE', '0'))  # A/B profiling knob; 0 = library heuristic
-        # batches up to this size replay through a captured hipGraph (one launch instead of ~100: detect.py's
-        # frame-at-a-time loop is launch-bound); 0 disables.  Frames are staged into a fixed input buffer.
-        self.graph_max_batch = int(os.environ.get('YOLO_HIP_GRAPH_BATCH', '8'))
+        # batches up to this size replay through a captured hipGraph (one launch instead of ~100).  Off by default:
+        # with the native plan executor the frame-at-a-time forward is GPU-bound (1.63 ms at batch 1, YOLOv3-608),
+        # and the graph's staged input / cloned outputs make it ~8 % slower (profiles/r01_latency_*.txt).
+        self.graph_max_batch = int(os.environ.get('YOLO_HIP_GRAPH_BATCH', '0'))
         self._plans = {}
         self._packed = {}  # block index -> dict(w=, b=, ...)
         self._signature = None
