@@ -203,6 +203,166 @@ def cpu_baseline(cfg, size, budget_s):
                 sample='%d images of YOLOv3-%d, batch 1, fp32, oracle.forward (BN folded), %.1f s' % (n, size, dt))
 
 
+HYP = {'giou': 3.54, 'cls': 37.4, 'cls_pw': 1.0, 'obj': 64.3, 'obj_pw': 1.0, 'iou_t': 0.20, 'lr0': 0.01, 'momentum': 0.937,
+       'weight_decay': 0.0005, 'fl_gamma': 0.0}  # reference train.py:25-35
+
+
+def synthetic_labels(batch, per_image, nc, seed, device):
+    g = torch.Generator().manual_seed(seed)
+    n = batch * per_image
+    wh = torch.rand(n, 2, generator=g) * 0.4 + 0.03
+    xy = torch.rand(n, 2, generator=g) * (1 - wh) + wh / 2
+    img = torch.arange(batch).repeat_interleave(per_image).float().view(-1, 1)
+    cls = torch.randint(0, nc, (n, 1), generator=g).float()
+    return torch.cat((img, cls, xy, wh), 1).to(device)
+
+
+def train_main(args, device, dist, world, rank, local_rank):
+    """configs[2]: one optimisation step = train-mode forward + compute_loss + backward + SGD (reference train.py:371-433:
+    autocast forward, loss scaled by batch/64, GradScaler backward, nesterov SGD with the three parameter groups)."""
+    from models import Darknet
+    from utils.utils import compute_loss
+    from engine import distutil
+    if args.precision == 'int8':
+        raise SystemExit('--mode train runs fp16 (autocast, fp32 master weights) or fp32')
+    torch.manual_seed(0)
+    model = Darknet(args.cfg, (args.size, args.size)).to(device)
+    pg0, pg1, pg2 = [], [], []
+    for k, v in dict(model.named_parameters()).items():   # train.py:112-119
+        if '.bias' in k:
+            pg2.append(v)
+        elif 'Conv2d.weight' in k:
+            pg1.append(v)
+        else:
+            pg0.append(v)
+    opt = torch.optim.SGD(pg0, lr=HYP['lr0'] * 0.01, momentum=HYP['momentum'], nesterov=True)
+    opt.add_param_group({'params': pg1, 'weight_decay': HYP['weight_decay']})
+    opt.add_param_group({'params': pg2})
+    core = model
+    if world > 1:
+        model = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank], output_device=local_rank)
+        model.yolo_layers = core.yolo_layers
+    for m in {model, core}:
+        m.nc, m.hyp, m.gr = 80, HYP, 1.0
+    model.train()
+    g = torch.Generator().manual_seed(100 + rank)
+    x = torch.rand(args.batch, 3, args.size, args.size, generator=g).to(device)
+    targets = synthetic_labels(args.batch, 8, 80, 200 + rank, device)
+    fp16 = args.precision == 'fp16'
+    scaler = torch.amp.GradScaler('cuda', enabled=fp16)
+    state = {}
+
+    def step():
+        with torch.autocast('cuda', dtype=torch.float16, enabled=fp16):
+            pred, _ = model(x)
+        loss, items = compute_loss(pred, targets, model)
+        loss = loss * (args.batch / 64)
+        opt.zero_grad(set_to_none=True)
+        scaler.scale(loss).backward()
+        scaler.step(opt)
+        scaler.update()
+        state['loss'] = items
+
+    for _ in range(args.warmup):
+        step()
+    eng = core.__dict__.get('_hip_train_engine')
+    if eng is None:
+        raise SystemExit('the HIP training path did not engage (cfg not lowered?)')
+    elapsed = distutil.timed_region(step, args.steps, dist, device)
+    if rank == 0:
+        images = world * args.batch * args.steps
+        value = images / elapsed
+        plan = eng._current
+        fwd_flops = sum(2.0 * plan['N'] * v.Ho * v.Wo * v.C * v.conv.in_channels * v.k * v.k
+                        for v in plan['values'] if v.kind == 'conv')
+        gflop_img = 3 * fwd_flops / args.batch / 1e9      # forward + data gradient + weight gradient
+        peak = PEAK_TFLOPS[args.precision]
+        net = value / world * gflop_img / 1e3
+        out = {
+            'metric': 'images/sec YOLOv3-608 train %s' % args.precision, 'value': round(value, 2), 'unit': 'images/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(elapsed / args.steps * 1e3, 3),
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': {'fp16': 'f16', 'fp32': 'f32'}[args.precision], 'data': 'synthetic',
+            'config': {'workload': 'YOLOv3 Darknet-53 %d COCO (80 classes) %s training step, batch %d/GPU: train-mode forward '
+                                   '(batch-stat BN) + compute_loss + backward + nesterov SGD, %s'
+                                   % (args.size, args.precision, args.batch,
+                                      'DDP gradient all-reduce over RCCL' if world > 1 else 'single GPU'),
+                       'global_batch': world * args.batch, 'parallelism': 'dp%d' % world, 'gflop_per_image': round(gflop_img, 2),
+                       'loss': [round(float(v), 4) for v in state['loss']]},
+            'roofline_net': {'bound': 'mfma', 'achieved': round(net, 2), 'peak': peak, 'unit': 'TFLOP/s',
+                             'frac': round(net / peak, 4), 'per': 'GPU, whole step incl. loss, optimizer and host gaps'},
+        }
+        out['roofline'] = train_roofline(eng, x, args.precision)
+        out['cpu_baseline'] = None if (world > 1 or args.no_cpu_baseline) else cpu_train_baseline(args.cfg, args.cpu_seconds)
+        print(json.dumps(out))
+    distutil.barrier(dist)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def train_roofline(eng, x, precision):
+    """Per-op HIP-event timing of one forward + backward plan replay; the dominant kernel class by time."""
+    import ctypes as C
+    lib, plan = eng.lib, eng._current
+    heads = eng.forward(x)
+    torch.cuda.synchronize()
+    groups = {}
+    for key, log in (('fwd', plan['fwd_ops']), ('bwd', plan['bwd_ops'])):
+        handle = plan[key]
+        lib.yh_plan_set_timing(handle, 1)
+        if key == 'fwd':
+            eng.forward(x)
+        else:
+            eng.backward([torch.randn_like(h) * 1e-3 for h in heads])
+        torch.cuda.synchronize()
+        n = lib.yh_plan_num_ops(handle)
+        buf = (C.c_float * n)()
+        lib.yh_plan_get_timings(handle, buf, n)
+        lib.yh_plan_set_timing(handle, 0)
+        for (what, desc), ms in zip(log, buf):
+            name = what.rstrip('0123456789')
+            grp = groups.setdefault(name, dict(ms=0.0, flops=0.0, n=0))
+            grp['ms'] += ms
+            grp['n'] += 1
+            if name in ('conv', 'dgrad'):
+                grp['flops'] += 2.0 * desc.n * desc.ho * desc.wo * desc.cout * desc.cin * desc.kh * desc.kw
+            elif name == 'wgrad':
+                grp['flops'] += 2.0 * desc.n * desc.ho * desc.wo * desc.cout * desc.cin * desc.kh * desc.kw
+    total = sum(g['ms'] for g in groups.values())
+    table = {k: dict(ms=round(g['ms'], 3), n=g['n'], tflops=round(g['flops'] / g['ms'] / 1e9, 1) if g['ms'] > 0 else 0)
+             for k, g in sorted(groups.items(), key=lambda kv: -kv[1]['ms'])}
+    top = max((k for k in groups if groups[k]['flops'] > 0), key=lambda k: groups[k]['ms'])
+    ach = groups[top]['flops'] / groups[top]['ms'] / 1e9
+    peak = PEAK_TFLOPS[precision]
+    return {'bound': 'mfma', 'kernel': top, 'achieved': round(ach, 1), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(ach / peak, 4),
+            'traffic': None, 'gpu_ms_per_step': round(total, 3), 'by_kernel': table}
+
+
+def cpu_train_baseline(cfg, budget_s):
+    """Eager fp32 training step of the same cfg on the host cores (this package's eager modules, bit-equal to the reference's)."""
+    from models import Darknet
+    from utils.utils import compute_loss
+    torch.set_num_threads(min(64, max(1, (os.cpu_count() or 2) // 2)))
+    torch.manual_seed(0)
+    size = 608
+    model = Darknet(cfg, (size, size)).train()
+    model.nc, model.hyp, model.gr = 80, HYP, 1.0
+    x = torch.rand(2, 3, size, size)
+    targets = synthetic_labels(2, 8, 80, 7, 'cpu')
+    t0, n = time.time(), 0
+    while True:
+        pred, _ = model(x)
+        loss, _ = compute_loss(pred, targets, model)
+        model.zero_grad()
+        loss.backward()
+        n += 2
+        dt = time.time() - t0
+        if dt >= budget_s or n >= 32:
+            break
+    return dict(value=round(n / dt, 3), unit='images/s', cores=torch.get_num_threads(), kind='port',
+                sample='%d images of YOLOv3-608, batch 2, fp32 eager forward+loss+backward (no optimizer), %.1f s' % (n, dt))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -212,6 +372,8 @@ def main():
     ap.add_argument('--size', type=int, default=608)
     ap.add_argument('--precision', default='fp16', choices=['fp16', 'fp32', 'int8'])
     ap.add_argument('--cfg', default=os.path.join(PKG, 'cfg', 'yolov3', 'yolov3.cfg'))
+    ap.add_argument('--mode', default='detect', choices=['detect', 'train'],
+                    help='detect: forward + NMS (configs[1]); train: forward + loss + backward + SGD step (configs[2])')
     ap.add_argument('--no-nms', action='store_true')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=12.0)
@@ -231,6 +393,8 @@ def main():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group('nccl', device_id=device)
 
+    if args.mode == 'train':
+        return train_main(args, device, dist, world, rank, local_rank)
     from utils.utils import non_max_suppression
     model = build_qmodel_synthetic(args.cfg, args.size, device) if args.precision == 'int8' else \
         build_model(args.cfg, args.size, args.precision, device)

@@ -277,13 +277,90 @@ int yh_nms_merge(const float* sorted, const int32_t* count, const int32_t* keep_
                  void* stream);
 
 /* ---------------------------------------------------------------------------------------------------
+ * Training path: train-mode BatchNorm + activation around the conv kernels above, and the
+ * backward kernels.  Replaces nn.BatchNorm2d in training mode (models.py:100, momentum 0.1, eps 1e-5), the
+ * activation modules and their autograd, and autograd's conv backward.  z = conv output (dtype), statistics fp32.
+ *
+ *  yh_bn_stats      sum[c] += sum_p z, sumsq[c] += sum_p z^2 over all pixels (caller zeroes sum/sumsq, fp32 [c]).
+ *  yh_bn_finalize   mean = sum/P, var = sumsq/P - mean^2 (biased); invstd = 1/sqrt(var+eps);
+ *                   running_mean = (1-m) running_mean + m mean; running_var = (1-m) running_var + m var P/(P-1).
+ *  yh_bn_act_fwd    y = act(gamma (z-mean) invstd + beta) [+ res]; optional 2x upsampled write (ups).
+ *  yh_bn_act_bwd_reduce   g = dy * act'(u), u = gamma xhat + beta, xhat = (z-mean) invstd:
+ *                         dbeta[c] += sum_p g, dgamma[c] += sum_p g xhat   (caller zeroes, fp32)
+ *  yh_bn_act_bwd_apply    dz = gamma invstd (g - dbeta/P - xhat dgamma/P)
+ * For blocks without BN (gamma == NULL in the desc) fwd is y = act(z + bias) and bwd is dz = dy * act'(z + bias)
+ * with dbeta = the bias gradient.                                                                              */
+typedef struct yh_bn_desc {
+    const void* z;          /* conv output, dtype, pitch ldz                                                  */
+    const void* dy;         /* bwd: gradient w.r.t. the block output (after residual add), pitch lddy         */
+    const void* res;        /* fwd: residual added after the activation (NULL for none), pitch ldr            */
+    void* out;              /* fwd: y (pitch ldo); bwd apply: dz (pitch ldo)                                   */
+    const float* gamma;     /* [c] or NULL (block without BN)                                                  */
+    const float* beta;      /* [c] BN beta, or the conv bias when gamma == NULL (may be NULL = 0)              */
+    float* mean;            /* [c] batch mean (finalize writes, others read)                                   */
+    float* invstd;          /* [c]                                                                             */
+    float* sum;             /* [c] stats: sum z     / bwd: dbeta  accumulator                                  */
+    float* sumsq;           /* [c] stats: sum z^2   / bwd: dgamma accumulator                                  */
+    float* running_mean;    /* [c] or NULL                                                                     */
+    float* running_var;     /* [c] or NULL                                                                     */
+    int64_t pixels;         /* n*h*w of z                                                                      */
+    int32_t n, h, w_in;     /* geometry of z (needed for ups)                                                  */
+    int32_t c, ldz, lddy, ldr, ldo, act, ups, dtype;
+    float slope, eps, momentum;
+} yh_bn_desc;
+int yh_bn_stats(const yh_bn_desc* d, void* stream);
+int yh_bn_finalize(const yh_bn_desc* d, void* stream);
+int yh_bn_act_fwd(const yh_bn_desc* d, void* stream);
+int yh_bn_act_bwd_reduce(const yh_bn_desc* d, void* stream);
+int yh_bn_act_bwd_apply(const yh_bn_desc* d, void* stream);
+
+/* Backward of the convolution itself (replaces autograd's conv2d backward behind nn.Conv2d, models.py:88-99).
+ *
+ *  data gradient   = the forward kernel run on dz with the transposed, spatially flipped weight image:
+ *                    yh_conv_pack_weights_dgrad builds [m_pad rows = cin][kh*kw flipped][cout_k] from the fp32 OIHW
+ *                    parameter; call yh_conv2d_fwd with x = dz, stride 1, pad = k-1-pad, act linear, res = y = the
+ *                    gradient buffer of the input when it already holds another consumer's contribution.
+ *                    Stride-2 layers first scatter dz onto the even positions of a zeroed (n, 2ho, 2wo, c) buffer
+ *                    (yh_dilate2; odd positions stay zero forever).
+ *  weight gradient = yh_conv2d_wgrad: dw[co][ci][r][s] += sum_pixels dz[p][co] * x[p shifted by tap][ci], fp32 OIHW,
+ *                    accumulated with atomics over pixel splits (caller zeroes dw).  MFMA with the pixel index as K.
+ *  yh_stem_wgrad   the same for the first layer, whose input is the fp32 NCHW image (cin <= 4, 3x3).
+ *  yh_upsample2_bwd  dx[n,h,w,c] = sum of the 2x2 block of dy (backward of the fused nearest-neighbour store).
+ *  yh_cast_f32     fp32 pitched rows -> dtype pitched rows (head gradients arrive from autograd as fp32).          */
+int yh_conv_pack_weights_dgrad(int dtype, const float* w, int cout, int cin, int kh, int kw, int cout_k, int m_pad,
+                               void* packed, void* stream);
+typedef struct yh_wgrad_desc {
+    const void* x;          /* forward input of the conv, NHWC dtype (stem: NCHW fp32 image)                    */
+    const void* dz;         /* gradient of the conv output, NHWC dtype, pitch lddz                              */
+    float* dw;              /* [cout][cin][kh][kw] fp32, accumulated                                            */
+    int32_t n, h, w_in, cin, ho, wo, cout, kh, kw, stride, pad, ldx, lddz, dtype;
+    int32_t splits;         /* pixel-range splits (0 = library heuristic)                                       */
+} yh_wgrad_desc;
+int yh_conv2d_wgrad(const yh_wgrad_desc* d, void* stream);
+int yh_stem_wgrad(const yh_wgrad_desc* d, void* stream);
+typedef struct yh_resample_desc {
+    const void* x; void* y;
+    int32_t n, h, w_in, c;  /* geometry of the SMALL tensor (dilate2: source; upsample2_bwd: destination)       */
+    int32_t big_h, big_w;   /* geometry of the LARGE tensor: 2h x 2w, or 2h-1 / 2w-1 for dilate2 onto an odd input  */
+    int32_t ldx, ldy, dtype;
+} yh_resample_desc;
+int yh_dilate2(const yh_resample_desc* d, void* stream);
+int yh_upsample2_bwd(const yh_resample_desc* d, void* stream);
+typedef struct yh_cast_desc {
+    const float* x; void* y; int64_t pixels; int32_t c, ldx, ldy, dtype;
+} yh_cast_desc;
+int yh_cast_f32(const yh_cast_desc* d, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------
  * Plans: a recorded sequence of the launches above, replayed by one native call per forward (the
  * replacement for the per-layer Python dispatch loop of models.py:524-545).  Pointers that change
  * from call to call (network input, per-call outputs) are "slots": a fixup patches one pointer field
  * of one recorded op with slot_base + byte_offset right before launch.                                  */
 typedef struct yh_plan yh_plan;
 enum { YH_OP_CONV = 1, YH_OP_STEM = 2, YH_OP_POOL = 3, YH_OP_COPY = 4, YH_OP_ADD = 5, YH_OP_DECODE = 6, YH_OP_DW = 7,
-       YH_OP_SE = 8, YH_OP_QCOPY = 9, YH_OP_QPOOL = 10, YH_OP_QADD = 11 };
+       YH_OP_SE = 8, YH_OP_QCOPY = 9, YH_OP_QPOOL = 10, YH_OP_QADD = 11, YH_OP_BN_STATS = 12, YH_OP_BN_FINALIZE = 13,
+       YH_OP_BN_ACT_FWD = 14, YH_OP_BN_BWD_REDUCE = 15, YH_OP_BN_BWD_APPLY = 16, YH_OP_WGRAD = 17, YH_OP_STEM_WGRAD = 18,
+       YH_OP_DILATE2 = 19, YH_OP_UPSAMPLE2_BWD = 20, YH_OP_CAST_F32 = 21 };
 
 yh_plan* yh_plan_create(void);
 void yh_plan_destroy(yh_plan* p);

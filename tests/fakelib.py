@@ -16,12 +16,17 @@ import torch.nn.functional as F
 
 from engine import hiplib
 from engine.hiplib import (ConvDesc, StemDesc, PoolDesc, CopyDesc, AddDesc, DecodeDesc, DwDesc, SeDesc, QCopyDesc, QPoolDesc,
-                           QAddDesc)
+                           QAddDesc, BnStatsDesc, BnFinalizeDesc, BnActFwdDesc, BnBwdReduceDesc, BnBwdApplyDesc, WgradDesc,
+                           StemWgradDesc, DilateDesc, UpsampleBwdDesc, CastDesc)
 
 _NP = {hiplib.YH_F16: np.float16, hiplib.YH_F32: np.float32, hiplib.YH_I8: np.int8}
 _DESC = {hiplib.OP_CONV: ConvDesc, hiplib.OP_STEM: StemDesc, hiplib.OP_POOL: PoolDesc, hiplib.OP_COPY: CopyDesc,
          hiplib.OP_ADD: AddDesc, hiplib.OP_DECODE: DecodeDesc, hiplib.OP_DW: DwDesc, hiplib.OP_SE: SeDesc,
-         hiplib.OP_QCOPY: QCopyDesc, hiplib.OP_QPOOL: QPoolDesc, hiplib.OP_QADD: QAddDesc}
+         hiplib.OP_QCOPY: QCopyDesc, hiplib.OP_QPOOL: QPoolDesc, hiplib.OP_QADD: QAddDesc,
+         hiplib.OP_BN_STATS: BnStatsDesc, hiplib.OP_BN_FINALIZE: BnFinalizeDesc, hiplib.OP_BN_ACT_FWD: BnActFwdDesc,
+         hiplib.OP_BN_BWD_REDUCE: BnBwdReduceDesc, hiplib.OP_BN_BWD_APPLY: BnBwdApplyDesc, hiplib.OP_WGRAD: WgradDesc,
+         hiplib.OP_STEM_WGRAD: StemWgradDesc, hiplib.OP_DILATE2: DilateDesc, hiplib.OP_UPSAMPLE2_BWD: UpsampleBwdDesc,
+         hiplib.OP_CAST_F32: CastDesc}
 
 
 def _addr(p):
@@ -325,6 +330,151 @@ class FakeLib:
             flat(d.raw, raw.numel(), np.float32)[:] = raw.reshape(-1).numpy()
         return 0
 
+    # ---- training path
+    @staticmethod
+    def _act_grad(u, act, slope):
+        if act == 1:
+            return torch.where(u > 0, torch.ones_like(u), torch.full_like(u, slope))
+        if act == 2:
+            return (u > 0).float()
+        if act == 3:
+            return ((u > 0) & (u < 6)).float()
+        if act == 4:
+            return torch.where(u <= -3, torch.zeros_like(u), torch.where(u >= 3, torch.ones_like(u), (2 * u + 3) / 6))
+        if act == 5:
+            t = torch.tanh(F.softplus(u))
+            return t + u * torch.sigmoid(u) * (1 - t * t)
+        return torch.ones_like(u)
+
+    def _bn_rows(self, d, p, ld):
+        return torch.from_numpy(pitched(p, d.pixels, d.c, ld, _NP[d.dtype]).astype(np.float32))
+
+    def yh_bn_stats(self, dref, stream):
+        d = dref._obj if hasattr(dref, '_obj') else dref
+        z = self._bn_rows(d, d.z, d.ldz)
+        flat(d.sum, d.c, np.float32)[:] += z.sum(0).numpy()
+        flat(d.sumsq, d.c, np.float32)[:] += (z * z).sum(0).numpy()
+        return 0
+
+    def yh_bn_finalize(self, dref, stream):
+        d = dref._obj if hasattr(dref, '_obj') else dref
+        P = float(d.pixels)
+        mean = flat(d.sum, d.c, np.float32) / np.float32(P)
+        var = np.maximum(flat(d.sumsq, d.c, np.float32) / np.float32(P) - mean * mean, 0).astype(np.float32)
+        flat(d.mean, d.c, np.float32)[:] = mean
+        flat(d.invstd, d.c, np.float32)[:] = 1.0 / np.sqrt(var + np.float32(d.eps))
+        if _addr(d.running_mean):
+            rm = flat(d.running_mean, d.c, np.float32)
+            rm[:] = (1 - d.momentum) * rm + d.momentum * mean
+        if _addr(d.running_var):
+            rv = flat(d.running_var, d.c, np.float32)
+            rv[:] = (1 - d.momentum) * rv + d.momentum * var * (P / (P - 1) if P > 1 else 1.0)
+        return 0
+
+    def _bn_u(self, d, z):
+        """pre-activation u and xhat from the stored conv output z ([pixels, c] fp32)."""
+        if _addr(d.gamma):
+            g = torch.from_numpy(flat(d.gamma, d.c, np.float32).copy())
+            b = torch.from_numpy(flat(d.beta, d.c, np.float32).copy())
+            mu = torch.from_numpy(flat(d.mean, d.c, np.float32).copy())
+            istd = torch.from_numpy(flat(d.invstd, d.c, np.float32).copy())
+            xh = (z - mu) * istd
+            return g * xh + b, xh, g, istd
+        b = torch.from_numpy(flat(d.beta, d.c, np.float32).copy()) if _addr(d.beta) else torch.zeros(d.c)
+        return z + b, z, None, None
+
+    def yh_bn_act_fwd(self, dref, stream):
+        d = dref._obj if hasattr(dref, '_obj') else dref
+        npdt = _NP[d.dtype]
+        u, _, _, _ = self._bn_u(d, self._bn_rows(d, d.z, d.ldz))
+        y = _act(u, d.act, d.slope)
+        if _addr(d.res):
+            y = y + self._bn_rows(d, d.res, d.ldr)
+        if d.ups == 2:
+            assert d.n * d.h * d.w_in == d.pixels
+            y = y.view(d.n, d.h, d.w_in, d.c).repeat_interleave(2, 1).repeat_interleave(2, 2).reshape(-1, d.c)
+        pitched(d.out, y.shape[0], d.c, d.ldo, npdt)[:] = y.numpy().astype(npdt)
+        return 0
+
+    def yh_bn_act_bwd_reduce(self, dref, stream):
+        d = dref._obj if hasattr(dref, '_obj') else dref
+        u, xh, _, _ = self._bn_u(d, self._bn_rows(d, d.z, d.ldz))
+        g = self._bn_rows(d, d.dy, d.lddy) * self._act_grad(u, d.act, d.slope)
+        flat(d.sum, d.c, np.float32)[:] += g.sum(0).numpy()
+        flat(d.sumsq, d.c, np.float32)[:] += (g * xh).sum(0).numpy()
+        return 0
+
+    def yh_bn_act_bwd_apply(self, dref, stream):
+        d = dref._obj if hasattr(dref, '_obj') else dref
+        npdt = _NP[d.dtype]
+        u, xh, gamma, istd = self._bn_u(d, self._bn_rows(d, d.z, d.ldz))
+        g = self._bn_rows(d, d.dy, d.lddy) * self._act_grad(u, d.act, d.slope)
+        if gamma is not None:
+            s1 = torch.from_numpy(flat(d.sum, d.c, np.float32).copy())
+            s2 = torch.from_numpy(flat(d.sumsq, d.c, np.float32).copy())
+            g = gamma * istd * (g - s1 / d.pixels - xh * s2 / d.pixels)
+        pitched(d.out, d.pixels, d.c, d.ldo, npdt)[:] = g.numpy().astype(npdt)
+        return 0
+
+    def yh_conv_pack_weights_dgrad(self, dtype, w, cout, cin, kh, kw, cout_k, m_pad, packed, stream):
+        npdt = _NP[dtype]
+        wt = torch.from_numpy(flat(w, cout * cin * kh * kw, np.float32).copy()).view(cout, cin, kh, kw)
+        img = torch.zeros(m_pad, kh, kw, cout_k)
+        img[:cin, :, :, :cout] = wt.flip(2, 3).permute(1, 2, 3, 0)
+        flat(packed, img.numel(), npdt)[:] = img.reshape(-1).numpy().astype(npdt)
+        return 0
+
+    def yh_conv2d_wgrad(self, dref, stream):
+        d = dref._obj if hasattr(dref, '_obj') else dref
+        npdt = _NP[d.dtype]
+        vec = 8 if d.dtype == hiplib.YH_F16 else 4
+        assert d.ldx % vec == 0 and d.lddz % vec == 0 and _addr(d.x) % 16 == 0 and _addr(d.dz) % 16 == 0
+        x = torch.from_numpy(pitched(d.x, d.n * d.h * d.w_in, d.cin, d.ldx, npdt).astype(np.float32))
+        x = x.view(d.n, d.h, d.w_in, d.cin).permute(0, 3, 1, 2)
+        dz = torch.from_numpy(pitched(d.dz, d.n * d.ho * d.wo, d.cout, d.lddz, npdt).astype(np.float32))
+        dz = dz.view(d.n, d.ho, d.wo, d.cout).permute(0, 3, 1, 2)
+        gw = torch.nn.grad.conv2d_weight(x, (d.cout, d.cin, d.kh, d.kw), dz, stride=d.stride, padding=d.pad)
+        flat(d.dw, gw.numel(), np.float32)[:] += gw.reshape(-1).numpy()
+        return 0
+
+    def yh_stem_wgrad(self, dref, stream):
+        d = dref._obj if hasattr(dref, '_obj') else dref
+        npdt = _NP[d.dtype]
+        assert d.cin == 3 and d.kh == 3 and d.kw == 3
+        x = torch.from_numpy(flat(d.x, d.n * d.cin * d.h * d.w_in, np.float32).copy()).view(d.n, d.cin, d.h, d.w_in)
+        dz = torch.from_numpy(pitched(d.dz, d.n * d.ho * d.wo, d.cout, d.lddz, npdt).astype(np.float32))
+        dz = dz.view(d.n, d.ho, d.wo, d.cout).permute(0, 3, 1, 2)
+        gw = torch.nn.grad.conv2d_weight(x, (d.cout, d.cin, d.kh, d.kw), dz, stride=d.stride, padding=d.pad)
+        flat(d.dw, gw.numel(), np.float32)[:] += gw.reshape(-1).numpy()
+        return 0
+
+    def yh_dilate2(self, dref, stream):
+        d = dref._obj if hasattr(dref, '_obj') else dref
+        npdt = _NP[d.dtype]
+        src = pitched(d.x, d.n * d.h * d.w_in, d.c, d.ldx, npdt).reshape(d.n, d.h, d.w_in, d.c)
+        assert 2 * d.h - 1 <= d.big_h <= 2 * d.h and 2 * d.w_in - 1 <= d.big_w <= 2 * d.w_in
+        dst = pitched(d.y, d.n * d.big_h * d.big_w, d.c, d.ldy, npdt)
+        idx = (np.arange(d.n)[:, None, None] * d.big_h + 2 * np.arange(d.h)[None, :, None]) * d.big_w \
+            + 2 * np.arange(d.w_in)[None, None, :]
+        dst[idx.reshape(-1)] = src.reshape(-1, d.c)
+        return 0
+
+    def yh_upsample2_bwd(self, dref, stream):
+        d = dref._obj if hasattr(dref, '_obj') else dref
+        npdt = _NP[d.dtype]
+        assert d.big_h == 2 * d.h and d.big_w == 2 * d.w_in
+        big = torch.from_numpy(pitched(d.x, d.n * 4 * d.h * d.w_in, d.c, d.ldx, npdt).astype(np.float32))
+        big = big.view(d.n, d.h, 2, d.w_in, 2, d.c)
+        small = (big[:, :, 0, :, 0] + big[:, :, 0, :, 1]) + (big[:, :, 1, :, 0] + big[:, :, 1, :, 1])
+        pitched(d.y, d.n * d.h * d.w_in, d.c, d.ldy, npdt)[:] = small.reshape(-1, d.c).numpy().astype(npdt)
+        return 0
+
+    def yh_cast_f32(self, dref, stream):
+        d = dref._obj if hasattr(dref, '_obj') else dref
+        npdt = _NP[d.dtype]
+        pitched(d.y, d.pixels, d.c, d.ldy, npdt)[:] = pitched(d.x, d.pixels, d.c, d.ldx, np.float32).astype(npdt)
+        return 0
+
     # ---- plans
     def yh_plan_create(self):
         h = self.next
@@ -363,7 +513,12 @@ class FakeLib:
                hiplib.OP_POOL: self.yh_maxpool2d_fwd, hiplib.OP_COPY: self.yh_copy_channels,
                hiplib.OP_ADD: self.yh_add_channels, hiplib.OP_DECODE: self.yh_yolo_decode,
                hiplib.OP_DW: self.yh_dwconv2d_fwd, hiplib.OP_SE: self.yh_se_fwd, hiplib.OP_QCOPY: self.yh_qcopy,
-               hiplib.OP_QPOOL: self.yh_qpool, hiplib.OP_QADD: self.yh_qadd}
+               hiplib.OP_QPOOL: self.yh_qpool, hiplib.OP_QADD: self.yh_qadd,
+               hiplib.OP_BN_STATS: self.yh_bn_stats, hiplib.OP_BN_FINALIZE: self.yh_bn_finalize,
+               hiplib.OP_BN_ACT_FWD: self.yh_bn_act_fwd, hiplib.OP_BN_BWD_REDUCE: self.yh_bn_act_bwd_reduce,
+               hiplib.OP_BN_BWD_APPLY: self.yh_bn_act_bwd_apply, hiplib.OP_WGRAD: self.yh_conv2d_wgrad,
+               hiplib.OP_STEM_WGRAD: self.yh_stem_wgrad, hiplib.OP_DILATE2: self.yh_dilate2,
+               hiplib.OP_UPSAMPLE2_BWD: self.yh_upsample2_bwd, hiplib.OP_CAST_F32: self.yh_cast_f32}
         for kind, desc, fixups in plan['ops'][first:last]:
             d = type(desc).from_buffer_copy(bytes(desc))
             for off, slot, boff in fixups:

@@ -131,10 +131,41 @@ def decode_fixture(ref):
     print('decode fixture ok', tuple(io.shape))
 
 
+HYP = {'giou': 3.54, 'cls': 37.4, 'cls_pw': 1.0, 'obj': 64.3, 'obj_pw': 1.0, 'iou_t': 0.20, 'fl_gamma': 0.0}  # train.py:25-35
+
+
+def loss_fixture(ref):
+    """compute_loss / build_targets of the reference on seeded raw heads and labels (tiny-hand cfg heads, nc = 1, and
+    an 80-class yolov3 head set), incl. the gradient w.r.t. every raw head and the focal-loss variant."""
+    out = {}
+    for tag, rel, size, nc, gamma in (('hand', 'yolov3tiny/yolov3-tiny-hand.cfg', 416, 1, 0.0),
+                                      ('coco', 'yolov3/yolov3.cfg', 320, 80, 0.0), ('focal', 'yolov3/yolov3.cfg', 320, 80, 1.5)):
+        torch.manual_seed(0)
+        model = ref.models.Darknet(os.path.join(REFCFG, rel), (size, size))
+        model.nc, model.hyp, model.gr = nc, dict(HYP, fl_gamma=gamma), 0.7
+        raws, targets = synth.loss_inputs(model, size, batch=3, seed=21)
+        for r in raws:
+            r.requires_grad_()
+        loss, items = ref.utils.compute_loss(raws, targets, model)
+        loss.backward()
+        tcls, tbox, indices, av = ref.utils.build_targets(raws, targets, model)
+        out[tag + '_items'] = items.numpy()
+        for i, r in enumerate(raws):
+            out['%s_grad%d_checks' % (tag, i)] = checks(r.grad)
+            out['%s_grad%d_rows' % (tag, i)] = r.grad.reshape(-1)[::97].numpy()
+            out['%s_idx%d' % (tag, i)] = torch.stack(indices[i]).numpy()
+            out['%s_tbox%d' % (tag, i)] = tbox[i].numpy()
+            out['%s_tcls%d' % (tag, i)] = tcls[i].numpy()
+    np.savez_compressed(os.path.join(HERE, 'loss.npz'), **out)
+    print('loss fixture ok', {k: v for k, v in out.items() if k.endswith('items')})
+
+
 def main():
     ref = refharness.load()
     torch.set_num_threads(8)
     only = sys.argv[1:]
+    if only == ['loss']:
+        return loss_fixture(ref)
     for case in NET_CASES:
         if only and case[0] not in only:
             continue
@@ -142,6 +173,7 @@ def main():
     if only:
         return
     nms_fixtures(ref)
+    loss_fixture(ref)
     fuse_fixture(ref)
     decode_fixture(ref)
 

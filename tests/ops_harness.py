@@ -221,3 +221,72 @@ def qadd(lib, x, a, rx, ra, scale_x, scale_a, scale_sum):
     rc = lib.yh_qadd(C.byref(d), stream())
     assert rc == 0, rc
     return y
+
+
+# ------------------------------------------------------------------------------------------ training path
+from engine.hiplib import BnDesc, WgradDesc, ResampleDesc, CastDesc  # noqa: E402
+
+
+def bn_desc(code, z, c, ldz_off=0, dy=None, res=None, out=None, gamma=None, beta=None, mean=None, invstd=None, s1=None,
+            s2=None, rmean=None, rvar=None, act=1, slope=0.1, ups=1, eps=1e-5, momentum=0.1, out_off=0):
+    """z, dy, res, out: (N,H,W,ld) NHWC buffers (channels [off, off+c) are used)."""
+    N, H, W, ldz = z.shape
+    return BnDesc(z=P(z, ldz_off), dy=P(dy), res=P(res), out=P(out, out_off) if out is not None else None, gamma=P(gamma),
+                  beta=P(beta), mean=P(mean), invstd=P(invstd), sum=P(s1), sumsq=P(s2), running_mean=P(rmean),
+                  running_var=P(rvar), pixels=N * H * W, n=N, h=H, w_in=W, c=c, ldz=ldz,
+                  lddy=0 if dy is None else dy.shape[3], ldr=0 if res is None else res.shape[3],
+                  ldo=0 if out is None else out.shape[3], act=act, ups=ups, dtype=code, slope=slope, eps=eps,
+                  momentum=momentum)
+
+
+def call(lib, name, desc):
+    rc = getattr(lib, name)(C.byref(desc), stream())
+    assert rc == 0, '%s rc=%d' % (name, rc)
+
+
+def wgrad(lib, code, x, dz, cin, cout, k, stride, pad, x_off=0, dz_off=0, splits=0):
+    """x (N,H,W,ldx), dz (N,Ho,Wo,lddz) -> dw (cout,cin,k,k) fp32 accumulated from zero."""
+    N, H, W, ldx = x.shape
+    _, Ho, Wo, lddz = dz.shape
+    dw = torch.zeros((cout, cin, k, k), device=x.device, dtype=torch.float32)
+    d = WgradDesc(x=P(x, x_off), dz=P(dz, dz_off), dw=P(dw), n=N, h=H, w_in=W, cin=cin, ho=Ho, wo=Wo, cout=cout, kh=k, kw=k,
+                  stride=stride, pad=pad, ldx=ldx, lddz=lddz, dtype=code, splits=splits)
+    call(lib, 'yh_conv2d_wgrad', d)
+    return dw
+
+
+def stem_wgrad(lib, code, x, dz, cout, stride=1, pad=1):
+    N, cin, H, W = x.shape
+    _, Ho, Wo, lddz = dz.shape
+    dw = torch.zeros((cout, cin, 3, 3), device=x.device, dtype=torch.float32)
+    d = WgradDesc(x=P(x), dz=P(dz), dw=P(dw), n=N, h=H, w_in=W, cin=cin, ho=Ho, wo=Wo, cout=cout, kh=3, kw=3, stride=stride,
+                  pad=pad, ldx=0, lddz=lddz, dtype=code, splits=0)
+    call(lib, 'yh_stem_wgrad', d)
+    return dw
+
+
+def dgrad(lib, code, dz, w, in_hw, stride, pad, acc=None):
+    """Data gradient through yh_conv2d_fwd on the dgrad weight image (yh_dilate2 first for stride 2).
+    dz (N,Ho,Wo,cout_phys), w (cout,cin,k,k) fp32 -> dx (N,H,W,cin_phys); ``acc`` (same shape) is accumulated into."""
+    cout, cin, k, _ = w.shape
+    N, Ho, Wo, cphys = dz.shape
+    H, W = in_hw
+    kstep = 32 if code == hiplib.YH_F16 else 16
+    cin_phys = round_up(cin, 8)
+    cout_k, dm_pad = round_up(cphys, kstep), round_up(cin_phys, 128)
+    wt = torch.empty(dm_pad * k * k * cout_k, device=dz.device, dtype=tdtype(code))
+    rc = lib.yh_conv_pack_weights_dgrad(code, P(w), cout, cin, k, k, cout_k, dm_pad, P(wt), stream())
+    assert rc == 0, rc
+    src, sh, sw = dz, Ho, Wo
+    if stride == 2:
+        src = torch.zeros((N, H, W, cphys), device=dz.device, dtype=dz.dtype)
+        call(lib, 'yh_dilate2', ResampleDesc(x=P(dz), y=P(src), n=N, h=Ho, w_in=Wo, c=cphys, big_h=H, big_w=W, ldx=cphys,
+                                            ldy=cphys, dtype=code))
+        sh, sw = H, W
+    dx = acc if acc is not None else torch.full((N, H, W, cin_phys), 3.0, device=dz.device, dtype=dz.dtype)
+    zero_bias = torch.zeros(dm_pad, device=dz.device, dtype=torch.float32)
+    d = ConvDesc(x=P(src), w=P(wt), bias=P(zero_bias), res=P(acc), y=P(dx), n=N, h=sh, w_in=sw, cin=cphys, ho=H, wo=W,
+                 cout=cin_phys, kh=k, kw=k, stride=1, pad=k - 1 - pad, ldx=cphys, ldr=0 if acc is None else cin_phys,
+                 ldy=cin_phys, cin_k=cout_k, m_pad=dm_pad, act=0, slope=0.0, ups=1, out_f32=0, dtype=code, tile=0)
+    call(lib, 'yh_conv2d_fwd', d)
+    return dx

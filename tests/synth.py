@@ -74,3 +74,23 @@ def nms_candidates(n_img, rows, nc, seed, n_clusters=12, img=608, hot=0.35):
             out[b, 2, 4] = 0.99
             out[b, 2, 0] = float('inf')
     return out
+
+
+def loss_inputs(model, size, batch=3, seed=21, labels_per_image=6):
+    """Seeded raw head tensors (bs, na, ny, nx, no) for ``model``'s yolo layers at ``size`` and a (nt, 6) label tensor
+    (image, class, x, y, w, h normalised).  Works on the reference's and this package's Darknet alike."""
+    g = torch.Generator().manual_seed(seed)
+    raws = []
+    for j in model.yolo_layers:
+        m = model.module_list[j]
+        stride = int(m.stride)
+        ny = nx = size // stride
+        raws.append(torch.randn(batch, m.na, ny, nx, m.no, generator=g) * 0.8)
+    rows = []
+    for b in range(batch):
+        for _ in range(labels_per_image):
+            cls = int(torch.randint(0, model.nc, (1,), generator=g))
+            wh = torch.rand(2, generator=g) * 0.5 + 0.03
+            xy = torch.rand(2, generator=g) * (1 - wh) + wh / 2
+            rows.append([b, cls, xy[0].item(), xy[1].item(), wh[0].item(), wh[1].item()])
+    return raws, torch.tensor(rows, dtype=torch.float32)

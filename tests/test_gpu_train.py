@@ -1,0 +1,312 @@
+"""GPU tier, training path: the backward / train-mode kernels against the host emulation AND against
+torch autograd, then whole training steps through ``models.Darknet`` on the GPU against eager fp32 autograd on CPU.
+
+Tolerances: fp32 mode (exact-product MFMA 16x16x4, fp32 statistics) agrees with fp32 autograd to round-off (1e-5
+relative); fp16 storage is one rounding per stored tensor with fp32 accumulation, bounded per kernel below.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import conftest
+import fakelib
+import ops_harness as oh
+import synth
+import train_harness as th
+from engine import hiplib
+from engine.hiplib import ResampleDesc, CastDesc
+
+pytestmark = pytest.mark.gpu
+
+F16, F32 = hiplib.YH_F16, hiplib.YH_F32
+DRY = bool(os.environ.get('YOLO_TEST_DRY_GPU'))
+GPU = 'cpu' if DRY else 'cuda'
+P = hiplib.ptr
+
+
+@pytest.fixture(scope='module')
+def libs():
+    if DRY:
+        return fakelib.FakeLib(), fakelib.FakeLib()
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU')
+    return hiplib.load(), fakelib.FakeLib()
+
+
+def _sync():
+    if GPU == 'cuda':
+        torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize('code', [F32, F16], ids=['fp32', 'fp16'])
+@pytest.mark.parametrize('case', [(3, 17, 19, 64, 1, 1, False, True), (2, 8, 8, 256, 5, 2, False, True),
+                                  (2, 12, 12, 32, 1, 1, True, True), (2, 9, 9, 24, 4, 1, False, False)],
+                         ids=['leaky', 'mish_ups', 'leaky_res', 'hswish_nobn'])
+def test_bn_train_kernels(libs, code, case):
+    """stats -> finalize -> act forward -> backward reduce -> backward apply, vs emulation and vs torch autograd."""
+    lib, fake = libs
+    N, H, W, c, act, ups, use_res, use_bn = case
+    g = torch.Generator().manual_seed(c * 7 + act)
+    dt = oh.tdtype(code)
+    z0 = (torch.randn(N, H, W, c + 8, generator=g) * 1.5 + 0.3).to(dt)       # channels [8, 8+c) of a wider buffer
+    res0 = torch.randn(N, H, W, c, generator=g).to(dt) if use_res else None
+    dy0 = torch.randn(N, H * ups, W * ups, c + 16, generator=g).to(dt)
+    gamma0, beta0 = torch.rand(c, generator=g) + 0.5, torch.randn(c, generator=g) * 0.2
+    outs = []
+    for L, dev in ((lib, GPU), (fake, 'cpu')):
+        mv = lambda t: None if t is None else t.to(dev).clone()
+        z, res, gamma, beta = mv(z0), mv(res0), mv(gamma0) if use_bn else None, mv(beta0)
+        f32 = lambda n=c: torch.zeros(n, device=dev, dtype=torch.float32)
+        mean, invstd, s1, s2, rm, rv = f32(), f32(), f32(), f32(), f32(), f32() + 1
+        y = torch.full((N, H * ups, W * ups, c + 16), 3.0, device=dev, dtype=dt)
+        kw = dict(gamma=gamma, beta=beta, mean=mean, invstd=invstd, act=act)
+        if use_bn:
+            oh.call(L, 'yh_bn_stats', oh.bn_desc(code, z, c, 8, s1=s1, s2=s2, **kw))
+            oh.call(L, 'yh_bn_finalize', oh.bn_desc(code, z, c, 8, s1=s1, s2=s2, rmean=rm, rvar=rv, **kw))
+        oh.call(L, 'yh_bn_act_fwd', oh.bn_desc(code, z, c, 8, res=res, out=y, out_off=16, ups=ups, **kw))
+        # backward at the un-upsampled resolution (the engine reduces the fused upsample first)
+        dy = mv(dy0)[:, ::ups, ::ups].contiguous()
+        dbeta, dgamma = f32(), f32()
+        dz = torch.full((N, H, W, c), 3.0, device=dev, dtype=dt)
+        dyv = dy[..., 16:].contiguous()
+        oh.call(L, 'yh_bn_act_bwd_reduce', oh.bn_desc(code, z, c, 8, dy=dyv, s1=dbeta, s2=dgamma, **kw))
+        oh.call(L, 'yh_bn_act_bwd_apply', oh.bn_desc(code, z, c, 8, dy=dyv, out=dz, s1=dbeta, s2=dgamma, **kw))
+        _sync()
+        outs.append([t.float().cpu() for t in (mean, invstd, rm, rv, y, dbeta, dgamma, dz)])
+    tol = 1e-5 if code == F32 else 2e-3
+    names = ['mean', 'invstd', 'running_mean', 'running_var', 'y', 'dbeta', 'dgamma', 'dz']
+    for name, a, b in zip(names, *outs):
+        assert (a - b).abs().max().item() <= tol * (b.abs().max().item() + 1e-3), name
+    assert torch.equal(outs[0][4][..., :16], torch.full_like(outs[0][4][..., :16], 3.0)), 'wrote outside the slice'
+    # independent check against torch autograd on the same (rounded) inputs
+    zz = z0[..., 8:8 + c].float().permute(0, 3, 1, 2).requires_grad_()
+    ga, be = gamma0.clone().requires_grad_(), beta0.clone().requires_grad_()
+    if use_bn:
+        u = F.batch_norm(zz, None, None, ga, be, True, 0.1, 1e-5)
+    else:
+        u = zz + be.view(1, -1, 1, 1)
+    yy = fakelib._act(u, act, 0.1)
+    dyr = dy0[:, ::ups, ::ups, 16:].float().permute(0, 3, 1, 2)
+    yy.backward(dyr)
+    dz_ref = zz.grad.permute(0, 2, 3, 1)
+    rt = 2e-4 if code == F32 else 4e-3
+    assert (outs[0][7] - dz_ref).abs().max().item() <= rt * dz_ref.abs().max().item()
+    assert (outs[0][5] - be.grad).abs().max().item() <= rt * be.grad.abs().max().item()
+    if use_bn:
+        assert (outs[0][6] - ga.grad).abs().max().item() <= rt * ga.grad.abs().max().item()
+
+
+WGRAD_CASES = [
+    # N, H, W, cin, cout, k, s, x_extra, dz_extra
+    (2, 16, 16, 64, 128, 1, 1, 0, 0),
+    (2, 20, 20, 32, 64, 3, 1, 0, 0),
+    (1, 33, 31, 64, 128, 3, 2, 0, 0),
+    (3, 19, 19, 128, 255, 1, 1, 0, 0),      # head: cout 255 in a 256-channel dz
+    (1, 10, 10, 512, 1024, 3, 1, 0, 0),     # many tiles
+    (2, 12, 12, 96, 72, 3, 1, 32, 16),      # pitched slices, partial tiles both ways
+    (4, 64, 64, 16, 32, 3, 1, 0, 0),        # long pixel axis -> many splits
+    (2, 26, 26, 256, 512, 3, 2, 0, 0),
+]
+
+
+@pytest.mark.parametrize('code', [F32, F16], ids=['fp32', 'fp16'])
+@pytest.mark.parametrize('case', WGRAD_CASES, ids=lambda c: 'n%d_%dx%d_c%d-%d_k%ds%d_x%d_z%d' % c)
+def test_wgrad_matches_autograd(libs, code, case):
+    lib, fake = libs
+    N, H, W, cin, cout, k, s, xe, ze = case
+    g = torch.Generator().manual_seed(hash(case) % (2 ** 31))
+    dt = oh.tdtype(code)
+    pad = (k - 1) // 2
+    Ho, Wo = (H + 2 * pad - k) // s + 1, (W + 2 * pad - k) // s + 1
+    cout_phys = oh.round_up(cout, 8)
+    x = torch.randn(N, H, W, cin + xe, generator=g).to(dt)
+    dz = torch.randn(N, Ho, Wo, cout_phys + ze, generator=g).to(dt)
+    dz[..., ze + cout:] = 0
+    got = oh.wgrad(lib, code, x.to(GPU), dz.to(GPU), cin, cout, k, s, pad, x_off=xe, dz_off=ze)
+    _sync()
+    emu = oh.wgrad(fake, code, x.clone(), dz.clone(), cin, cout, k, s, pad, x_off=xe, dz_off=ze)
+    xr = x[..., xe:].float().permute(0, 3, 1, 2)
+    dzr = dz[..., ze:ze + cout].float().permute(0, 3, 1, 2)
+    ref = torch.nn.grad.conv2d_weight(xr, (cout, cin, k, k), dzr, stride=s, padding=pad)
+    scale = ref.abs().max().item()
+    assert (emu - ref).abs().max().item() <= 1e-4 * scale
+    # operands are identical on both sides; only the fp32 accumulation order differs
+    assert (got.cpu() - ref).abs().max().item() <= (2e-5 if code == F32 else 1e-4) * scale
+
+
+def test_wgrad_f16_exact_on_small_integers(libs):
+    """Integer operands: every product and partial sum is exact, so MFMA + atomics must reproduce autograd bit for bit."""
+    lib, _ = libs
+    g = torch.Generator().manual_seed(3)
+    x = torch.randint(-3, 4, (2, 14, 14, 64), generator=g).half()
+    dz = torch.randint(-2, 3, (2, 14, 14, 128), generator=g).half()
+    got = oh.wgrad(lib, F16, x.to(GPU), dz.to(GPU), 64, 128, 3, 1, 1)
+    _sync()
+    ref = torch.nn.grad.conv2d_weight(x.float().permute(0, 3, 1, 2), (128, 64, 3, 3), dz.float().permute(0, 3, 1, 2), padding=1)
+    assert torch.equal(got.cpu(), ref)
+
+
+@pytest.mark.parametrize('code', [F32, F16], ids=['fp32', 'fp16'])
+@pytest.mark.parametrize('shape', [(2, 32, 32, 32, 1), (3, 21, 19, 16, 1), (1, 40, 40, 32, 2)], ids=str)
+def test_stem_wgrad_matches_autograd(libs, code, shape):
+    lib, _ = libs
+    N, H, W, cout, s = shape
+    g = torch.Generator().manual_seed(H)
+    dt = oh.tdtype(code)
+    Ho, Wo = (H + 2 - 3) // s + 1, (W + 2 - 3) // s + 1
+    x = torch.rand(N, 3, H, W, generator=g)
+    dz = torch.randn(N, Ho, Wo, cout, generator=g).to(dt)
+    got = oh.stem_wgrad(lib, code, x.to(GPU), dz.to(GPU), cout, stride=s)
+    _sync()
+    ref = torch.nn.grad.conv2d_weight(x, (cout, 3, 3, 3), dz.float().permute(0, 3, 1, 2), stride=s, padding=1)
+    assert (got.cpu() - ref).abs().max().item() <= 2e-5 * ref.abs().max().item()
+
+
+DGRAD_CASES = [(2, 16, 16, 64, 128, 1, 1), (2, 20, 20, 32, 64, 3, 1), (2, 32, 32, 64, 128, 3, 2), (1, 25, 27, 32, 64, 3, 2),
+               (2, 13, 13, 128, 255, 1, 1), (1, 10, 10, 256, 512, 3, 1)]
+
+
+@pytest.mark.parametrize('code', [F32, F16], ids=['fp32', 'fp16'])
+@pytest.mark.parametrize('accumulate', [False, True], ids=['write', 'acc'])
+@pytest.mark.parametrize('case', DGRAD_CASES, ids=lambda c: 'n%d_%dx%d_c%d-%d_k%ds%d' % c)
+def test_dgrad_matches_autograd(libs, code, accumulate, case):
+    """conv(dz [dilated], transposed+flipped weights) == autograd's input gradient, incl. odd sizes under stride 2."""
+    lib, _ = libs
+    N, H, W, cin, cout, k, s = case
+    g = torch.Generator().manual_seed(hash(case) % (2 ** 31))
+    dt = oh.tdtype(code)
+    pad = (k - 1) // 2
+    Ho, Wo = (H + 2 * pad - k) // s + 1, (W + 2 * pad - k) // s + 1
+    cphys = oh.round_up(cout, 8)
+    w = torch.randn(cout, cin, k, k, generator=g) * (cout * k * k) ** -0.5
+    dz = torch.randn(N, Ho, Wo, cphys, generator=g).to(dt)
+    dz[..., cout:] = 0
+    acc0 = torch.randn(N, H, W, cin, generator=g).to(dt) if accumulate else None
+    acc = None if acc0 is None else acc0.to(GPU).clone()
+    dx = oh.dgrad(lib, code, dz.to(GPU), w.to(GPU), (H, W), s, pad, acc=acc)
+    _sync()
+    wq = w.to(dt).float()
+    ref = torch.nn.grad.conv2d_input((N, cin, H, W), wq, dz[..., :cout].float().permute(0, 3, 1, 2), stride=s, padding=pad)
+    ref = ref.permute(0, 2, 3, 1)
+    if accumulate:
+        ref = ref + acc0.float()
+    tol = 2e-5 if code == F32 else 2.5e-3
+    assert (dx.float().cpu() - ref).abs().max().item() <= tol * ref.abs().max().item()
+
+
+@pytest.mark.parametrize('code', [F32, F16], ids=['fp32', 'fp16'])
+def test_resample_and_cast_kernels(libs, code):
+    lib, fake = libs
+    g = torch.Generator().manual_seed(9)
+    dt = oh.tdtype(code)
+    N, H, W, c = 2, 7, 9, 24
+    big = torch.randn(N, 2 * H, 2 * W, c + 8, generator=g).to(dt)
+    src32 = torch.randn(N, H, W, c + 4, generator=g)
+    outs = []
+    for L, dev in ((lib, GPU), (fake, 'cpu')):
+        b = big.to(dev)
+        small = torch.full((N, H, W, c), 3.0, device=dev, dtype=dt)
+        oh.call(L, 'yh_upsample2_bwd', ResampleDesc(x=P(b, 8), y=P(small), n=N, h=H, w_in=W, c=c, big_h=2 * H, big_w=2 * W,
+                                                    ldx=c + 8, ldy=c, dtype=code))
+        dil = torch.zeros((N, 2 * H - 1, 2 * W, c), device=dev, dtype=dt)      # odd height, even width
+        oh.call(L, 'yh_dilate2', ResampleDesc(x=P(small), y=P(dil), n=N, h=H, w_in=W, c=c, big_h=2 * H - 1, big_w=2 * W,
+                                              ldx=c, ldy=c, dtype=code))
+        s32 = src32.to(dev)
+        cast = torch.full((N, H, W, c), 3.0, device=dev, dtype=dt)
+        oh.call(L, 'yh_cast_f32', CastDesc(x=P(s32), y=P(cast), pixels=N * H * W, c=c, ldx=c + 4, ldy=c, dtype=code))
+        _sync()
+        outs.append([t.float().cpu() for t in (small, dil, cast)])
+    for a, b in zip(*outs):
+        assert (a - b).abs().max().item() <= (1e-6 if code == F32 else 2e-3) * b.abs().max().item()
+    small_ref = big[..., 8:].float().view(N, H, 2, W, 2, c).sum((2, 4))
+    assert (outs[0][0] - small_ref).abs().max().item() <= (1e-5 if code == F32 else 4e-3) * small_ref.abs().max().item()
+    assert torch.equal(outs[0][1][:, ::2, ::2], outs[0][0]) and outs[0][1][:, 1::2].abs().max() == 0 \
+        and outs[0][1][:, :, 1::2].abs().max() == 0
+    assert torch.equal(outs[0][2], src32[..., :c].to(dt).float())
+
+
+# ------------------------------------------------------------------------------------------ whole steps
+@pytest.fixture(scope='module')
+def mini():
+    path = th.write_cfg(th.mini_cfg_text())
+    yield path
+    os.unlink(path)
+
+
+def _engine_lib():
+    return fakelib.FakeLib() if DRY else None
+
+
+@pytest.mark.parametrize('size', [64, 52])
+def test_mini_train_step_fp32_matches_eager_autograd(libs, mini, size):
+    model = th.build(mini, size)
+    x = synth.image_batch(4, size, seed=0)
+    raws_ref, grads_ref, m_ref, ws = th.eager_step(model, x)
+    raws, grads, m = th.engine_step(model, x, ws, 'fp32', lib=_engine_lib(), device=GPU)
+    for a, b in zip(raws, raws_ref):
+        assert (a - b).abs().max().item() <= 2e-5 * b.abs().max().item()
+    for k in grads_ref:
+        assert th.rel_l2(grads[k], grads_ref[k]) < 5e-5, k
+    for (k, a), (_, b) in zip(m.state_dict().items(), m_ref.state_dict().items()):
+        if 'running' in k:
+            assert (a.cpu() - b).abs().max().item() <= 1e-5 * (b.abs().max().item() + 1), k
+
+
+def test_mini_train_step_fp16_close_to_emulated_fp16(libs, mini):
+    """fp16 kernels vs the fp16 emulation of the same plan (same rounding points): statistical, kinks flip."""
+    model = th.build(mini, 64)
+    x = synth.image_batch(4, 64, seed=0)
+    _, grads_ref, _, ws = th.eager_step(model, x)
+    raws_e, grads_e, _ = th.engine_step(model, x, ws, 'fp16', lib=fakelib.FakeLib())
+    raws, grads, _ = th.engine_step(model, x, ws, 'fp16', lib=_engine_lib(), device=GPU)
+    for a, b in zip(raws, raws_e):
+        assert (a - b).abs().max().item() <= 5e-3 * b.abs().max().item()
+    for k in grads_ref:
+        assert th.cosine(grads[k], grads_ref[k]) > 0.97, k
+        assert th.cosine(grads[k], grads_e[k]) > 0.97, k
+
+
+def test_mini_sgd_steps_track_eager(libs, mini):
+    """Five SGD steps on the GPU path vs five eager steps on CPU: parameters stay together (fp32)."""
+    model = th.build(mini, 64)
+    import copy
+    a = copy.deepcopy(model).train()
+    b = copy.deepcopy(model).to(GPU).train()
+    if DRY:
+        from engine.train import TrainEngine
+        b.__dict__['_hip_train_engine'] = TrainEngine(b, 'fp32', lib=fakelib.FakeLib())
+    oa = torch.optim.SGD(a.parameters(), lr=2e-6, momentum=0.9)
+    ob = torch.optim.SGD(b.parameters(), lr=2e-6, momentum=0.9)
+    ws = None
+    for step in range(5):
+        x = synth.image_batch(4, 64, seed=step)
+        ra = a._forward_eager(x)[0]
+        ws = ws or th.loss_weights(ra)
+        oa.zero_grad()
+        th.toy_loss(ra, ws).backward()
+        oa.step()
+        rb = (b._forward_hip_train(x.to(GPU)) if DRY else b(x.to(GPU)))[0]
+        ob.zero_grad()
+        th.toy_loss(rb, ws).backward()
+        ob.step()
+    for (k, pa), (_, pb) in zip(a.state_dict().items(), b.state_dict().items()):
+        if pa.dtype.is_floating_point:
+            assert (pa - pb.cpu()).abs().max().item() <= 1e-4 * (pa.abs().max().item() + 1e-3), k
+
+
+def test_yolov3_train_step_against_fp64(libs):
+    cfg = os.path.join(conftest.PKG, 'cfg', 'yolov3', 'yolov3.cfg')
+    model = th.build(cfg, 128)
+    x = synth.image_batch(4, 128, seed=0)
+    raws64, grads64, _, ws = th.eager_step(model, x, dtype=torch.float64)
+    _, grads32, _, _ = th.eager_step(model, x, ws=ws)
+    raws, grads, _ = th.engine_step(model, x, ws, 'fp32', lib=_engine_lib(), device=GPU)
+    for a, b in zip(raws, raws64):
+        assert (a - b).abs().max().item() <= 2e-4 * b.abs().max().item()
+    num = sum((grads[k] - grads64[k]).norm().item() ** 2 for k in grads64) ** 0.5
+    den = sum((grads32[k] - grads64[k]).norm().item() ** 2 for k in grads64) ** 0.5
+    tot = sum(grads64[k].norm().item() ** 2 for k in grads64) ** 0.5
+    assert num <= 4 * den + 1e-4 * tot, (num / tot, den / tot)

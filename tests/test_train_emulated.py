@@ -1,0 +1,112 @@
+"""CPU tier: the training-step lowering (engine/train.py) replayed on the host emulation of the C ABI.
+
+What this pins down without a GPU: the forward/backward op sequences, buffer placement (zero-copy concat slices for
+activations AND their gradients), write-vs-accumulate decisions for multi-consumer gradients, the dgrad weight image
+and the stride-2 dilation geometry, the gradient arena slicing, running-stat updates, and the autograd glue in
+``models.Darknet`` — all against eager fp32 autograd.  The kernels themselves are checked on the GPU tier.
+"""
+import os
+
+import pytest
+import torch
+
+import conftest
+import fakelib
+import synth
+import train_harness as th
+
+
+@pytest.fixture(scope='module')
+def mini():
+    path = th.write_cfg(th.mini_cfg_text())
+    yield path
+    os.unlink(path)
+
+
+@pytest.mark.parametrize('size', [64, 52], ids=['64', '52_odd_grid'])
+def test_mini_train_step_matches_eager_autograd(mini, size):
+    model = th.build(mini, size)
+    x = synth.image_batch(4, size, seed=0)
+    raws_ref, grads_ref, m_ref, ws = th.eager_step(model, x)
+    raws, grads, m = th.engine_step(model, x, ws, 'fp32', lib=fakelib.FakeLib())
+    for a, b in zip(raws, raws_ref):
+        assert a.shape == b.shape
+        assert (a - b).abs().max().item() <= 2e-5 * b.abs().max().item()
+    assert set(grads) == set(grads_ref)
+    for k in grads_ref:
+        assert th.rel_l2(grads[k], grads_ref[k]) < 2e-5, k
+    # BatchNorm running statistics and the step counter follow nn.BatchNorm2d (momentum 0.1, unbiased variance)
+    for (k, a), (_, b) in zip(m.state_dict().items(), m_ref.state_dict().items()):
+        if 'running' in k:
+            assert (a - b).abs().max().item() <= 1e-5 * (b.abs().max().item() + 1), k
+        if 'num_batches_tracked' in k:
+            assert int(a) == int(b) == 1, k
+
+
+def test_mini_fp16_storage_stays_close(mini):
+    """fp16 activations/gradients with fp32 accumulation: statistical agreement (leaky kinks flip under rounding)."""
+    model = th.build(mini, 64)
+    x = synth.image_batch(4, 64, seed=0)
+    raws_ref, grads_ref, _, ws = th.eager_step(model, x)
+    raws, grads, _ = th.engine_step(model, x, ws, 'fp16', lib=fakelib.FakeLib())
+    for a, b in zip(raws, raws_ref):
+        assert (a - b).abs().max().item() <= 5e-3 * b.abs().max().item()
+    for k in grads_ref:
+        assert th.cosine(grads[k], grads_ref[k]) > 0.97, k
+
+
+def test_gradient_accumulation_and_stale_backward(mini):
+    from engine.train import TrainEngine
+    model = th.build(mini, 64)
+    x = synth.image_batch(2, 64, seed=0)
+    model.__dict__['_hip_train_engine'] = TrainEngine(model, 'fp32', lib=fakelib.FakeLib())
+    ws = None
+    for _ in range(2):  # two forward/backward pairs accumulate into .grad like eager autograd
+        raws, _ = model._forward_hip_train(x)
+        ws = ws or th.loss_weights(raws)
+        th.toy_loss(raws, ws).backward()
+    g2 = {k: p.grad.clone() for k, p in model.named_parameters()}
+    for p in model.parameters():
+        p.grad = None
+    raws, _ = model._forward_hip_train(x)
+    th.toy_loss(raws, ws).backward()
+    # BN statistics moved between the passes only through running stats (not used in train mode): grads are 2x
+    for k, p in model.named_parameters():
+        assert th.rel_l2(g2[k], 2 * p.grad) < 1e-5, k
+    # a backward whose forward buffers were overwritten must fail loudly
+    raws_a, _ = model._forward_hip_train(x)
+    raws_b, _ = model._forward_hip_train(x)
+    with pytest.raises(RuntimeError, match='overwritten'):
+        th.toy_loss(raws_a, ws).backward()
+
+
+def test_unsupported_cfg_reports_not_implemented():
+    from engine.train import TrainEngine
+    from models import Darknet
+    cfg = os.path.join(conftest.PKG, 'cfg', 'yolov3tiny', 'yolov3-tiny.cfg')
+    model = Darknet(cfg, (64, 64)).train()
+    eng = TrainEngine(model, 'fp32', lib=fakelib.FakeLib())
+    with pytest.raises(NotImplementedError, match='pool'):
+        eng._get_plan(torch.zeros(1, 3, 64, 64))
+
+
+def test_yolov3_train_plan_against_fp64(mini):
+    """Full YOLOv3 graph at 64x64: random-weight fp32 gradients are ill-conditioned (eager fp32 vs fp64 differ by
+    ~1e-2), so the engine's error against an fp64 eager run is bounded by a multiple of eager fp32's own error."""
+    cfg = os.path.join(conftest.PKG, 'cfg', 'yolov3', 'yolov3.cfg')
+    model = th.build(cfg, 64)
+    x = synth.image_batch(4, 64, seed=0)
+    raws64, grads64, _, ws = th.eager_step(model, x, dtype=torch.float64)
+    raws32, grads32, _, _ = th.eager_step(model, x, ws=ws)
+    raws, grads, m = th.engine_step(model, x, ws, 'fp32', lib=fakelib.FakeLib())
+    assert len(grads) == 222
+    for a, b in zip(raws, raws64):
+        assert (a - b).abs().max().item() <= 1e-4 * b.abs().max().item()
+    num = sum((grads[k] - grads64[k]).norm().item() ** 2 for k in grads64) ** 0.5
+    den = sum((grads32[k] - grads64[k]).norm().item() ** 2 for k in grads64) ** 0.5
+    tot = sum(grads64[k].norm().item() ** 2 for k in grads64) ** 0.5
+    assert num <= 4 * den + 1e-4 * tot, (num / tot, den / tot)
+    plan = m.__dict__['_hip_train_engine']._current
+    assert plan['zero_list'] == []  # every gradient buffer's first writer covers it: no memsets in the step
+    kinds = [w.rstrip('0123456789') for w, _ in plan['bwd_ops']]
+    assert kinds.count('wgrad') == 75 and kinds.count('dgrad') == 74 and kinds.count('dilate') == 5

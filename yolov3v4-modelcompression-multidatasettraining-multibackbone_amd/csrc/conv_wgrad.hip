@@ -1,0 +1,378 @@
+// Weight gradient of the NHWC convolution on MFMA, plus the small backward helpers around it.
+//
+//   dw[co][ci][r][s] = sum over output pixels p of dz[p][co] * x[pixel p shifted by tap (r,s)][ci]
+//
+// is a GEMM whose contraction index is the PIXEL, while both operands are stored pixel-major (NHWC).  MFMA wants,
+// per lane, 8 (fp16) consecutive K values of one row, so the kernel transposes on the way into LDS: every thread
+// loads two 16-byte channel vectors (pixels 2q, 2q+1) and stores them as [channel][pixel] pairs; fragment reads are
+// then plain 16-byte rows.  Row pitch 80 bytes makes the fragment reads bank-conflict free (20 dwords * i mod 64 hits
+// every 4-bank group once for i = 0..15).  One workgroup owns a 128 (co) x 128 (ci) tile of ONE tap and a contiguous
+// range of pixels; partial sums are added to dw with fp32 atomics (a few thousand per workgroup).
+#include "common.h"
+
+namespace yh {
+
+template <typename T> struct WG;
+template <> struct WG<f16> {
+    static constexpr int VEC = 8, BK = 32;
+    typedef f16x8 vec;
+};
+template <> struct WG<float> {
+    static constexpr int VEC = 4, BK = 16;
+    typedef f32x4 vec;
+};
+
+constexpr int WG_TILE = 128;     // co and ci tile
+constexpr int WG_PITCH_DW = 20;  // LDS row pitch in dwords (80 B)
+
+struct WgradArgs {
+    yh_wgrad_desc d;
+    int tiles_m, tiles_n, ksteps, ksteps_per_split;
+    long pixels;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
+    typedef typename WG<T>::vec V;
+    constexpr int VEC = WG<T>::VEC, BK = WG<T>::BK, PP = BK / 2;
+    const yh_wgrad_desc& d = a.d;
+    __shared__ uint32_t lds_a[WG_TILE * WG_PITCH_DW];
+    __shared__ uint32_t lds_b[WG_TILE * WG_PITCH_DW];
+
+    int bid = blockIdx.x;
+    const int tm = bid % a.tiles_m; bid /= a.tiles_m;
+    const int tn = bid % a.tiles_n; bid /= a.tiles_n;
+    const int tap = bid;
+    const int tr = tap / d.kw, ts = tap % d.kw;
+    const int co0 = tm * WG_TILE, ci0 = tn * WG_TILE;
+    const int ks0 = blockIdx.y * a.ksteps_per_split;
+    const int ks1 = min(ks0 + a.ksteps_per_split, a.ksteps);
+    if (ks0 >= ks1) return;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int cg = tid / PP, pp = tid % PP;       // loader role: channel group, pixel pair
+    const int ca = co0 + cg * VEC, cb = ci0 + cg * VEC;
+    const bool a_ok = ca < d.cout, b_ok = cb < d.cin;  // cout / cin here are the PHYSICAL channel counts of dz / x
+    const T* dz = reinterpret_cast<const T*>(d.dz);
+    const T* x = reinterpret_cast<const T*>(d.x);
+    const int hw_o = d.ho * d.wo;
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    V ra[2], rb[2];
+    auto fetch = [&](int ks) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const long p = (long)ks * BK + 2 * pp + u;
+            V va, vb;
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) { va[e] = (T)0; vb[e] = (T)0; }
+            if (p < a.pixels) {
+                if (a_ok) va = *reinterpret_cast<const V*>(dz + p * d.lddz + ca);
+                const int n = (int)(p / hw_o);
+                const int rem = (int)(p - (long)n * hw_o);
+                const int ho = rem / d.wo, wo = rem - ho * d.wo;
+                const int hi = ho * d.stride + tr - d.pad, wi = wo * d.stride + ts - d.pad;
+                if (b_ok && (unsigned)hi < (unsigned)d.h && (unsigned)wi < (unsigned)d.w_in)
+                    vb = *reinterpret_cast<const V*>(x + (((long)n * d.h + hi) * d.w_in + wi) * d.ldx + cb);
+            }
+            ra[u] = va;
+            rb[u] = vb;
+        }
+    };
+    auto stash = [&]() {
+        if constexpr (sizeof(T) == 2) {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                const f16x2 wa = {ra[0][e], ra[1][e]};
+                const f16x2 wb = {rb[0][e], rb[1][e]};
+                lds_a[(cg * VEC + e) * WG_PITCH_DW + pp] = __builtin_bit_cast(uint32_t, wa);
+                lds_b[(cg * VEC + e) * WG_PITCH_DW + pp] = __builtin_bit_cast(uint32_t, wb);
+            }
+        } else {
+            typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+            const u32x4_t a0 = __builtin_bit_cast(u32x4_t, ra[0]), a1 = __builtin_bit_cast(u32x4_t, ra[1]);
+            const u32x4_t b0 = __builtin_bit_cast(u32x4_t, rb[0]), b1 = __builtin_bit_cast(u32x4_t, rb[1]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                lds_a[(cg * 4 + e) * WG_PITCH_DW + 2 * pp] = a0[e];
+                lds_a[(cg * 4 + e) * WG_PITCH_DW + 2 * pp + 1] = a1[e];
+                lds_b[(cg * 4 + e) * WG_PITCH_DW + 2 * pp] = b0[e];
+                lds_b[(cg * 4 + e) * WG_PITCH_DW + 2 * pp + 1] = b1[e];
+            }
+        }
+    };
+
+    fetch(ks0);
+    for (int ks = ks0; ks < ks1; ++ks) {
+        __syncthreads();  // previous step's fragment reads are done
+        stash();
+        __syncthreads();
+        if (ks + 1 < ks1) fetch(ks + 1);  // global loads fly under the MFMAs
+        const int ri = lane & 15, kq = lane >> 4;
+        if constexpr (sizeof(T) == 2) {
+            f16x8 fa[4], fb[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                fa[i] = *reinterpret_cast<const f16x8*>(&lds_a[(wm * 64 + i * 16 + ri) * WG_PITCH_DW + kq * 4]);
+                fb[i] = *reinterpret_cast<const f16x8*>(&lds_b[(wn * 64 + i * 16 + ri) * WG_PITCH_DW + kq * 4]);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                float fa[4], fb[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    fa[i] = __builtin_bit_cast(float, lds_a[(wm * 64 + i * 16 + ri) * WG_PITCH_DW + kk * 4 + kq]);
+                    fb[i] = __builtin_bit_cast(float, lds_b[(wn * 64 + i * 16 + ri) * WG_PITCH_DW + kk * 4 + kq]);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
+            }
+        }
+    }
+
+    // D layout: column (lane & 15) = ci, row 4*(lane>>4)+reg = co
+    const int taps = d.kh * d.kw;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int ci = ci0 + wn * 64 + j * 16 + (lane & 15);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int co = co0 + wm * 64 + i * 16 + 4 * (lane >> 4) + r;
+                if (co < d.cout && ci < d.cin) atomicAdd(d.dw + ((long)co * d.cin + ci) * taps + tap, acc[i][j][r]);
+            }
+        }
+}
+
+// First layer: x is the fp32 NCHW image with 3 channels, 3x3 taps.  Thread = (co, pixel lane); 27 accumulators.
+template <typename T>
+__global__ __launch_bounds__(256) void stem_wgrad_kernel(const yh_wgrad_desc d, long pixels, int chunk) {
+    constexpr int CIN = 3, KK = 3;
+    const int co = threadIdx.x % d.cout;
+    const int lanes = 256 / d.cout;
+    const int pl = threadIdx.x / d.cout;
+    const T* dz = reinterpret_cast<const T*>(d.dz);
+    const float* x = reinterpret_cast<const float*>(d.x);
+    float acc[CIN * KK * KK];
+#pragma unroll
+    for (int i = 0; i < CIN * KK * KK; ++i) acc[i] = 0.f;
+    const long p0 = (long)blockIdx.x * chunk, p1 = min(p0 + chunk, pixels);
+    const int hw_o = d.ho * d.wo;
+    const long plane = (long)d.h * d.w_in;
+    if (pl < lanes)
+        for (long p = p0 + pl; p < p1; p += lanes) {
+            const float g = (float)dz[p * d.lddz + co];
+            const int n = (int)(p / hw_o);
+            const int rem = (int)(p - (long)n * hw_o);
+            const int ho = rem / d.wo, wo = rem - ho * d.wo;
+            const float* xn = x + (long)n * CIN * plane;
+#pragma unroll
+            for (int c = 0; c < CIN; ++c)
+#pragma unroll
+                for (int r = 0; r < KK; ++r)
+#pragma unroll
+                    for (int s = 0; s < KK; ++s) {
+                        const int hi = ho * d.stride + r - d.pad, wi = wo * d.stride + s - d.pad;
+                        const bool ok = (unsigned)hi < (unsigned)d.h && (unsigned)wi < (unsigned)d.w_in;
+                        const float xv = ok ? xn[c * plane + (long)hi * d.w_in + wi] : 0.f;
+                        acc[(c * KK + r) * KK + s] = fmaf(g, xv, acc[(c * KK + r) * KK + s]);
+                    }
+        }
+    // reduce the pixel lanes through LDS, then one atomic per (co, ci, r, s) per workgroup
+    __shared__ float red[256];
+#pragma unroll
+    for (int i = 0; i < CIN * KK * KK; ++i) {
+        red[threadIdx.x] = (pl < lanes) ? acc[i] : 0.f;
+        __syncthreads();
+        if (threadIdx.x < d.cout) {
+            float v = 0.f;
+            for (int q = 0; q < lanes; ++q) v += red[q * d.cout + threadIdx.x];
+            atomicAdd(d.dw + (long)threadIdx.x * (CIN * KK * KK) + i, v);
+        }
+        __syncthreads();
+    }
+}
+
+template <typename T>
+__global__ void pack_dgrad_kernel(const float* w, int cout, int cin, int kh, int kw, int cout_k, int m_pad, T* packed) {
+    const long total = (long)m_pad * kh * kw * cout_k;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int co = (int)(i % cout_k);
+        long r = i / cout_k;
+        const int tap = (int)(r % (kh * kw));
+        const int ci = (int)(r / (kh * kw));
+        float v = 0.f;
+        if (ci < cin && co < cout) {
+            const int fr = kh - 1 - tap / kw, fs = kw - 1 - tap % kw;
+            v = w[(((long)co * cin + ci) * kh + fr) * kw + fs];
+        }
+        packed[i] = (T)v;
+    }
+}
+
+template <typename T, bool SCATTER>
+__global__ void resample2_kernel(const yh_resample_desc d) {
+    typedef typename WG<T>::vec V;
+    constexpr int VEC = WG<T>::VEC;
+    const int cg = d.c / VEC;
+    const long total = (long)d.n * d.h * d.w_in * cg;
+    const T* x = reinterpret_cast<const T*>(d.x);
+    T* y = reinterpret_cast<T*>(d.y);
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int g = (int)(i % cg);
+        long pix = i / cg;
+        const int wi = (int)(pix % d.w_in);
+        const long r = pix / d.w_in;
+        const int hi = (int)(r % d.h);
+        const long n = r / d.h;
+        const long w2 = d.big_w;
+        const long big = ((n * d.big_h + 2L * hi) * w2 + 2L * wi);
+        if constexpr (SCATTER) {  // dilate: small x -> even positions of big y
+            *reinterpret_cast<V*>(y + big * d.ldy + g * VEC) = *reinterpret_cast<const V*>(x + pix * d.ldx + g * VEC);
+        } else {                   // upsample backward: big x summed into small y
+            const T* s = x + big * d.ldx + g * VEC;
+            const V v0 = *reinterpret_cast<const V*>(s), v1 = *reinterpret_cast<const V*>(s + d.ldx);
+            const V v2 = *reinterpret_cast<const V*>(s + w2 * d.ldx), v3 = *reinterpret_cast<const V*>(s + (w2 + 1) * d.ldx);
+            V o;
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) o[e] = (T)(((float)v0[e] + (float)v1[e]) + ((float)v2[e] + (float)v3[e]));
+            *reinterpret_cast<V*>(y + pix * d.ldy + g * VEC) = o;
+        }
+    }
+}
+
+template <typename T>
+__global__ void cast_f32_kernel(const yh_cast_desc d) {
+    typedef typename WG<T>::vec V;
+    constexpr int VEC = WG<T>::VEC;
+    const int cg = d.c / VEC;
+    const long total = d.pixels * cg;
+    T* y = reinterpret_cast<T*>(d.y);
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int g = (int)(i % cg);
+        const long pix = i / cg;
+        V o;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) o[e] = (T)d.x[pix * d.ldx + g * VEC + e];
+        *reinterpret_cast<V*>(y + pix * d.ldy + g * VEC) = o;
+    }
+}
+
+static inline unsigned grid_for(long total) {
+    long g = (total + 255) / 256;
+    return (unsigned)(g < 1 ? 1 : (g > 8192 ? 8192 : g));
+}
+
+}  // namespace yh
+
+using namespace yh;
+
+extern "C" int yh_conv_pack_weights_dgrad(int dtype, const float* w, int cout, int cin, int kh, int kw, int cout_k,
+                                          int m_pad, void* packed, void* stream) {
+    if (!w || !packed || cout <= 0 || cin <= 0 || kh <= 0 || kw <= 0 || cout_k < cout || m_pad < cin) return YH_EINVAL;
+    const long total = (long)m_pad * kh * kw * cout_k;
+    if (dtype == YH_F16)
+        hipLaunchKernelGGL(pack_dgrad_kernel<f16>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, w, cout, cin, kh,
+                           kw, cout_k, m_pad, (f16*)packed);
+    else if (dtype == YH_F32)
+        hipLaunchKernelGGL(pack_dgrad_kernel<float>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, w, cout, cin,
+                           kh, kw, cout_k, m_pad, (float*)packed);
+    else return YH_EINVAL;
+    return check_launch();
+}
+
+extern "C" int yh_conv2d_wgrad(const yh_wgrad_desc* d, void* stream) {
+    if (!d || !d->x || !d->dz || !d->dw || d->n <= 0 || d->cin <= 0 || d->cout <= 0) return YH_EINVAL;
+    if (d->dtype != YH_F16 && d->dtype != YH_F32) return YH_EINVAL;
+    const int vec = d->dtype == YH_F16 ? 8 : 4, bk = d->dtype == YH_F16 ? 32 : 16;
+    if (d->ldx % vec || d->lddz % vec || !aligned16(d->x) || !aligned16(d->dz)) return YH_EALIGN;
+    WgradArgs a;
+    a.d = *d;
+    a.pixels = (long)d->n * d->ho * d->wo;
+    a.tiles_m = (d->cout + WG_TILE - 1) / WG_TILE;
+    a.tiles_n = (d->cin + WG_TILE - 1) / WG_TILE;
+    a.ksteps = (int)((a.pixels + bk - 1) / bk);
+    const int tiles = a.tiles_m * a.tiles_n * d->kh * d->kw;
+    int splits = d->splits;
+    if (splits <= 0) {
+        splits = (2048 + tiles - 1) / tiles;               // ~8 workgroups per CU
+        const int max_splits = (a.ksteps + 7) / 8;         // at least 8 K steps per workgroup
+        if (splits > max_splits) splits = max_splits;
+        if (splits < 1) splits = 1;
+    }
+    a.ksteps_per_split = (a.ksteps + splits - 1) / splits;
+    splits = (a.ksteps + a.ksteps_per_split - 1) / a.ksteps_per_split;
+    const dim3 grid(tiles, splits);
+    if (d->dtype == YH_F16) hipLaunchKernelGGL(conv_wgrad_kernel<f16>, grid, dim3(256), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(conv_wgrad_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, a);
+    return check_launch();
+}
+
+extern "C" int yh_stem_wgrad(const yh_wgrad_desc* d, void* stream) {
+    if (!d || !d->x || !d->dz || !d->dw) return YH_EINVAL;
+    if (d->cin != 3 || d->kh != 3 || d->kw != 3 || d->cout <= 0 || d->cout > 256) return YH_EINVAL;
+    if (d->dtype != YH_F16 && d->dtype != YH_F32) return YH_EINVAL;
+    const long pixels = (long)d->n * d->ho * d->wo;
+    const int chunk = 4096;
+    const dim3 grid((unsigned)((pixels + chunk - 1) / chunk));
+    if (d->dtype == YH_F16) hipLaunchKernelGGL(stem_wgrad_kernel<f16>, grid, dim3(256), 0, (hipStream_t)stream, *d, pixels, chunk);
+    else hipLaunchKernelGGL(stem_wgrad_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, *d, pixels, chunk);
+    return check_launch();
+}
+
+static int check_resample(const yh_resample_desc* d) {
+    if (!d || !d->x || !d->y || d->n <= 0 || d->h <= 0 || d->w_in <= 0 || d->c <= 0) return YH_EINVAL;
+    if (d->dtype != YH_F16 && d->dtype != YH_F32) return YH_EINVAL;
+    if (d->big_h < 2 * d->h - 1 || d->big_h > 2 * d->h || d->big_w < 2 * d->w_in - 1 || d->big_w > 2 * d->w_in) return YH_EINVAL;
+    const int vec = d->dtype == YH_F16 ? 8 : 4;
+    if (d->c % vec || d->ldx % vec || d->ldy % vec || !aligned16(d->x) || !aligned16(d->y)) return YH_EALIGN;
+    return YH_OK;
+}
+
+extern "C" int yh_dilate2(const yh_resample_desc* d, void* stream) {
+    int rc = check_resample(d);
+    if (rc) return rc;
+    const int vec = d->dtype == YH_F16 ? 8 : 4;
+    const long total = (long)d->n * d->h * d->w_in * (d->c / vec);
+    if (d->dtype == YH_F16) hipLaunchKernelGGL((resample2_kernel<f16, true>), dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, *d);
+    else hipLaunchKernelGGL((resample2_kernel<float, true>), dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, *d);
+    return check_launch();
+}
+
+extern "C" int yh_upsample2_bwd(const yh_resample_desc* d, void* stream) {
+    int rc = check_resample(d);
+    if (rc) return rc;
+    if (d->big_h != 2 * d->h || d->big_w != 2 * d->w_in) return YH_EINVAL;
+    const int vec = d->dtype == YH_F16 ? 8 : 4;
+    const long total = (long)d->n * d->h * d->w_in * (d->c / vec);
+    if (d->dtype == YH_F16) hipLaunchKernelGGL((resample2_kernel<f16, false>), dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, *d);
+    else hipLaunchKernelGGL((resample2_kernel<float, false>), dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, *d);
+    return check_launch();
+}
+
+extern "C" int yh_cast_f32(const yh_cast_desc* d, void* stream) {
+    if (!d || !d->x || !d->y || d->pixels <= 0 || d->c <= 0) return YH_EINVAL;
+    if (d->dtype != YH_F16 && d->dtype != YH_F32) return YH_EINVAL;
+    const int vec = d->dtype == YH_F16 ? 8 : 4;
+    if (d->c % vec || d->ldy % vec || !aligned16(d->y)) return YH_EALIGN;
+    const long total = d->pixels * (d->c / vec);
+    if (d->dtype == YH_F16) hipLaunchKernelGGL(cast_f32_kernel<f16>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, *d);
+    else hipLaunchKernelGGL(cast_f32_kernel<float>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, *d);
+    return check_launch();
+}

@@ -21,6 +21,10 @@ union AnyDesc {
     yh_se_desc se;
     yh_qcopy_desc qcopy;
     yh_qadd_desc qadd;
+    yh_bn_desc bn;
+    yh_wgrad_desc wgrad;
+    yh_resample_desc resample;
+    yh_cast_desc cast;
 };
 
 struct Fixup {
@@ -48,6 +52,11 @@ size_t desc_size(int kind) {
         case YH_OP_QCOPY: return sizeof(yh_qcopy_desc);
         case YH_OP_QPOOL: return sizeof(yh_pool_desc);
         case YH_OP_QADD: return sizeof(yh_qadd_desc);
+        case YH_OP_BN_STATS: case YH_OP_BN_FINALIZE: case YH_OP_BN_ACT_FWD: case YH_OP_BN_BWD_REDUCE: case YH_OP_BN_BWD_APPLY:
+            return sizeof(yh_bn_desc);
+        case YH_OP_WGRAD: case YH_OP_STEM_WGRAD: return sizeof(yh_wgrad_desc);
+        case YH_OP_DILATE2: case YH_OP_UPSAMPLE2_BWD: return sizeof(yh_resample_desc);
+        case YH_OP_CAST_F32: return sizeof(yh_cast_desc);
         default: return 0;
     }
 }
@@ -65,6 +74,16 @@ int launch(int kind, const AnyDesc& d, void* stream) {
         case YH_OP_QCOPY: return yh_qcopy(&d.qcopy, stream);
         case YH_OP_QPOOL: return yh_qpool(&d.pool, stream);
         case YH_OP_QADD: return yh_qadd(&d.qadd, stream);
+        case YH_OP_BN_STATS: return yh_bn_stats(&d.bn, stream);
+        case YH_OP_BN_FINALIZE: return yh_bn_finalize(&d.bn, stream);
+        case YH_OP_BN_ACT_FWD: return yh_bn_act_fwd(&d.bn, stream);
+        case YH_OP_BN_BWD_REDUCE: return yh_bn_act_bwd_reduce(&d.bn, stream);
+        case YH_OP_BN_BWD_APPLY: return yh_bn_act_bwd_apply(&d.bn, stream);
+        case YH_OP_WGRAD: return yh_conv2d_wgrad(&d.wgrad, stream);
+        case YH_OP_STEM_WGRAD: return yh_stem_wgrad(&d.wgrad, stream);
+        case YH_OP_DILATE2: return yh_dilate2(&d.resample, stream);
+        case YH_OP_UPSAMPLE2_BWD: return yh_upsample2_bwd(&d.resample, stream);
+        case YH_OP_CAST_F32: return yh_cast_f32(&d.cast, stream);
         default: return YH_EINVAL;
     }
 }

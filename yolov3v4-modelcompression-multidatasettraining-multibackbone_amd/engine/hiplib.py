@@ -88,7 +88,69 @@ class QPoolDesc(PoolDesc):
     """Same layout as PoolDesc; a distinct Python type so plans record it as YH_OP_QPOOL."""
 
 
-OP_KIND = {ConvDesc: OP_CONV, StemDesc: OP_STEM, PoolDesc: OP_POOL, CopyDesc: OP_COPY, AddDesc: OP_ADD,
+class BnDesc(C.Structure):
+    _fields_ = [('z', _vp), ('dy', _vp), ('res', _vp), ('out', _vp), ('gamma', _vp), ('beta', _vp), ('mean', _vp),
+                ('invstd', _vp), ('sum', _vp), ('sumsq', _vp), ('running_mean', _vp), ('running_var', _vp),
+                ('pixels', _i64), ('n', _i32), ('h', _i32), ('w_in', _i32),
+                ('c', _i32), ('ldz', _i32), ('lddy', _i32), ('ldr', _i32), ('ldo', _i32), ('act', _i32), ('ups', _i32),
+                ('dtype', _i32), ('slope', _f32), ('eps', _f32), ('momentum', _f32)]
+
+
+class BnStatsDesc(BnDesc):
+    """Same layout as BnDesc; the distinct Python types select the plan op kind."""
+
+
+class BnFinalizeDesc(BnDesc):
+    pass
+
+
+class BnActFwdDesc(BnDesc):
+    pass
+
+
+class BnBwdReduceDesc(BnDesc):
+    pass
+
+
+class BnBwdApplyDesc(BnDesc):
+    pass
+
+
+class WgradDesc(C.Structure):
+    _fields_ = [('x', _vp), ('dz', _vp), ('dw', _vp),
+                ('n', _i32), ('h', _i32), ('w_in', _i32), ('cin', _i32), ('ho', _i32), ('wo', _i32), ('cout', _i32),
+                ('kh', _i32), ('kw', _i32), ('stride', _i32), ('pad', _i32), ('ldx', _i32), ('lddz', _i32), ('dtype', _i32),
+                ('splits', _i32)]
+
+
+class StemWgradDesc(WgradDesc):
+    pass
+
+
+class ResampleDesc(C.Structure):
+    _fields_ = [('x', _vp), ('y', _vp), ('n', _i32), ('h', _i32), ('w_in', _i32), ('c', _i32), ('big_h', _i32),
+                ('big_w', _i32), ('ldx', _i32), ('ldy', _i32), ('dtype', _i32)]
+
+
+class DilateDesc(ResampleDesc):
+    pass
+
+
+class UpsampleBwdDesc(ResampleDesc):
+    pass
+
+
+class CastDesc(C.Structure):
+    _fields_ = [('x', _vp), ('y', _vp), ('pixels', _i64), ('c', _i32), ('ldx', _i32), ('ldy', _i32), ('dtype', _i32)]
+
+
+OP_BN_STATS, OP_BN_FINALIZE, OP_BN_ACT_FWD, OP_BN_BWD_REDUCE, OP_BN_BWD_APPLY = 12, 13, 14, 15, 16
+OP_WGRAD, OP_STEM_WGRAD, OP_DILATE2, OP_UPSAMPLE2_BWD, OP_CAST_F32 = 17, 18, 19, 20, 21
+
+OP_KIND = {BnStatsDesc: OP_BN_STATS, BnFinalizeDesc: OP_BN_FINALIZE, BnActFwdDesc: OP_BN_ACT_FWD,
+           BnBwdReduceDesc: OP_BN_BWD_REDUCE, BnBwdApplyDesc: OP_BN_BWD_APPLY, WgradDesc: OP_WGRAD,
+           StemWgradDesc: OP_STEM_WGRAD, DilateDesc: OP_DILATE2, UpsampleBwdDesc: OP_UPSAMPLE2_BWD, CastDesc: OP_CAST_F32,
+           ConvDesc: OP_CONV, StemDesc: OP_STEM, PoolDesc: OP_POOL, CopyDesc: OP_COPY, AddDesc: OP_ADD,
            DecodeDesc: OP_DECODE, DwDesc: OP_DW, SeDesc: OP_SE, QCopyDesc: OP_QCOPY, QPoolDesc: OP_QPOOL, QAddDesc: OP_QADD}
 
 _SIGNATURES = {
@@ -117,6 +179,17 @@ _SIGNATURES = {
     'yh_nms_mask': (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, _f32, C.c_int, _vp, _vp]),
     'yh_nms_reduce': (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp]),
     'yh_nms_merge': (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _f32, C.c_int, C.c_int, C.c_int, _vp, _vp]),
+    'yh_bn_stats': (C.c_int, [C.POINTER(BnDesc), _vp]),
+    'yh_bn_finalize': (C.c_int, [C.POINTER(BnDesc), _vp]),
+    'yh_bn_act_fwd': (C.c_int, [C.POINTER(BnDesc), _vp]),
+    'yh_bn_act_bwd_reduce': (C.c_int, [C.POINTER(BnDesc), _vp]),
+    'yh_bn_act_bwd_apply': (C.c_int, [C.POINTER(BnDesc), _vp]),
+    'yh_conv_pack_weights_dgrad': (C.c_int, [C.c_int, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp]),
+    'yh_conv2d_wgrad': (C.c_int, [C.POINTER(WgradDesc), _vp]),
+    'yh_stem_wgrad': (C.c_int, [C.POINTER(WgradDesc), _vp]),
+    'yh_dilate2': (C.c_int, [C.POINTER(ResampleDesc), _vp]),
+    'yh_upsample2_bwd': (C.c_int, [C.POINTER(ResampleDesc), _vp]),
+    'yh_cast_f32': (C.c_int, [C.POINTER(CastDesc), _vp]),
     'yh_plan_create': (_vp, []),
     'yh_plan_destroy': (None, [_vp]),
     'yh_plan_add': (C.c_int, [_vp, C.c_int, _vp, C.c_int]),

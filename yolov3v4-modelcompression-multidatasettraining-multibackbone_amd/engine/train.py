@@ -1,0 +1,527 @@
+"""Training step of the cfg graph on the HIP kernels.
+
+Replaces, for CUDA tensors in ``model.train()`` mode, what the reference gets from eager PyTorch + autograd:
+``Darknet.forward`` in training mode (models.py:414-492: conv -> train-mode BatchNorm -> activation per block, shortcut
+adds, route concats, upsample, raw ``p`` per yolo head, models.py:336-340) and the backward of all of it.  The loss
+(``compute_loss``, utils.py:368) stays a torch function on the three raw head tensors; its gradient enters here as
+fp32 head gradients and leaves as fp32 parameter gradients (fp16 compute with fp32 master weights and gradients, the
+``-mpt`` mixed-precision recipe of train.py; or fp32 throughout).
+
+Lowering is shared with the inference engine (``DarknetEngine._build_values`` / ``_place``): the same values, the same
+zero-copy concat placement, the same fused residual / 2x-upsample stores.  Per conv block the forward plan runs
+
+    conv (linear, MFMA implicit GEMM) -> z      yh_conv2d_fwd / yh_conv2d_stem_fwd
+    batch statistics of z                      yh_bn_stats, yh_bn_finalize (also the running-stat update)
+    y = act(bn(z)) [+ residual] [2x store]     yh_bn_act_fwd
+
+and the backward plan, walking the values in reverse,
+
+    dy of a fused upsample                     yh_upsample2_bwd
+    residual: grad(res) += dy                  yh_add_channels / yh_copy_channels
+    dgamma, dbeta (or conv-bias grad)          yh_bn_act_bwd_reduce   (written straight into the gradient arena)
+    dz                                         yh_bn_act_bwd_apply
+    dW                                         yh_conv2d_wgrad / yh_stem_wgrad (fp32 atomics into the arena)
+    grad(input) (+)= conv(dz, W^T flipped)     yh_conv2d_fwd on the dgrad weight image (yh_dilate2 first for stride 2)
+
+Every activation, z and gradient buffer is kept for the whole step (288 GB of HBM: YOLOv3-608 batch 64 needs ~40 GB).
+Blocks this path does not lower yet (maxpool, depthwise, SE, weighted shortcuts) raise NotImplementedError at plan
+build; ``models.Darknet`` then keeps such cfgs on its eager torch path for training.
+"""
+import ctypes as C
+
+import torch
+import torch.nn as nn
+
+from . import hiplib
+from .hiplib import (ConvDesc, StemDesc, CopyDesc, AddDesc, BnStatsDesc, BnFinalizeDesc, BnActFwdDesc, BnBwdReduceDesc,
+                     BnBwdApplyDesc, WgradDesc, StemWgradDesc, DilateDesc, UpsampleBwdDesc, CastDesc)
+from .plan import DarknetEngine, ALIGN_C, _round_up
+
+SLOT_INPUT = 0
+SLOT_HEAD0 = 1       # forward: head output tensors; backward: head gradient tensors (fp32 NHWC)
+LINEAR = hiplib.ACT_CODES['linear']
+
+
+class _Arena:
+    """One flat fp32 tensor handed out in 16-byte aligned pieces (per-channel statistics, parameter gradients)."""
+
+    def __init__(self):
+        self.size = 0
+        self.items = []
+
+    def reserve(self, n):
+        off = self.size
+        self.size += _round_up(n, 4)
+        return off
+
+    def allocate(self, device):
+        self.buf = torch.zeros(max(self.size, 4), device=device, dtype=torch.float32)
+        return self.buf
+
+    def ptr(self, off):
+        return self.buf.data_ptr() + 4 * off
+
+    def view(self, off, n):
+        return self.buf[off:off + n]
+
+
+class TrainEngine(DarknetEngine):
+    def __init__(self, model, precision='fp16', lib=None):
+        if precision not in ('fp16', 'fp32'):
+            raise ValueError("training precision must be 'fp16' or 'fp32'")
+        super().__init__(model, precision, lib)
+        self._tplans = {}
+        self._wsig = None
+        self._current = None
+        self.steps = 0   # forward count; the autograd node checks it so a stale backward fails loudly
+
+    # --------------------------------------------------------------------------------- parameters
+    def parameters(self):
+        """Trainable tensors in the order the autograd function receives them (and returns gradients for)."""
+        out = []
+        for block in self.model.module_list:
+            if isinstance(block, nn.Sequential) and len(block) and isinstance(block[0], nn.Conv2d):
+                conv, bn = block[0], None
+                for k in list(block.children())[1:]:
+                    if isinstance(k, nn.modules.batchnorm.BatchNorm2d):
+                        bn = k
+                out.append(conv.weight)
+                if conv.bias is not None:
+                    out.append(conv.bias)
+                if bn is not None:
+                    out.extend((bn.weight, bn.bias))
+        return out
+
+    # --------------------------------------------------------------------------------- weights
+    def _pack_train(self, plan):
+        """fp32 parameters -> forward weight image (plain cast, no BN fold) and dgrad image (transposed, flipped)."""
+        P, lib = hiplib.ptr, self.lib
+        keep = []
+        for v in plan['values']:
+            if v.kind != 'conv':
+                continue
+            conv = v.conv
+            w = conv.weight.detach()
+            if w.dtype != torch.float32 or not w.is_contiguous():
+                w = w.float().contiguous()
+                keep.append(w)
+            cb = None
+            if conv.bias is not None:
+                cb = conv.bias.detach().float().contiguous()
+                keep.append(cb)
+            pk = v.tpack
+            if v.src.kind == 'input':
+                rc = lib.yh_stem_pack_weights(P(w), P(cb), None, None, None, None, 0.0, v.C, v.src.C, v.k, v.k, pk['cout_pad'],
+                                              P(pk['w']), P(pk['b']), hiplib.stream_ptr())
+                hiplib.check(rc, 'yh_stem_pack_weights')
+                continue
+            rc = lib.yh_conv_pack_weights(self.code, P(w), P(cb), None, None, None, None, 0.0, None, v.C, conv.in_channels,
+                                          v.k, v.k, pk['cin_k'], pk['m_pad'], P(pk['w']), P(pk['b']), hiplib.stream_ptr())
+            hiplib.check(rc, 'yh_conv_pack_weights')
+            rc = lib.yh_conv_pack_weights_dgrad(self.code, P(w), v.C, conv.in_channels, v.k, v.k, pk['cout_k'], pk['dm_pad'],
+                                                P(pk['wt']), hiplib.stream_ptr())
+            hiplib.check(rc, 'yh_conv_pack_weights_dgrad')
+        plan['keep'] = keep
+
+    def _weight_signature(self):
+        return tuple((t.data_ptr(), t._version) for t in self.parameters())
+
+    # --------------------------------------------------------------------------------- plans
+    def _check_supported(self, values):
+        for v in values:
+            if v.kind in ('pool', 'dw', 'se', 'slice', 'qadd'):
+                raise NotImplementedError('HIP training path: %s blocks are not lowered yet (block %s)' % (v.kind, v.block))
+            if v.kind == 'conv':
+                if v.src.kind != 'input' and (v.src.C % ALIGN_C or v.src.c_phys != v.src.C):
+                    raise NotImplementedError('HIP training path: channel counts must be multiples of %d' % ALIGN_C)
+                if not v.fp32 and v.C % ALIGN_C:
+                    raise NotImplementedError('HIP training path: channel counts must be multiples of %d' % ALIGN_C)
+                if v.src.kind == 'input' and (v.src.C != 3 or v.k != 3):
+                    raise NotImplementedError('HIP training path: the first conv must be 3x3 over 3 channels')
+                if v.stride == 2 and not (v.k == 3 and v.pad == 1):
+                    raise NotImplementedError('HIP training path: stride-2 convs must be 3x3 pad 1')
+                if v.stride not in (1, 2):
+                    raise NotImplementedError('HIP training path: conv stride %d' % v.stride)
+                if v.bn is not None and v.fp32:
+                    raise NotImplementedError('HIP training path: BatchNorm on a yolo-head conv')
+
+    def _build_train_plan(self, N, Cin, H, W):
+        values, heads, outs = self._build_values(N, Cin, H, W)
+        self._check_supported(values)
+        self._place(values)
+        lib, dev, P = self.lib, self.device, hiplib.ptr
+        plan = dict(values=values, heads=heads, N=N, storages=[], fwd_ops=[], bwd_ops=[], zero_list=[])
+        fwd = plan['fwd'] = lib.yh_plan_create()
+        bwd = plan['bwd'] = lib.yh_plan_create()
+        if not fwd or not bwd:
+            raise MemoryError('yh_plan_create failed')
+        stats = plan['stats'] = _Arena()      # zeroed before every forward: BN sums
+        saved = plan['saved'] = _Arena()      # mean / invstd per BN (kept from forward to backward)
+        grads = plan['grads'] = _Arena()      # parameter gradients (zeroed before every backward)
+
+        def add(handle, log, desc, what):
+            idx = lib.yh_plan_add(handle, hiplib.OP_KIND[type(desc)], C.byref(desc), C.sizeof(desc))
+            if idx < 0:
+                hiplib.check(idx, 'yh_plan_add(%s)' % what)
+            log.append((what, desc))
+            return idx
+
+        def fixup(handle, op, desc_type, field, slot):
+            hiplib.check(lib.yh_plan_add_fixup(handle, op, getattr(desc_type, field).offset, slot, 0), 'fixup')
+
+        def alloc(shape, fp32=False, zero=False):
+            t = (torch.zeros if zero else torch.empty)(shape, device=dev, dtype=torch.float32 if fp32 else self.dtype)
+            plan['storages'].append(t)
+            return t
+
+        def materialize(v):
+            if v.storage is not None:
+                return
+            if v.parent is not None:
+                materialize(v.parent)
+                v.storage, v.c_off, v.ld = v.parent.storage, v.parent.c_off + v.parent_off, v.parent.ld
+                v.gstorage = v.parent.gstorage
+            else:
+                v.storage = None if v.fp32 else alloc((N, v.H, v.W, v.c_phys))
+                v.gstorage = None if v.fp32 else alloc((N, v.H, v.W, v.c_phys))
+                v.c_off, v.ld = 0, v.c_phys
+
+        # ---- pass 1: buffers, parameter slots
+        kstep = self.kstep
+        pidx = 0
+        plan['param_slices'] = []   # (arena offset, numel, shape) in parameters() order
+        for v in values:
+            if v.kind == 'input':
+                continue
+            materialize(v)
+            if v.kind != 'conv':
+                continue
+            conv, bn = v.conv, v.bn
+            taps = v.k * v.k
+            v.g_w = grads.reserve(conv.weight.numel())
+            plan['param_slices'].append((v.g_w, conv.weight.numel(), tuple(conv.weight.shape)))
+            v.g_b = None
+            if conv.bias is not None:
+                v.g_b = grads.reserve(v.c_phys)
+                plan['param_slices'].append((v.g_b, v.C, (v.C,)))
+            if bn is not None:
+                v.g_gamma, v.g_beta = grads.reserve(v.C), grads.reserve(v.C)
+                plan['param_slices'].append((v.g_gamma, v.C, (v.C,)))
+                plan['param_slices'].append((v.g_beta, v.C, (v.C,)))
+                v.s_sum, v.s_sumsq = stats.reserve(v.C), stats.reserve(v.C)
+                v.s_mean, v.s_invstd = saved.reserve(v.C), saved.reserve(v.C)
+            if v.src.kind == 'input':
+                cout_pad = _round_up(v.C, 32) if v.C % 32 == 0 else _round_up(v.C, 16)
+                v.tpack = dict(w=torch.empty(taps * v.src.C * cout_pad, device=dev, dtype=torch.float32),
+                               b=torch.empty(cout_pad, device=dev, dtype=torch.float32), cout_pad=cout_pad)
+            else:
+                cin_k = _round_up(v.src.c_phys, kstep)
+                m_pad = _round_up(v.c_phys, 128)
+                cout_k = _round_up(v.c_phys, kstep)          # dgrad: K runs over the output channels
+                dm_pad = _round_up(v.src.c_phys, 128)
+                v.tpack = dict(w=torch.empty(m_pad * taps * cin_k, device=dev, dtype=self.dtype),
+                               b=torch.empty(m_pad, device=dev, dtype=torch.float32), cin_k=cin_k, m_pad=m_pad,
+                               wt=torch.empty(dm_pad * taps * cout_k, device=dev, dtype=self.dtype), cout_k=cout_k,
+                               dm_pad=dm_pad)
+            # z: the conv output before BN / activation.  Blocks with neither BN nor activation store straight to y.
+            v.plain = bn is None and v.act == LINEAR and v.res is None and v.ups == 1
+            if v.fp32:
+                if not v.plain:
+                    raise NotImplementedError('HIP training path: yolo-head conv with BN / activation / residual')
+                v.z = None
+            elif v.plain:
+                v.z = None
+            else:
+                v.z = alloc((N, v.Ho, v.Wo, v.c_phys))
+        plan['junk_n'] = max(v.c_phys for v in values if v.kind == 'conv')
+        plan['junk'] = grads.reserve(plan['junk_n'])
+        stats.allocate(dev)
+        saved.allocate(dev)
+        grads.allocate(dev)
+        zero_bias = alloc((max([_round_up(v.src.c_phys, 128) for v in values if v.kind == 'conv' and v.src.kind != 'input']
+                               + [128]),), fp32=True, zero=True)
+        dz_elems = max(N * v.Ho * v.Wo * v.c_phys for v in values if v.kind == 'conv')
+        dz_scratch = alloc((dz_elems,))
+        head_index = {id(h.src): k for k, h in enumerate(heads)}
+
+        # ---- pass 2: forward ops
+        for v in values:
+            if v.kind == 'input':
+                continue
+            y = None if v.storage is None else P(v.storage, v.c_off)
+            if v.kind == 'conv':
+                pk, s = v.tpack, v.src
+                direct = v.plain                     # conv epilogue writes the block output itself
+                zt = None if direct else v.z
+                if s.kind == 'input':
+                    d = StemDesc(x=None, w=P(pk['w']), bias=P(pk['b']), y=y if direct else P(zt), n=N, cin=s.C, h=s.H,
+                                 w_in=s.W, ho=v.Ho, wo=v.Wo, cout=v.c_phys, cout_pad=pk['cout_pad'], kh=v.k, kw=v.k,
+                                 stride=v.stride, pad=v.pad, ldy=v.ld if direct else v.c_phys, act=LINEAR, slope=0.0,
+                                 dtype=self.code, out_scale=0.0)
+                    if v.c_phys > pk['cout_pad'] or v.fp32:
+                        raise NotImplementedError('HIP training path: stem geometry')
+                    op = add(fwd, plan['fwd_ops'], d, 'stem%d' % v.block)
+                    fixup(fwd, op, StemDesc, 'x', SLOT_INPUT)
+                else:
+                    d = ConvDesc(x=P(s.storage, s.c_off), w=P(pk['w']), bias=P(pk['b']), res=None,
+                                 y=None if v.fp32 else (y if direct else P(zt)), n=N, h=s.H, w_in=s.W, cin=s.c_phys,
+                                 ho=v.Ho, wo=v.Wo, cout=v.c_phys, kh=v.k, kw=v.k, stride=v.stride, pad=v.pad, ldx=s.ld,
+                                 ldr=0, ldy=v.c_phys if (v.fp32 or not direct) else v.ld, cin_k=pk['cin_k'],
+                                 m_pad=pk['m_pad'], act=LINEAR, slope=0.0, ups=1, out_f32=1 if v.fp32 else 0,
+                                 dtype=self.code, tile=self.force_tile, acc_scale=0.0, out_scale=0.0)
+                    op = add(fwd, plan['fwd_ops'], d, 'conv%d' % v.block)
+                    if v.fp32:
+                        fixup(fwd, op, ConvDesc, 'y', SLOT_HEAD0 + head_index[id(v)])
+                if direct:
+                    continue
+                pixels = N * v.Ho * v.Wo
+                bn = v.bn
+                base = dict(z=P(zt), pixels=pixels, n=N, h=v.Ho, w_in=v.Wo, c=v.c_phys, ldz=v.c_phys, act=v.act,
+                            slope=v.slope, dtype=self.code, ups=v.ups)
+                if bn is not None:
+                    bnp = dict(gamma=P(bn.weight), beta=P(bn.bias), mean=saved.ptr(v.s_mean), invstd=saved.ptr(v.s_invstd),
+                               sum=stats.ptr(v.s_sum), sumsq=stats.ptr(v.s_sumsq), eps=float(bn.eps),
+                               momentum=float(bn.momentum))
+                    if bn.momentum is None or not bn.track_running_stats or not bn.affine:
+                        raise NotImplementedError('HIP training path: BatchNorm without momentum / running stats / affine')
+                    for t in (bn.weight, bn.bias, bn.running_mean, bn.running_var):
+                        if t.dtype != torch.float32 or not t.is_contiguous():
+                            raise NotImplementedError('HIP training path: BatchNorm tensors must be contiguous fp32')
+                    add(fwd, plan['fwd_ops'], BnStatsDesc(**base, **bnp), 'bnstat%d' % v.block)
+                    add(fwd, plan['fwd_ops'], BnFinalizeDesc(**base, **bnp, running_mean=P(bn.running_mean),
+                                                             running_var=P(bn.running_var)), 'bnfin%d' % v.block)
+                else:
+                    bnp = dict()
+                v.bn_args = (base, bnp)
+                add(fwd, plan['fwd_ops'],
+                    BnActFwdDesc(**base, **bnp, out=y, ldo=v.ld, res=None if v.res is None else P(v.res.storage, v.res.c_off),
+                                 ldr=0 if v.res is None else v.res.ld), 'bnact%d' % v.block)
+            elif v.kind == 'copy':
+                s = v.src
+                add(fwd, plan['fwd_ops'], CopyDesc(x=P(s.storage, s.c_off), y=y, n=N, h=s.H, w_in=s.W, c=s.c_phys, ups=v.ups,
+                                                   ldx=s.ld, ldy=v.ld, dtype=self.code), 'ups%d' % v.block)
+            elif v.kind == 'add':
+                add(fwd, plan['fwd_ops'], AddDesc(a=P(v.a.storage, v.a.c_off), b=P(v.b.storage, v.b.c_off), y=y,
+                                                  pixels=N * v.H * v.W, c=v.c_phys, lda=v.a.ld, ldb=v.b.ld, ldy=v.ld,
+                                                  dtype=self.code), 'add%d' % v.block)
+            elif v.kind == 'concat':
+                for s, off, inplace in v.parts:
+                    if not inplace:
+                        add(fwd, plan['fwd_ops'], CopyDesc(x=P(s.storage, s.c_off), y=P(v.storage, v.c_off + off), n=N, h=s.H,
+                                                           w_in=s.W, c=s.c_phys, ups=1, ldx=s.ld, ldy=v.ld, dtype=self.code),
+                            'cat%d' % v.block)
+
+        # ---- pass 3: backward ops.  A gradient storage's first writer must cover it entirely; otherwise the
+        # storage is zeroed before the backward plan runs and every contribution accumulates.
+        initialised = set()
+
+        def contribution_mode(t, full_width):
+            key = id(t.gstorage)
+            if key in initialised:
+                return 'acc'
+            initialised.add(key)
+            if full_width and t.c_off == 0 and t.ld == t.c_phys:
+                return 'write'
+            plan['zero_list'].append(t.gstorage)
+            return 'acc'
+
+        def gptr(t):
+            return P(t.gstorage, t.c_off)
+
+        def contribute(t, src_ptr, src_ld, pixels_hw, what):
+            """grad(t) (+)= rows at src_ptr (same spatial size and channel count as t)."""
+            mode = contribution_mode(t, True)
+            if mode == 'write':
+                add(bwd, plan['bwd_ops'], CopyDesc(x=src_ptr, y=gptr(t), n=N, h=t.H, w_in=t.W, c=t.c_phys, ups=1, ldx=src_ld,
+                                                   ldy=t.ld, dtype=self.code), what)
+            else:
+                add(bwd, plan['bwd_ops'], AddDesc(a=gptr(t), b=src_ptr, y=gptr(t), pixels=N * t.H * t.W, c=t.c_phys, lda=t.ld,
+                                                  ldb=src_ld, ldy=t.ld, dtype=self.code), what)
+
+        def has_grad(t):
+            return t.fp32 or id(t.gstorage) in initialised
+
+        for v in reversed(values):
+            if v.kind == 'input':
+                continue
+            if v.kind == 'concat':
+                if not has_grad(v):
+                    continue
+                for s, off, inplace in v.parts:
+                    if not inplace:
+                        contribute(s, P(v.gstorage, v.c_off + off), v.ld, None, 'dcat%d' % v.block)
+                continue
+            if v.kind == 'add':
+                if has_grad(v):
+                    contribute(v.a, gptr(v), v.ld, None, 'dadd%d' % v.block)
+                    contribute(v.b, gptr(v), v.ld, None, 'dadd%d' % v.block)
+                continue
+            if v.kind == 'copy':
+                if has_grad(v):
+                    s = v.src
+                    if contribution_mode(s, True) == 'write':
+                        add(bwd, plan['bwd_ops'], UpsampleBwdDesc(x=gptr(v), y=gptr(s), n=N, h=s.H, w_in=s.W, c=s.c_phys, big_h=2 * s.H, big_w=2 * s.W,
+                                                                  ldx=v.ld, ldy=s.ld, dtype=self.code), 'dups%d' % v.block)
+                    else:
+                        tmp = alloc((N, s.H, s.W, s.c_phys))
+                        add(bwd, plan['bwd_ops'], UpsampleBwdDesc(x=gptr(v), y=P(tmp), n=N, h=s.H, w_in=s.W, c=s.c_phys, big_h=2 * s.H, big_w=2 * s.W,
+                                                                  ldx=v.ld, ldy=s.c_phys, dtype=self.code), 'dups%d' % v.block)
+                        add(bwd, plan['bwd_ops'], AddDesc(a=gptr(s), b=P(tmp), y=gptr(s), pixels=N * s.H * s.W, c=s.c_phys,
+                                                          lda=s.ld, ldb=s.c_phys, ldy=s.ld, dtype=self.code), 'dups%d' % v.block)
+                continue
+            if v.kind != 'conv':
+                raise NotImplementedError('HIP training path: backward of %s' % v.kind)
+            if not has_grad(v):
+                continue                      # dead branch: its parameters get zero gradients
+            s, pk = v.src, v.tpack
+            pixels = N * v.Ho * v.Wo
+            dzp, lddz = P(dz_scratch), v.c_phys
+            if v.fp32:                        # head: fp32 gradient from autograd -> dtype
+                op = add(bwd, plan['bwd_ops'], CastDesc(x=None, y=dzp, pixels=pixels, c=v.c_phys, ldx=v.c_phys, ldy=v.c_phys,
+                                                        dtype=self.code), 'dhead%d' % v.block)
+                fixup(bwd, op, CastDesc, 'x', SLOT_HEAD0 + head_index[id(v)])
+                if v.g_b is not None:         # bias gradient = sum over pixels of dz
+                    add(bwd, plan['bwd_ops'],
+                        BnBwdReduceDesc(z=dzp, dy=dzp, pixels=pixels, n=N, h=v.Ho, w_in=v.Wo, c=v.c_phys, ldz=v.c_phys,
+                                        lddy=v.c_phys, act=LINEAR, slope=0.0, dtype=self.code, ups=1,
+                                        sum=grads.ptr(v.g_b), sumsq=grads.ptr(self._junk(plan, grads, v.c_phys))),
+                        'dbias%d' % v.block)
+            else:
+                dyp, lddy = gptr(v), v.ld
+                if v.ups == 2:
+                    small = alloc((N, v.Ho, v.Wo, v.c_phys))
+                    add(bwd, plan['bwd_ops'], UpsampleBwdDesc(x=dyp, y=P(small), n=N, h=v.Ho, w_in=v.Wo, c=v.c_phys, big_h=2 * v.Ho, big_w=2 * v.Wo, ldx=lddy,
+                                                              ldy=v.c_phys, dtype=self.code), 'dups%d' % v.block)
+                    dyp, lddy = P(small), v.c_phys
+                if v.res is not None:
+                    contribute(v.res, dyp, lddy, None, 'dres%d' % v.block)
+                if v.plain:                   # no BN, linear: dz is dy itself
+                    dzp, lddz = dyp, lddy
+                    if v.g_b is not None:
+                        add(bwd, plan['bwd_ops'],
+                            BnBwdReduceDesc(z=dyp, dy=dyp, pixels=pixels, n=N, h=v.Ho, w_in=v.Wo, c=v.c_phys, ldz=lddy,
+                                            lddy=lddy, act=LINEAR, slope=0.0, dtype=self.code, ups=1, sum=grads.ptr(v.g_b),
+                                            sumsq=grads.ptr(self._junk(plan, grads, v.c_phys))), 'dbias%d' % v.block)
+                else:
+                    base, bnp = v.bn_args
+                    base = dict(base, ups=1)
+                    if v.bn is not None:
+                        acc = dict(bnp, sum=grads.ptr(v.g_beta), sumsq=grads.ptr(v.g_gamma))
+                    else:                     # activation without BN: z already holds the bias
+                        acc = dict(sum=grads.ptr(v.g_b if v.g_b is not None else self._junk(plan, grads, v.c_phys)),
+                                   sumsq=grads.ptr(self._junk(plan, grads, v.c_phys)))
+                    add(bwd, plan['bwd_ops'], BnBwdReduceDesc(**base, **acc, dy=dyp, lddy=lddy), 'dbn%d' % v.block)
+                    add(bwd, plan['bwd_ops'], BnBwdApplyDesc(**base, **acc, dy=dyp, lddy=lddy, out=dzp, ldo=v.c_phys),
+                        'dbnx%d' % v.block)
+            # weight gradient
+            if s.kind == 'input':
+                op = add(bwd, plan['bwd_ops'],
+                         StemWgradDesc(x=None, dz=dzp, dw=grads.ptr(v.g_w), n=N, h=s.H, w_in=s.W, cin=s.C, ho=v.Ho, wo=v.Wo,
+                                       cout=v.C, kh=v.k, kw=v.k, stride=v.stride, pad=v.pad, ldx=0, lddz=lddz, dtype=self.code,
+                                       splits=0), 'wgrad%d' % v.block)
+                fixup(bwd, op, StemWgradDesc, 'x', SLOT_INPUT)
+                continue
+            add(bwd, plan['bwd_ops'],
+                WgradDesc(x=P(s.storage, s.c_off), dz=dzp, dw=grads.ptr(v.g_w), n=N, h=s.H, w_in=s.W, cin=s.C, ho=v.Ho,
+                          wo=v.Wo, cout=v.C, kh=v.k, kw=v.k, stride=v.stride, pad=v.pad, ldx=s.ld, lddz=lddz, dtype=self.code,
+                          splits=0), 'wgrad%d' % v.block)
+            # data gradient into grad(src)
+            gx, gh, gw_, gld = dzp, v.Ho, v.Wo, lddz
+            if v.stride == 2:
+                # dz onto the even positions of a zeroed tensor of the INPUT's spatial size (odd positions stay zero)
+                dil = alloc((N, s.H, s.W, v.c_phys), zero=True)
+                add(bwd, plan['bwd_ops'], DilateDesc(x=dzp, y=P(dil), n=N, h=v.Ho, w_in=v.Wo, c=v.c_phys, big_h=s.H, big_w=s.W,
+                                                     ldx=lddz, ldy=v.c_phys, dtype=self.code), 'dilate%d' % v.block)
+                gx, gh, gw_, gld = P(dil), s.H, s.W, v.c_phys
+            mode = contribution_mode(s, True)
+            add(bwd, plan['bwd_ops'],
+                ConvDesc(x=gx, w=P(pk['wt']), bias=P(zero_bias), res=gptr(s) if mode == 'acc' else None, y=gptr(s), n=N, h=gh,
+                         w_in=gw_, cin=v.c_phys, ho=s.H, wo=s.W, cout=s.c_phys, kh=v.k, kw=v.k, stride=1, pad=v.k - 1 - v.pad,
+                         ldx=gld, ldr=s.ld if mode == 'acc' else 0, ldy=s.ld, cin_k=pk['cout_k'], m_pad=pk['dm_pad'], act=LINEAR,
+                         slope=0.0, ups=1, out_f32=0, dtype=self.code, tile=self.force_tile, acc_scale=0.0, out_scale=0.0),
+                'dgrad%d' % v.block)
+        plan['head_shapes'] = [(N, h.src.H, h.src.W, h.src.c_phys) for h in heads]
+        return plan
+
+    @staticmethod
+    def _junk(plan, grads, n):
+        """Scratch accumulator for a reduction output nobody reads (lives past the parameter slices)."""
+        junk = plan.get('junk')
+        if junk is None or plan['junk_n'] < n:
+            raise RuntimeError('junk accumulator was not reserved')
+        return junk
+
+    # --------------------------------------------------------------------------------- execute
+    def _get_plan(self, x):
+        if x.dim() != 4:
+            raise ValueError('expected an (N, C, H, W) batch')
+        if self.device is None:
+            self.device = x.device
+        elif self.device != x.device:
+            raise RuntimeError('engine was built on %s, input is on %s' % (self.device, x.device))
+        key = tuple(x.shape)
+        plan = self._tplans.get(key)
+        if plan is None:
+            plan = self._tplans[key] = self._build_train_plan(*key)
+            self._wsig = None
+        return plan
+
+    def forward(self, x):
+        """Run the training forward; returns the fp32 NHWC head tensors [(N, ny, nx, c_phys)] (fresh tensors)."""
+        x = x.contiguous()
+        if x.dtype != torch.float32:
+            x = x.float()
+        plan = self._get_plan(x)
+        sig = self._weight_signature()
+        if sig != self._wsig or plan.get('packed_for') != sig:
+            self._pack_train(plan)
+            self._wsig = plan['packed_for'] = sig
+        lib = self.lib
+        plan['stats'].buf.zero_()
+        heads = [torch.empty(shape, device=x.device, dtype=torch.float32) for shape in plan['head_shapes']]
+        lib.yh_plan_bind_slot(plan['fwd'], SLOT_INPUT, x.data_ptr())
+        for k, h in enumerate(heads):
+            lib.yh_plan_bind_slot(plan['fwd'], SLOT_HEAD0 + k, h.data_ptr())
+        hiplib.check(lib.yh_plan_run(plan['fwd'], hiplib.stream_ptr()), 'yh_plan_run(train forward)')
+        counters = [v.bn.num_batches_tracked for v in plan['values']
+                    if v.kind == 'conv' and v.bn is not None and v.bn.num_batches_tracked is not None]
+        if counters:
+            torch._foreach_add_(counters, 1)
+        plan['x'] = x
+        self._current = plan
+        self.steps += 1
+        return heads
+
+    def backward(self, head_grads):
+        """fp32 head gradients (same shapes as ``forward``'s outputs) -> list of fp32 parameter gradients."""
+        plan = self._current
+        if plan is None:
+            raise RuntimeError('backward() without a preceding forward()')
+        lib = self.lib
+        x = plan['x']
+        plan['grads'].buf.zero_()
+        for t in plan['zero_list']:
+            t.zero_()
+        keep = []
+        lib.yh_plan_bind_slot(plan['bwd'], SLOT_INPUT, x.data_ptr())
+        for k, (g, shape) in enumerate(zip(head_grads, plan['head_shapes'])):
+            if g is None:
+                g = torch.zeros(shape, device=x.device, dtype=torch.float32)
+            g = g.contiguous().float()
+            if tuple(g.shape) != tuple(shape):
+                raise ValueError('head gradient %d has shape %s, expected %s' % (k, tuple(g.shape), shape))
+            keep.append(g)
+            lib.yh_plan_bind_slot(plan['bwd'], SLOT_HEAD0 + k, g.data_ptr())
+        hiplib.check(lib.yh_plan_run(plan['bwd'], hiplib.stream_ptr()), 'yh_plan_run(train backward)')
+        flat = plan['grads'].buf.clone()   # autograd may keep (and later accumulate into) what we return
+        return [flat[off:off + n].view(shape) for off, n, shape in plan['param_slices']]
+
+    def _drop_plans(self):
+        super()._drop_plans()
+        for plan in getattr(self, '_tplans', {}).values():
+            for key in ('fwd', 'bwd'):
+                try:
+                    self.lib.yh_plan_destroy(plan[key])
+                except Exception:
+                    pass
+        self._tplans = {}

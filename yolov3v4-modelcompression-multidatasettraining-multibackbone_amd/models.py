@@ -316,6 +316,30 @@ class YOLOLayer(nn.Module):
 
 
 # ------------------------------------------------------------------------------------------- network
+class _HipTrainFunction(torch.autograd.Function):
+    """Autograd node of one training step on the HIP engine: parameters in, fp32 NHWC head tensors out.
+
+    ``backward`` hands the head gradients to ``TrainEngine.backward`` and returns its fp32 parameter gradients, so
+    optimizers, GradScaler, gradient accumulation and DistributedDataParallel hooks see ordinary ``.grad`` tensors."""
+
+    @staticmethod
+    def forward(ctx, engine, x, *params):
+        heads = engine.forward(x)
+        ctx.engine = engine
+        ctx.step = engine.steps
+        return tuple(heads)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, *head_grads):
+        eng = ctx.engine
+        if eng.steps != ctx.step:
+            raise RuntimeError('HIP training path: backward() of a forward whose buffers were overwritten by a later '
+                               'forward (one forward per backward, like gradient checkpointing-free eager training)')
+        grads = eng.backward(head_grads)
+        return (None, None) + tuple(grads)
+
+
 class Darknet(nn.Module):
     """YOLOv3/v4 detector assembled from a darknet cfg (path or list of block dicts)."""
 
@@ -375,10 +399,43 @@ class Darknet(nn.Module):
         # quantisers (1, 2) stay on the eager modules
         return x.is_cuda and not self.training and self.quantized in (-1, 3)
 
+    def _use_hip_train(self, x):
+        # training step on the HIP kernels (engine/train.py): float graphs only; cfgs with blocks that path does
+        # not lower yet are remembered and stay on the eager modules
+        return (x.is_cuda and self.training and self.quantized == -1 and not self.__dict__.get('_hip_train_unsupported')
+                and os.environ.get('YOLO_HIP_TRAIN', '1') != '0')
+
     def forward_once(self, x, augment=False, verbose=False):
-        if self._use_hip(x) and not verbose and not augment:
-            return self._forward_hip(x)
+        if not verbose and not augment:
+            if self._use_hip(x):
+                return self._forward_hip(x)
+            if self._use_hip_train(x):
+                try:
+                    return self._forward_hip_train(x)
+                except NotImplementedError as e:
+                    print('HIP training path unavailable for this cfg (%s); using the eager modules' % e)
+                    self.__dict__['_hip_train_unsupported'] = True
         return self._forward_eager(x, augment=augment, verbose=verbose)
+
+    def _forward_hip_train(self, x):
+        """Train-mode forward on the HIP engine; returns ``(raw_p_list, [])`` like the eager path (models.py:336-340:
+        raw p is the (bs, na, ny, nx, no) view of the head conv).  fp16 compute under ``torch.autocast`` (the -mpt
+        recipe), fp32 otherwise; ``YOLO_HIP_TRAIN_PRECISION`` overrides."""
+        from engine.train import TrainEngine  # raises if libyolo_hip.so is missing: no fallback
+        precision = os.environ.get('YOLO_HIP_TRAIN_PRECISION') or \
+            ('fp16' if torch.is_autocast_enabled() else 'fp32')
+        eng = self.__dict__.get('_hip_train_engine')
+        if eng is None or eng.precision != precision:
+            eng = TrainEngine(self, precision=precision)
+            eng._get_plan(x)  # NotImplementedError surfaces here, before any state changes
+            self.__dict__['_hip_train_engine'] = eng
+        heads = _HipTrainFunction.apply(eng, x, *eng.parameters())
+        yolo_out = []
+        for h, idx in zip(heads, self.yolo_layers):
+            m = self.module_list[idx]
+            bs, ny, nx, _ = h.shape
+            yolo_out.append(h[..., :m.na * m.no].view(bs, ny, nx, m.na, m.no).permute(0, 3, 1, 2, 4))
+        return yolo_out, []
 
     def _forward_hip(self, x):
         from engine.plan import DarknetEngine  # raises if libyolo_hip.so is missing: no fallback
@@ -440,7 +497,7 @@ class Darknet(nn.Module):
                         break
             fused_list.append(block)
         self.module_list = fused_list
-        self.__dict__['_hip_engine'] = None
+        self.__dict__['_hip_engine'] = self.__dict__['_hip_train_engine'] = None
 
     def info(self, verbose=False):
         torch_utils.model_info(self, verbose)
@@ -451,19 +508,19 @@ class Darknet(nn.Module):
 
         The engine already notices optimizer steps and ``param.data = ...`` rebinding (tensor version /
         address); call this after editing weights through ``param.data`` views in place."""
-        self.__dict__['_hip_engine'] = None
+        self.__dict__['_hip_engine'] = self.__dict__['_hip_train_engine'] = None
 
     def _apply(self, fn, *args, **kwargs):
-        self.__dict__['_hip_engine'] = None
+        self.__dict__['_hip_engine'] = self.__dict__['_hip_train_engine'] = None
         return super()._apply(fn, *args, **kwargs)
 
     def load_state_dict(self, *args, **kwargs):
-        self.__dict__['_hip_engine'] = None
+        self.__dict__['_hip_engine'] = self.__dict__['_hip_train_engine'] = None
         return super().load_state_dict(*args, **kwargs)
 
     def train(self, mode=True):
         if mode:
-            self.__dict__['_hip_engine'] = None
+            self.__dict__['_hip_engine'] = None  # weights are about to change; the train engine re-packs every step
         return super().train(mode)
 
     def __deepcopy__(self, memo):
@@ -551,7 +608,7 @@ def load_darknet_weights(self, weights, cutoff=-1, pt=False, quant=False, **igno
 
     assert cur.pos == len(cur.flat), 'weights file holds %d floats, model consumed %d' % (len(cur.flat), cur.pos)
     if isinstance(self, Darknet):
-        self.__dict__['_hip_engine'] = None
+        self.__dict__['_hip_engine'] = self.__dict__['_hip_train_engine'] = None
 
 
 def save_weights(self, path='model.weights', cutoff=-1):

@@ -162,6 +162,117 @@ def bbox_iou(box1, box2, x1y1x2y2=True, GIoU=False, DIoU=False, CIoU=False):
     return iou - (rho2 / diag2 + v * alpha)
 
 
+# ------------------------------------------------------------------------------------------------- loss
+class FocalLoss(nn.Module):
+    """Focal modulation around an ``nn.BCEWithLogitsLoss`` (reference utils/utils.py:333-360, the TF-addons form)."""
+
+    def __init__(self, loss_fcn, gamma=1.5, alpha=0.25):
+        super().__init__()
+        self.loss_fcn, self.gamma, self.alpha = loss_fcn, gamma, alpha
+        self.reduction = loss_fcn.reduction
+        self.loss_fcn.reduction = 'none'
+
+    def forward(self, pred, true):
+        loss = self.loss_fcn(pred, true)
+        prob = torch.sigmoid(pred)
+        p_t = true * prob + (1 - true) * (1 - prob)
+        loss = loss * (true * self.alpha + (1 - true) * (1 - self.alpha)) * (1.0 - p_t) ** self.gamma
+        if self.reduction == 'mean':
+            return loss.mean()
+        return loss.sum() if self.reduction == 'sum' else loss
+
+
+def smooth_BCE(eps=0.1):
+    """(positive, negative) BCE targets under label smoothing (utils.py:363-365)."""
+    return 1.0 - 0.5 * eps, 0.5 * eps
+
+
+def _yolo_modules(model):
+    core = model.module if type(model) in (nn.parallel.DataParallel, nn.parallel.DistributedDataParallel) else model
+    return [core.module_list[j] for j in core.yolo_layers]
+
+
+def build_targets(p, targets, model):
+    """Assign every label to every anchor of every head whose wh-IoU with it exceeds ``hyp['iou_t']``.
+
+    ``targets`` is (nt, 6) = image, class, x, y, w, h (normalised).  Per head: classes, boxes (cell-relative xy,
+    grid-unit wh), index tuple (image, anchor, gy, gx) and the matching anchor vectors (reference utils.py:725-779)."""
+    nt = targets.shape[0]
+    dev = targets.device
+    tcls, tbox, indices, av = [], [], [], []
+    for i, layer in enumerate(_yolo_modules(model)):
+        anchors = layer.anchor_vec
+        ny, nx = p[i].shape[2], p[i].shape[3]
+        gain = torch.tensor([1, 1, nx, ny, nx, ny], device=dev, dtype=targets.dtype)
+        t = targets * gain
+        a = torch.zeros(0, dtype=torch.long, device=dev)
+        if nt:
+            na = anchors.shape[0]
+            iou = wh_iou(anchors.to(dev), t[:, 4:6])                    # (na, nt)
+            a = torch.arange(na, device=dev).view(-1, 1).repeat(1, nt).view(-1)
+            t = t.repeat(na, 1)
+            keep = iou.view(-1) > model.hyp['iou_t']
+            t, a = t[keep], a[keep]
+        b, c = t[:, :2].long().t()
+        gxy, gwh = t[:, 2:4], t[:, 4:6]
+        gi, gj = gxy.long().t()
+        indices.append((b, a, gj, gi))
+        tbox.append(torch.cat((gxy - gxy.floor(), gwh), 1))
+        av.append(anchors.to(dev)[a])
+        tcls.append(c)
+        if c.shape[0] and int(c.max()) >= model.nc:
+            raise AssertionError('Model accepts %g classes labeled from 0-%g, however you labelled a class %g. '
+                                 % (model.nc, model.nc - 1, int(c.max())))
+    return tcls, tbox, indices, av
+
+
+def compute_loss(p, targets, model):
+    """GIoU box loss + objectness BCE + class BCE over the raw head tensors (reference utils.py:368-432).
+
+    Returns ``(loss, detached [lbox, lobj, lcls, loss])``; mean reduction, gains from ``model.hyp``, objectness
+    target ``(1 - gr) + gr * giou`` with ``model.gr``."""
+    dev = p[0].device
+    z = lambda: torch.zeros(1, device=dev)
+    lcls, lbox, lobj = z(), z(), z()
+    tcls, tbox, indices, anchor_vec = build_targets(p, targets, model)
+    h = model.hyp
+    bce_cls = nn.BCEWithLogitsLoss(pos_weight=torch.tensor([h['cls_pw']], device=dev), reduction='mean')
+    bce_obj = nn.BCEWithLogitsLoss(pos_weight=torch.tensor([h['obj_pw']], device=dev), reduction='mean')
+    cp, cn = smooth_BCE(eps=0.0)
+    if h['fl_gamma'] > 0:
+        bce_cls, bce_obj = FocalLoss(bce_cls, h['fl_gamma']), FocalLoss(bce_obj, h['fl_gamma'])
+    for i, pi in enumerate(p):
+        b, a, gj, gi = indices[i]
+        tobj = torch.zeros_like(pi[..., 0])
+        nb = len(b)
+        if nb:
+            ps = pi[b, a, gj, gi]
+            pxy = torch.sigmoid(ps[:, 0:2])
+            pwh = torch.exp(ps[:, 2:4]).clamp(max=1E3) * anchor_vec[i]
+            giou = bbox_iou(torch.cat((pxy, pwh), 1).t(), tbox[i], x1y1x2y2=False, GIoU=True)
+            lbox = lbox + (1.0 - giou).mean()
+            tobj[b, a, gj, gi] = (1.0 - model.gr) + model.gr * giou.detach().clamp(0).type(tobj.dtype)
+            if model.nc > 1:
+                t = torch.full_like(ps[:, 5:], cn)
+                t[range(nb), tcls[i]] = cp
+                lcls = lcls + bce_cls(ps[:, 5:], t)
+        lobj = lobj + bce_obj(pi[..., 4], tobj)
+    lbox = lbox * h['giou']
+    lobj = lobj * h['obj']
+    lcls = lcls * h['cls']
+    loss = lbox + lobj + lcls
+    return loss, torch.cat((lbox, lobj, lcls, loss)).detach()
+
+
+def compute_lost_KD(output_s, output_t, num_classes, batch_size):
+    """Hinton soft-target distillation between student and teacher raw heads (reference utils.py:435-444)."""
+    T, weight = 3.0, 0.001
+    s = torch.cat([o.reshape(-1, num_classes + 5) for o in output_s])
+    t = torch.cat([o.reshape(-1, num_classes + 5) for o in output_t])
+    kl = nn.KLDivLoss(reduction='sum')(F.log_softmax(s / T, dim=1), F.softmax(t / T, dim=1))
+    return kl * (T * T) / batch_size * weight
+
+
 # -------------------------------------------------------------------------------------------------- NMS
 def nms_greedy(boxes, scores, iou_thres):
     """Host restatement of torchvision.ops.boxes.nms (see module docstring). Returns LongTensor."""
