@@ -307,7 +307,11 @@ typedef struct yh_bn_desc {
     int32_t n, h, w_in;     /* geometry of z (needed for ups)                                                  */
     int32_t c, ldz, lddy, ldr, ldo, act, ups, dtype;
     float slope, eps, momentum;
+    float* ws;              /* optional workspace for the two reductions (yh_bn_stats, yh_bn_act_bwd_reduce): per-workgroup */
+    int64_t ws_floats;      /* partial sums are stored there and summed by a second launch instead of contended atomics; */
+                            /* size from yh_bn_reduce_workspace().  NULL / too small -> fp32 atomics.                     */
 } yh_bn_desc;
+int64_t yh_bn_reduce_workspace(const yh_bn_desc* d);
 int yh_bn_stats(const yh_bn_desc* d, void* stream);
 int yh_bn_finalize(const yh_bn_desc* d, void* stream);
 int yh_bn_act_fwd(const yh_bn_desc* d, void* stream);
@@ -335,7 +339,10 @@ typedef struct yh_wgrad_desc {
     float* dw;              /* [cout][cin][kh][kw] fp32, accumulated                                            */
     int32_t n, h, w_in, cin, ho, wo, cout, kh, kw, stride, pad, ldx, lddz, dtype;
     int32_t splits;         /* pixel-range splits (0 = library heuristic)                                       */
+    float* ws;              /* optional workspace: per-split partial tiles, summed by a second launch instead of atomics; */
+    int64_t ws_floats;      /* size from yh_conv2d_wgrad_workspace().  NULL / too small -> fp32 atomics.                  */
 } yh_wgrad_desc;
+int64_t yh_conv2d_wgrad_workspace(const yh_wgrad_desc* d);
 int yh_conv2d_wgrad(const yh_wgrad_desc* d, void* stream);
 int yh_stem_wgrad(const yh_wgrad_desc* d, void* stream);
 typedef struct yh_resample_desc {

@@ -416,6 +416,12 @@ class FakeLib:
         pitched(d.out, d.pixels, d.c, d.ldo, npdt)[:] = g.numpy().astype(npdt)
         return 0
 
+    def yh_conv2d_wgrad_workspace(self, dref):
+        return 0
+
+    def yh_bn_reduce_workspace(self, dref):
+        return 0
+
     def yh_conv_pack_weights_dgrad(self, dtype, w, cout, cin, kh, kw, cout_k, m_pad, packed, stream):
         npdt = _NP[dtype]
         wt = torch.from_numpy(flat(w, cout * cin * kh * kw, np.float32).copy()).view(cout, cin, kh, kw)

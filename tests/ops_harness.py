@@ -227,6 +227,15 @@ def qadd(lib, x, a, rx, ra, scale_x, scale_a, scale_sum):
 from engine.hiplib import BnDesc, WgradDesc, ResampleDesc, CastDesc  # noqa: E402
 
 
+def with_bn_workspace(lib, d):
+    """Attach the two-stage reduction workspace the library asks for (kept alive on the descriptor object)."""
+    need = int(lib.yh_bn_reduce_workspace(C.byref(d)))
+    if need:
+        d._ws_keep = torch.full((need,), float('nan'), device='cuda', dtype=torch.float32)
+        d.ws, d.ws_floats = P(d._ws_keep), need
+    return d
+
+
 def bn_desc(code, z, c, ldz_off=0, dy=None, res=None, out=None, gamma=None, beta=None, mean=None, invstd=None, s1=None,
             s2=None, rmean=None, rvar=None, act=1, slope=0.1, ups=1, eps=1e-5, momentum=0.1, out_off=0):
     """z, dy, res, out: (N,H,W,ld) NHWC buffers (channels [off, off+c) are used)."""
@@ -244,13 +253,17 @@ def call(lib, name, desc):
     assert rc == 0, '%s rc=%d' % (name, rc)
 
 
-def wgrad(lib, code, x, dz, cin, cout, k, stride, pad, x_off=0, dz_off=0, splits=0):
+def wgrad(lib, code, x, dz, cin, cout, k, stride, pad, x_off=0, dz_off=0, splits=0, use_ws=True):
     """x (N,H,W,ldx), dz (N,Ho,Wo,lddz) -> dw (cout,cin,k,k) fp32 accumulated from zero."""
     N, H, W, ldx = x.shape
     _, Ho, Wo, lddz = dz.shape
     dw = torch.zeros((cout, cin, k, k), device=x.device, dtype=torch.float32)
     d = WgradDesc(x=P(x, x_off), dz=P(dz, dz_off), dw=P(dw), n=N, h=H, w_in=W, cin=cin, ho=Ho, wo=Wo, cout=cout, kh=k, kw=k,
                   stride=stride, pad=pad, ldx=ldx, lddz=lddz, dtype=code, splits=splits)
+    need = int(lib.yh_conv2d_wgrad_workspace(C.byref(d))) if use_ws else 0
+    if need:   # two-stage reduction (per-split partial tiles + summing launch); without it: fp32 atomics
+        ws = torch.full((need,), float('nan'), device=x.device, dtype=torch.float32)
+        d.ws, d.ws_floats = P(ws), need
     call(lib, 'yh_conv2d_wgrad', d)
     return dw
 

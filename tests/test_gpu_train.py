@@ -41,11 +41,12 @@ def _sync():
         torch.cuda.synchronize()
 
 
+@pytest.mark.parametrize('two_stage', [False, True], ids=['atomics', 'workspace'])
 @pytest.mark.parametrize('code', [F32, F16], ids=['fp32', 'fp16'])
 @pytest.mark.parametrize('case', [(3, 17, 19, 64, 1, 1, False, True), (2, 8, 8, 256, 5, 2, False, True),
                                   (2, 12, 12, 32, 1, 1, True, True), (2, 9, 9, 24, 4, 1, False, False)],
                          ids=['leaky', 'mish_ups', 'leaky_res', 'hswish_nobn'])
-def test_bn_train_kernels(libs, code, case):
+def test_bn_train_kernels(libs, code, case, two_stage):
     """stats -> finalize -> act forward -> backward reduce -> backward apply, vs emulation and vs torch autograd."""
     lib, fake = libs
     N, H, W, c, act, ups, use_res, use_bn = case
@@ -63,8 +64,9 @@ def test_bn_train_kernels(libs, code, case):
         mean, invstd, s1, s2, rm, rv = f32(), f32(), f32(), f32(), f32(), f32() + 1
         y = torch.full((N, H * ups, W * ups, c + 16), 3.0, device=dev, dtype=dt)
         kw = dict(gamma=gamma, beta=beta, mean=mean, invstd=invstd, act=act)
+        WS = (lambda d: oh.with_bn_workspace(L, d)) if (two_stage and L is lib and not DRY) else (lambda d: d)
         if use_bn:
-            oh.call(L, 'yh_bn_stats', oh.bn_desc(code, z, c, 8, s1=s1, s2=s2, **kw))
+            oh.call(L, 'yh_bn_stats', WS(oh.bn_desc(code, z, c, 8, s1=s1, s2=s2, **kw)))
             oh.call(L, 'yh_bn_finalize', oh.bn_desc(code, z, c, 8, s1=s1, s2=s2, rmean=rm, rvar=rv, **kw))
         oh.call(L, 'yh_bn_act_fwd', oh.bn_desc(code, z, c, 8, res=res, out=y, out_off=16, ups=ups, **kw))
         # backward at the un-upsampled resolution (the engine reduces the fused upsample first)
@@ -72,7 +74,7 @@ def test_bn_train_kernels(libs, code, case):
         dbeta, dgamma = f32(), f32()
         dz = torch.full((N, H, W, c), 3.0, device=dev, dtype=dt)
         dyv = dy[..., 16:].contiguous()
-        oh.call(L, 'yh_bn_act_bwd_reduce', oh.bn_desc(code, z, c, 8, dy=dyv, s1=dbeta, s2=dgamma, **kw))
+        oh.call(L, 'yh_bn_act_bwd_reduce', WS(oh.bn_desc(code, z, c, 8, dy=dyv, s1=dbeta, s2=dgamma, **kw)))
         oh.call(L, 'yh_bn_act_bwd_apply', oh.bn_desc(code, z, c, 8, dy=dyv, out=dz, s1=dbeta, s2=dgamma, **kw))
         _sync()
         outs.append([t.float().cpu() for t in (mean, invstd, rm, rv, y, dbeta, dgamma, dz)])
@@ -109,12 +111,16 @@ WGRAD_CASES = [
     (2, 12, 12, 96, 72, 3, 1, 32, 16),      # pitched slices, partial tiles both ways
     (4, 64, 64, 16, 32, 3, 1, 0, 0),        # long pixel axis -> many splits
     (2, 26, 26, 256, 512, 3, 2, 0, 0),
+    (2, 18, 18, 24, 40, 3, 1, 0, 0),        # 64-row tile, 216 flattened (tap, ci) columns
+    (2, 16, 16, 64, 32, 1, 1, 0, 0),
+    (1, 38, 38, 32, 64, 3, 2, 8, 8),
 ]
 
 
+@pytest.mark.parametrize('use_ws', [True, False], ids=['workspace', 'atomics'])
 @pytest.mark.parametrize('code', [F32, F16], ids=['fp32', 'fp16'])
 @pytest.mark.parametrize('case', WGRAD_CASES, ids=lambda c: 'n%d_%dx%d_c%d-%d_k%ds%d_x%d_z%d' % c)
-def test_wgrad_matches_autograd(libs, code, case):
+def test_wgrad_matches_autograd(libs, code, case, use_ws):
     lib, fake = libs
     N, H, W, cin, cout, k, s, xe, ze = case
     g = torch.Generator().manual_seed(hash(case) % (2 ** 31))
@@ -125,7 +131,7 @@ def test_wgrad_matches_autograd(libs, code, case):
     x = torch.randn(N, H, W, cin + xe, generator=g).to(dt)
     dz = torch.randn(N, Ho, Wo, cout_phys + ze, generator=g).to(dt)
     dz[..., ze + cout:] = 0
-    got = oh.wgrad(lib, code, x.to(GPU), dz.to(GPU), cin, cout, k, s, pad, x_off=xe, dz_off=ze)
+    got = oh.wgrad(lib, code, x.to(GPU), dz.to(GPU), cin, cout, k, s, pad, x_off=xe, dz_off=ze, use_ws=use_ws)
     _sync()
     emu = oh.wgrad(fake, code, x.clone(), dz.clone(), cin, cout, k, s, pad, x_off=xe, dz_off=ze)
     xr = x[..., xe:].float().permute(0, 3, 1, 2)

@@ -9,6 +9,7 @@
 // every 4-bank group once for i = 0..15).  One workgroup owns a 128 (co) x 128 (ci) tile of ONE tap and a contiguous
 // range of pixels; partial sums are added to dw with fp32 atomics (a few thousand per workgroup).
 #include "common.h"
+#include <stdlib.h>
 
 namespace yh {
 
@@ -27,24 +28,24 @@ constexpr int WG_PITCH_DW = 20;  // LDS row pitch in dwords (80 B)
 
 struct WgradArgs {
     yh_wgrad_desc d;
-    int tiles_m, tiles_n, ksteps, ksteps_per_split;
+    int tiles_m, tiles_n, ksteps, ksteps_per_split, ncols;  // ncols = kh*kw*cin: the flattened (tap, ci) axis
+    int two_stage;
     long pixels;
 };
 
-template <typename T>
+// TM = 16-row MFMA tiles per wave along co: TM 4 -> 128 x 128 tile, TM 2 -> 64 x 128 (layers with <= 64 outputs).
+// The N axis of the GEMM is the flattened (tap, ci) index, so a 3x3 layer with 32 inputs fills 128-wide tiles with
+// 4 taps each instead of running 9 quarter-empty tiles, and dz is read once per 128 columns, not once per tap.
+template <typename T, int TM>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
     typedef typename WG<T>::vec V;
-    constexpr int VEC = WG<T>::VEC, BK = WG<T>::BK, PP = BK / 2;
+    constexpr int VEC = WG<T>::VEC, BK = WG<T>::BK, PP = BK / 2, BM = TM * 32;
     const yh_wgrad_desc& d = a.d;
-    __shared__ uint32_t lds_a[WG_TILE * WG_PITCH_DW];
+    __shared__ uint32_t lds_a[BM * WG_PITCH_DW];
     __shared__ uint32_t lds_b[WG_TILE * WG_PITCH_DW];
 
-    int bid = blockIdx.x;
-    const int tm = bid % a.tiles_m; bid /= a.tiles_m;
-    const int tn = bid % a.tiles_n; bid /= a.tiles_n;
-    const int tap = bid;
-    const int tr = tap / d.kw, ts = tap % d.kw;
-    const int co0 = tm * WG_TILE, ci0 = tn * WG_TILE;
+    const int tm = blockIdx.x % a.tiles_m, tn = blockIdx.x / a.tiles_m;
+    const int co0 = tm * BM, n0 = tn * WG_TILE;
     const int ks0 = blockIdx.y * a.ksteps_per_split;
     const int ks1 = min(ks0 + a.ksteps_per_split, a.ksteps);
     if (ks0 >= ks1) return;
@@ -52,17 +53,33 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int cg = tid / PP, pp = tid % PP;       // loader role: channel group, pixel pair
-    const int ca = co0 + cg * VEC, cb = ci0 + cg * VEC;
-    const bool a_ok = ca < d.cout, b_ok = cb < d.cin;  // cout / cin here are the PHYSICAL channel counts of dz / x
+    const int ca = co0 + cg * VEC;
+    const bool a_ok = cg * VEC < BM && ca < d.cout;   // cout / cin are the PHYSICAL channel counts of dz / x
+    const int nb = n0 + cg * VEC;                     // this thread's column group: (tap, ci..ci+VEC)
+    const bool b_ok = nb < a.ncols;
+    const int tap_b = b_ok ? nb / d.cin : 0;
+    const int cb = nb - tap_b * d.cin;
+    const int tr = tap_b / d.kw - d.pad, ts = tap_b % d.kw - d.pad;
     const T* dz = reinterpret_cast<const T*>(d.dz);
     const T* x = reinterpret_cast<const T*>(d.x);
-    const int hw_o = d.ho * d.wo;
 
-    f32x4 acc[4][4];
+    f32x4 acc[TM][4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // (n, ho, wo) of this thread's two pixels, advanced by BK pixels per K step without divisions
+    int pn[2], ph[2], pw[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const long p = (long)ks0 * BK + 2 * pp + u;
+        const int hw_o = d.ho * d.wo;
+        pn[u] = (int)(p / hw_o);
+        const int rem = (int)(p - (long)pn[u] * hw_o);
+        ph[u] = rem / d.wo;
+        pw[u] = rem - ph[u] * d.wo;
+    }
 
     V ra[2], rb[2];
     auto fetch = [&](int ks) {
@@ -74,15 +91,15 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
             for (int e = 0; e < VEC; ++e) { va[e] = (T)0; vb[e] = (T)0; }
             if (p < a.pixels) {
                 if (a_ok) va = *reinterpret_cast<const V*>(dz + p * d.lddz + ca);
-                const int n = (int)(p / hw_o);
-                const int rem = (int)(p - (long)n * hw_o);
-                const int ho = rem / d.wo, wo = rem - ho * d.wo;
-                const int hi = ho * d.stride + tr - d.pad, wi = wo * d.stride + ts - d.pad;
+                const int hi = ph[u] * d.stride + tr, wi = pw[u] * d.stride + ts;
                 if (b_ok && (unsigned)hi < (unsigned)d.h && (unsigned)wi < (unsigned)d.w_in)
-                    vb = *reinterpret_cast<const V*>(x + (((long)n * d.h + hi) * d.w_in + wi) * d.ldx + cb);
+                    vb = *reinterpret_cast<const V*>(x + (((long)pn[u] * d.h + hi) * d.w_in + wi) * d.ldx + cb);
             }
             ra[u] = va;
             rb[u] = vb;
+            pw[u] += BK;
+            while (pw[u] >= d.wo) { pw[u] -= d.wo; ++ph[u]; }
+            while (ph[u] >= d.ho) { ph[u] -= d.ho; ++pn[u]; }
         }
     };
     auto stash = [&]() {
@@ -91,7 +108,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
             for (int e = 0; e < VEC; ++e) {
                 const f16x2 wa = {ra[0][e], ra[1][e]};
                 const f16x2 wb = {rb[0][e], rb[1][e]};
-                lds_a[(cg * VEC + e) * WG_PITCH_DW + pp] = __builtin_bit_cast(uint32_t, wa);
+                if (cg * VEC < BM) lds_a[(cg * VEC + e) * WG_PITCH_DW + pp] = __builtin_bit_cast(uint32_t, wa);
                 lds_b[(cg * VEC + e) * WG_PITCH_DW + pp] = __builtin_bit_cast(uint32_t, wb);
             }
         } else {
@@ -100,8 +117,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
             const u32x4_t b0 = __builtin_bit_cast(u32x4_t, rb[0]), b1 = __builtin_bit_cast(u32x4_t, rb[1]);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                lds_a[(cg * 4 + e) * WG_PITCH_DW + 2 * pp] = a0[e];
-                lds_a[(cg * 4 + e) * WG_PITCH_DW + 2 * pp + 1] = a1[e];
+                if (cg * 4 < BM) {
+                    lds_a[(cg * 4 + e) * WG_PITCH_DW + 2 * pp] = a0[e];
+                    lds_a[(cg * 4 + e) * WG_PITCH_DW + 2 * pp + 1] = a1[e];
+                }
                 lds_b[(cg * 4 + e) * WG_PITCH_DW + 2 * pp] = b0[e];
                 lds_b[(cg * 4 + e) * WG_PITCH_DW + 2 * pp + 1] = b1[e];
             }
@@ -116,28 +135,30 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
         if (ks + 1 < ks1) fetch(ks + 1);  // global loads fly under the MFMAs
         const int ri = lane & 15, kq = lane >> 4;
         if constexpr (sizeof(T) == 2) {
-            f16x8 fa[4], fb[4];
+            f16x8 fa[TM], fb[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                fa[i] = *reinterpret_cast<const f16x8*>(&lds_a[(wm * 64 + i * 16 + ri) * WG_PITCH_DW + kq * 4]);
-                fb[i] = *reinterpret_cast<const f16x8*>(&lds_b[(wn * 64 + i * 16 + ri) * WG_PITCH_DW + kq * 4]);
-            }
+            for (int i = 0; i < TM; ++i)
+                fa[i] = *reinterpret_cast<const f16x8*>(&lds_a[(wm * TM * 16 + i * 16 + ri) * WG_PITCH_DW + kq * 4]);
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int j = 0; j < 4; ++j)
+                fb[j] = *reinterpret_cast<const f16x8*>(&lds_b[(wn * 64 + j * 16 + ri) * WG_PITCH_DW + kq * 4]);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[i], fb[j], acc[i][j], 0, 0, 0);
         } else {
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
-                float fa[4], fb[4];
+                float fa[TM], fb[4];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    fa[i] = __builtin_bit_cast(float, lds_a[(wm * 64 + i * 16 + ri) * WG_PITCH_DW + kk * 4 + kq]);
-                    fb[i] = __builtin_bit_cast(float, lds_b[(wn * 64 + i * 16 + ri) * WG_PITCH_DW + kk * 4 + kq]);
-                }
+                for (int i = 0; i < TM; ++i)
+                    fa[i] = __builtin_bit_cast(float, lds_a[(wm * TM * 16 + i * 16 + ri) * WG_PITCH_DW + kk * 4 + kq]);
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
+                for (int j = 0; j < 4; ++j)
+                    fb[j] = __builtin_bit_cast(float, lds_b[(wn * 64 + j * 16 + ri) * WG_PITCH_DW + kk * 4 + kq]);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
@@ -145,19 +166,55 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
         }
     }
 
-    // D layout: column (lane & 15) = ci, row 4*(lane>>4)+reg = co
+    if (a.two_stage) {
+        // partial tile in MFMA-native order, 16 bytes per lane, fully coalesced; wgrad_reduce_kernel sums the splits
+        f32x4* part = reinterpret_cast<f32x4*>(d.ws) + ((long)blockIdx.y * gridDim.x + blockIdx.x) * (TM * 4 * 256);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) part[(i * 4 + j) * 256 + tid] = acc[i][j];
+        return;
+    }
+    // D layout: column (lane & 15) = flattened (tap, ci), row 4*(lane>>4)+reg = co
     const int taps = d.kh * d.kw;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 4; ++j) {
+        const int n = n0 + wn * 64 + j * 16 + (lane & 15);
+        if (n >= a.ncols) continue;
+        const int tap = n / d.cin, ci = n - tap * d.cin;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int ci = ci0 + wn * 64 + j * 16 + (lane & 15);
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int co = co0 + wm * 64 + i * 16 + 4 * (lane >> 4) + r;
-                if (co < d.cout && ci < d.cin) atomicAdd(d.dw + ((long)co * d.cin + ci) * taps + tap, acc[i][j][r]);
+                const int co = co0 + wm * TM * 16 + i * 16 + 4 * (lane >> 4) + r;
+                if (co < d.cout) atomicAdd(d.dw + ((long)co * d.cin + ci) * taps + tap, acc[i][j][r]);
             }
-        }
+    }
+}
+
+// Second stage: one thread per (tile, i, j, lane slot): sum the splits, add into dw[co][ci][tap].
+template <int TM>
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradArgs a, int splits) {
+    const yh_wgrad_desc& d = a.d;
+    const int tiles = a.tiles_m * a.tiles_n;
+    const int tile = blockIdx.x / (TM * 4), ij = blockIdx.x % (TM * 4);
+    const int i = ij / 4, j = ij % 4;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const f32x4* part = reinterpret_cast<const f32x4*>(d.ws) + ((long)tile * (TM * 4) + ij) * 256 + tid;
+    const long stride = (long)tiles * (TM * 4) * 256;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < splits; ++s) v += part[s * stride];
+    const int tm = tile % a.tiles_m, tn = tile / a.tiles_m;
+    const int n = tn * WG_TILE + wn * 64 + j * 16 + (lane & 15);
+    if (n >= a.ncols) return;
+    const int taps = d.kh * d.kw;
+    const int tap = n / d.cin, ci = n - tap * d.cin;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int co = tm * (TM * 32) + wm * TM * 16 + i * 16 + 4 * (lane >> 4) + r;
+        if (co < d.cout) d.dw[((long)co * d.cin + ci) * taps + tap] += v[r];
+    }
 }
 
 // First layer: x is the fp32 NCHW image with 3 channels, 3x3 taps.  Thread = (co, pixel lane); 27 accumulators.
@@ -297,18 +354,18 @@ extern "C" int yh_conv_pack_weights_dgrad(int dtype, const float* w, int cout, i
     return check_launch();
 }
 
-extern "C" int yh_conv2d_wgrad(const yh_wgrad_desc* d, void* stream) {
-    if (!d || !d->x || !d->dz || !d->dw || d->n <= 0 || d->cin <= 0 || d->cout <= 0) return YH_EINVAL;
-    if (d->dtype != YH_F16 && d->dtype != YH_F32) return YH_EINVAL;
-    const int vec = d->dtype == YH_F16 ? 8 : 4, bk = d->dtype == YH_F16 ? 32 : 16;
-    if (d->ldx % vec || d->lddz % vec || !aligned16(d->x) || !aligned16(d->dz)) return YH_EALIGN;
-    WgradArgs a;
+static void wgrad_geometry(const yh_wgrad_desc* d, WgradArgs* pa, int* psplits) {
+    WgradArgs& a = *pa;
+    const int bk = d->dtype == YH_F16 ? 32 : 16;
     a.d = *d;
     a.pixels = (long)d->n * d->ho * d->wo;
-    a.tiles_m = (d->cout + WG_TILE - 1) / WG_TILE;
-    a.tiles_n = (d->cin + WG_TILE - 1) / WG_TILE;
+    const int bm = d->cout <= 64 ? 64 : WG_TILE;        // 64-row tiles for the early, wide-resolution layers
+    a.ncols = d->kh * d->kw * d->cin;
+    a.tiles_m = (d->cout + bm - 1) / bm;
+    a.tiles_n = (a.ncols + WG_TILE - 1) / WG_TILE;
     a.ksteps = (int)((a.pixels + bk - 1) / bk);
-    const int tiles = a.tiles_m * a.tiles_n * d->kh * d->kw;
+    a.two_stage = 0;
+    const int tiles = a.tiles_m * a.tiles_n;
     int splits = d->splits;
     if (splits <= 0) {
         splits = (2048 + tiles - 1) / tiles;               // ~8 workgroups per CU
@@ -317,11 +374,43 @@ extern "C" int yh_conv2d_wgrad(const yh_wgrad_desc* d, void* stream) {
         if (splits < 1) splits = 1;
     }
     a.ksteps_per_split = (a.ksteps + splits - 1) / splits;
-    splits = (a.ksteps + a.ksteps_per_split - 1) / a.ksteps_per_split;
+    *psplits = (a.ksteps + a.ksteps_per_split - 1) / a.ksteps_per_split;
+}
+
+extern "C" int yh_conv2d_wgrad(const yh_wgrad_desc* d, void* stream) {
+    if (!d || !d->x || !d->dz || !d->dw || d->n <= 0 || d->cin <= 0 || d->cout <= 0) return YH_EINVAL;
+    if (d->dtype != YH_F16 && d->dtype != YH_F32) return YH_EINVAL;
+    const int vec = d->dtype == YH_F16 ? 8 : 4;
+    if (d->ldx % vec || d->lddz % vec || !aligned16(d->x) || !aligned16(d->dz)) return YH_EALIGN;
+    if (d->cin % vec) return YH_EALIGN;
+    WgradArgs a;
+    int splits;
+    wgrad_geometry(d, &a, &splits);
+    const int tiles = a.tiles_m * a.tiles_n;
+    const bool narrow = d->cout <= 64;
+    a.two_stage = d->ws && d->ws_floats >= (int64_t)splits * tiles * (narrow ? 64 : 128) * 128;
     const dim3 grid(tiles, splits);
-    if (d->dtype == YH_F16) hipLaunchKernelGGL(conv_wgrad_kernel<f16>, grid, dim3(256), 0, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL(conv_wgrad_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, a);
+    hipStream_t st = (hipStream_t)stream;
+    if (d->dtype == YH_F16) {
+        if (narrow) hipLaunchKernelGGL((conv_wgrad_kernel<f16, 2>), grid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((conv_wgrad_kernel<f16, 4>), grid, dim3(256), 0, st, a);
+    } else {
+        if (narrow) hipLaunchKernelGGL((conv_wgrad_kernel<float, 2>), grid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((conv_wgrad_kernel<float, 4>), grid, dim3(256), 0, st, a);
+    }
+    if (a.two_stage) {
+        if (narrow) hipLaunchKernelGGL(wgrad_reduce_kernel<2>, dim3(tiles * 8), dim3(256), 0, st, a, splits);
+        else hipLaunchKernelGGL(wgrad_reduce_kernel<4>, dim3(tiles * 16), dim3(256), 0, st, a, splits);
+    }
     return check_launch();
+}
+
+extern "C" int64_t yh_conv2d_wgrad_workspace(const yh_wgrad_desc* d) {
+    if (!d || d->n <= 0 || d->cin <= 0 || d->cout <= 0 || (d->dtype != YH_F16 && d->dtype != YH_F32)) return 0;
+    WgradArgs a;
+    int splits;
+    wgrad_geometry(d, &a, &splits);
+    return (int64_t)splits * a.tiles_m * a.tiles_n * (d->cout <= 64 ? 64 : 128) * 128;
 }
 
 extern "C" int yh_stem_wgrad(const yh_wgrad_desc* d, void* stream) {

@@ -27,53 +27,90 @@ __device__ __forceinline__ float act_grad(float u, int act, float slope) {
     }
 }
 
-// Block-level per-channel reduction of NV partial sums per thread for the channel group this block owns.
-// Layout: grid.x = channel groups, grid.y = pixel chunks; threads stride over the chunk's pixels.
-template <typename T, int NQ>
-__device__ __forceinline__ void block_reduce_atomic(float (&acc)[NQ][TV<T>::N], float* const (&dst)[NQ], int cbase) {
-    constexpr int VN = TV<T>::N;
-    __shared__ float red[NQ * VN * 4];  // one slot per wave
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+// Thread mapping shared by all five kernels: a workgroup covers `cgb` channel groups (16 bytes each) x `rows` pixels
+// per pass, consecutive lanes on consecutive channel groups of the same pixel, so a wave reads whole contiguous rows
+// (1 KB per instruction when the tensor is dense).  Each thread keeps ONE channel group for its whole pixel range:
+// the per-channel parameters live in registers, loaded once.
+struct BnGeom {
+    int cgs;      // channel groups in the tensor (c / VN)
+    int cgb;      // channel groups per workgroup (<= 256)
+    int rows;     // pixels per pass = 256 / cgb
+    int ppb;      // pixels per workgroup
+    int two_stage;  // reductions: partial sums to the workspace + a summing launch (no atomics)
+};
+
+template <int VN>
+__device__ __forceinline__ void load8(const float* p, int c0, float (&dst)[VN], float fill) {
+#pragma unroll
+    for (int e = 0; e < VN; ++e) dst[e] = p ? p[c0 + e] : fill;
+}
+
+// Sum acc[NQ][VN] over the `rows` threads that share a channel group, then one atomic per channel per workgroup.
+template <int NQ, int VN>
+__device__ __forceinline__ void rows_reduce_atomic(float (&acc)[NQ][VN], float* const (&dst)[NQ], const BnGeom& gm, int cgl,
+                                                   int prow, int c0, bool active, float* part, int c_total) {
+    __shared__ float red[256 * NQ * VN];
 #pragma unroll
     for (int q = 0; q < NQ; ++q)
 #pragma unroll
-        for (int e = 0; e < VN; ++e) {
-            float v = acc[q][e];
-            for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d);
-            if (lane == 0) red[(q * VN + e) * 4 + wave] = v;
-        }
+        for (int e = 0; e < VN; ++e) red[(q * VN + e) * 256 + threadIdx.x] = active ? acc[q][e] : 0.f;
     __syncthreads();
-    if (threadIdx.x < NQ * VN) {
-        const int q = threadIdx.x / VN, e = threadIdx.x % VN;
-        const float v = red[threadIdx.x * 4] + red[threadIdx.x * 4 + 1] + red[threadIdx.x * 4 + 2] + red[threadIdx.x * 4 + 3];
-        atomicAdd(dst[q] + cbase + e, v);
-    }
+    // the `rows` threads of one channel group share the NQ*VN columns; each sums its columns over the rows
+    if (active)
+        for (int it = prow; it < NQ * VN; it += gm.rows) {
+            float v = 0.f;
+            for (int r = 0; r < gm.rows; ++r) v += red[it * 256 + r * gm.cgb + cgl];
+            if (part) part[((long)blockIdx.y * NQ + it / VN) * c_total + c0 + it % VN] = v;  // summed by bn_partials_kernel
+            else atomicAdd(dst[it / VN] + c0 + it % VN, v);
+        }
 }
 
-constexpr int PIX_PER_BLOCK = 4096;
-
 template <typename T>
-__global__ __launch_bounds__(256) void bn_stats_kernel(const yh_bn_desc d) {
+__global__ __launch_bounds__(256) void bn_stats_kernel(const yh_bn_desc d, const BnGeom gm) {
     typedef typename TV<T>::type V;
     constexpr int VN = TV<T>::N;
-    const int g = blockIdx.x;
-    const long p0 = (long)blockIdx.y * PIX_PER_BLOCK;
-    const long p1 = min(p0 + PIX_PER_BLOCK, (long)d.pixels);
+    const int cgl = threadIdx.x % gm.cgb, prow = threadIdx.x / gm.cgb;
+    const int g = blockIdx.x * gm.cgb + cgl;
+    const bool lane_ok = prow < gm.rows && g < gm.cgs;
+    const long p0 = (long)blockIdx.y * gm.ppb;
+    const long p1 = min(p0 + gm.ppb, (long)d.pixels);
     const T* z = reinterpret_cast<const T*>(d.z) + g * VN;
     float acc[2][VN];
 #pragma unroll
     for (int e = 0; e < VN; ++e) acc[0][e] = acc[1][e] = 0.f;
-    for (long p = p0 + threadIdx.x; p < p1; p += 256) {
-        const V v = *reinterpret_cast<const V*>(z + p * d.ldz);
+    if (lane_ok)
+        for (long p = p0 + prow; p < p1; p += gm.rows) {
+            const V v = *reinterpret_cast<const V*>(z + p * d.ldz);
 #pragma unroll
-        for (int e = 0; e < VN; ++e) {
-            const float f = (float)v[e];
-            acc[0][e] += f;
-            acc[1][e] = fmaf(f, f, acc[1][e]);
+            for (int e = 0; e < VN; ++e) {
+                const float f = (float)v[e];
+                acc[0][e] += f;
+                acc[1][e] = fmaf(f, f, acc[1][e]);
+            }
         }
-    }
     float* const dst[2] = {d.sum, d.sumsq};
-    block_reduce_atomic<T, 2>(acc, dst, g * VN);
+    rows_reduce_atomic<2, VN>(acc, dst, gm, cgl, prow, g * VN, lane_ok, gm.two_stage ? d.ws : nullptr, d.c);
+}
+
+// second stage of the reductions: sum[c] += sum over workgroups of part[wg][0][c], sumsq likewise.
+// 16 columns x 16 partial-lanes per workgroup: a wave reads 64-byte row pieces of 4 partial rows at a time.
+__global__ __launch_bounds__(256) void bn_partials_kernel(const float* part, int nparts, int c, float* s0, float* s1) {
+    __shared__ float red[256];
+    const int col = blockIdx.x * 16 + (threadIdx.x & 15), lane = threadIdx.x >> 4;
+    float v = 0.f;
+    if (col < 2 * c)
+        for (int k = lane; k < nparts; k += 16) {
+            const int q = col / c, ch = col - q * c;
+            v += part[((long)k * 2 + q) * c + ch];
+        }
+    red[threadIdx.x] = v;
+    __syncthreads();
+    if (threadIdx.x < 16 && col < 2 * c) {
+        float t = 0.f;
+        for (int r = 0; r < 16; ++r) t += red[r * 16 + threadIdx.x];
+        const int q = col / c, ch = col - q * c;
+        (q ? s1 : s0)[ch] += t;
+    }
 }
 
 __global__ void bn_finalize_kernel(const yh_bn_desc d) {
@@ -92,29 +129,30 @@ __global__ void bn_finalize_kernel(const yh_bn_desc d) {
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void bn_act_fwd_kernel(const yh_bn_desc d) {
+__global__ __launch_bounds__(256) void bn_act_fwd_kernel(const yh_bn_desc d, const BnGeom gm) {
     typedef typename TV<T>::type V;
     constexpr int VN = TV<T>::N;
-    const int cg = d.c / VN;
-    const long total = d.pixels * cg;
-    const T* z = reinterpret_cast<const T*>(d.z);
-    const T* res = reinterpret_cast<const T*>(d.res);
-    T* y = reinterpret_cast<T*>(d.out);
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int g = (int)(i % cg);
-        const long pix = i / cg;
-        const V v = *reinterpret_cast<const V*>(z + pix * d.ldz + g * VN);
+    const int cgl = threadIdx.x % gm.cgb, prow = threadIdx.x / gm.cgb;
+    const int g = blockIdx.x * gm.cgb + cgl;
+    if (prow >= gm.rows || g >= gm.cgs) return;
+    const long p0 = (long)blockIdx.y * gm.ppb;
+    const long p1 = min(p0 + gm.ppb, (long)d.pixels);
+    const int c0 = g * VN;
+    const T* z = reinterpret_cast<const T*>(d.z) + c0;
+    const T* res = d.res ? reinterpret_cast<const T*>(d.res) + c0 : nullptr;
+    T* y = reinterpret_cast<T*>(d.out) + c0;
+    float ga[VN], be[VN], mu[VN], is[VN];
+    load8<VN>(d.gamma, c0, ga, 1.f);
+    load8<VN>(d.beta, c0, be, 0.f);
+    load8<VN>(d.gamma ? d.mean : nullptr, c0, mu, 0.f);
+    load8<VN>(d.gamma ? d.invstd : nullptr, c0, is, 1.f);
+    for (long p = p0 + prow; p < p1; p += gm.rows) {
+        const V v = *reinterpret_cast<const V*>(z + p * d.ldz);
         float o[VN];
 #pragma unroll
-        for (int e = 0; e < VN; ++e) {
-            const int c = g * VN + e;
-            float u;
-            if (d.gamma) u = d.gamma[c] * (((float)v[e] - d.mean[c]) * d.invstd[c]) + d.beta[c];
-            else u = (float)v[e] + (d.beta ? d.beta[c] : 0.f);
-            o[e] = activate(u, d.act, d.slope);
-        }
+        for (int e = 0; e < VN; ++e) o[e] = activate(ga[e] * (((float)v[e] - mu[e]) * is[e]) + be[e], d.act, d.slope);
         if (res) {
-            const V r = *reinterpret_cast<const V*>(res + pix * d.ldr + g * VN);
+            const V r = *reinterpret_cast<const V*>(res + p * d.ldr);
 #pragma unroll
             for (int e = 0; e < VN; ++e) o[e] += (float)r[e];
         }
@@ -122,96 +160,119 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const yh_bn_desc d) {
 #pragma unroll
         for (int e = 0; e < VN; ++e) ov[e] = (T)o[e];
         if (d.ups == 2) {
-            const int wi = (int)(pix % d.w_in);
-            const long r = pix / d.w_in;
+            const int wi = (int)(p % d.w_in);
+            const long r = p / d.w_in;
             const int hi = (int)(r % d.h);
             const long n = r / d.h;
             const long wo2 = 2L * d.w_in;
-            T* dst = y + ((n * 2 * d.h + 2L * hi) * wo2 + 2L * wi) * d.ldo + g * VN;
+            T* dst = y + ((n * 2 * d.h + 2L * hi) * wo2 + 2L * wi) * d.ldo;
             *reinterpret_cast<V*>(dst) = ov;
             *reinterpret_cast<V*>(dst + d.ldo) = ov;
             *reinterpret_cast<V*>(dst + wo2 * d.ldo) = ov;
             *reinterpret_cast<V*>(dst + (wo2 + 1) * d.ldo) = ov;
         } else {
-            *reinterpret_cast<V*>(y + pix * d.ldo + g * VN) = ov;
+            *reinterpret_cast<V*>(y + p * d.ldo) = ov;
         }
     }
 }
 
 // g = dy * act'(u); accumulates sum g (-> d.sum) and sum g*xhat (-> d.sumsq)
 template <typename T>
-__global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(const yh_bn_desc d) {
+__global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(const yh_bn_desc d, const BnGeom gm) {
     typedef typename TV<T>::type V;
     constexpr int VN = TV<T>::N;
-    const int g = blockIdx.x;
-    const long p0 = (long)blockIdx.y * PIX_PER_BLOCK;
-    const long p1 = min(p0 + PIX_PER_BLOCK, (long)d.pixels);
-    const T* z = reinterpret_cast<const T*>(d.z) + g * VN;
-    const T* dy = reinterpret_cast<const T*>(d.dy) + g * VN;
+    const int cgl = threadIdx.x % gm.cgb, prow = threadIdx.x / gm.cgb;
+    const int g = blockIdx.x * gm.cgb + cgl;
+    const bool lane_ok = prow < gm.rows && g < gm.cgs;
+    const long p0 = (long)blockIdx.y * gm.ppb;
+    const long p1 = min(p0 + gm.ppb, (long)d.pixels);
+    const int c0 = g * VN;
+    const T* z = reinterpret_cast<const T*>(d.z) + c0;
+    const T* dy = reinterpret_cast<const T*>(d.dy) + c0;
     float ga[VN], be[VN], mu[VN], is[VN];
-#pragma unroll
-    for (int e = 0; e < VN; ++e) {
-        const int c = g * VN + e;
-        ga[e] = d.gamma ? d.gamma[c] : 1.f;
-        be[e] = d.beta ? d.beta[c] : 0.f;
-        mu[e] = d.gamma ? d.mean[c] : 0.f;
-        is[e] = d.gamma ? d.invstd[c] : 1.f;
-    }
     float acc[2][VN];
 #pragma unroll
     for (int e = 0; e < VN; ++e) acc[0][e] = acc[1][e] = 0.f;
-    for (long p = p0 + threadIdx.x; p < p1; p += 256) {
+    if (lane_ok) {
+        load8<VN>(d.gamma, c0, ga, 1.f);
+        load8<VN>(d.beta, c0, be, 0.f);
+        load8<VN>(d.gamma ? d.mean : nullptr, c0, mu, 0.f);
+        load8<VN>(d.gamma ? d.invstd : nullptr, c0, is, 1.f);
+        for (long p = p0 + prow; p < p1; p += gm.rows) {
+            const V zv = *reinterpret_cast<const V*>(z + p * d.ldz);
+            const V gv = *reinterpret_cast<const V*>(dy + p * d.lddy);
+#pragma unroll
+            for (int e = 0; e < VN; ++e) {
+                const float xh = ((float)zv[e] - mu[e]) * is[e];
+                const float u = ga[e] * xh + be[e];
+                const float gg = (float)gv[e] * act_grad(u, d.act, d.slope);
+                acc[0][e] += gg;
+                acc[1][e] = fmaf(gg, xh, acc[1][e]);
+            }
+        }
+    }
+    float* const dst[2] = {d.sum, d.sumsq};
+    rows_reduce_atomic<2, VN>(acc, dst, gm, cgl, prow, c0, lane_ok, gm.two_stage ? d.ws : nullptr, d.c);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const yh_bn_desc d, const BnGeom gm) {
+    typedef typename TV<T>::type V;
+    constexpr int VN = TV<T>::N;
+    const int cgl = threadIdx.x % gm.cgb, prow = threadIdx.x / gm.cgb;
+    const int g = blockIdx.x * gm.cgb + cgl;
+    if (prow >= gm.rows || g >= gm.cgs) return;
+    const long p0 = (long)blockIdx.y * gm.ppb;
+    const long p1 = min(p0 + gm.ppb, (long)d.pixels);
+    const int c0 = g * VN;
+    const T* z = reinterpret_cast<const T*>(d.z) + c0;
+    const T* dy = reinterpret_cast<const T*>(d.dy) + c0;
+    T* dz = reinterpret_cast<T*>(d.out) + c0;
+    const float invP = 1.f / (float)d.pixels;
+    const bool bn = d.gamma != nullptr;
+    float ga[VN], be[VN], mu[VN], is[VN], m1[VN], m2[VN];
+    load8<VN>(d.gamma, c0, ga, 1.f);
+    load8<VN>(d.beta, c0, be, 0.f);
+    load8<VN>(bn ? d.mean : nullptr, c0, mu, 0.f);
+    load8<VN>(bn ? d.invstd : nullptr, c0, is, 1.f);
+    load8<VN>(bn ? d.sum : nullptr, c0, m1, 0.f);
+    load8<VN>(bn ? d.sumsq : nullptr, c0, m2, 0.f);
+#pragma unroll
+    for (int e = 0; e < VN; ++e) { m1[e] *= invP; m2[e] *= invP; }
+    for (long p = p0 + prow; p < p1; p += gm.rows) {
         const V zv = *reinterpret_cast<const V*>(z + p * d.ldz);
         const V gv = *reinterpret_cast<const V*>(dy + p * d.lddy);
+        V ov;
 #pragma unroll
         for (int e = 0; e < VN; ++e) {
             const float xh = ((float)zv[e] - mu[e]) * is[e];
             const float u = ga[e] * xh + be[e];
             const float gg = (float)gv[e] * act_grad(u, d.act, d.slope);
-            acc[0][e] += gg;
-            acc[1][e] = fmaf(gg, xh, acc[1][e]);
+            ov[e] = bn ? (T)(ga[e] * is[e] * (gg - m1[e] - xh * m2[e])) : (T)gg;
         }
-    }
-    float* const dst[2] = {d.sum, d.sumsq};
-    block_reduce_atomic<T, 2>(acc, dst, g * VN);
-}
-
-template <typename T>
-__global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const yh_bn_desc d) {
-    typedef typename TV<T>::type V;
-    constexpr int VN = TV<T>::N;
-    const int cg = d.c / VN;
-    const long total = d.pixels * cg;
-    const T* z = reinterpret_cast<const T*>(d.z);
-    const T* dy = reinterpret_cast<const T*>(d.dy);
-    T* dz = reinterpret_cast<T*>(d.out);
-    const float invP = 1.f / (float)d.pixels;
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int g = (int)(i % cg);
-        const long pix = i / cg;
-        const V zv = *reinterpret_cast<const V*>(z + pix * d.ldz + g * VN);
-        const V gv = *reinterpret_cast<const V*>(dy + pix * d.lddy + g * VN);
-        V ov;
-#pragma unroll
-        for (int e = 0; e < VN; ++e) {
-            const int c = g * VN + e;
-            if (d.gamma) {
-                const float xh = ((float)zv[e] - d.mean[c]) * d.invstd[c];
-                const float u = d.gamma[c] * xh + d.beta[c];
-                const float gg = (float)gv[e] * act_grad(u, d.act, d.slope);
-                ov[e] = (T)(d.gamma[c] * d.invstd[c] * (gg - d.sum[c] * invP - xh * d.sumsq[c] * invP));
-            } else {
-                const float u = (float)zv[e] + (d.beta ? d.beta[c] : 0.f);
-                ov[e] = (T)((float)gv[e] * act_grad(u, d.act, d.slope));
-            }
-        }
-        *reinterpret_cast<V*>(dz + pix * d.ldo + g * VN) = ov;
+        *reinterpret_cast<V*>(dz + p * d.ldo) = ov;
     }
 }
 
-static inline unsigned grid1(long total) {
-    long g = (total + 255) / 256;
-    return (unsigned)(g < 1 ? 1 : (g > 8192 ? 8192 : g));
+static BnGeom bn_geom(const yh_bn_desc* d, int vn, dim3* grid, int target = 4096) {
+    BnGeom gm;
+    gm.cgs = d->c / vn;
+    gm.cgb = gm.cgs < 256 ? gm.cgs : 256;
+    gm.rows = 256 / gm.cgb;
+    const int gx = (gm.cgs + gm.cgb - 1) / gm.cgb;
+    long ppb = (d->pixels * gx + target - 1) / target;  // reductions: ~1024 workgroups, streaming kernels: ~4096
+    const long min_ppb = (long)gm.rows * 8;             // at least 8 passes: amortise the parameter loads / atomics
+    if (ppb < min_ppb) ppb = min_ppb;
+    ppb = (ppb + gm.rows - 1) / gm.rows * gm.rows;
+    gm.ppb = (int)ppb;
+    *grid = dim3(gx, (unsigned)((d->pixels + ppb - 1) / ppb));
+    gm.two_stage = d->ws && d->ws_floats >= (int64_t)grid->y * 2 * d->c;
+    return gm;
+}
+
+static void sum_partials(const yh_bn_desc* d, const dim3& grid, void* stream) {
+    hipLaunchKernelGGL(bn_partials_kernel, dim3((2 * d->c + 15) / 16), dim3(256), 0, (hipStream_t)stream, d->ws, (int)grid.y,
+                       d->c, d->sum, d->sumsq);
 }
 
 static int check_bn(const yh_bn_desc* d, bool need_dy, bool need_out) {
@@ -230,14 +291,24 @@ static int check_bn(const yh_bn_desc* d, bool need_dy, bool need_out) {
 
 using namespace yh;
 
+extern "C" int64_t yh_bn_reduce_workspace(const yh_bn_desc* d) {
+    if (!d || d->c <= 0 || d->pixels <= 0 || (d->dtype != YH_F16 && d->dtype != YH_F32)) return 0;
+    dim3 grid;
+    yh_bn_desc tmp = *d;
+    tmp.ws = nullptr;
+    bn_geom(&tmp, d->dtype == YH_F16 ? 8 : 4, &grid, 1024);
+    return (int64_t)grid.y * 2 * d->c;
+}
+
 extern "C" int yh_bn_stats(const yh_bn_desc* d, void* stream) {
     int rc = check_bn(d, false, false);
     if (rc) return rc;
     if (!d->sum || !d->sumsq) return YH_EINVAL;
-    const int v = d->dtype == YH_F16 ? 8 : 4;
-    const dim3 grid(d->c / v, (unsigned)((d->pixels + PIX_PER_BLOCK - 1) / PIX_PER_BLOCK));
-    if (d->dtype == YH_F16) hipLaunchKernelGGL(bn_stats_kernel<f16>, grid, dim3(256), 0, (hipStream_t)stream, *d);
-    else hipLaunchKernelGGL(bn_stats_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, *d);
+    dim3 grid;
+    const BnGeom gm = bn_geom(d, d->dtype == YH_F16 ? 8 : 4, &grid, 1024);
+    if (d->dtype == YH_F16) hipLaunchKernelGGL(bn_stats_kernel<f16>, grid, dim3(256), 0, (hipStream_t)stream, *d, gm);
+    else hipLaunchKernelGGL(bn_stats_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, *d, gm);
+    if (gm.two_stage) sum_partials(d, grid, stream);
     return check_launch();
 }
 
@@ -252,10 +323,10 @@ extern "C" int yh_bn_act_fwd(const yh_bn_desc* d, void* stream) {
     if (rc) return rc;
     if (d->ups != 1 && d->ups != 2) return YH_EINVAL;
     if (d->ups == 2 && (long)d->n * d->h * d->w_in != d->pixels) return YH_EINVAL;
-    const int v = d->dtype == YH_F16 ? 8 : 4;
-    const long total = d->pixels * (d->c / v);
-    if (d->dtype == YH_F16) hipLaunchKernelGGL(bn_act_fwd_kernel<f16>, dim3(grid1(total)), dim3(256), 0, (hipStream_t)stream, *d);
-    else hipLaunchKernelGGL(bn_act_fwd_kernel<float>, dim3(grid1(total)), dim3(256), 0, (hipStream_t)stream, *d);
+    dim3 grid;
+    const BnGeom gm = bn_geom(d, d->dtype == YH_F16 ? 8 : 4, &grid);
+    if (d->dtype == YH_F16) hipLaunchKernelGGL(bn_act_fwd_kernel<f16>, grid, dim3(256), 0, (hipStream_t)stream, *d, gm);
+    else hipLaunchKernelGGL(bn_act_fwd_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, *d, gm);
     return check_launch();
 }
 
@@ -263,10 +334,11 @@ extern "C" int yh_bn_act_bwd_reduce(const yh_bn_desc* d, void* stream) {
     int rc = check_bn(d, true, false);
     if (rc) return rc;
     if (!d->sum || !d->sumsq) return YH_EINVAL;
-    const int v = d->dtype == YH_F16 ? 8 : 4;
-    const dim3 grid(d->c / v, (unsigned)((d->pixels + PIX_PER_BLOCK - 1) / PIX_PER_BLOCK));
-    if (d->dtype == YH_F16) hipLaunchKernelGGL(bn_act_bwd_reduce_kernel<f16>, grid, dim3(256), 0, (hipStream_t)stream, *d);
-    else hipLaunchKernelGGL(bn_act_bwd_reduce_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, *d);
+    dim3 grid;
+    const BnGeom gm = bn_geom(d, d->dtype == YH_F16 ? 8 : 4, &grid, 1024);
+    if (d->dtype == YH_F16) hipLaunchKernelGGL(bn_act_bwd_reduce_kernel<f16>, grid, dim3(256), 0, (hipStream_t)stream, *d, gm);
+    else hipLaunchKernelGGL(bn_act_bwd_reduce_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, *d, gm);
+    if (gm.two_stage) sum_partials(d, grid, stream);
     return check_launch();
 }
 
@@ -274,9 +346,9 @@ extern "C" int yh_bn_act_bwd_apply(const yh_bn_desc* d, void* stream) {
     int rc = check_bn(d, true, true);
     if (rc) return rc;
     if (d->gamma && (!d->sum || !d->sumsq)) return YH_EINVAL;
-    const int v = d->dtype == YH_F16 ? 8 : 4;
-    const long total = d->pixels * (d->c / v);
-    if (d->dtype == YH_F16) hipLaunchKernelGGL(bn_act_bwd_apply_kernel<f16>, dim3(grid1(total)), dim3(256), 0, (hipStream_t)stream, *d);
-    else hipLaunchKernelGGL(bn_act_bwd_apply_kernel<float>, dim3(grid1(total)), dim3(256), 0, (hipStream_t)stream, *d);
+    dim3 grid;
+    const BnGeom gm = bn_geom(d, d->dtype == YH_F16 ? 8 : 4, &grid);
+    if (d->dtype == YH_F16) hipLaunchKernelGGL(bn_act_bwd_apply_kernel<f16>, grid, dim3(256), 0, (hipStream_t)stream, *d, gm);
+    else hipLaunchKernelGGL(bn_act_bwd_apply_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, *d, gm);
     return check_launch();
 }

@@ -93,7 +93,7 @@ class BnDesc(C.Structure):
                 ('invstd', _vp), ('sum', _vp), ('sumsq', _vp), ('running_mean', _vp), ('running_var', _vp),
                 ('pixels', _i64), ('n', _i32), ('h', _i32), ('w_in', _i32),
                 ('c', _i32), ('ldz', _i32), ('lddy', _i32), ('ldr', _i32), ('ldo', _i32), ('act', _i32), ('ups', _i32),
-                ('dtype', _i32), ('slope', _f32), ('eps', _f32), ('momentum', _f32)]
+                ('dtype', _i32), ('slope', _f32), ('eps', _f32), ('momentum', _f32), ('ws', _vp), ('ws_floats', _i64)]
 
 
 class BnStatsDesc(BnDesc):
@@ -120,7 +120,7 @@ class WgradDesc(C.Structure):
     _fields_ = [('x', _vp), ('dz', _vp), ('dw', _vp),
                 ('n', _i32), ('h', _i32), ('w_in', _i32), ('cin', _i32), ('ho', _i32), ('wo', _i32), ('cout', _i32),
                 ('kh', _i32), ('kw', _i32), ('stride', _i32), ('pad', _i32), ('ldx', _i32), ('lddz', _i32), ('dtype', _i32),
-                ('splits', _i32)]
+                ('splits', _i32), ('ws', _vp), ('ws_floats', _i64)]
 
 
 class StemWgradDesc(WgradDesc):
@@ -186,6 +186,8 @@ _SIGNATURES = {
     'yh_bn_act_bwd_apply': (C.c_int, [C.POINTER(BnDesc), _vp]),
     'yh_conv_pack_weights_dgrad': (C.c_int, [C.c_int, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp]),
     'yh_conv2d_wgrad': (C.c_int, [C.POINTER(WgradDesc), _vp]),
+    'yh_conv2d_wgrad_workspace': (_i64, [C.POINTER(WgradDesc)]),
+    'yh_bn_reduce_workspace': (_i64, [C.POINTER(BnDesc)]),
     'yh_stem_wgrad': (C.c_int, [C.POINTER(WgradDesc), _vp]),
     'yh_dilate2': (C.c_int, [C.POINTER(ResampleDesc), _vp]),
     'yh_upsample2_bwd': (C.c_int, [C.POINTER(ResampleDesc), _vp]),

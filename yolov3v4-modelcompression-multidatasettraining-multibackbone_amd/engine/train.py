@@ -38,7 +38,8 @@ from .hiplib import (ConvDesc, StemDesc, CopyDesc, AddDesc, BnStatsDesc, BnFinal
 from .plan import DarknetEngine, ALIGN_C, _round_up
 
 SLOT_INPUT = 0
-SLOT_HEAD0 = 1       # forward: head output tensors; backward: head gradient tensors (fp32 NHWC)
+SLOT_WS = 1          # shared fp32 workspace of the two-stage reductions
+SLOT_HEAD0 = 2       # forward: head output tensors; backward: head gradient tensors (fp32 NHWC)
 LINEAR = hiplib.ACT_CODES['linear']
 
 
@@ -150,7 +151,7 @@ class TrainEngine(DarknetEngine):
         self._check_supported(values)
         self._place(values)
         lib, dev, P = self.lib, self.device, hiplib.ptr
-        plan = dict(values=values, heads=heads, N=N, storages=[], fwd_ops=[], bwd_ops=[], zero_list=[])
+        plan = dict(values=values, heads=heads, N=N, storages=[], fwd_ops=[], bwd_ops=[], zero_list=[], ws_floats=0)
         fwd = plan['fwd'] = lib.yh_plan_create()
         bwd = plan['bwd'] = lib.yh_plan_create()
         if not fwd or not bwd:
@@ -168,6 +169,18 @@ class TrainEngine(DarknetEngine):
 
         def fixup(handle, op, desc_type, field, slot):
             hiplib.check(lib.yh_plan_add_fixup(handle, op, getattr(desc_type, field).offset, slot, 0), 'fixup')
+
+        def add_reduction(handle, log, desc, what):
+            """Reductions get the shared workspace (bound to SLOT_WS at run time) sized by the library's own query."""
+            query = lib.yh_conv2d_wgrad_workspace if isinstance(desc, WgradDesc) and not isinstance(desc, StemWgradDesc) \
+                else lib.yh_bn_reduce_workspace
+            need = int(query(C.byref(desc)))
+            desc.ws_floats = need
+            plan['ws_floats'] = max(plan['ws_floats'], need)
+            op = add(handle, log, desc, what)
+            if need:
+                fixup(handle, op, type(desc), 'ws', SLOT_WS)
+            return op
 
         def alloc(shape, fp32=False, zero=False):
             t = (torch.zeros if zero else torch.empty)(shape, device=dev, dtype=torch.float32 if fp32 else self.dtype)
@@ -287,7 +300,7 @@ class TrainEngine(DarknetEngine):
                     for t in (bn.weight, bn.bias, bn.running_mean, bn.running_var):
                         if t.dtype != torch.float32 or not t.is_contiguous():
                             raise NotImplementedError('HIP training path: BatchNorm tensors must be contiguous fp32')
-                    add(fwd, plan['fwd_ops'], BnStatsDesc(**base, **bnp), 'bnstat%d' % v.block)
+                    add_reduction(fwd, plan['fwd_ops'], BnStatsDesc(**base, **bnp), 'bnstat%d' % v.block)
                     add(fwd, plan['fwd_ops'], BnFinalizeDesc(**base, **bnp, running_mean=P(bn.running_mean),
                                                              running_var=P(bn.running_var)), 'bnfin%d' % v.block)
                 else:
@@ -381,7 +394,7 @@ class TrainEngine(DarknetEngine):
                                                         dtype=self.code), 'dhead%d' % v.block)
                 fixup(bwd, op, CastDesc, 'x', SLOT_HEAD0 + head_index[id(v)])
                 if v.g_b is not None:         # bias gradient = sum over pixels of dz
-                    add(bwd, plan['bwd_ops'],
+                    add_reduction(bwd, plan['bwd_ops'],
                         BnBwdReduceDesc(z=dzp, dy=dzp, pixels=pixels, n=N, h=v.Ho, w_in=v.Wo, c=v.c_phys, ldz=v.c_phys,
                                         lddy=v.c_phys, act=LINEAR, slope=0.0, dtype=self.code, ups=1,
                                         sum=grads.ptr(v.g_b), sumsq=grads.ptr(self._junk(plan, grads, v.c_phys))),
@@ -398,7 +411,7 @@ class TrainEngine(DarknetEngine):
                 if v.plain:                   # no BN, linear: dz is dy itself
                     dzp, lddz = dyp, lddy
                     if v.g_b is not None:
-                        add(bwd, plan['bwd_ops'],
+                        add_reduction(bwd, plan['bwd_ops'],
                             BnBwdReduceDesc(z=dyp, dy=dyp, pixels=pixels, n=N, h=v.Ho, w_in=v.Wo, c=v.c_phys, ldz=lddy,
                                             lddy=lddy, act=LINEAR, slope=0.0, dtype=self.code, ups=1, sum=grads.ptr(v.g_b),
                                             sumsq=grads.ptr(self._junk(plan, grads, v.c_phys))), 'dbias%d' % v.block)
@@ -410,7 +423,7 @@ class TrainEngine(DarknetEngine):
                     else:                     # activation without BN: z already holds the bias
                         acc = dict(sum=grads.ptr(v.g_b if v.g_b is not None else self._junk(plan, grads, v.c_phys)),
                                    sumsq=grads.ptr(self._junk(plan, grads, v.c_phys)))
-                    add(bwd, plan['bwd_ops'], BnBwdReduceDesc(**base, **acc, dy=dyp, lddy=lddy), 'dbn%d' % v.block)
+                    add_reduction(bwd, plan['bwd_ops'], BnBwdReduceDesc(**base, **acc, dy=dyp, lddy=lddy), 'dbn%d' % v.block)
                     add(bwd, plan['bwd_ops'], BnBwdApplyDesc(**base, **acc, dy=dyp, lddy=lddy, out=dzp, ldo=v.c_phys),
                         'dbnx%d' % v.block)
             # weight gradient
@@ -421,7 +434,7 @@ class TrainEngine(DarknetEngine):
                                        splits=0), 'wgrad%d' % v.block)
                 fixup(bwd, op, StemWgradDesc, 'x', SLOT_INPUT)
                 continue
-            add(bwd, plan['bwd_ops'],
+            add_reduction(bwd, plan['bwd_ops'],
                 WgradDesc(x=P(s.storage, s.c_off), dz=dzp, dw=grads.ptr(v.g_w), n=N, h=s.H, w_in=s.W, cin=s.C, ho=v.Ho,
                           wo=v.Wo, cout=v.C, kh=v.k, kw=v.k, stride=v.stride, pad=v.pad, ldx=s.ld, lddz=lddz, dtype=self.code,
                           splits=0), 'wgrad%d' % v.block)
@@ -441,6 +454,9 @@ class TrainEngine(DarknetEngine):
                          slope=0.0, ups=1, out_f32=0, dtype=self.code, tile=self.force_tile, acc_scale=0.0, out_scale=0.0),
                 'dgrad%d' % v.block)
         plan['head_shapes'] = [(N, h.src.H, h.src.W, h.src.c_phys) for h in heads]
+        plan['ws'] = alloc((max(plan['ws_floats'], 4),), fp32=True)
+        for handle in (fwd, bwd):
+            lib.yh_plan_bind_slot(handle, SLOT_WS, plan['ws'].data_ptr())
         return plan
 
     @staticmethod
