@@ -339,6 +339,8 @@ typedef struct yh_wgrad_desc {
     float* dw;              /* [cout][cin][kh][kw] fp32, accumulated                                            */
     int32_t n, h, w_in, cin, ho, wo, cout, kh, kw, stride, pad, ldx, lddz, dtype;
     int32_t splits;         /* pixel-range splits (0 = library heuristic)                                       */
+    int32_t cin_w;          /* input channels of dw (0 = cin): the first layer reads the image through an 8-channel  */
+                            /* NHWC copy (yh_nchw_to_nhwc) whose channels 3..7 are zero and have no dw entries       */
     float* ws;              /* optional workspace: per-split partial tiles, summed by a second launch instead of atomics; */
     int64_t ws_floats;      /* size from yh_conv2d_wgrad_workspace().  NULL / too small -> fp32 atomics.                  */
 } yh_wgrad_desc;
@@ -357,6 +359,9 @@ typedef struct yh_cast_desc {
     const float* x; void* y; int64_t pixels; int32_t c, ldx, ldy, dtype;
 } yh_cast_desc;
 int yh_cast_f32(const yh_cast_desc* d, void* stream);
+/* fp32 NCHW image (n, c, h, w) -> dtype NHWC (n, h, w, ldy) with channels c..c_pad-1 written as zeros (c_pad <= ldy):
+ * the first layer's weight gradient then runs on the MFMA kernel like every other layer.                          */
+int yh_nchw_to_nhwc(const float* x, void* y, int n, int c, int h, int w, int c_pad, int ldy, int dtype, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * Plans: a recorded sequence of the launches above, replayed by one native call per forward (the
@@ -367,7 +372,8 @@ typedef struct yh_plan yh_plan;
 enum { YH_OP_CONV = 1, YH_OP_STEM = 2, YH_OP_POOL = 3, YH_OP_COPY = 4, YH_OP_ADD = 5, YH_OP_DECODE = 6, YH_OP_DW = 7,
        YH_OP_SE = 8, YH_OP_QCOPY = 9, YH_OP_QPOOL = 10, YH_OP_QADD = 11, YH_OP_BN_STATS = 12, YH_OP_BN_FINALIZE = 13,
        YH_OP_BN_ACT_FWD = 14, YH_OP_BN_BWD_REDUCE = 15, YH_OP_BN_BWD_APPLY = 16, YH_OP_WGRAD = 17, YH_OP_STEM_WGRAD = 18,
-       YH_OP_DILATE2 = 19, YH_OP_UPSAMPLE2_BWD = 20, YH_OP_CAST_F32 = 21 };
+       YH_OP_DILATE2 = 19, YH_OP_UPSAMPLE2_BWD = 20, YH_OP_CAST_F32 = 21, YH_OP_NCHW_TO_NHWC = 22 };
+typedef struct yh_layout_desc { const float* x; void* y; int32_t n, c, h, w_in, c_pad, ldy, dtype; } yh_layout_desc;
 
 yh_plan* yh_plan_create(void);
 void yh_plan_destroy(yh_plan* p);

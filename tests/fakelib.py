@@ -17,7 +17,7 @@ import torch.nn.functional as F
 from engine import hiplib
 from engine.hiplib import (ConvDesc, StemDesc, PoolDesc, CopyDesc, AddDesc, DecodeDesc, DwDesc, SeDesc, QCopyDesc, QPoolDesc,
                            QAddDesc, BnStatsDesc, BnFinalizeDesc, BnActFwdDesc, BnBwdReduceDesc, BnBwdApplyDesc, WgradDesc,
-                           StemWgradDesc, DilateDesc, UpsampleBwdDesc, CastDesc)
+                           StemWgradDesc, DilateDesc, UpsampleBwdDesc, CastDesc, LayoutDesc)
 
 _NP = {hiplib.YH_F16: np.float16, hiplib.YH_F32: np.float32, hiplib.YH_I8: np.int8}
 _DESC = {hiplib.OP_CONV: ConvDesc, hiplib.OP_STEM: StemDesc, hiplib.OP_POOL: PoolDesc, hiplib.OP_COPY: CopyDesc,
@@ -26,7 +26,7 @@ _DESC = {hiplib.OP_CONV: ConvDesc, hiplib.OP_STEM: StemDesc, hiplib.OP_POOL: Poo
          hiplib.OP_BN_STATS: BnStatsDesc, hiplib.OP_BN_FINALIZE: BnFinalizeDesc, hiplib.OP_BN_ACT_FWD: BnActFwdDesc,
          hiplib.OP_BN_BWD_REDUCE: BnBwdReduceDesc, hiplib.OP_BN_BWD_APPLY: BnBwdApplyDesc, hiplib.OP_WGRAD: WgradDesc,
          hiplib.OP_STEM_WGRAD: StemWgradDesc, hiplib.OP_DILATE2: DilateDesc, hiplib.OP_UPSAMPLE2_BWD: UpsampleBwdDesc,
-         hiplib.OP_CAST_F32: CastDesc}
+         hiplib.OP_CAST_F32: CastDesc, hiplib.OP_NCHW_TO_NHWC: LayoutDesc}
 
 
 def _addr(p):
@@ -440,8 +440,20 @@ class FakeLib:
         dz = torch.from_numpy(pitched(d.dz, d.n * d.ho * d.wo, d.cout, d.lddz, npdt).astype(np.float32))
         dz = dz.view(d.n, d.ho, d.wo, d.cout).permute(0, 3, 1, 2)
         gw = torch.nn.grad.conv2d_weight(x, (d.cout, d.cin, d.kh, d.kw), dz, stride=d.stride, padding=d.pad)
+        if 0 < d.cin_w < d.cin:
+            gw = gw[:, :d.cin_w].contiguous()
         flat(d.dw, gw.numel(), np.float32)[:] += gw.reshape(-1).numpy()
         return 0
+
+    def yh_nchw_to_nhwc(self, x, y, n, c, h, w, c_pad, ldy, dtype, stream):
+        src = flat(x, n * c * h * w, np.float32).reshape(n, c, h, w)
+        dst = pitched(y, n * h * w, c_pad, ldy, _NP[dtype])
+        dst[:, :c] = src.transpose(0, 2, 3, 1).reshape(-1, c).astype(_NP[dtype])
+        dst[:, c:] = 0
+        return 0
+
+    def _layout(self, d, stream):
+        return self.yh_nchw_to_nhwc(d.x, d.y, d.n, d.c, d.h, d.w_in, d.c_pad, d.ldy, d.dtype, stream)
 
     def yh_stem_wgrad(self, dref, stream):
         d = dref._obj if hasattr(dref, '_obj') else dref
@@ -524,7 +536,8 @@ class FakeLib:
                hiplib.OP_BN_ACT_FWD: self.yh_bn_act_fwd, hiplib.OP_BN_BWD_REDUCE: self.yh_bn_act_bwd_reduce,
                hiplib.OP_BN_BWD_APPLY: self.yh_bn_act_bwd_apply, hiplib.OP_WGRAD: self.yh_conv2d_wgrad,
                hiplib.OP_STEM_WGRAD: self.yh_stem_wgrad, hiplib.OP_DILATE2: self.yh_dilate2,
-               hiplib.OP_UPSAMPLE2_BWD: self.yh_upsample2_bwd, hiplib.OP_CAST_F32: self.yh_cast_f32}
+               hiplib.OP_UPSAMPLE2_BWD: self.yh_upsample2_bwd, hiplib.OP_CAST_F32: self.yh_cast_f32,
+               hiplib.OP_NCHW_TO_NHWC: self._layout}
         for kind, desc, fixups in plan['ops'][first:last]:
             d = type(desc).from_buffer_copy(bytes(desc))
             for off, slot, boff in fixups:

@@ -303,3 +303,21 @@ def dgrad(lib, code, dz, w, in_hw, stride, pad, acc=None):
                  ldy=cin_phys, cin_k=cout_k, m_pad=dm_pad, act=0, slope=0.0, ups=1, out_f32=0, dtype=code, tile=0)
     call(lib, 'yh_conv2d_fwd', d)
     return dx
+
+
+def stem_wgrad_mfma(lib, code, x, dz, cout, stride=1, pad=1):
+    """First-layer weight gradient the way the engine runs it: image -> NHWC dtype with 8 channels, MFMA wgrad, cin_w."""
+    N, cin, H, W = x.shape
+    _, Ho, Wo, lddz = dz.shape
+    img = torch.full((N, H, W, 8), 5.0, device=x.device, dtype=tdtype(code))
+    rc = lib.yh_nchw_to_nhwc(P(x), P(img), N, cin, H, W, 8, 8, code, stream())
+    assert rc == 0, rc
+    dw = torch.zeros((cout, cin, 3, 3), device=x.device, dtype=torch.float32)
+    d = WgradDesc(x=P(img), dz=P(dz), dw=P(dw), n=N, h=H, w_in=W, cin=8, ho=Ho, wo=Wo, cout=cout, kh=3, kw=3, stride=stride,
+                  pad=pad, ldx=8, lddz=lddz, dtype=code, splits=0, cin_w=cin)
+    need = int(lib.yh_conv2d_wgrad_workspace(C.byref(d)))
+    if need:
+        ws = torch.full((need,), float('nan'), device=x.device, dtype=torch.float32)
+        d.ws, d.ws_floats = P(ws), need
+    call(lib, 'yh_conv2d_wgrad', d)
+    return dw, img

@@ -169,6 +169,12 @@ def test_stem_wgrad_matches_autograd(libs, code, shape):
     _sync()
     ref = torch.nn.grad.conv2d_weight(x, (cout, 3, 3, 3), dz.float().permute(0, 3, 1, 2), stride=s, padding=1)
     assert (got.cpu() - ref).abs().max().item() <= 2e-5 * ref.abs().max().item()
+    # the route the engine takes: 8-channel NHWC copy of the image + the MFMA kernel with cin_w = 3
+    got2, img = oh.stem_wgrad_mfma(lib, code, x.to(GPU), dz.to(GPU), cout, stride=s)
+    _sync()
+    assert torch.equal(img[..., :3].float().cpu(), x.permute(0, 2, 3, 1).to(dt).float()) and img[..., 3:].abs().max() == 0
+    ref2 = torch.nn.grad.conv2d_weight(x.to(dt).float(), (cout, 3, 3, 3), dz.float().permute(0, 3, 1, 2), stride=s, padding=1)
+    assert (got2.cpu() - ref2).abs().max().item() <= 1e-4 * ref2.abs().max().item()
 
 
 DGRAD_CASES = [(2, 16, 16, 64, 128, 1, 1), (2, 20, 20, 32, 64, 3, 1), (2, 32, 32, 64, 128, 3, 2), (1, 25, 27, 32, 64, 3, 2),

@@ -9,7 +9,7 @@
 // every 4-bank group once for i = 0..15).  One workgroup owns a 128 (co) x 128 (ci) tile of ONE tap and a contiguous
 // range of pixels; partial sums are added to dw with fp32 atomics (a few thousand per workgroup).
 #include "common.h"
-#include <stdlib.h>
+#include <type_traits>
 
 namespace yh {
 
@@ -23,13 +23,15 @@ template <> struct WG<float> {
     typedef f32x4 vec;
 };
 
+__device__ const uint32_t g_zero16[4] = {0u, 0u, 0u, 0u};  // source of every padded / out-of-range 16-byte load
+
 constexpr int WG_TILE = 128;     // co and ci tile
 constexpr int WG_PITCH_DW = 20;  // LDS row pitch in dwords (80 B)
 
 struct WgradArgs {
     yh_wgrad_desc d;
     int tiles_m, tiles_n, ksteps, ksteps_per_split, ncols;  // ncols = kh*kw*cin: the flattened (tap, ci) axis
-    int two_stage;
+    int two_stage, cin_w, rw, rh, qh;  // bk = qw * wo + rw, qw = qh * ho + rh: per-step pixel advance without divisions
     long pixels;
 };
 
@@ -41,8 +43,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
     typedef typename WG<T>::vec V;
     constexpr int VEC = WG<T>::VEC, BK = WG<T>::BK, PP = BK / 2, BM = TM * 32;
     const yh_wgrad_desc& d = a.d;
-    __shared__ uint32_t lds_a[BM * WG_PITCH_DW];
-    __shared__ uint32_t lds_b[WG_TILE * WG_PITCH_DW];
+    __shared__ uint32_t lds_a2[2][BM * WG_PITCH_DW];      // double-buffered: one barrier per K step
+    __shared__ uint32_t lds_b2[2][WG_TILE * WG_PITCH_DW];
 
     const int tm = blockIdx.x % a.tiles_m, tn = blockIdx.x / a.tiles_m;
     const int co0 = tm * BM, n0 = tn * WG_TILE;
@@ -69,7 +71,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // (n, ho, wo) of this thread's two pixels, advanced by BK pixels per K step without divisions
+    // (n, ho, wo) of this thread's two pixels, advanced by BK pixels per K step without divisions or branches:
+    // BK / wo row wraps at most (wrap_w conditional subtracts), one image wrap per row wrap.
     int pn[2], ph[2], pw[2];
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
@@ -80,41 +83,59 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
         ph[u] = rem / d.wo;
         pw[u] = rem - ph[u] * d.wo;
     }
+    typedef const V __attribute__((address_space(1))) * gvec_ptr;   // plain global loads (a generic pointer would go flat)
+    const gvec_ptr zero = (gvec_ptr)(uintptr_t)g_zero16;
+    const T* dz_t = dz + ca;              // this thread's channel group
+    const T* x_t = x + cb;
+    const unsigned npix = (unsigned)a.pixels;
 
-    V ra[2], rb[2];
-    auto fetch = [&](int ks) {
+    // Register staging in two sets: the loads of tile ks+2 are issued while tile ks is multiplied, and consumed (stashed
+    // to LDS, transposed) one iteration later -- two K steps of latency cover instead of one.  Out-of-range pixels,
+    // padding taps and channel tails load from a 16-byte zero page: every load is unconditional.  Element offsets
+    // fit 32 bits (checked by the launcher).
+    V ra[2][2], rb[2][2];
+    auto fetch = [&](auto set, int ks) {
+        constexpr int S = decltype(set)::value;
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-            const long p = (long)ks * BK + 2 * pp + u;
-            V va, vb;
-#pragma unroll
-            for (int e = 0; e < VEC; ++e) { va[e] = (T)0; vb[e] = (T)0; }
-            if (p < a.pixels) {
-                if (a_ok) va = *reinterpret_cast<const V*>(dz + p * d.lddz + ca);
-                const int hi = ph[u] * d.stride + tr, wi = pw[u] * d.stride + ts;
-                if (b_ok && (unsigned)hi < (unsigned)d.h && (unsigned)wi < (unsigned)d.w_in)
-                    vb = *reinterpret_cast<const V*>(x + (((long)pn[u] * d.h + hi) * d.w_in + wi) * d.ldx + cb);
-            }
-            ra[u] = va;
-            rb[u] = vb;
-            pw[u] += BK;
-            while (pw[u] >= d.wo) { pw[u] -= d.wo; ++ph[u]; }
-            while (ph[u] >= d.ho) { ph[u] -= d.ho; ++pn[u]; }
+            const unsigned p = (unsigned)ks * BK + 2 * pp + u;
+            const bool in = p < npix;
+            const int hi = ph[u] * d.stride + tr, wi = pw[u] * d.stride + ts;
+            const bool tap_ok = in && b_ok && (unsigned)hi < (unsigned)d.h && (unsigned)wi < (unsigned)d.w_in;
+            const unsigned offa = p * (unsigned)d.lddz;
+            const unsigned offb = ((unsigned)(pn[u] * d.h + hi) * (unsigned)d.w_in + (unsigned)wi) * (unsigned)d.ldx;
+            const gvec_ptr pa = (in && a_ok) ? (gvec_ptr)(uintptr_t)(dz_t + offa) : zero;
+            const gvec_ptr pb = tap_ok ? (gvec_ptr)(uintptr_t)(x_t + offb) : zero;
+            ra[S][u] = *pa;
+            rb[S][u] = *pb;
+            // advance by BK pixels: BK = qw * wo + rw and qw = qh * ho + rh (launcher constants), so one compare-and-
+            // carry per level replaces the divisions
+            int w = pw[u] + a.rw, h = ph[u] + a.rh, n = pn[u] + a.qh;
+            const bool cw = w >= d.wo;
+            w = cw ? w - d.wo : w;
+            h = cw ? h + 1 : h;
+            const bool ch = h >= d.ho;
+            h = ch ? h - d.ho : h;
+            n = ch ? n + 1 : n;
+            pw[u] = w; ph[u] = h; pn[u] = n;
         }
     };
-    auto stash = [&]() {
+    auto stash = [&](auto set, int buf) {
+        constexpr int S = decltype(set)::value;
+        uint32_t* lds_a = lds_a2[buf];
+        uint32_t* lds_b = lds_b2[buf];
         if constexpr (sizeof(T) == 2) {
 #pragma unroll
             for (int e = 0; e < VEC; ++e) {
-                const f16x2 wa = {ra[0][e], ra[1][e]};
-                const f16x2 wb = {rb[0][e], rb[1][e]};
+                const f16x2 wa = {ra[S][0][e], ra[S][1][e]};
+                const f16x2 wb = {rb[S][0][e], rb[S][1][e]};
                 if (cg * VEC < BM) lds_a[(cg * VEC + e) * WG_PITCH_DW + pp] = __builtin_bit_cast(uint32_t, wa);
                 lds_b[(cg * VEC + e) * WG_PITCH_DW + pp] = __builtin_bit_cast(uint32_t, wb);
             }
         } else {
             typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
-            const u32x4_t a0 = __builtin_bit_cast(u32x4_t, ra[0]), a1 = __builtin_bit_cast(u32x4_t, ra[1]);
-            const u32x4_t b0 = __builtin_bit_cast(u32x4_t, rb[0]), b1 = __builtin_bit_cast(u32x4_t, rb[1]);
+            const u32x4_t a0 = __builtin_bit_cast(u32x4_t, ra[S][0]), a1 = __builtin_bit_cast(u32x4_t, ra[S][1]);
+            const u32x4_t b0 = __builtin_bit_cast(u32x4_t, rb[S][0]), b1 = __builtin_bit_cast(u32x4_t, rb[S][1]);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 if (cg * 4 < BM) {
@@ -126,13 +147,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
             }
         }
     };
-
-    fetch(ks0);
-    for (int ks = ks0; ks < ks1; ++ks) {
-        __syncthreads();  // previous step's fragment reads are done
-        stash();
-        __syncthreads();
-        if (ks + 1 < ks1) fetch(ks + 1);  // global loads fly under the MFMAs
+    auto multiply = [&](int buf) {
+        const uint32_t* lds_a = lds_a2[buf];
+        const uint32_t* lds_b = lds_b2[buf];
         const int ri = lane & 15, kq = lane >> 4;
         if constexpr (sizeof(T) == 2) {
             f16x8 fa[TM], fb[4];
@@ -164,6 +181,29 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
             }
         }
+    };
+    typedef std::integral_constant<int, 0> S0;
+    typedef std::integral_constant<int, 1> S1;
+
+    // prologue: tile ks0 -> LDS buffer 0, tile ks0+1 in flight in set 1
+    fetch(S0{}, ks0);
+    fetch(S1{}, ks0 + 1);
+    stash(S0{}, 0);
+    __syncthreads();
+    // Two K steps per trip, no conditionals: prefetch tile ks+2 into the set tile ks came from, stash tile ks+1 (loaded
+    // one step ago) into the other LDS buffer, multiply tile ks, one barrier.  The step count is even by construction
+    // (ksteps_per_split is even; the last split may run one step past the end, which reads the zero page), and tiles
+    // fetched or stashed beyond ks1 are simply never multiplied.
+    const int ks1e = ks0 + ((ks1 - ks0 + 1) & ~1);
+    for (int ks = ks0; ks < ks1e; ks += 2) {
+        fetch(S0{}, ks + 2);
+        stash(S1{}, 1);
+        multiply(0);
+        __syncthreads();
+        fetch(S1{}, ks + 3);
+        stash(S0{}, 0);
+        multiply(1);
+        __syncthreads();
     }
 
     if (a.two_stage) {
@@ -182,19 +222,21 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
         const int n = n0 + wn * 64 + j * 16 + (lane & 15);
         if (n >= a.ncols) continue;
         const int tap = n / d.cin, ci = n - tap * d.cin;
+        if (ci >= a.cin_w) continue;
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int co = co0 + wm * TM * 16 + i * 16 + 4 * (lane >> 4) + r;
-                if (co < d.cout) atomicAdd(d.dw + ((long)co * d.cin + ci) * taps + tap, acc[i][j][r]);
+                if (co < d.cout) atomicAdd(d.dw + ((long)co * a.cin_w + ci) * taps + tap, acc[i][j][r]);
             }
     }
 }
 
-// Second stage: one thread per (tile, i, j, lane slot): sum the splits, add into dw[co][ci][tap].
+// Second stage: one thread per (tile, i, j, lane slot) and split group: sum the group's splits, add into dw[co][ci][tap]
+// (a handful of groups per element, so these atomics are uncontended).
 template <int TM>
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradArgs a, int splits) {
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradArgs a, int splits, int per_group) {
     const yh_wgrad_desc& d = a.d;
     const int tiles = a.tiles_m * a.tiles_n;
     const int tile = blockIdx.x / (TM * 4), ij = blockIdx.x % (TM * 4);
@@ -203,17 +245,37 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradArgs a, in
     const int wm = wave >> 1, wn = wave & 1;
     const f32x4* part = reinterpret_cast<const f32x4*>(d.ws) + ((long)tile * (TM * 4) + ij) * 256 + tid;
     const long stride = (long)tiles * (TM * 4) * 256;
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    for (int s = 0; s < splits; ++s) v += part[s * stride];
+    const int s0 = blockIdx.y * per_group, s1 = min(s0 + per_group, splits);
+    f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = v0, v2 = v0, v3 = v0;
+    int sp = s0;
+    for (; sp + 3 < s1; sp += 4) {   // four independent chains: the loads pipeline
+        v0 += part[sp * stride];
+        v1 += part[(sp + 1) * stride];
+        v2 += part[(sp + 2) * stride];
+        v3 += part[(sp + 3) * stride];
+    }
+    for (; sp < s1; ++sp) v0 += part[sp * stride];
+    const f32x4 v = (v0 + v1) + (v2 + v3);
     const int tm = tile % a.tiles_m, tn = tile / a.tiles_m;
     const int n = tn * WG_TILE + wn * 64 + j * 16 + (lane & 15);
     if (n >= a.ncols) return;
     const int taps = d.kh * d.kw;
     const int tap = n / d.cin, ci = n - tap * d.cin;
+    if (ci >= a.cin_w) return;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int co = tm * (TM * 32) + wm * TM * 16 + i * 16 + 4 * (lane >> 4) + r;
-        if (co < d.cout) d.dw[((long)co * d.cin + ci) * taps + tap] += v[r];
+        if (co < d.cout) atomicAdd(d.dw + ((long)co * a.cin_w + ci) * taps + tap, v[r]);
+    }
+}
+
+template <typename T>
+__global__ void nchw_to_nhwc_kernel(const float* x, T* y, int n, int c, int h, int w, int c_pad, int ldy) {
+    const long total = (long)n * h * w;
+    const long plane = (long)h * w;
+    for (long p = blockIdx.x * (long)blockDim.x + threadIdx.x; p < total; p += (long)gridDim.x * blockDim.x) {
+        const long img = p / plane, off = p - img * plane;
+        for (int ch = 0; ch < c_pad; ++ch) y[p * ldy + ch] = ch < c ? (T)x[(img * c + ch) * plane + off] : (T)0;
     }
 }
 
@@ -365,6 +427,8 @@ static void wgrad_geometry(const yh_wgrad_desc* d, WgradArgs* pa, int* psplits) 
     a.tiles_n = (a.ncols + WG_TILE - 1) / WG_TILE;
     a.ksteps = (int)((a.pixels + bk - 1) / bk);
     a.two_stage = 0;
+    a.cin_w = d->cin_w > 0 ? d->cin_w : d->cin;
+    { const int qw = bk / d->wo; a.rw = bk - qw * d->wo; a.qh = qw / d->ho; a.rh = qw - a.qh * d->ho; }
     const int tiles = a.tiles_m * a.tiles_n;
     int splits = d->splits;
     if (splits <= 0) {
@@ -373,7 +437,7 @@ static void wgrad_geometry(const yh_wgrad_desc* d, WgradArgs* pa, int* psplits) 
         if (splits > max_splits) splits = max_splits;
         if (splits < 1) splits = 1;
     }
-    a.ksteps_per_split = (a.ksteps + splits - 1) / splits;
+    a.ksteps_per_split = ((a.ksteps + splits - 1) / splits + 1) & ~1;   // even: the kernel runs two steps per trip
     *psplits = (a.ksteps + a.ksteps_per_split - 1) / a.ksteps_per_split;
 }
 
@@ -382,7 +446,8 @@ extern "C" int yh_conv2d_wgrad(const yh_wgrad_desc* d, void* stream) {
     if (d->dtype != YH_F16 && d->dtype != YH_F32) return YH_EINVAL;
     const int vec = d->dtype == YH_F16 ? 8 : 4;
     if (d->ldx % vec || d->lddz % vec || !aligned16(d->x) || !aligned16(d->dz)) return YH_EALIGN;
-    if (d->cin % vec) return YH_EALIGN;
+    if (d->cin % vec || d->cin_w > d->cin) return YH_EALIGN;
+    if ((long)d->n * d->h * d->w_in * d->ldx >= (1L << 31) || (long)d->n * d->ho * d->wo * d->lddz >= (1L << 31)) return YH_EINVAL;
     WgradArgs a;
     int splits;
     wgrad_geometry(d, &a, &splits);
@@ -399,8 +464,12 @@ extern "C" int yh_conv2d_wgrad(const yh_wgrad_desc* d, void* stream) {
         else hipLaunchKernelGGL((conv_wgrad_kernel<float, 4>), grid, dim3(256), 0, st, a);
     }
     if (a.two_stage) {
-        if (narrow) hipLaunchKernelGGL(wgrad_reduce_kernel<2>, dim3(tiles * 8), dim3(256), 0, st, a, splits);
-        else hipLaunchKernelGGL(wgrad_reduce_kernel<4>, dim3(tiles * 16), dim3(256), 0, st, a, splits);
+        int groups = (splits + 15) / 16;                    // >= 16 splits per group, <= 32 groups
+        if (groups > 32) groups = 32;
+        const int per_group = (splits + groups - 1) / groups;
+        groups = (splits + per_group - 1) / per_group;
+        if (narrow) hipLaunchKernelGGL(wgrad_reduce_kernel<2>, dim3(tiles * 8, groups), dim3(256), 0, st, a, splits, per_group);
+        else hipLaunchKernelGGL(wgrad_reduce_kernel<4>, dim3(tiles * 16, groups), dim3(256), 0, st, a, splits, per_group);
     }
     return check_launch();
 }
@@ -452,6 +521,17 @@ extern "C" int yh_upsample2_bwd(const yh_resample_desc* d, void* stream) {
     const long total = (long)d->n * d->h * d->w_in * (d->c / vec);
     if (d->dtype == YH_F16) hipLaunchKernelGGL((resample2_kernel<f16, false>), dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, *d);
     else hipLaunchKernelGGL((resample2_kernel<float, false>), dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, *d);
+    return check_launch();
+}
+
+extern "C" int yh_nchw_to_nhwc(const float* x, void* y, int n, int c, int h, int w, int c_pad, int ldy, int dtype, void* stream) {
+    if (!x || !y || n <= 0 || c <= 0 || h <= 0 || w <= 0 || c_pad < c || ldy < c_pad) return YH_EINVAL;
+    const long total = (long)n * h * w;
+    if (dtype == YH_F16)
+        hipLaunchKernelGGL(nchw_to_nhwc_kernel<f16>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, (f16*)y, n, c, h, w, c_pad, ldy);
+    else if (dtype == YH_F32)
+        hipLaunchKernelGGL(nchw_to_nhwc_kernel<float>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, (float*)y, n, c, h, w, c_pad, ldy);
+    else return YH_EINVAL;
     return check_launch();
 }
 

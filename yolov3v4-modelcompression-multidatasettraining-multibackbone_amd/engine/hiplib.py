@@ -120,7 +120,7 @@ class WgradDesc(C.Structure):
     _fields_ = [('x', _vp), ('dz', _vp), ('dw', _vp),
                 ('n', _i32), ('h', _i32), ('w_in', _i32), ('cin', _i32), ('ho', _i32), ('wo', _i32), ('cout', _i32),
                 ('kh', _i32), ('kw', _i32), ('stride', _i32), ('pad', _i32), ('ldx', _i32), ('lddz', _i32), ('dtype', _i32),
-                ('splits', _i32), ('ws', _vp), ('ws_floats', _i64)]
+                ('splits', _i32), ('cin_w', _i32), ('ws', _vp), ('ws_floats', _i64)]
 
 
 class StemWgradDesc(WgradDesc):
@@ -140,16 +140,21 @@ class UpsampleBwdDesc(ResampleDesc):
     pass
 
 
+class LayoutDesc(C.Structure):
+    _fields_ = [('x', _vp), ('y', _vp), ('n', _i32), ('c', _i32), ('h', _i32), ('w_in', _i32), ('c_pad', _i32), ('ldy', _i32),
+                ('dtype', _i32)]
+
+
 class CastDesc(C.Structure):
     _fields_ = [('x', _vp), ('y', _vp), ('pixels', _i64), ('c', _i32), ('ldx', _i32), ('ldy', _i32), ('dtype', _i32)]
 
 
 OP_BN_STATS, OP_BN_FINALIZE, OP_BN_ACT_FWD, OP_BN_BWD_REDUCE, OP_BN_BWD_APPLY = 12, 13, 14, 15, 16
-OP_WGRAD, OP_STEM_WGRAD, OP_DILATE2, OP_UPSAMPLE2_BWD, OP_CAST_F32 = 17, 18, 19, 20, 21
+OP_WGRAD, OP_STEM_WGRAD, OP_DILATE2, OP_UPSAMPLE2_BWD, OP_CAST_F32, OP_NCHW_TO_NHWC = 17, 18, 19, 20, 21, 22
 
 OP_KIND = {BnStatsDesc: OP_BN_STATS, BnFinalizeDesc: OP_BN_FINALIZE, BnActFwdDesc: OP_BN_ACT_FWD,
            BnBwdReduceDesc: OP_BN_BWD_REDUCE, BnBwdApplyDesc: OP_BN_BWD_APPLY, WgradDesc: OP_WGRAD,
-           StemWgradDesc: OP_STEM_WGRAD, DilateDesc: OP_DILATE2, UpsampleBwdDesc: OP_UPSAMPLE2_BWD, CastDesc: OP_CAST_F32,
+           StemWgradDesc: OP_STEM_WGRAD, DilateDesc: OP_DILATE2, UpsampleBwdDesc: OP_UPSAMPLE2_BWD, CastDesc: OP_CAST_F32, LayoutDesc: OP_NCHW_TO_NHWC,
            ConvDesc: OP_CONV, StemDesc: OP_STEM, PoolDesc: OP_POOL, CopyDesc: OP_COPY, AddDesc: OP_ADD,
            DecodeDesc: OP_DECODE, DwDesc: OP_DW, SeDesc: OP_SE, QCopyDesc: OP_QCOPY, QPoolDesc: OP_QPOOL, QAddDesc: OP_QADD}
 
@@ -192,6 +197,7 @@ _SIGNATURES = {
     'yh_dilate2': (C.c_int, [C.POINTER(ResampleDesc), _vp]),
     'yh_upsample2_bwd': (C.c_int, [C.POINTER(ResampleDesc), _vp]),
     'yh_cast_f32': (C.c_int, [C.POINTER(CastDesc), _vp]),
+    'yh_nchw_to_nhwc': (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
     'yh_plan_create': (_vp, []),
     'yh_plan_destroy': (None, [_vp]),
     'yh_plan_add': (C.c_int, [_vp, C.c_int, _vp, C.c_int]),

@@ -34,7 +34,7 @@ import torch.nn as nn
 
 from . import hiplib
 from .hiplib import (ConvDesc, StemDesc, CopyDesc, AddDesc, BnStatsDesc, BnFinalizeDesc, BnActFwdDesc, BnBwdReduceDesc,
-                     BnBwdApplyDesc, WgradDesc, StemWgradDesc, DilateDesc, UpsampleBwdDesc, CastDesc)
+                     BnBwdApplyDesc, WgradDesc, StemWgradDesc, DilateDesc, UpsampleBwdDesc, CastDesc, LayoutDesc)
 from .plan import DarknetEngine, ALIGN_C, _round_up
 
 SLOT_INPUT = 0
@@ -428,11 +428,15 @@ class TrainEngine(DarknetEngine):
                         'dbnx%d' % v.block)
             # weight gradient
             if s.kind == 'input':
-                op = add(bwd, plan['bwd_ops'],
-                         StemWgradDesc(x=None, dz=dzp, dw=grads.ptr(v.g_w), n=N, h=s.H, w_in=s.W, cin=s.C, ho=v.Ho, wo=v.Wo,
-                                       cout=v.C, kh=v.k, kw=v.k, stride=v.stride, pad=v.pad, ldx=0, lddz=lddz, dtype=self.code,
-                                       splits=0), 'wgrad%d' % v.block)
-                fixup(bwd, op, StemWgradDesc, 'x', SLOT_INPUT)
+                # the image as NHWC dtype with 8 channels (3..7 zero): the first layer then uses the MFMA wgrad kernel
+                img = alloc((N, s.H, s.W, ALIGN_C))
+                op = add(bwd, plan['bwd_ops'], LayoutDesc(x=None, y=P(img), n=N, c=s.C, h=s.H, w_in=s.W, c_pad=ALIGN_C, ldy=ALIGN_C,
+                                                          dtype=self.code), 'image%d' % v.block)
+                fixup(bwd, op, LayoutDesc, 'x', SLOT_INPUT)
+                add_reduction(bwd, plan['bwd_ops'],
+                              WgradDesc(x=P(img), dz=dzp, dw=grads.ptr(v.g_w), n=N, h=s.H, w_in=s.W, cin=ALIGN_C, ho=v.Ho, wo=v.Wo,
+                                        cout=v.C, kh=v.k, kw=v.k, stride=v.stride, pad=v.pad, ldx=ALIGN_C, lddz=lddz,
+                                        dtype=self.code, splits=0, cin_w=s.C), 'wgrad%d' % v.block)
                 continue
             add_reduction(bwd, plan['bwd_ops'],
                 WgradDesc(x=P(s.storage, s.c_off), dz=dzp, dw=grads.ptr(v.g_w), n=N, h=s.H, w_in=s.W, cin=s.C, ho=v.Ho,
