@@ -45,3 +45,63 @@ def test_two_rank_timing_uses_slowest_rank():
     assert abs(e0 - e1) < 1e-9, 'both ranks must report the same (max) time'
     assert e0 >= 5 * 0.06 * 0.95, 'time must be the straggler rank\'s'
     assert abs(r0 - 2 * 8 * 5 / e0) < 1e-6 and r0 == r1
+
+
+# ---------------------------------------------------------------------------- data-parallel training
+def _ddp_worker(rank, world, port, cfg_path, out):
+    """One DDP rank on CPU: the HIP training path replayed on the host emulation of the C ABI, gradients all-reduced by
+    DistributedDataParallel over gloo exactly as RCCL does on the GPUs (train.py:283-286 wraps the model the same way)."""
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, here)
+    import conftest  # noqa: F401
+    import fakelib
+    import synth
+    import train_harness as th
+    from engine.train import TrainEngine
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    model = th.build(cfg_path, 64)                       # same seed on both ranks: identical initial weights
+    model.__dict__['_hip_train_engine'] = TrainEngine(model, 'fp32', lib=fakelib.FakeLib())
+    ddp = torch.nn.parallel.DistributedDataParallel(model)
+    x = synth.image_batch(2, 64, seed=10 + rank)          # each rank its own shard of the minibatch
+    os.environ['YOLO_HIP_TRAIN_PRECISION'] = 'fp32'
+    # DDP calls model.forward; route the CPU tensors through the HIP path (on a GPU box x.is_cuda does this)
+    model._use_hip_train = lambda inp: True
+    raws, _ = ddp(x)
+    ws = th.loss_weights(raws, seed=5)
+    th.toy_loss(raws, ws).backward()
+    grads = {k: p.grad.clone() for k, p in model.named_parameters()}
+    # local (un-averaged) gradients of the same shard, for the parent to average itself
+    local = th.build(cfg_path, 64)
+    local.__dict__['_hip_train_engine'] = TrainEngine(local, 'fp32', lib=fakelib.FakeLib())
+    raws_l, _ = local._forward_hip_train(x)
+    th.toy_loss(raws_l, ws).backward()
+    out.put((rank, {k: v.numpy() for k, v in grads.items()}, {k: p.grad.numpy() for k, p in local.named_parameters()}))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_ddp_training_step_averages_hip_path_gradients():
+    import numpy as np
+    import conftest
+    import train_harness as th
+    os.environ['PYTHONPATH'] = os.pathsep.join([conftest.PKG, conftest.REPO, os.environ.get('PYTHONPATH', '')])
+    cfg_path = th.write_cfg(th.mini_cfg_text())
+    ctx = mp.get_context('spawn')
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_ddp_worker, args=(r, 2, port, cfg_path, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((out.get(timeout=300) for _ in procs), key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    os.unlink(cfg_path)
+    (_, g0, l0), (_, g1, l1) = res
+    for k in g0:
+        assert np.array_equal(g0[k], g1[k]), 'ranks disagree on %s after the all-reduce' % k
+        mean = (l0[k] + l1[k]) / 2
+        assert np.abs(g0[k] - mean).max() <= 1e-5 * (np.abs(mean).max() + 1e-12), k
