@@ -91,12 +91,17 @@ typedef struct yh_conv_desc {
     int32_t cin_k, m_pad;         /* as given to yh_conv_pack_weights                                    */
     int32_t act;                  /* YH_ACT_*                                                            */
     float slope;                  /* leaky slope                                                         */
-    int32_t ups;                  /* 1, or 2 = write every output pixel to its 2x2 upsampled block       */
+    int32_t ups;                  /* 1, or 2 = write every output pixel to its 2x2 upsampled block, or   */
+                                  /* 3 = phase scatter (see y_h .. y_off_w below)                         */
     int32_t out_f32;              /* store fp32 regardless of dtype (yolo head inputs)                   */
     int32_t dtype;                /* YH_F16 / YH_F32                                                     */
     int32_t tile;                 /* 0 = auto; else forces a tile config (bench/autotune only)           */
     float acc_scale;              /* YH_I8 only: s_w * s_x, turns the int32 accumulator into real units   */
     float out_scale;              /* YH_I8 only: s_a of the block's activation quantizer                  */
+    int32_t y_h, y_w;             /* ups == 3 only: output pixel (n, ho, wo) is stored (and res read) at  */
+    int32_t y_off_h, y_off_w;     /* (n, 2 ho + y_off_h, 2 wo + y_off_w) of a y_h x y_w tensor; ho/wo are  */
+                                  /* then free (taps beyond the input read zeros).  This is one of the four */
+                                  /* phases of a stride-2 data gradient, see yh_conv_pack_weights_dgrad_phase */
 } yh_conv_desc;
 
 int yh_conv2d_fwd(const yh_conv_desc* d, void* stream);
@@ -333,6 +338,13 @@ int yh_bn_act_bwd_apply(const yh_bn_desc* d, void* stream);
  *  yh_cast_f32     fp32 pitched rows -> dtype pitched rows (head gradients arrive from autograd as fp32).          */
 int yh_conv_pack_weights_dgrad(int dtype, const float* w, int cout, int cin, int kh, int kw, int cout_k, int m_pad,
                                void* packed, void* stream);
+/* Stride-2 data gradient without the zero-dilated copy: the input pixels of parity (a, b) = (h & 1, w & 1) only see
+ * the taps r = a + pad - 2t, s = b + pad - 2u (t, u >= 0), i.e. a (kh_p x kw_p)-tap correlation of dz whose window
+ * starts at (h >> 1, w >> 1).  This packs that phase's image [m_pad rows = cin][kh_p*kw_p][cout_k] and returns
+ * kh_p / kw_p; run yh_conv2d_fwd with x = dz, kh = kh_p, kw = kw_p, stride 1, pad 0, ups = 3, y_off = (a, b).
+ * For 3x3 / pad 1 the four phases have 1, 2, 2 and 4 taps: 9 tap-GEMMs instead of the 36 of the dilated form.      */
+int yh_conv_pack_weights_dgrad_phase(int dtype, const float* w, int cout, int cin, int kh, int kw, int pad, int a, int b,
+                                     int cout_k, int m_pad, void* packed, int* kh_p, int* kw_p, void* stream);
 typedef struct yh_wgrad_desc {
     const void* x;          /* forward input of the conv, NHWC dtype (stem: NCHW fp32 image)                    */
     const void* dz;         /* gradient of the conv output, NHWC dtype, pitch lddz                              */

@@ -246,6 +246,21 @@ class FakeLib:
         w = wimg[:d.cout, :, :, :d.cin].permute(0, 3, 1, 2).contiguous()
         assert wimg[:, :, :, d.cin:].abs().max().item() == 0 if d.cin_k > d.cin else True
         b = torch.from_numpy(flat(d.bias, d.m_pad, np.float32)[:d.cout].copy())
+        if d.ups == 3:   # phase scatter: free window geometry, taps beyond the input read zeros
+            need_h, need_w = (d.ho - 1) * d.stride + d.kh - d.pad, (d.wo - 1) * d.stride + d.kw - d.pad
+            x = F.pad(x, (d.pad, max(need_w - d.w_in, 0), d.pad, max(need_h - d.h, 0)))
+            y = F.conv2d(x, w, b, stride=d.stride)[:, :, :d.ho, :d.wo]
+            y = _act(y, d.act, d.slope)
+            npdt_o = np.float32 if d.out_f32 else npdt
+            out = pitched(d.y, d.n * d.y_h * d.y_w, d.cout, d.ldy, npdt_o)
+            idx = ((np.arange(d.n)[:, None, None] * d.y_h + 2 * np.arange(d.ho)[None, :, None] + d.y_off_h) * d.y_w
+                   + 2 * np.arange(d.wo)[None, None, :] + d.y_off_w).reshape(-1)
+            vals = y.permute(0, 2, 3, 1).reshape(-1, d.cout)
+            if _addr(d.res):
+                rr = pitched(d.res, d.n * d.y_h * d.y_w, d.cout, d.ldr, npdt)
+                vals = vals + torch.from_numpy(rr[idx].astype(np.float32))
+            out[idx] = vals.numpy().astype(npdt_o)
+            return 0
         y = F.conv2d(x, w, b, stride=d.stride, padding=d.pad)
         assert y.shape[2] == d.ho and y.shape[3] == d.wo
         y = _act(y, d.act, d.slope)
@@ -414,6 +429,22 @@ class FakeLib:
             s2 = torch.from_numpy(flat(d.sumsq, d.c, np.float32).copy())
             g = gamma * istd * (g - s1 / d.pixels - xh * s2 / d.pixels)
         pitched(d.out, d.pixels, d.c, d.ldo, npdt)[:] = g.numpy().astype(npdt)
+        return 0
+
+    def yh_conv_pack_weights_dgrad_phase(self, dtype, w, cout, cin, kh, kw, pad, pa, pb, cout_k, m_pad, packed, kh_p, kw_p, stream):
+        npdt = _NP[dtype]
+        wt = torch.from_numpy(flat(w, cout * cin * kh * kw, np.float32).copy()).view(cout, cin, kh, kw)
+        khp, kwp = (pa + pad) // 2 + 1, (pb + pad) // 2 + 1
+        img = torch.zeros(m_pad, khp, kwp, cout_k)
+        for t in range(khp):
+            for u in range(kwp):
+                r, s_ = pa + pad - 2 * t, pb + pad - 2 * u
+                if 0 <= r < kh and 0 <= s_ < kw:
+                    img[:cin, t, u, :cout] = wt[:, :, r, s_].t()
+        flat(packed, img.numel(), npdt)[:] = img.reshape(-1).numpy().astype(npdt)
+        for ptr, val in ((kh_p, khp), (kw_p, kwp)):
+            if ptr is not None:
+                (ptr._obj if hasattr(ptr, '_obj') else ptr.contents).value = val
         return 0
 
     def yh_conv2d_wgrad_workspace(self, dref):

@@ -279,7 +279,7 @@ def stem_wgrad(lib, code, x, dz, cout, stride=1, pad=1):
 
 
 def dgrad(lib, code, dz, w, in_hw, stride, pad, acc=None):
-    """Data gradient through yh_conv2d_fwd on the dgrad weight image (yh_dilate2 first for stride 2).
+    """Data gradient through yh_conv2d_fwd on the dgrad weight image (stride 2: four parity phases, ups = 3 scatter).
     dz (N,Ho,Wo,cout_phys), w (cout,cin,k,k) fp32 -> dx (N,H,W,cin_phys); ``acc`` (same shape) is accumulated into."""
     cout, cin, k, _ = w.shape
     N, Ho, Wo, cphys = dz.shape
@@ -290,17 +290,28 @@ def dgrad(lib, code, dz, w, in_hw, stride, pad, acc=None):
     wt = torch.empty(dm_pad * k * k * cout_k, device=dz.device, dtype=tdtype(code))
     rc = lib.yh_conv_pack_weights_dgrad(code, P(w), cout, cin, k, k, cout_k, dm_pad, P(wt), stream())
     assert rc == 0, rc
-    src, sh, sw = dz, Ho, Wo
-    if stride == 2:
-        src = torch.zeros((N, H, W, cphys), device=dz.device, dtype=dz.dtype)
-        call(lib, 'yh_dilate2', ResampleDesc(x=P(dz), y=P(src), n=N, h=Ho, w_in=Wo, c=cphys, big_h=H, big_w=W, ldx=cphys,
-                                            ldy=cphys, dtype=code))
-        sh, sw = H, W
     dx = acc if acc is not None else torch.full((N, H, W, cin_phys), 3.0, device=dz.device, dtype=dz.dtype)
     zero_bias = torch.zeros(dm_pad, device=dz.device, dtype=torch.float32)
-    d = ConvDesc(x=P(src), w=P(wt), bias=P(zero_bias), res=P(acc), y=P(dx), n=N, h=sh, w_in=sw, cin=cphys, ho=H, wo=W,
-                 cout=cin_phys, kh=k, kw=k, stride=1, pad=k - 1 - pad, ldx=cphys, ldr=0 if acc is None else cin_phys,
-                 ldy=cin_phys, cin_k=cout_k, m_pad=dm_pad, act=0, slope=0.0, ups=1, out_f32=0, dtype=code, tile=0)
+    common = dict(x=P(dz), bias=P(zero_bias), res=P(acc), y=P(dx), n=N, h=Ho, w_in=Wo, cin=cphys, cout=cin_phys, stride=1,
+                  ldx=cphys, ldr=0 if acc is None else cin_phys, ldy=cin_phys, cin_k=cout_k, m_pad=dm_pad, act=0, slope=0.0,
+                  out_f32=0, dtype=code, tile=0)
+    if stride == 2:   # four parity phases, scattered onto every other pixel
+        keep = []
+        for a in (0, 1):
+            for b in (0, 1):
+                khp, kwp = C.c_int(0), C.c_int(0)
+                img = torch.empty(dm_pad * 4 * cout_k, device=dz.device, dtype=tdtype(code))
+                rc = lib.yh_conv_pack_weights_dgrad_phase(code, P(w), cout, cin, k, k, pad, a, b, cout_k, dm_pad, P(img),
+                                                          C.byref(khp), C.byref(kwp), stream())
+                assert rc == 0, rc
+                keep.append(img)
+                hp, wp = (H - a + 1) // 2, (W - b + 1) // 2
+                if hp <= 0 or wp <= 0:
+                    continue
+                call(lib, 'yh_conv2d_fwd', ConvDesc(w=P(img), ho=hp, wo=wp, kh=khp.value, kw=kwp.value, pad=0, ups=3, y_h=H, y_w=W,
+                                                    y_off_h=a, y_off_w=b, **common))
+        return dx
+    d = ConvDesc(w=P(wt), ho=H, wo=W, kh=k, kw=k, pad=k - 1 - pad, ups=1, **common)
     call(lib, 'yh_conv2d_fwd', d)
     return dx
 

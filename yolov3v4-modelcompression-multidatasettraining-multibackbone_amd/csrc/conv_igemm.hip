@@ -44,6 +44,7 @@ struct ConvArgs {
     int act;
     float slope;
     int ups;
+    int y_h, y_w, y_off_h, y_off_w;  // ups == 3: output pixel (n, ho, wo) is stored at (n, 2 ho + y_off_h, 2 wo + y_off_w) of a y_h x y_w tensor
 };
 
 // compile-time unrolled loop: every array index below is a constant, so staging registers never
@@ -304,6 +305,11 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm_kernel(const ConvA
             const int ho = rem / a.Wo, wo = rem - ho * a.Wo;
             wo2 = 2 * a.Wo;
             opix = ((long)n * 2 * a.Ho + 2 * ho) * wo2 + 2 * wo;
+        } else if (a.ups == 3) {  // phase scatter (stride-2 data gradient): every other pixel of a y_h x y_w tensor
+            const int n = (int)(p / HoWo);
+            const int rem = (int)(p - (long)n * HoWo);
+            const int ho = rem / a.Wo, wo = rem - ho * a.Wo;
+            opix = ((long)n * a.y_h + 2 * ho + a.y_off_h) * a.y_w + 2 * wo + a.y_off_w;
         }
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
@@ -315,7 +321,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm_kernel(const ConvA
             for (int e = 0; e < 4; ++e) v[e] = activate(acc[i][j][e] + bv[e], a.act, a.slope);
             if (rg != nullptr) {
                 float r4[4];
-                load4<T>(rg + p * a.ldr + m, r4);
+                load4<T>(rg + (a.ups == 3 ? opix : p) * a.ldr + m, r4);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] += r4[e];
             }
@@ -564,6 +570,11 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm_glds_kernel(const 
             const int ho = rem / a.Wo, wo = rem - ho * a.Wo;
             wo2 = 2 * a.Wo;
             opix = ((long)n * 2 * a.Ho + 2 * ho) * wo2 + 2 * wo;
+        } else if (a.ups == 3) {  // phase scatter (stride-2 data gradient): every other pixel of a y_h x y_w tensor
+            const int n = (int)(p / HoWo);
+            const int rem = (int)(p - (long)n * HoWo);
+            const int ho = rem / a.Wo, wo = rem - ho * a.Wo;
+            opix = ((long)n * a.y_h + 2 * ho + a.y_off_h) * a.y_w + 2 * wo + a.y_off_w;
         }
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
@@ -585,7 +596,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm_glds_kernel(const 
                 for (int e = 0; e < 4; ++e) v[e] = activate((float)acc[i][j][e] + bv[e], a.act, a.slope);
                 if (rg != nullptr) {
                     float r4[4];
-                    load4<T>(rg + p * a.ldr + m, r4);
+                    load4<T>(rg + (a.ups == 3 ? opix : p) * a.ldr + m, r4);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] += r4[e];
                 }
@@ -821,7 +832,7 @@ __global__ __launch_bounds__(512, (BM <= 128 ? 4 : 2)) void conv3x3_halo_kernel(
             for (int e = 0; e < 4; ++e) v[e] = activate(acc[i][j][e] + bv[e], a.act, a.slope);
             if (rg != nullptr) {
                 float r4[4];
-                load4<T>(rg + p * a.ldr + m, r4);
+                load4<T>(rg + (a.ups == 3 ? opix : p) * a.ldr + m, r4);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] += r4[e];
             }
@@ -1000,8 +1011,14 @@ extern "C" int yh_conv2d_fwd(const yh_conv_desc* d, void* stream) {
     if (d->cin % vec || d->ldx % vec || d->cin_k % bk || d->cin_k < d->cin || d->m_pad % 128 || d->m_pad < d->cout) return YH_EALIGN;
     if (d->cout % 4 || d->ldy % 4 || (d->res && d->ldr % 4)) return YH_EALIGN;
     if (!aligned16(d->x) || !aligned16(d->w) || !aligned16(d->bias) || (((uintptr_t)d->y) & 7u) || (((uintptr_t)d->res) & 7u)) return YH_EALIGN;
-    if (d->ups != 1 && d->ups != 2) return YH_EINVAL;
-    if (d->ho != (d->h + 2 * d->pad - d->kh) / d->stride + 1 || d->wo != (d->w_in + 2 * d->pad - d->kw) / d->stride + 1) return YH_EINVAL;
+    if (d->ups != 1 && d->ups != 2 && d->ups != 3) return YH_EINVAL;
+    if (d->ups == 3) {
+        // phase scatter: free window geometry (taps beyond the input read zeros), destination must hold every pixel
+        if (d->dtype == YH_I8 || (d->tile >= 40 && d->tile < 50)) return YH_EINVAL;
+        if (d->y_off_h < 0 || d->y_off_w < 0 || 2 * (d->ho - 1) + d->y_off_h >= d->y_h || 2 * (d->wo - 1) + d->y_off_w >= d->y_w) return YH_EINVAL;
+    } else if (d->ho != (d->h + 2 * d->pad - d->kh) / d->stride + 1 || d->wo != (d->w_in + 2 * d->pad - d->kw) / d->stride + 1) {
+        return YH_EINVAL;
+    }
 
     ConvArgs a;
     a.x = d->x; a.w = d->w; a.bias = d->bias; a.res = d->res; a.y = d->y;
@@ -1014,6 +1031,7 @@ extern "C" int yh_conv2d_fwd(const yh_conv_desc* d, void* stream) {
     a.m_pad = d->m_pad;
     a.acc_scale = d->acc_scale; a.out_scale = d->out_scale; a.inv_out_scale = d->out_scale > 0.f ? 1.f / d->out_scale : 0.f;
     a.act = d->act; a.slope = d->slope; a.ups = d->ups;
+    a.y_h = d->y_h; a.y_w = d->y_w; a.y_off_h = d->y_off_h; a.y_off_w = d->y_off_w;
     hipStream_t s = (hipStream_t)stream;
     if (d->dtype == YH_F16) {
         return d->out_f32 ? dispatch_tile<f16, float>(a, d->tile, s) : dispatch_tile<f16, f16>(a, d->tile, s);

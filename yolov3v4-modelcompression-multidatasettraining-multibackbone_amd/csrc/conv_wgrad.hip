@@ -345,6 +345,23 @@ __global__ void pack_dgrad_kernel(const float* w, int cout, int cin, int kh, int
     }
 }
 
+// one phase of the stride-2 data gradient: packed[ci][t*kwp + u][co] = w[co][ci][a + pad - 2t][b + pad - 2u]
+template <typename T>
+__global__ void pack_dgrad_phase_kernel(const float* w, int cout, int cin, int kh, int kw, int pad, int pa, int pb, int khp,
+                                        int kwp, int cout_k, int m_pad, T* packed) {
+    const long total = (long)m_pad * khp * kwp * cout_k;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int co = (int)(i % cout_k);
+        long r = i / cout_k;
+        const int tap = (int)(r % (khp * kwp));
+        const int ci = (int)(r / (khp * kwp));
+        const int fr = pa + pad - 2 * (tap / kwp), fs = pb + pad - 2 * (tap % kwp);
+        float v = 0.f;
+        if (ci < cin && co < cout && fr >= 0 && fr < kh && fs >= 0 && fs < kw) v = w[(((long)co * cin + ci) * kh + fr) * kw + fs];
+        packed[i] = (T)v;
+    }
+}
+
 template <typename T, bool SCATTER>
 __global__ void resample2_kernel(const yh_resample_desc d) {
     typedef typename WG<T>::vec V;
@@ -439,6 +456,26 @@ static void wgrad_geometry(const yh_wgrad_desc* d, WgradArgs* pa, int* psplits) 
     }
     a.ksteps_per_split = ((a.ksteps + splits - 1) / splits + 1) & ~1;   // even: the kernel runs two steps per trip
     *psplits = (a.ksteps + a.ksteps_per_split - 1) / a.ksteps_per_split;
+}
+
+extern "C" int yh_conv_pack_weights_dgrad_phase(int dtype, const float* w, int cout, int cin, int kh, int kw, int pad, int pa,
+                                                int pb, int cout_k, int m_pad, void* packed, int* kh_p, int* kw_p, void* stream) {
+    if (!w || !packed || cout <= 0 || cin <= 0 || kh <= 0 || kw <= 0 || pad < 0 || cout_k < cout || m_pad < cin) return YH_EINVAL;
+    if (pa < 0 || pa > 1 || pb < 0 || pb > 1) return YH_EINVAL;
+    // taps r = pa + pad - 2t with 0 <= r < kh: t from max(0, ceil((pa+pad-kh+1)/2)) .. floor((pa+pad)/2); the window
+    // is anchored at t = 0, so leading taps that fall outside the kernel are packed as zeros
+    const int khp = (pa + pad) / 2 + 1, kwp = (pb + pad) / 2 + 1;
+    if (kh_p) *kh_p = khp;
+    if (kw_p) *kw_p = kwp;
+    const long total = (long)m_pad * khp * kwp * cout_k;
+    if (dtype == YH_F16)
+        hipLaunchKernelGGL(pack_dgrad_phase_kernel<f16>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, w, cout, cin, kh,
+                           kw, pad, pa, pb, khp, kwp, cout_k, m_pad, (f16*)packed);
+    else if (dtype == YH_F32)
+        hipLaunchKernelGGL(pack_dgrad_phase_kernel<float>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, w, cout, cin,
+                           kh, kw, pad, pa, pb, khp, kwp, cout_k, m_pad, (float*)packed);
+    else return YH_EINVAL;
+    return check_launch();
 }
 
 extern "C" int yh_conv2d_wgrad(const yh_wgrad_desc* d, void* stream) {

@@ -25,7 +25,8 @@ class ConvDesc(C.Structure):
                 ('ldx', _i32), ('ldr', _i32), ('ldy', _i32),
                 ('cin_k', _i32), ('m_pad', _i32),
                 ('act', _i32), ('slope', _f32), ('ups', _i32), ('out_f32', _i32), ('dtype', _i32), ('tile', _i32),
-                ('acc_scale', _f32), ('out_scale', _f32)]
+                ('acc_scale', _f32), ('out_scale', _f32),
+                ('y_h', _i32), ('y_w', _i32), ('y_off_h', _i32), ('y_off_w', _i32)]
 
 
 class StemDesc(C.Structure):
@@ -190,6 +191,8 @@ _SIGNATURES = {
     'yh_bn_act_bwd_reduce': (C.c_int, [C.POINTER(BnDesc), _vp]),
     'yh_bn_act_bwd_apply': (C.c_int, [C.POINTER(BnDesc), _vp]),
     'yh_conv_pack_weights_dgrad': (C.c_int, [C.c_int, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp]),
+    'yh_conv_pack_weights_dgrad_phase': (C.c_int, [C.c_int, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                                   C.c_int, C.c_int, _vp, C.POINTER(C.c_int), C.POINTER(C.c_int), _vp]),
     'yh_conv2d_wgrad': (C.c_int, [C.POINTER(WgradDesc), _vp]),
     'yh_conv2d_wgrad_workspace': (_i64, [C.POINTER(WgradDesc)]),
     'yh_bn_reduce_workspace': (_i64, [C.POINTER(BnDesc)]),

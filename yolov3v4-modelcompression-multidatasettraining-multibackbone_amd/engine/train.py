@@ -21,7 +21,7 @@ and the backward plan, walking the values in reverse,
     dgamma, dbeta (or conv-bias grad)          yh_bn_act_bwd_reduce   (written straight into the gradient arena)
     dz                                         yh_bn_act_bwd_apply
     dW                                         yh_conv2d_wgrad / yh_stem_wgrad (fp32 atomics into the arena)
-    grad(input) (+)= conv(dz, W^T flipped)     yh_conv2d_fwd on the dgrad weight image (yh_dilate2 first for stride 2)
+    grad(input) (+)= conv(dz, W^T flipped)     yh_conv2d_fwd on the dgrad weight image (stride 2: four parity phases)
 
 Every activation, z and gradient buffer is kept for the whole step (288 GB of HBM: YOLOv3-608 batch 64 needs ~40 GB).
 Blocks this path does not lower yet (maxpool, depthwise, SE, weighted shortcuts) raise NotImplementedError at plan
@@ -34,7 +34,7 @@ import torch.nn as nn
 
 from . import hiplib
 from .hiplib import (ConvDesc, StemDesc, CopyDesc, AddDesc, BnStatsDesc, BnFinalizeDesc, BnActFwdDesc, BnBwdReduceDesc,
-                     BnBwdApplyDesc, WgradDesc, StemWgradDesc, DilateDesc, UpsampleBwdDesc, CastDesc, LayoutDesc)
+                     BnBwdApplyDesc, WgradDesc, StemWgradDesc, UpsampleBwdDesc, CastDesc, LayoutDesc)
 from .plan import DarknetEngine, ALIGN_C, _round_up
 
 SLOT_INPUT = 0
@@ -119,6 +119,12 @@ class TrainEngine(DarknetEngine):
             rc = lib.yh_conv_pack_weights(self.code, P(w), P(cb), None, None, None, None, 0.0, None, v.C, conv.in_channels,
                                           v.k, v.k, pk['cin_k'], pk['m_pad'], P(pk['w']), P(pk['b']), hiplib.stream_ptr())
             hiplib.check(rc, 'yh_conv_pack_weights')
+            if v.stride == 2:   # four parity phases instead of one dilated pass
+                for (a, b), img in zip(((0, 0), (0, 1), (1, 0), (1, 1)), pk['wt_phase']):
+                    rc = lib.yh_conv_pack_weights_dgrad_phase(self.code, P(w), v.C, conv.in_channels, v.k, v.k, v.pad, a, b,
+                                                              pk['cout_k'], pk['dm_pad'], P(img), None, None, hiplib.stream_ptr())
+                    hiplib.check(rc, 'yh_conv_pack_weights_dgrad_phase')
+                continue
             rc = lib.yh_conv_pack_weights_dgrad(self.code, P(w), v.C, conv.in_channels, v.k, v.k, pk['cout_k'], pk['dm_pad'],
                                                 P(pk['wt']), hiplib.stream_ptr())
             hiplib.check(rc, 'yh_conv_pack_weights_dgrad')
@@ -234,8 +240,13 @@ class TrainEngine(DarknetEngine):
                 dm_pad = _round_up(v.src.c_phys, 128)
                 v.tpack = dict(w=torch.empty(m_pad * taps * cin_k, device=dev, dtype=self.dtype),
                                b=torch.empty(m_pad, device=dev, dtype=torch.float32), cin_k=cin_k, m_pad=m_pad,
-                               wt=torch.empty(dm_pad * taps * cout_k, device=dev, dtype=self.dtype), cout_k=cout_k,
-                               dm_pad=dm_pad)
+                               wt=None if v.stride == 2 else torch.empty(dm_pad * taps * cout_k, device=dev, dtype=self.dtype),
+                               cout_k=cout_k, dm_pad=dm_pad)
+                if v.stride == 2:
+                    # parity (a, b) sees ((a + pad) // 2 + 1) x ((b + pad) // 2 + 1) taps
+                    v.tpack['phase_taps'] = [((a + v.pad) // 2 + 1, (b + v.pad) // 2 + 1) for a in (0, 1) for b in (0, 1)]
+                    v.tpack['wt_phase'] = [torch.empty(dm_pad * th * tw * cout_k, device=dev, dtype=self.dtype)
+                                           for th, tw in v.tpack['phase_taps']]
             # z: the conv output before BN / activation.  Blocks with neither BN nor activation store straight to y.
             v.plain = bn is None and v.act == LINEAR and v.res is None and v.ups == 1
             if v.fp32:
@@ -443,20 +454,25 @@ class TrainEngine(DarknetEngine):
                           wo=v.Wo, cout=v.C, kh=v.k, kw=v.k, stride=v.stride, pad=v.pad, ldx=s.ld, lddz=lddz, dtype=self.code,
                           splits=0), 'wgrad%d' % v.block)
             # data gradient into grad(src)
-            gx, gh, gw_, gld = dzp, v.Ho, v.Wo, lddz
-            if v.stride == 2:
-                # dz onto the even positions of a zeroed tensor of the INPUT's spatial size (odd positions stay zero)
-                dil = alloc((N, s.H, s.W, v.c_phys), zero=True)
-                add(bwd, plan['bwd_ops'], DilateDesc(x=dzp, y=P(dil), n=N, h=v.Ho, w_in=v.Wo, c=v.c_phys, big_h=s.H, big_w=s.W,
-                                                     ldx=lddz, ldy=v.c_phys, dtype=self.code), 'dilate%d' % v.block)
-                gx, gh, gw_, gld = P(dil), s.H, s.W, v.c_phys
             mode = contribution_mode(s, True)
-            add(bwd, plan['bwd_ops'],
-                ConvDesc(x=gx, w=P(pk['wt']), bias=P(zero_bias), res=gptr(s) if mode == 'acc' else None, y=gptr(s), n=N, h=gh,
-                         w_in=gw_, cin=v.c_phys, ho=s.H, wo=s.W, cout=s.c_phys, kh=v.k, kw=v.k, stride=1, pad=v.k - 1 - v.pad,
-                         ldx=gld, ldr=s.ld if mode == 'acc' else 0, ldy=s.ld, cin_k=pk['cout_k'], m_pad=pk['dm_pad'], act=LINEAR,
-                         slope=0.0, ups=1, out_f32=0, dtype=self.code, tile=self.force_tile, acc_scale=0.0, out_scale=0.0),
-                'dgrad%d' % v.block)
+            common = dict(bias=P(zero_bias), n=N, cin=v.c_phys, cout=s.c_phys, stride=1, ldx=lddz, ldr=s.ld if mode == 'acc' else 0,
+                          ldy=s.ld, cin_k=pk['cout_k'], m_pad=pk['dm_pad'], act=LINEAR, slope=0.0, out_f32=0, dtype=self.code,
+                          tile=self.force_tile if self.force_tile < 40 else 0, acc_scale=0.0, out_scale=0.0)
+            if v.stride == 2:
+                # input pixels of parity (a, b) only see the taps r = a + pad - 2t, s = b + pad - 2u: four small
+                # correlations of dz scattered onto every other pixel, 9 tap-GEMMs in total (a dilated pass runs 36)
+                for (a, b), (th, tw), img in zip(((0, 0), (0, 1), (1, 0), (1, 1)), pk['phase_taps'], pk['wt_phase']):
+                    hp, wp = (s.H - a + 1) // 2, (s.W - b + 1) // 2
+                    if hp <= 0 or wp <= 0:
+                        continue
+                    add(bwd, plan['bwd_ops'],
+                        ConvDesc(x=dzp, w=P(img), res=gptr(s) if mode == 'acc' else None, y=gptr(s), h=v.Ho, w_in=v.Wo, ho=hp, wo=wp,
+                                 kh=th, kw=tw, pad=0, ups=3, y_h=s.H, y_w=s.W, y_off_h=a, y_off_w=b, **common),
+                        'dgrad%d' % v.block)
+            else:
+                add(bwd, plan['bwd_ops'],
+                    ConvDesc(x=dzp, w=P(pk['wt']), res=gptr(s) if mode == 'acc' else None, y=gptr(s), h=v.Ho, w_in=v.Wo, ho=s.H,
+                             wo=s.W, kh=v.k, kw=v.k, pad=v.k - 1 - v.pad, ups=1, **common), 'dgrad%d' % v.block)
         plan['head_shapes'] = [(N, h.src.H, h.src.W, h.src.c_phys) for h in heads]
         plan['ws'] = alloc((max(plan['ws_floats'], 4),), fp32=True)
         for handle in (fwd, bwd):
