@@ -10,6 +10,7 @@
 // range of pixels; partial sums are added to dw with fp32 atomics (a few thousand per workgroup).
 #include "common.h"
 #include <type_traits>
+#include <stdlib.h>
 
 namespace yh {
 
@@ -23,7 +24,14 @@ template <> struct WG<float> {
     typedef f32x4 vec;
 };
 
-__device__ const uint32_t g_zero16[4] = {0u, 0u, 0u, 0u};  // source of every padded / out-of-range 16-byte load
+__device__ __attribute__((aligned(16))) const uint32_t g_zero16[4] = {0u, 0u, 0u, 0u};  // source of every padded / out-of-range 16-byte load
+
+template <int N, typename F> __device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (N > 0) {
+        static_for<N - 1>(f);
+        f(std::integral_constant<int, N - 1>{});
+    }
+}
 
 constexpr int WG_TILE = 128;     // co and ci tile
 constexpr int WG_PITCH_DW = 20;  // LDS row pitch in dwords (80 B)
@@ -31,7 +39,7 @@ constexpr int WG_PITCH_DW = 20;  // LDS row pitch in dwords (80 B)
 struct WgradArgs {
     yh_wgrad_desc d;
     int tiles_m, tiles_n, ksteps, ksteps_per_split, ncols;  // ncols = kh*kw*cin: the flattened (tap, ci) axis
-    int two_stage, cin_w, rw, rh, qh;  // bk = qw * wo + rw, qw = qh * ho + rh: per-step pixel advance without divisions
+    int two_stage, interleaved, bn, cin_w, rw, rh, qh;  // interleaved: the DMA kernel's tile <-> channel mapping  // bk = qw * wo + rw, qw = qh * ho + rh: per-step pixel advance without divisions
     long pixels;
 };
 
@@ -233,18 +241,230 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// fp16 production kernel: same GEMM, but the pixel-major tiles go global -> LDS by LDS-DMA exactly as they lie in memory
+// (row = one pixel, 256 B of channels; no VGPR staging, no packing, no ds_write), a 3-stage ring with counted vmcnt and
+// one raw barrier per K step like the forward kernel, and the transpose happens on the READ side: a lane's MFMA fragment
+// (8 consecutive pixels of one channel) is eight ds_read_u16 at a fixed 256 B stride (immediate offsets, no address math).
+// 16 lanes of a fragment read 32 contiguous bytes of one row; the four 8-pixel groups of a wave read rows 2 KB apart, which
+// would alias to the same banks, so the 16-byte units of a row are XOR-permuted by 2 * (row >> 3 & 3) on the way in (the
+// DMA lane fetches source unit u ^ f for destination cell u) and un-permuted by the reader: conflict free.
+// unit permutation of pixel row r in a row of UNITS 16-byte units: toggles the 128-byte half per 8-row group so that the
+// four 8-pixel groups of a fragment read spread over both halves of the banks (8 units/row: only 2-bit room, keep 2g)
+template <int UNITS> __device__ __forceinline__ int wg_swz(int r) {
+    return UNITS == 16 ? (((r >> 3) & 1) << 3) : (((r >> 3) & 3) << 1);
+}
+
+template <int N> __device__ __forceinline__ void wg_wait_vmcnt() {
+#define YH_WG_VMCNT(K) else if constexpr (N == K) asm volatile("s_waitcnt vmcnt(" #K ")" ::: "memory")
+    if constexpr (N < 0) {}
+    YH_WG_VMCNT(0); YH_WG_VMCNT(2); YH_WG_VMCNT(3); YH_WG_VMCNT(4); YH_WG_VMCNT(6); YH_WG_VMCNT(8);
+    else static_assert(N < 0, "add the literal");
+#undef YH_WG_VMCNT
+}
+
+// WNW = waves along the (tap, ci) axis: 2 -> 128 columns on 4 waves, 4 -> 256 columns on 8 waves (24 KB per K step for
+// twice the MFMA work of the 16 KB 128 x 128 step: the L2 -> LDS stream is what bounds this kernel).
+template <int TM, int WNW>
+__global__ __launch_bounds__(128 * WNW) void conv_wgrad_dma_kernel(const WgradArgs a) {
+    constexpr int BK = 32, BM = TM * 32, BN = WNW * 64, NWAVES = 2 * WNW, NT = 64 * NWAVES, STAGES = 3;
+    constexpr int A_UNITS = BM / 8;                    // 16-byte units per A row (16 or 8)
+    constexpr int A_ROWS_PER_INSTR = 64 / A_UNITS;     // 4 or 8 pixel rows per LDS-DMA instruction
+    constexpr int A_INSTR = BK / A_ROWS_PER_INSTR;     // 8 or 4 per K step
+    constexpr int A_PER_WAVE = (A_INSTR + NWAVES - 1) / NWAVES;  // 2, 1 (or 1 on the first A_INSTR waves only)
+    constexpr int B_UNITS = BN / 8;                    // 16 or 32 units per B row
+    constexpr int B_ROWS_PER_INSTR = 64 / B_UNITS;     // 4 or 2
+    constexpr int B_INSTR = BK / B_ROWS_PER_INSTR;     // 8 or 16
+    constexpr int B_PER_WAVE = B_INSTR / NWAVES;       // 2
+    static_assert(B_INSTR % NWAVES == 0, "B instructions must split evenly over the waves");
+    constexpr int GPW = A_PER_WAVE + B_PER_WAVE;
+    constexpr int A_BYTES = BK * BM * 2, B_BYTES = BK * BN * 2, STAGE_BYTES = A_BYTES + B_BYTES;
+    const yh_wgrad_desc& d = a.d;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[STAGES * STAGE_BYTES];
+
+    const int tm = blockIdx.x % a.tiles_m, tn = blockIdx.x / a.tiles_m;
+    const int co0 = tm * BM, n0 = tn * BN;
+    const int ks0 = blockIdx.y * a.ksteps_per_split;
+    const int ks1 = min(ks0 + a.ksteps_per_split, a.ksteps);
+    if (ks0 >= ks1) return;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WNW, wn = wave % WNW;
+    typedef const void __attribute__((address_space(1))) * gptr_t;
+    typedef void __attribute__((address_space(3))) * lptr_t;
+    const f16* dz = reinterpret_cast<const f16*>(d.dz);
+    const f16* x = reinterpret_cast<const f16*>(d.x);
+    const f16* zero = reinterpret_cast<const f16*>(g_zero16);
+    const unsigned npix = (unsigned)a.pixels;
+
+    // ---- loader roles.  A instruction q covers pixel rows q*A_ROWS_PER_INSTR.., B instruction q rows 4q..4q+3.
+    int a_row[A_PER_WAVE];          // pixel row within the K step
+    int a_coff[A_PER_WAVE];         // channel offset of the source unit, or -1 when beyond cout
+    static_for<A_PER_WAVE>([&](auto c) {
+        constexpr int i = decltype(c)::value;
+        const int q = wave + NWAVES * i;                 // waves beyond A_INSTR have no A share (a_live below)
+        const int row = q * A_ROWS_PER_INSTR + lane / A_UNITS;
+        const int us = (lane % A_UNITS) ^ wg_swz<A_UNITS>(row);
+        a_row[i] = row;
+        a_coff[i] = (co0 + us * 8 < d.cout) ? co0 + us * 8 : -1;
+    });
+    int b_row[B_PER_WAVE], b_coff[B_PER_WAVE], b_tr[B_PER_WAVE], b_ts[B_PER_WAVE];
+    static_for<B_PER_WAVE>([&](auto c) {
+        constexpr int i = decltype(c)::value;
+        const int q = wave + NWAVES * i;
+        const int row = q * B_ROWS_PER_INSTR + lane / B_UNITS;
+        const int us = (lane % B_UNITS) ^ wg_swz<16>(row);
+        const int nb = n0 + us * 8;
+        b_row[i] = row;
+        if (nb < a.ncols) {
+            const int tap = nb / d.cin;
+            b_coff[i] = nb - tap * d.cin;
+            b_tr[i] = tap / d.kw - d.pad;
+            b_ts[i] = tap % d.kw - d.pad;
+        } else {
+            b_coff[i] = -1; b_tr[i] = 0; b_ts[i] = 0;
+        }
+    });
+    // pixel coordinates of this lane's rows (A and B rows coincide when A_PER_WAVE == 2; tracked separately otherwise)
+    constexpr int NP = A_PER_WAVE + B_PER_WAVE;
+    int pn[NP], ph[NP], pw[NP];
+    static_for<NP>([&](auto c) {
+        constexpr int i = decltype(c)::value;
+        const int row = i < A_PER_WAVE ? a_row[i < A_PER_WAVE ? i : 0] : b_row[i >= A_PER_WAVE ? i - A_PER_WAVE : 0];
+        const long p = (long)ks0 * BK + row;
+        const int hw_o = d.ho * d.wo;
+        pn[i] = (int)(p / hw_o);
+        const int rem = (int)(p - (long)pn[i] * hw_o);
+        ph[i] = rem / d.wo;
+        pw[i] = rem - ph[i] * d.wo;
+    });
+
+    const bool a_live = wave < A_INSTR || A_PER_WAVE > 1;   // wave-uniform: this wave issues A loads
+    int ks_issue = ks0;
+    auto issue = [&](int st) {
+        unsigned char* const base = smem + st * STAGE_BYTES;
+        static_for<A_PER_WAVE>([&](auto c) {
+            constexpr int i = decltype(c)::value;
+            const unsigned p = (unsigned)ks_issue * BK + a_row[i];
+            const bool ok = p < npix && a_coff[i] >= 0;
+            const f16* src = ok ? dz + p * (unsigned)d.lddz + a_coff[i] : zero;
+            unsigned char* dst = base + (wave + NWAVES * i) * 1024;
+            if (a_live) __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)dst, 16, 0, 0);
+        });
+        static_for<B_PER_WAVE>([&](auto c) {
+            constexpr int i = decltype(c)::value;
+            constexpr int k = A_PER_WAVE + i;
+            const unsigned p = (unsigned)ks_issue * BK + b_row[i];
+            const int hi = ph[k] * d.stride + b_tr[i], wi = pw[k] * d.stride + b_ts[i];
+            const bool ok = p < npix && b_coff[i] >= 0 && (unsigned)hi < (unsigned)d.h && (unsigned)wi < (unsigned)d.w_in;
+            const unsigned off = ((unsigned)(pn[k] * d.h + hi) * (unsigned)d.w_in + (unsigned)wi) * (unsigned)d.ldx + b_coff[i];
+            const f16* src = ok ? x + off : zero;
+            unsigned char* dst = base + A_BYTES + (wave + NWAVES * i) * 1024;
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)dst, 16, 0, 0);
+        });
+        // advance every tracked pixel by BK (only the B rows need coordinates; A rows use the flat index)
+        static_for<B_PER_WAVE>([&](auto c) {
+            constexpr int k = A_PER_WAVE + decltype(c)::value;
+            int w = pw[k] + a.rw, h = ph[k] + a.rh, n = pn[k] + a.qh;
+            const bool cw = w >= d.wo;
+            w = cw ? w - d.wo : w;
+            h = cw ? h + 1 : h;
+            const bool ch = h >= d.ho;
+            h = ch ? h - d.ho : h;
+            n = ch ? n + 1 : n;
+            pw[k] = w; ph[k] = h; pn[k] = n;
+        });
+        ++ks_issue;
+    };
+
+    f32x4 acc[TM][4];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // ---- fragment addressing.  The wave's TM (resp. 4) MFMA tiles interleave channels: row ri of tile i is channel
+    // TM*ri + i of the wave's block, so one 8-byte (TM = 4) or 4-byte (TM = 2) LDS read per pixel feeds all tiles at once:
+    // 8 reads per operand per K step instead of 8 per fragment.
+    const int ri = lane & 15, g = lane >> 4;
+    const int cha = wm * TM * 16 + TM * ri;            // first of this lane's TM consecutive A channels
+    const int chb = wn * 64 + 4 * ri;                  // first of its 4 consecutive B columns
+    const int a_off = (8 * g) * (BM * 2) + (((cha >> 3) ^ wg_swz<A_UNITS>(8 * g)) << 4) + (cha & 7) * 2;
+    const int b_off = A_BYTES + (8 * g) * (BN * 2) + (((chb >> 3) ^ wg_swz<16>(8 * g)) << 4) + (chb & 7) * 2;
+    typedef f16 f16xTM __attribute__((ext_vector_type(TM)));
+
+    const int nk = ks1 - ks0;
+#pragma unroll
+    for (int s = 0; s < STAGES - 1; ++s)
+        if (s < nk) issue(s);
+    int st_read = 0, st_write = STAGES - 1;
+    for (int kt = 0; kt < nk; ++kt) {
+        const int ahead = min(STAGES - 2, nk - 1 - kt);
+        if (ahead >= 1) {
+            if (a_live) wg_wait_vmcnt<GPW>(); else wg_wait_vmcnt<B_PER_WAVE>();
+        } else {
+            wg_wait_vmcnt<0>();
+        }
+        __builtin_amdgcn_s_barrier();
+        if (kt + STAGES - 1 < nk) issue(st_write);
+        const unsigned char* stage = smem + st_read * STAGE_BYTES;
+        f16x8 fa[TM], fb[4];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const f16xTM va = *reinterpret_cast<const f16xTM*>(stage + a_off + t * (BM * 2));
+            const f16x4 vb = *reinterpret_cast<const f16x4*>(stage + b_off + t * (BN * 2));
+#pragma unroll
+            for (int i = 0; i < TM; ++i) fa[i][t] = va[i];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) fb[j][t] = vb[j];
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        st_read = st_read + 1 == STAGES ? 0 : st_read + 1;
+        st_write = st_write + 1 == STAGES ? 0 : st_write + 1;
+    }
+
+    if (a.two_stage) {
+        f32x4* part = reinterpret_cast<f32x4*>(d.ws) + ((long)blockIdx.y * gridDim.x + blockIdx.x) * (TM * 4 * NT);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) part[(i * 4 + j) * NT + tid] = acc[i][j];
+        return;
+    }
+    const int taps = d.kh * d.kw;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int n = n0 + wn * 64 + 4 * (lane & 15) + j;
+        if (n >= a.ncols) continue;
+        const int tap = n / d.cin, ci = n - tap * d.cin;
+        if (ci >= a.cin_w) continue;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int co = co0 + wm * TM * 16 + TM * (4 * (lane >> 4) + r) + i;
+                if (co < d.cout) atomicAdd(d.dw + ((long)co * a.cin_w + ci) * taps + tap, acc[i][j][r]);
+            }
+    }
+}
+
 // Second stage: one thread per (tile, i, j, lane slot) and split group: sum the group's splits, add into dw[co][ci][tap]
 // (a handful of groups per element, so these atomics are uncontended).
-template <int TM>
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradArgs a, int splits, int per_group) {
+template <int TM, int WNW>
+__global__ __launch_bounds__(128 * WNW) void wgrad_reduce_kernel(const WgradArgs a, int splits, int per_group) {
+    constexpr int NT = 128 * WNW, BN = 64 * WNW;
     const yh_wgrad_desc& d = a.d;
     const int tiles = a.tiles_m * a.tiles_n;
     const int tile = blockIdx.x / (TM * 4), ij = blockIdx.x % (TM * 4);
     const int i = ij / 4, j = ij % 4;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-    const f32x4* part = reinterpret_cast<const f32x4*>(d.ws) + ((long)tile * (TM * 4) + ij) * 256 + tid;
-    const long stride = (long)tiles * (TM * 4) * 256;
+    const int wm = wave / WNW, wn = wave % WNW;
+    const f32x4* part = reinterpret_cast<const f32x4*>(d.ws) + ((long)tile * (TM * 4) + ij) * NT + tid;
+    const long stride = (long)tiles * (TM * 4) * NT;
     const int s0 = blockIdx.y * per_group, s1 = min(s0 + per_group, splits);
     f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = v0, v2 = v0, v3 = v0;
     int sp = s0;
@@ -257,14 +477,14 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradArgs a, in
     for (; sp < s1; ++sp) v0 += part[sp * stride];
     const f32x4 v = (v0 + v1) + (v2 + v3);
     const int tm = tile % a.tiles_m, tn = tile / a.tiles_m;
-    const int n = tn * WG_TILE + wn * 64 + j * 16 + (lane & 15);
+    const int n = tn * BN + wn * 64 + (a.interleaved ? 4 * (lane & 15) + j : j * 16 + (lane & 15));
     if (n >= a.ncols) return;
     const int taps = d.kh * d.kw;
     const int tap = n / d.cin, ci = n - tap * d.cin;
     if (ci >= a.cin_w) return;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        const int co = tm * (TM * 32) + wm * TM * 16 + i * 16 + 4 * (lane >> 4) + r;
+        const int co = tm * (TM * 32) + wm * TM * 16 + (a.interleaved ? TM * (4 * (lane >> 4) + r) + i : i * 16 + 4 * (lane >> 4) + r);
         if (co < d.cout) atomicAdd(d.dw + ((long)co * a.cin_w + ci) * taps + tap, v[r]);
     }
 }
@@ -440,8 +660,12 @@ static void wgrad_geometry(const yh_wgrad_desc* d, WgradArgs* pa, int* psplits) 
     a.pixels = (long)d->n * d->ho * d->wo;
     const int bm = d->cout <= 64 ? 64 : WG_TILE;        // 64-row tiles for the early, wide-resolution layers
     a.ncols = d->kh * d->kw * d->cin;
+    a.interleaved = d->dtype == YH_F16 && d->splits != -1;   // the LDS-DMA kernel
+    // 256-column tiles (8 waves) when they stay >= 85 % full; the register-staged kernels are 128 wide
+    a.bn = WG_TILE;   // 256-column (8-wave) tiles measured slower (VGPR-limited to one workgroup per CU); YH_WGRAD_BN=256 selects them
+    { const char* e = getenv("YH_WGRAD_BN"); if (e && a.interleaved && bm == 128) a.bn = atoi(e); }
     a.tiles_m = (d->cout + bm - 1) / bm;
-    a.tiles_n = (a.ncols + WG_TILE - 1) / WG_TILE;
+    a.tiles_n = (a.ncols + a.bn - 1) / a.bn;
     a.ksteps = (int)((a.pixels + bk - 1) / bk);
     a.two_stage = 0;
     a.cin_w = d->cin_w > 0 ? d->cin_w : d->cin;
@@ -449,7 +673,7 @@ static void wgrad_geometry(const yh_wgrad_desc* d, WgradArgs* pa, int* psplits) 
     const int tiles = a.tiles_m * a.tiles_n;
     int splits = d->splits;
     if (splits <= 0) {
-        splits = (2048 + tiles - 1) / tiles;               // ~8 workgroups per CU
+        splits = (1024 + tiles - 1) / tiles;               // ~4 workgroups per CU: every split costs a partial tile of traffic
         const int max_splits = (a.ksteps + 7) / 8;         // at least 8 K steps per workgroup
         if (splits > max_splits) splits = max_splits;
         if (splits < 1) splits = 1;
@@ -490,10 +714,14 @@ extern "C" int yh_conv2d_wgrad(const yh_wgrad_desc* d, void* stream) {
     wgrad_geometry(d, &a, &splits);
     const int tiles = a.tiles_m * a.tiles_n;
     const bool narrow = d->cout <= 64;
-    a.two_stage = d->ws && d->ws_floats >= (int64_t)splits * tiles * (narrow ? 64 : 128) * 128;
+    a.two_stage = d->ws && d->ws_floats >= (int64_t)splits * tiles * (narrow ? 64 : 128) * a.bn;
     const dim3 grid(tiles, splits);
     hipStream_t st = (hipStream_t)stream;
-    if (d->dtype == YH_F16) {
+    if (a.interleaved) {
+        if (narrow) hipLaunchKernelGGL((conv_wgrad_dma_kernel<2, 2>), grid, dim3(256), 0, st, a);
+        else if (a.bn == 256) hipLaunchKernelGGL((conv_wgrad_dma_kernel<4, 4>), grid, dim3(512), 0, st, a);
+        else hipLaunchKernelGGL((conv_wgrad_dma_kernel<4, 2>), grid, dim3(256), 0, st, a);
+    } else if (d->dtype == YH_F16) {   // splits == -1: the register-staged kernel (kept as the A/B baseline)
         if (narrow) hipLaunchKernelGGL((conv_wgrad_kernel<f16, 2>), grid, dim3(256), 0, st, a);
         else hipLaunchKernelGGL((conv_wgrad_kernel<f16, 4>), grid, dim3(256), 0, st, a);
     } else {
@@ -505,8 +733,9 @@ extern "C" int yh_conv2d_wgrad(const yh_wgrad_desc* d, void* stream) {
         if (groups > 32) groups = 32;
         const int per_group = (splits + groups - 1) / groups;
         groups = (splits + per_group - 1) / per_group;
-        if (narrow) hipLaunchKernelGGL(wgrad_reduce_kernel<2>, dim3(tiles * 8, groups), dim3(256), 0, st, a, splits, per_group);
-        else hipLaunchKernelGGL(wgrad_reduce_kernel<4>, dim3(tiles * 16, groups), dim3(256), 0, st, a, splits, per_group);
+        if (narrow) hipLaunchKernelGGL((wgrad_reduce_kernel<2, 2>), dim3(tiles * 8, groups), dim3(256), 0, st, a, splits, per_group);
+        else if (a.bn == 256) hipLaunchKernelGGL((wgrad_reduce_kernel<4, 4>), dim3(tiles * 16, groups), dim3(512), 0, st, a, splits, per_group);
+        else hipLaunchKernelGGL((wgrad_reduce_kernel<4, 2>), dim3(tiles * 16, groups), dim3(256), 0, st, a, splits, per_group);
     }
     return check_launch();
 }
@@ -516,7 +745,7 @@ extern "C" int64_t yh_conv2d_wgrad_workspace(const yh_wgrad_desc* d) {
     WgradArgs a;
     int splits;
     wgrad_geometry(d, &a, &splits);
-    return (int64_t)splits * a.tiles_m * a.tiles_n * (d->cout <= 64 ? 64 : 128) * 128;
+    return (int64_t)splits * a.tiles_m * a.tiles_n * (d->cout <= 64 ? 64 : 128) * a.bn;
 }
 
 extern "C" int yh_stem_wgrad(const yh_wgrad_desc* d, void* stream) {
