@@ -1,24 +1,31 @@
 #!/usr/bin/env python3
-"""Benchmark of the Darknet hot path on MI355X: YOLOv3-608 fp16 detection (BASELINE.json configs[1]).
+"""Benchmark of the Darknet hot path on MI355X (BASELINE.json: "images/sec YOLOv3-608 train fp16 @1/2/4/8 GPU; detect
+fp16/int8 FPS").
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--mode both|train|detect] [--precision fp16|fp32|int8]
 
-One *step* = one pass of the hot path over one batch of synthetic 608x608 frames already resident in
-HBM: Darknet forward (75 fused conv blocks, 23 residual adds, 2 routes/upsamples, 3-scale YOLO decode)
-through libyolo_hip.so + NMS at detect.py's settings (conf 0.3, iou 0.6, best class).  Weights are
-random-init YOLOv3 with non-trivial BN statistics (no network access for checkpoints).
+Default (--mode both): the headline `value` is the TRAINING step (configs[2] shape: YOLOv3-608, batch 64 per GPU, fp16
+autocast with fp32 master weights) and the detection leg (configs[1]: forward + NMS) rides along under "detect".
 
-N > 1 (launched by torch.distributed.run, one process per GPU): inference does not exchange data, so
-every rank runs the same per-GPU batch ("replicas only", weak scaling); ranks are only synchronised by
-the barrier that brackets the timed region, and the slowest rank's time is used.
+* train step = train-mode forward (batch-statistics BatchNorm) + compute_loss on synthetic labels + backward + GradScaler
+  + nesterov SGD (reference train.py:371-433), all convolution / BatchNorm / activation work on libyolo_hip.so.
+  N > 1: one process per GPU, DistributedDataParallel over RCCL, per-GPU batch fixed (weak scaling), gradients
+  all-reduced by DDP's hooks.
+* detect step = Darknet eval forward (BN folded, fused epilogues, 3-scale YOLO decode) + NMS at detect.py's settings
+  (conf 0.3, iou 0.6, best class) on a batch already resident in HBM.  N > 1: replicas only (no exchange).
 
-Rank 0 prints ONE JSON line.  Besides the driver contract it carries
-  roofline      the dominant kernel (the MFMA implicit-GEMM conv instantiation with the largest total
-                time), algorithmic conv FLOPs of the layers it ran / its summed duration measured with HIP
-                events on the launch stream (yh_plan_set_timing), against the 2.5 PFLOP/s fp16 dense peak;
-  roofline_net  whole-network conv FLOPs/s from the un-instrumented timed region;
-  cpu_baseline  the CPU oracle (torch fp32 restatement of the reference path) timed on this host's cores
-                on a bounded sample of the same workload (N = 1 only).
+Synthetic data and random-init weights (no network access).  Timing: W warm-up steps, then exactly K steps bracketed
+by barrier + synchronize on both sides, MAX over ranks (engine/distutil.py).  Rank 0 prints ONE JSON line; besides the
+driver contract it carries
+  roofline      the dominant kernel class of the measured step (per-op HIP events recorded by the native plan executor
+                on the launch stream): algorithmic conv FLOPs / summed duration against the 2.5 PFLOP/s dense fp16 peak,
+                plus the per-kernel-class table of the step;
+  roofline_net  whole-step conv FLOPs/s from the un-instrumented timed region (forward + dgrad + wgrad = 3 x 140.7 GFLOP
+                per image for training);
+  cpu_baseline  the same step on this host's cores (eager fp32 torch modules, bit-equal to the reference's) on a bounded
+                sample (N = 1 only);
+  detect        metric/value/roofline of the detection leg.
+If the training leg cannot run, the detection leg becomes the headline and "train_error" says why.
 """
 import argparse
 import ctypes as C
@@ -294,10 +301,13 @@ def train_main(args, device, dist, world, rank, local_rank):
         }
         out['roofline'] = train_roofline(eng, x, args.precision)
         out['cpu_baseline'] = None if (world > 1 or args.no_cpu_baseline) else cpu_train_baseline(args.cfg, args.cpu_seconds)
-        print(json.dumps(out))
+    else:
+        out = None
     distutil.barrier(dist)
-    if dist is not None:
-        dist.destroy_process_group()
+    core.__dict__['_hip_train_engine'] = None   # release the ~40 GB of step buffers before the next leg
+    del model, core, opt, eng
+    torch.cuda.empty_cache()
+    return out
 
 
 def train_roofline(eng, x, precision):
@@ -335,7 +345,9 @@ def train_roofline(eng, x, precision):
     ach = groups[top]['flops'] / groups[top]['ms'] / 1e9
     peak = PEAK_TFLOPS[precision]
     return {'bound': 'mfma', 'kernel': top, 'achieved': round(ach, 1), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(ach / peak, 4),
-            'traffic': None, 'gpu_ms_per_step': round(total, 3), 'by_kernel': table}
+            'traffic': None, 'launches_per_step': groups[top]['n'], 'avg_launch_ms': round(groups[top]['ms'] / groups[top]['n'], 5),
+            'gflop_per_launch': round(groups[top]['flops'] / groups[top]['n'] / 1e9, 3), 'gpu_ms_per_step': round(total, 3),
+            'by_kernel': table}
 
 
 def cpu_train_baseline(cfg, budget_s):
@@ -372,8 +384,9 @@ def main():
     ap.add_argument('--size', type=int, default=608)
     ap.add_argument('--precision', default='fp16', choices=['fp16', 'fp32', 'int8'])
     ap.add_argument('--cfg', default=os.path.join(PKG, 'cfg', 'yolov3', 'yolov3.cfg'))
-    ap.add_argument('--mode', default='detect', choices=['detect', 'train'],
-                    help='detect: forward + NMS (configs[1]); train: forward + loss + backward + SGD step (configs[2])')
+    ap.add_argument('--mode', default='both', choices=['both', 'detect', 'train'],
+                    help='train: forward + loss + backward + SGD step (BASELINE metric "train fp16", configs[2] at N GPUs); '
+                         'detect: forward + NMS (configs[1]); both (default): train is the headline value, detect rides along')
     ap.add_argument('--no-nms', action='store_true')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=12.0)
@@ -393,8 +406,37 @@ def main():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group('nccl', device_id=device)
 
-    if args.mode == 'train':
-        return train_main(args, device, dist, world, rank, local_rank)
+    out = None
+    if args.mode in ('train', 'both'):
+        try:
+            out = train_main(args, device, dist, world, rank, local_rank)
+        except (NotImplementedError, RuntimeError, MemoryError) as e:  # keep the contract: one JSON line, say what happened
+            if args.mode == 'train':
+                raise
+            train_error = '%s: %s' % (type(e).__name__, str(e)[:300])
+            torch.cuda.empty_cache()
+            det = detect_main(args, device, dist, world, rank, cpu_baseline_leg=True)
+            if rank == 0:
+                det['train_error'] = train_error
+                print(json.dumps(det))
+            if dist is not None:
+                dist.destroy_process_group()
+            return
+    if args.mode in ('detect', 'both'):
+        det = detect_main(args, device, dist, world, rank, cpu_baseline_leg=(args.mode == 'detect'))
+        if rank == 0:
+            if out is None:
+                out = det
+            else:   # the second headline metric of BASELINE.json, measured in the same run
+                out['detect'] = {k: det[k] for k in ('metric', 'value', 'unit', 'ms_per_step', 'dtype', 'config', 'roofline_net', 'roofline')}
+    if rank == 0:
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def detect_main(args, device, dist, world, rank, cpu_baseline_leg=True):
+    """configs[1]: forward + NMS on a resident synthetic batch; returns the JSON dict on rank 0 (None elsewhere)."""
     from utils.utils import non_max_suppression
     model = build_qmodel_synthetic(args.cfg, args.size, device) if args.precision == 'int8' else \
         build_model(args.cfg, args.size, args.precision, device)
@@ -438,14 +480,16 @@ def main():
                              'frac': round(net_tflops / peak, 4), 'per': 'GPU, whole step incl. NMS and host gaps'},
         }
         out['roofline'] = roofline_leg(model, x, max(3, min(args.steps, 10)), args.precision)
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and cpu_baseline_leg:
             out['cpu_baseline'] = cpu_baseline(args.cfg, args.size, args.cpu_seconds)
         else:
             out['cpu_baseline'] = None
-        print(json.dumps(out))
+    else:
+        out = None
     barrier()
-    if dist is not None:
-        dist.destroy_process_group()
+    del model
+    torch.cuda.empty_cache()
+    return out
 
 
 if __name__ == '__main__':
