@@ -371,6 +371,17 @@ typedef struct yh_cast_desc {
     const float* x; void* y; int64_t pixels; int32_t c, ldx, ldy, dtype;
 } yh_cast_desc;
 int yh_cast_f32(const yh_cast_desc* d, void* stream);
+/* Backward of yh_maxpool2d_fwd (autograd of nn.MaxPool2d, models.py:207-215): every output element adds its gradient
+ * to the FIRST maximum of its window in row-major scan order (the index torch's forward records); windows that
+ * overlap (SPP, stride 1) meet in atomics, so dx must hold zeros or an earlier contribution.  With edge_zero a
+ * window whose maximum is the implicit zero padding passes no gradient.                                            */
+typedef struct yh_pool_bwd_desc {
+    const void* x;          /* forward input, dtype, pitch ldx                                                 */
+    const void* dy;         /* gradient of the pooled output, pitch lddy                                       */
+    void* dx;               /* accumulated into, pitch lddx                                                    */
+    int32_t n, h, w_in, c, ho, wo, k, stride, pad_lo, edge_zero, ldx, lddy, lddx, dtype;
+} yh_pool_bwd_desc;
+int yh_maxpool2d_bwd(const yh_pool_bwd_desc* d, void* stream);
 /* fp32 NCHW image (n, c, h, w) -> dtype NHWC (n, h, w, ldy) with channels c..c_pad-1 written as zeros (c_pad <= ldy):
  * the first layer's weight gradient then runs on the MFMA kernel like every other layer.                          */
 int yh_nchw_to_nhwc(const float* x, void* y, int n, int c, int h, int w, int c_pad, int ldy, int dtype, void* stream);
@@ -384,7 +395,7 @@ typedef struct yh_plan yh_plan;
 enum { YH_OP_CONV = 1, YH_OP_STEM = 2, YH_OP_POOL = 3, YH_OP_COPY = 4, YH_OP_ADD = 5, YH_OP_DECODE = 6, YH_OP_DW = 7,
        YH_OP_SE = 8, YH_OP_QCOPY = 9, YH_OP_QPOOL = 10, YH_OP_QADD = 11, YH_OP_BN_STATS = 12, YH_OP_BN_FINALIZE = 13,
        YH_OP_BN_ACT_FWD = 14, YH_OP_BN_BWD_REDUCE = 15, YH_OP_BN_BWD_APPLY = 16, YH_OP_WGRAD = 17, YH_OP_STEM_WGRAD = 18,
-       YH_OP_DILATE2 = 19, YH_OP_UPSAMPLE2_BWD = 20, YH_OP_CAST_F32 = 21, YH_OP_NCHW_TO_NHWC = 22 };
+       YH_OP_DILATE2 = 19, YH_OP_UPSAMPLE2_BWD = 20, YH_OP_CAST_F32 = 21, YH_OP_NCHW_TO_NHWC = 22, YH_OP_POOL_BWD = 23 };
 typedef struct yh_layout_desc { const float* x; void* y; int32_t n, c, h, w_in, c_pad, ldy, dtype; } yh_layout_desc;
 
 yh_plan* yh_plan_create(void);

@@ -17,7 +17,7 @@ import torch.nn.functional as F
 from engine import hiplib
 from engine.hiplib import (ConvDesc, StemDesc, PoolDesc, CopyDesc, AddDesc, DecodeDesc, DwDesc, SeDesc, QCopyDesc, QPoolDesc,
                            QAddDesc, BnStatsDesc, BnFinalizeDesc, BnActFwdDesc, BnBwdReduceDesc, BnBwdApplyDesc, WgradDesc,
-                           StemWgradDesc, DilateDesc, UpsampleBwdDesc, CastDesc, LayoutDesc)
+                           StemWgradDesc, DilateDesc, UpsampleBwdDesc, CastDesc, LayoutDesc, PoolBwdDesc)
 
 _NP = {hiplib.YH_F16: np.float16, hiplib.YH_F32: np.float32, hiplib.YH_I8: np.int8}
 _DESC = {hiplib.OP_CONV: ConvDesc, hiplib.OP_STEM: StemDesc, hiplib.OP_POOL: PoolDesc, hiplib.OP_COPY: CopyDesc,
@@ -26,7 +26,7 @@ _DESC = {hiplib.OP_CONV: ConvDesc, hiplib.OP_STEM: StemDesc, hiplib.OP_POOL: Poo
          hiplib.OP_BN_STATS: BnStatsDesc, hiplib.OP_BN_FINALIZE: BnFinalizeDesc, hiplib.OP_BN_ACT_FWD: BnActFwdDesc,
          hiplib.OP_BN_BWD_REDUCE: BnBwdReduceDesc, hiplib.OP_BN_BWD_APPLY: BnBwdApplyDesc, hiplib.OP_WGRAD: WgradDesc,
          hiplib.OP_STEM_WGRAD: StemWgradDesc, hiplib.OP_DILATE2: DilateDesc, hiplib.OP_UPSAMPLE2_BWD: UpsampleBwdDesc,
-         hiplib.OP_CAST_F32: CastDesc, hiplib.OP_NCHW_TO_NHWC: LayoutDesc}
+         hiplib.OP_CAST_F32: CastDesc, hiplib.OP_NCHW_TO_NHWC: LayoutDesc, hiplib.OP_POOL_BWD: PoolBwdDesc}
 
 
 def _addr(p):
@@ -518,6 +518,24 @@ class FakeLib:
         pitched(d.y, d.n * d.h * d.w_in, d.c, d.ldy, npdt)[:] = small.reshape(-1, d.c).numpy().astype(npdt)
         return 0
 
+    def yh_maxpool2d_bwd(self, dref, stream):
+        """Autograd of the emulated forward pooling (F.max_pool2d picks the first maximum in scan order)."""
+        d = dref._obj if hasattr(dref, '_obj') else dref
+        npdt = _NP[d.dtype]
+        x = torch.from_numpy(pitched(d.x, d.n * d.h * d.w_in, d.c, d.ldx, npdt).astype(np.float32))
+        gy = torch.from_numpy(pitched(d.dy, d.n * d.ho * d.wo, d.c, d.lddy, npdt).astype(np.float32))
+        with torch.enable_grad():   # this runs inside an autograd backward, where grad mode is off
+            x = x.view(d.n, d.h, d.w_in, d.c).permute(0, 3, 1, 2).contiguous().requires_grad_()
+            if d.edge_zero:
+                y = F.max_pool2d(F.pad(x, (0, 1, 0, 1)), d.k, d.stride)
+            else:
+                y = F.max_pool2d(x, d.k, d.stride, d.pad_lo)
+            assert y.shape[2] == d.ho and y.shape[3] == d.wo
+            y.backward(gy.view(d.n, d.ho, d.wo, d.c).permute(0, 3, 1, 2))
+        out = pitched(d.dx, d.n * d.h * d.w_in, d.c, d.lddx, npdt)
+        out[:] = (out.astype(np.float32) + x.grad.permute(0, 2, 3, 1).reshape(-1, d.c).numpy()).astype(npdt)
+        return 0
+
     def yh_cast_f32(self, dref, stream):
         d = dref._obj if hasattr(dref, '_obj') else dref
         npdt = _NP[d.dtype]
@@ -568,7 +586,7 @@ class FakeLib:
                hiplib.OP_BN_BWD_APPLY: self.yh_bn_act_bwd_apply, hiplib.OP_WGRAD: self.yh_conv2d_wgrad,
                hiplib.OP_STEM_WGRAD: self.yh_stem_wgrad, hiplib.OP_DILATE2: self.yh_dilate2,
                hiplib.OP_UPSAMPLE2_BWD: self.yh_upsample2_bwd, hiplib.OP_CAST_F32: self.yh_cast_f32,
-               hiplib.OP_NCHW_TO_NHWC: self._layout}
+               hiplib.OP_NCHW_TO_NHWC: self._layout, hiplib.OP_POOL_BWD: self.yh_maxpool2d_bwd}
         for kind, desc, fixups in plan['ops'][first:last]:
             d = type(desc).from_buffer_copy(bytes(desc))
             for off, slot, boff in fixups:

@@ -17,7 +17,7 @@ import ops_harness as oh
 import synth
 import train_harness as th
 from engine import hiplib
-from engine.hiplib import ResampleDesc, CastDesc
+from engine.hiplib import ResampleDesc, CastDesc, PoolBwdDesc
 
 pytestmark = pytest.mark.gpu
 
@@ -240,6 +240,42 @@ def test_resample_and_cast_kernels(libs, code):
     assert torch.equal(outs[0][2], src32[..., :c].to(dt).float())
 
 
+@pytest.mark.parametrize('code', [F32, F16], ids=['fp32', 'fp16'])
+@pytest.mark.parametrize('case', [(2, 16, 16, 32, 2, 2, 0), (2, 13, 13, 64, 2, 1, 1), (2, 19, 19, 32, 5, 1, 0), (1, 19, 19, 16, 13, 1, 0),
+                                  (2, 15, 17, 24, 9, 1, 0)], ids=lambda c: 'n%d_%dx%d_c%d_k%ds%d_z%d' % c)
+def test_maxpool_backward_matches_autograd(libs, code, case):
+    """Gradient goes to the first maximum of each window (torch's recorded index); overlapping windows add up."""
+    lib, fake = libs
+    N, H, W, c, k, s, edge_zero = case
+    g = torch.Generator().manual_seed(k * 31 + H)
+    dt = oh.tdtype(code)
+    if edge_zero:
+        Ho, Wo, pad_lo = H, W, 0
+    else:
+        pad_lo = (k - 1) // 2 if s == 1 else 0
+        Ho, Wo = (H + 2 * pad_lo - k) // s + 1, (W + 2 * pad_lo - k) // s + 1
+    x = torch.randn(N, H, W, c + 8, generator=g).to(dt)
+    dy = torch.randn(N, Ho, Wo, c, generator=g).to(dt)
+    acc0 = torch.randn(N, H, W, c + 8, generator=g).to(dt)       # an earlier contribution already in dx
+    outs = []
+    for L, dev in ((lib, GPU), (fake, 'cpu')):
+        xd, dyd, dx = x.to(dev), dy.to(dev), acc0.to(dev).clone()
+        d = PoolBwdDesc(x=P(xd, 8), dy=P(dyd), dx=P(dx, 8), n=N, h=H, w_in=W, c=c, ho=Ho, wo=Wo, k=k, stride=s, pad_lo=pad_lo,
+                        edge_zero=edge_zero, ldx=c + 8, lddy=c, lddx=c + 8, dtype=code)
+        oh.call(L, 'yh_maxpool2d_bwd', d)
+        _sync()
+        outs.append(dx.float().cpu())
+    assert torch.equal(outs[0][..., :8], acc0[..., :8].float()), 'wrote outside the channel slice'
+    scale = outs[1].abs().max().item()
+    # fp16: packed-half atomics round after every add, in arrival order
+    assert (outs[0] - outs[1]).abs().max().item() <= (1e-5 if code == F32 else 4e-3) * scale
+    xr = x[..., 8:].float().permute(0, 3, 1, 2).requires_grad_()
+    y = F.max_pool2d(F.pad(xr, (0, 1, 0, 1)), k, s) if edge_zero else F.max_pool2d(xr, k, s, pad_lo)
+    y.backward(dy.float().permute(0, 3, 1, 2))
+    ref = xr.grad.permute(0, 2, 3, 1) + acc0[..., 8:].float()
+    assert (outs[0][..., 8:] - ref).abs().max().item() <= (1e-5 if code == F32 else 4e-3) * scale
+
+
 # ------------------------------------------------------------------------------------------ whole steps
 @pytest.fixture(scope='module')
 def mini():
@@ -307,6 +343,23 @@ def test_mini_sgd_steps_track_eager(libs, mini):
     for (k, pa), (_, pb) in zip(a.state_dict().items(), b.state_dict().items()):
         if pa.dtype.is_floating_point:
             assert (pa - pb.cpu()).abs().max().item() <= 1e-4 * (pa.abs().max().item() + 1e-3), k
+
+
+@pytest.mark.parametrize('rel', ['yolov3tiny/yolov3-tiny.cfg', 'yolov4/yolov4.cfg'], ids=['yolov3-tiny', 'yolov4'])
+def test_maxpool_graphs_train_step_against_fp64(libs, rel):
+    """yolov3-tiny (maxpools) and YOLOv4 (mish, SPP, PAN) on the GPU training path vs an fp64 eager run."""
+    cfg = os.path.join(conftest.PKG, 'cfg', rel)
+    model = th.build(cfg, 128)
+    x = synth.image_batch(4, 128, seed=0)
+    raws64, grads64, _, ws = th.eager_step(model, x, dtype=torch.float64)
+    _, grads32, _, _ = th.eager_step(model, x, ws=ws)
+    raws, grads, _ = th.engine_step(model, x, ws, 'fp32', lib=_engine_lib(), device=GPU)
+    for a, b in zip(raws, raws64):
+        assert (a - b).abs().max().item() <= 3e-4 * b.abs().max().item()
+    num = sum((grads[k] - grads64[k]).norm().item() ** 2 for k in grads64) ** 0.5
+    den = sum((grads32[k] - grads64[k]).norm().item() ** 2 for k in grads64) ** 0.5
+    tot = sum(grads64[k].norm().item() ** 2 for k in grads64) ** 0.5
+    assert num <= 4 * den + 2e-4 * tot, (num / tot, den / tot)
 
 
 def test_yolov3_train_step_against_fp64(libs):

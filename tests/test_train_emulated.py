@@ -83,11 +83,32 @@ def test_gradient_accumulation_and_stale_backward(mini):
 def test_unsupported_cfg_reports_not_implemented():
     from engine.train import TrainEngine
     from models import Darknet
-    cfg = os.path.join(conftest.PKG, 'cfg', 'yolov3tiny', 'yolov3-tiny.cfg')
+    cfg = os.path.join(conftest.PKG, 'cfg', 'yolov3-mobilenet', 'yolov3-mobilenet-coco.cfg')
     model = Darknet(cfg, (64, 64)).train()
     eng = TrainEngine(model, 'fp32', lib=fakelib.FakeLib())
-    with pytest.raises(NotImplementedError, match='pool'):
+    with pytest.raises(NotImplementedError, match='dw|se|multiples'):
         eng._get_plan(torch.zeros(1, 3, 64, 64))
+
+
+@pytest.mark.parametrize('rel,size', [('yolov3tiny/yolov3-tiny.cfg', 64), ('yolov4/yolov4.cfg', 64)], ids=['yolov3-tiny', 'yolov4'])
+def test_maxpool_and_mish_graphs_train_on_the_hip_path(rel, size):
+    """yolov3-tiny (2/2 and 2/1 zero-edge maxpools) and YOLOv4 (mish, SPP 5/9/13, PAN routes) against eager autograd.
+    Maxpool routes gradient by argmax, which flips under round-off when two window entries are within an ulp, so the
+    comparison is against an fp64 run like the deep YOLOv3 test."""
+    cfg = os.path.join(conftest.PKG, 'cfg', rel)
+    model = th.build(cfg, size)
+    x = synth.image_batch(4, size, seed=0)
+    raws64, grads64, _, ws = th.eager_step(model, x, dtype=torch.float64)
+    _, grads32, _, _ = th.eager_step(model, x, ws=ws)
+    raws, grads, m = th.engine_step(model, x, ws, 'fp32', lib=fakelib.FakeLib())
+    for a, b in zip(raws, raws64):
+        assert (a - b).abs().max().item() <= 2e-4 * b.abs().max().item()
+    num = sum((grads[k] - grads64[k]).norm().item() ** 2 for k in grads64) ** 0.5
+    den = sum((grads32[k] - grads64[k]).norm().item() ** 2 for k in grads64) ** 0.5
+    tot = sum(grads64[k].norm().item() ** 2 for k in grads64) ** 0.5
+    assert num <= 4 * den + 2e-4 * tot, (num / tot, den / tot)
+    kinds = [w.rstrip('0123456789') for w, _ in m.__dict__['_hip_train_engine']._current['bwd_ops']]
+    assert kinds.count('dpool') == (6 if 'tiny' in rel else 3)
 
 
 def test_yolov3_train_plan_against_fp64(mini):

@@ -275,6 +275,59 @@ static void sum_partials(const yh_bn_desc* d, const dim3& grid, void* stream) {
                        d->c, d->sum, d->sumsq);
 }
 
+// ------------------------------------------------------------------------------------------ maxpool backward
+__device__ __forceinline__ void atomic_add_elem(float* base, long idx, float v) { atomicAdd(base + idx, v); }
+__device__ __forceinline__ void atomic_add_elem(f16* base, long idx, float v) {
+    // packed fp16 atomic on the aligned pair that holds the element; the other half adds zero
+    typedef f16 __attribute__((ext_vector_type(2))) h2;
+    const h2 val = (idx & 1) ? h2{(f16)0.f, (f16)v} : h2{(f16)v, (f16)0.f};
+    __builtin_amdgcn_global_atomic_fadd_v2f16(reinterpret_cast<h2 __attribute__((address_space(1)))*>((uintptr_t)(base + (idx & ~1L))), val);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const yh_pool_bwd_desc d) {
+    typedef typename TV<T>::type V;
+    constexpr int VN = TV<T>::N;
+    const int cg = d.c / VN;
+    const long total = (long)d.n * d.ho * d.wo * cg;
+    const T* x = reinterpret_cast<const T*>(d.x);
+    const T* dy = reinterpret_cast<const T*>(d.dy);
+    T* dx = reinterpret_cast<T*>(d.dx);
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int g = (int)(i % cg);
+        long r = i / cg;
+        const int wo = (int)(r % d.wo);
+        r /= d.wo;
+        const int ho = (int)(r % d.ho);
+        const int n = (int)(r / d.ho);
+        float m[VN];
+        long arg[VN];
+#pragma unroll
+        for (int e = 0; e < VN; ++e) { m[e] = -INFINITY; arg[e] = -1; }
+        for (int ky = 0; ky < d.k; ++ky) {
+            const int hi = ho * d.stride - d.pad_lo + ky;
+            for (int kx = 0; kx < d.k; ++kx) {
+                const int wi = wo * d.stride - d.pad_lo + kx;
+                if ((unsigned)hi < (unsigned)d.h && (unsigned)wi < (unsigned)d.w_in) {
+                    const long pix = ((long)n * d.h + hi) * d.w_in + wi;
+                    const V v = *reinterpret_cast<const V*>(x + pix * d.ldx + g * VN);
+#pragma unroll
+                    for (int e = 0; e < VN; ++e)
+                        if ((float)v[e] > m[e]) { m[e] = (float)v[e]; arg[e] = pix; }
+                } else if (d.edge_zero && hi >= 0 && wi >= 0) {
+#pragma unroll
+                    for (int e = 0; e < VN; ++e)
+                        if (0.f > m[e]) { m[e] = 0.f; arg[e] = -1; }   // the zero padding wins: no gradient
+                }
+            }
+        }
+        const V gy = *reinterpret_cast<const V*>(dy + (((long)n * d.ho + ho) * d.wo + wo) * d.lddy + g * VN);
+#pragma unroll
+        for (int e = 0; e < VN; ++e)
+            if (arg[e] >= 0) atomic_add_elem(dx, arg[e] * d.lddx + g * VN + e, (float)gy[e]);
+    }
+}
+
 static int check_bn(const yh_bn_desc* d, bool need_dy, bool need_out) {
     if (!d || !d->z || d->pixels <= 0 || d->c <= 0) return YH_EINVAL;
     if (d->dtype != YH_F16 && d->dtype != YH_F32) return YH_EINVAL;
@@ -290,6 +343,19 @@ static int check_bn(const yh_bn_desc* d, bool need_dy, bool need_out) {
 }  // namespace yh
 
 using namespace yh;
+
+extern "C" int yh_maxpool2d_bwd(const yh_pool_bwd_desc* d, void* stream) {
+    if (!d || !d->x || !d->dy || !d->dx || d->n <= 0 || d->c <= 0 || d->k <= 0 || d->stride <= 0) return YH_EINVAL;
+    if (d->dtype != YH_F16 && d->dtype != YH_F32) return YH_EINVAL;
+    const int v = d->dtype == YH_F16 ? 8 : 4;
+    if (d->c % v || d->ldx % v || d->lddy % v || d->lddx % 2 || !aligned16(d->x) || !aligned16(d->dy) || (((uintptr_t)d->dx) & 3u)) return YH_EALIGN;
+    const long total = (long)d->n * d->ho * d->wo * (d->c / v);
+    long gsz = (total + 255) / 256;
+    const dim3 grid((unsigned)(gsz < 1 ? 1 : (gsz > 16384 ? 16384 : gsz)));
+    if (d->dtype == YH_F16) hipLaunchKernelGGL(maxpool_bwd_kernel<f16>, grid, dim3(256), 0, (hipStream_t)stream, *d);
+    else hipLaunchKernelGGL(maxpool_bwd_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, *d);
+    return check_launch();
+}
 
 extern "C" int64_t yh_bn_reduce_workspace(const yh_bn_desc* d) {
     if (!d || d->c <= 0 || d->pixels <= 0 || (d->dtype != YH_F16 && d->dtype != YH_F32)) return 0;

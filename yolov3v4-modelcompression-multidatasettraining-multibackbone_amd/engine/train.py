@@ -24,7 +24,7 @@ and the backward plan, walking the values in reverse,
     grad(input) (+)= conv(dz, W^T flipped)     yh_conv2d_fwd on the dgrad weight image (stride 2: four parity phases)
 
 Every activation, z and gradient buffer is kept for the whole step (288 GB of HBM: YOLOv3-608 batch 64 needs ~40 GB).
-Blocks this path does not lower yet (maxpool, depthwise, SE, weighted shortcuts) raise NotImplementedError at plan
+Blocks this path does not lower yet (depthwise, SE, group-split routes, weighted shortcuts) raise NotImplementedError at plan
 build; ``models.Darknet`` then keeps such cfgs on its eager torch path for training.
 """
 import ctypes as C
@@ -34,7 +34,7 @@ import torch.nn as nn
 
 from . import hiplib
 from .hiplib import (ConvDesc, StemDesc, CopyDesc, AddDesc, BnStatsDesc, BnFinalizeDesc, BnActFwdDesc, BnBwdReduceDesc,
-                     BnBwdApplyDesc, WgradDesc, StemWgradDesc, UpsampleBwdDesc, CastDesc, LayoutDesc)
+                     BnBwdApplyDesc, WgradDesc, StemWgradDesc, UpsampleBwdDesc, CastDesc, LayoutDesc, PoolDesc, PoolBwdDesc)
 from .plan import DarknetEngine, ALIGN_C, _round_up
 
 SLOT_INPUT = 0
@@ -136,7 +136,7 @@ class TrainEngine(DarknetEngine):
     # --------------------------------------------------------------------------------- plans
     def _check_supported(self, values):
         for v in values:
-            if v.kind in ('pool', 'dw', 'se', 'slice', 'qadd'):
+            if v.kind in ('dw', 'se', 'slice', 'qadd'):
                 raise NotImplementedError('HIP training path: %s blocks are not lowered yet (block %s)' % (v.kind, v.block))
             if v.kind == 'conv':
                 if v.src.kind != 'input' and (v.src.C % ALIGN_C or v.src.c_phys != v.src.C):
@@ -320,6 +320,11 @@ class TrainEngine(DarknetEngine):
                 add(fwd, plan['fwd_ops'],
                     BnActFwdDesc(**base, **bnp, out=y, ldo=v.ld, res=None if v.res is None else P(v.res.storage, v.res.c_off),
                                  ldr=0 if v.res is None else v.res.ld), 'bnact%d' % v.block)
+            elif v.kind == 'pool':
+                s = v.src
+                add(fwd, plan['fwd_ops'], PoolDesc(x=P(s.storage, s.c_off), y=y, n=N, h=s.H, w_in=s.W, c=s.c_phys, ho=v.H, wo=v.W,
+                                                   k=v.k, stride=v.stride, pad_lo=v.pad_lo, edge_zero=v.edge_zero, ldx=s.ld,
+                                                   ldy=v.ld, dtype=self.code), 'pool%d' % v.block)
             elif v.kind == 'copy':
                 s = v.src
                 add(fwd, plan['fwd_ops'], CopyDesc(x=P(s.storage, s.c_off), y=y, n=N, h=s.H, w_in=s.W, c=s.c_phys, ups=v.ups,
@@ -379,6 +384,15 @@ class TrainEngine(DarknetEngine):
                 if has_grad(v):
                     contribute(v.a, gptr(v), v.ld, None, 'dadd%d' % v.block)
                     contribute(v.b, gptr(v), v.ld, None, 'dadd%d' % v.block)
+                continue
+            if v.kind == 'pool':
+                if has_grad(v):
+                    s = v.src
+                    contribution_mode(s, False)   # scatter-add: the target must hold zeros or an earlier contribution
+                    add(bwd, plan['bwd_ops'],
+                        PoolBwdDesc(x=P(s.storage, s.c_off), dy=gptr(v), dx=gptr(s), n=N, h=s.H, w_in=s.W, c=s.c_phys, ho=v.H,
+                                    wo=v.W, k=v.k, stride=v.stride, pad_lo=v.pad_lo, edge_zero=v.edge_zero, ldx=s.ld, lddy=v.ld,
+                                    lddx=s.ld, dtype=self.code), 'dpool%d' % v.block)
                 continue
             if v.kind == 'copy':
                 if has_grad(v):
