@@ -345,6 +345,21 @@ int yh_conv_pack_weights_dgrad(int dtype, const float* w, int cout, int cin, int
  * For 3x3 / pad 1 the four phases have 1, 2, 2 and 4 taps: 9 tap-GEMMs instead of the 36 of the dilated form.      */
 int yh_conv_pack_weights_dgrad_phase(int dtype, const float* w, int cout, int cin, int kh, int kw, int pad, int a, int b,
                                      int cout_k, int m_pad, void* packed, int* kh_p, int* kw_p, void* stream);
+/* All weight images of a training step in ONE launch (the parameters change every optimizer step; 75 layers x
+ * (forward image + data-gradient image[s]) would otherwise be ~170 tiny launches).  `items` is a DEVICE array.       */
+typedef struct yh_pack_item {
+    const float* w;         /* fp32 OIHW parameter                                                              */
+    const float* bias;      /* conv bias or NULL                                                                */
+    void* packed;           /* destination image                                                                */
+    float* bias_out;        /* modes 0 and 3: fp32 bias row (zeros when bias == NULL); else NULL                */
+    int32_t mode;           /* 0 forward [m_pad][kh*kw][k_pad] (yh_conv_pack_weights without BN)                 */
+                            /* 1 data gradient [m_pad = cin rows][flipped taps][k_pad] (yh_conv_pack_weights_dgrad) */
+                            /* 2 one parity phase of a stride-2 data gradient (.._dgrad_phase, pa/pb)            */
+                            /* 3 first layer [kh*kw*cin][cout_pad] fp32 (yh_stem_pack_weights without BN)        */
+    int32_t dtype, cout, cin, kh, kw, k_pad, m_pad, pad, pa, pb, cout_pad;
+} yh_pack_item;
+int yh_pack_batch(const yh_pack_item* items, int n_items, void* stream);
+
 typedef struct yh_wgrad_desc {
     const void* x;          /* forward input of the conv, NHWC dtype (stem: NCHW fp32 image)                    */
     const void* dz;         /* gradient of the conv output, NHWC dtype, pitch lddz                              */
@@ -395,7 +410,8 @@ typedef struct yh_plan yh_plan;
 enum { YH_OP_CONV = 1, YH_OP_STEM = 2, YH_OP_POOL = 3, YH_OP_COPY = 4, YH_OP_ADD = 5, YH_OP_DECODE = 6, YH_OP_DW = 7,
        YH_OP_SE = 8, YH_OP_QCOPY = 9, YH_OP_QPOOL = 10, YH_OP_QADD = 11, YH_OP_BN_STATS = 12, YH_OP_BN_FINALIZE = 13,
        YH_OP_BN_ACT_FWD = 14, YH_OP_BN_BWD_REDUCE = 15, YH_OP_BN_BWD_APPLY = 16, YH_OP_WGRAD = 17, YH_OP_STEM_WGRAD = 18,
-       YH_OP_DILATE2 = 19, YH_OP_UPSAMPLE2_BWD = 20, YH_OP_CAST_F32 = 21, YH_OP_NCHW_TO_NHWC = 22, YH_OP_POOL_BWD = 23 };
+       YH_OP_DILATE2 = 19, YH_OP_UPSAMPLE2_BWD = 20, YH_OP_CAST_F32 = 21, YH_OP_NCHW_TO_NHWC = 22, YH_OP_POOL_BWD = 23, YH_OP_PACK_BATCH = 24 };
+typedef struct yh_pack_batch_desc { const yh_pack_item* items; int32_t n_items; } yh_pack_batch_desc;
 typedef struct yh_layout_desc { const float* x; void* y; int32_t n, c, h, w_in, c_pad, ldy, dtype; } yh_layout_desc;
 
 yh_plan* yh_plan_create(void);

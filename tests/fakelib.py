@@ -17,7 +17,7 @@ import torch.nn.functional as F
 from engine import hiplib
 from engine.hiplib import (ConvDesc, StemDesc, PoolDesc, CopyDesc, AddDesc, DecodeDesc, DwDesc, SeDesc, QCopyDesc, QPoolDesc,
                            QAddDesc, BnStatsDesc, BnFinalizeDesc, BnActFwdDesc, BnBwdReduceDesc, BnBwdApplyDesc, WgradDesc,
-                           StemWgradDesc, DilateDesc, UpsampleBwdDesc, CastDesc, LayoutDesc, PoolBwdDesc)
+                           StemWgradDesc, DilateDesc, UpsampleBwdDesc, CastDesc, LayoutDesc, PoolBwdDesc, PackBatchDesc, PackItem)
 
 _NP = {hiplib.YH_F16: np.float16, hiplib.YH_F32: np.float32, hiplib.YH_I8: np.int8}
 _DESC = {hiplib.OP_CONV: ConvDesc, hiplib.OP_STEM: StemDesc, hiplib.OP_POOL: PoolDesc, hiplib.OP_COPY: CopyDesc,
@@ -26,7 +26,7 @@ _DESC = {hiplib.OP_CONV: ConvDesc, hiplib.OP_STEM: StemDesc, hiplib.OP_POOL: Poo
          hiplib.OP_BN_STATS: BnStatsDesc, hiplib.OP_BN_FINALIZE: BnFinalizeDesc, hiplib.OP_BN_ACT_FWD: BnActFwdDesc,
          hiplib.OP_BN_BWD_REDUCE: BnBwdReduceDesc, hiplib.OP_BN_BWD_APPLY: BnBwdApplyDesc, hiplib.OP_WGRAD: WgradDesc,
          hiplib.OP_STEM_WGRAD: StemWgradDesc, hiplib.OP_DILATE2: DilateDesc, hiplib.OP_UPSAMPLE2_BWD: UpsampleBwdDesc,
-         hiplib.OP_CAST_F32: CastDesc, hiplib.OP_NCHW_TO_NHWC: LayoutDesc, hiplib.OP_POOL_BWD: PoolBwdDesc}
+         hiplib.OP_CAST_F32: CastDesc, hiplib.OP_NCHW_TO_NHWC: LayoutDesc, hiplib.OP_POOL_BWD: PoolBwdDesc, hiplib.OP_PACK_BATCH: PackBatchDesc}
 
 
 def _addr(p):
@@ -447,6 +447,25 @@ class FakeLib:
                 (ptr._obj if hasattr(ptr, '_obj') else ptr.contents).value = val
         return 0
 
+    def yh_pack_batch(self, items, n_items, stream):
+        """The batched packer = the single-layer packers applied to every item of the (host-resident) table."""
+        arr = (PackItem * n_items).from_address(_addr(items))
+        for it in arr:
+            if it.mode == 0:
+                rc = self.yh_conv_pack_weights(it.dtype, it.w, it.bias, None, None, None, None, 0.0, None, it.cout, it.cin, it.kh,
+                                               it.kw, it.k_pad, it.m_pad, it.packed, it.bias_out, stream)
+            elif it.mode == 1:
+                rc = self.yh_conv_pack_weights_dgrad(it.dtype, it.w, it.cout, it.cin, it.kh, it.kw, it.k_pad, it.m_pad, it.packed,
+                                                     stream)
+            elif it.mode == 2:
+                rc = self.yh_conv_pack_weights_dgrad_phase(it.dtype, it.w, it.cout, it.cin, it.kh, it.kw, it.pad, it.pa, it.pb,
+                                                           it.k_pad, it.m_pad, it.packed, None, None, stream)
+            else:
+                rc = self.yh_stem_pack_weights(it.w, it.bias, None, None, None, None, 0.0, it.cout, it.cin, it.kh, it.kw,
+                                               it.cout_pad, it.packed, it.bias_out, stream)
+            assert rc == 0
+        return 0
+
     def yh_conv2d_wgrad_workspace(self, dref):
         return 0
 
@@ -586,7 +605,8 @@ class FakeLib:
                hiplib.OP_BN_BWD_APPLY: self.yh_bn_act_bwd_apply, hiplib.OP_WGRAD: self.yh_conv2d_wgrad,
                hiplib.OP_STEM_WGRAD: self.yh_stem_wgrad, hiplib.OP_DILATE2: self.yh_dilate2,
                hiplib.OP_UPSAMPLE2_BWD: self.yh_upsample2_bwd, hiplib.OP_CAST_F32: self.yh_cast_f32,
-               hiplib.OP_NCHW_TO_NHWC: self._layout, hiplib.OP_POOL_BWD: self.yh_maxpool2d_bwd}
+               hiplib.OP_NCHW_TO_NHWC: self._layout, hiplib.OP_POOL_BWD: self.yh_maxpool2d_bwd,
+               hiplib.OP_PACK_BATCH: lambda d, st: self.yh_pack_batch(d.items, d.n_items, st)}
         for kind, desc, fixups in plan['ops'][first:last]:
             d = type(desc).from_buffer_copy(bytes(desc))
             for off, slot, boff in fixups:

@@ -267,13 +267,74 @@ def test_maxpool_backward_matches_autograd(libs, code, case):
         outs.append(dx.float().cpu())
     assert torch.equal(outs[0][..., :8], acc0[..., :8].float()), 'wrote outside the channel slice'
     scale = outs[1].abs().max().item()
-    # fp16: packed-half atomics round after every add, in arrival order
-    assert (outs[0] - outs[1]).abs().max().item() <= (1e-5 if code == F32 else 4e-3) * scale
+    # fp16: packed-half atomics round after every add, in arrival order (up to k*k adds meet in one element)
+    tol16 = 4e-3 if k <= 5 else 2e-2
+    assert (outs[0] - outs[1]).abs().max().item() <= (1e-5 if code == F32 else tol16) * scale
     xr = x[..., 8:].float().permute(0, 3, 1, 2).requires_grad_()
     y = F.max_pool2d(F.pad(xr, (0, 1, 0, 1)), k, s) if edge_zero else F.max_pool2d(xr, k, s, pad_lo)
     y.backward(dy.float().permute(0, 3, 1, 2))
     ref = xr.grad.permute(0, 2, 3, 1) + acc0[..., 8:].float()
-    assert (outs[0][..., 8:] - ref).abs().max().item() <= (1e-5 if code == F32 else 4e-3) * scale
+    assert (outs[0][..., 8:] - ref).abs().max().item() <= (1e-5 if code == F32 else tol16) * scale
+
+
+@pytest.mark.parametrize('code', [F32, F16], ids=['fp32', 'fp16'])
+def test_pack_batch_equals_single_layer_packers(libs, code):
+    """One launch for every weight image of the step == the per-layer entry points, bit for bit."""
+    import ctypes as C
+    from engine.hiplib import PackItem
+    lib, _ = libs
+    g = torch.Generator().manual_seed(17)
+    dt = oh.tdtype(code)
+    kstep = 32 if code == F16 else 16
+    w1 = torch.randn(40, 24, 3, 3, generator=g).to(GPU)          # stride-1 layer: forward + dgrad image
+    w2 = torch.randn(64, 40, 3, 3, generator=g).to(GPU)          # stride-2 layer: forward + four phases
+    b2 = torch.randn(64, generator=g).to(GPU)
+    w0 = torch.randn(32, 3, 3, 3, generator=g).to(GPU)           # first layer
+    keep, items, singles = [], [], []
+
+    def buf(n, dtype=dt, fill=7.0):
+        t = torch.full((n,), fill, device=GPU, dtype=dtype)
+        keep.append(t)
+        return t
+
+    def both(n, dtype=dt):
+        return buf(n, dtype), buf(n, dtype)
+    for w, bias, stride in ((w1, None, 1), (w2, b2, 2)):
+        cout, cin, k, _ = w.shape
+        cin_k, m_pad = oh.round_up(oh.round_up(cin, 8), kstep), oh.round_up(oh.round_up(cout, 8), 128)
+        cout_k, dm_pad = oh.round_up(oh.round_up(cout, 8), kstep), oh.round_up(oh.round_up(cin, 8), 128)
+        pa, pb = both(m_pad * 9 * cin_k)
+        ba, bb = both(m_pad, torch.float32)
+        geo = dict(dtype=code, cout=cout, cin=cin, kh=3, kw=3, pad=1)
+        items.append(PackItem(w=P(w), bias=P(bias), packed=P(pa), bias_out=P(ba), mode=0, k_pad=cin_k, m_pad=m_pad, **geo))
+        assert lib.yh_conv_pack_weights(code, P(w), P(bias), None, None, None, None, 0.0, None, cout, cin, 3, 3, cin_k, m_pad, P(pb),
+                                        P(bb), oh.stream()) == 0
+        singles += [(pa, pb), (ba, bb)]
+        if stride == 1:
+            da, db = both(dm_pad * 9 * cout_k)
+            items.append(PackItem(w=P(w), packed=P(da), mode=1, k_pad=cout_k, m_pad=dm_pad, **geo))
+            assert lib.yh_conv_pack_weights_dgrad(code, P(w), cout, cin, 3, 3, cout_k, dm_pad, P(db), oh.stream()) == 0
+            singles.append((da, db))
+        else:
+            for a in (0, 1):
+                for b in (0, 1):
+                    taps = ((a + 1) // 2 + 1) * ((b + 1) // 2 + 1)
+                    da, db = both(dm_pad * taps * cout_k)
+                    items.append(PackItem(w=P(w), packed=P(da), mode=2, k_pad=cout_k, m_pad=dm_pad, pa=a, pb=b, **geo))
+                    assert lib.yh_conv_pack_weights_dgrad_phase(code, P(w), cout, cin, 3, 3, 1, a, b, cout_k, dm_pad, P(db), None, None,
+                                                                oh.stream()) == 0
+                    singles.append((da, db))
+    sa, sb = both(27 * 32, torch.float32)
+    sba, sbb = both(32, torch.float32)
+    items.append(PackItem(w=P(w0), packed=P(sa), bias_out=P(sba), mode=3, dtype=code, cout=32, cin=3, kh=3, kw=3, pad=1, cout_pad=32))
+    assert lib.yh_stem_pack_weights(P(w0), None, None, None, None, None, 0.0, 32, 3, 3, 3, 32, P(sb), P(sbb), oh.stream()) == 0
+    singles += [(sa, sb), (sba, sbb)]
+    arr = (PackItem * len(items))(*items)
+    table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(GPU)
+    assert lib.yh_pack_batch(P(table), len(items), oh.stream()) == 0
+    _sync()
+    for k, (a, b) in enumerate(singles):
+        assert torch.equal(a, b), 'image %d differs' % k
 
 
 # ------------------------------------------------------------------------------------------ whole steps

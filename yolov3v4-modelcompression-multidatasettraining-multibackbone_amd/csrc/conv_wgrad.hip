@@ -582,6 +582,62 @@ __global__ void pack_dgrad_phase_kernel(const float* w, int cout, int cin, int k
     }
 }
 
+// every weight image of the step: blockIdx.y = item, blockIdx.x strides over the destination elements (gather form: padding
+// rows / columns are written as zeros, no memset)
+template <typename T>
+__device__ __forceinline__ void pack_item_elems(const yh_pack_item& it) {
+    T* out = reinterpret_cast<T*>(it.packed);
+    const int taps = it.kh * it.kw;
+    if (it.mode == 0) {
+        const long total = (long)it.m_pad * taps * it.k_pad;
+        for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+            const int c = (int)(i % it.k_pad);
+            const long r = i / it.k_pad;
+            const int tap = (int)(r % taps), m = (int)(r / taps);
+            out[i] = (m < it.cout && c < it.cin) ? (T)it.w[((long)m * it.cin + c) * taps + tap] : (T)0.f;
+        }
+    } else {
+        const int khp = it.mode == 2 ? (it.pa + it.pad) / 2 + 1 : it.kh, kwp = it.mode == 2 ? (it.pb + it.pad) / 2 + 1 : it.kw;
+        const long total = (long)it.m_pad * khp * kwp * it.k_pad;
+        for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+            const int co = (int)(i % it.k_pad);
+            const long r = i / it.k_pad;
+            const int tap = (int)(r % (khp * kwp)), ci = (int)(r / (khp * kwp));
+            int fr, fs;
+            if (it.mode == 2) { fr = it.pa + it.pad - 2 * (tap / kwp); fs = it.pb + it.pad - 2 * (tap % kwp); }
+            else { fr = it.kh - 1 - tap / it.kw; fs = it.kw - 1 - tap % it.kw; }
+            float v = 0.f;
+            if (ci < it.cin && co < it.cout && fr >= 0 && fr < it.kh && fs >= 0 && fs < it.kw)
+                v = it.w[(((long)co * it.cin + ci) * it.kh + fr) * it.kw + fs];
+            out[i] = (T)v;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void pack_batch_kernel(const yh_pack_item* items) {
+    const yh_pack_item it = items[blockIdx.y];
+    const int taps = it.kh * it.kw;
+    if (it.mode == 3) {
+        float* out = reinterpret_cast<float*>(it.packed);
+        const long total = (long)taps * it.cin * it.cout_pad;
+        for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+            const int co = (int)(i % it.cout_pad);
+            const long r = i / it.cout_pad;
+            const int ci = (int)(r % it.cin), tap = (int)(r / it.cin);
+            out[i] = co < it.cout ? it.w[((long)co * it.cin + ci) * taps + tap] : 0.f;
+        }
+    } else if (it.dtype == YH_F16) {
+        pack_item_elems<f16>(it);
+    } else {
+        pack_item_elems<float>(it);
+    }
+    if (it.bias_out) {
+        const int nb = it.mode == 3 ? it.cout_pad : it.m_pad;
+        for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nb; i += gridDim.x * blockDim.x)
+            it.bias_out[i] = (it.bias && i < it.cout) ? it.bias[i] : 0.f;
+    }
+}
+
 template <typename T, bool SCATTER>
 __global__ void resample2_kernel(const yh_resample_desc d) {
     typedef typename WG<T>::vec V;
@@ -699,6 +755,12 @@ extern "C" int yh_conv_pack_weights_dgrad_phase(int dtype, const float* w, int c
         hipLaunchKernelGGL(pack_dgrad_phase_kernel<float>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, w, cout, cin,
                            kh, kw, pad, pa, pb, khp, kwp, cout_k, m_pad, (float*)packed);
     else return YH_EINVAL;
+    return check_launch();
+}
+
+extern "C" int yh_pack_batch(const yh_pack_item* items, int n_items, void* stream) {
+    if (!items || n_items <= 0 || n_items > 65535) return YH_EINVAL;
+    hipLaunchKernelGGL(pack_batch_kernel, dim3(128, n_items), dim3(256), 0, (hipStream_t)stream, items);
     return check_launch();
 }
 

@@ -27,6 +27,7 @@ union AnyDesc {
     yh_cast_desc cast;
     yh_layout_desc layout;
     yh_pool_bwd_desc pool_bwd;
+    yh_pack_batch_desc pack_batch;
 };
 
 struct Fixup {
@@ -61,6 +62,7 @@ size_t desc_size(int kind) {
         case YH_OP_CAST_F32: return sizeof(yh_cast_desc);
         case YH_OP_NCHW_TO_NHWC: return sizeof(yh_layout_desc);
         case YH_OP_POOL_BWD: return sizeof(yh_pool_bwd_desc);
+        case YH_OP_PACK_BATCH: return sizeof(yh_pack_batch_desc);
         default: return 0;
     }
 }
@@ -89,6 +91,7 @@ int launch(int kind, const AnyDesc& d, void* stream) {
         case YH_OP_UPSAMPLE2_BWD: return yh_upsample2_bwd(&d.resample, stream);
         case YH_OP_CAST_F32: return yh_cast_f32(&d.cast, stream);
         case YH_OP_POOL_BWD: return yh_maxpool2d_bwd(&d.pool_bwd, stream);
+        case YH_OP_PACK_BATCH: return yh_pack_batch(d.pack_batch.items, d.pack_batch.n_items, stream);
         case YH_OP_NCHW_TO_NHWC:
             return yh_nchw_to_nhwc(d.layout.x, d.layout.y, d.layout.n, d.layout.c, d.layout.h, d.layout.w_in, d.layout.c_pad,
                                    d.layout.ldy, d.layout.dtype, stream);

@@ -153,16 +153,26 @@ class PoolBwdDesc(C.Structure):
                 ('dtype', _i32)]
 
 
+class PackItem(C.Structure):
+    _fields_ = [('w', _vp), ('bias', _vp), ('packed', _vp), ('bias_out', _vp),
+                ('mode', _i32), ('dtype', _i32), ('cout', _i32), ('cin', _i32), ('kh', _i32), ('kw', _i32), ('k_pad', _i32),
+                ('m_pad', _i32), ('pad', _i32), ('pa', _i32), ('pb', _i32), ('cout_pad', _i32)]
+
+
+class PackBatchDesc(C.Structure):
+    _fields_ = [('items', _vp), ('n_items', _i32)]
+
+
 class CastDesc(C.Structure):
     _fields_ = [('x', _vp), ('y', _vp), ('pixels', _i64), ('c', _i32), ('ldx', _i32), ('ldy', _i32), ('dtype', _i32)]
 
 
 OP_BN_STATS, OP_BN_FINALIZE, OP_BN_ACT_FWD, OP_BN_BWD_REDUCE, OP_BN_BWD_APPLY = 12, 13, 14, 15, 16
-OP_WGRAD, OP_STEM_WGRAD, OP_DILATE2, OP_UPSAMPLE2_BWD, OP_CAST_F32, OP_NCHW_TO_NHWC, OP_POOL_BWD = 17, 18, 19, 20, 21, 22, 23
+OP_WGRAD, OP_STEM_WGRAD, OP_DILATE2, OP_UPSAMPLE2_BWD, OP_CAST_F32, OP_NCHW_TO_NHWC, OP_POOL_BWD, OP_PACK_BATCH = 17, 18, 19, 20, 21, 22, 23, 24
 
 OP_KIND = {BnStatsDesc: OP_BN_STATS, BnFinalizeDesc: OP_BN_FINALIZE, BnActFwdDesc: OP_BN_ACT_FWD,
            BnBwdReduceDesc: OP_BN_BWD_REDUCE, BnBwdApplyDesc: OP_BN_BWD_APPLY, WgradDesc: OP_WGRAD,
-           StemWgradDesc: OP_STEM_WGRAD, DilateDesc: OP_DILATE2, UpsampleBwdDesc: OP_UPSAMPLE2_BWD, CastDesc: OP_CAST_F32, LayoutDesc: OP_NCHW_TO_NHWC, PoolBwdDesc: OP_POOL_BWD,
+           StemWgradDesc: OP_STEM_WGRAD, DilateDesc: OP_DILATE2, UpsampleBwdDesc: OP_UPSAMPLE2_BWD, CastDesc: OP_CAST_F32, LayoutDesc: OP_NCHW_TO_NHWC, PoolBwdDesc: OP_POOL_BWD, PackBatchDesc: OP_PACK_BATCH,
            ConvDesc: OP_CONV, StemDesc: OP_STEM, PoolDesc: OP_POOL, CopyDesc: OP_COPY, AddDesc: OP_ADD,
            DecodeDesc: OP_DECODE, DwDesc: OP_DW, SeDesc: OP_SE, QCopyDesc: OP_QCOPY, QPoolDesc: OP_QPOOL, QAddDesc: OP_QADD}
 
@@ -208,6 +218,7 @@ _SIGNATURES = {
     'yh_upsample2_bwd': (C.c_int, [C.POINTER(ResampleDesc), _vp]),
     'yh_cast_f32': (C.c_int, [C.POINTER(CastDesc), _vp]),
     'yh_maxpool2d_bwd': (C.c_int, [C.POINTER(PoolBwdDesc), _vp]),
+    'yh_pack_batch': (C.c_int, [_vp, C.c_int, _vp]),
     'yh_nchw_to_nhwc': (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
     'yh_plan_create': (_vp, []),
     'yh_plan_destroy': (None, [_vp]),

@@ -34,7 +34,7 @@ import torch.nn as nn
 
 from . import hiplib
 from .hiplib import (ConvDesc, StemDesc, CopyDesc, AddDesc, BnStatsDesc, BnFinalizeDesc, BnActFwdDesc, BnBwdReduceDesc,
-                     BnBwdApplyDesc, WgradDesc, StemWgradDesc, UpsampleBwdDesc, CastDesc, LayoutDesc, PoolDesc, PoolBwdDesc)
+                     BnBwdApplyDesc, WgradDesc, StemWgradDesc, UpsampleBwdDesc, CastDesc, LayoutDesc, PoolDesc, PoolBwdDesc, PackItem, PackBatchDesc)
 from .plan import DarknetEngine, ALIGN_C, _round_up
 
 SLOT_INPUT = 0
@@ -94,41 +94,44 @@ class TrainEngine(DarknetEngine):
         return out
 
     # --------------------------------------------------------------------------------- weights
-    def _pack_train(self, plan):
-        """fp32 parameters -> forward weight image (plain cast, no BN fold) and dgrad image (transposed, flipped)."""
-        P, lib = hiplib.ptr, self.lib
-        keep = []
+    def _pack_items(self, plan):
+        """Host image of the yh_pack_item table: every weight image of the step (forward, data gradient or its four
+        stride-2 phases, first layer) straight from the live fp32 parameters."""
+        items = []
+        P = hiplib.ptr
         for v in plan['values']:
             if v.kind != 'conv':
                 continue
-            conv = v.conv
-            w = conv.weight.detach()
-            if w.dtype != torch.float32 or not w.is_contiguous():
-                w = w.float().contiguous()
-                keep.append(w)
-            cb = None
-            if conv.bias is not None:
-                cb = conv.bias.detach().float().contiguous()
-                keep.append(cb)
-            pk = v.tpack
+            conv, pk = v.conv, v.tpack
+            for t in (conv.weight, conv.bias):
+                if t is not None and (t.dtype != torch.float32 or not t.is_contiguous()):
+                    raise NotImplementedError('HIP training path: parameters must be contiguous fp32 (master weights)')
+            w, cb = P(conv.weight), P(conv.bias)
+            geo = dict(dtype=self.code, cout=v.C, cin=conv.in_channels, kh=v.k, kw=v.k, pad=v.pad)
             if v.src.kind == 'input':
-                rc = lib.yh_stem_pack_weights(P(w), P(cb), None, None, None, None, 0.0, v.C, v.src.C, v.k, v.k, pk['cout_pad'],
-                                              P(pk['w']), P(pk['b']), hiplib.stream_ptr())
-                hiplib.check(rc, 'yh_stem_pack_weights')
+                items.append(PackItem(w=w, bias=cb, packed=P(pk['w']), bias_out=P(pk['b']), mode=3, cout_pad=pk['cout_pad'], **geo))
                 continue
-            rc = lib.yh_conv_pack_weights(self.code, P(w), P(cb), None, None, None, None, 0.0, None, v.C, conv.in_channels,
-                                          v.k, v.k, pk['cin_k'], pk['m_pad'], P(pk['w']), P(pk['b']), hiplib.stream_ptr())
-            hiplib.check(rc, 'yh_conv_pack_weights')
-            if v.stride == 2:   # four parity phases instead of one dilated pass
+            items.append(PackItem(w=w, bias=cb, packed=P(pk['w']), bias_out=P(pk['b']), mode=0, k_pad=pk['cin_k'], m_pad=pk['m_pad'],
+                                  **geo))
+            if v.stride == 2:
                 for (a, b), img in zip(((0, 0), (0, 1), (1, 0), (1, 1)), pk['wt_phase']):
-                    rc = lib.yh_conv_pack_weights_dgrad_phase(self.code, P(w), v.C, conv.in_channels, v.k, v.k, v.pad, a, b,
-                                                              pk['cout_k'], pk['dm_pad'], P(img), None, None, hiplib.stream_ptr())
-                    hiplib.check(rc, 'yh_conv_pack_weights_dgrad_phase')
-                continue
-            rc = lib.yh_conv_pack_weights_dgrad(self.code, P(w), v.C, conv.in_channels, v.k, v.k, pk['cout_k'], pk['dm_pad'],
-                                                P(pk['wt']), hiplib.stream_ptr())
-            hiplib.check(rc, 'yh_conv_pack_weights_dgrad')
-        plan['keep'] = keep
+                    items.append(PackItem(w=w, packed=P(img), mode=2, k_pad=pk['cout_k'], m_pad=pk['dm_pad'], pa=a, pb=b, **geo))
+            else:
+                items.append(PackItem(w=w, packed=P(pk['wt']), mode=1, k_pad=pk['cout_k'], m_pad=pk['dm_pad'], **geo))
+        arr = (PackItem * len(items))(*items)
+        return bytes(arr), len(items)
+
+    def _refresh_pack_table(self, plan):
+        """(Re)write the device table when a parameter moved (plan build, ``param.data = ...``)."""
+        ptrs = tuple(t.data_ptr() for t in self.parameters())
+        if plan.get('pack_ptrs') == ptrs:
+            return
+        raw, n = self._pack_items(plan)
+        host = torch.frombuffer(bytearray(raw), dtype=torch.uint8)
+        if plan.get('pack_table') is None or plan['pack_table'].numel() != host.numel():
+            raise RuntimeError('pack table size changed: rebuild the plan')
+        plan['pack_table'].copy_(host)
+        plan['pack_ptrs'] = ptrs
 
     def _weight_signature(self):
         return tuple((t.data_ptr(), t._version) for t in self.parameters())
@@ -267,6 +270,11 @@ class TrainEngine(DarknetEngine):
         dz_elems = max(N * v.Ho * v.Wo * v.c_phys for v in values if v.kind == 'conv')
         dz_scratch = alloc((dz_elems,))
         head_index = {id(h.src): k for k, h in enumerate(heads)}
+
+        raw, n_items = self._pack_items(plan)
+        plan['pack_table'] = torch.zeros(len(raw), device=dev, dtype=torch.uint8)
+        plan['storages'].append(plan['pack_table'])
+        add(fwd, plan['fwd_ops'], PackBatchDesc(items=plan['pack_table'].data_ptr(), n_items=n_items), 'pack')
 
         # ---- pass 2: forward ops
         for v in values:
@@ -522,10 +530,7 @@ class TrainEngine(DarknetEngine):
         if x.dtype != torch.float32:
             x = x.float()
         plan = self._get_plan(x)
-        sig = self._weight_signature()
-        if sig != self._wsig or plan.get('packed_for') != sig:
-            self._pack_train(plan)
-            self._wsig = plan['packed_for'] = sig
+        self._refresh_pack_table(plan)   # the packing itself is op 0 of the forward plan (one launch)
         lib = self.lib
         plan['stats'].buf.zero_()
         heads = [torch.empty(shape, device=x.device, dtype=torch.float32) for shape in plan['head_shapes']]
