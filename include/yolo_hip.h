@@ -345,6 +345,37 @@ int yh_conv_pack_weights_dgrad(int dtype, const float* w, int cout, int cin, int
  * For 3x3 / pad 1 the four phases have 1, 2, 2 and 4 taps: 9 tap-GEMMs instead of the 36 of the dilated form.      */
 int yh_conv_pack_weights_dgrad_phase(int dtype, const float* w, int cout, int cin, int kh, int kw, int pad, int a, int b,
                                      int cout_k, int m_pad, void* packed, int* kh_p, int* kw_p, void* stream);
+/* ---------------------------------------------------------------------------------------------------
+ * compute_loss (utils/utils.py:368-432) and its gradient on the raw head tensors, fl_gamma == 0, mean reduction:
+ *   lbox = giou_gain * sum_heads mean_i (1 - GIoU(box(ps_i), tbox_i))
+ *   lobj = obj_gain  * sum_heads mean_cells BCE(p[..., 4], tobj),  tobj = (1 - gr) + gr * max(GIoU, 0) at matched cells
+ *   lcls = cls_gain  * sum_heads mean_{i, c} BCE(ps_i[5 + c], cp if c == tcls_i else cn)          (nc > 1 only)
+ * with box(ps) = (sigmoid(ps[0:2]), min(exp(ps[2:4]), 1e3) * anchor).  The target assignment (build_targets,
+ * utils.py:725-779) stays on the host side of the ABI and arrives as the matched lists below.  Raw tensors are
+ * addressed through element strides, so the (bs, na, ny, nx, no) views of NHWC head buffers are read in place.
+ *
+ *  yh_yolo_loss_fwd   fills tobj (caller zeroes it) and adds the three un-normalised sums to sums[0..2]
+ *                     (caller zeroes; lbox: sum (1 - giou), lobj: sum bce, lcls: sum bce) for one head.
+ *  yh_yolo_loss_bwd   writes d(loss)/d(p) for EVERY logical element of the head (zeros included) scaled by *scale
+ *                     (device scalar: autograd's grad_output), gradient tensor addressed by its own strides.       */
+typedef struct yh_loss_desc {
+    const float* p;             /* raw head, element (b, a, y, x, o) at p + b*sb + a*sa + y*sy + x*sx + o          */
+    float* grad;                /* bwd only, same indexing with gb, ga, gy, gx                                       */
+    float* tobj;                /* (bs, na, ny, nx) dense fp32                                                       */
+    const int32_t* idx;         /* (nb, 4): image, anchor, gy, gx                                                    */
+    const float* tbox;          /* (nb, 4): cell-relative xy, grid-unit wh                                           */
+    const int32_t* tcls;        /* (nb)                                                                              */
+    const float* anchor;        /* (nb, 2): matched anchor wh in grid units                                          */
+    float* sums;                /* fwd: [3] accumulators                                                             */
+    const float* scale;         /* bwd: device scalar multiplied into every gradient                                 */
+    int64_t sb, sa, sy, sx, gb, ga, gy, gx;
+    int32_t bs, na, ny, nx, no, nc, nb;
+    float gr, cp, cn, cls_pw, obj_pw;
+    float w_box, w_obj, w_cls;  /* bwd: giou_gain / nb, obj_gain / cells, cls_gain / (nb * nc)                       */
+} yh_loss_desc;
+int yh_yolo_loss_fwd(const yh_loss_desc* d, void* stream);
+int yh_yolo_loss_bwd(const yh_loss_desc* d, void* stream);
+
 /* All weight images of a training step in ONE launch (the parameters change every optimizer step; 75 layers x
  * (forward image + data-gradient image[s]) would otherwise be ~170 tiny launches).  `items` is a DEVICE array.       */
 typedef struct yh_pack_item {

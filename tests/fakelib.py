@@ -447,6 +447,69 @@ class FakeLib:
                 (ptr._obj if hasattr(ptr, '_obj') else ptr.contents).value = val
         return 0
 
+    # ---- fused loss
+    @staticmethod
+    def _loss_view(ptr, d, sb, sa, sy, sx):
+        """Strided numpy view (bs, na, ny, nx, no) of a raw head / its gradient at a host address."""
+        n = (d.bs - 1) * sb + (d.na - 1) * sa + (d.ny - 1) * sy + (d.nx - 1) * sx + d.no
+        base = flat(ptr, n, np.float32)
+        return np.lib.stride_tricks.as_strided(base, shape=(d.bs, d.na, d.ny, d.nx, d.no),
+                                               strides=(4 * sb, 4 * sa, 4 * sy, 4 * sx, 4), writeable=True)
+
+    def _loss_terms(self, d, p):
+        """(sum (1 - giou), sum obj bce, sum cls bce, tobj) of one head in torch, differentiable in p."""
+        tobj = torch.zeros(d.bs, d.na, d.ny, d.nx)
+        lbox = p.sum() * 0
+        lcls = p.sum() * 0
+        if d.nb:
+            idx = torch.from_numpy(flat(d.idx, 4 * d.nb, np.int32).reshape(d.nb, 4).astype(np.int64))
+            tbox = torch.from_numpy(flat(d.tbox, 4 * d.nb, np.float32).reshape(d.nb, 4).copy())
+            anc = torch.from_numpy(flat(d.anchor, 2 * d.nb, np.float32).reshape(d.nb, 2).copy())
+            b, a, gj, gi = idx.t()
+            ps = p[b, a, gj, gi]
+            pxy = torch.sigmoid(ps[:, 0:2])
+            pwh = torch.exp(ps[:, 2:4]).clamp(max=1e3) * anc
+            pb = torch.cat((pxy, pwh), 1)
+            ax1, ax2 = pb[:, 0] - pb[:, 2] / 2, pb[:, 0] + pb[:, 2] / 2
+            ay1, ay2 = pb[:, 1] - pb[:, 3] / 2, pb[:, 1] + pb[:, 3] / 2
+            bx1, bx2 = tbox[:, 0] - tbox[:, 2] / 2, tbox[:, 0] + tbox[:, 2] / 2
+            by1, by2 = tbox[:, 1] - tbox[:, 3] / 2, tbox[:, 1] + tbox[:, 3] / 2
+            inter = (torch.min(ax2, bx2) - torch.max(ax1, bx1)).clamp(0) * (torch.min(ay2, by2) - torch.max(ay1, by1)).clamp(0)
+            union = ((ax2 - ax1) * (ay2 - ay1) + 1e-16) + (bx2 - bx1) * (by2 - by1) - inter
+            iou = inter / union
+            hull = (torch.max(ax2, bx2) - torch.min(ax1, bx1)) * (torch.max(ay2, by2) - torch.min(ay1, by1)) + 1e-16
+            giou = iou - (hull - union) / hull
+            lbox = (1.0 - giou).sum()
+            tobj[b, a, gj, gi] = (1.0 - d.gr) + d.gr * giou.detach().clamp(0)
+            if d.nc > 1:
+                tcls = torch.from_numpy(flat(d.tcls, d.nb, np.int32).astype(np.int64))
+                t = torch.full_like(ps[:, 5:], d.cn)
+                t[range(d.nb), tcls] = d.cp
+                lcls = F.binary_cross_entropy_with_logits(ps[:, 5:], t, pos_weight=torch.tensor([d.cls_pw]), reduction='sum')
+        lobj = F.binary_cross_entropy_with_logits(p[..., 4], tobj, pos_weight=torch.tensor([d.obj_pw]), reduction='sum')
+        return lbox, lobj, lcls, tobj
+
+    def yh_yolo_loss_fwd(self, dref, stream):
+        d = dref._obj if hasattr(dref, '_obj') else dref
+        p = torch.from_numpy(self._loss_view(d.p, d, d.sb, d.sa, d.sy, d.sx).copy())
+        lbox, lobj, lcls, tobj = self._loss_terms(d, p)
+        flat(d.tobj, tobj.numel(), np.float32)[:] = tobj.reshape(-1).numpy()
+        sums = flat(d.sums, 3, np.float32)
+        sums[0] += float(lbox)
+        sums[1] += float(lobj)
+        sums[2] += float(lcls)
+        return 0
+
+    def yh_yolo_loss_bwd(self, dref, stream):
+        d = dref._obj if hasattr(dref, '_obj') else dref
+        scale = float(flat(d.scale, 1, np.float32)[0])
+        with torch.enable_grad():
+            p = torch.from_numpy(self._loss_view(d.p, d, d.sb, d.sa, d.sy, d.sx).copy()).requires_grad_()
+            lbox, lobj, lcls, _ = self._loss_terms(d, p)
+            (scale * (d.w_box * lbox + d.w_obj * lobj + d.w_cls * lcls)).backward()
+        self._loss_view(d.grad, d, d.gb, d.ga, d.gy, d.gx)[:] = p.grad.numpy()
+        return 0
+
     def yh_pack_batch(self, items, n_items, stream):
         """The batched packer = the single-layer packers applied to every item of the (host-resident) table."""
         arr = (PackItem * n_items).from_address(_addr(items))

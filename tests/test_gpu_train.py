@@ -337,6 +337,39 @@ def test_pack_batch_equals_single_layer_packers(libs, code):
         assert torch.equal(a, b), 'image %d differs' % k
 
 
+@pytest.mark.parametrize('rel,size,nc', [('yolov3/yolov3.cfg', 320, 80), ('yolov3tiny/yolov3-tiny-hand.cfg', 416, 1)], ids=['coco80', 'hand1'])
+def test_fused_loss_kernels_match_torch_loss(libs, rel, size, nc):
+    """csrc/loss.hip vs the torch restatement of compute_loss (itself pinned by the reference goldens on the CPU tier):
+    loss items to 1e-5, gradient of every raw head element to 1e-4 of its scale, through strided NHWC head views."""
+    if DRY:
+        pytest.skip('the loss glue is covered on the emulator by tests/test_loss_golden.py')
+    from models import Darknet
+    from utils import utils as U
+    torch.manual_seed(0)
+    model = Darknet(os.path.join(conftest.PKG, 'cfg', rel), (size, size))
+    model.nc, model.gr = nc, 0.6
+    model.hyp = {'giou': 3.54, 'cls': 37.4, 'cls_pw': 1.3, 'obj': 64.3, 'obj_pw': 0.8, 'iou_t': 0.20, 'fl_gamma': 0.0}
+    raws, targets = synth.loss_inputs(model, size, batch=4, seed=33, labels_per_image=12)
+    targets = targets.to(GPU)
+    results = []
+    for fused in (True, False):
+        bases, views = [], []
+        for r in raws:
+            bs, na, ny, nx, no = r.shape
+            base = torch.zeros(bs, ny, nx, oh.round_up(na * no, 8), device=GPU)
+            base[..., :na * no] = r.to(GPU).permute(0, 2, 3, 1, 4).reshape(bs, ny, nx, na * no)
+            base.requires_grad_()
+            bases.append(base)
+            views.append(base[..., :na * no].view(bs, ny, nx, na, no).permute(0, 3, 1, 2, 4))
+        loss, items = U.compute_loss(views, targets, model, fused=fused)
+        (loss * 7.0).backward()
+        results.append((items.cpu(), [b.grad.cpu() for b in bases]))
+    (it_f, g_f), (it_t, g_t) = results
+    assert torch.allclose(it_f, it_t, rtol=1e-5, atol=1e-6), (it_f, it_t)
+    for a, b in zip(g_f, g_t):
+        assert (a - b).abs().max().item() <= 1e-4 * b.abs().max().item()
+
+
 # ------------------------------------------------------------------------------------------ whole steps
 @pytest.fixture(scope='module')
 def mini():

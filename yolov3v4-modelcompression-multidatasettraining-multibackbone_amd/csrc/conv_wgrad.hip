@@ -729,7 +729,10 @@ static void wgrad_geometry(const yh_wgrad_desc* d, WgradArgs* pa, int* psplits) 
     const int tiles = a.tiles_m * a.tiles_n;
     int splits = d->splits;
     if (splits <= 0) {
-        splits = (1024 + tiles - 1) / tiles;               // ~4 workgroups per CU: every split costs a partial tile of traffic
+        int target = 1024;                                 // workgroups in flight: every split costs a partial tile of traffic
+        { const char* e = getenv("YH_WGRAD_TARGET"); if (e) target = atoi(e); }
+        splits = target > 0 ? (target + tiles - 1) / tiles : (-target) / tiles;   // negative: round down (one wave of workgroups)
+        if (splits < 1) splits = 1;
         const int max_splits = (a.ksteps + 7) / 8;         // at least 8 K steps per workgroup
         if (splits > max_splits) splits = max_splits;
         if (splits < 1) splits = 1;

@@ -163,6 +163,15 @@ class PackBatchDesc(C.Structure):
     _fields_ = [('items', _vp), ('n_items', _i32)]
 
 
+class LossDesc(C.Structure):
+    _fields_ = [('p', _vp), ('grad', _vp), ('tobj', _vp), ('idx', _vp), ('tbox', _vp), ('tcls', _vp), ('anchor', _vp), ('sums', _vp),
+                ('scale', _vp),
+                ('sb', _i64), ('sa', _i64), ('sy', _i64), ('sx', _i64), ('gb', _i64), ('ga', _i64), ('gy', _i64), ('gx', _i64),
+                ('bs', _i32), ('na', _i32), ('ny', _i32), ('nx', _i32), ('no', _i32), ('nc', _i32), ('nb', _i32),
+                ('gr', _f32), ('cp', _f32), ('cn', _f32), ('cls_pw', _f32), ('obj_pw', _f32),
+                ('w_box', _f32), ('w_obj', _f32), ('w_cls', _f32)]
+
+
 class CastDesc(C.Structure):
     _fields_ = [('x', _vp), ('y', _vp), ('pixels', _i64), ('c', _i32), ('ldx', _i32), ('ldy', _i32), ('dtype', _i32)]
 
@@ -219,6 +228,8 @@ _SIGNATURES = {
     'yh_cast_f32': (C.c_int, [C.POINTER(CastDesc), _vp]),
     'yh_maxpool2d_bwd': (C.c_int, [C.POINTER(PoolBwdDesc), _vp]),
     'yh_pack_batch': (C.c_int, [_vp, C.c_int, _vp]),
+    'yh_yolo_loss_fwd': (C.c_int, [C.POINTER(LossDesc), _vp]),
+    'yh_yolo_loss_bwd': (C.c_int, [C.POINTER(LossDesc), _vp]),
     'yh_nchw_to_nhwc': (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
     'yh_plan_create': (_vp, []),
     'yh_plan_destroy': (None, [_vp]),

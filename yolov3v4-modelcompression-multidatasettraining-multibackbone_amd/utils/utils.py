@@ -226,11 +226,25 @@ def build_targets(p, targets, model):
     return tcls, tbox, indices, av
 
 
-def compute_loss(p, targets, model):
+def _fused_loss_override():
+    try:
+        from engine import loss as hip_loss
+    except Exception:
+        return False
+    return hip_loss._LIB_OVERRIDE is not None
+
+
+def compute_loss(p, targets, model, fused=None):
     """GIoU box loss + objectness BCE + class BCE over the raw head tensors (reference utils.py:368-432).
 
     Returns ``(loss, detached [lbox, lobj, lcls, loss])``; mean reduction, gains from ``model.hyp``, objectness
-    target ``(1 - gr) + gr * giou`` with ``model.gr``."""
+    target ``(1 - gr) + gr * giou`` with ``model.gr``.  CUDA fp32 raw heads without focal loss go through the fused HIP
+    kernels (engine/loss.py, csrc/loss.hip: same values, gradient written directly); everything else runs the torch
+    ops below."""
+    if fused is not False and (p[0].is_cuda or _fused_loss_override()):
+        from engine import loss as hip_loss
+        if hip_loss.usable(p, model):
+            return hip_loss.compute_loss(p, targets, model, build_targets, smooth_BCE)
     dev = p[0].device
     z = lambda: torch.zeros(1, device=dev)
     lcls, lbox, lobj = z(), z(), z()
