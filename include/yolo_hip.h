@@ -102,7 +102,11 @@ typedef struct yh_conv_desc {
     int32_t y_off_h, y_off_w;     /* (n, 2 ho + y_off_h, 2 wo + y_off_w) of a y_h x y_w tensor; ho/wo are  */
                                   /* then free (taps beyond the input read zeros).  This is one of the four */
                                   /* phases of a stride-2 data gradient, see yh_conv_pack_weights_dgrad_phase */
+    float* stats_ws;              /* training forward: when set, the epilogue also emits per-channel partial sums of  */
+    int64_t stats_ws_floats;      /* y and y*y (as stored) — yh_conv2d_stats_rows(d) rows of [2][cout] floats — which  */
+                                  /* yh_bn_finalize (nparts) turns into the batch statistics: no separate pass over y */
 } yh_conv_desc;
+int64_t yh_conv2d_stats_rows(const yh_conv_desc* d);
 
 int yh_conv2d_fwd(const yh_conv_desc* d, void* stream);
 /* YH_I8 form of the block = eval branch of BNFold_COSPTQuantizedConv2d_For_FPGA.forward
@@ -312,6 +316,8 @@ typedef struct yh_bn_desc {
     int32_t n, h, w_in;     /* geometry of z (needed for ups)                                                  */
     int32_t c, ldz, lddy, ldr, ldo, act, ups, dtype;
     float slope, eps, momentum;
+    int32_t nparts;         /* yh_bn_finalize only: > 0 = first add `nparts` rows of [2][c] partial sums at ws (written by  */
+                            /* yh_conv2d_fwd with stats_ws) into sum / sumsq                                              */
     float* ws;              /* optional workspace for the two reductions (yh_bn_stats, yh_bn_act_bwd_reduce): per-workgroup */
     int64_t ws_floats;      /* partial sums are stored there and summed by a second launch instead of contended atomics; */
                             /* size from yh_bn_reduce_workspace().  NULL / too small -> fp32 atomics.                     */

@@ -272,6 +272,12 @@ class FakeLib:
         odt = np.float32 if d.out_f32 else npdt
         out = pitched(d.y, d.n * y.shape[2] * y.shape[3], d.cout, d.ldy, odt)
         out[:] = y.permute(0, 2, 3, 1).reshape(-1, d.cout).numpy().astype(odt)
+        if _addr(d.stats_ws):   # fused BatchNorm statistics of the stored values: the emulator emits a single partial row
+            assert d.ups == 1 and not _addr(d.res) and d.stats_ws_floats >= 2 * d.cout
+            q = torch.from_numpy(out.astype(np.float32))
+            row = flat(d.stats_ws, 2 * d.cout, np.float32)
+            row[:d.cout] = q.sum(0).numpy()
+            row[d.cout:] = (q * q).sum(0).numpy()
         return 0
 
     def yh_conv2d_stem_fwd(self, dref, stream):
@@ -371,8 +377,15 @@ class FakeLib:
         flat(d.sumsq, d.c, np.float32)[:] += (z * z).sum(0).numpy()
         return 0
 
+    def yh_conv2d_stats_rows(self, dref):
+        return 1
+
     def yh_bn_finalize(self, dref, stream):
         d = dref._obj if hasattr(dref, '_obj') else dref
+        if d.nparts > 0:
+            part = flat(d.ws, d.nparts * 2 * d.c, np.float32).reshape(d.nparts, 2, d.c)
+            flat(d.sum, d.c, np.float32)[:] += part[:, 0].sum(0)
+            flat(d.sumsq, d.c, np.float32)[:] += part[:, 1].sum(0)
         P = float(d.pixels)
         mean = flat(d.sum, d.c, np.float32) / np.float32(P)
         var = np.maximum(flat(d.sumsq, d.c, np.float32) / np.float32(P) - mean * mean, 0).astype(np.float32)

@@ -42,7 +42,7 @@ def pack_conv(lib, code, w, cb=None, bn=None, eps=1e-5, cmap=None, cin_phys=None
 
 
 def conv(lib, code, x, packed, bias, cin_k, m_pad, cout_phys, k, stride, pad, act=0, slope=0.1, res=None, ups=1,
-         out_f32=False, tile=0, cin=None, x_off=0, y=None, y_off=0, res_off=0):
+         out_f32=False, tile=0, cin=None, x_off=0, y=None, y_off=0, res_off=0, stats=None):
     """x: (N,H,W,ldx) NHWC buffer; reads channels [x_off, x_off+cin).  Returns the (N,Ho*ups,Wo*ups,ldy) output."""
     N, H, W, ldx = x.shape
     cin = cin if cin is not None else ldx - x_off
@@ -54,6 +54,12 @@ def conv(lib, code, x, packed, bias, cin_k, m_pad, cout_phys, k, stride, pad, ac
                  n=N, h=H, w_in=W, cin=cin, ho=Ho, wo=Wo, cout=cout_phys, kh=k, kw=k, stride=stride, pad=pad,
                  ldx=ldx, ldr=0 if res is None else res.shape[3], ldy=y.shape[3], cin_k=cin_k, m_pad=m_pad, act=act,
                  slope=slope, ups=ups, out_f32=1 if out_f32 else 0, dtype=code, tile=tile)
+    if stats is not None:   # fused BatchNorm statistics: stats is a dict that receives the partial rows
+        rows = int(lib.yh_conv2d_stats_rows(C.byref(d)))
+        assert rows > 0
+        ws = torch.full((rows * 2 * cout_phys,), float('nan'), device=x.device, dtype=torch.float32)
+        d.stats_ws, d.stats_ws_floats = P(ws), ws.numel()
+        stats['rows'], stats['ws'] = rows, ws
     rc = lib.yh_conv2d_fwd(C.byref(d), stream())
     assert rc == 0, 'yh_conv2d_fwd rc=%d' % rc
     return y

@@ -278,6 +278,38 @@ def test_maxpool_backward_matches_autograd(libs, code, case):
 
 
 @pytest.mark.parametrize('code', [F32, F16], ids=['fp32', 'fp16'])
+@pytest.mark.parametrize('case', [(2, 20, 20, 32, 64, 3, 1, 0), (1, 33, 31, 64, 128, 3, 2, 0), (3, 19, 19, 128, 256, 1, 1, 0),
+                                  (4, 32, 32, 32, 32, 3, 1, 3), (2, 26, 26, 128, 256, 3, 1, 26), (2, 40, 40, 64, 128, 1, 1, 27),
+                                  (2, 24, 24, 64, 64, 3, 1, 24), (2, 16, 16, 64, 128, 1, 1, 25), (2, 16, 16, 64, 128, 3, 1, 1)],
+                         ids=lambda c: 'n%d_%dx%d_c%d-%d_k%ds%d_t%d' % c)
+def test_conv_epilogue_batch_statistics(libs, code, case):
+    """Training forward: the conv epilogue's partial sums + yh_bn_finalize(nparts) == statistics of the stored output."""
+    lib, _ = libs
+    N, H, W, cin, cout, k, s, tile = case
+    g = torch.Generator().manual_seed(hash(case) % (2 ** 31))
+    dt = oh.tdtype(code)
+    pad = (k - 1) // 2
+    w = (torch.randn(cout, cin, k, k, generator=g) * (cin * k * k) ** -0.5).to(GPU)
+    x = (torch.randn(N, H, W, cin, generator=g) + 0.3).to(dt).to(GPU)
+    packed, bias, cin_k, m_pad = oh.pack_conv(lib, code, w, None, None, cin_phys=cin)
+    st = {}
+    y = oh.conv(lib, code, x, packed, bias, cin_k, m_pad, cout, k, s, pad, act=0, tile=tile, stats=st)
+    f32 = lambda: torch.zeros(cout, device=GPU, dtype=torch.float32)
+    mean, invstd, s1, s2 = f32(), f32(), f32(), f32()
+    pix = y.shape[0] * y.shape[1] * y.shape[2]
+    d = oh.bn_desc(code, y, cout, mean=mean, invstd=invstd, s1=s1, s2=s2)
+    d.nparts, d.ws, d.ws_floats = st['rows'], P(st['ws']), st['ws'].numel()
+    oh.call(lib, 'yh_bn_finalize', d)
+    _sync()
+    q = y.float().reshape(pix, cout)
+    ref_mean = q.mean(0)
+    ref_var = q.var(0, unbiased=False)
+    assert not torch.isnan(st['ws']).any() or DRY, 'a partial row was not written'
+    assert (mean - ref_mean).abs().max().item() <= 2e-5 * (ref_mean.abs().max().item() + 1)
+    assert ((1 / invstd ** 2 - 1e-5) - ref_var).abs().max().item() <= 1e-4 * ref_var.abs().max().item()
+
+
+@pytest.mark.parametrize('code', [F32, F16], ids=['fp32', 'fp16'])
 def test_pack_batch_equals_single_layer_packers(libs, code):
     """One launch for every weight image of the step == the per-layer entry points, bit for bit."""
     import ctypes as C

@@ -44,6 +44,7 @@ struct ConvArgs {
     int act;
     float slope;
     int ups;
+    float* stats_part;   // training forward: per (pixel tile, wave column) partial sums of y and y^2 per channel, or NULL
     int y_h, y_w, y_off_h, y_off_w;  // ups == 3: output pixel (n, ho, wo) is stored at (n, 2 ho + y_off_h, 2 wo + y_off_w) of a y_h x y_w tensor
 };
 
@@ -293,6 +294,11 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm_kernel(const ConvA
     const int mq = (lane >> 4) << 2, pc = lane & 15;
     OutT* const yg = reinterpret_cast<OutT*>(a.y);
     const T* const rg = reinterpret_cast<const T*>(a.res);
+    float st1[TM][4], st2[TM][4];   // BatchNorm batch statistics of this wave's outputs (training forward only)
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) st1[i][e] = st2[i][e] = 0.f;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const long p = p0 + wn * TN * 16 + j * 16 + pc;
@@ -319,6 +325,14 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm_kernel(const ConvA
             float v[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = activate(acc[i][j][e] + bv[e], a.act, a.slope);
+            if (a.stats_part != nullptr) {   // statistics of the values as stored (rounded to the output type)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float q = (float)(OutT)v[e];
+                    st1[i][e] += q;
+                    st2[i][e] = fmaf(q, q, st2[i][e]);
+                }
+            }
             if (rg != nullptr) {
                 float r4[4];
                 load4<T>(rg + (a.ups == 3 ? opix : p) * a.ldr + m, r4);
@@ -331,6 +345,27 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm_kernel(const ConvA
                 store4<OutT>(dst + a.ldy, v[0], v[1], v[2], v[3]);
                 store4<OutT>(dst + (long)wo2 * a.ldy, v[0], v[1], v[2], v[3]);
                 store4<OutT>(dst + (long)(wo2 + 1) * a.ldy, v[0], v[1], v[2], v[3]);
+            }
+        }
+    }
+    if (a.stats_part != nullptr) {
+        // sum over the 16 pixel lanes (lane & 15) of every channel quad, then one row of partials per (pixel tile, wn)
+        float* const row = a.stats_part + ((long)(p0 / BN) * WN + wn) * 2 * a.Cout;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float s1 = st1[i][e], s2 = st2[i][e];
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) {
+                    s1 += __shfl_xor(s1, o);
+                    s2 += __shfl_xor(s2, o);
+                }
+                const int m = m0 + wm * TM * 16 + i * 16 + mq + e;
+                if (pc == 0 && m < a.Cout) {
+                    row[m] = s1;
+                    row[a.Cout + m] = s2;
+                }
             }
         }
     }
@@ -558,6 +593,11 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm_glds_kernel(const 
     const int mq = (lane >> 4) << 2, pc = lane & 15;
     OutT* const yg = reinterpret_cast<OutT*>(a.y);
     const T* const rg = reinterpret_cast<const T*>(a.res);
+    float st1[TM][4], st2[TM][4];   // BatchNorm batch statistics of this wave's outputs (training forward only)
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) st1[i][e] = st2[i][e] = 0.f;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const long p = p0 + wn * TN * 16 + j * 16 + pc;
@@ -594,6 +634,14 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm_glds_kernel(const 
             } else {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = activate((float)acc[i][j][e] + bv[e], a.act, a.slope);
+                if (a.stats_part != nullptr) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float q = (float)(OutT)v[e];
+                        st1[i][e] += q;
+                        st2[i][e] = fmaf(q, q, st2[i][e]);
+                    }
+                }
                 if (rg != nullptr) {
                     float r4[4];
                     load4<T>(rg + (a.ups == 3 ? opix : p) * a.ldr + m, r4);
@@ -607,6 +655,27 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm_glds_kernel(const 
                 store4<OutT>(dst + a.ldy, v[0], v[1], v[2], v[3]);
                 store4<OutT>(dst + (long)wo2 * a.ldy, v[0], v[1], v[2], v[3]);
                 store4<OutT>(dst + (long)(wo2 + 1) * a.ldy, v[0], v[1], v[2], v[3]);
+            }
+        }
+    }
+    if (a.stats_part != nullptr) {
+        // sum over the 16 pixel lanes (lane & 15) of every channel quad, then one row of partials per (pixel tile, wn)
+        float* const row = a.stats_part + ((long)(p0 / BN) * WN + wn) * 2 * a.Cout;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float s1 = st1[i][e], s2 = st2[i][e];
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) {
+                    s1 += __shfl_xor(s1, o);
+                    s2 += __shfl_xor(s2, o);
+                }
+                const int m = m0 + wm * TM * 16 + i * 16 + mq + e;
+                if (pc == 0 && m < a.Cout) {
+                    row[m] = s1;
+                    row[a.Cout + m] = s2;
+                }
             }
         }
     }
@@ -1000,6 +1069,27 @@ extern "C" int yh_conv2d_tile(const yh_conv_desc* d) {
     return (d->dtype == YH_I8 && t == 3) ? 24 : t;
 }
 
+// (pixel-tile width, wave columns) of a tile code: the geometry of the fused-statistics partial rows
+static bool tile_geometry(int tile, int* bn, int* wn) {
+    switch (tile) {
+        case 1: case 11: case 21: case 31: *bn = 128; *wn = 2; return true;
+        case 2: case 12: case 22: case 32: case 3: *bn = 256; *wn = 4; return true;
+        case 4: case 14: case 24: case 34: *bn = 128; *wn = 2; return true;
+        case 5: case 15: case 25: case 35: *bn = 64; *wn = 2; return true;
+        case 6: case 16: case 26: case 51: case 52: *bn = 128; *wn = 2; return true;
+        case 27: *bn = 256; *wn = 4; return true;
+        default: return false;
+    }
+}
+
+extern "C" int64_t yh_conv2d_stats_rows(const yh_conv_desc* d) {
+    if (!d || d->n <= 0 || d->ho <= 0 || d->wo <= 0 || d->dtype == YH_I8) return 0;
+    int bn, wn;
+    if (!tile_geometry(yh_conv2d_tile(d), &bn, &wn)) return 0;
+    const long P = (long)d->n * d->ho * d->wo;
+    return (int64_t)((P + bn - 1) / bn) * wn;
+}
+
 extern "C" int yh_conv2d_fwd(const yh_conv_desc* d, void* stream) {
     using namespace yh;
     if (!d || !d->x || !d->w || !d->bias || !d->y) return YH_EINVAL;
@@ -1032,6 +1122,14 @@ extern "C" int yh_conv2d_fwd(const yh_conv_desc* d, void* stream) {
     a.acc_scale = d->acc_scale; a.out_scale = d->out_scale; a.inv_out_scale = d->out_scale > 0.f ? 1.f / d->out_scale : 0.f;
     a.act = d->act; a.slope = d->slope; a.ups = d->ups;
     a.y_h = d->y_h; a.y_w = d->y_w; a.y_off_h = d->y_off_h; a.y_off_w = d->y_off_w;
+    a.stats_part = nullptr;
+    if (d->stats_ws) {
+        // fused BatchNorm statistics: plain dense output only, and never on the halo kernels
+        if (d->ups != 1 || d->res || d->dtype == YH_I8 || (d->tile >= 40 && d->tile < 50)) return YH_EINVAL;
+        const int64_t rows = yh_conv2d_stats_rows(d);
+        if (rows <= 0 || d->stats_ws_floats < rows * 2 * d->cout) return YH_EINVAL;
+        a.stats_part = d->stats_ws;
+    }
     hipStream_t s = (hipStream_t)stream;
     if (d->dtype == YH_F16) {
         return d->out_f32 ? dispatch_tile<f16, float>(a, d->tile, s) : dispatch_tile<f16, f16>(a, d->tile, s);

@@ -378,8 +378,35 @@ extern "C" int yh_bn_stats(const yh_bn_desc* d, void* stream) {
     return check_launch();
 }
 
+// rows of [2][c] partials (conv epilogue) -> sum / sumsq: 16 columns x 16 row lanes per workgroup, row groups in grid.y
+__global__ __launch_bounds__(256) void bn_conv_partials_kernel(const float* part, int nparts, int per_group, int c, float* s0,
+                                                               float* s1) {
+    __shared__ float red[256];
+    const int col = blockIdx.x * 16 + (threadIdx.x & 15), lane = threadIdx.x >> 4;
+    const int r0 = blockIdx.y * per_group, r1 = min(r0 + per_group, nparts);
+    float v = 0.f;
+    if (col < 2 * c)
+        for (int k = r0 + lane; k < r1; k += 16) v += part[(long)k * 2 * c + col];
+    red[threadIdx.x] = v;
+    __syncthreads();
+    if (threadIdx.x < 16 && col < 2 * c) {
+        float t = 0.f;
+        for (int r = 0; r < 16; ++r) t += red[r * 16 + threadIdx.x];
+        atomicAdd((col < c ? s0 : s1) + (col < c ? col : col - c), t);
+    }
+}
+
 extern "C" int yh_bn_finalize(const yh_bn_desc* d, void* stream) {
     if (!d || !d->sum || !d->sumsq || !d->mean || !d->invstd || d->c <= 0 || d->pixels <= 0) return YH_EINVAL;
+    if (d->nparts > 0) {
+        if (!d->ws || d->ws_floats < (int64_t)d->nparts * 2 * d->c) return YH_EINVAL;
+        int groups = (d->nparts + 255) / 256;               // >= 256 rows per group, <= 64 groups (64 atomics per channel)
+        if (groups > 64) groups = 64;
+        const int per_group = (d->nparts + groups - 1) / groups;
+        groups = (d->nparts + per_group - 1) / per_group;
+        hipLaunchKernelGGL(bn_conv_partials_kernel, dim3((2 * d->c + 15) / 16, groups), dim3(256), 0, (hipStream_t)stream, d->ws,
+                           d->nparts, per_group, d->c, d->sum, d->sumsq);
+    }
     hipLaunchKernelGGL(bn_finalize_kernel, dim3((d->c + 255) / 256), dim3(256), 0, (hipStream_t)stream, *d);
     return check_launch();
 }

@@ -26,7 +26,7 @@ class ConvDesc(C.Structure):
                 ('cin_k', _i32), ('m_pad', _i32),
                 ('act', _i32), ('slope', _f32), ('ups', _i32), ('out_f32', _i32), ('dtype', _i32), ('tile', _i32),
                 ('acc_scale', _f32), ('out_scale', _f32),
-                ('y_h', _i32), ('y_w', _i32), ('y_off_h', _i32), ('y_off_w', _i32)]
+                ('y_h', _i32), ('y_w', _i32), ('y_off_h', _i32), ('y_off_w', _i32), ('stats_ws', _vp), ('stats_ws_floats', _i64)]
 
 
 class StemDesc(C.Structure):
@@ -94,7 +94,7 @@ class BnDesc(C.Structure):
                 ('invstd', _vp), ('sum', _vp), ('sumsq', _vp), ('running_mean', _vp), ('running_var', _vp),
                 ('pixels', _i64), ('n', _i32), ('h', _i32), ('w_in', _i32),
                 ('c', _i32), ('ldz', _i32), ('lddy', _i32), ('ldr', _i32), ('ldo', _i32), ('act', _i32), ('ups', _i32),
-                ('dtype', _i32), ('slope', _f32), ('eps', _f32), ('momentum', _f32), ('ws', _vp), ('ws_floats', _i64)]
+                ('dtype', _i32), ('slope', _f32), ('eps', _f32), ('momentum', _f32), ('nparts', _i32), ('ws', _vp), ('ws_floats', _i64)]
 
 
 class BnStatsDesc(BnDesc):
@@ -192,6 +192,7 @@ _SIGNATURES = {
                                        C.c_int, C.c_int, C.c_int, _vp, _vp, _vp]),
     'yh_conv2d_fwd': (C.c_int, [C.POINTER(ConvDesc), _vp]),
     'yh_conv2d_tile': (C.c_int, [C.POINTER(ConvDesc)]),
+    'yh_conv2d_stats_rows': (_i64, [C.POINTER(ConvDesc)]),
     'yh_qconv_pack_weights': (C.c_int, [_vp, _f32, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp]),
     'yh_stem_pack_weights': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _f32, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                        _vp, _vp, _vp]),

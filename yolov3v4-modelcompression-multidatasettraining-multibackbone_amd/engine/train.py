@@ -283,6 +283,7 @@ class TrainEngine(DarknetEngine):
             y = None if v.storage is None else P(v.storage, v.c_off)
             if v.kind == 'conv':
                 pk, s = v.tpack, v.src
+                fused_stats = 0
                 direct = v.plain                     # conv epilogue writes the block output itself
                 zt = None if direct else v.z
                 if s.kind == 'input':
@@ -301,7 +302,15 @@ class TrainEngine(DarknetEngine):
                                  ldr=0, ldy=v.c_phys if (v.fp32 or not direct) else v.ld, cin_k=pk['cin_k'],
                                  m_pad=pk['m_pad'], act=LINEAR, slope=0.0, ups=1, out_f32=1 if v.fp32 else 0,
                                  dtype=self.code, tile=self.force_tile, acc_scale=0.0, out_scale=0.0)
+                    if v.bn is not None and not direct:
+                        # BatchNorm statistics ride in the conv epilogue: per-tile partial sums into the shared workspace
+                        fused_stats = int(lib.yh_conv2d_stats_rows(C.byref(d)))
+                        if fused_stats:
+                            d.stats_ws_floats = fused_stats * 2 * v.c_phys
+                            plan['ws_floats'] = max(plan['ws_floats'], d.stats_ws_floats)
                     op = add(fwd, plan['fwd_ops'], d, 'conv%d' % v.block)
+                    if fused_stats:
+                        fixup(fwd, op, ConvDesc, 'stats_ws', SLOT_WS)
                     if v.fp32:
                         fixup(fwd, op, ConvDesc, 'y', SLOT_HEAD0 + head_index[id(v)])
                 if direct:
@@ -319,9 +328,14 @@ class TrainEngine(DarknetEngine):
                     for t in (bn.weight, bn.bias, bn.running_mean, bn.running_var):
                         if t.dtype != torch.float32 or not t.is_contiguous():
                             raise NotImplementedError('HIP training path: BatchNorm tensors must be contiguous fp32')
-                    add_reduction(fwd, plan['fwd_ops'], BnStatsDesc(**base, **bnp), 'bnstat%d' % v.block)
-                    add(fwd, plan['fwd_ops'], BnFinalizeDesc(**base, **bnp, running_mean=P(bn.running_mean),
-                                                             running_var=P(bn.running_var)), 'bnfin%d' % v.block)
+                    fused = s.kind != 'input' and fused_stats
+                    if not fused:
+                        add_reduction(fwd, plan['fwd_ops'], BnStatsDesc(**base, **bnp), 'bnstat%d' % v.block)
+                    fin = BnFinalizeDesc(**base, **bnp, running_mean=P(bn.running_mean), running_var=P(bn.running_var),
+                                         nparts=fused_stats if fused else 0, ws_floats=(fused_stats * 2 * v.c_phys) if fused else 0)
+                    op = add(fwd, plan['fwd_ops'], fin, 'bnfin%d' % v.block)
+                    if fused:
+                        fixup(fwd, op, BnFinalizeDesc, 'ws', SLOT_WS)
                 else:
                     bnp = dict()
                 v.bn_args = (base, bnp)
