@@ -346,11 +346,11 @@ def train_roofline(eng, x, precision):
     peak = PEAK_TFLOPS[precision]
     traffic = None
     try:   # HBM bytes per launch from the committed rocprofv3 FETCH_SIZE / WRITE_SIZE passes of this command
-        table = json.load(open(os.path.join(REPO, 'profiles', 'hbm_traffic.json'))).get('train_batch%d' % x.shape[0], {})
+        hbm = json.load(open(os.path.join(REPO, 'profiles', 'hbm_traffic.json'))).get('train_batch%d' % x.shape[0], {})
         key = {'wgrad': 'void yh::conv_wgrad_dma_kernel<4, 2>', 'dgrad': 'conv_igemm_glds<f16,f16,256x128,S3>',
                'conv': 'conv_igemm_glds<f16,f16,256x128,S3>'}.get(top)
-        if key in table and precision == 'fp16':
-            traffic = {'hbm_bytes_per_launch': table[key]['hbm_bytes_per_dispatch'], 'kernel': key, 'source': 'profiles/hbm_traffic.json'}
+        if key in hbm and precision == 'fp16':
+            traffic = {'hbm_bytes_per_launch': hbm[key]['hbm_bytes_per_dispatch'], 'kernel': key, 'source': 'profiles/hbm_traffic.json'}
     except Exception:
         traffic = None
     return {'bound': 'mfma', 'kernel': top, 'achieved': round(ach, 1), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(ach / peak, 4),

@@ -794,8 +794,8 @@ extern "C" int yh_conv2d_wgrad(const yh_wgrad_desc* d, void* stream) {
         else hipLaunchKernelGGL((conv_wgrad_kernel<float, 4>), grid, dim3(256), 0, st, a);
     }
     if (a.two_stage) {
-        int groups = (splits + 15) / 16;                    // >= 16 splits per group, <= 32 groups
-        if (groups > 32) groups = 32;
+        int groups = (splits + 15) / 16;                    // >= 16 splits per group, <= 32 groups: the atomics that join the
+        if (groups > 32) groups = 32;                       // groups are the expensive part (4x more groups measured 30 % slower)
         const int per_group = (splits + groups - 1) / groups;
         groups = (splits + per_group - 1) / per_group;
         if (narrow) hipLaunchKernelGGL((wgrad_reduce_kernel<2, 2>), dim3(tiles * 8, groups), dim3(256), 0, st, a, splits, per_group);

@@ -93,13 +93,15 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const yh_bn_desc d, const
 }
 
 // second stage of the reductions: sum[c] += sum over workgroups of part[wg][0][c], sumsq likewise.
-// 16 columns x 16 partial-lanes per workgroup: a wave reads 64-byte row pieces of 4 partial rows at a time.
-__global__ __launch_bounds__(256) void bn_partials_kernel(const float* part, int nparts, int c, float* s0, float* s1) {
+// 16 columns x 16 partial-lanes per workgroup (a wave reads 64-byte row pieces of 4 partial rows at a time), row groups
+// in grid.y meeting in a few atomics per channel.
+__global__ __launch_bounds__(256) void bn_partials_kernel(const float* part, int nparts, int per_group, int c, float* s0, float* s1) {
     __shared__ float red[256];
     const int col = blockIdx.x * 16 + (threadIdx.x & 15), lane = threadIdx.x >> 4;
+    const int r0 = blockIdx.y * per_group, r1 = min(r0 + per_group, nparts);
     float v = 0.f;
     if (col < 2 * c)
-        for (int k = lane; k < nparts; k += 16) {
+        for (int k = r0 + lane; k < r1; k += 16) {
             const int q = col / c, ch = col - q * c;
             v += part[((long)k * 2 + q) * c + ch];
         }
@@ -109,7 +111,7 @@ __global__ __launch_bounds__(256) void bn_partials_kernel(const float* part, int
         float t = 0.f;
         for (int r = 0; r < 16; ++r) t += red[r * 16 + threadIdx.x];
         const int q = col / c, ch = col - q * c;
-        (q ? s1 : s0)[ch] += t;
+        atomicAdd((q ? s1 : s0) + ch, t);
     }
 }
 
@@ -271,8 +273,12 @@ static BnGeom bn_geom(const yh_bn_desc* d, int vn, dim3* grid, int target = 4096
 }
 
 static void sum_partials(const yh_bn_desc* d, const dim3& grid, void* stream) {
-    hipLaunchKernelGGL(bn_partials_kernel, dim3((2 * d->c + 15) / 16), dim3(256), 0, (hipStream_t)stream, d->ws, (int)grid.y,
-                       d->c, d->sum, d->sumsq);
+    const int nparts = (int)grid.y;
+    int groups = (nparts + 63) / 64;                        // >= 64 rows per group
+    const int per_group = (nparts + groups - 1) / groups;
+    groups = (nparts + per_group - 1) / per_group;
+    hipLaunchKernelGGL(bn_partials_kernel, dim3((2 * d->c + 15) / 16, groups), dim3(256), 0, (hipStream_t)stream, d->ws, nparts,
+                       per_group, d->c, d->sum, d->sumsq);
 }
 
 // ------------------------------------------------------------------------------------------ maxpool backward

@@ -454,7 +454,17 @@ class TrainEngine(DarknetEngine):
                                                               ldy=v.c_phys, dtype=self.code), 'dups%d' % v.block)
                     dyp, lddy = P(small), v.c_phys
                 if v.res is not None:
-                    contribute(v.res, dyp, lddy, None, 'dres%d' % v.block)
+                    t = v.res
+                    own = lambda u: u.parent is None and u.c_off == 0 and u.ld == u.c_phys
+                    if (id(t.gstorage) not in initialised and v.ups == 1 and own(t) and own(v) and not t.fp32
+                            and (t.H, t.W, t.c_phys) == (v.H, v.W, v.c_phys) and not getattr(t, 'galias', False)):
+                        # first contribution to the residual source is dy itself: share the buffer instead of copying it.
+                        # Later contributions (the data gradient of the source's other consumer) accumulate in place, after
+                        # this block's backward has consumed dy.
+                        plan['storages'] = [u for u in plan['storages'] if u is not t.gstorage]   # free the unused buffer
+                        t.gstorage, t.galias = v.gstorage, True
+                    else:
+                        contribute(t, dyp, lddy, None, 'dres%d' % v.block)
                 if v.plain:                   # no BN, linear: dz is dy itself
                     dzp, lddz = dyp, lddy
                     if v.g_b is not None:
