@@ -39,7 +39,7 @@ constexpr int WG_PITCH_DW = 20;  // LDS row pitch in dwords (80 B)
 struct WgradArgs {
     yh_wgrad_desc d;
     int tiles_m, tiles_n, ksteps, ksteps_per_split, ncols;  // ncols = kh*kw*cin: the flattened (tap, ci) axis
-    int two_stage, interleaved, bn, cin_w, rw, rh, qh;  // interleaved: the DMA kernel's tile <-> channel mapping  // bk = qw * wo + rw, qw = qh * ho + rh: per-step pixel advance without divisions
+    int two_stage, interleaved, dma, bn, cin_w, rw, rh, qh;  // interleaved: the DMA kernel's tile <-> channel mapping  // bk = qw * wo + rw, qw = qh * ho + rh: per-step pixel advance without divisions
     long pixels;
 };
 
@@ -249,10 +249,21 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
 // 16 lanes of a fragment read 32 contiguous bytes of one row; the four 8-pixel groups of a wave read rows 2 KB apart, which
 // would alias to the same banks, so the 16-byte units of a row are XOR-permuted by 2 * (row >> 3 & 3) on the way in (the
 // DMA lane fetches source unit u ^ f for destination cell u) and un-permuted by the reader: conflict free.
-// unit permutation of pixel row r in a row of UNITS 16-byte units: toggles the 128-byte half per 8-row group so that the
-// four 8-pixel groups of a fragment read spread over both halves of the banks (8 units/row: only 2-bit room, keep 2g)
+// Unit permutation of pixel row r in a row of UNITS 16-byte units.  Fragments are fetched with ds_read_b64_tr_b16: a
+// 16-lane group reads a [4 pixels][16 channels] block (32 bytes of 4 consecutive rows) and receives it transposed.  Rows
+// are 256 B apart (= all 64 banks), so without a permutation the 4 rows of a block, and the blocks of the two groups that
+// share an LDS cycle (rows 8 apart), would all sit on the same 8 banks: the 32-byte column of row r is XORed with
+// (r & 3) | ((r >> 3) & 1) << 2, which spreads those 8 row pieces over all 64 banks.  64-channel rows (8 units) only have
+// room for the (r & 3) part.
 template <int UNITS> __device__ __forceinline__ int wg_swz(int r) {
-    return UNITS == 16 ? (((r >> 3) & 1) << 3) : (((r >> 3) & 3) << 1);
+    return UNITS >= 16 ? (((r & 3) | (((r >> 3) & 1) << 2)) << 1) : ((r & 3) << 1);
+}
+
+typedef int wg_v2i __attribute__((ext_vector_type(2)));
+template <int OFF> __device__ __forceinline__ wg_v2i ds_read_tr16(unsigned lds_byte_addr) {
+    wg_v2i r;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(r) : "v"(lds_byte_addr), "n"(OFF));
+    return r;
 }
 
 template <int N> __device__ __forceinline__ void wg_wait_vmcnt() {
@@ -383,15 +394,19 @@ __global__ __launch_bounds__(128 * WNW) void conv_wgrad_dma_kernel(const WgradAr
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // ---- fragment addressing.  The wave's TM (resp. 4) MFMA tiles interleave channels: row ri of tile i is channel
-    // TM*ri + i of the wave's block, so one 8-byte (TM = 4) or 4-byte (TM = 2) LDS read per pixel feeds all tiles at once:
-    // 8 reads per operand per K step instead of 8 per fragment.
-    const int ri = lane & 15, g = lane >> 4;
-    const int cha = wm * TM * 16 + TM * ri;            // first of this lane's TM consecutive A channels
-    const int chb = wn * 64 + 4 * ri;                  // first of its 4 consecutive B columns
-    const int a_off = (8 * g) * (BM * 2) + (((cha >> 3) ^ wg_swz<A_UNITS>(8 * g)) << 4) + (cha & 7) * 2;
-    const int b_off = A_BYTES + (8 * g) * (BN * 2) + (((chb >> 3) ^ wg_swz<16>(8 * g)) << 4) + (chb & 7) * 2;
-    typedef f16 f16xTM __attribute__((ext_vector_type(TM)));
+    // ---- fragment addressing for ds_read_b64_tr_b16.  Lane (q = lane & 15, g = lane >> 4) of a 16-lane group supplies the
+    // address of 4 consecutive channels (8 bytes) of pixel row 8g + 4h + q/4 (h = which half of the 8-pixel K group) and
+    // receives 4 consecutive pixels of channel (tile base + q): two reads build one MFMA fragment, no packing.
+    const int q = lane & 15, g = lane >> 4;
+    const unsigned lds0 = (unsigned)(uintptr_t)(lptr_t)smem;
+    unsigned a_addr[2], b_addr[2];   // per half h: byte address inside a stage for tile 0; tiles step 32 bytes (16 channels)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int row = 8 * g + 4 * h + (q >> 2);
+        const int cha = wm * TM * 16 + 4 * (q & 3), chb = wn * 64 + 4 * (q & 3);
+        a_addr[h] = row * (BM * 2) + ((((cha >> 3) ^ wg_swz<A_UNITS>(row)) << 4) | ((cha & 7) * 2));
+        b_addr[h] = A_BYTES + row * (BN * 2) + ((((chb >> 3) ^ wg_swz<16>(row)) << 4) | ((chb & 7) * 2));
+    }
 
     const int nk = ks1 - ks0;
 #pragma unroll
@@ -407,16 +422,45 @@ __global__ __launch_bounds__(128 * WNW) void conv_wgrad_dma_kernel(const WgradAr
         }
         __builtin_amdgcn_s_barrier();
         if (kt + STAGES - 1 < nk) issue(st_write);
-        const unsigned char* stage = smem + st_read * STAGE_BYTES;
+        const unsigned stage = lds0 + st_read * STAGE_BYTES;
+        // tile i of the wave sits 16 channels = 32 bytes further; the XOR permutation acts on bits >= 5 of the in-row
+        // offset for a fixed row, so stepping tiles is an XOR with i << 5 (folded into the address, offset field 0)
+        wg_v2i ra[TM][2], rb[4][2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) ra[i][h] = ds_read_tr16<0>(stage + (a_addr[h] ^ (i << 5)));
+#pragma unroll
+            for (int j = 0; j < 4; ++j) rb[j][h] = ds_read_tr16<0>(stage + (b_addr[h] ^ (j << 5)));
+        }
+        // the reads are asynchronous and invisible to the compiler's waitcnt insertion: wait here, and thread every
+        // fragment through the asm so that no consumer can be scheduled above it
+        if constexpr (TM == 4) {
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+v"(ra[0][0]), "+v"(ra[0][1]), "+v"(ra[1][0]), "+v"(ra[1][1]), "+v"(ra[2][0]), "+v"(ra[2][1]),
+                           "+v"(ra[3][0]), "+v"(ra[3][1]), "+v"(rb[0][0]), "+v"(rb[0][1]), "+v"(rb[1][0]), "+v"(rb[1][1]),
+                           "+v"(rb[2][0]), "+v"(rb[2][1]), "+v"(rb[3][0]), "+v"(rb[3][1])
+                         :
+                         : "memory");
+        } else {
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+v"(ra[0][0]), "+v"(ra[0][1]), "+v"(ra[1][0]), "+v"(ra[1][1]), "+v"(rb[0][0]), "+v"(rb[0][1]),
+                           "+v"(rb[1][0]), "+v"(rb[1][1]), "+v"(rb[2][0]), "+v"(rb[2][1]), "+v"(rb[3][0]), "+v"(rb[3][1])
+                         :
+                         : "memory");
+        }
         f16x8 fa[TM], fb[4];
 #pragma unroll
-        for (int t = 0; t < 8; ++t) {
-            const f16xTM va = *reinterpret_cast<const f16xTM*>(stage + a_off + t * (BM * 2));
-            const f16x4 vb = *reinterpret_cast<const f16x4*>(stage + b_off + t * (BN * 2));
+        for (int i = 0; i < TM; ++i) {
+            typedef int v4i __attribute__((ext_vector_type(4)));
+            const v4i t = {ra[i][0][0], ra[i][0][1], ra[i][1][0], ra[i][1][1]};
+            fa[i] = __builtin_bit_cast(f16x8, t);
+        }
 #pragma unroll
-            for (int i = 0; i < TM; ++i) fa[i][t] = va[i];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) fb[j][t] = vb[j];
+        for (int j = 0; j < 4; ++j) {
+            typedef int v4i __attribute__((ext_vector_type(4)));
+            const v4i t = {rb[j][0][0], rb[j][0][1], rb[j][1][0], rb[j][1][1]};
+            fb[j] = __builtin_bit_cast(f16x8, t);
         }
 #pragma unroll
         for (int i = 0; i < TM; ++i)
@@ -438,7 +482,7 @@ __global__ __launch_bounds__(128 * WNW) void conv_wgrad_dma_kernel(const WgradAr
     const int taps = d.kh * d.kw;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const int n = n0 + wn * 64 + 4 * (lane & 15) + j;
+        const int n = n0 + wn * 64 + j * 16 + (lane & 15);
         if (n >= a.ncols) continue;
         const int tap = n / d.cin, ci = n - tap * d.cin;
         if (ci >= a.cin_w) continue;
@@ -446,7 +490,7 @@ __global__ __launch_bounds__(128 * WNW) void conv_wgrad_dma_kernel(const WgradAr
         for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int co = co0 + wm * TM * 16 + TM * (4 * (lane >> 4) + r) + i;
+                const int co = co0 + wm * TM * 16 + i * 16 + 4 * (lane >> 4) + r;
                 if (co < d.cout) atomicAdd(d.dw + ((long)co * a.cin_w + ci) * taps + tap, acc[i][j][r]);
             }
     }
@@ -716,10 +760,11 @@ static void wgrad_geometry(const yh_wgrad_desc* d, WgradArgs* pa, int* psplits) 
     a.pixels = (long)d->n * d->ho * d->wo;
     const int bm = d->cout <= 64 ? 64 : WG_TILE;        // 64-row tiles for the early, wide-resolution layers
     a.ncols = d->kh * d->kw * d->cin;
-    a.interleaved = d->dtype == YH_F16 && d->splits != -1;   // the LDS-DMA kernel
+    a.dma = d->dtype == YH_F16 && d->splits != -1;           // the LDS-DMA kernel
+    a.interleaved = 0;
     // 256-column tiles (8 waves) when they stay >= 85 % full; the register-staged kernels are 128 wide
     a.bn = WG_TILE;   // 256-column (8-wave) tiles measured slower (VGPR-limited to one workgroup per CU); YH_WGRAD_BN=256 selects them
-    { const char* e = getenv("YH_WGRAD_BN"); if (e && a.interleaved && bm == 128) a.bn = atoi(e); }
+    { const char* e = getenv("YH_WGRAD_BN"); if (e && a.dma && bm == 128) a.bn = atoi(e); }
     a.tiles_m = (d->cout + bm - 1) / bm;
     a.tiles_n = (a.ncols + a.bn - 1) / a.bn;
     a.ksteps = (int)((a.pixels + bk - 1) / bk);
@@ -782,7 +827,7 @@ extern "C" int yh_conv2d_wgrad(const yh_wgrad_desc* d, void* stream) {
     a.two_stage = d->ws && d->ws_floats >= (int64_t)splits * tiles * (narrow ? 64 : 128) * a.bn;
     const dim3 grid(tiles, splits);
     hipStream_t st = (hipStream_t)stream;
-    if (a.interleaved) {
+    if (a.dma) {
         if (narrow) hipLaunchKernelGGL((conv_wgrad_dma_kernel<2, 2>), grid, dim3(256), 0, st, a);
         else if (a.bn == 256) hipLaunchKernelGGL((conv_wgrad_dma_kernel<4, 4>), grid, dim3(512), 0, st, a);
         else hipLaunchKernelGGL((conv_wgrad_dma_kernel<4, 2>), grid, dim3(256), 0, st, a);
