@@ -48,6 +48,19 @@ struct ConvArgs {
     int y_h, y_w, y_off_h, y_off_w;  // ups == 3: output pixel (n, ho, wo) is stored at (n, 2 ho + y_off_h, 2 wo + y_off_w) of a y_h x y_w tensor
 };
 
+template <int CTRL> __device__ __forceinline__ float dpp_shr_add(float v) {
+    const int t = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true);
+    return v + __builtin_bit_cast(float, t);
+}
+// inclusive scan step pattern over a 16-lane DPP row; lane 15 of the row holds the sum of all 16 lanes
+__device__ __forceinline__ float row16_sum(float v) {
+    v = dpp_shr_add<0x111>(v);   // row_shr:1
+    v = dpp_shr_add<0x112>(v);   // row_shr:2
+    v = dpp_shr_add<0x114>(v);   // row_shr:4
+    v = dpp_shr_add<0x118>(v);   // row_shr:8
+    return v;
+}
+
 // compile-time unrolled loop: every array index below is a constant, so staging registers never
 // fall back to scratch (runtime-indexed private arrays do on this compiler)
 template <int N, typename F> __device__ __forceinline__ void static_for(F&& f) {
@@ -355,14 +368,10 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm_kernel(const ConvA
         for (int i = 0; i < TM; ++i) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                float s1 = st1[i][e], s2 = st2[i][e];
-#pragma unroll
-                for (int o = 1; o < 16; o <<= 1) {
-                    s1 += __shfl_xor(s1, o);
-                    s2 += __shfl_xor(s2, o);
-                }
+                // 16-lane row sums on the DPP path (row_shr 1, 2, 4, 8 with zero fill): lane 15 of each row ends with the total
+                const float s1 = row16_sum(st1[i][e]), s2 = row16_sum(st2[i][e]);
                 const int m = m0 + wm * TM * 16 + i * 16 + mq + e;
-                if (pc == 0 && m < a.Cout) {
+                if (pc == 15 && m < a.Cout) {
                     row[m] = s1;
                     row[a.Cout + m] = s2;
                 }
@@ -665,14 +674,10 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm_glds_kernel(const 
         for (int i = 0; i < TM; ++i) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                float s1 = st1[i][e], s2 = st2[i][e];
-#pragma unroll
-                for (int o = 1; o < 16; o <<= 1) {
-                    s1 += __shfl_xor(s1, o);
-                    s2 += __shfl_xor(s2, o);
-                }
+                // 16-lane row sums on the DPP path (row_shr 1, 2, 4, 8 with zero fill): lane 15 of each row ends with the total
+                const float s1 = row16_sum(st1[i][e]), s2 = row16_sum(st2[i][e]);
                 const int m = m0 + wm * TM * 16 + i * 16 + mq + e;
-                if (pc == 0 && m < a.Cout) {
+                if (pc == 15 && m < a.Cout) {
                     row[m] = s1;
                     row[a.Cout + m] = s2;
                 }

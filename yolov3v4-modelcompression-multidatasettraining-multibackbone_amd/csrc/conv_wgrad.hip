@@ -529,7 +529,10 @@ __global__ __launch_bounds__(128 * WNW) void wgrad_reduce_kernel(const WgradArgs
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int co = tm * (TM * 32) + wm * TM * 16 + (a.interleaved ? TM * (4 * (lane >> 4) + r) + i : i * 16 + 4 * (lane >> 4) + r);
-        if (co < d.cout) atomicAdd(d.dw + ((long)co * a.cin_w + ci) * taps + tap, v[r]);
+        if (co >= d.cout) continue;
+        float* dst = d.dw + ((long)co * a.cin_w + ci) * taps + tap;
+        if (gridDim.y == 1) *dst += v[r];     // a single split group owns the element: plain accumulate
+        else atomicAdd(dst, v[r]);
     }
 }
 
