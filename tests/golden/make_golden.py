@@ -32,6 +32,7 @@ NET_CASES = [
     ('yolov4_320', 'yolov4/yolov4.cfg', 320, 1, 16),
     ('yolov3_608', 'yolov3/yolov3.cfg', 608, 1, 64),
     ('mobilenet_224', 'yolov3-mobilenet/yolov3-mobilenet-coco.cfg', 224, 2, 4),
+    ('yolov4tiny_416', 'yolov4tiny/yolov4-tiny.cfg', 416, 2, 2),
 ]
 
 

@@ -8,6 +8,7 @@ import refharness
 from utils.parse_config import parse_model_cfg
 
 PAIRS = ['yolov3/yolov3.cfg', 'yolov3tiny/yolov3-tiny.cfg', 'yolov3tiny/yolov3-tiny-hand.cfg', 'yolov4/yolov4.cfg',
+         'yolov4tiny/yolov4-tiny.cfg',
          'yolov3-mobilenet/yolov3-mobilenet-coco.cfg']
 
 

@@ -36,7 +36,7 @@ def _hip_forward(model, x, precision):
     return out
 
 
-@pytest.mark.parametrize('name', ['tiny_hand_416', 'yolov3_320', 'yolov4_320', 'yolov3_608', 'mobilenet_224'])
+@pytest.mark.parametrize('name', ['tiny_hand_416', 'yolov3_320', 'yolov4_320', 'yolov3_608', 'mobilenet_224', 'yolov4tiny_416'])
 def test_fp32_engine_matches_reference_golden_and_oracle(name, cfg_dir):
     fx = np.load(os.path.join(GOLD, 'net_%s.npz' % name))
     rel, size, batch, rs = str(fx['cfg']), int(fx['size']), int(fx['batch']), int(fx['row_stride'])
@@ -57,7 +57,7 @@ def test_fp32_engine_matches_reference_golden_and_oracle(name, cfg_dir):
         assert (r.cpu() - ro).abs().max().item() <= 5e-4
 
 
-@pytest.mark.parametrize('name', ['tiny_hand_416', 'yolov3_320', 'yolov4_320', 'mobilenet_224'])
+@pytest.mark.parametrize('name', ['tiny_hand_416', 'yolov3_320', 'yolov4_320', 'mobilenet_224', 'yolov4tiny_416'])
 def test_fp16_engine_bounded_drift(name, cfg_dir):
     fx = np.load(os.path.join(GOLD, 'net_%s.npz' % name))
     rel, size, batch, rs = str(fx['cfg']), int(fx['size']), int(fx['batch']), int(fx['row_stride'])

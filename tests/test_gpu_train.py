@@ -471,7 +471,8 @@ def test_mini_sgd_steps_track_eager(libs, mini):
             assert (pa - pb.cpu()).abs().max().item() <= 1e-4 * (pa.abs().max().item() + 1e-3), k
 
 
-@pytest.mark.parametrize('rel', ['yolov3tiny/yolov3-tiny.cfg', 'yolov4/yolov4.cfg'], ids=['yolov3-tiny', 'yolov4'])
+@pytest.mark.parametrize('rel', ['yolov3tiny/yolov3-tiny.cfg', 'yolov4/yolov4.cfg', 'yolov4tiny/yolov4-tiny.cfg'],
+                         ids=['yolov3-tiny', 'yolov4', 'yolov4-tiny'])
 def test_maxpool_graphs_train_step_against_fp64(libs, rel):
     """yolov3-tiny (maxpools) and YOLOv4 (mish, SPP, PAN) on the GPU training path vs an fp64 eager run."""
     cfg = os.path.join(conftest.PKG, 'cfg', rel)

@@ -15,7 +15,7 @@ import synth
 from engine.plan import DarknetEngine
 from test_oracle_golden import GOLD, build_mirror
 
-CASES = ['tiny_hand_416', 'yolov3_320', 'yolov4_320', 'mobilenet_224']
+CASES = ['tiny_hand_416', 'yolov3_320', 'yolov4_320', 'mobilenet_224', 'yolov4tiny_416']
 
 
 @pytest.mark.parametrize('name', CASES)
@@ -38,7 +38,10 @@ def test_lowered_network_matches_reference_golden(name, prec, cfg_dir):
         assert (r - rr).abs().max().item() <= (2e-4 if prec == 'fp32' else 0.05)
     plan = next(iter(eng._plans.values()))
     kinds = {''.join(c for c in what if not c.isdigit()) for what, _ in plan['ops']}
-    assert kinds <= {'stem', 'conv', 'pool', 'yolo', 'dw', 'se'}, 'shortcut/route/upsample must all be fused: %s' % kinds
+    allowed = {'stem', 'conv', 'pool', 'yolo', 'dw', 'se'}
+    if 'yolov4tiny' in name:   # its stride-16 feature map sits in two concats: the second one has to copy it
+        allowed = allowed | {'cat'}
+    assert kinds <= allowed, 'shortcut/route/upsample must all be fused: %s' % kinds
 
 
 def _odd_cfg():

@@ -90,7 +90,8 @@ def test_unsupported_cfg_reports_not_implemented():
         eng._get_plan(torch.zeros(1, 3, 64, 64))
 
 
-@pytest.mark.parametrize('rel,size', [('yolov3tiny/yolov3-tiny.cfg', 64), ('yolov4/yolov4.cfg', 64)], ids=['yolov3-tiny', 'yolov4'])
+@pytest.mark.parametrize('rel,size', [('yolov3tiny/yolov3-tiny.cfg', 64), ('yolov4/yolov4.cfg', 64), ('yolov4tiny/yolov4-tiny.cfg', 64)],
+                         ids=['yolov3-tiny', 'yolov4', 'yolov4-tiny'])
 def test_maxpool_and_mish_graphs_train_on_the_hip_path(rel, size):
     """yolov3-tiny (2/2 and 2/1 zero-edge maxpools) and YOLOv4 (mish, SPP 5/9/13, PAN routes) against eager autograd.
     Maxpool routes gradient by argmax, which flips under round-off when two window entries are within an ulp, so the
@@ -108,7 +109,7 @@ def test_maxpool_and_mish_graphs_train_on_the_hip_path(rel, size):
     tot = sum(grads64[k].norm().item() ** 2 for k in grads64) ** 0.5
     assert num <= 4 * den + 2e-4 * tot, (num / tot, den / tot)
     kinds = [w.rstrip('0123456789') for w, _ in m.__dict__['_hip_train_engine']._current['bwd_ops']]
-    assert kinds.count('dpool') == (6 if 'tiny' in rel else 3)
+    assert kinds.count('dpool') == {'yolov3tiny/yolov3-tiny.cfg': 6, 'yolov4/yolov4.cfg': 3, 'yolov4tiny/yolov4-tiny.cfg': 3}[rel]
 
 
 def test_yolov3_train_plan_against_fp64(mini):

@@ -973,8 +973,8 @@ static int launch(const ConvArgs& a0, hipStream_t stream) {
 // The automatic choice below was fitted to per-layer measurements on MI355X (profiles/r01_tile_ab.txt):
 // the kernels are bound by global->LDS delivery, so the tile with the most FLOP per staged byte wins as
 // long as it still yields >= ~1 workgroup wave over the 256 CUs.
-static int pick_tile(int cout, long P, int cin_k, int vec) {
-    (void)cin_k; (void)vec;
+static int pick_tile(int cout, long P, int cin_k, int vec, int taps = 1) {
+    (void)vec;
     const int c = cout;
     const long w256 = ((c + 255) / 256) * 256, w128 = ((c + 127) / 128) * 128, w64 = ((c + 63) / 64) * 64,
                w32 = ((c + 31) / 32) * 32;
@@ -986,11 +986,14 @@ static int pick_tile(int cout, long P, int cin_k, int vec) {
         return 25;
     }
     if (w64 <= w32) return blocks(64, 256) >= 2048 ? 24 : 24;
+    // <= 32 outputs: the 32-row register-staged tile, except for long K (3x3 over >= 64 channels: the data gradient of the
+    // early layers), where the LDS-DMA 64x128 tile wins despite its idle upper half (0.77 vs 0.98 ms at 304x304, 64 -> 32)
+    if ((long)cin_k * taps >= 512) return 24;
     return 3;
 }
 
 template <typename T, typename OutT> static int dispatch_tile(const ConvArgs& a, int tile, hipStream_t s) {
-    if (tile == 0) tile = pick_tile(a.Cout, a.P, a.cin_k, Prec<T>::VEC);
+    if (tile == 0) tile = pick_tile(a.Cout, a.P, a.cin_k, Prec<T>::VEC, a.R * a.S);
     switch (tile) {
         case 1: return launch<T, OutT, 128, 128, 2, 2, 4>(a, s);
         case 2: return launch<T, OutT, 64, 256, 1, 4, 4>(a, s);
@@ -1070,7 +1073,7 @@ extern "C" int yh_qconv_pack_weights(const float* q_weight, float w_scale, const
 extern "C" int yh_conv2d_tile(const yh_conv_desc* d) {
     if (!d) return YH_EINVAL;
     if (d->tile != 0) return d->tile;
-    const int t = yh::pick_tile(d->cout, (long)d->n * d->ho * d->wo, d->cin_k, d->dtype == YH_F16 ? 8 : 4);
+    const int t = yh::pick_tile(d->cout, (long)d->n * d->ho * d->wo, d->cin_k, d->dtype == YH_F16 ? 8 : 4, d->kh * d->kw);
     return (d->dtype == YH_I8 && t == 3) ? 24 : t;
 }
 

@@ -139,7 +139,7 @@ class TrainEngine(DarknetEngine):
     # --------------------------------------------------------------------------------- plans
     def _check_supported(self, values):
         for v in values:
-            if v.kind in ('dw', 'se', 'slice', 'qadd'):
+            if v.kind in ('dw', 'se', 'qadd'):
                 raise NotImplementedError('HIP training path: %s blocks are not lowered yet (block %s)' % (v.kind, v.block))
             if v.kind == 'conv':
                 if v.src.kind != 'input' and (v.src.C % ALIGN_C or v.src.c_phys != v.src.C):
@@ -214,6 +214,10 @@ class TrainEngine(DarknetEngine):
         plan['param_slices'] = []   # (arena offset, numel, shape) in parameters() order
         for v in values:
             if v.kind == 'input':
+                continue
+            if v.kind == 'slice':   # a channel range of its source: same buffers, forward and gradient
+                materialize(v.src)
+                v.storage, v.gstorage, v.c_off, v.ld = v.src.storage, v.src.gstorage, v.src.c_off + v.first, v.src.ld
                 continue
             materialize(v)
             if v.kind != 'conv':
@@ -407,6 +411,8 @@ class TrainEngine(DarknetEngine):
                     contribute(v.a, gptr(v), v.ld, None, 'dadd%d' % v.block)
                     contribute(v.b, gptr(v), v.ld, None, 'dadd%d' % v.block)
                 continue
+            if v.kind == 'slice':
+                continue   # contributions to the slice were written straight into the source's gradient buffer
             if v.kind == 'pool':
                 if has_grad(v):
                     s = v.src

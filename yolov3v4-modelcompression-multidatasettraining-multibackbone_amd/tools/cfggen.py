@@ -131,6 +131,45 @@ def yolov3_tiny(classes=80, size=416, anchors=TINY_ANCHORS, steps='400000,450000
     return w.text()
 
 
+def yolov4_tiny(classes=80, size=416, anchors=TINY_ANCHORS):
+    """CSPDarknet-tiny: three CSP stages whose inner branch is the second channel half of the stage input
+    (``route groups=2 group_id=1``), 2/2 maxpools, two heads (stride 32, 16)."""
+    w = CfgWriter()
+    w.net(batch=64, subdivisions=1, width=size, height=size, channels=3, momentum=0.9, decay=0.0005, angle=0, saturation=1.5,
+          exposure=1.5, hue='.1', learning_rate=0.00261, burn_in=1000, max_batches=500200, policy='steps',
+          steps='400000,450000', scales='.1,.1')
+    head_filters = 3 * (classes + 5)
+    yolo_extra = dict(scale_x_y='1.05', cls_normalizer='1.0', iou_normalizer='0.07', iou_loss='ciou', ignore_thresh='.7',
+                      truth_thresh=1, random=0, resize='1.5', nms_kind='greedynms', beta_nms='0.6')
+    w.conv(32, 3, stride=2)
+    w.conv(64, 3, stride=2)
+    feat = None
+    for width in (64, 128, 256):
+        w.conv(width, 3)
+        w.block('route', layers=-1, groups=2, group_id=1)
+        w.conv(width // 2, 3)
+        w.conv(width // 2, 3)
+        w.route(-1, -2)
+        w.conv(width, 1)
+        if width == 256:
+            feat = w.n
+        w.route(-6, -1)
+        w.maxpool(2, 2)
+    w.conv(512, 3)
+    w.conv(256, 1)
+    w.conv(512, 3)
+    w.conv(head_filters, 1, act='linear', bn=0)
+    w.yolo((3, 4, 5), anchors, classes, 6, **yolo_extra)
+    w.route(-4)
+    w.conv(128, 1)
+    w.upsample(2)
+    w.route(-1, feat)
+    w.conv(256, 3)
+    w.conv(head_filters, 1, act='linear', bn=0)
+    w.yolo((0, 1, 2), anchors, classes, 6, **yolo_extra)
+    return w.text()
+
+
 def yolov4(classes=80, size=608, anchors=COCO_ANCHORS_V4):
     """CSPDarknet-53 (Mish) + SPP + PANet neck (LeakyReLU) + 3 heads ordered stride 8, 16, 32."""
     w = CfgWriter()
@@ -259,6 +298,7 @@ GENERATED = {
     'yolov3tiny/yolov3-tiny-hand.cfg': lambda: yolov3_tiny(1, 416, TINY_HAND_ANCHORS, '15,25,60,99,150,160,180',
                                                            '0.5,0.5,0.1,0.5,0.5,0.1,0.1'),
     'yolov4/yolov4.cfg': lambda: yolov4(80, 608),
+    'yolov4tiny/yolov4-tiny.cfg': lambda: yolov4_tiny(80, 416),
 }
 
 
