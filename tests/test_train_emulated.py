@@ -133,3 +133,39 @@ def test_yolov3_train_plan_against_fp64(mini):
     kinds = [w.rstrip('0123456789') for w, _ in plan['bwd_ops']]
     # 69 stride-1 data gradients + 5 stride-2 layers x 4 parity phases
     assert kinds.count('wgrad') == 75 and kinds.count('dgrad') == 69 + 5 * 4
+
+
+def test_backward_ranges_hand_gradients_over_early(mini, monkeypatch):
+    """The backward plan is cut into ranges (engine/train.py ``_make_segments``): same gradients as one range, and the
+    gradients of the last layers reach autograd (hence DDP's bucket hooks) before the first layers' backward has run."""
+    from engine.train import TrainEngine
+    model = th.build(mini, 64)
+    x = synth.image_batch(2, 64, seed=0)
+    results = {}
+    for nseg in (1, 4):
+        monkeypatch.setenv('YOLO_HIP_TRAIN_SEGMENTS', str(nseg))
+        m = __import__('copy').deepcopy(model)
+        lib = fakelib.FakeLib()
+        m.__dict__['_hip_train_engine'] = TrainEngine(m, 'fp32', lib=lib)
+        raws, _ = m._forward_hip_train(x)
+        plan = m.__dict__['_hip_train_engine']._current
+        assert len(plan['segments']) == nseg
+        assert [s['ops'][0] for s in plan['segments']] == sorted((s['ops'][0] for s in plan['segments']), reverse=True)
+        params = list(m.parameters())
+        fired = {}
+        n_fwd = len(lib.calls)
+        def mark(name, fired=fired, lib=lib, n_fwd=n_fwd):
+            def hook(g):
+                fired.setdefault(name, len(lib.calls) - n_fwd)
+            return hook
+        params[-1].register_hook(mark('last'))
+        params[0].register_hook(mark('first'))
+        ws = th.loss_weights(raws)
+        th.toy_loss(raws, ws).backward()
+        results[nseg] = ({k: p.grad.clone() for k, p in m.named_parameters()}, fired, len(plan['bwd_ops']))
+    g1, _, _ = results[1]
+    g4, fired, nops = results[4]
+    for k in g1:
+        assert torch.equal(g1[k], g4[k]), k
+    assert fired['first'] == nops                      # the first layer's gradient needs the whole backward plan
+    assert 0 < fired['last'] < nops // 2               # the last layer's gradient is out after the first range

@@ -28,6 +28,7 @@ Blocks this path does not lower yet (depthwise, SE, group-split routes, weighted
 build; ``models.Darknet`` then keeps such cfgs on its eager torch path for training.
 """
 import ctypes as C
+import os
 
 import torch
 import torch.nn as nn
@@ -224,6 +225,7 @@ class TrainEngine(DarknetEngine):
                 continue
             conv, bn = v.conv, v.bn
             taps = v.k * v.k
+            v.p_first = len(plan['param_slices'])
             v.g_w = grads.reserve(conv.weight.numel())
             plan['param_slices'].append((v.g_w, conv.weight.numel(), tuple(conv.weight.shape)))
             v.g_b = None
@@ -396,7 +398,9 @@ class TrainEngine(DarknetEngine):
         def has_grad(t):
             return t.fp32 or id(t.gstorage) in initialised
 
+        bwd_pos = {}   # value -> index of its first backward op (ops of value i span [pos[i], pos[i-1]) in emission order)
         for v in reversed(values):
+            bwd_pos[id(v)] = len(plan['bwd_ops'])
             if v.kind == 'input':
                 continue
             if v.kind == 'concat':
@@ -526,6 +530,7 @@ class TrainEngine(DarknetEngine):
                     ConvDesc(x=dzp, w=P(pk['wt']), res=gptr(s) if mode == 'acc' else None, y=gptr(s), h=v.Ho, w_in=v.Wo, ho=s.H,
                              wo=s.W, kh=v.k, kw=v.k, pad=v.k - 1 - v.pad, ups=1, **common), 'dgrad%d' % v.block)
         plan['head_shapes'] = [(N, h.src.H, h.src.W, h.src.c_phys) for h in heads]
+        plan['segments'] = self._make_segments(plan, values, heads, bwd_pos)
         plan['ws'] = alloc((max(plan['ws_floats'], 4),), fp32=True)
         for handle in (fwd, bwd):
             lib.yh_plan_bind_slot(handle, SLOT_WS, plan['ws'].data_ptr())
@@ -577,29 +582,86 @@ class TrainEngine(DarknetEngine):
         self.steps += 1
         return heads
 
-    def backward(self, head_grads):
-        """fp32 head gradients (same shapes as ``forward``'s outputs) -> list of fp32 parameter gradients."""
+    def _make_segments(self, plan, values, heads, bwd_pos):
+        """Cut the backward plan into ranges of about equal parameter size (forward order of the conv blocks).
+
+        Each range is one autograd node in ``models.Darknet``: its parameter gradients are handed to autograd (and to
+        DistributedDataParallel's bucket hooks) as soon as the range has run, so the RCCL all-reduce of a bucket overlaps
+        with the backward kernels of the earlier layers instead of starting after the whole backward plan."""
+        want = max(1, int(os.environ.get('YOLO_HIP_TRAIN_SEGMENTS', '8')))
+        convs = [i for i, v in enumerate(values) if v.kind == 'conv']
+        total = sum(values[i].conv.weight.numel() for i in convs)
+        cuts, acc, target = [1], 0, total / want           # value index where each segment starts (value 0 is the input)
+        for i in convs:
+            if acc >= target * len(cuts) and i > cuts[-1]:
+                cuts.append(i)
+            acc += values[i].conv.weight.numel()
+        cuts.append(len(values))
+        nparams = len(plan['param_slices'])
+        segs = []
+        for k in range(len(cuts) - 1):
+            lo, hi = cuts[k], cuts[k + 1]
+            cv = [values[i] for i in range(lo, hi) if values[i].kind == 'conv']
+            p_lo = cv[0].p_first if cv else nparams
+            nxt = [values[i] for i in range(hi, len(values)) if values[i].kind == 'conv']
+            p_hi = nxt[0].p_first if nxt else nparams
+            segs.append(dict(values=(lo, hi), ops=(bwd_pos[id(values[hi - 1])], bwd_pos[id(values[lo - 1])]), params=(p_lo, p_hi),
+                             heads=[j for j, h in enumerate(heads) if any(h.src is values[i] for i in range(lo, hi))]))
+        assert segs[0]['ops'][1] == len(plan['bwd_ops']) and segs[-1]['ops'][0] == 0
+        return segs
+
+    def backward_segment(self, k, head_grads):
+        """Run backward range ``k`` (the last range first).  ``head_grads``: fp32 gradients of this range's heads, in the
+        order of ``plan['segments'][k]['heads']``.  Returns the fp32 gradients of the range's parameters."""
         plan = self._current
         if plan is None:
             raise RuntimeError('backward() without a preceding forward()')
-        lib = self.lib
-        x = plan['x']
-        plan['grads'].buf.zero_()
-        for t in plan['zero_list']:
-            t.zero_()
-        keep = []
-        lib.yh_plan_bind_slot(plan['bwd'], SLOT_INPUT, x.data_ptr())
-        for k, (g, shape) in enumerate(zip(head_grads, plan['head_shapes'])):
+        lib, x = self.lib, plan['x']
+        seg, nseg = plan['segments'][k], len(plan['segments'])
+        if k == nseg - 1:
+            plan['grads'].buf.zero_()
+            for t in plan['zero_list']:
+                t.zero_()
+            lib.yh_plan_bind_slot(plan['bwd'], SLOT_INPUT, x.data_ptr())
+            plan['bwd_next'] = nseg - 1
+            plan['bwd_keep'] = []
+        if plan.get('bwd_next') != k:
+            raise RuntimeError('backward ranges must run last to first (expected %s, got %d)' % (plan.get('bwd_next'), k))
+        for j, g in zip(seg['heads'], head_grads):
+            shape = plan['head_shapes'][j]
             if g is None:
                 g = torch.zeros(shape, device=x.device, dtype=torch.float32)
             g = g.contiguous().float()
             if tuple(g.shape) != tuple(shape):
-                raise ValueError('head gradient %d has shape %s, expected %s' % (k, tuple(g.shape), shape))
-            keep.append(g)
-            lib.yh_plan_bind_slot(plan['bwd'], SLOT_HEAD0 + k, g.data_ptr())
-        hiplib.check(lib.yh_plan_run(plan['bwd'], hiplib.stream_ptr()), 'yh_plan_run(train backward)')
-        flat = plan['grads'].buf.clone()   # autograd may keep (and later accumulate into) what we return
-        return [flat[off:off + n].view(shape) for off, n, shape in plan['param_slices']]
+                raise ValueError('head gradient %d has shape %s, expected %s' % (j, tuple(g.shape), shape))
+            plan['bwd_keep'].append(g)
+            lib.yh_plan_bind_slot(plan['bwd'], SLOT_HEAD0 + j, g.data_ptr())
+        first, last = seg['ops']
+        if last > first:
+            hiplib.check(lib.yh_plan_run_range(plan['bwd'], first, last, hiplib.stream_ptr()), 'yh_plan_run_range(train backward)')
+        plan['bwd_next'] = k - 1
+        p_lo, p_hi = seg['params']
+        if p_hi == p_lo:
+            return []
+        off_lo = plan['param_slices'][p_lo][0]
+        off_hi = plan['param_slices'][p_hi - 1][0] + _round_up(plan['param_slices'][p_hi - 1][1], 4)
+        flat = plan['grads'].buf[off_lo:off_hi].clone()   # autograd may keep (and later accumulate into) what we return
+        return [flat[off - off_lo:off - off_lo + n].view(shape) for off, n, shape in plan['param_slices'][p_lo:p_hi]]
+
+    def backward(self, head_grads):
+        """All ranges at once: fp32 head gradients (``forward``'s order) -> list of fp32 parameter gradients."""
+        plan = self._current
+        if plan is None:
+            raise RuntimeError('backward() without a preceding forward()')
+        out = [None] * len(plan['segments'])
+        for k in reversed(range(len(plan['segments']))):
+            out[k] = self.backward_segment(k, [head_grads[j] for j in plan['segments'][k]['heads']])
+        return [g for seg in out for g in seg]
+
+    def segment_parameters(self, plan):
+        """The parameter list split per backward range (same order as ``parameters()``)."""
+        params = self.parameters()
+        return [params[seg['params'][0]:seg['params'][1]] for seg in plan['segments']]
 
     def _drop_plans(self):
         super()._drop_plans()

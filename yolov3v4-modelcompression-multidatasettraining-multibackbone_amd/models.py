@@ -316,28 +316,33 @@ class YOLOLayer(nn.Module):
 
 
 # ------------------------------------------------------------------------------------------- network
-class _HipTrainFunction(torch.autograd.Function):
-    """Autograd node of one training step on the HIP engine: parameters in, fp32 NHWC head tensors out.
+class _HipTrainSegment(torch.autograd.Function):
+    """Autograd node of one backward RANGE of a training step on the HIP engine.
 
-    ``backward`` hands the head gradients to ``TrainEngine.backward`` and returns its fp32 parameter gradients, so
-    optimizers, GradScaler, gradient accumulation and DistributedDataParallel hooks see ordinary ``.grad`` tensors."""
+    The step is a chain of these nodes (engine/train.py ``_make_segments``): node 0's forward runs the whole forward
+    plan, the others only hand out the head tensors computed in their range; a dummy token links node k to node k+1
+    so autograd runs the backward ranges last to first.  Each node returns its range's fp32 parameter gradients as
+    soon as that range has run — optimizers, GradScaler, gradient accumulation and DistributedDataParallel's bucket
+    hooks see ordinary ``.grad`` tensors, and DDP can all-reduce a bucket while earlier layers are still in backward."""
 
     @staticmethod
-    def forward(ctx, engine, x, *params):
-        heads = engine.forward(x)
-        ctx.engine = engine
-        ctx.step = engine.steps
-        return tuple(heads)
+    def forward(ctx, engine, k, token, *params):
+        if k == 0:
+            engine.step_heads = engine.forward(token)       # token of range 0 is the input batch
+        plan = engine._current
+        ctx.engine, ctx.k, ctx.step = engine, k, engine.steps
+        heads = [engine.step_heads[j] for j in plan['segments'][k]['heads']]
+        return (torch.zeros(1, device=heads[0].device if heads else engine.step_heads[0].device),) + tuple(heads)
 
     @staticmethod
     @torch.autograd.function.once_differentiable
-    def backward(ctx, *head_grads):
+    def backward(ctx, g_token, *head_grads):
         eng = ctx.engine
         if eng.steps != ctx.step:
             raise RuntimeError('HIP training path: backward() of a forward whose buffers were overwritten by a later '
                                'forward (one forward per backward, like gradient checkpointing-free eager training)')
-        grads = eng.backward(head_grads)
-        return (None, None) + tuple(grads)
+        grads = eng.backward_segment(ctx.k, head_grads)
+        return (None, None, None) + tuple(grads)
 
 
 class Darknet(nn.Module):
@@ -429,7 +434,14 @@ class Darknet(nn.Module):
             eng = TrainEngine(self, precision=precision)
             eng._get_plan(x)  # NotImplementedError surfaces here, before any state changes
             self.__dict__['_hip_train_engine'] = eng
-        heads = _HipTrainFunction.apply(eng, x, *eng.parameters())
+        plan = eng._get_plan(x)
+        heads = [None] * len(self.yolo_layers)
+        token = x
+        for k, params in enumerate(eng.segment_parameters(plan)):
+            res = _HipTrainSegment.apply(eng, k, token, *params)
+            token = res[0]
+            for j, h in zip(plan['segments'][k]['heads'], res[1:]):
+                heads[j] = h
         yolo_out = []
         for h, idx in zip(heads, self.yolo_layers):
             m = self.module_list[idx]
