@@ -502,3 +502,56 @@ def test_yolov3_train_step_against_fp64(libs):
     den = sum((grads32[k] - grads64[k]).norm().item() ** 2 for k in grads64) ** 0.5
     tot = sum(grads64[k].norm().item() ** 2 for k in grads64) ** 0.5
     assert num <= 4 * den + 1e-4 * tot, (num / tot, den / tot)
+
+
+def _protocol_targets(batch, seed=1):
+    """nt = 8 N rows [img, cls, x, y, w, h], xy ~ U(0.1, 0.9), wh ~ U(0.05, 0.35), seed 1."""
+    g = torch.Generator().manual_seed(seed)
+    n = 8 * batch
+    img = torch.arange(batch).repeat_interleave(8).float().view(-1, 1)
+    cls = torch.randint(0, 80, (n, 1), generator=g).float()
+    xy = torch.rand(n, 2, generator=g) * 0.8 + 0.1
+    wh = torch.rand(n, 2, generator=g) * 0.30 + 0.05
+    return torch.cat((img, cls, xy, wh), 1)
+
+
+@pytest.mark.parametrize('precision,loss_tol,norm_tol', [('fp32', 1e-3, 1e-2), ('fp16', 1e-2, 5e-2)], ids=['fp32', 'fp16'])
+def test_training_step_protocol_loss_and_grad_norm(libs, precision, loss_tol, norm_tol):
+    """The SURVEY 8(d) training-parity protocol on YOLOv3 @320, batch 2: train-mode forward + compute_loss (train.py's
+    default hyp, gr = 1) + backward on the GPU path against the same step on the CPU eager modules (fp32): loss items
+    within 1e-3 relative and the global gradient norm within 1e-2 relative (fp16 engine vs the fp32 oracle: 1e-2 / 5e-2)."""
+    import copy
+    from models import Darknet
+    from utils.utils import compute_loss
+    hyp = {'giou': 3.54, 'cls': 37.4, 'cls_pw': 1.0, 'obj': 64.3, 'obj_pw': 1.0, 'iou_t': 0.20, 'fl_gamma': 0.0}
+    torch.manual_seed(0)
+    model = Darknet(os.path.join(conftest.PKG, 'cfg', 'yolov3', 'yolov3.cfg'), (320, 320)).train()
+    state = model.state_dict()
+    synth.randomize_bn_(state, seed=1)
+    model.load_state_dict(state)
+    model.nc, model.hyp, model.gr = 80, hyp, 1.0
+    x = synth.image_batch(2, 320, seed=0)
+    targets = _protocol_targets(2)
+    ref = copy.deepcopy(model)
+    pred, _ = ref(x)
+    loss_ref, items_ref = compute_loss(pred, targets, ref)
+    loss_ref.backward()
+    norm_ref = sum(p.grad.norm().item() ** 2 for p in ref.parameters()) ** 0.5
+    dev = copy.deepcopy(model).to(GPU)
+    os.environ['YOLO_HIP_TRAIN_PRECISION'] = precision
+    try:
+        if DRY:
+            from engine.train import TrainEngine
+            dev.__dict__['_hip_train_engine'] = TrainEngine(dev, precision, lib=fakelib.FakeLib())
+            pred, _ = dev._forward_hip_train(x)
+        else:
+            pred, _ = dev(x.to(GPU))
+        loss, items = compute_loss(pred, targets.to(GPU), dev)
+        loss.backward()
+    finally:
+        del os.environ['YOLO_HIP_TRAIN_PRECISION']
+    assert dev.__dict__.get('_hip_train_engine') is not None
+    rel = ((items.cpu() - items_ref).abs() / items_ref.abs().clamp(min=1e-6)).max().item()
+    assert rel <= loss_tol, (items.cpu(), items_ref)
+    norm = sum(p.grad.norm().item() ** 2 for p in dev.parameters()) ** 0.5
+    assert abs(norm - norm_ref) <= norm_tol * norm_ref, (norm, norm_ref)
