@@ -1,0 +1,149 @@
+"""Host side of the drop-in boundary: utils.datasets, test.test, train.train, detect.detect on a small
+synthetic image set (PNG files + label files generated here), CPU eager path.  The reference's own loaders need OpenCV
+(absent in this image), so parity here is on documented behaviour: letterbox geometry, label transforms, collate
+format, the test() return contract, checkpoint contents."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+from PIL import Image
+
+import conftest
+
+
+@pytest.fixture(scope='module')
+def dataset_dir(tmp_path_factory):
+    """12 images of random size with 1-3 bright rectangles on a dark background; class = 0 (wide) / 1 (tall)."""
+    root = tmp_path_factory.mktemp('synthdata')
+    img_dir, lab_dir = root / 'images', root / 'labels'
+    img_dir.mkdir()
+    lab_dir.mkdir()
+    rng = np.random.RandomState(0)
+    files = []
+    for i in range(12):
+        w, h = int(rng.randint(90, 160)), int(rng.randint(70, 140))
+        img = (rng.rand(h, w, 3) * 40).astype(np.uint8)
+        rows = []
+        for _ in range(rng.randint(1, 4)):
+            bw, bh = rng.uniform(0.2, 0.5), rng.uniform(0.2, 0.5)
+            cx, cy = rng.uniform(bw / 2, 1 - bw / 2), rng.uniform(bh / 2, 1 - bh / 2)
+            x1, x2, y1, y2 = int((cx - bw / 2) * w), int((cx + bw / 2) * w), int((cy - bh / 2) * h), int((cy + bh / 2) * h)
+            img[y1:y2, x1:x2] = rng.randint(150, 255, 3)
+            rows.append('%d %.6f %.6f %.6f %.6f' % (0 if bw * w > bh * h else 1, cx, cy, bw, bh))
+        p = img_dir / ('im_%02d.png' % i)
+        Image.fromarray(img).save(p)
+        (lab_dir / ('im_%02d.txt' % i)).write_text('\n'.join(rows) + '\n')
+        files.append(str(p))
+    (root / 'train.txt').write_text('\n'.join(files[:8]) + '\n')
+    (root / 'valid.txt').write_text('\n'.join(files[8:]) + '\n')
+    (root / 'synth.names').write_text('wide\ntall\n')
+    (root / 'synth.data').write_text('classes=2\ntrain=%s\nvalid=%s\nnames=%s\n' % (root / 'train.txt', root / 'valid.txt', root / 'synth.names'))
+    return root
+
+
+@pytest.fixture(scope='module')
+def tiny_cfg(tmp_path_factory):
+    import train_harness as th
+    path = tmp_path_factory.mktemp('cfg') / 'mini2.cfg'
+    path.write_text(th.mini_cfg_text())
+    return str(path)
+
+
+def test_letterbox_geometry():
+    from utils.datasets import letterbox
+    img = np.full((50, 100, 3), 200, np.uint8)
+    out, ratio, (dw, dh) = letterbox(img, 64, auto=False)
+    assert out.shape == (64, 64, 3) and ratio == (0.64, 0.64) and (dw, dh) == (0.0, 16.0)
+    assert (out[:16] == 114).all() and (out[48:] == 114).all() and (out[16:48] == 200).all()
+    out, ratio, (dw, dh) = letterbox(img, 128, auto=True)           # minimum rectangle: pad only to a multiple of 64
+    assert out.shape == (64, 128, 3) and (dw, dh) == (0.0, 0.0)
+    out, ratio, _ = letterbox(img, (64, 64), auto=False, scaleFill=True)
+    assert out.shape == (64, 64, 3) and ratio == (0.64, 1.28)
+    small = np.zeros((10, 20, 3), np.uint8)
+    out, ratio, _ = letterbox(small, 64, auto=False, scaleup=False)  # never enlarges
+    assert ratio == (1.0, 1.0) and out.shape == (64, 64, 3)
+
+
+def test_dataset_items_and_collate(dataset_dir):
+    from utils.datasets import LoadImagesAndLabels
+    ds = LoadImagesAndLabels(str(dataset_dir / 'valid.txt'), img_size=96, batch_size=2, rect=True)
+    assert len(ds) == 4 and ds.batch_shapes.shape == (2, 2) and (ds.batch_shapes % 32 == 0).all()
+    ar = ds.shapes[:, 1] / ds.shapes[:, 0]
+    assert (np.diff(ar) >= 0).all(), 'rect mode sorts by aspect ratio'
+    batch = [ds[i] for i in range(2)]
+    imgs, labels, paths, shapes = ds.collate_fn(batch)
+    assert imgs.dtype == torch.uint8 and imgs.shape[0] == 2 and imgs.shape[1] == 3
+    assert tuple(imgs.shape[2:]) == tuple(ds.batch_shapes[0])
+    assert labels.shape[1] == 6 and set(labels[:, 0].tolist()) <= {0.0, 1.0}
+    assert (labels[:, 2:] >= 0).all() and (labels[:, 2:] <= 1).all()
+    # a label's box still covers its bright rectangle after the letterbox transform
+    img0, lab0 = batch[0][0].numpy(), batch[0][1].numpy()
+    h, w = img0.shape[1:]
+    for _, cls, cx, cy, bw, bh in lab0:
+        x1, x2, y1, y2 = int((cx - bw / 2) * w) + 2, int((cx + bw / 2) * w) - 2, int((cy - bh / 2) * h) + 2, int((cy + bh / 2) * h) - 2
+        assert img0[:, y1:y2, x1:x2].mean() > 100
+    # training mode: mosaic + flip + hsv keep the contract
+    hyp = dict(hsv_h=0.0138, hsv_s=0.678, hsv_v=0.36, degrees=0, translate=0, scale=0, shear=0)
+    tr = LoadImagesAndLabels(str(dataset_dir / 'train.txt'), img_size=64, batch_size=4, augment=True, hyp=hyp)
+    im, lab, _, sh = tr[0]
+    assert tuple(im.shape) == (3, 64, 64) and sh is None and lab.shape[1] == 6
+    assert (lab[:, 2:] >= 0).all() and (lab[:, 2:] <= 1).all()
+
+
+def test_train_test_detect_round_trip(dataset_dir, tiny_cfg, tmp_path, monkeypatch):
+    monkeypatch.chdir(tmp_path)
+    import train as train_mod
+    import test as test_mod
+    import detect as detect_mod
+    opt = train_mod.make_parser().parse_args(['--epochs', '2', '--batch-size', '4', '--cfg', tiny_cfg, '--data', str(dataset_dir / 'synth.data'),
+                                              '--img-size', '64', '64', '64', '--device', 'cpu', '--nosave', '--ema'])
+    opt.local_rank = -1
+    results = train_mod.train(opt, train_mod.hyp)
+    assert len(results) == 7 and all(np.isfinite(results))
+    assert os.path.isfile('weights/last.pt') and os.path.isfile('results.txt')
+    ckpt = torch.load('weights/last.pt', map_location='cpu', weights_only=False)
+    assert set(ckpt) >= {'epoch', 'best_fitness', 'training_results', 'model', 'optimizer'} and ckpt['epoch'] == 1
+    assert any(k.endswith('Conv2d.weight') for k in ckpt['model'])
+    # library call as the prune scripts make it: test(cfg, data, weights, ...)[0][2] is mAP
+    test_mod.opt = None
+    (mp, mr, m_ap, mf1, *losses), maps = test_mod.test(tiny_cfg, str(dataset_dir / 'synth.data'), 'weights/last.pt', batch_size=2, imgsz=64, plot=False)
+    assert 0.0 <= m_ap <= 1.0 and maps.shape == (2,) and len(losses) == 3
+    dopt = detect_mod.make_parser().parse_args(['--cfg', tiny_cfg, '--weights', 'weights/last.pt', '--source', str(dataset_dir / 'images'),
+                                               '--output', 'out', '--img-size', '64', '--conf-thres', '0.001', '--device', 'cpu',
+                                               '--names', str(dataset_dir / 'synth.names'), '--save-txt'])
+    res = detect_mod.detect(dopt)
+    assert len(res) == 12 and len(os.listdir('out')) >= 12
+
+
+def test_terminaltables_shim_and_star_imports():
+    import terminaltables
+    t = terminaltables.AsciiTable([['Metric', 'Before'], ['mAP', '0.5']]).table
+    assert 'Metric' in t and t.count('\n') == 4
+    ns = {}
+    exec('from models import *\nfrom utils.utils import *\nfrom utils.datasets import *', ns)
+    for name in ('Darknet', 'load_darknet_weights', 'non_max_suppression', 'compute_loss', 'LoadImages', 'LoadImagesAndLabels',
+                 'scale_coords', 'xyxy2xywh', 'ap_per_class', 'plot_one_box', 'labels_to_class_weights', 'fitness', 'init_seeds',
+                 'output_to_target', 'plot_images', 'strip_optimizer', 'letterbox'):
+        assert name in ns, name
+
+
+@pytest.mark.gpu
+def test_train_and_test_on_the_gpu_path(dataset_dir, tiny_cfg, tmp_path, monkeypatch):
+    """train.py (mixed precision) + test.test on a GPU: the HIP training and inference paths behind the entry points."""
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU')
+    monkeypatch.chdir(tmp_path)
+    import train as train_mod
+    import test as test_mod
+    opt = train_mod.make_parser().parse_args(['--epochs', '2', '--batch-size', '4', '--cfg', tiny_cfg, '--data', str(dataset_dir / 'synth.data'),
+                                              '--img-size', '64', '64', '64', '-mpt', '--nosave'])
+    opt.local_rank = -1
+    results = train_mod.train(opt, train_mod.hyp)
+    assert len(results) == 7 and all(np.isfinite(results))
+    ckpt = torch.load('weights/last.pt', map_location='cpu', weights_only=False)
+    assert ckpt['epoch'] == 1
+    test_mod.opt = None
+    (mp, mr, m_ap, mf1, *losses), maps = test_mod.test(tiny_cfg, str(dataset_dir / 'synth.data'), 'weights/last.pt', batch_size=2, imgsz=64, plot=False)
+    assert 0.0 <= m_ap <= 1.0 and all(np.isfinite(losses))

@@ -555,8 +555,18 @@ class TrainEngine(DarknetEngine):
         key = tuple(x.shape)
         plan = self._tplans.get(key)
         if plan is None:
+            # a plan owns every activation and gradient buffer of a step: keep only the two most recent input shapes
+            # (multi-scale training walks through a dozen sizes)
+            while len(self._tplans) >= 2:
+                old = self._tplans.pop(next(iter(self._tplans)))
+                for h in ('fwd', 'bwd'):
+                    self.lib.yh_plan_destroy(old[h])
+                if self._current is old:
+                    self._current = None
             plan = self._tplans[key] = self._build_train_plan(*key)
             self._wsig = None
+        else:
+            self._tplans[key] = self._tplans.pop(key)   # most recently used last
         return plan
 
     def forward(self, x):

@@ -395,3 +395,133 @@ def fitness(x):
 
 def get_yolo_layers(model):
     return [i for i, d in enumerate(model.module_defs) if d['type'] == 'yolo']
+
+
+# ------------------------------------------------------------------------------------ training / reporting helpers
+def labels_to_class_weights(labels, nc=80):
+    """Inverse-frequency class weights from the dataset's label arrays (reference utils.py:44-58)."""
+    if len(labels) == 0 or labels[0] is None:
+        return torch.Tensor()
+    classes = np.concatenate(labels, 0)[:, 0].astype(np.int64) if len(labels) else np.zeros(0, np.int64)
+    weights = np.bincount(classes, minlength=nc).astype(np.float64)
+    weights[weights == 0] = 1
+    weights = 1 / weights
+    return torch.from_numpy(weights / weights.sum()).float()
+
+
+def labels_to_image_weights(labels, nc=80, class_weights=np.ones(80)):
+    """Per-image sampling weight = class weights dotted with the image's class histogram (reference utils.py:61-68)."""
+    counts = np.array([np.bincount(l[:, 0].astype(np.int64), minlength=nc) for l in labels])
+    return (np.asarray(class_weights).reshape(1, nc) * counts).sum(1)
+
+
+def output_to_target(output, width, height):
+    """NMS output list -> (n, 7) rows [image, class, x, y, w, h, conf] normalised, for plotting (reference utils.py:1011-1036)."""
+    rows = []
+    for i, o in enumerate(output):
+        if o is None:
+            continue
+        o = o.detach().cpu().numpy() if isinstance(o, torch.Tensor) else np.asarray(o)
+        for x1, y1, x2, y2, conf, cls in o[:, :6]:
+            rows.append([i, cls, ((x1 + x2) / 2) / width, ((y1 + y2) / 2) / height, (x2 - x1) / width, (y2 - y1) / height, conf])
+    return np.array(rows, dtype=np.float32).reshape(-1, 7)
+
+
+def plot_one_box(x, img, color=None, label=None, line_thickness=None):
+    """Draw one xyxy box (and label) into an HWC uint8 RGB array, in place (reference utils.py:962-975; PIL instead of cv2)."""
+    from PIL import Image, ImageDraw
+    color = tuple(int(c) for c in (color or [random.randint(0, 255) for _ in range(3)]))
+    tl = line_thickness or max(round(0.002 * (img.shape[0] + img.shape[1]) / 2), 1)
+    pil = Image.fromarray(img)
+    draw = ImageDraw.Draw(pil)
+    box = [int(v) for v in x[:4]]
+    draw.rectangle(box, outline=color, width=int(tl))
+    if label:
+        w, h = 6 * len(label) + 4, 12
+        draw.rectangle([box[0], max(box[1] - h, 0), box[0] + w, max(box[1] - h, 0) + h], fill=color)
+        draw.text((box[0] + 2, max(box[1] - h, 0)), label, fill=(255, 255, 255))
+    img[:] = np.asarray(pil)
+
+
+def plot_images(images, targets, paths=None, fname='images.jpg', names=None, max_size=640, max_subplots=16, is_gray_scale=False):
+    """Mosaic of a batch with its boxes, written to ``fname`` (reference utils.py:1039-1111; PIL instead of cv2)."""
+    from PIL import Image
+    if os.path.isfile(fname):
+        return None
+    imgs = images.detach().cpu().float().numpy() if isinstance(images, torch.Tensor) else np.asarray(images, dtype=np.float32)
+    tg = targets.detach().cpu().numpy() if isinstance(targets, torch.Tensor) else np.asarray(targets)
+    if imgs.max() <= 1.0 + 1e-6:
+        imgs = imgs * 255
+    bs, c, h, w = imgs.shape
+    bs = min(bs, max_subplots)
+    ns = int(np.ceil(bs ** 0.5))
+    scale = min(max_size / max(h, w), 1.0)
+    hh, ww = int(math.ceil(h * scale)), int(math.ceil(w * scale))
+    canvas = np.full((ns * hh, ns * ww, 3), 255, dtype=np.uint8)
+    for i in range(bs):
+        im = imgs[i].transpose(1, 2, 0).clip(0, 255).astype(np.uint8)
+        if im.shape[2] == 1:
+            im = np.repeat(im, 3, 2)
+        if scale < 1:
+            im = np.asarray(Image.fromarray(im).resize((ww, hh)))
+        im = np.ascontiguousarray(im)
+        rows = tg[tg[:, 0] == i] if len(tg) else []
+        for r in rows:
+            cls = int(r[1])
+            cx, cy, bw, bh = r[2] * ww, r[3] * hh, r[4] * ww, r[5] * hh
+            conf = r[6] if len(r) > 6 else None
+            if conf is None or conf > 0.3:
+                label = (names[cls] if names else str(cls)) + ('' if conf is None else ' %.1f' % conf)
+                plot_one_box([cx - bw / 2, cy - bh / 2, cx + bw / 2, cy + bh / 2], im, color=[(37 * cls) % 255, (91 * cls) % 255, 200],
+                             label=label, line_thickness=1)
+        y0, x0 = (i // ns) * hh, (i % ns) * ww
+        canvas[y0:y0 + hh, x0:x0 + ww] = im
+    if fname:
+        Image.fromarray(canvas).save(fname)
+    return canvas
+
+
+def strip_optimizer(f='weights/best.pt'):
+    """Drop optimizer state from a checkpoint so it can be shared (reference utils.py:862-868)."""
+    x = torch.load(f, map_location='cpu', weights_only=False)
+    x['optimizer'] = None
+    torch.save(x, f)
+
+
+def print_mutation(hyp, results, bucket=''):
+    """Append one hyper-parameter evolution record to evolve.txt (reference utils.py:921-939; no cloud bucket here)."""
+    a = '%10s' * len(hyp) % tuple(hyp.keys())
+    b = '%10.3g' * len(hyp) % tuple(hyp.values())
+    c = '%10.4g' * len(results) % tuple(results)
+    print('\n%s\n%s\nEvolved fitness: %s\n' % (a, b, c))
+    with open('evolve.txt', 'a') as f:
+        f.write(c + b + '\n')
+
+
+def plot_results(start=0, stop=0, bucket='', id=()):
+    """results*.txt curves -> results.png when matplotlib is importable (reference utils.py:1187-1218); otherwise a no-op."""
+    try:
+        import matplotlib
+        matplotlib.use('Agg')
+        import matplotlib.pyplot as plt
+    except Exception:
+        return
+    files = sorted(glob.glob('results*.txt'))
+    if not files:
+        return
+    titles = ['GIoU', 'Objectness', 'Classification', 'Precision', 'Recall', 'val GIoU', 'val Objectness', 'val Classification', 'mAP@0.5', 'F1']
+    fig, ax = plt.subplots(2, 5, figsize=(14, 7))
+    ax = ax.ravel()
+    for f in files:
+        try:
+            res = np.loadtxt(f, usecols=[2, 3, 4, 8, 9, 12, 13, 14, 10, 11], ndmin=2).T
+        except Exception:
+            continue
+        x = range(start, min(stop, res.shape[1]) if stop else res.shape[1])
+        for i in range(10):
+            ax[i].plot(x, res[i, x], marker='.', label=Path(f).stem)
+            ax[i].set_title(titles[i])
+    ax[1].legend()
+    fig.tight_layout()
+    fig.savefig('results.png', dpi=150)
+    plt.close(fig)
