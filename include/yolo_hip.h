@@ -409,6 +409,9 @@ typedef struct yh_wgrad_desc {
     int64_t ws_floats;      /* size from yh_conv2d_wgrad_workspace().  NULL / too small -> fp32 atomics.                  */
 } yh_wgrad_desc;
 int64_t yh_conv2d_wgrad_workspace(const yh_wgrad_desc* d);
+/* Tuning knobs read from the environment by yh_conv2d_wgrad (A/B measurements only): YH_WGRAD_TARGET = workgroups the
+ * pixel split aims for (default 1024; negative = round the split count down), YH_WGRAD_BN = 256 selects the 8-wave
+ * 128 x 256 tile.  splits = -1 in the descriptor selects the register-staged fp16 kernel.                          */
 int yh_conv2d_wgrad(const yh_wgrad_desc* d, void* stream);
 int yh_stem_wgrad(const yh_wgrad_desc* d, void* stream);
 typedef struct yh_resample_desc {

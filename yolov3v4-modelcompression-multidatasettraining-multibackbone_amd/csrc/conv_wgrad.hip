@@ -39,7 +39,8 @@ constexpr int WG_PITCH_DW = 20;  // LDS row pitch in dwords (80 B)
 struct WgradArgs {
     yh_wgrad_desc d;
     int tiles_m, tiles_n, ksteps, ksteps_per_split, ncols;  // ncols = kh*kw*cin: the flattened (tap, ci) axis
-    int two_stage, interleaved, dma, bn, cin_w, rw, rh, qh;  // interleaved: the DMA kernel's tile <-> channel mapping  // bk = qw * wo + rw, qw = qh * ho + rh: per-step pixel advance without divisions
+    int two_stage, dma, bn, cin_w;   // dma: the fp16 LDS-DMA kernel; bn: its column-tile width
+    int rw, rh, qh;                  // bk = qw * wo + rw, qw = qh * ho + rh: per-step pixel advance without divisions
     long pixels;
 };
 
@@ -521,14 +522,14 @@ __global__ __launch_bounds__(128 * WNW) void wgrad_reduce_kernel(const WgradArgs
     for (; sp < s1; ++sp) v0 += part[sp * stride];
     const f32x4 v = (v0 + v1) + (v2 + v3);
     const int tm = tile % a.tiles_m, tn = tile / a.tiles_m;
-    const int n = tn * BN + wn * 64 + (a.interleaved ? 4 * (lane & 15) + j : j * 16 + (lane & 15));
+    const int n = tn * BN + wn * 64 + j * 16 + (lane & 15);
     if (n >= a.ncols) return;
     const int taps = d.kh * d.kw;
     const int tap = n / d.cin, ci = n - tap * d.cin;
     if (ci >= a.cin_w) return;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        const int co = tm * (TM * 32) + wm * TM * 16 + (a.interleaved ? TM * (4 * (lane >> 4) + r) + i : i * 16 + 4 * (lane >> 4) + r);
+        const int co = tm * (TM * 32) + wm * TM * 16 + i * 16 + 4 * (lane >> 4) + r;
         if (co >= d.cout) continue;
         float* dst = d.dw + ((long)co * a.cin_w + ci) * taps + tap;
         if (gridDim.y == 1) *dst += v[r];     // a single split group owns the element: plain accumulate
@@ -764,7 +765,6 @@ static void wgrad_geometry(const yh_wgrad_desc* d, WgradArgs* pa, int* psplits) 
     const int bm = d->cout <= 64 ? 64 : WG_TILE;        // 64-row tiles for the early, wide-resolution layers
     a.ncols = d->kh * d->kw * d->cin;
     a.dma = d->dtype == YH_F16 && d->splits != -1;           // the LDS-DMA kernel
-    a.interleaved = 0;
     // 256-column tiles (8 waves) when they stay >= 85 % full; the register-staged kernels are 128 wide
     a.bn = WG_TILE;   // 256-column (8-wave) tiles measured slower (VGPR-limited to one workgroup per CU); YH_WGRAD_BN=256 selects them
     { const char* e = getenv("YH_WGRAD_BN"); if (e && a.dma && bm == 128) a.bn = atoi(e); }

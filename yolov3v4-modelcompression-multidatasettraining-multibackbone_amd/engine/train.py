@@ -73,7 +73,6 @@ class TrainEngine(DarknetEngine):
             raise ValueError("training precision must be 'fp16' or 'fp32'")
         super().__init__(model, precision, lib)
         self._tplans = {}
-        self._wsig = None
         self._current = None
         self.steps = 0   # forward count; the autograd node checks it so a stale backward fails loudly
 
@@ -133,9 +132,6 @@ class TrainEngine(DarknetEngine):
             raise RuntimeError('pack table size changed: rebuild the plan')
         plan['pack_table'].copy_(host)
         plan['pack_ptrs'] = ptrs
-
-    def _weight_signature(self):
-        return tuple((t.data_ptr(), t._version) for t in self.parameters())
 
     # --------------------------------------------------------------------------------- plans
     def _check_supported(self, values):
@@ -564,7 +560,6 @@ class TrainEngine(DarknetEngine):
                 if self._current is old:
                     self._current = None
             plan = self._tplans[key] = self._build_train_plan(*key)
-            self._wsig = None
         else:
             self._tplans[key] = self._tplans.pop(key)   # most recently used last
         return plan
