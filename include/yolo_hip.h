@@ -382,6 +382,31 @@ typedef struct yh_loss_desc {
 int yh_yolo_loss_fwd(const yh_loss_desc* d, void* stream);
 int yh_yolo_loss_bwd(const yh_loss_desc* d, void* stream);
 
+/* Backward of the depthwise block and of squeeze-excite (training of the Mobilenet / Ghost backbones).
+ *  yh_dw_wgrad   dw[c][r][s] += sum_pixels dz[p][c] * x[p shifted by (r, s)][c]   (fp32 [c][k][k], caller zeroes)
+ *  yh_dw_dgrad   dx[hi, wi, c] (+)= sum_taps dz[(hi + pad - r) / stride, (wi + pad - s) / stride, c] * w[r][s][c] over the
+ *                taps whose source position is integral and inside dz; w is the FORWARD packed image [k*k][c]
+ *  yh_se_bwd     y = x * g, g = hsigmoid(W2 relu(W1 mean(x))):  dx (+)= dy * g + W1^T(relu' (W2^T(hsig' (sum_p dy x)))) / HW,
+ *                dw1 / dw2 += the two outer products (fp32, nn.Linear layout); pooled / gate are the forward's buffers,
+ *                scratch is fp32 [n][c].                                                                              */
+typedef struct yh_dw_bwd_desc {
+    const void* x;          /* wgrad: forward input of the block                                                     */
+    const void* dz;         /* gradient of the (pre-BN) depthwise output                                             */
+    const void* w;          /* dgrad: forward packed weights [k*k][c] dtype                                          */
+    void* dx;               /* dgrad output                                                                          */
+    float* dw;              /* wgrad output                                                                          */
+    int32_t n, h, w_in, c, ho, wo, k, stride, pad, ldx, lddz, lddx, accumulate, dtype;
+} yh_dw_bwd_desc;
+int yh_dw_wgrad(const yh_dw_bwd_desc* d, void* stream);
+int yh_dw_dgrad(const yh_dw_bwd_desc* d, void* stream);
+typedef struct yh_se_bwd_desc {
+    const void* x; const void* dy; void* dx;
+    const float* w1; const float* w2; const float* pooled; const float* gate;
+    float* dw1; float* dw2; float* scratch;
+    int32_t n, h, w_in, c, cr, ldx, lddy, lddx, accumulate, dtype;
+} yh_se_bwd_desc;
+int yh_se_bwd(const yh_se_bwd_desc* d, void* stream);
+
 /* All weight images of a training step in ONE launch (the parameters change every optimizer step; 75 layers x
  * (forward image + data-gradient image[s]) would otherwise be ~170 tiny launches).  `items` is a DEVICE array.       */
 typedef struct yh_pack_item {
@@ -393,6 +418,7 @@ typedef struct yh_pack_item {
                             /* 1 data gradient [m_pad = cin rows][flipped taps][k_pad] (yh_conv_pack_weights_dgrad) */
                             /* 2 one parity phase of a stride-2 data gradient (.._dgrad_phase, pa/pb)            */
                             /* 3 first layer [kh*kw*cin][cout_pad] fp32 (yh_stem_pack_weights without BN)        */
+                            /* 4 depthwise [kh*kw][k_pad = c_phys] (yh_dw_pack_weights without BN), cout = channels */
     int32_t dtype, cout, cin, kh, kw, k_pad, m_pad, pad, pa, pb, cout_pad;
 } yh_pack_item;
 int yh_pack_batch(const yh_pack_item* items, int n_items, void* stream);
@@ -450,7 +476,8 @@ typedef struct yh_plan yh_plan;
 enum { YH_OP_CONV = 1, YH_OP_STEM = 2, YH_OP_POOL = 3, YH_OP_COPY = 4, YH_OP_ADD = 5, YH_OP_DECODE = 6, YH_OP_DW = 7,
        YH_OP_SE = 8, YH_OP_QCOPY = 9, YH_OP_QPOOL = 10, YH_OP_QADD = 11, YH_OP_BN_STATS = 12, YH_OP_BN_FINALIZE = 13,
        YH_OP_BN_ACT_FWD = 14, YH_OP_BN_BWD_REDUCE = 15, YH_OP_BN_BWD_APPLY = 16, YH_OP_WGRAD = 17, YH_OP_STEM_WGRAD = 18,
-       YH_OP_DILATE2 = 19, YH_OP_UPSAMPLE2_BWD = 20, YH_OP_CAST_F32 = 21, YH_OP_NCHW_TO_NHWC = 22, YH_OP_POOL_BWD = 23, YH_OP_PACK_BATCH = 24 };
+       YH_OP_DILATE2 = 19, YH_OP_UPSAMPLE2_BWD = 20, YH_OP_CAST_F32 = 21, YH_OP_NCHW_TO_NHWC = 22, YH_OP_POOL_BWD = 23, YH_OP_PACK_BATCH = 24, YH_OP_DW_WGRAD = 25, YH_OP_DW_DGRAD = 26,
+       YH_OP_SE_BWD = 27 };
 typedef struct yh_pack_batch_desc { const yh_pack_item* items; int32_t n_items; } yh_pack_batch_desc;
 typedef struct yh_layout_desc { const float* x; void* y; int32_t n, c, h, w_in, c_pad, ldy, dtype; } yh_layout_desc;
 

@@ -17,7 +17,7 @@ import torch.nn.functional as F
 from engine import hiplib
 from engine.hiplib import (ConvDesc, StemDesc, PoolDesc, CopyDesc, AddDesc, DecodeDesc, DwDesc, SeDesc, QCopyDesc, QPoolDesc,
                            QAddDesc, BnStatsDesc, BnFinalizeDesc, BnActFwdDesc, BnBwdReduceDesc, BnBwdApplyDesc, WgradDesc,
-                           StemWgradDesc, DilateDesc, UpsampleBwdDesc, CastDesc, LayoutDesc, PoolBwdDesc, PackBatchDesc, PackItem)
+                           StemWgradDesc, DilateDesc, UpsampleBwdDesc, CastDesc, LayoutDesc, PoolBwdDesc, PackBatchDesc, PackItem, DwWgradDesc, DwDgradDesc, SeBwdDesc)
 
 _NP = {hiplib.YH_F16: np.float16, hiplib.YH_F32: np.float32, hiplib.YH_I8: np.int8}
 _DESC = {hiplib.OP_CONV: ConvDesc, hiplib.OP_STEM: StemDesc, hiplib.OP_POOL: PoolDesc, hiplib.OP_COPY: CopyDesc,
@@ -26,7 +26,8 @@ _DESC = {hiplib.OP_CONV: ConvDesc, hiplib.OP_STEM: StemDesc, hiplib.OP_POOL: Poo
          hiplib.OP_BN_STATS: BnStatsDesc, hiplib.OP_BN_FINALIZE: BnFinalizeDesc, hiplib.OP_BN_ACT_FWD: BnActFwdDesc,
          hiplib.OP_BN_BWD_REDUCE: BnBwdReduceDesc, hiplib.OP_BN_BWD_APPLY: BnBwdApplyDesc, hiplib.OP_WGRAD: WgradDesc,
          hiplib.OP_STEM_WGRAD: StemWgradDesc, hiplib.OP_DILATE2: DilateDesc, hiplib.OP_UPSAMPLE2_BWD: UpsampleBwdDesc,
-         hiplib.OP_CAST_F32: CastDesc, hiplib.OP_NCHW_TO_NHWC: LayoutDesc, hiplib.OP_POOL_BWD: PoolBwdDesc, hiplib.OP_PACK_BATCH: PackBatchDesc}
+         hiplib.OP_CAST_F32: CastDesc, hiplib.OP_NCHW_TO_NHWC: LayoutDesc, hiplib.OP_POOL_BWD: PoolBwdDesc, hiplib.OP_PACK_BATCH: PackBatchDesc, hiplib.OP_DW_WGRAD: DwWgradDesc, hiplib.OP_DW_DGRAD: DwDgradDesc,
+         hiplib.OP_SE_BWD: SeBwdDesc}
 
 
 def _addr(p):
@@ -460,6 +461,52 @@ class FakeLib:
                 (ptr._obj if hasattr(ptr, '_obj') else ptr.contents).value = val
         return 0
 
+    # ---- depthwise / squeeze-excite backward
+    def yh_dw_wgrad(self, dref, stream):
+        d = dref._obj if hasattr(dref, '_obj') else dref
+        npdt = _NP[d.dtype]
+        x = torch.from_numpy(pitched(d.x, d.n * d.h * d.w_in, d.c, d.ldx, npdt).astype(np.float32)).view(d.n, d.h, d.w_in, d.c)
+        dz = torch.from_numpy(pitched(d.dz, d.n * d.ho * d.wo, d.c, d.lddz, npdt).astype(np.float32)).view(d.n, d.ho, d.wo, d.c)
+        gw = torch.nn.grad.conv2d_weight(x.permute(0, 3, 1, 2), (d.c, 1, d.k, d.k), dz.permute(0, 3, 1, 2), stride=d.stride,
+                                         padding=d.pad, groups=d.c)
+        flat(d.dw, gw.numel(), np.float32)[:] += gw.reshape(-1).numpy()
+        return 0
+
+    def yh_dw_dgrad(self, dref, stream):
+        d = dref._obj if hasattr(dref, '_obj') else dref
+        npdt = _NP[d.dtype]
+        dz = torch.from_numpy(pitched(d.dz, d.n * d.ho * d.wo, d.c, d.lddz, npdt).astype(np.float32)).view(d.n, d.ho, d.wo, d.c)
+        w = torch.from_numpy(flat(d.w, d.k * d.k * d.c, npdt).astype(np.float32)).view(d.k, d.k, d.c).permute(2, 0, 1).unsqueeze(1)
+        gx = torch.nn.grad.conv2d_input((d.n, d.c, d.h, d.w_in), w.contiguous(), dz.permute(0, 3, 1, 2), stride=d.stride,
+                                        padding=d.pad, groups=d.c)
+        out = pitched(d.dx, d.n * d.h * d.w_in, d.c, d.lddx, npdt)
+        v = gx.permute(0, 2, 3, 1).reshape(-1, d.c).numpy()
+        out[:] = (out.astype(np.float32) + v if d.accumulate else v).astype(npdt)
+        return 0
+
+    def yh_se_bwd(self, dref, stream):
+        d = dref._obj if hasattr(dref, '_obj') else dref
+        npdt = _NP[d.dtype]
+        hw = d.h * d.w_in
+        x = torch.from_numpy(pitched(d.x, d.n * hw, d.c, d.ldx, npdt).astype(np.float32)).view(d.n, hw, d.c)
+        dy = torch.from_numpy(pitched(d.dy, d.n * hw, d.c, d.lddy, npdt).astype(np.float32)).view(d.n, hw, d.c)
+        w1 = torch.from_numpy(flat(d.w1, d.cr * d.c, np.float32).copy()).view(d.cr, d.c)
+        w2 = torch.from_numpy(flat(d.w2, d.c * d.cr, np.float32).copy()).view(d.c, d.cr)
+        pooled = torch.from_numpy(flat(d.pooled, d.n * d.c, np.float32).copy()).view(d.n, d.c)
+        gate = torch.from_numpy(flat(d.gate, d.n * d.c, np.float32).copy()).view(d.n, d.c)
+        with torch.enable_grad():
+            pv, w1v, w2v = pooled.clone().requires_grad_(), w1.clone().requires_grad_(), w2.clone().requires_grad_()
+            g = F.relu6(F.linear(F.relu(F.linear(pv, w1v)), w2v) + 3.0) / 6.0
+            dg = (dy * x).sum(1)
+            g.backward(dg)
+        dxv = dy * gate.unsqueeze(1) + pv.grad.unsqueeze(1) / hw
+        out = pitched(d.dx, d.n * hw, d.c, d.lddx, npdt)
+        v = dxv.reshape(-1, d.c).numpy()
+        out[:] = (out.astype(np.float32) + v if d.accumulate else v).astype(npdt)
+        flat(d.dw1, d.cr * d.c, np.float32)[:] += w1v.grad.reshape(-1).numpy()
+        flat(d.dw2, d.c * d.cr, np.float32)[:] += w2v.grad.reshape(-1).numpy()
+        return 0
+
     # ---- fused loss
     @staticmethod
     def _loss_view(ptr, d, sb, sa, sy, sx):
@@ -533,6 +580,9 @@ class FakeLib:
             elif it.mode == 1:
                 rc = self.yh_conv_pack_weights_dgrad(it.dtype, it.w, it.cout, it.cin, it.kh, it.kw, it.k_pad, it.m_pad, it.packed,
                                                      stream)
+            elif it.mode == 4:
+                rc = self.yh_dw_pack_weights(it.dtype, it.w, it.bias, None, None, None, None, 0.0, None, it.cout, it.kh, it.k_pad,
+                                             it.packed, it.bias_out, stream)
             elif it.mode == 2:
                 rc = self.yh_conv_pack_weights_dgrad_phase(it.dtype, it.w, it.cout, it.cin, it.kh, it.kw, it.pad, it.pa, it.pb,
                                                            it.k_pad, it.m_pad, it.packed, None, None, stream)
@@ -682,7 +732,8 @@ class FakeLib:
                hiplib.OP_STEM_WGRAD: self.yh_stem_wgrad, hiplib.OP_DILATE2: self.yh_dilate2,
                hiplib.OP_UPSAMPLE2_BWD: self.yh_upsample2_bwd, hiplib.OP_CAST_F32: self.yh_cast_f32,
                hiplib.OP_NCHW_TO_NHWC: self._layout, hiplib.OP_POOL_BWD: self.yh_maxpool2d_bwd,
-               hiplib.OP_PACK_BATCH: lambda d, st: self.yh_pack_batch(d.items, d.n_items, st)}
+               hiplib.OP_PACK_BATCH: lambda d, st: self.yh_pack_batch(d.items, d.n_items, st),
+               hiplib.OP_DW_WGRAD: self.yh_dw_wgrad, hiplib.OP_DW_DGRAD: self.yh_dw_dgrad, hiplib.OP_SE_BWD: self.yh_se_bwd}
         for kind, desc, fixups in plan['ops'][first:last]:
             d = type(desc).from_buffer_copy(bytes(desc))
             for off, slot, boff in fixups:

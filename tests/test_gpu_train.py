@@ -402,6 +402,79 @@ def test_fused_loss_kernels_match_torch_loss(libs, rel, size, nc):
         assert (a - b).abs().max().item() <= 1e-4 * b.abs().max().item()
 
 
+@pytest.mark.parametrize('code', [F32, F16], ids=['fp32', 'fp16'])
+@pytest.mark.parametrize('case', [(2, 20, 20, 32, 3, 1), (2, 21, 19, 24, 5, 2), (1, 26, 26, 96, 3, 2), (3, 13, 13, 240, 5, 1)],
+                         ids=lambda c: 'n%d_%dx%d_c%d_k%ds%d' % c)
+def test_depthwise_backward_matches_autograd(libs, code, case):
+    import ctypes as C
+    from engine.hiplib import DwBwdDesc
+    lib, _ = libs
+    N, H, W, c, k, s = case
+    g = torch.Generator().manual_seed(hash(case) % (2 ** 31))
+    dt = oh.tdtype(code)
+    pad = (k - 1) // 2
+    Ho, Wo = (H + 2 * pad - k) // s + 1, (W + 2 * pad - k) // s + 1
+    x = torch.randn(N, H, W, c, generator=g).to(dt)
+    dz = torch.randn(N, Ho, Wo, c, generator=g).to(dt)
+    w = torch.randn(c, 1, k, k, generator=g) * 0.3
+    acc0 = torch.randn(N, H, W, c, generator=g).to(dt)
+    xd, dzd = x.to(GPU), dz.to(GPU)
+    packed = torch.empty(k * k * c, device=GPU, dtype=dt)
+    bias = torch.empty(c, device=GPU, dtype=torch.float32)
+    assert lib.yh_dw_pack_weights(code, P(w.to(GPU)), None, None, None, None, None, 0.0, None, c, k, c, P(packed), P(bias), oh.stream()) == 0
+    dw = torch.zeros(c, 1, k, k, device=GPU)
+    geo = dict(n=N, h=H, w_in=W, c=c, ho=Ho, wo=Wo, k=k, stride=s, pad=pad, ldx=c, lddz=c, dtype=code)
+    oh.call(lib, 'yh_dw_wgrad', DwBwdDesc(x=P(xd), dz=P(dzd), dw=P(dw), lddx=0, accumulate=0, **geo))
+    dx = torch.full((N, H, W, c), 3.0, device=GPU, dtype=dt)
+    oh.call(lib, 'yh_dw_dgrad', DwBwdDesc(dz=P(dzd), w=P(packed), dx=P(dx), lddx=c, accumulate=0, **geo))
+    dxa = acc0.to(GPU).clone()
+    oh.call(lib, 'yh_dw_dgrad', DwBwdDesc(dz=P(dzd), w=P(packed), dx=P(dxa), lddx=c, accumulate=1, **geo))
+    _sync()
+    xr, dzr = x.float().permute(0, 3, 1, 2), dz.float().permute(0, 3, 1, 2)
+    wq = w.to(dt).float()
+    ref_w = torch.nn.grad.conv2d_weight(xr, (c, 1, k, k), dzr, stride=s, padding=pad, groups=c)
+    ref_x = torch.nn.grad.conv2d_input((N, c, H, W), wq, dzr, stride=s, padding=pad, groups=c).permute(0, 2, 3, 1)
+    assert (dw.cpu() - ref_w).abs().max().item() <= (2e-5 if code == F32 else 1e-4) * ref_w.abs().max().item()
+    tol = 2e-5 if code == F32 else 2.5e-3
+    assert (dx.float().cpu() - ref_x).abs().max().item() <= tol * ref_x.abs().max().item()
+    ref_a = ref_x + acc0.float()
+    assert (dxa.float().cpu() - ref_a).abs().max().item() <= tol * ref_a.abs().max().item()
+
+
+@pytest.mark.parametrize('code', [F32, F16], ids=['fp32', 'fp16'])
+@pytest.mark.parametrize('case', [(3, 13, 13, 72), (2, 7, 9, 960), (4, 26, 26, 40)], ids=lambda c: 'n%d_%dx%d_c%d' % c)
+def test_squeeze_excite_backward_matches_autograd(libs, code, case):
+    from engine.hiplib import SeBwdDesc, SeDesc
+    lib, _ = libs
+    N, H, W, c = case
+    cr = c // 4
+    g = torch.Generator().manual_seed(c)
+    dt = oh.tdtype(code)
+    x = torch.randn(N, H, W, c, generator=g).to(dt)
+    dy = torch.randn(N, H, W, c, generator=g).to(dt)
+    w1 = (torch.randn(cr, c, generator=g) * c ** -0.5).contiguous()
+    w2 = (torch.randn(c, cr, generator=g) * cr ** -0.5 * 3).contiguous()
+    xd, dyd, w1d, w2d = x.to(GPU), dy.to(GPU), w1.to(GPU), w2.to(GPU)
+    f32 = lambda *shape: torch.zeros(*shape, device=GPU, dtype=torch.float32)
+    pooled, gate, scratch, dw1, dw2 = f32(N, c), f32(N, c), f32(N, c), f32(cr, c), f32(c, cr)
+    y = torch.empty(N, H, W, c, device=GPU, dtype=dt)
+    oh.call(lib, 'yh_se_fwd', SeDesc(x=P(xd), y=P(y), w1=P(w1d), w2=P(w2d), pooled=P(pooled), gate=P(gate), ch_map=None, n=N, h=H,
+                                     w_in=W, c=c, c_phys=c, cr=cr, ldx=c, ldy=c, dtype=code))
+    dx = torch.full((N, H, W, c), 3.0, device=GPU, dtype=dt)
+    oh.call(lib, 'yh_se_bwd', SeBwdDesc(x=P(xd), dy=P(dyd), dx=P(dx), w1=P(w1d), w2=P(w2d), pooled=P(pooled), gate=P(gate), dw1=P(dw1),
+                                        dw2=P(dw2), scratch=P(scratch), n=N, h=H, w_in=W, c=c, cr=cr, ldx=c, lddy=c, lddx=c,
+                                        accumulate=0, dtype=code))
+    _sync()
+    xr = x.float().requires_grad_()
+    w1r, w2r = w1.clone().requires_grad_(), w2.clone().requires_grad_()
+    gt = F.relu6(F.linear(F.relu(F.linear(xr.mean((1, 2)), w1r)), w2r) + 3.0) / 6.0
+    (xr * gt.view(N, 1, 1, c)).backward(dy.float())
+    tol = 5e-5 if code == F32 else 3e-3
+    assert (dx.float().cpu() - xr.grad).abs().max().item() <= tol * xr.grad.abs().max().item()
+    assert (dw1.cpu() - w1r.grad).abs().max().item() <= tol * (w1r.grad.abs().max().item() + 1e-6)
+    assert (dw2.cpu() - w2r.grad).abs().max().item() <= tol * (w2r.grad.abs().max().item() + 1e-6)
+
+
 # ------------------------------------------------------------------------------------------ whole steps
 @pytest.fixture(scope='module')
 def mini():
@@ -471,8 +544,8 @@ def test_mini_sgd_steps_track_eager(libs, mini):
             assert (pa - pb.cpu()).abs().max().item() <= 1e-4 * (pa.abs().max().item() + 1e-3), k
 
 
-@pytest.mark.parametrize('rel', ['yolov3tiny/yolov3-tiny.cfg', 'yolov4/yolov4.cfg', 'yolov4tiny/yolov4-tiny.cfg'],
-                         ids=['yolov3-tiny', 'yolov4', 'yolov4-tiny'])
+@pytest.mark.parametrize('rel', ['yolov3tiny/yolov3-tiny.cfg', 'yolov4/yolov4.cfg', 'yolov4tiny/yolov4-tiny.cfg',
+                                 'yolov3-mobilenet/yolov3-mobilenet-coco.cfg'], ids=['yolov3-tiny', 'yolov4', 'yolov4-tiny', 'mobilenet'])
 def test_maxpool_graphs_train_step_against_fp64(libs, rel):
     """yolov3-tiny (maxpools) and YOLOv4 (mish, SPP, PAN) on the GPU training path vs an fp64 eager run."""
     cfg = os.path.join(conftest.PKG, 'cfg', rel)

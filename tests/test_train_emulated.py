@@ -83,15 +83,20 @@ def test_gradient_accumulation_and_stale_backward(mini):
 def test_unsupported_cfg_reports_not_implemented():
     from engine.train import TrainEngine
     from models import Darknet
-    cfg = os.path.join(conftest.PKG, 'cfg', 'yolov3-mobilenet', 'yolov3-mobilenet-coco.cfg')
-    model = Darknet(cfg, (64, 64)).train()
-    eng = TrainEngine(model, 'fp32', lib=fakelib.FakeLib())
-    with pytest.raises(NotImplementedError, match='dw|se|multiples'):
-        eng._get_plan(torch.zeros(1, 3, 64, 64))
+    cfg_text = th.mini_cfg_text().replace('filters=8\nsize=3\nstride=1', 'filters=12\nsize=3\nstride=1', 1)   # 12 channels: not a multiple of 8
+    path = th.write_cfg(cfg_text)
+    try:
+        model = Darknet(path, (64, 64)).train()
+        eng = TrainEngine(model, 'fp32', lib=fakelib.FakeLib())
+        with pytest.raises(NotImplementedError, match='multiples'):
+            eng._get_plan(torch.zeros(1, 3, 64, 64))
+    finally:
+        os.unlink(path)
 
 
-@pytest.mark.parametrize('rel,size', [('yolov3tiny/yolov3-tiny.cfg', 64), ('yolov4/yolov4.cfg', 64), ('yolov4tiny/yolov4-tiny.cfg', 64)],
-                         ids=['yolov3-tiny', 'yolov4', 'yolov4-tiny'])
+@pytest.mark.parametrize('rel,size', [('yolov3tiny/yolov3-tiny.cfg', 64), ('yolov4/yolov4.cfg', 64), ('yolov4tiny/yolov4-tiny.cfg', 64),
+                                      ('yolov3-mobilenet/yolov3-mobilenet-coco.cfg', 128)],
+                         ids=['yolov3-tiny', 'yolov4', 'yolov4-tiny', 'mobilenet'])
 def test_maxpool_and_mish_graphs_train_on_the_hip_path(rel, size):
     """yolov3-tiny (2/2 and 2/1 zero-edge maxpools) and YOLOv4 (mish, SPP 5/9/13, PAN routes) against eager autograd.
     Maxpool routes gradient by argmax, which flips under round-off when two window entries are within an ulp, so the
@@ -109,7 +114,9 @@ def test_maxpool_and_mish_graphs_train_on_the_hip_path(rel, size):
     tot = sum(grads64[k].norm().item() ** 2 for k in grads64) ** 0.5
     assert num <= 4 * den + 2e-4 * tot, (num / tot, den / tot)
     kinds = [w.rstrip('0123456789') for w, _ in m.__dict__['_hip_train_engine']._current['bwd_ops']]
-    assert kinds.count('dpool') == {'yolov3tiny/yolov3-tiny.cfg': 6, 'yolov4/yolov4.cfg': 3, 'yolov4tiny/yolov4-tiny.cfg': 3}[rel]
+    assert kinds.count('dpool') == {'yolov3tiny/yolov3-tiny.cfg': 6, 'yolov4/yolov4.cfg': 3, 'yolov4tiny/yolov4-tiny.cfg': 3}.get(rel, 0)
+    if 'mobilenet' in rel:
+        assert kinds.count('dwwgrad') == 15 and kinds.count('dse') == 8
 
 
 def test_yolov3_train_plan_against_fp64(mini):

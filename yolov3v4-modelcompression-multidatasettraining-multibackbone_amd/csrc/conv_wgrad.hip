@@ -665,7 +665,15 @@ __device__ __forceinline__ void pack_item_elems(const yh_pack_item& it) {
 __global__ __launch_bounds__(256) void pack_batch_kernel(const yh_pack_item* items) {
     const yh_pack_item it = items[blockIdx.y];
     const int taps = it.kh * it.kw;
-    if (it.mode == 3) {
+    if (it.mode == 4) {   // depthwise: packed[tap][c] = w[c][tap], zero for padded channels
+        const long total = (long)taps * it.k_pad;
+        for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+            const int c = (int)(i % it.k_pad), tap = (int)(i / it.k_pad);
+            const float v = c < it.cout ? it.w[(long)c * taps + tap] : 0.f;
+            if (it.dtype == YH_F16) reinterpret_cast<f16*>(it.packed)[i] = (f16)v;
+            else reinterpret_cast<float*>(it.packed)[i] = v;
+        }
+    } else if (it.mode == 3) {
         float* out = reinterpret_cast<float*>(it.packed);
         const long total = (long)taps * it.cin * it.cout_pad;
         for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -680,7 +688,7 @@ __global__ __launch_bounds__(256) void pack_batch_kernel(const yh_pack_item* ite
         pack_item_elems<float>(it);
     }
     if (it.bias_out) {
-        const int nb = it.mode == 3 ? it.cout_pad : it.m_pad;
+        const int nb = it.mode == 3 ? it.cout_pad : (it.mode == 4 ? it.k_pad : it.m_pad);
         for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nb; i += gridDim.x * blockDim.x)
             it.bias_out[i] = (it.bias && i < it.cout) ? it.bias[i] : 0.f;
     }

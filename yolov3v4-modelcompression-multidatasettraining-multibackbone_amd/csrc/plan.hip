@@ -28,6 +28,8 @@ union AnyDesc {
     yh_layout_desc layout;
     yh_pool_bwd_desc pool_bwd;
     yh_pack_batch_desc pack_batch;
+    yh_dw_bwd_desc dw_bwd;
+    yh_se_bwd_desc se_bwd;
 };
 
 struct Fixup {
@@ -63,6 +65,8 @@ size_t desc_size(int kind) {
         case YH_OP_NCHW_TO_NHWC: return sizeof(yh_layout_desc);
         case YH_OP_POOL_BWD: return sizeof(yh_pool_bwd_desc);
         case YH_OP_PACK_BATCH: return sizeof(yh_pack_batch_desc);
+        case YH_OP_DW_WGRAD: case YH_OP_DW_DGRAD: return sizeof(yh_dw_bwd_desc);
+        case YH_OP_SE_BWD: return sizeof(yh_se_bwd_desc);
         default: return 0;
     }
 }
@@ -92,6 +96,9 @@ int launch(int kind, const AnyDesc& d, void* stream) {
         case YH_OP_CAST_F32: return yh_cast_f32(&d.cast, stream);
         case YH_OP_POOL_BWD: return yh_maxpool2d_bwd(&d.pool_bwd, stream);
         case YH_OP_PACK_BATCH: return yh_pack_batch(d.pack_batch.items, d.pack_batch.n_items, stream);
+        case YH_OP_DW_WGRAD: return yh_dw_wgrad(&d.dw_bwd, stream);
+        case YH_OP_DW_DGRAD: return yh_dw_dgrad(&d.dw_bwd, stream);
+        case YH_OP_SE_BWD: return yh_se_bwd(&d.se_bwd, stream);
         case YH_OP_NCHW_TO_NHWC:
             return yh_nchw_to_nhwc(d.layout.x, d.layout.y, d.layout.n, d.layout.c, d.layout.h, d.layout.w_in, d.layout.c_pad,
                                    d.layout.ldy, d.layout.dtype, stream);

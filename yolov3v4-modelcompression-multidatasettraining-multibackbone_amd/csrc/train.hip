@@ -334,6 +334,206 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const yh_pool_bwd_desc
     }
 }
 
+// ------------------------------------------------------------------------------------------ depthwise backward
+// one tap per grid.z: thread keeps one channel group, sums dz * x(shifted) over its pixels; rows meet in LDS, workgroups
+// in one atomic per channel
+template <typename T>
+__global__ __launch_bounds__(256) void dw_wgrad_kernel(const yh_dw_bwd_desc d, const BnGeom gm) {
+    typedef typename TV<T>::type V;
+    constexpr int VN = TV<T>::N;
+    const int cgl = threadIdx.x % gm.cgb, prow = threadIdx.x / gm.cgb;
+    const int g = blockIdx.x * gm.cgb + cgl;
+    const bool lane_ok = prow < gm.rows && g < gm.cgs;
+    const int tap = blockIdx.z, tr = tap / d.k - d.pad, ts = tap % d.k - d.pad;
+    const long pixels = (long)d.n * d.ho * d.wo;
+    const long p0 = (long)blockIdx.y * gm.ppb, p1 = min(p0 + gm.ppb, pixels);
+    const T* x = reinterpret_cast<const T*>(d.x) + g * VN;
+    const T* dz = reinterpret_cast<const T*>(d.dz) + g * VN;
+    float acc[1][VN];
+#pragma unroll
+    for (int e = 0; e < VN; ++e) acc[0][e] = 0.f;
+    if (lane_ok)
+        for (long p = p0 + prow; p < p1; p += gm.rows) {
+            const int wo = (int)(p % d.wo);
+            const long r = p / d.wo;
+            const int ho = (int)(r % d.ho);
+            const long n = r / d.ho;
+            const int hi = ho * d.stride + tr, wi = wo * d.stride + ts;
+            if ((unsigned)hi >= (unsigned)d.h || (unsigned)wi >= (unsigned)d.w_in) continue;
+            const V gv = *reinterpret_cast<const V*>(dz + p * d.lddz);
+            const V xv = *reinterpret_cast<const V*>(x + ((n * d.h + hi) * d.w_in + wi) * d.ldx);
+#pragma unroll
+            for (int e = 0; e < VN; ++e) acc[0][e] = fmaf((float)gv[e], (float)xv[e], acc[0][e]);
+        }
+    // dw layout [c][k*k]: the helper adds to dst[0] + c0 + e, so point it at this tap with a channel stride of k*k
+    __shared__ float red1[256 * VN];
+#pragma unroll
+    for (int e = 0; e < VN; ++e) red1[e * 256 + threadIdx.x] = lane_ok ? acc[0][e] : 0.f;
+    __syncthreads();
+    if (lane_ok)
+        for (int it = prow; it < VN; it += gm.rows) {
+            float v = 0.f;
+            for (int r = 0; r < gm.rows; ++r) v += red1[it * 256 + r * gm.cgb + cgl];
+            atomicAdd(d.dw + (long)(g * VN + it) * d.k * d.k + tap, v);
+        }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void dw_dgrad_kernel(const yh_dw_bwd_desc d) {
+    typedef typename TV<T>::type V;
+    constexpr int VN = TV<T>::N;
+    const int cg = d.c / VN;
+    const long total = (long)d.n * d.h * d.w_in * cg;
+    const T* dz = reinterpret_cast<const T*>(d.dz);
+    const T* w = reinterpret_cast<const T*>(d.w);
+    T* dx = reinterpret_cast<T*>(d.dx);
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int g = (int)(i % cg);
+        long r = i / cg;
+        const int wi = (int)(r % d.w_in);
+        r /= d.w_in;
+        const int hi = (int)(r % d.h);
+        const long n = r / d.h;
+        float acc[VN];
+#pragma unroll
+        for (int e = 0; e < VN; ++e) acc[e] = 0.f;
+        for (int kr = 0; kr < d.k; ++kr) {
+            const int th = hi + d.pad - kr;
+            if (th < 0 || th % d.stride) continue;
+            const int ho = th / d.stride;
+            if (ho >= d.ho) continue;
+            for (int ks = 0; ks < d.k; ++ks) {
+                const int tw = wi + d.pad - ks;
+                if (tw < 0 || tw % d.stride) continue;
+                const int wo = tw / d.stride;
+                if (wo >= d.wo) continue;
+                const V gv = *reinterpret_cast<const V*>(dz + ((n * d.ho + ho) * d.wo + wo) * d.lddz + g * VN);
+                const V wv = *reinterpret_cast<const V*>(w + (long)(kr * d.k + ks) * d.c + g * VN);
+#pragma unroll
+                for (int e = 0; e < VN; ++e) acc[e] = fmaf((float)gv[e], (float)wv[e], acc[e]);
+            }
+        }
+        T* dst = dx + ((n * d.h + hi) * d.w_in + wi) * d.lddx + g * VN;
+        V o;
+        if (d.accumulate) {
+            const V old = *reinterpret_cast<const V*>(dst);
+#pragma unroll
+            for (int e = 0; e < VN; ++e) o[e] = (T)((float)old[e] + acc[e]);
+        } else {
+#pragma unroll
+            for (int e = 0; e < VN; ++e) o[e] = (T)acc[e];
+        }
+        *reinterpret_cast<V*>(dst) = o;
+    }
+}
+
+// ------------------------------------------------------------------------------------------ squeeze-excite backward
+// A: scratch[n][c] = sum over the image's pixels of dy * x   (grid: channel groups x images)
+template <typename T>
+__global__ __launch_bounds__(256) void se_bwd_reduce_kernel(const yh_se_bwd_desc d) {
+    typedef typename TV<T>::type V;
+    constexpr int VN = TV<T>::N;
+    __shared__ float red[256 * VN];
+    const int cgs = d.c / VN;
+    const int cgb = cgs < 256 ? cgs : 256, rows = 256 / cgb;
+    const int cgl = threadIdx.x % cgb, prow = threadIdx.x / cgb;
+    const int g = blockIdx.x * cgb + cgl, n = blockIdx.y;
+    const bool ok = prow < rows && g < cgs;
+    const int hw = d.h * d.w_in;
+    float acc[VN];
+#pragma unroll
+    for (int e = 0; e < VN; ++e) acc[e] = 0.f;
+    if (ok) {
+        const T* x = reinterpret_cast<const T*>(d.x) + (long)n * hw * d.ldx + g * VN;
+        const T* dy = reinterpret_cast<const T*>(d.dy) + (long)n * hw * d.lddy + g * VN;
+        for (int p = prow; p < hw; p += rows) {
+            const V xv = *reinterpret_cast<const V*>(x + (long)p * d.ldx);
+            const V gv = *reinterpret_cast<const V*>(dy + (long)p * d.lddy);
+#pragma unroll
+            for (int e = 0; e < VN; ++e) acc[e] = fmaf((float)xv[e], (float)gv[e], acc[e]);
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < VN; ++e) red[e * 256 + threadIdx.x] = ok ? acc[e] : 0.f;
+    __syncthreads();
+    if (ok)
+        for (int it = prow; it < VN; it += rows) {
+            float v = 0.f;
+            for (int r = 0; r < rows; ++r) v += red[it * 256 + r * cgb + cgl];
+            d.scratch[(long)n * d.c + g * VN + it] = v;
+        }
+}
+
+// B: the two Linear layers backward for one image; scratch[n] turns from d(gate) into d(pooled)
+__global__ __launch_bounds__(256) void se_bwd_fc_kernel(const yh_se_bwd_desc d) {
+    extern __shared__ float sh[];            // a1[cr] | dA1[cr] | dA2[c]
+    float* a1 = sh;
+    float* dA1 = sh + d.cr;
+    float* dA2 = sh + 2 * d.cr;
+    const int n = blockIdx.x;
+    const float* pooled = d.pooled + (long)n * d.c;
+    float* sc = d.scratch + (long)n * d.c;
+    for (int j = threadIdx.x; j < d.cr; j += blockDim.x) {
+        float v = 0.f;
+        for (int c = 0; c < d.c; ++c) v = fmaf(d.w1[(long)j * d.c + c], pooled[c], v);
+        a1[j] = v;                           // pre-ReLU
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < d.c; c += blockDim.x) {
+        float a2 = 0.f;
+        for (int j = 0; j < d.cr; ++j) a2 = fmaf(d.w2[(long)c * d.cr + j], fmaxf(a1[j], 0.f), a2);
+        const float dsig = (a2 > -3.f && a2 < 3.f) ? (1.f / 6.f) : 0.f;   // hsigmoid(x) = relu6(x + 3) / 6
+        dA2[c] = sc[c] * dsig;
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < d.cr; j += blockDim.x) {
+        float v = 0.f;
+        for (int c = 0; c < d.c; ++c) v = fmaf(d.w2[(long)c * d.cr + j], dA2[c], v);
+        dA1[j] = a1[j] > 0.f ? v : 0.f;
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < d.c; c += blockDim.x) {
+        float v = 0.f;
+        for (int j = 0; j < d.cr; ++j) v = fmaf(d.w1[(long)j * d.c + c], dA1[j], v);
+        sc[c] = v;                           // d(pooled)
+    }
+    // weight gradients: outer products, summed over the images by atomics
+    for (int i = threadIdx.x; i < d.c * d.cr; i += blockDim.x) {
+        const int c = i / d.cr, j = i - c * d.cr;
+        atomicAdd(d.dw2 + i, dA2[c] * fmaxf(a1[j], 0.f));            // dw2[c][j]
+        const int j1 = i / d.c, c1 = i - j1 * d.c;
+        atomicAdd(d.dw1 + i, dA1[j1] * pooled[c1]);                  // dw1[j][c]
+    }
+}
+
+// C: dx (+)= dy * gate + d(pooled) / HW
+template <typename T>
+__global__ __launch_bounds__(256) void se_bwd_apply_kernel(const yh_se_bwd_desc d) {
+    typedef typename TV<T>::type V;
+    constexpr int VN = TV<T>::N;
+    const int cg = d.c / VN, hw = d.h * d.w_in;
+    const long total = (long)d.n * hw * cg;
+    const float inv = 1.f / (float)hw;
+    const T* dy = reinterpret_cast<const T*>(d.dy);
+    T* dx = reinterpret_cast<T*>(d.dx);
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int g = (int)(i % cg);
+        const long pix = i / cg;
+        const long n = pix / hw;
+        const V gv = *reinterpret_cast<const V*>(dy + pix * d.lddy + g * VN);
+        T* dst = dx + pix * d.lddx + g * VN;
+        V o;
+#pragma unroll
+        for (int e = 0; e < VN; ++e) {
+            const int c = g * VN + e;
+            float v = (float)gv[e] * d.gate[n * d.c + c] + d.scratch[n * d.c + c] * inv;
+            if (d.accumulate) v += (float)dst[e];
+            o[e] = (T)v;
+        }
+        *reinterpret_cast<V*>(dst) = o;
+    }
+}
+
 static int check_bn(const yh_bn_desc* d, bool need_dy, bool need_out) {
     if (!d || !d->z || d->pixels <= 0 || d->c <= 0) return YH_EINVAL;
     if (d->dtype != YH_F16 && d->dtype != YH_F32) return YH_EINVAL;
@@ -349,6 +549,65 @@ static int check_bn(const yh_bn_desc* d, bool need_dy, bool need_out) {
 }  // namespace yh
 
 using namespace yh;
+
+static int check_dw(const yh_dw_bwd_desc* d) {
+    if (!d || !d->dz || d->n <= 0 || d->c <= 0 || d->k <= 0 || d->stride <= 0 || d->pad < 0) return YH_EINVAL;
+    if (d->dtype != YH_F16 && d->dtype != YH_F32) return YH_EINVAL;
+    const int v = d->dtype == YH_F16 ? 8 : 4;
+    if (d->c % v || d->lddz % v || !aligned16(d->dz)) return YH_EALIGN;
+    return YH_OK;
+}
+
+extern "C" int yh_dw_wgrad(const yh_dw_bwd_desc* d, void* stream) {
+    int rc = check_dw(d);
+    if (rc) return rc;
+    if (!d->x || !d->dw) return YH_EINVAL;
+    const int v = d->dtype == YH_F16 ? 8 : 4;
+    if (d->ldx % v || !aligned16(d->x)) return YH_EALIGN;
+    yh_bn_desc geo = {};
+    geo.c = d->c;
+    geo.pixels = (long)d->n * d->ho * d->wo;
+    geo.dtype = d->dtype;
+    dim3 grid;
+    const BnGeom gm = bn_geom(&geo, v, &grid, 512);
+    grid.z = d->k * d->k;
+    if (d->dtype == YH_F16) hipLaunchKernelGGL(dw_wgrad_kernel<f16>, grid, dim3(256), 0, (hipStream_t)stream, *d, gm);
+    else hipLaunchKernelGGL(dw_wgrad_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, *d, gm);
+    return check_launch();
+}
+
+extern "C" int yh_dw_dgrad(const yh_dw_bwd_desc* d, void* stream) {
+    int rc = check_dw(d);
+    if (rc) return rc;
+    if (!d->w || !d->dx) return YH_EINVAL;
+    const int v = d->dtype == YH_F16 ? 8 : 4;
+    if (d->lddx % v || !aligned16(d->dx) || !aligned16(d->w)) return YH_EALIGN;
+    const long total = (long)d->n * d->h * d->w_in * (d->c / v);
+    long gsz = (total + 255) / 256;
+    const dim3 grid((unsigned)(gsz < 1 ? 1 : (gsz > 16384 ? 16384 : gsz)));
+    if (d->dtype == YH_F16) hipLaunchKernelGGL(dw_dgrad_kernel<f16>, grid, dim3(256), 0, (hipStream_t)stream, *d);
+    else hipLaunchKernelGGL(dw_dgrad_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, *d);
+    return check_launch();
+}
+
+extern "C" int yh_se_bwd(const yh_se_bwd_desc* d, void* stream) {
+    if (!d || !d->x || !d->dy || !d->dx || !d->w1 || !d->w2 || !d->pooled || !d->gate || !d->dw1 || !d->dw2 || !d->scratch) return YH_EINVAL;
+    if (d->n <= 0 || d->c <= 0 || d->cr <= 0 || (d->dtype != YH_F16 && d->dtype != YH_F32)) return YH_EINVAL;
+    const int v = d->dtype == YH_F16 ? 8 : 4;
+    if (d->c % v || d->ldx % v || d->lddy % v || d->lddx % v || !aligned16(d->x) || !aligned16(d->dy) || !aligned16(d->dx)) return YH_EALIGN;
+    hipStream_t s = (hipStream_t)stream;
+    const int cgs = d->c / v, cgb = cgs < 256 ? cgs : 256;
+    const dim3 rgrid((cgs + cgb - 1) / cgb, d->n);
+    if (d->dtype == YH_F16) hipLaunchKernelGGL(se_bwd_reduce_kernel<f16>, rgrid, dim3(256), 0, s, *d);
+    else hipLaunchKernelGGL(se_bwd_reduce_kernel<float>, rgrid, dim3(256), 0, s, *d);
+    hipLaunchKernelGGL(se_bwd_fc_kernel, dim3(d->n), dim3(256), (size_t)(2 * d->cr + d->c) * sizeof(float), s, *d);
+    const long total = (long)d->n * d->h * d->w_in * cgs;
+    long gsz = (total + 255) / 256;
+    const dim3 agrid((unsigned)(gsz < 1 ? 1 : (gsz > 16384 ? 16384 : gsz)));
+    if (d->dtype == YH_F16) hipLaunchKernelGGL(se_bwd_apply_kernel<f16>, agrid, dim3(256), 0, s, *d);
+    else hipLaunchKernelGGL(se_bwd_apply_kernel<float>, agrid, dim3(256), 0, s, *d);
+    return check_launch();
+}
 
 extern "C" int yh_maxpool2d_bwd(const yh_pool_bwd_desc* d, void* stream) {
     if (!d || !d->x || !d->dy || !d->dx || d->n <= 0 || d->c <= 0 || d->k <= 0 || d->stride <= 0) return YH_EINVAL;

@@ -163,6 +163,27 @@ class PackBatchDesc(C.Structure):
     _fields_ = [('items', _vp), ('n_items', _i32)]
 
 
+class DwBwdDesc(C.Structure):
+    _fields_ = [('x', _vp), ('dz', _vp), ('w', _vp), ('dx', _vp), ('dw', _vp),
+                ('n', _i32), ('h', _i32), ('w_in', _i32), ('c', _i32), ('ho', _i32), ('wo', _i32), ('k', _i32), ('stride', _i32),
+                ('pad', _i32), ('ldx', _i32), ('lddz', _i32), ('lddx', _i32), ('accumulate', _i32), ('dtype', _i32)]
+
+
+class DwWgradDesc(DwBwdDesc):
+    pass
+
+
+class DwDgradDesc(DwBwdDesc):
+    pass
+
+
+class SeBwdDesc(C.Structure):
+    _fields_ = [('x', _vp), ('dy', _vp), ('dx', _vp), ('w1', _vp), ('w2', _vp), ('pooled', _vp), ('gate', _vp), ('dw1', _vp),
+                ('dw2', _vp), ('scratch', _vp),
+                ('n', _i32), ('h', _i32), ('w_in', _i32), ('c', _i32), ('cr', _i32), ('ldx', _i32), ('lddy', _i32), ('lddx', _i32),
+                ('accumulate', _i32), ('dtype', _i32)]
+
+
 class LossDesc(C.Structure):
     _fields_ = [('p', _vp), ('grad', _vp), ('tobj', _vp), ('idx', _vp), ('tbox', _vp), ('tcls', _vp), ('anchor', _vp), ('sums', _vp),
                 ('scale', _vp),
@@ -178,10 +199,12 @@ class CastDesc(C.Structure):
 
 OP_BN_STATS, OP_BN_FINALIZE, OP_BN_ACT_FWD, OP_BN_BWD_REDUCE, OP_BN_BWD_APPLY = 12, 13, 14, 15, 16
 OP_WGRAD, OP_STEM_WGRAD, OP_DILATE2, OP_UPSAMPLE2_BWD, OP_CAST_F32, OP_NCHW_TO_NHWC, OP_POOL_BWD, OP_PACK_BATCH = 17, 18, 19, 20, 21, 22, 23, 24
+OP_DW_WGRAD, OP_DW_DGRAD, OP_SE_BWD = 25, 26, 27
 
 OP_KIND = {BnStatsDesc: OP_BN_STATS, BnFinalizeDesc: OP_BN_FINALIZE, BnActFwdDesc: OP_BN_ACT_FWD,
            BnBwdReduceDesc: OP_BN_BWD_REDUCE, BnBwdApplyDesc: OP_BN_BWD_APPLY, WgradDesc: OP_WGRAD,
-           StemWgradDesc: OP_STEM_WGRAD, DilateDesc: OP_DILATE2, UpsampleBwdDesc: OP_UPSAMPLE2_BWD, CastDesc: OP_CAST_F32, LayoutDesc: OP_NCHW_TO_NHWC, PoolBwdDesc: OP_POOL_BWD, PackBatchDesc: OP_PACK_BATCH,
+           StemWgradDesc: OP_STEM_WGRAD, DilateDesc: OP_DILATE2, UpsampleBwdDesc: OP_UPSAMPLE2_BWD, CastDesc: OP_CAST_F32, LayoutDesc: OP_NCHW_TO_NHWC, PoolBwdDesc: OP_POOL_BWD, PackBatchDesc: OP_PACK_BATCH, DwWgradDesc: OP_DW_WGRAD, DwDgradDesc: OP_DW_DGRAD,
+           SeBwdDesc: OP_SE_BWD,
            ConvDesc: OP_CONV, StemDesc: OP_STEM, PoolDesc: OP_POOL, CopyDesc: OP_COPY, AddDesc: OP_ADD,
            DecodeDesc: OP_DECODE, DwDesc: OP_DW, SeDesc: OP_SE, QCopyDesc: OP_QCOPY, QPoolDesc: OP_QPOOL, QAddDesc: OP_QADD}
 
@@ -229,6 +252,9 @@ _SIGNATURES = {
     'yh_cast_f32': (C.c_int, [C.POINTER(CastDesc), _vp]),
     'yh_maxpool2d_bwd': (C.c_int, [C.POINTER(PoolBwdDesc), _vp]),
     'yh_pack_batch': (C.c_int, [_vp, C.c_int, _vp]),
+    'yh_dw_wgrad': (C.c_int, [C.POINTER(DwBwdDesc), _vp]),
+    'yh_dw_dgrad': (C.c_int, [C.POINTER(DwBwdDesc), _vp]),
+    'yh_se_bwd': (C.c_int, [C.POINTER(SeBwdDesc), _vp]),
     'yh_yolo_loss_fwd': (C.c_int, [C.POINTER(LossDesc), _vp]),
     'yh_yolo_loss_bwd': (C.c_int, [C.POINTER(LossDesc), _vp]),
     'yh_nchw_to_nhwc': (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),

@@ -35,7 +35,8 @@ import torch.nn as nn
 
 from . import hiplib
 from .hiplib import (ConvDesc, StemDesc, CopyDesc, AddDesc, BnStatsDesc, BnFinalizeDesc, BnActFwdDesc, BnBwdReduceDesc,
-                     BnBwdApplyDesc, WgradDesc, StemWgradDesc, UpsampleBwdDesc, CastDesc, LayoutDesc, PoolDesc, PoolBwdDesc, PackItem, PackBatchDesc)
+                     BnBwdApplyDesc, WgradDesc, StemWgradDesc, UpsampleBwdDesc, CastDesc, LayoutDesc, PoolDesc, PoolBwdDesc, PackItem, PackBatchDesc, DwDesc, SeDesc, DwWgradDesc,
+                     DwDgradDesc, SeBwdDesc)
 from .plan import DarknetEngine, ALIGN_C, _round_up
 
 SLOT_INPUT = 0
@@ -91,6 +92,8 @@ class TrainEngine(DarknetEngine):
                     out.append(conv.bias)
                 if bn is not None:
                     out.extend((bn.weight, bn.bias))
+            elif isinstance(block, nn.Sequential) and len(block) and block[0].__class__.__name__ == 'SE':
+                out.extend((block[0].fc[0].weight, block[0].fc[2].weight))
         return out
 
     # --------------------------------------------------------------------------------- weights
@@ -100,6 +103,14 @@ class TrainEngine(DarknetEngine):
         items = []
         P = hiplib.ptr
         for v in plan['values']:
+            if v.kind == 'dw':
+                conv = v.conv
+                for t in (conv.weight, conv.bias):
+                    if t is not None and (t.dtype != torch.float32 or not t.is_contiguous()):
+                        raise NotImplementedError('HIP training path: parameters must be contiguous fp32 (master weights)')
+                items.append(PackItem(w=P(conv.weight), bias=P(conv.bias), packed=P(v.tpack['w']), bias_out=P(v.tpack['b']), mode=4,
+                                      dtype=self.code, cout=v.C, cin=1, kh=v.k, kw=v.k, k_pad=v.c_phys, pad=v.pad))
+                continue
             if v.kind != 'conv':
                 continue
             conv, pk = v.conv, v.tpack
@@ -136,7 +147,9 @@ class TrainEngine(DarknetEngine):
     # --------------------------------------------------------------------------------- plans
     def _check_supported(self, values):
         for v in values:
-            if v.kind in ('dw', 'se', 'qadd'):
+            if v.kind in ('dw', 'se') and v.c_phys != v.C:
+                raise NotImplementedError('HIP training path: depthwise / SE blocks need channel counts that are multiples of %d' % ALIGN_C)
+            if v.kind in ('qadd',):
                 raise NotImplementedError('HIP training path: %s blocks are not lowered yet (block %s)' % (v.kind, v.block))
             if v.kind == 'conv':
                 if v.src.kind != 'input' and (v.src.C % ALIGN_C or v.src.c_phys != v.src.C):
@@ -217,6 +230,40 @@ class TrainEngine(DarknetEngine):
                 v.storage, v.gstorage, v.c_off, v.ld = v.src.storage, v.src.gstorage, v.src.c_off + v.first, v.src.ld
                 continue
             materialize(v)
+            if v.kind == 'dw':
+                conv, bn = v.conv, v.bn
+                v.p_first = len(plan['param_slices'])
+                v.g_w = grads.reserve(conv.weight.numel())
+                plan['param_slices'].append((v.g_w, conv.weight.numel(), tuple(conv.weight.shape)))
+                v.g_b = None
+                if conv.bias is not None:
+                    v.g_b = grads.reserve(v.c_phys)
+                    plan['param_slices'].append((v.g_b, v.C, (v.C,)))
+                if bn is not None:
+                    v.g_gamma, v.g_beta = grads.reserve(v.C), grads.reserve(v.C)
+                    plan['param_slices'].append((v.g_gamma, v.C, (v.C,)))
+                    plan['param_slices'].append((v.g_beta, v.C, (v.C,)))
+                    v.s_sum, v.s_sumsq = stats.reserve(v.C), stats.reserve(v.C)
+                    v.s_mean, v.s_invstd = saved.reserve(v.C), saved.reserve(v.C)
+                v.tpack = dict(w=torch.empty(v.k * v.k * v.c_phys, device=dev, dtype=self.dtype),
+                               b=torch.empty(v.c_phys, device=dev, dtype=torch.float32))
+                v.plain = bn is None and v.act == LINEAR
+                v.z = None if v.plain else alloc((N, v.H, v.W, v.c_phys))
+                v.res, v.ups, v.Ho, v.Wo, v.fp32 = None, 1, v.H, v.W, False
+                continue
+            if v.kind == 'se':
+                v.p_first = len(plan['param_slices'])
+                v.g_w1 = grads.reserve(v.fc1.weight.numel())
+                plan['param_slices'].append((v.g_w1, v.fc1.weight.numel(), tuple(v.fc1.weight.shape)))
+                v.g_w2 = grads.reserve(v.fc2.weight.numel())
+                plan['param_slices'].append((v.g_w2, v.fc2.weight.numel(), tuple(v.fc2.weight.shape)))
+                for t in (v.fc1.weight, v.fc2.weight):
+                    if t.dtype != torch.float32 or not t.is_contiguous():
+                        raise NotImplementedError('HIP training path: parameters must be contiguous fp32 (master weights)')
+                v.pooled = alloc((N, v.c_phys), fp32=True)
+                v.gate = alloc((N, v.c_phys), fp32=True)
+                v.scratch = alloc((N, v.c_phys), fp32=True)
+                continue
             if v.kind != 'conv':
                 continue
             conv, bn = v.conv, v.bn
@@ -262,14 +309,14 @@ class TrainEngine(DarknetEngine):
                 v.z = None
             else:
                 v.z = alloc((N, v.Ho, v.Wo, v.c_phys))
-        plan['junk_n'] = max(v.c_phys for v in values if v.kind == 'conv')
+        plan['junk_n'] = max(v.c_phys for v in values if v.kind in ('conv', 'dw'))
         plan['junk'] = grads.reserve(plan['junk_n'])
         stats.allocate(dev)
         saved.allocate(dev)
         grads.allocate(dev)
         zero_bias = alloc((max([_round_up(v.src.c_phys, 128) for v in values if v.kind == 'conv' and v.src.kind != 'input']
                                + [128]),), fp32=True, zero=True)
-        dz_elems = max(N * v.Ho * v.Wo * v.c_phys for v in values if v.kind == 'conv')
+        dz_elems = max(N * v.Ho * v.Wo * v.c_phys for v in values if v.kind in ('conv', 'dw'))
         dz_scratch = alloc((dz_elems,))
         head_index = {id(h.src): k for k, h in enumerate(heads)}
 
@@ -344,6 +391,34 @@ class TrainEngine(DarknetEngine):
                 add(fwd, plan['fwd_ops'],
                     BnActFwdDesc(**base, **bnp, out=y, ldo=v.ld, res=None if v.res is None else P(v.res.storage, v.res.c_off),
                                  ldr=0 if v.res is None else v.res.ld), 'bnact%d' % v.block)
+            elif v.kind == 'dw':
+                s, pk, bn = v.src, v.tpack, v.bn
+                zt = None if v.plain else v.z
+                add(fwd, plan['fwd_ops'],
+                    DwDesc(x=P(s.storage, s.c_off), w=P(pk['w']), bias=P(pk['b']), y=y if v.plain else P(zt), n=N, h=s.H, w_in=s.W,
+                           c=s.c_phys, ho=v.H, wo=v.W, k=v.k, stride=v.stride, pad=v.pad, ldx=s.ld, ldy=v.ld if v.plain else v.c_phys,
+                           act=LINEAR, slope=0.0, dtype=self.code), 'dw%d' % v.block)
+                if not v.plain:
+                    pixels = N * v.H * v.W
+                    base = dict(z=P(zt), pixels=pixels, n=N, h=v.H, w_in=v.W, c=v.c_phys, ldz=v.c_phys, act=v.act, slope=v.slope,
+                                dtype=self.code, ups=1)
+                    bnp = dict()
+                    if bn is not None:
+                        if bn.momentum is None or not bn.track_running_stats or not bn.affine:
+                            raise NotImplementedError('HIP training path: BatchNorm without momentum / running stats / affine')
+                        bnp = dict(gamma=P(bn.weight), beta=P(bn.bias), mean=saved.ptr(v.s_mean), invstd=saved.ptr(v.s_invstd),
+                                   sum=stats.ptr(v.s_sum), sumsq=stats.ptr(v.s_sumsq), eps=float(bn.eps), momentum=float(bn.momentum))
+                        add_reduction(fwd, plan['fwd_ops'], BnStatsDesc(**base, **bnp), 'bnstat%d' % v.block)
+                        add(fwd, plan['fwd_ops'], BnFinalizeDesc(**base, **bnp, running_mean=P(bn.running_mean),
+                                                                 running_var=P(bn.running_var)), 'bnfin%d' % v.block)
+                    v.bn_args = (base, bnp)
+                    add(fwd, plan['fwd_ops'], BnActFwdDesc(**base, **bnp, out=y, ldo=v.ld), 'bnact%d' % v.block)
+            elif v.kind == 'se':
+                s = v.src
+                add(fwd, plan['fwd_ops'],
+                    SeDesc(x=P(s.storage, s.c_off), y=y, w1=P(v.fc1.weight), w2=P(v.fc2.weight), pooled=P(v.pooled), gate=P(v.gate),
+                           ch_map=None, n=N, h=s.H, w_in=s.W, c=v.C, c_phys=v.c_phys, cr=v.fc1.weight.shape[0], ldx=s.ld, ldy=v.ld,
+                           dtype=self.code), 'se%d' % v.block)
             elif v.kind == 'pool':
                 s = v.src
                 add(fwd, plan['fwd_ops'], PoolDesc(x=P(s.storage, s.c_off), y=y, n=N, h=s.H, w_in=s.W, c=s.c_phys, ho=v.H, wo=v.W,
@@ -413,6 +488,44 @@ class TrainEngine(DarknetEngine):
                 continue
             if v.kind == 'slice':
                 continue   # contributions to the slice were written straight into the source's gradient buffer
+            if v.kind == 'se':
+                if has_grad(v):
+                    s = v.src
+                    mode = contribution_mode(s, True)
+                    hw = s.H * s.W
+                    add(bwd, plan['bwd_ops'],
+                        SeBwdDesc(x=P(s.storage, s.c_off), dy=gptr(v), dx=gptr(s), w1=P(v.fc1.weight), w2=P(v.fc2.weight),
+                                  pooled=P(v.pooled), gate=P(v.gate), dw1=grads.ptr(v.g_w1), dw2=grads.ptr(v.g_w2), scratch=P(v.scratch),
+                                  n=N, h=s.H, w_in=s.W, c=v.c_phys, cr=v.fc1.weight.shape[0], ldx=s.ld, lddy=v.ld, lddx=s.ld,
+                                  accumulate=1 if mode == 'acc' else 0, dtype=self.code), 'dse%d' % v.block)
+                continue
+            if v.kind == 'dw':
+                if not has_grad(v):
+                    continue
+                s, pk = v.src, v.tpack
+                pixels = N * v.H * v.W
+                dyp, lddy = gptr(v), v.ld
+                if v.plain:
+                    dzp, lddz = dyp, lddy
+                else:
+                    dzp, lddz = P(dz_scratch), v.c_phys
+                    base, bnp = v.bn_args
+                    if v.bn is not None:
+                        acc = dict(bnp, sum=grads.ptr(v.g_beta), sumsq=grads.ptr(v.g_gamma))
+                    else:
+                        acc = dict(sum=grads.ptr(v.g_b if v.g_b is not None else self._junk(plan, grads, v.c_phys)),
+                                   sumsq=grads.ptr(self._junk(plan, grads, v.c_phys)))
+                    add_reduction(bwd, plan['bwd_ops'], BnBwdReduceDesc(**base, **acc, dy=dyp, lddy=lddy), 'dbn%d' % v.block)
+                    add(bwd, plan['bwd_ops'], BnBwdApplyDesc(**base, **acc, dy=dyp, lddy=lddy, out=dzp, ldo=v.c_phys), 'dbnx%d' % v.block)
+                geo = dict(n=N, h=s.H, w_in=s.W, c=v.c_phys, ho=v.H, wo=v.W, k=v.k, stride=v.stride, pad=v.pad, ldx=s.ld, lddz=lddz,
+                           dtype=self.code)
+                add(bwd, plan['bwd_ops'], DwWgradDesc(x=P(s.storage, s.c_off), dz=dzp, dw=grads.ptr(v.g_w), lddx=0, accumulate=0, **geo),
+                    'dwwgrad%d' % v.block)
+                if s.kind != 'input':
+                    mode = contribution_mode(s, True)
+                    add(bwd, plan['bwd_ops'], DwDgradDesc(dz=dzp, w=P(pk['w']), dx=gptr(s), lddx=s.ld,
+                                                          accumulate=1 if mode == 'acc' else 0, **geo), 'dwdgrad%d' % v.block)
+                continue
             if v.kind == 'pool':
                 if has_grad(v):
                     s = v.src
@@ -606,9 +719,9 @@ class TrainEngine(DarknetEngine):
         segs = []
         for k in range(len(cuts) - 1):
             lo, hi = cuts[k], cuts[k + 1]
-            cv = [values[i] for i in range(lo, hi) if values[i].kind == 'conv']
+            cv = [values[i] for i in range(lo, hi) if hasattr(values[i], 'p_first')]
             p_lo = cv[0].p_first if cv else nparams
-            nxt = [values[i] for i in range(hi, len(values)) if values[i].kind == 'conv']
+            nxt = [values[i] for i in range(hi, len(values)) if hasattr(values[i], 'p_first')]
             p_hi = nxt[0].p_first if nxt else nparams
             segs.append(dict(values=(lo, hi), ops=(bwd_pos[id(values[hi - 1])], bwd_pos[id(values[lo - 1])]), params=(p_lo, p_hi),
                              heads=[j for j, h in enumerate(heads) if any(h.src is values[i] for i in range(lo, hi))]))
