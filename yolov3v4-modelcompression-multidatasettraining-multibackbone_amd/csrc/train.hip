@@ -329,53 +329,68 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const yh_pool_bwd_desc
         }
         const V gy = *reinterpret_cast<const V*>(dy + (((long)n * d.ho + ho) * d.wo + wo) * d.lddy + g * VN);
 #pragma unroll
-        for (int e = 0; e < VN; ++e)
-            if (arg[e] >= 0) atomic_add_elem(dx, arg[e] * d.lddx + g * VN + e, (float)gy[e]);
+        for (int e = 0; e < VN; ++e) {
+            if (arg[e] < 0) continue;
+            const long at = arg[e] * d.lddx + g * VN + e;
+            if (d.stride >= d.k) dx[at] = (T)((float)dx[at] + (float)gy[e]);   // windows do not overlap: one writer per element
+            else atomic_add_elem(dx, at, (float)gy[e]);
+        }
     }
 }
 
 // ------------------------------------------------------------------------------------------ depthwise backward
-// one tap per grid.z: thread keeps one channel group, sums dz * x(shifted) over its pixels; rows meet in LDS, workgroups
-// in one atomic per channel
+// Up to 9 taps per pass (grid.z = tap groups): a thread owns one 16-byte channel vector and 9 x VN accumulators, so dz is
+// read once per group (once for 3x3, three times for 5x5) instead of once per tap, with full-width loads.
 template <typename T>
-__global__ __launch_bounds__(256) void dw_wgrad_kernel(const yh_dw_bwd_desc d, const BnGeom gm) {
+__global__ __launch_bounds__(256) void dw_wgrad_taps_kernel(const yh_dw_bwd_desc d, const BnGeom gm) {
     typedef typename TV<T>::type V;
-    constexpr int VN = TV<T>::N;
+    constexpr int VN = TV<T>::N, TG = 9;
     const int cgl = threadIdx.x % gm.cgb, prow = threadIdx.x / gm.cgb;
     const int g = blockIdx.x * gm.cgb + cgl;
-    const bool lane_ok = prow < gm.rows && g < gm.cgs;
-    const int tap = blockIdx.z, tr = tap / d.k - d.pad, ts = tap % d.k - d.pad;
+    const bool ok = prow < gm.rows && g < gm.cgs;
+    const int t0 = blockIdx.z * TG, taps = d.k * d.k;
     const long pixels = (long)d.n * d.ho * d.wo;
     const long p0 = (long)blockIdx.y * gm.ppb, p1 = min(p0 + gm.ppb, pixels);
     const T* x = reinterpret_cast<const T*>(d.x) + g * VN;
     const T* dz = reinterpret_cast<const T*>(d.dz) + g * VN;
-    float acc[1][VN];
+    float acc[TG][VN];
 #pragma unroll
-    for (int e = 0; e < VN; ++e) acc[0][e] = 0.f;
-    if (lane_ok)
+    for (int t = 0; t < TG; ++t)
+#pragma unroll
+        for (int e = 0; e < VN; ++e) acc[t][e] = 0.f;
+    if (ok)
         for (long p = p0 + prow; p < p1; p += gm.rows) {
             const int wo = (int)(p % d.wo);
             const long r = p / d.wo;
             const int ho = (int)(r % d.ho);
             const long n = r / d.ho;
-            const int hi = ho * d.stride + tr, wi = wo * d.stride + ts;
-            if ((unsigned)hi >= (unsigned)d.h || (unsigned)wi >= (unsigned)d.w_in) continue;
             const V gv = *reinterpret_cast<const V*>(dz + p * d.lddz);
-            const V xv = *reinterpret_cast<const V*>(x + ((n * d.h + hi) * d.w_in + wi) * d.ldx);
 #pragma unroll
-            for (int e = 0; e < VN; ++e) acc[0][e] = fmaf((float)gv[e], (float)xv[e], acc[0][e]);
-        }
-    // dw layout [c][k*k]: the helper adds to dst[0] + c0 + e, so point it at this tap with a channel stride of k*k
-    __shared__ float red1[256 * VN];
+            for (int t = 0; t < TG; ++t) {
+                const int tap = t0 + t;
+                const int hi = ho * d.stride + tap / d.k - d.pad, wi = wo * d.stride + tap % d.k - d.pad;
+                if (tap < taps && (unsigned)hi < (unsigned)d.h && (unsigned)wi < (unsigned)d.w_in) {
+                    const V xv = *reinterpret_cast<const V*>(x + ((n * d.h + hi) * d.w_in + wi) * d.ldx);
 #pragma unroll
-    for (int e = 0; e < VN; ++e) red1[e * 256 + threadIdx.x] = lane_ok ? acc[0][e] : 0.f;
-    __syncthreads();
-    if (lane_ok)
-        for (int it = prow; it < VN; it += gm.rows) {
-            float v = 0.f;
-            for (int r = 0; r < gm.rows; ++r) v += red1[it * 256 + r * gm.cgb + cgl];
-            atomicAdd(d.dw + (long)(g * VN + it) * d.k * d.k + tap, v);
+                    for (int e = 0; e < VN; ++e) acc[t][e] = fmaf((float)gv[e], (float)xv[e], acc[t][e]);
+                }
+            }
         }
+    __shared__ float red[256 * VN];
+#pragma unroll
+    for (int t = 0; t < TG; ++t) {
+        const bool live = t0 + t < taps;      // block-uniform
+#pragma unroll
+        for (int e = 0; e < VN; ++e) red[e * 256 + threadIdx.x] = ok ? acc[t][e] : 0.f;
+        __syncthreads();
+        if (ok && live)
+            for (int it = prow; it < VN; it += gm.rows) {
+                float v = 0.f;
+                for (int r = 0; r < gm.rows; ++r) v += red[it * 256 + r * gm.cgb + cgl];
+                atomicAdd(d.dw + (long)(g * VN + it) * taps + t0 + t, v);
+            }
+        __syncthreads();
+    }
 }
 
 template <typename T>
@@ -570,9 +585,9 @@ extern "C" int yh_dw_wgrad(const yh_dw_bwd_desc* d, void* stream) {
     geo.dtype = d->dtype;
     dim3 grid;
     const BnGeom gm = bn_geom(&geo, v, &grid, 512);
-    grid.z = d->k * d->k;
-    if (d->dtype == YH_F16) hipLaunchKernelGGL(dw_wgrad_kernel<f16>, grid, dim3(256), 0, (hipStream_t)stream, *d, gm);
-    else hipLaunchKernelGGL(dw_wgrad_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, *d, gm);
+    grid.z = (d->k * d->k + 8) / 9;                     // tap groups of 9
+    if (d->dtype == YH_F16) hipLaunchKernelGGL(dw_wgrad_taps_kernel<f16>, grid, dim3(256), 0, (hipStream_t)stream, *d, gm);
+    else hipLaunchKernelGGL(dw_wgrad_taps_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, *d, gm);
     return check_launch();
 }
 
