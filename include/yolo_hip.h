@@ -339,7 +339,8 @@ int yh_bn_act_bwd_apply(const yh_bn_desc* d, void* stream);
  *                    (yh_dilate2; odd positions stay zero forever).
  *  weight gradient = yh_conv2d_wgrad: dw[co][ci][r][s] += sum_pixels dz[p][co] * x[p shifted by tap][ci], fp32 OIHW,
  *                    accumulated with atomics over pixel splits (caller zeroes dw).  MFMA with the pixel index as K.
- *  yh_stem_wgrad   the same for the first layer, whose input is the fp32 NCHW image (cin <= 4, 3x3).
+ *  yh_stem_wgrad   the same for the first layer straight from the fp32 NCHW image (cin = 3, 3x3; scalar kernel).  The engine
+ *                  prefers yh_nchw_to_nhwc + yh_conv2d_wgrad(cin_w = 3), which runs the layer on the MFMA kernel (6x faster).
  *  yh_upsample2_bwd  dx[n,h,w,c] = sum of the 2x2 block of dy (backward of the fused nearest-neighbour store).
  *  yh_cast_f32     fp32 pitched rows -> dtype pitched rows (head gradients arrive from autograd as fp32).          */
 int yh_conv_pack_weights_dgrad(int dtype, const float* w, int cout, int cin, int kh, int kw, int cout_k, int m_pad,

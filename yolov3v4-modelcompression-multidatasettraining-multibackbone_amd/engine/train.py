@@ -20,7 +20,7 @@ and the backward plan, walking the values in reverse,
     residual: grad(res) += dy                  yh_add_channels / yh_copy_channels
     dgamma, dbeta (or conv-bias grad)          yh_bn_act_bwd_reduce   (written straight into the gradient arena)
     dz                                         yh_bn_act_bwd_apply
-    dW                                         yh_conv2d_wgrad / yh_stem_wgrad (fp32 atomics into the arena)
+    dW                                         yh_conv2d_wgrad (first layer: through an 8-channel NHWC copy of the image)
     grad(input) (+)= conv(dz, W^T flipped)     yh_conv2d_fwd on the dgrad weight image (stride 2: four parity phases)
 
 Every activation, z and gradient buffer is kept for the whole step (288 GB of HBM: YOLOv3-608 batch 64 needs ~40 GB).
