@@ -316,7 +316,8 @@ def train_roofline(eng, x, precision):
     lib, plan = eng.lib, eng._current
     heads = eng.forward(x)
     torch.cuda.synchronize()
-    groups = {}
+    from engine import hiplib
+    groups, roles = {}, {}
     for key, log in (('fwd', plan['fwd_ops']), ('bwd', plan['bwd_ops'])):
         handle = plan[key]
         lib.yh_plan_set_timing(handle, 1)
@@ -330,14 +331,20 @@ def train_roofline(eng, x, precision):
         lib.yh_plan_get_timings(handle, buf, n)
         lib.yh_plan_set_timing(handle, 0)
         for (what, desc), ms in zip(log, buf):
-            name = what.rstrip('0123456789')
+            role = what.rstrip('0123456789')
+            # group by KERNEL instantiation: the forward convs and the data gradients share the implicit-GEMM kernels
+            if isinstance(desc, hiplib.ConvDesc):
+                name = 'conv_igemm_%s_%s' % (precision, TILE_NAMES.get(lib.yh_conv2d_tile(C.byref(desc)), '?'))
+            elif role == 'wgrad':
+                name = 'conv_wgrad_dma' if precision == 'fp16' else 'conv_wgrad'
+            else:
+                name = role
             grp = groups.setdefault(name, dict(ms=0.0, flops=0.0, n=0))
             grp['ms'] += ms
             grp['n'] += 1
-            if name in ('conv', 'dgrad'):
+            if role in ('conv', 'dgrad', 'wgrad'):
                 grp['flops'] += 2.0 * desc.n * desc.ho * desc.wo * desc.cout * desc.cin * desc.kh * desc.kw
-            elif name == 'wgrad':
-                grp['flops'] += 2.0 * desc.n * desc.ho * desc.wo * desc.cout * desc.cin * desc.kh * desc.kw
+            roles.setdefault(role, [0.0])[0] += ms
     total = sum(g['ms'] for g in groups.values())
     table = {k: dict(ms=round(g['ms'], 3), n=g['n'], tflops=round(g['flops'] / g['ms'] / 1e9, 1) if g['ms'] > 0 else 0)
              for k, g in sorted(groups.items(), key=lambda kv: -kv[1]['ms'])}
@@ -347,8 +354,8 @@ def train_roofline(eng, x, precision):
     traffic = None
     try:   # HBM bytes per launch from the committed rocprofv3 FETCH_SIZE / WRITE_SIZE passes of this command
         hbm = json.load(open(os.path.join(REPO, 'profiles', 'hbm_traffic.json'))).get('train_batch%d' % x.shape[0], {})
-        key = {'wgrad': 'void yh::conv_wgrad_dma_kernel<4, 2>', 'dgrad': 'conv_igemm_glds<f16,f16,256x128,S3>',
-               'conv': 'conv_igemm_glds<f16,f16,256x128,S3>'}.get(top)
+        key = {'conv_wgrad_dma': 'void yh::conv_wgrad_dma_kernel<4, 2>', 'conv_igemm_fp16_dma3_256x128': 'conv_igemm_glds<f16,f16,256x128,S3>',
+               'conv_igemm_fp16_dma3_128x256': 'conv_igemm_glds<f16,f16,128x256,S3>'}.get(top)
         if key in hbm and precision == 'fp16':
             traffic = {'hbm_bytes_per_launch': hbm[key]['hbm_bytes_per_dispatch'], 'kernel': key, 'source': 'profiles/hbm_traffic.json'}
     except Exception:
@@ -356,7 +363,7 @@ def train_roofline(eng, x, precision):
     return {'bound': 'mfma', 'kernel': top, 'achieved': round(ach, 1), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(ach / peak, 4),
             'traffic': traffic, 'launches_per_step': groups[top]['n'], 'avg_launch_ms': round(groups[top]['ms'] / groups[top]['n'], 5),
             'gflop_per_launch': round(groups[top]['flops'] / groups[top]['n'] / 1e9, 3), 'gpu_ms_per_step': round(total, 3),
-            'by_kernel': table}
+            'by_kernel': table, 'by_role_ms': {k: round(v[0], 3) for k, v in sorted(roles.items(), key=lambda kv: -kv[1][0])}}
 
 
 def cpu_train_baseline(cfg, budget_s):
