@@ -147,3 +147,20 @@ def test_batch_and_shape_change_build_new_plans():
             ref = model(x)[0]
         assert (eng(x)[0] - ref).abs().max().item() <= 2e-4
     assert len(eng._plans) == 2
+
+
+def test_plan_cache_is_bounded(cfg_dir):
+    """Rectangular evaluation feeds many input shapes: only the most recently used plans (and their buffers) stay."""
+    import torch
+    import fakelib
+    from engine.plan import DarknetEngine
+    from models import Darknet
+    model = Darknet(os.path.join(cfg_dir, 'yolov3tiny', 'yolov3-tiny-hand.cfg'), (64, 64)).eval()
+    eng = DarknetEngine(model, 'fp32', lib=fakelib.FakeLib())
+    eng.max_plans = 2
+    outs = {}
+    for hw in ((64, 64), (64, 96), (96, 64), (64, 64)):
+        outs.setdefault(hw, []).append(eng(torch.rand(1, 3, *hw, generator=torch.Generator().manual_seed(0)))[0])
+        assert len(eng._plans) <= 2
+    assert list(eng._plans)[-1] == (1, 3, 64, 64)
+    assert torch.equal(outs[(64, 64)][0], outs[(64, 64)][1])   # the rebuilt plan reproduces the evicted one

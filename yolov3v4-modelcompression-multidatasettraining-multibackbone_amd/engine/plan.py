@@ -144,6 +144,7 @@ class DarknetEngine:
         # with the native plan executor the frame-at-a-time forward is GPU-bound (1.63 ms at batch 1, YOLOv3-608),
         # and the graph's staged input / cloned outputs make it ~8 % slower (profiles/r01_latency_*.txt).
         self.graph_max_batch = int(os.environ.get('YOLO_HIP_GRAPH_BATCH', '0'))
+        self.max_plans = max(1, int(os.environ.get('YOLO_HIP_MAX_PLANS', '6')))   # input shapes kept resident
         self._plans = {}
         self._packed = {}  # block index -> dict(w=, b=, ...)
         self._signature = None
@@ -677,7 +678,14 @@ class DarknetEngine:
         key = (N, Cin, H, W)
         plan = self._plans.get(key)
         if plan is None:
+            # every plan owns the activation buffers of its input shape; rectangular evaluation (test.py rect=True) walks
+            # through dozens of shapes, so only the most recently used few are kept
+            while len(self._plans) >= self.max_plans:
+                old = self._plans.pop(next(iter(self._plans)))
+                self.lib.yh_plan_destroy(old['handle'])
             plan = self._plans[key] = self._build_plan(N, Cin, H, W)
+        else:
+            self._plans[key] = self._plans.pop(key)   # most recently used last
 
         lib, handle = self.lib, plan['handle']
         if 0 < N <= self.graph_max_batch and x.is_cuda and hasattr(lib, 'yh_plan_graph_launch'):
