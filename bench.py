@@ -424,6 +424,8 @@ def main():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group('nccl', device_id=device)
 
+    if args.precision == 'int8' and args.mode == 'both':
+        args.mode = 'detect'   # the int8 PTQ graph is an inference path
     out = None
     if args.mode in ('train', 'both'):
         try:
