@@ -369,6 +369,8 @@ typedef struct yh_loss_desc {
     const float* p;             /* raw head, element (b, a, y, x, o) at p + b*sb + a*sa + y*sy + x*sx + o          */
     float* grad;                /* bwd only, same indexing with gb, ga, gy, gx                                       */
     float* tobj;                /* (bs, na, ny, nx) dense fp32                                                       */
+    int32_t* winner;            /* (bs, na, ny, nx) int32, caller fills with -1: when several targets match one cell the */
+                                /* LAST one sets tobj, like the reference's sequential index_put on the CPU              */
     const int32_t* idx;         /* (nb, 4): image, anchor, gy, gx                                                    */
     const float* tbox;          /* (nb, 4): cell-relative xy, grid-unit wh                                           */
     const int32_t* tcls;        /* (nb)                                                                              */

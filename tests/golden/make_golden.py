@@ -161,12 +161,50 @@ def loss_fixture(ref):
     print('loss fixture ok', {k: v for k, v in out.items() if k.endswith('items')})
 
 
+def train_fixture(ref):
+    """One training step of the REFERENCE on CPU (row T): train-mode forward (batch-statistics BatchNorm), compute_loss,
+    backward — yolov3-tiny-hand @128 batch 4 and the first stage of yolov3 is too slow for a fixture, so tiny + yolov4-tiny
+    (maxpools, group routes).  Stored: raw-head checksums, loss items, per-parameter gradient checksums and a row subset,
+    running statistics after the step."""
+    out = {}
+    for tag, rel, size, nc in (('tinyhand', 'yolov3tiny/yolov3-tiny-hand.cfg', 128, 1), ('v4tiny', 'yolov4tiny/yolov4-tiny.cfg', 128, 80)):
+        torch.manual_seed(0)
+        model = ref.models.Darknet(os.path.join(REFCFG, rel), (size, size))
+        state = model.state_dict()
+        synth.randomize_bn_(state, seed=1)
+        model.load_state_dict(state)
+        model.train()
+        model.nc, model.hyp, model.gr = nc, dict(HYP), 1.0
+        x = synth.image_batch(4, size, seed=0)
+        targets = synth.loss_inputs(model, size, batch=4, seed=9, labels_per_image=5)[1]
+        pred, _ = model(x)
+        loss, items = ref.utils.compute_loss(pred, targets, model)
+        loss.backward()
+        out[tag + '_items'] = items.numpy()
+        for i, p in enumerate(pred):
+            out['%s_raw%d_checks' % (tag, i)] = checks(p)
+        names, gsum = [], []
+        for k, p in model.named_parameters():
+            names.append(k)
+            gsum.append(checks(p.grad))
+            out['%s_grow_%s' % (tag, k)] = p.grad.reshape(-1)[::211].numpy()
+        out[tag + '_param_names'] = np.array(names)
+        out[tag + '_grad_checks'] = np.stack(gsum)
+        rs = {k: v for k, v in model.state_dict().items() if 'running' in k}
+        out[tag + '_running_names'] = np.array(list(rs))
+        out[tag + '_running_checks'] = np.stack([checks(v) for v in rs.values()])
+    np.savez_compressed(os.path.join(HERE, 'train_step.npz'), **out)
+    print('train fixture ok', {k: v for k, v in out.items() if k.endswith('items')})
+
+
 def main():
     ref = refharness.load()
     torch.set_num_threads(8)
     only = sys.argv[1:]
     if only == ['loss']:
         return loss_fixture(ref)
+    if only == ['train']:
+        return train_fixture(ref)
     for case in NET_CASES:
         if only and case[0] not in only:
             continue
@@ -175,6 +213,7 @@ def main():
         return
     nms_fixtures(ref)
     loss_fixture(ref)
+    train_fixture(ref)
     fuse_fixture(ref)
     decode_fixture(ref)
 

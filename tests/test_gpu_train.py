@@ -371,8 +371,10 @@ def test_pack_batch_equals_single_layer_packers(libs, code):
 
 @pytest.mark.parametrize('rel,size,nc', [('yolov3/yolov3.cfg', 320, 80), ('yolov3tiny/yolov3-tiny-hand.cfg', 416, 1)], ids=['coco80', 'hand1'])
 def test_fused_loss_kernels_match_torch_loss(libs, rel, size, nc):
-    """csrc/loss.hip vs the torch restatement of compute_loss (itself pinned by the reference goldens on the CPU tier):
-    loss items to 1e-5, gradient of every raw head element to 1e-4 of its scale, through strided NHWC head views."""
+    """csrc/loss.hip vs the torch restatement of compute_loss run on the CPU (itself pinned by the reference goldens on the CPU
+    tier): loss items to 1e-5, gradient of every raw head element to 1e-4 of its scale, through strided NHWC head views.
+    The CPU is the comparison point because cells matched by several targets take the LAST target's objectness there (what
+    the kernels reproduce); torch's index_put on a GPU picks an arbitrary one."""
     if DRY:
         pytest.skip('the loss glue is covered on the emulator by tests/test_loss_golden.py')
     from models import Darknet
@@ -382,18 +384,18 @@ def test_fused_loss_kernels_match_torch_loss(libs, rel, size, nc):
     model.nc, model.gr = nc, 0.6
     model.hyp = {'giou': 3.54, 'cls': 37.4, 'cls_pw': 1.3, 'obj': 64.3, 'obj_pw': 0.8, 'iou_t': 0.20, 'fl_gamma': 0.0}
     raws, targets = synth.loss_inputs(model, size, batch=4, seed=33, labels_per_image=12)
-    targets = targets.to(GPU)
     results = []
     for fused in (True, False):
+        dev = GPU if fused else torch.device('cpu')
         bases, views = [], []
         for r in raws:
             bs, na, ny, nx, no = r.shape
-            base = torch.zeros(bs, ny, nx, oh.round_up(na * no, 8), device=GPU)
-            base[..., :na * no] = r.to(GPU).permute(0, 2, 3, 1, 4).reshape(bs, ny, nx, na * no)
+            base = torch.zeros(bs, ny, nx, oh.round_up(na * no, 8), device=dev)
+            base[..., :na * no] = r.to(dev).permute(0, 2, 3, 1, 4).reshape(bs, ny, nx, na * no)
             base.requires_grad_()
             bases.append(base)
             views.append(base[..., :na * no].view(bs, ny, nx, na, no).permute(0, 3, 1, 2, 4))
-        loss, items = U.compute_loss(views, targets, model, fused=fused)
+        loss, items = U.compute_loss(views, targets.to(dev), model, fused=fused)
         (loss * 7.0).backward()
         results.append((items.cpu(), [b.grad.cpu() for b in bases]))
     (it_f, g_f), (it_t, g_t) = results
@@ -628,3 +630,27 @@ def test_training_step_protocol_loss_and_grad_norm(libs, precision, loss_tol, no
     assert rel <= loss_tol, (items.cpu(), items_ref)
     norm = sum(p.grad.norm().item() ** 2 for p in dev.parameters()) ** 0.5
     assert abs(norm - norm_ref) <= norm_tol * norm_ref, (norm, norm_ref)
+
+
+@pytest.mark.parametrize('tag,rel,size,nc', [('tinyhand', 'yolov3tiny/yolov3-tiny-hand.cfg', 128, 1), ('v4tiny', 'yolov4tiny/yolov4-tiny.cfg', 128, 80)],
+                         ids=['tinyhand', 'v4tiny'])
+def test_training_step_on_gpu_matches_reference_golden(libs, tag, rel, size, nc):
+    """The reference's own training step (tests/golden/train_step.npz, generated from /root/reference on CPU) vs the GPU
+    path: HIP train forward + fused compute_loss + HIP backward, fp32.  Loss items 1e-4; gradients in the l2 sense
+    (isolated maxpool-argmax / leaky-kink flips move single elements)."""
+    if DRY:
+        pytest.skip('covered on the emulator by tests/test_train_emulated.py')
+    import test_train_emulated as tte
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'train_step.npz'))
+    model, pred, items = tte._golden_step(tag, rel, size, nc, path='gpu', device=GPU)
+    assert model.__dict__.get('_hip_train_engine') is not None
+    np.testing.assert_allclose(items.detach().cpu().numpy(), gold[tag + '_items'], rtol=1e-4)
+    params = dict(model.named_parameters())
+    num = den = 0.0
+    for k, want in zip([str(n) for n in gold[tag + '_param_names']], gold[tag + '_grad_checks']):
+        rows = gold['%s_grow_%s' % (tag, k)]
+        got = params[k].grad.reshape(-1)[::211].cpu().numpy()
+        num += float(((got - rows) ** 2).sum())
+        den += float((rows ** 2).sum())
+        assert abs(params[k].grad.abs().sum().item() - want[1]) <= 1e-2 * want[1] + 1e-6, k
+    assert (num / den) ** 0.5 <= 3e-3

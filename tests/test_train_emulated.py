@@ -176,3 +176,74 @@ def test_backward_ranges_hand_gradients_over_early(mini, monkeypatch):
         assert torch.equal(g1[k], g4[k]), k
     assert fired['first'] == nops                      # the first layer's gradient needs the whole backward plan
     assert 0 < fired['last'] < nops // 2               # the last layer's gradient is out after the first range
+
+
+TRAIN_GOLD = [('tinyhand', 'yolov3tiny/yolov3-tiny-hand.cfg', 128, 1), ('v4tiny', 'yolov4tiny/yolov4-tiny.cfg', 128, 80)]
+GOLD_HYP = {'giou': 3.54, 'cls': 37.4, 'cls_pw': 1.0, 'obj': 64.3, 'obj_pw': 1.0, 'iou_t': 0.20, 'fl_gamma': 0.0}
+
+
+def _golden_step(tag, rel, size, nc, path='eager', device='cpu'):
+    """The recipe of tests/golden/make_golden.py train_fixture on this package's Darknet."""
+    import numpy as np
+    from models import Darknet
+    from utils.utils import compute_loss
+    from engine.train import TrainEngine
+    torch.manual_seed(0)
+    model = Darknet(os.path.join(conftest.PKG, 'cfg', rel), (size, size))
+    state = model.state_dict()
+    synth.randomize_bn_(state, seed=1)
+    model.load_state_dict(state)
+    model.train().to(device)
+    model.nc, model.hyp, model.gr = nc, dict(GOLD_HYP), 1.0
+    x = synth.image_batch(4, size, seed=0).to(device)
+    targets = synth.loss_inputs(model, size, batch=4, seed=9, labels_per_image=5)[1].to(device)
+    if path == 'eager':
+        pred, _ = model._forward_eager(x)
+    else:
+        if path == 'emulated':
+            model.__dict__['_hip_train_engine'] = TrainEngine(model, 'fp32', lib=fakelib.FakeLib())
+        os.environ['YOLO_HIP_TRAIN_PRECISION'] = 'fp32'
+        try:
+            pred, _ = model._forward_hip_train(x) if path == 'emulated' else model(x)
+        finally:
+            del os.environ['YOLO_HIP_TRAIN_PRECISION']
+    loss, items = compute_loss(pred, targets, model, fused=False if device == 'cpu' else None)
+    loss.backward()
+    return model, pred, items
+
+
+@pytest.mark.parametrize('path', ['eager', 'emulated'])
+@pytest.mark.parametrize('tag,rel,size,nc', TRAIN_GOLD, ids=[t[0] for t in TRAIN_GOLD])
+def test_training_step_matches_reference_golden(tag, rel, size, nc, path):
+    """Row T pinned by the reference itself: train-mode forward + compute_loss + backward of the REFERENCE on CPU
+    (tests/golden/train_step.npz) vs this package's eager modules (the training oracle of the GPU tier; 1e-5) and vs the
+    HIP lowering replayed on the emulated C ABI (3e-3 of each gradient's scale: a different summation order through
+    maxpool argmax routing and 16-sample BatchNorm statistics at this size)."""
+    import numpy as np
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'train_step.npz'))
+    model, pred, items = _golden_step(tag, rel, size, nc, path)
+    tight = path == 'eager'
+    np.testing.assert_allclose(items.detach().cpu().numpy(), gold[tag + '_items'], rtol=1e-6 if tight else 2e-5)
+
+    def chk(t):
+        t = t.detach().double().cpu()
+        return np.array([t.sum().item(), t.abs().sum().item(), t.abs().max().item()])
+    for i, p in enumerate(pred):
+        np.testing.assert_allclose(chk(p)[1:], gold['%s_raw%d_checks' % (tag, i)][1:], rtol=1e-6 if tight else 2e-5)
+    names = [str(n) for n in gold[tag + '_param_names']]
+    params = dict(model.named_parameters())
+    assert names == list(params)
+    for k, want in zip(names, gold[tag + '_grad_checks']):
+        g = params[k].grad
+        rows = gold['%s_grow_%s' % (tag, k)]
+        scale = want[2] + 1e-12
+        got = g.reshape(-1)[::211].cpu().numpy()
+        if tight:
+            np.testing.assert_allclose(got, rows, rtol=0, atol=1e-5 * scale, err_msg=k)
+        else:   # single argmax / kink flips move isolated elements: bound the error in the l2 sense
+            assert np.linalg.norm(got - rows) <= 3e-3 * np.linalg.norm(rows) + 2e-3 * scale * len(rows) ** 0.5, k
+        assert abs(chk(g)[1] - want[1]) <= (1e-5 if tight else 3e-3) * want[1] + 1e-12, k
+    rs = {k: v for k, v in model.state_dict().items() if 'running' in k}
+    assert [str(n) for n in gold[tag + '_running_names']] == list(rs)
+    for v, want in zip(rs.values(), gold[tag + '_running_checks']):
+        assert abs(chk(v)[1] - want[1]) <= 1e-5 * want[1] + 1e-9

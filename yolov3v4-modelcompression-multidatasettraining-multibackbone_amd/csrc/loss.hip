@@ -74,6 +74,14 @@ __device__ __forceinline__ void block_sum_atomic(float v, float* dst) {
     __syncthreads();
 }
 
+// several targets may match the same (image, anchor, cell): remember the last one per cell
+__global__ __launch_bounds__(256) void loss_winner_kernel(const yh_loss_desc d) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= d.nb) return;
+    const int b = d.idx[4 * i], a = d.idx[4 * i + 1], gy = d.idx[4 * i + 2], gx = d.idx[4 * i + 3];
+    atomicMax(d.winner + (((long)b * d.na + a) * d.ny + gy) * d.nx + gx, i);
+}
+
 // matched targets, forward: box and class sums, objectness targets
 __global__ __launch_bounds__(256) void loss_matched_fwd_kernel(const yh_loss_desc d) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -84,7 +92,8 @@ __global__ __launch_bounds__(256) void loss_matched_fwd_kernel(const yh_loss_des
         const float box[4] = {ps[0], ps[1], ps[2], ps[3]};
         const Dual4 g = giou_of(box, d.anchor + 2 * i, d.tbox + 4 * i);
         lbox = 1.f - g.v;
-        d.tobj[(((long)b * d.na + a) * d.ny + gy) * d.nx + gx] = (1.f - d.gr) + d.gr * fmaxf(g.v, 0.f);
+        const long cell = (((long)b * d.na + a) * d.ny + gy) * d.nx + gx;
+        if (d.winner[cell] == i) d.tobj[cell] = (1.f - d.gr) + d.gr * fmaxf(g.v, 0.f);
         if (d.nc > 1) {
             const int tc = d.tcls[i];
             for (int c = 0; c < d.nc; ++c) lcls += bce(ps[5 + c], c == tc ? d.cp : d.cn, d.cls_pw);
@@ -149,7 +158,7 @@ __global__ __launch_bounds__(256) void loss_matched_bwd_kernel(const yh_loss_des
 
 static int check_loss(const yh_loss_desc* d, bool bwd) {
     if (!d || !d->p || !d->tobj || d->bs <= 0 || d->na <= 0 || d->ny <= 0 || d->nx <= 0 || d->no < 5 || d->nc != d->no - 5) return YH_EINVAL;
-    if (d->nb < 0 || (d->nb > 0 && (!d->idx || !d->tbox || !d->anchor || (d->nc > 1 && !d->tcls)))) return YH_EINVAL;
+    if (d->nb < 0 || (d->nb > 0 && (!d->idx || !d->tbox || !d->anchor || (d->nc > 1 && !d->tcls) || (!bwd && !d->winner)))) return YH_EINVAL;
     if (bwd ? (!d->grad || !d->scale) : !d->sums) return YH_EINVAL;
     return YH_OK;
 }
@@ -167,7 +176,10 @@ extern "C" int yh_yolo_loss_fwd(const yh_loss_desc* d, void* stream) {
     int rc = check_loss(d, false);
     if (rc) return rc;
     hipStream_t s = (hipStream_t)stream;
-    if (d->nb > 0) hipLaunchKernelGGL(loss_matched_fwd_kernel, dim3((d->nb + 255) / 256), dim3(256), 0, s, *d);
+    if (d->nb > 0) {
+        hipLaunchKernelGGL(loss_winner_kernel, dim3((d->nb + 255) / 256), dim3(256), 0, s, *d);
+        hipLaunchKernelGGL(loss_matched_fwd_kernel, dim3((d->nb + 255) / 256), dim3(256), 0, s, *d);
+    }
     hipLaunchKernelGGL(loss_obj_fwd_kernel, dim3(grid_n((long)d->bs * d->na * d->ny * d->nx)), dim3(256), 0, s, *d);
     return check_launch();
 }

@@ -185,7 +185,7 @@ class SeBwdDesc(C.Structure):
 
 
 class LossDesc(C.Structure):
-    _fields_ = [('p', _vp), ('grad', _vp), ('tobj', _vp), ('idx', _vp), ('tbox', _vp), ('tcls', _vp), ('anchor', _vp), ('sums', _vp),
+    _fields_ = [('p', _vp), ('grad', _vp), ('tobj', _vp), ('winner', _vp), ('idx', _vp), ('tbox', _vp), ('tcls', _vp), ('anchor', _vp), ('sums', _vp),
                 ('scale', _vp),
                 ('sb', _i64), ('sa', _i64), ('sy', _i64), ('sx', _i64), ('gb', _i64), ('ga', _i64), ('gy', _i64), ('gx', _i64),
                 ('bs', _i32), ('na', _i32), ('ny', _i32), ('nx', _i32), ('no', _i32), ('nc', _i32), ('nb', _i32),

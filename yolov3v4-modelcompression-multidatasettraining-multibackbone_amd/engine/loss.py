@@ -43,8 +43,9 @@ class _YoloLoss(torch.autograd.Function):
             idx, tbox, tcls, anchor = meta['matched'][i]
             nb = int(idx.shape[0])
             tobj = torch.zeros((bs, na, ny, nx), device=dev, dtype=torch.float32)
+            winner = torch.full((bs, na, ny, nx), -1, device=dev, dtype=torch.int32) if nb else None
             cells = bs * na * ny * nx
-            d = LossDesc(p=hiplib.ptr(p), grad=None, tobj=hiplib.ptr(tobj), idx=hiplib.ptr(idx) if nb else None,
+            d = LossDesc(p=hiplib.ptr(p), grad=None, tobj=hiplib.ptr(tobj), winner=hiplib.ptr(winner), idx=hiplib.ptr(idx) if nb else None,
                          tbox=hiplib.ptr(tbox) if nb else None, tcls=hiplib.ptr(tcls) if nb else None,
                          anchor=hiplib.ptr(anchor) if nb else None, sums=hiplib.ptr(sums, 3 * i), scale=None,
                          sb=p.stride(0), sa=p.stride(1), sy=p.stride(2), sx=p.stride(3), gb=0, ga=0, gy=0, gx=0,
@@ -54,6 +55,7 @@ class _YoloLoss(torch.autograd.Function):
                          w_cls=meta['cls'] / max(nb * (no - 5), 1))
             hiplib.check(lib.yh_yolo_loss_fwd(C.byref(d), hiplib.stream_ptr()), 'yh_yolo_loss_fwd')
             heads.append((d, tobj, p))
+            del winner   # only the forward needs it (stream-ordered free)
             if nb:
                 lbox = lbox + sums[i, 0] * d.w_box
                 if no - 5 > 1:
