@@ -242,7 +242,12 @@ def train_main(args, device, dist, world, rank, local_rank):
             pg1.append(v)
         else:
             pg0.append(v)
-    opt = torch.optim.SGD(pg0, lr=HYP['lr0'] * 0.01, momentum=HYP['momentum'], nesterov=True)
+    # same update rule as train.py:121; torch's single-launch multi-tensor implementation when the build has it
+    sgd_impl = os.environ.get('YOLO_BENCH_SGD', 'fused')
+    try:
+        opt = torch.optim.SGD(pg0, lr=HYP['lr0'] * 0.01, momentum=HYP['momentum'], nesterov=True, fused=(sgd_impl == 'fused'))
+    except (RuntimeError, TypeError):
+        opt = torch.optim.SGD(pg0, lr=HYP['lr0'] * 0.01, momentum=HYP['momentum'], nesterov=True)
     opt.add_param_group({'params': pg1, 'weight_decay': HYP['weight_decay']})
     opt.add_param_group({'params': pg2})
     core = model

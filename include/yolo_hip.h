@@ -197,13 +197,19 @@ typedef struct yh_copy_desc {
 } yh_copy_desc;
 int yh_copy_channels(const yh_copy_desc* d, void* stream);
 
-/* Unfused Shortcut (utils/layers.py:52-72): y[..., 0:c] = a[..., 0:c] + b[..., 0:c] (c = min channels) */
+/* Unfused Shortcut (utils/layers.py:52-72): y[..., 0:c] = a[..., 0:c] + b[..., 0:c].
+ * With amap / bmap (device int32[c], both or neither) the operands are gathered per channel instead:
+ * y[..., k] = a[..., amap[k]] + b[..., bmap[k]], a negative index contributing zero - the reference's sum over the
+ * leading min(Ca, Cb) channels when the operands differ in width (layers.py:65-70), and operands that are concats of
+ * padded pieces (GhostNet).  The gather form has no alignment requirement on c.                                      */
 typedef struct yh_add_desc {
     const void* a;
     const void* b;
     void* y;
     int64_t pixels;
     int32_t c, lda, ldb, ldy, dtype;
+    const int32_t* amap;
+    const int32_t* bmap;
 } yh_add_desc;
 int yh_add_channels(const yh_add_desc* d, void* stream);
 
@@ -358,29 +364,33 @@ int yh_conv_pack_weights_dgrad_phase(int dtype, const float* w, int cout, int ci
  *   lobj = obj_gain  * sum_heads mean_cells BCE(p[..., 4], tobj),  tobj = (1 - gr) + gr * max(GIoU, 0) at matched cells
  *   lcls = cls_gain  * sum_heads mean_{i, c} BCE(ps_i[5 + c], cp if c == tcls_i else cn)          (nc > 1 only)
  * with box(ps) = (sigmoid(ps[0:2]), min(exp(ps[2:4]), 1e3) * anchor).  The target assignment (build_targets,
- * utils.py:725-779) stays on the host side of the ABI and arrives as the matched lists below.  Raw tensors are
+ * utils.py:725-779) happens inside the kernels, so a step needs no host round trip: candidate k = a * nt + t (anchor a,
+ * label t, the reference's order) is matched when wh_iou(anchors[a], label wh in grid units) > iou_t; its cell is
+ * (image, a, int(y * ny), int(x * nx)) and its box (frac(x * nx), frac(y * ny), w * nx, h * ny).  Raw tensors are
  * addressed through element strides, so the (bs, na, ny, nx, no) views of NHWC head buffers are read in place.
  *
  *  yh_yolo_loss_fwd   fills tobj (caller zeroes it) and adds the three un-normalised sums to sums[0..2]
- *                     (caller zeroes; lbox: sum (1 - giou), lobj: sum bce, lcls: sum bce) for one head.
+ *                     (caller zeroes; lbox: sum (1 - giou), lobj: sum bce, lcls: sum bce) for one head; adds the number
+ *                     of matched candidates to count[0] and ORs a label error mask into count[1] (1: class outside
+ *                     [0, nc), 2: image or cell outside the head; such candidates are skipped) - caller zeroes both.
  *  yh_yolo_loss_bwd   writes d(loss)/d(p) for EVERY logical element of the head (zeros included) scaled by *scale
- *                     (device scalar: autograd's grad_output), gradient tensor addressed by its own strides.       */
+ *                     (device scalar: autograd's grad_output), gradient tensor addressed by its own strides; the mean
+ *                     weights g_box / nb, g_obj / cells, g_cls / (nb * nc) use nb = count[0] from the forward.      */
 typedef struct yh_loss_desc {
     const float* p;             /* raw head, element (b, a, y, x, o) at p + b*sb + a*sa + y*sy + x*sx + o          */
     float* grad;                /* bwd only, same indexing with gb, ga, gy, gx                                       */
     float* tobj;                /* (bs, na, ny, nx) dense fp32                                                       */
-    int32_t* winner;            /* (bs, na, ny, nx) int32, caller fills with -1: when several targets match one cell the */
-                                /* LAST one sets tobj, like the reference's sequential index_put on the CPU              */
-    const int32_t* idx;         /* (nb, 4): image, anchor, gy, gx                                                    */
-    const float* tbox;          /* (nb, 4): cell-relative xy, grid-unit wh                                           */
-    const int32_t* tcls;        /* (nb)                                                                              */
-    const float* anchor;        /* (nb, 2): matched anchor wh in grid units                                          */
+    int32_t* winner;            /* (bs, na, ny, nx) int32, caller fills with -1: when several candidates match one  */
+                                /* cell the LAST one sets tobj, like the reference's sequential index_put on the CPU */
+    const float* targets;       /* (nt, 6): image, class, x, y, w, h (normalised to the image)                       */
+    const float* anchors;       /* (na, 2): anchor wh in grid units (YOLOLayer.anchor_vec)                           */
     float* sums;                /* fwd: [3] accumulators                                                             */
+    int32_t* count;             /* [2]: matched candidates, label error mask                                         */
     const float* scale;         /* bwd: device scalar multiplied into every gradient                                 */
     int64_t sb, sa, sy, sx, gb, ga, gy, gx;
-    int32_t bs, na, ny, nx, no, nc, nb;
-    float gr, cp, cn, cls_pw, obj_pw;
-    float w_box, w_obj, w_cls;  /* bwd: giou_gain / nb, obj_gain / cells, cls_gain / (nb * nc)                       */
+    int32_t bs, na, ny, nx, no, nc, nt;
+    float iou_t, gr, cp, cn, cls_pw, obj_pw;
+    float g_box, g_obj, g_cls;  /* hyp['giou'], hyp['obj'], hyp['cls']                                              */
 } yh_loss_desc;
 int yh_yolo_loss_fwd(const yh_loss_desc* d, void* stream);
 int yh_yolo_loss_bwd(const yh_loss_desc* d, void* stream);

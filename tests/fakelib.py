@@ -325,6 +325,15 @@ class FakeLib:
     def yh_add_channels(self, dref, stream):
         d = dref._obj if hasattr(dref, '_obj') else dref
         npdt = _NP[d.dtype]
+        if d.amap or d.bmap:
+            assert d.amap and d.bmap
+            am, bm = flat(d.amap, d.c, np.int32), flat(d.bmap, d.c, np.int32)
+            a = pitched(d.a, d.pixels, max(int(am.max()), 0) + 1, d.lda, npdt).astype(np.float32)
+            b = pitched(d.b, d.pixels, max(int(bm.max()), 0) + 1, d.ldb, npdt).astype(np.float32)
+            va = np.where(am[None, :] >= 0, a[:, np.maximum(am, 0)], 0.0)
+            vb = np.where(bm[None, :] >= 0, b[:, np.maximum(bm, 0)], 0.0)
+            pitched(d.y, d.pixels, d.c, d.ldy, npdt)[:] = (va + vb).astype(npdt)
+            return 0
         a = pitched(d.a, d.pixels, d.c, d.lda, npdt).astype(np.float32)
         b = pitched(d.b, d.pixels, d.c, d.ldb, npdt).astype(np.float32)
         pitched(d.y, d.pixels, d.c, d.ldy, npdt)[:] = (a + b).astype(npdt)
@@ -516,15 +525,38 @@ class FakeLib:
         return np.lib.stride_tricks.as_strided(base, shape=(d.bs, d.na, d.ny, d.nx, d.no),
                                                strides=(4 * sb, 4 * sa, 4 * sy, 4 * sx, 4), writeable=True)
 
+    @staticmethod
+    def _loss_assign(d):
+        """build_targets for one head from the descriptor: (idx (nb, 4) long, tbox (nb, 4), tcls (nb), anchors (nb, 2), mask)."""
+        if not d.nt:
+            z = torch.zeros
+            return z(0, 4, dtype=torch.long), z(0, 4), z(0, dtype=torch.long), z(0, 2), 0
+        tg = torch.from_numpy(flat(d.targets, 6 * d.nt, np.float32).reshape(d.nt, 6).copy())
+        anc = torch.from_numpy(flat(d.anchors, 2 * d.na, np.float32).reshape(d.na, 2).copy())
+        t = tg * torch.tensor([1, 1, d.nx, d.ny, d.nx, d.ny], dtype=torch.float32)
+        inter = torch.min(anc[:, None], t[None, :, 4:6]).prod(2)
+        iou = inter / (anc[:, None].prod(2) + t[None, :, 4:6].prod(2) - inter)
+        a = torch.arange(d.na).view(-1, 1).repeat(1, d.nt).view(-1)
+        keep = iou.view(-1) > torch.tensor(d.iou_t, dtype=torch.float32)
+        t, a = t.repeat(d.na, 1)[keep], a[keep]
+        b, c = t[:, 0].long(), t[:, 1].long()
+        gi, gj = t[:, 2].long(), t[:, 3].long()
+        bad_c = (c < 0) | (c >= d.nc)
+        bad_i = (b < 0) | (b >= d.bs) | (gi < 0) | (gi >= d.nx) | (gj < 0) | (gj >= d.ny)
+        mask = (1 if bool(bad_c.any()) else 0) | (2 if bool(bad_i.any()) else 0)
+        ok = ~(bad_c | bad_i)
+        t, a, b, c, gi, gj = t[ok], a[ok], b[ok], c[ok], gi[ok], gj[ok]
+        tbox = torch.cat((t[:, 2:4] - t[:, 2:4].floor(), t[:, 4:6]), 1)
+        return torch.stack((b, a, gj, gi), 1), tbox, c, anc[a], mask
+
     def _loss_terms(self, d, p):
-        """(sum (1 - giou), sum obj bce, sum cls bce, tobj) of one head in torch, differentiable in p."""
+        """(sum (1 - giou), sum obj bce, sum cls bce, tobj, nb, mask) of one head in torch, differentiable in p."""
         tobj = torch.zeros(d.bs, d.na, d.ny, d.nx)
         lbox = p.sum() * 0
         lcls = p.sum() * 0
-        if d.nb:
-            idx = torch.from_numpy(flat(d.idx, 4 * d.nb, np.int32).reshape(d.nb, 4).astype(np.int64))
-            tbox = torch.from_numpy(flat(d.tbox, 4 * d.nb, np.float32).reshape(d.nb, 4).copy())
-            anc = torch.from_numpy(flat(d.anchor, 2 * d.nb, np.float32).reshape(d.nb, 2).copy())
+        idx, tbox, tcls, anc, mask = self._loss_assign(d)
+        nb = idx.shape[0]
+        if nb:
             b, a, gj, gi = idx.t()
             ps = p[b, a, gj, gi]
             pxy = torch.sigmoid(ps[:, 0:2])
@@ -542,31 +574,35 @@ class FakeLib:
             lbox = (1.0 - giou).sum()
             tobj[b, a, gj, gi] = (1.0 - d.gr) + d.gr * giou.detach().clamp(0)
             if d.nc > 1:
-                tcls = torch.from_numpy(flat(d.tcls, d.nb, np.int32).astype(np.int64))
                 t = torch.full_like(ps[:, 5:], d.cn)
-                t[range(d.nb), tcls] = d.cp
+                t[range(nb), tcls] = d.cp
                 lcls = F.binary_cross_entropy_with_logits(ps[:, 5:], t, pos_weight=torch.tensor([d.cls_pw]), reduction='sum')
         lobj = F.binary_cross_entropy_with_logits(p[..., 4], tobj, pos_weight=torch.tensor([d.obj_pw]), reduction='sum')
-        return lbox, lobj, lcls, tobj
+        return lbox, lobj, lcls, tobj, nb, mask
 
     def yh_yolo_loss_fwd(self, dref, stream):
         d = dref._obj if hasattr(dref, '_obj') else dref
         p = torch.from_numpy(self._loss_view(d.p, d, d.sb, d.sa, d.sy, d.sx).copy())
-        lbox, lobj, lcls, tobj = self._loss_terms(d, p)
+        lbox, lobj, lcls, tobj, nb, mask = self._loss_terms(d, p)
         flat(d.tobj, tobj.numel(), np.float32)[:] = tobj.reshape(-1).numpy()
         sums = flat(d.sums, 3, np.float32)
         sums[0] += float(lbox)
         sums[1] += float(lobj)
         sums[2] += float(lcls)
+        count = flat(d.count, 2, np.int32)
+        count[0] += nb
+        count[1] |= mask
         return 0
 
     def yh_yolo_loss_bwd(self, dref, stream):
         d = dref._obj if hasattr(dref, '_obj') else dref
         scale = float(flat(d.scale, 1, np.float32)[0])
+        nb = max(int(flat(d.count, 2, np.int32)[0]), 1)
         with torch.enable_grad():
             p = torch.from_numpy(self._loss_view(d.p, d, d.sb, d.sa, d.sy, d.sx).copy()).requires_grad_()
-            lbox, lobj, lcls, _ = self._loss_terms(d, p)
-            (scale * (d.w_box * lbox + d.w_obj * lobj + d.w_cls * lcls)).backward()
+            lbox, lobj, lcls, _, _, _ = self._loss_terms(d, p)
+            cells = d.bs * d.na * d.ny * d.nx
+            (scale * (d.g_box / nb * lbox + d.g_obj / cells * lobj + d.g_cls / (nb * max(d.nc, 1)) * lcls)).backward()
         self._loss_view(d.grad, d, d.gb, d.ga, d.gy, d.gx)[:] = p.grad.numpy()
         return 0
 

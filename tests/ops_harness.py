@@ -109,12 +109,17 @@ def copy_channels(lib, code, x, y, c, ups=1, x_off=0, y_off=0):
     return y
 
 
-def add_channels(lib, code, a, b, c):
+def add_channels(lib, code, a, b, c, amap=None, bmap=None):
+    """y = a + b over c channels; with amap / bmap (lists of c source channels, -1 = zero) the gather form."""
     N, H, W, lda = a.shape
     y = torch.full((N, H, W, c), 3.0, device=a.device, dtype=a.dtype)
-    d = AddDesc(a=P(a), b=P(b), y=P(y), pixels=N * H * W, c=c, lda=lda, ldb=b.shape[3], ldy=c, dtype=code)
+    maps = [None if m is None else torch.tensor(m, dtype=torch.int32).to(a.device) for m in (amap, bmap)]
+    d = AddDesc(a=P(a), b=P(b), y=P(y), pixels=N * H * W, c=c, lda=lda, ldb=b.shape[3], ldy=c, dtype=code,
+                amap=P(maps[0]) if maps[0] is not None else None, bmap=P(maps[1]) if maps[1] is not None else None)
     rc = lib.yh_add_channels(C.byref(d), stream())
     assert rc == 0, rc
+    if a.is_cuda:
+        torch.cuda.synchronize()   # the maps must outlive the launch
     return y
 
 

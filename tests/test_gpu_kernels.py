@@ -192,6 +192,28 @@ def test_copy_and_add_match_emulation(libs, code, ups):
     assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
 
 
+@pytest.mark.parametrize('code', [F32, F16], ids=['fp32', 'fp16'])
+def test_gathered_add_matches_torch(libs, code):
+    """yh_add_channels with channel maps: operands of different widths / concats of padded pieces (GhostNet shortcuts)."""
+    lib, fake = libs
+    g = torch.Generator().manual_seed(15)
+    dt = oh.tdtype(code)
+    a = _rand(g, 2, 7, 5, 24).to(dt)
+    b = _rand(g, 2, 7, 5, 32).to(dt)
+    amap = list(range(21)) + [-1] * 3                                     # 21 logical channels, 24 physical
+    bmap = list(range(12)) + list(range(16, 22)) + [-1] * 3 + [-1] * 3    # 12 + 6 of a padded concat, then nothing
+    want = torch.zeros(2, 7, 5, 24)
+    for k in range(24):
+        if amap[k] >= 0:
+            want[..., k] += a[..., amap[k]].float()
+        if bmap[k] >= 0:
+            want[..., k] += b[..., bmap[k]].float()
+    want = want.to(dt).float()
+    for L, dev in ((lib, GPU), (fake, 'cpu')):
+        got = oh.add_channels(L, code, a.to(dev), b.to(dev), c=24, amap=amap, bmap=bmap).float().cpu()
+        assert torch.equal(got, want)
+
+
 def test_decode_matches_emulation_and_oracle(libs):
     from oracle import darknet_oracle as oracle
     lib, fake = libs

@@ -155,3 +155,24 @@ def test_graph_replay_equals_direct_replay(cfg_dir):
         for p, q in zip(ra, rb):
             assert torch.equal(p, q)
     assert not torch.equal(outs[8][0][0], outs[8][1][0]), 'graph must see the new frame'
+
+
+@pytest.mark.parametrize('which', ['odd', 'odd_mobile', 'ghost'])
+@pytest.mark.parametrize('precision', ['fp32', 'fp16'])
+def test_unfused_and_padded_forms_match_eager(which, precision):
+    """The cfgs of tests/test_plan_emulated.py that force the non-fused ops (explicit add / copy / upsample, channel counts
+    that need padding, depthwise + SE, GhostNet's gathered shortcuts) on the real library against the eager CPU modules."""
+    import models
+    import test_plan_emulated as tpe
+    defs = {'odd': tpe._odd_cfg, 'odd_mobile': tpe._odd_mobile_cfg, 'ghost': tpe._ghost_like_cfg}[which]()
+    torch.manual_seed(5)
+    model = models.Darknet(defs, (64, 64))
+    model.load_state_dict(synth.randomize_bn_(model.state_dict(), seed=6))
+    model.eval()
+    x = synth.image_batch(2, 64, seed=7)
+    with torch.no_grad():
+        ref, raws_ref, _ = model(x)
+    io, raws, _ = _hip_forward(model.cuda(), x, precision)
+    tol = 2e-4 if precision == 'fp32' else 0.08
+    assert (io.cpu() - ref).abs().max().item() <= tol
+    assert (raws[0].cpu() - raws_ref[0]).abs().max().item() <= tol

@@ -654,3 +654,29 @@ def test_training_step_on_gpu_matches_reference_golden(libs, tag, rel, size, nc)
         den += float((rows ** 2).sum())
         assert abs(params[k].grad.abs().sum().item() - want[1]) <= 1e-2 * want[1] + 1e-6, k
     assert (num / den) ** 0.5 <= 3e-3
+
+
+def test_fused_loss_defers_the_label_check_without_a_host_sync(libs):
+    """The kernels record labels outside the class range on the device; the reference's AssertionError surfaces at the next
+    compute_loss call / flush_label_check() instead of stalling the step on a device-to-host read."""
+    if DRY:
+        pytest.skip('the emulator raises immediately (tests/test_loss_golden.py)')
+    from models import Darknet
+    from utils import utils as U
+    from engine import loss as hip_loss
+    torch.manual_seed(0)
+    model = Darknet(os.path.join(conftest.PKG, 'cfg', 'yolov3tiny/yolov3-tiny-hand.cfg'), (416, 416))
+    model.nc, model.gr = 1, 1.0
+    model.hyp = {'giou': 3.54, 'cls': 37.4, 'cls_pw': 1.0, 'obj': 64.3, 'obj_pw': 1.0, 'iou_t': 0.20, 'fl_gamma': 0.0}
+    raws, targets = synth.loss_inputs(model, 416, batch=2, seed=3)
+    raws = [r.to(GPU) for r in raws]
+    bad = targets.clone()
+    bad[:, 1] = 1.0
+    hip_loss.flush_label_check()
+    loss, _ = U.compute_loss(raws, bad.to(GPU), model)          # launches, does not raise
+    with pytest.raises(AssertionError):
+        hip_loss.flush_label_check()
+    loss, items = U.compute_loss(raws, targets.to(GPU), model)  # a clean batch afterwards is unaffected
+    hip_loss.flush_label_check()
+    ref, ref_items = U.compute_loss([r.cpu() for r in raws], targets, model, fused=False)
+    assert torch.allclose(items.cpu(), ref_items, rtol=1e-5, atol=1e-6)

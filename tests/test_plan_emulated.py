@@ -118,6 +118,49 @@ def test_depthwise_and_se_on_padded_channels(prec):
     assert (io - ref).abs().max().item() <= tol
 
 
+def _ghost_like_cfg():
+    """GhostNet idioms (reference cfg/yolov3-ghostnet): grouped 3x3 convs written as ``convolutional`` + ``groups``, a
+    shortcut whose operand is a concat of padded pieces, and shortcuts between tensors of different widths (the sum runs
+    over the leading min(Ca, Cb) channels, reference layers.py:65-70)."""
+    net = {'type': 'net', 'width': 64, 'height': 64, 'channels': 3}
+    conv = lambda f, k, s=1, act='relu', bn=1, g=1: {'type': 'convolutional', 'batch_normalize': bn, 'filters': f, 'size': k,
+                                                     'stride': s, 'pad': 1, 'groups': g, 'activation': act}
+    anchors = np.array([[10., 13.], [16., 30.], [33., 23.]])
+    return [net,
+            conv(16, 3, 2),                                   # 0
+            conv(12, 1),                                      # 1  primary half of a ghost module
+            conv(12, 3, 1, 'relu', 1, 12),                    # 2  cheap half: per-channel 3x3
+            {'type': 'route', 'layers': [-1, 1]},             # 3  12 + 12 -> pieces padded to 16 each
+            conv(24, 1, 1, 'linear'),                         # 4
+            {'type': 'shortcut', 'from': [-2], 'activation': 'linear'},   # 5  operand is the padded concat
+            conv(10, 1, 1, 'linear'),                         # 6
+            {'type': 'shortcut', 'from': [4], 'activation': 'linear'},    # 7  10 + first 10 of 24
+            conv(24, 1),                                      # 8
+            {'type': 'shortcut', 'from': [6], 'activation': 'linear'},    # 9  first 10 of 24 += 10
+            conv(24, 1, 1, 'linear', 0),                      # 10 head
+            {'type': 'yolo', 'mask': [0, 1, 2], 'anchors': anchors, 'classes': 3, 'num': 3}]
+
+
+@pytest.mark.parametrize('prec', ['fp32', 'fp16'])
+def test_ghost_idioms_are_lowered(prec):
+    import models
+    torch.manual_seed(21)
+    model = models.Darknet(_ghost_like_cfg(), (64, 64))
+    model.load_state_dict(synth.randomize_bn_(model.state_dict(), seed=22))
+    model.eval()
+    x = synth.image_batch(2, 64, seed=23)
+    with torch.no_grad():
+        ref, raws_ref, _ = model(x)
+    eng = DarknetEngine(model, precision=prec, lib=fakelib.FakeLib())
+    io, raws, _ = eng(x)
+    tol = 2e-4 if prec == 'fp32' else 0.08
+    assert (io - ref).abs().max().item() <= tol
+    assert (raws[0] - raws_ref[0]).abs().max().item() <= tol
+    plan = next(iter(eng._plans.values()))
+    mapped = [d for what, d in plan['ops'] if what.startswith('add') and d.amap]
+    assert len(mapped) == 3
+
+
 def test_weight_edits_are_picked_up():
     """In-place parameter updates (optimizer step, prune script) must reach the packed weights."""
     import models

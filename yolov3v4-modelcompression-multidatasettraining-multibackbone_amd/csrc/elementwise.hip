@@ -233,6 +233,21 @@ __global__ __launch_bounds__(256) void add_channels_kernel(const yh_add_desc d) 
     }
 }
 
+template <typename T>
+__global__ __launch_bounds__(256) void add_gather_kernel(const yh_add_desc d) {
+    const long total = d.pixels * d.c;
+    const T* a = reinterpret_cast<const T*>(d.a);
+    const T* b = reinterpret_cast<const T*>(d.b);
+    T* y = reinterpret_cast<T*>(d.y);
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int k = (int)(i % d.c);
+        const long pix = i / d.c;
+        const int ka = d.amap[k], kb = d.bmap[k];
+        const float va = ka >= 0 ? (float)a[pix * d.lda + ka] : 0.f, vb = kb >= 0 ? (float)b[pix * d.ldb + kb] : 0.f;
+        y[pix * d.ldy + k] = (T)(va + vb);
+    }
+}
+
 // ------------------------------------------------------------------------------------- yolo decode
 // grid.x = n * na * ny: one workgroup per (image, anchor, grid row); threads sweep the nx * no outputs of the
 // row, which are contiguous in both io and raw; the head map is read in 4*no-byte runs (one per cell).
@@ -376,10 +391,17 @@ extern "C" int yh_copy_channels(const yh_copy_desc* d, void* stream) {
 extern "C" int yh_add_channels(const yh_add_desc* d, void* stream) {
     if (!d || !d->a || !d->b || !d->y || d->pixels <= 0 || d->c <= 0) return YH_EINVAL;
     if (d->dtype != YH_F16 && d->dtype != YH_F32) return YH_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    if (d->amap || d->bmap) {
+        if (!d->amap || !d->bmap) return YH_EINVAL;
+        const long n = d->pixels * d->c;
+        if (d->dtype == YH_F16) hipLaunchKernelGGL(add_gather_kernel<f16>, dim3(grid_for(n)), dim3(256), 0, s, *d);
+        else hipLaunchKernelGGL(add_gather_kernel<float>, dim3(grid_for(n)), dim3(256), 0, s, *d);
+        return check_launch();
+    }
     const int v = vec_of(d->dtype);
     if (d->c % v || d->lda % v || d->ldb % v || d->ldy % v || !aligned16(d->a) || !aligned16(d->b) || !aligned16(d->y)) return YH_EALIGN;
     const long total = d->pixels * (d->c / v);
-    hipStream_t s = (hipStream_t)stream;
     if (d->dtype == YH_F16) hipLaunchKernelGGL(add_channels_kernel<f16>, dim3(grid_for(total)), dim3(256), 0, s, *d);
     else hipLaunchKernelGGL(add_channels_kernel<float>, dim3(grid_for(total)), dim3(256), 0, s, *d);
     return check_launch();

@@ -74,30 +74,61 @@ __device__ __forceinline__ void block_sum_atomic(float v, float* dst) {
     __syncthreads();
 }
 
-// several targets may match the same (image, anchor, cell): remember the last one per cell
-__global__ __launch_bounds__(256) void loss_winner_kernel(const yh_loss_desc d) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= d.nb) return;
-    const int b = d.idx[4 * i], a = d.idx[4 * i + 1], gy = d.idx[4 * i + 2], gx = d.idx[4 * i + 3];
-    atomicMax(d.winner + (((long)b * d.na + a) * d.ny + gy) * d.nx + gx, i);
+// build_targets (utils/utils.py:725-779) for one candidate k = a * nt + t, in the reference's fp32 arithmetic
+struct Match {
+    int b, a, gy, gx, cls;
+    long cell;
+    float tb[4], an[2];
+};
+// 0: matched, -1: wh_iou <= iou_t, > 0: label error mask (class / image / cell out of range)
+__device__ __forceinline__ int assign(const yh_loss_desc& d, int k, Match& m) {
+    m.a = k / d.nt;
+    const float* tg = d.targets + 6L * (k - m.a * d.nt);
+    const float gx = tg[2] * (float)d.nx, gy = tg[3] * (float)d.ny, gw = tg[4] * (float)d.nx, gh = tg[5] * (float)d.ny;
+    m.an[0] = d.anchors[2 * m.a];
+    m.an[1] = d.anchors[2 * m.a + 1];
+    const float inter = fminf(m.an[0], gw) * fminf(m.an[1], gh);      // wh_iou (utils.py:325-331)
+    if (!(inter / (m.an[0] * m.an[1] + gw * gh - inter) > d.iou_t)) return -1;
+    m.b = (int)tg[0];
+    m.cls = (int)tg[1];
+    m.gx = (int)gx;
+    m.gy = (int)gy;
+    int err = 0;
+    if (m.cls < 0 || m.cls >= d.nc) err |= 1;
+    if (m.b < 0 || m.b >= d.bs || m.gx < 0 || m.gx >= d.nx || m.gy < 0 || m.gy >= d.ny) err |= 2;
+    if (err) return err;
+    m.tb[0] = gx - floorf(gx);
+    m.tb[1] = gy - floorf(gy);
+    m.tb[2] = gw;
+    m.tb[3] = gh;
+    m.cell = (((long)m.b * d.na + m.a) * d.ny + m.gy) * d.nx + m.gx;
+    return 0;
 }
 
-// matched targets, forward: box and class sums, objectness targets
+// count the matched candidates; several may share a cell: remember the last one per cell
+__global__ __launch_bounds__(256) void loss_assign_kernel(const yh_loss_desc d) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    Match m;
+    const int r = k < d.na * d.nt ? assign(d, k, m) : -1;
+    if (r == 0) atomicMax(d.winner + m.cell, k);
+    if (r > 0) atomicOr(d.count + 1, r);
+    const unsigned long long hit = __ballot(r == 0);
+    if ((threadIdx.x & 63) == 0 && hit) atomicAdd(d.count, __popcll(hit));
+}
+
+// matched candidates, forward: box and class sums, objectness targets
 __global__ __launch_bounds__(256) void loss_matched_fwd_kernel(const yh_loss_desc d) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
     float lbox = 0.f, lcls = 0.f;
-    if (i < d.nb) {
-        const int b = d.idx[4 * i], a = d.idx[4 * i + 1], gy = d.idx[4 * i + 2], gx = d.idx[4 * i + 3];
-        const float* ps = d.p + b * d.sb + a * d.sa + gy * d.sy + gx * d.sx;
+    Match m;
+    if (k < d.na * d.nt && assign(d, k, m) == 0) {
+        const float* ps = d.p + m.b * d.sb + m.a * d.sa + m.gy * d.sy + m.gx * d.sx;
         const float box[4] = {ps[0], ps[1], ps[2], ps[3]};
-        const Dual4 g = giou_of(box, d.anchor + 2 * i, d.tbox + 4 * i);
+        const Dual4 g = giou_of(box, m.an, m.tb);
         lbox = 1.f - g.v;
-        const long cell = (((long)b * d.na + a) * d.ny + gy) * d.nx + gx;
-        if (d.winner[cell] == i) d.tobj[cell] = (1.f - d.gr) + d.gr * fmaxf(g.v, 0.f);
-        if (d.nc > 1) {
-            const int tc = d.tcls[i];
-            for (int c = 0; c < d.nc; ++c) lcls += bce(ps[5 + c], c == tc ? d.cp : d.cn, d.cls_pw);
-        }
+        if (d.winner[m.cell] == k) d.tobj[m.cell] = (1.f - d.gr) + d.gr * fmaxf(g.v, 0.f);
+        if (d.nc > 1)
+            for (int c = 0; c < d.nc; ++c) lcls += bce(ps[5 + c], c == m.cls ? d.cp : d.cn, d.cls_pw);
     }
     block_sum_atomic(lbox, d.sums + 0);
     if (d.nc > 1) block_sum_atomic(lcls, d.sums + 2);
@@ -122,7 +153,7 @@ __global__ __launch_bounds__(256) void loss_obj_fwd_kernel(const yh_loss_desc d)
 // every cell, backward: the whole gradient row of the cell (zeros, objectness term in slot 4)
 __global__ __launch_bounds__(256) void loss_dense_bwd_kernel(const yh_loss_desc d) {
     const long total = (long)d.bs * d.na * d.ny * d.nx * d.no;
-    const float sc = *d.scale * d.w_obj;
+    const float sc = *d.scale * d.g_obj / (float)((long)d.bs * d.na * d.ny * d.nx);
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int o = (int)(i % d.no);
         long cell = i / d.no;
@@ -138,27 +169,26 @@ __global__ __launch_bounds__(256) void loss_dense_bwd_kernel(const yh_loss_desc 
     }
 }
 
-// matched targets, backward: box and class terms added on top of the dense pass (duplicates of a cell accumulate)
+// matched candidates, backward: box and class terms added on top of the dense pass (duplicates of a cell accumulate)
 __global__ __launch_bounds__(256) void loss_matched_bwd_kernel(const yh_loss_desc d) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= d.nb) return;
-    const int b = d.idx[4 * i], a = d.idx[4 * i + 1], gy = d.idx[4 * i + 2], gx = d.idx[4 * i + 3];
-    const float* ps = d.p + b * d.sb + a * d.sa + gy * d.sy + gx * d.sx;
-    float* gp = d.grad + b * d.gb + a * d.ga + gy * d.gy + gx * d.gx;
-    const float sc = *d.scale;
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    Match m;
+    if (k >= d.na * d.nt || assign(d, k, m) != 0) return;
+    const float* ps = d.p + m.b * d.sb + m.a * d.sa + m.gy * d.sy + m.gx * d.sx;
+    float* gp = d.grad + m.b * d.gb + m.a * d.ga + m.gy * d.gy + m.gx * d.gx;
+    const int nb = d.count[0] > 1 ? d.count[0] : 1;
+    const float w_box = *d.scale * d.g_box / (float)nb, w_cls = *d.scale * d.g_cls / (float)((long)nb * d.nc);
     const float box[4] = {ps[0], ps[1], ps[2], ps[3]};
-    const Dual4 g = giou_of(box, d.anchor + 2 * i, d.tbox + 4 * i);
+    const Dual4 g = giou_of(box, m.an, m.tb);
 #pragma unroll
-    for (int k = 0; k < 4; ++k) atomicAdd(gp + k, -sc * d.w_box * g.d[k]);
-    if (d.nc > 1) {
-        const int tc = d.tcls[i];
-        for (int c = 0; c < d.nc; ++c) atomicAdd(gp + 5 + c, sc * d.w_cls * bce_grad(ps[5 + c], c == tc ? d.cp : d.cn, d.cls_pw));
-    }
+    for (int i = 0; i < 4; ++i) atomicAdd(gp + i, -w_box * g.d[i]);
+    if (d.nc > 1)
+        for (int c = 0; c < d.nc; ++c) atomicAdd(gp + 5 + c, w_cls * bce_grad(ps[5 + c], c == m.cls ? d.cp : d.cn, d.cls_pw));
 }
 
 static int check_loss(const yh_loss_desc* d, bool bwd) {
     if (!d || !d->p || !d->tobj || d->bs <= 0 || d->na <= 0 || d->ny <= 0 || d->nx <= 0 || d->no < 5 || d->nc != d->no - 5) return YH_EINVAL;
-    if (d->nb < 0 || (d->nb > 0 && (!d->idx || !d->tbox || !d->anchor || (d->nc > 1 && !d->tcls) || (!bwd && !d->winner)))) return YH_EINVAL;
+    if (d->nt < 0 || !d->count || (d->nt > 0 && (!d->targets || !d->anchors || (!bwd && !d->winner)))) return YH_EINVAL;
     if (bwd ? (!d->grad || !d->scale) : !d->sums) return YH_EINVAL;
     return YH_OK;
 }
@@ -176,9 +206,10 @@ extern "C" int yh_yolo_loss_fwd(const yh_loss_desc* d, void* stream) {
     int rc = check_loss(d, false);
     if (rc) return rc;
     hipStream_t s = (hipStream_t)stream;
-    if (d->nb > 0) {
-        hipLaunchKernelGGL(loss_winner_kernel, dim3((d->nb + 255) / 256), dim3(256), 0, s, *d);
-        hipLaunchKernelGGL(loss_matched_fwd_kernel, dim3((d->nb + 255) / 256), dim3(256), 0, s, *d);
+    if (d->nt > 0) {
+        const unsigned blocks = (unsigned)(((long)d->na * d->nt + 255) / 256);
+        hipLaunchKernelGGL(loss_assign_kernel, dim3(blocks), dim3(256), 0, s, *d);
+        hipLaunchKernelGGL(loss_matched_fwd_kernel, dim3(blocks), dim3(256), 0, s, *d);
     }
     hipLaunchKernelGGL(loss_obj_fwd_kernel, dim3(grid_n((long)d->bs * d->na * d->ny * d->nx)), dim3(256), 0, s, *d);
     return check_launch();
@@ -189,6 +220,6 @@ extern "C" int yh_yolo_loss_bwd(const yh_loss_desc* d, void* stream) {
     if (rc) return rc;
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(loss_dense_bwd_kernel, dim3(grid_n((long)d->bs * d->na * d->ny * d->nx * d->no)), dim3(256), 0, s, *d);
-    if (d->nb > 0) hipLaunchKernelGGL(loss_matched_bwd_kernel, dim3((d->nb + 255) / 256), dim3(256), 0, s, *d);
+    if (d->nt > 0) hipLaunchKernelGGL(loss_matched_bwd_kernel, dim3((unsigned)(((long)d->na * d->nt + 255) / 256)), dim3(256), 0, s, *d);
     return check_launch();
 }

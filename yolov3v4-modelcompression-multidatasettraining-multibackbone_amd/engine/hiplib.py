@@ -50,7 +50,7 @@ class CopyDesc(C.Structure):
 
 class AddDesc(C.Structure):
     _fields_ = [('a', _vp), ('b', _vp), ('y', _vp), ('pixels', _i64),
-                ('c', _i32), ('lda', _i32), ('ldb', _i32), ('ldy', _i32), ('dtype', _i32)]
+                ('c', _i32), ('lda', _i32), ('ldb', _i32), ('ldy', _i32), ('dtype', _i32), ('amap', _vp), ('bmap', _vp)]
 
 
 class DecodeDesc(C.Structure):
@@ -185,12 +185,12 @@ class SeBwdDesc(C.Structure):
 
 
 class LossDesc(C.Structure):
-    _fields_ = [('p', _vp), ('grad', _vp), ('tobj', _vp), ('winner', _vp), ('idx', _vp), ('tbox', _vp), ('tcls', _vp), ('anchor', _vp), ('sums', _vp),
-                ('scale', _vp),
+    _fields_ = [('p', _vp), ('grad', _vp), ('tobj', _vp), ('winner', _vp), ('targets', _vp), ('anchors', _vp), ('sums', _vp),
+                ('count', _vp), ('scale', _vp),
                 ('sb', _i64), ('sa', _i64), ('sy', _i64), ('sx', _i64), ('gb', _i64), ('ga', _i64), ('gy', _i64), ('gx', _i64),
-                ('bs', _i32), ('na', _i32), ('ny', _i32), ('nx', _i32), ('no', _i32), ('nc', _i32), ('nb', _i32),
-                ('gr', _f32), ('cp', _f32), ('cn', _f32), ('cls_pw', _f32), ('obj_pw', _f32),
-                ('w_box', _f32), ('w_obj', _f32), ('w_cls', _f32)]
+                ('bs', _i32), ('na', _i32), ('ny', _i32), ('nx', _i32), ('no', _i32), ('nc', _i32), ('nt', _i32),
+                ('iou_t', _f32), ('gr', _f32), ('cp', _f32), ('cn', _f32), ('cls_pw', _f32), ('obj_pw', _f32),
+                ('g_box', _f32), ('g_obj', _f32), ('g_cls', _f32)]
 
 
 class CastDesc(C.Structure):

@@ -1,9 +1,15 @@
 """compute_loss on the HIP kernels (csrc/loss.hip): the autograd node behind ``utils.utils.compute_loss`` for CUDA tensors.
 
-The reference evaluates the loss with ~200 small torch kernels per step and autograd then builds several full-size
-zero-filled temporaries per head (index_put / select backward).  Here the forward is two launches per head (matched
-targets, objectness over every cell) and the backward two more that write the complete gradient of each raw head tensor,
-scaled by autograd's incoming scalar on the device (no host sync).  Target assignment stays ``build_targets``.
+The reference evaluates the loss with ~200 small torch kernels per step, autograd then builds several full-size
+zero-filled temporaries per head (index_put / select backward), and ``build_targets`` reads data-dependent sizes back to
+the host three times per head.  Here the forward is three launches per head (target assignment, matched candidates,
+objectness over every cell) and the backward two more that write the complete gradient of each raw head tensor, scaled
+by autograd's incoming scalar on the device.  Nothing in the step waits for the GPU, so the host keeps enqueuing the
+backward while the forward still runs.
+
+The reference's label check (``build_targets`` asserts every class < nc, utils.py:757-760) needs the labels on the host;
+here the kernels record a label error mask on the device, the mask is copied to pinned host memory asynchronously and the
+same AssertionError is raised by the NEXT ``compute_loss`` call (or ``flush_label_check()``), after the copy has landed.
 """
 import ctypes as C
 
@@ -28,40 +34,65 @@ def usable(p, model):
     return all(t.dtype == torch.float32 and t.dim() == 5 and t.stride(4) == 1 for t in p)
 
 
+_pending = []   # (event or None, host int32 tensor (heads, 2), nc) of launched forwards whose label mask is unread
+
+
+def flush_label_check():
+    """Raise for label errors recorded by earlier compute_loss launches (waits for their kernels)."""
+    while _pending:
+        event, host, nc = _pending.pop(0)
+        if event is not None:
+            event.synchronize()
+        mask = int(host[:, 1].max()) if host.numel() else 0
+        if mask & 1:
+            raise AssertionError('Model accepts %g classes labeled from 0-%g, however you labelled a class outside that '
+                                 'range. See https://docs.ultralytics.com/yolov5/tutorials/train_custom_data' % (nc, nc - 1))
+        if mask & 2:
+            raise IndexError('a label refers to an image index outside the batch or a box centre outside [0, 1)')
+
+
 class _YoloLoss(torch.autograd.Function):
     @staticmethod
     def forward(ctx, meta, *ps):
         lib = _lib()
         dev = ps[0].device
-        heads = []
-        sums = torch.zeros((len(ps), 3), device=dev, dtype=torch.float32)
-        lbox = torch.zeros((), device=dev)
-        lobj = torch.zeros((), device=dev)
-        lcls = torch.zeros((), device=dev)
+        nh = len(ps)
+        targets = meta['targets']
+        nt = int(targets.shape[0])
+        sums = torch.zeros((nh, 3), device=dev, dtype=torch.float32)
+        counts = torch.zeros((nh, 2), device=dev, dtype=torch.int32)
+        heads, cells = [], []
         for i, p in enumerate(ps):
             bs, na, ny, nx, no = p.shape
-            idx, tbox, tcls, anchor = meta['matched'][i]
-            nb = int(idx.shape[0])
             tobj = torch.zeros((bs, na, ny, nx), device=dev, dtype=torch.float32)
-            winner = torch.full((bs, na, ny, nx), -1, device=dev, dtype=torch.int32) if nb else None
-            cells = bs * na * ny * nx
-            d = LossDesc(p=hiplib.ptr(p), grad=None, tobj=hiplib.ptr(tobj), winner=hiplib.ptr(winner), idx=hiplib.ptr(idx) if nb else None,
-                         tbox=hiplib.ptr(tbox) if nb else None, tcls=hiplib.ptr(tcls) if nb else None,
-                         anchor=hiplib.ptr(anchor) if nb else None, sums=hiplib.ptr(sums, 3 * i), scale=None,
+            winner = torch.full((bs, na, ny, nx), -1, device=dev, dtype=torch.int32) if nt else None
+            anchors = meta['anchors'][i]
+            d = LossDesc(p=hiplib.ptr(p), grad=None, tobj=hiplib.ptr(tobj), winner=hiplib.ptr(winner),
+                         targets=hiplib.ptr(targets) if nt else None, anchors=hiplib.ptr(anchors), sums=hiplib.ptr(sums, 3 * i),
+                         count=hiplib.ptr(counts, 2 * i), scale=None,
                          sb=p.stride(0), sa=p.stride(1), sy=p.stride(2), sx=p.stride(3), gb=0, ga=0, gy=0, gx=0,
-                         bs=bs, na=na, ny=ny, nx=nx, no=no, nc=no - 5, nb=nb, gr=meta['gr'], cp=meta['cp'], cn=meta['cn'],
-                         cls_pw=meta['cls_pw'], obj_pw=meta['obj_pw'],
-                         w_box=meta['giou'] / max(nb, 1), w_obj=meta['obj'] / cells,
-                         w_cls=meta['cls'] / max(nb * (no - 5), 1))
+                         bs=bs, na=na, ny=ny, nx=nx, no=no, nc=no - 5, nt=nt, iou_t=meta['iou_t'], gr=meta['gr'],
+                         cp=meta['cp'], cn=meta['cn'], cls_pw=meta['cls_pw'], obj_pw=meta['obj_pw'],
+                         g_box=meta['giou'], g_obj=meta['obj'], g_cls=meta['cls'])
             hiplib.check(lib.yh_yolo_loss_fwd(C.byref(d), hiplib.stream_ptr()), 'yh_yolo_loss_fwd')
             heads.append((d, tobj, p))
+            cells.append(float(bs * na * ny * nx))
             del winner   # only the forward needs it (stream-ordered free)
-            if nb:
-                lbox = lbox + sums[i, 0] * d.w_box
-                if no - 5 > 1:
-                    lcls = lcls + sums[i, 2] * d.w_cls
-            lobj = lobj + sums[i, 1] * d.w_obj
-        ctx.heads, ctx.meta = heads, meta
+        nc = ps[0].shape[4] - 5
+        nb = counts[:, 0].clamp(min=1).to(torch.float32)
+        lbox = (sums[:, 0] / nb).sum() * meta['giou']
+        lobj = sum(sums[i, 1] / cells[i] for i in range(nh)) * meta['obj']
+        lcls = (sums[:, 2] / (nb * nc)).sum() * meta['cls'] if nc > 1 else torch.zeros((), device=dev)
+        if dev.type == 'cuda':
+            host = torch.empty((nh, 2), dtype=torch.int32, pin_memory=True)
+            host.copy_(counts, non_blocking=True)
+            event = torch.cuda.Event()
+            event.record()
+            _pending.append((event, host, nc))
+        else:
+            _pending.append((None, counts, nc))
+            flush_label_check()
+        ctx.heads, ctx.keep_fwd = heads, (targets, counts, meta['anchors'])
         loss = lbox + lobj + lcls
         ctx.mark_non_differentiable(lbox, lobj, lcls)
         return loss, lbox, lobj, lcls
@@ -82,18 +113,15 @@ class _YoloLoss(torch.autograd.Function):
         return (None,) + tuple(grads)
 
 
-def compute_loss(p, targets, model, build_targets, smooth_bce):
+def compute_loss(p, targets, model, yolo_modules, smooth_bce):
     """Same contract as utils.utils.compute_loss: ``(loss[1], detached [lbox, lobj, lcls, loss])``."""
-    tcls, tbox, indices, anchor_vec = build_targets(p, targets, model)
+    flush_label_check()
     h = model.hyp
     cp, cn = smooth_bce(eps=0.0)
-    matched = []
-    for i in range(len(p)):
-        b, a, gj, gi = indices[i]
-        idx = torch.stack((b, a, gj, gi), 1).to(torch.int32).contiguous()
-        matched.append((idx, tbox[i].float().contiguous(), tcls[i].to(torch.int32).contiguous(),
-                        anchor_vec[i].float().contiguous()))
-    meta = dict(matched=matched, gr=float(model.gr), cp=float(cp), cn=float(cn), cls_pw=float(h['cls_pw']),
+    dev = p[0].device
+    anchors = [layer.anchor_vec.to(device=dev, dtype=torch.float32).contiguous() for layer in yolo_modules(model)]
+    meta = dict(targets=targets.to(device=dev, dtype=torch.float32).contiguous(), anchors=anchors, iou_t=float(h['iou_t']),
+                gr=float(model.gr), cp=float(cp), cn=float(cn), cls_pw=float(h['cls_pw']),
                 obj_pw=float(h['obj_pw']), giou=float(h['giou']), obj=float(h['obj']), cls=float(h['cls']))
     loss, lbox, lobj, lcls = _YoloLoss.apply(meta, *p)
     return loss.reshape(1), torch.stack((lbox, lobj, lcls, loss.detach())).detach()

@@ -67,7 +67,13 @@ class Value:
         return m
 
     def is_dense(self):
-        return len(self.segs) == 1 and self.segs[0] == (0, self.C)
+        """Logical channel c sits at physical channel c (a concat of unpadded pieces counts)."""
+        at = 0
+        for start, length in self.segs:
+            if start != at:
+                return False
+            at += length
+        return at == self.C
 
 
 class Head:
@@ -297,10 +303,15 @@ class DarknetEngine:
                     raise NotImplementedError('HIP engine: weighted shortcut (block %d)' % i)
                 for l in module.layers:
                     other = ref(i, l)
-                    c = min(cur.C, other.C)
-                    if c != cur.C or not cur.is_dense() or not other.is_dense():
-                        raise NotImplementedError('HIP engine: channel-mismatched shortcut (block %d)' % i)
+                    if (other.H, other.W) != (cur.H, cur.W) or cur.fp32 or other.fp32:
+                        raise NotImplementedError('HIP engine: shortcut over mismatched maps (block %d)' % i)
                     v = Value('add', cur.C, cur.H, cur.W, block=i, a=cur, b=other)
+                    if other.C != cur.C or not cur.is_dense() or not other.is_dense():
+                        # operands of different width sum over the leading min(Ca, Cb) channels (layers.py:65-70);
+                        # concats of padded pieces are gathered through their channel maps
+                        ma, mb = cur.channel_map(), other.channel_map()
+                        v.amap = ma + [-1] * (v.c_phys - len(ma))
+                        v.bmap = [mb[k] if k < len(mb) else -1 for k in range(cur.C)] + [-1] * (v.c_phys - cur.C)
                     values.append(v)
                     cur = v
             elif kind == 'yolo':
@@ -594,8 +605,14 @@ class DarknetEngine:
                 add(CopyDesc(x=P(s.storage, s.c_off), y=y, n=N, h=s.H, w_in=s.W, c=s.c_phys, ups=v.ups, ldx=s.ld,
                              ldy=v.ld, dtype=self.code), 'ups%d' % v.block)
             elif v.kind == 'add':
+                maps = [None, None]
+                if getattr(v, 'amap', None) is not None:
+                    maps = [torch.tensor(m, dtype=torch.int32).to(self.device) for m in (v.amap, v.bmap)]
+                    plan['storages'].extend(maps)
                 add(AddDesc(a=P(v.a.storage, v.a.c_off), b=P(v.b.storage, v.b.c_off), y=y, pixels=N * v.H * v.W,
-                            c=v.c_phys, lda=v.a.ld, ldb=v.b.ld, ldy=v.ld, dtype=self.code), 'add%d' % v.block)
+                            c=v.c_phys, lda=v.a.ld, ldb=v.b.ld, ldy=v.ld, dtype=self.code,
+                            amap=P(maps[0]) if maps[0] is not None else None,
+                            bmap=P(maps[1]) if maps[1] is not None else None), 'add%d' % v.block)
             elif v.kind == 'concat':
                 for s, off, inplace in v.parts:
                     if inplace:

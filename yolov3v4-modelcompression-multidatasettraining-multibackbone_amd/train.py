@@ -102,10 +102,13 @@ def train(opt, hyp):
             pg1.append(v)
         else:
             pg0.append(v)
+    # same update rules as the reference (train.py:119-122); on a GPU torch's single-launch multi-tensor kernels do them
+    # (with GradScaler's unscale folded in): the default per-op foreach form costs ~5 ms of a 72 ms YOLOv3-608 step
+    fused = {'fused': True} if device.type == 'cuda' else {}
     if opt.adam:
-        optimizer = optim.Adam(pg0, lr=hyp['lr0'])
+        optimizer = optim.Adam(pg0, lr=hyp['lr0'], **fused)
     else:
-        optimizer = optim.SGD(pg0, lr=hyp['lr0'], momentum=hyp['momentum'], nesterov=True)
+        optimizer = optim.SGD(pg0, lr=hyp['lr0'], momentum=hyp['momentum'], nesterov=True, **fused)
     optimizer.add_param_group({'params': pg1, 'weight_decay': hyp['weight_decay']})
     optimizer.add_param_group({'params': pg2})
     del pg0, pg1, pg2

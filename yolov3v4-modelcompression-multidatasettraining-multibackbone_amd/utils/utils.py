@@ -244,7 +244,7 @@ def compute_loss(p, targets, model, fused=None):
     if fused is not False and (p[0].is_cuda or _fused_loss_override()):
         from engine import loss as hip_loss
         if hip_loss.usable(p, model):
-            return hip_loss.compute_loss(p, targets, model, build_targets, smooth_BCE)
+            return hip_loss.compute_loss(p, targets, model, _yolo_modules, smooth_BCE)
     dev = p[0].device
     z = lambda: torch.zeros(1, device=dev)
     lcls, lbox, lobj = z(), z(), z()
