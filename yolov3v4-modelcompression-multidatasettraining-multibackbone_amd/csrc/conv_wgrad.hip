@@ -40,6 +40,7 @@ struct WgradArgs {
     yh_wgrad_desc d;
     int tiles_m, tiles_n, ksteps, ksteps_per_split, ncols;  // ncols = kh*kw*cin: the flattened (tap, ci) axis
     int two_stage, dma, bn, cin_w;   // dma: the fp16 LDS-DMA kernel; bn: its column-tile width
+    int xcd_splits;                  // > 0: 1-D launch, pixel split s runs on XCD s % 8 (all its tiles share that L2)
     int rw, rh, qh;                  // bk = qw * wo + rw, qw = qh * ho + rh: per-step pixel advance without divisions
     long pixels;
 };
@@ -294,9 +295,18 @@ __global__ __launch_bounds__(128 * WNW) void conv_wgrad_dma_kernel(const WgradAr
     const yh_wgrad_desc& d = a.d;
     __shared__ __attribute__((aligned(16))) unsigned char smem[STAGES * STAGE_BYTES];
 
-    const int tm = blockIdx.x % a.tiles_m, tn = blockIdx.x / a.tiles_m;
+    // Workgroups go to the 8 XCDs round-robin by linear id.  All tiles of one pixel split read the same dz / x rows, so a
+    // split is kept on one XCD (its private L2 then fetches those rows once instead of each of the 8 L2s fetching them).
+    int tile_id = blockIdx.x, split_id = blockIdx.y;
+    if (a.xcd_splits > 0) {
+        const int tiles = a.tiles_m * a.tiles_n, idx = blockIdx.x >> 3;
+        split_id = (idx / tiles) * 8 + (blockIdx.x & 7);
+        tile_id = idx % tiles;
+        if (split_id >= a.xcd_splits) return;
+    }
+    const int tm = tile_id % a.tiles_m, tn = tile_id / a.tiles_m;
     const int co0 = tm * BM, n0 = tn * BN;
-    const int ks0 = blockIdx.y * a.ksteps_per_split;
+    const int ks0 = split_id * a.ksteps_per_split;
     const int ks1 = min(ks0 + a.ksteps_per_split, a.ksteps);
     if (ks0 >= ks1) return;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -473,7 +483,7 @@ __global__ __launch_bounds__(128 * WNW) void conv_wgrad_dma_kernel(const WgradAr
     }
 
     if (a.two_stage) {
-        f32x4* part = reinterpret_cast<f32x4*>(d.ws) + ((long)blockIdx.y * gridDim.x + blockIdx.x) * (TM * 4 * NT);
+        f32x4* part = reinterpret_cast<f32x4*>(d.ws) + ((long)split_id * (a.tiles_m * a.tiles_n) + tile_id) * (TM * 4 * NT);
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -765,6 +775,11 @@ extern "C" int yh_conv_pack_weights_dgrad(int dtype, const float* w, int cout, i
     return check_launch();
 }
 
+static bool wgrad_xcd_mapping() {
+    const char* e = getenv("YH_WGRAD_XCD");   // A/B knob: 0 = plain (tile, split) grid
+    return !e || atoi(e) != 0;
+}
+
 static void wgrad_geometry(const yh_wgrad_desc* d, WgradArgs* pa, int* psplits) {
     WgradArgs& a = *pa;
     const int bk = d->dtype == YH_F16 ? 32 : 16;
@@ -785,13 +800,21 @@ static void wgrad_geometry(const yh_wgrad_desc* d, WgradArgs* pa, int* psplits) 
     const int tiles = a.tiles_m * a.tiles_n;
     int splits = d->splits;
     if (splits <= 0) {
-        int target = 1024;                                 // workgroups in flight: every split costs a partial tile of traffic
+        // one resident wave of workgroups (3 per CU at 48 KB of LDS, 4 for the 64-row tiles; 256 CUs), rounded DOWN: a
+        // partly filled second wave costs 10-20 % (measured: 1024 -> 768 workgroups, 76x76 128 -> 256: 0.324 -> 0.287 ms),
+        // and every extra split costs a partial tile of traffic
+        int target = bm == 64 ? -1024 : -768;
         { const char* e = getenv("YH_WGRAD_TARGET"); if (e) target = atoi(e); }
         splits = target > 0 ? (target + tiles - 1) / tiles : (-target) / tiles;   // negative: round down (one wave of workgroups)
         if (splits < 1) splits = 1;
         const int max_splits = (a.ksteps + 7) / 8;         // at least 8 K steps per workgroup
         if (splits > max_splits) splits = max_splits;
         if (splits < 1) splits = 1;
+        // splits are dealt to the 8 XCDs round-robin (see the kernel): a multiple of 8 keeps them evenly loaded
+        if (a.dma && wgrad_xcd_mapping() && splits >= 8) {
+            const int up = (splits + 7) / 8 * 8;
+            splits = target > 0 && up <= max_splits && up - splits <= 2 ? up : splits / 8 * 8;   // never past the resident wave
+        }
     }
     a.ksteps_per_split = ((a.ksteps + splits - 1) / splits + 1) & ~1;   // even: the kernel runs two steps per trip
     *psplits = (a.ksteps + a.ksteps_per_split - 1) / a.ksteps_per_split;
@@ -836,8 +859,13 @@ extern "C" int yh_conv2d_wgrad(const yh_wgrad_desc* d, void* stream) {
     const int tiles = a.tiles_m * a.tiles_n;
     const bool narrow = d->cout <= 64;
     a.two_stage = d->ws && d->ws_floats >= (int64_t)splits * tiles * (narrow ? 64 : 128) * a.bn;
-    const dim3 grid(tiles, splits);
+    dim3 grid(tiles, splits);
     hipStream_t st = (hipStream_t)stream;
+    a.xcd_splits = 0;
+    if (a.dma && splits >= 8 && wgrad_xcd_mapping()) {
+        a.xcd_splits = splits;
+        grid = dim3((unsigned)(tiles * ((splits + 7) / 8 * 8)), 1);
+    }
     if (a.dma) {
         if (narrow) hipLaunchKernelGGL((conv_wgrad_dma_kernel<2, 2>), grid, dim3(256), 0, st, a);
         else if (a.bn == 256) hipLaunchKernelGGL((conv_wgrad_dma_kernel<4, 4>), grid, dim3(512), 0, st, a);
