@@ -40,6 +40,8 @@ for p in (PKG, REPO):
     if p not in sys.path:
         sys.path.insert(0, p)
 
+os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')   # the host driver only supports dmabuf IPC (RCCL needs it)
+
 import torch  # noqa: E402
 
 PEAK_TFLOPS = {'fp16': 2500.0, 'fp32': 157.3, 'int8': 5000.0}  # dense MFMA peaks (int8: TOP/s), MI355X_MICROARCH.md

@@ -80,6 +80,7 @@ def train(opt, hyp):
             torch.cuda.set_device(rank)
             device = torch.device('cuda', rank)
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')   # dmabuf IPC only on this driver (RCCL)
         dist.init_process_group(backend='nccl' if device.type != 'cpu' else 'gloo', init_method='env://')
         assert batch_size % world == 0, '--batch-size must be multiple of the process count'
         batch_size //= world
