@@ -143,6 +143,30 @@ def test_wgrad_matches_autograd(libs, code, case, use_ws):
     assert (got.cpu() - ref).abs().max().item() <= (2e-5 if code == F32 else 1e-4) * scale
 
 
+@pytest.mark.parametrize('use_ws', [True, False], ids=['workspace', 'atomics'])
+@pytest.mark.parametrize('bm', ['128', '256'])
+@pytest.mark.parametrize('case', [(2, 21, 19, 40, 256, 3, 1), (3, 16, 16, 64, 512, 1, 1), (1, 33, 31, 24, 256, 3, 2)],
+                         ids=lambda c: 'n%d_%dx%d_c%d-%d_k%ds%d' % c)
+def test_wgrad_row_tiles_agree(libs, monkeypatch, case, bm, use_ws):
+    """Both row tiles of the LDS-DMA kernel (128 and 256 output channels per workgroup; the library picks by layer size,
+    YH_WGRAD_BM forces one) against autograd, exact on small-integer operands, with ragged pixel counts and several splits."""
+    if DRY:
+        pytest.skip('kernel-only property')
+    lib, _ = libs
+    monkeypatch.setenv('YH_WGRAD_BM', bm)
+    N, H, W, cin, cout, k, s = case
+    g = torch.Generator().manual_seed(sum(case))
+    pad = (k - 1) // 2
+    Ho, Wo = (H + 2 * pad - k) // s + 1, (W + 2 * pad - k) // s + 1
+    x = torch.randint(-3, 4, (N, H, W, cin), generator=g).half()
+    dz = torch.randint(-2, 3, (N, Ho, Wo, cout), generator=g).half()
+    got = oh.wgrad(lib, F16, x.to(GPU), dz.to(GPU), cin, cout, k, s, pad, use_ws=use_ws)
+    _sync()
+    ref = torch.nn.grad.conv2d_weight(x.float().permute(0, 3, 1, 2), (cout, cin, k, k), dz.float().permute(0, 3, 1, 2),
+                                      stride=s, padding=pad)
+    assert torch.equal(got.cpu(), ref)
+
+
 def test_wgrad_f16_exact_on_small_integers(libs):
     """Integer operands: every product and partial sum is exact, so MFMA + atomics must reproduce autograd bit for bit."""
     lib, _ = libs

@@ -39,8 +39,8 @@ constexpr int WG_PITCH_DW = 20;  // LDS row pitch in dwords (80 B)
 struct WgradArgs {
     yh_wgrad_desc d;
     int tiles_m, tiles_n, ksteps, ksteps_per_split, ncols;  // ncols = kh*kw*cin: the flattened (tap, ci) axis
-    int two_stage, dma, bn, cin_w;   // dma: the fp16 LDS-DMA kernel; bn: its column-tile width
-    int xcd_splits;                  // > 0: 1-D launch, pixel split s runs on XCD s % 8 (all its tiles share that L2)
+    int two_stage, dma, bn, bm, cin_w;   // dma: the fp16 LDS-DMA kernel; bn / bm: its column / row tile
+    int xcd_splits;                  // > 0: 1-D launch, consecutive pixel splits share an XCD (and its L2)
     int rw, rh, qh;                  // bk = qw * wo + rw, qw = qh * ho + rh: per-step pixel advance without divisions
     long pixels;
 };
@@ -295,14 +295,16 @@ __global__ __launch_bounds__(128 * WNW) void conv_wgrad_dma_kernel(const WgradAr
     const yh_wgrad_desc& d = a.d;
     __shared__ __attribute__((aligned(16))) unsigned char smem[STAGES * STAGE_BYTES];
 
-    // Workgroups go to the 8 XCDs round-robin by linear id.  All tiles of one pixel split read the same dz / x rows, so a
-    // split is kept on one XCD (its private L2 then fetches those rows once instead of each of the 8 L2s fetching them).
+    // Workgroups go to the 8 XCDs round-robin by linear id.  All tiles of one pixel split read the same dz / x rows, so
+    // each XCD is given a contiguous run of the split-major order (its private L2 then fetches those rows once instead
+    // of all 8 L2s fetching them): the same chunked mapping as the forward kernel.
     int tile_id = blockIdx.x, split_id = blockIdx.y;
     if (a.xcd_splits > 0) {
-        const int tiles = a.tiles_m * a.tiles_n, idx = blockIdx.x >> 3;
-        split_id = (idx / tiles) * 8 + (blockIdx.x & 7);
-        tile_id = idx % tiles;
-        if (split_id >= a.xcd_splits) return;
+        const int tiles = a.tiles_m * a.tiles_n, nb = gridDim.x, bid = blockIdx.x;
+        const int q = nb >> 3, rr = nb & 7, xcd = bid & 7;
+        const int logical = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (bid >> 3);
+        split_id = logical / tiles;
+        tile_id = logical - split_id * tiles;
     }
     const int tm = tile_id % a.tiles_m, tn = tile_id / a.tiles_m;
     const int co0 = tm * BM, n0 = tn * BN;
@@ -446,7 +448,15 @@ __global__ __launch_bounds__(128 * WNW) void conv_wgrad_dma_kernel(const WgradAr
         }
         // the reads are asynchronous and invisible to the compiler's waitcnt insertion: wait here, and thread every
         // fragment through the asm so that no consumer can be scheduled above it
-        if constexpr (TM == 4) {
+        if constexpr (TM == 8) {
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+v"(ra[0][0]), "+v"(ra[0][1]), "+v"(ra[1][0]), "+v"(ra[1][1]), "+v"(ra[2][0]), "+v"(ra[2][1]),
+                           "+v"(ra[3][0]), "+v"(ra[3][1]), "+v"(ra[4][0]), "+v"(ra[4][1]), "+v"(ra[5][0]), "+v"(ra[5][1]),
+                           "+v"(ra[6][0]), "+v"(ra[6][1]), "+v"(ra[7][0]), "+v"(ra[7][1]), "+v"(rb[0][0]), "+v"(rb[0][1]),
+                           "+v"(rb[1][0]), "+v"(rb[1][1]), "+v"(rb[2][0]), "+v"(rb[2][1]), "+v"(rb[3][0]), "+v"(rb[3][1])
+                         :
+                         : "memory");
+        } else if constexpr (TM == 4) {
             asm volatile("s_waitcnt lgkmcnt(0)"
                          : "+v"(ra[0][0]), "+v"(ra[0][1]), "+v"(ra[1][0]), "+v"(ra[1][1]), "+v"(ra[2][0]), "+v"(ra[2][1]),
                            "+v"(ra[3][0]), "+v"(ra[3][1]), "+v"(rb[0][0]), "+v"(rb[0][1]), "+v"(rb[1][0]), "+v"(rb[1][1]),
@@ -785,12 +795,24 @@ static void wgrad_geometry(const yh_wgrad_desc* d, WgradArgs* pa, int* psplits) 
     const int bk = d->dtype == YH_F16 ? 32 : 16;
     a.d = *d;
     a.pixels = (long)d->n * d->ho * d->wo;
-    const int bm = d->cout <= 64 ? 64 : WG_TILE;        // 64-row tiles for the early, wide-resolution layers
+    int bm = d->cout <= 64 ? 64 : WG_TILE;        // 64-row tiles for the early, wide-resolution layers
     a.ncols = d->kh * d->kw * d->cin;
     a.dma = d->dtype == YH_F16 && d->splits != -1;           // the LDS-DMA kernel
     // 256-column tiles (8 waves) when they stay >= 85 % full; the register-staged kernels are 128 wide
     a.bn = WG_TILE;   // 256-column (8-wave) tiles measured slower (VGPR-limited to one workgroup per CU); YH_WGRAD_BN=256 selects them
     { const char* e = getenv("YH_WGRAD_BN"); if (e && a.dma && bm == 128) a.bn = atoi(e); }
+    // 256-row tiles on 4 waves (128 x 64 per wave: 25 % fewer LDS bytes and 33 % fewer L2 bytes per MFMA; 72 KB of LDS, two
+    // workgroups per CU) for the K-heavy layers that fill them: +20 % on the 3x3 layers at batch 64 (76x76 128 -> 256:
+    // 633 -> 765 TFLOP/s, 38x38 256 -> 512: 775 -> 917), neutral on 1x1 layers and when a workgroup gets < 64 K steps.
+    if (a.dma && a.bn == 128 && bm == 128 && d->cout % 256 == 0) {
+        const char* e = getenv("YH_WGRAD_BM");              // A/B knob: 128 / 256 force the tile
+        const int force = e ? atoi(e) : 0;
+        const long ksteps = ((long)d->n * d->ho * d->wo + bk - 1) / bk;
+        const int tiles256 = (d->cout / 256) * ((a.ncols + a.bn - 1) / a.bn);
+        const int splits256 = tiles256 >= 512 ? 1 : 512 / tiles256;
+        if (force == 256 || (force != 128 && d->kh * d->kw > 1 && ksteps / splits256 >= 64)) bm = 256;
+    }
+    a.bm = bm;
     a.tiles_m = (d->cout + bm - 1) / bm;
     a.tiles_n = (a.ncols + a.bn - 1) / a.bn;
     a.ksteps = (int)((a.pixels + bk - 1) / bk);
@@ -803,18 +825,13 @@ static void wgrad_geometry(const yh_wgrad_desc* d, WgradArgs* pa, int* psplits) 
         // one resident wave of workgroups (3 per CU at 48 KB of LDS, 4 for the 64-row tiles; 256 CUs), rounded DOWN: a
         // partly filled second wave costs 10-20 % (measured: 1024 -> 768 workgroups, 76x76 128 -> 256: 0.324 -> 0.287 ms),
         // and every extra split costs a partial tile of traffic
-        int target = bm == 64 ? -1024 : -768;
+        int target = bm == 64 ? -1024 : (bm == 256 ? -512 : -768);
         { const char* e = getenv("YH_WGRAD_TARGET"); if (e) target = atoi(e); }
         splits = target > 0 ? (target + tiles - 1) / tiles : (-target) / tiles;   // negative: round down (one wave of workgroups)
         if (splits < 1) splits = 1;
         const int max_splits = (a.ksteps + 7) / 8;         // at least 8 K steps per workgroup
         if (splits > max_splits) splits = max_splits;
         if (splits < 1) splits = 1;
-        // splits are dealt to the 8 XCDs round-robin (see the kernel): a multiple of 8 keeps them evenly loaded
-        if (a.dma && wgrad_xcd_mapping() && splits >= 8) {
-            const int up = (splits + 7) / 8 * 8;
-            splits = target > 0 && up <= max_splits && up - splits <= 2 ? up : splits / 8 * 8;   // never past the resident wave
-        }
     }
     a.ksteps_per_split = ((a.ksteps + splits - 1) / splits + 1) & ~1;   // even: the kernel runs two steps per trip
     *psplits = (a.ksteps + a.ksteps_per_split - 1) / a.ksteps_per_split;
@@ -858,16 +875,17 @@ extern "C" int yh_conv2d_wgrad(const yh_wgrad_desc* d, void* stream) {
     wgrad_geometry(d, &a, &splits);
     const int tiles = a.tiles_m * a.tiles_n;
     const bool narrow = d->cout <= 64;
-    a.two_stage = d->ws && d->ws_floats >= (int64_t)splits * tiles * (narrow ? 64 : 128) * a.bn;
+    a.two_stage = d->ws && d->ws_floats >= (int64_t)splits * tiles * a.bm * a.bn;
     dim3 grid(tiles, splits);
     hipStream_t st = (hipStream_t)stream;
     a.xcd_splits = 0;
-    if (a.dma && splits >= 8 && wgrad_xcd_mapping()) {
+    if (a.dma && splits >= 2 && wgrad_xcd_mapping()) {
         a.xcd_splits = splits;
-        grid = dim3((unsigned)(tiles * ((splits + 7) / 8 * 8)), 1);
+        grid = dim3((unsigned)(tiles * splits), 1);
     }
     if (a.dma) {
         if (narrow) hipLaunchKernelGGL((conv_wgrad_dma_kernel<2, 2>), grid, dim3(256), 0, st, a);
+        else if (a.bm == 256) hipLaunchKernelGGL((conv_wgrad_dma_kernel<8, 2>), grid, dim3(256), 0, st, a);
         else if (a.bn == 256) hipLaunchKernelGGL((conv_wgrad_dma_kernel<4, 4>), grid, dim3(512), 0, st, a);
         else hipLaunchKernelGGL((conv_wgrad_dma_kernel<4, 2>), grid, dim3(256), 0, st, a);
     } else if (d->dtype == YH_F16) {   // splits == -1: the register-staged kernel (kept as the A/B baseline)
@@ -883,6 +901,7 @@ extern "C" int yh_conv2d_wgrad(const yh_wgrad_desc* d, void* stream) {
         const int per_group = (splits + groups - 1) / groups;
         groups = (splits + per_group - 1) / per_group;
         if (narrow) hipLaunchKernelGGL((wgrad_reduce_kernel<2, 2>), dim3(tiles * 8, groups), dim3(256), 0, st, a, splits, per_group);
+        else if (a.bm == 256) hipLaunchKernelGGL((wgrad_reduce_kernel<8, 2>), dim3(tiles * 32, groups), dim3(256), 0, st, a, splits, per_group);
         else if (a.bn == 256) hipLaunchKernelGGL((wgrad_reduce_kernel<4, 4>), dim3(tiles * 16, groups), dim3(512), 0, st, a, splits, per_group);
         else hipLaunchKernelGGL((wgrad_reduce_kernel<4, 2>), dim3(tiles * 16, groups), dim3(256), 0, st, a, splits, per_group);
     }
@@ -894,7 +913,7 @@ extern "C" int64_t yh_conv2d_wgrad_workspace(const yh_wgrad_desc* d) {
     WgradArgs a;
     int splits;
     wgrad_geometry(d, &a, &splits);
-    return (int64_t)splits * a.tiles_m * a.tiles_n * (d->cout <= 64 ? 64 : 128) * a.bn;
+    return (int64_t)splits * a.tiles_m * a.tiles_n * a.bm * a.bn;
 }
 
 extern "C" int yh_stem_wgrad(const yh_wgrad_desc* d, void* stream) {
