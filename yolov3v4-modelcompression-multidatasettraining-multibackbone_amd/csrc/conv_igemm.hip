@@ -1013,6 +1013,8 @@ template <typename T, typename OutT> static int dispatch_tile(const ConvArgs& a,
         case 25: return launch_glds<T, OutT, 128, 64, 2, 2, 3>(a, s);
         case 26: return launch_glds<T, OutT, 256, 128, 4, 2, 3>(a, s);
         case 27: return launch_glds<T, OutT, 128, 256, 2, 4, 3>(a, s);
+        // (the same tiles on 4 waves, 128 x 64 per wave, measured 10-20 % slower here - 8 waves per CU do not hide the
+        // per-step barrier + LDS latency without intra-wave pipelining - although that shape wins in the wgrad kernel)
         case 51: return launch_glds<T, OutT, 256, 128, 4, 2, 3, 1>(a, s);  // ablation: no loads (results are garbage)
         case 52: return launch_glds<T, OutT, 256, 128, 4, 2, 3, 2>(a, s);  // ablation: no MFMAs (results are garbage)
         case 41: return launch_halo<T, OutT, 128>(a, s);   // 3x3 s1 halo kernel, 128 channels x 256 virtual pixels
