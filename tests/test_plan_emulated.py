@@ -161,6 +161,22 @@ def test_ghost_idioms_are_lowered(prec):
     assert len(mapped) == 3
 
 
+def test_feature_out_on_request(cfg_dir):
+    """eval returns (inf_out, raw_p, feature_out); feature_out holds every conv block that does not feed a yolo layer
+    (reference models.py:540-543).  The engine only copies them out when asked (Darknet.hip_return_features)."""
+    model = build_mirror(cfg_dir, 'yolov3tiny/yolov3-tiny-hand.cfg', 64)
+    x = synth.image_batch(2, 64, seed=4)
+    with torch.no_grad():
+        _, _, want = model(x)
+    eng = DarknetEngine(model, precision='fp32', lib=fakelib.FakeLib())
+    assert eng(x)[2] == []
+    eng.return_features = True
+    got = eng(x)[2]
+    assert len(got) == len(want) > 0
+    for a, b in zip(got, want):
+        assert a.shape == b.shape and (a - b).abs().max().item() <= 2e-4 * max(1.0, b.abs().max().item())
+
+
 def test_weight_edits_are_picked_up():
     """In-place parameter updates (optimizer step, prune script) must reach the packed weights."""
     import models
@@ -205,5 +221,5 @@ def test_plan_cache_is_bounded(cfg_dir):
     for hw in ((64, 64), (64, 96), (96, 64), (64, 64)):
         outs.setdefault(hw, []).append(eng(torch.rand(1, 3, *hw, generator=torch.Generator().manual_seed(0)))[0])
         assert len(eng._plans) <= 2
-    assert list(eng._plans)[-1] == (1, 3, 64, 64)
+    assert list(eng._plans)[-1][:4] == (1, 3, 64, 64)
     assert torch.equal(outs[(64, 64)][0], outs[(64, 64)][1])   # the rebuilt plan reproduces the evicted one

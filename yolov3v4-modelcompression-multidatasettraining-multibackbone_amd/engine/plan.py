@@ -211,11 +211,12 @@ class DarknetEngine:
                 if self.q:
                     v.s_w, v.scale = s_w, s_a
                 nxt = defs[i + 1]['type'] if i + 1 < L else None
-                if nxt == 'shortcut' and not routs[i] and self._fusable_shortcut(i + 1, v, outs):
+                keep = self.return_features   # feature_out needs every conv block's own output: no epilogue fusion
+                if nxt == 'shortcut' and not routs[i] and not keep and self._fusable_shortcut(i + 1, v, outs):
                     v.res = ref(i + 1, mods[i + 1].layers[0])
                     skip.add(i + 1)
                     hidden = True
-                elif nxt == 'upsample' and not routs[i] and int(defs[i + 1]['stride']) == 2:
+                elif nxt == 'upsample' and not routs[i] and not keep and int(defs[i + 1]['stride']) == 2:
                     v.ups = 2
                     v.H, v.W = 2 * Ho, 2 * Wo
                     v.Ho, v.Wo = Ho, Wo
@@ -692,7 +693,7 @@ class DarknetEngine:
                     self.refresh_weights()
 
         N, Cin, H, W = x.shape
-        key = (N, Cin, H, W)
+        key = (N, Cin, H, W, bool(self.return_features))
         plan = self._plans.get(key)
         if plan is None:
             # every plan owns the activation buffers of its input shape; rectangular evaluation (test.py rect=True) walks

@@ -380,6 +380,10 @@ class Darknet(nn.Module):
         self.seen = np.array([0], dtype=np.int64)  # darknet file header: images seen in training
         self._hip_engine = None  # built lazily on the first CUDA eval forward
         self.hip_precision = os.environ.get('YOLO_HIP_PRECISION', 'fp16')
+        # feature_out (models.py:540-543: every conv block not feeding a yolo layer, used by the feature-distillation
+        # losses KD4 / KD5) costs an NCHW fp32 copy of ~70 tensors per forward, so the HIP paths return [] unless asked:
+        # eval copies them out of the engine's buffers, train falls back to the eager modules
+        self.hip_return_features = False
         if quantized == -1:
             self.info(verbose)
 
@@ -408,7 +412,7 @@ class Darknet(nn.Module):
         # training step on the HIP kernels (engine/train.py): float graphs only; cfgs with blocks that path does
         # not lower yet are remembered and stay on the eager modules
         return (x.is_cuda and self.training and self.quantized == -1 and not self.__dict__.get('_hip_train_unsupported')
-                and os.environ.get('YOLO_HIP_TRAIN', '1') != '0')
+                and not self.__dict__.get('hip_return_features', False) and os.environ.get('YOLO_HIP_TRAIN', '1') != '0')
 
     def forward_once(self, x, augment=False, verbose=False):
         if not verbose and not augment:
@@ -456,6 +460,7 @@ class Darknet(nn.Module):
         if eng is None or eng.precision != precision:
             eng = DarknetEngine(self, precision=precision)
             self.__dict__['_hip_engine'] = eng
+        eng.return_features = bool(self.__dict__.get('hip_return_features', False))
         return eng(x)
 
     def _forward_eager(self, x, augment=False, verbose=False):
