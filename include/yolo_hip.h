@@ -102,6 +102,11 @@ typedef struct yh_conv_desc {
     int32_t y_off_h, y_off_w;     /* (n, 2 ho + y_off_h, 2 wo + y_off_w) of a y_h x y_w tensor; ho/wo are  */
                                   /* then free (taps beyond the input read zeros).  This is one of the four */
                                   /* phases of a stride-2 data gradient, see yh_conv_pack_weights_dgrad_phase */
+                                  /* ups == 4: all four phases in one pass - the cout rows are four groups of */
+                                  /* cout / 4 channels, group p = 2a + b is stored at (n, 2 ho + a, 2 wo + b) */
+                                  /* (skipped beyond y_h x y_w), y has cout / 4 channels; kh = kw = 2, pad 0,  */
+                                  /* weight image from yh_pack_batch mode 5.  For memory-bound layers (few     */
+                                  /* channels): dz is read once instead of four times and rows are written whole */
     float* stats_ws;              /* training forward: when set, the epilogue also emits per-channel partial sums of  */
     int64_t stats_ws_floats;      /* y and y*y (as stored) — yh_conv2d_stats_rows(d) rows of [2][cout] floats — which  */
                                   /* yh_bn_finalize (nparts) turns into the batch statistics: no separate pass over y */
@@ -432,6 +437,8 @@ typedef struct yh_pack_item {
                             /* 2 one parity phase of a stride-2 data gradient (.._dgrad_phase, pa/pb)            */
                             /* 3 first layer [kh*kw*cin][cout_pad] fp32 (yh_stem_pack_weights without BN)        */
                             /* 4 depthwise [kh*kw][k_pad = c_phys] (yh_dw_pack_weights without BN), cout = channels */
+                            /* 5 all four parity phases of a stride-2 data gradient: rows [4][cout_pad = channels per  */
+                            /*   phase], 2x2 taps (t, u) holding w[co][ci][a + pad - 2t][b + pad - 2u] or zero (ups == 4) */
     int32_t dtype, cout, cin, kh, kw, k_pad, m_pad, pad, pa, pb, cout_pad;
 } yh_pack_item;
 int yh_pack_batch(const yh_pack_item* items, int n_items, void* stream);

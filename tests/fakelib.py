@@ -247,6 +247,21 @@ class FakeLib:
         w = wimg[:d.cout, :, :, :d.cin].permute(0, 3, 1, 2).contiguous()
         assert wimg[:, :, :, d.cin:].abs().max().item() == 0 if d.cin_k > d.cin else True
         b = torch.from_numpy(flat(d.bias, d.m_pad, np.float32)[:d.cout].copy())
+        if d.ups == 4:   # the four phases of a stride-2 data gradient at once: row group p = 2a + b -> pixel (2ho + a, 2wo + b)
+            assert d.kh == 2 and d.kw == 2 and d.pad == 0 and d.stride == 1 and d.cout % 16 == 0
+            cpp = d.cout // 4
+            xp = F.pad(x, (0, max(d.wo + 1 - d.w_in, 0), 0, max(d.ho + 1 - d.h, 0)))
+            y = _act(F.conv2d(xp, w, b)[:, :, :d.ho, :d.wo], d.act, d.slope)
+            out = pitched(d.y, d.n * d.y_h * d.y_w, cpp, d.ldy, np.float32 if d.out_f32 else npdt)
+            rr = pitched(d.res, d.n * d.y_h * d.y_w, cpp, d.ldr, npdt) if _addr(d.res) else None
+            full = out.reshape(d.n, d.y_h, d.y_w, cpp)
+            for ph in range(4):
+                a_, b_ = ph >> 1, ph & 1
+                part = y[:, ph * cpp:(ph + 1) * cpp].permute(0, 2, 3, 1)[:, :(d.y_h - a_ + 1) // 2, :(d.y_w - b_ + 1) // 2]
+                if rr is not None:
+                    part = part + torch.from_numpy(rr.reshape(d.n, d.y_h, d.y_w, cpp)[:, a_::2, b_::2].astype(np.float32))
+                full[:, a_::2, b_::2] = part.numpy().astype(out.dtype)
+            return 0
         if d.ups == 3:   # phase scatter: free window geometry, taps beyond the input read zeros
             need_h, need_w = (d.ho - 1) * d.stride + d.kh - d.pad, (d.wo - 1) * d.stride + d.kw - d.pad
             x = F.pad(x, (d.pad, max(need_w - d.w_in, 0), d.pad, max(need_h - d.h, 0)))
@@ -619,6 +634,17 @@ class FakeLib:
             elif it.mode == 4:
                 rc = self.yh_dw_pack_weights(it.dtype, it.w, it.bias, None, None, None, None, 0.0, None, it.cout, it.kh, it.k_pad,
                                              it.packed, it.bias_out, stream)
+            elif it.mode == 5:
+                wt = torch.from_numpy(flat(it.w, it.cout * it.cin * it.kh * it.kw, np.float32).copy()).view(it.cout, it.cin, it.kh, it.kw)
+                img = torch.zeros(it.m_pad, 2, 2, it.k_pad)
+                for ph in range(4):
+                    for t in range(2):
+                        for u in range(2):
+                            fr, fs = (ph >> 1) + it.pad - 2 * t, (ph & 1) + it.pad - 2 * u
+                            if 0 <= fr < it.kh and 0 <= fs < it.kw:
+                                img[ph * it.cout_pad:ph * it.cout_pad + it.cin, t, u, :it.cout] = wt[:, :, fr, fs].t()
+                flat(it.packed, img.numel(), _NP[it.dtype])[:] = img.reshape(-1).numpy().astype(_NP[it.dtype])
+                rc = 0
             elif it.mode == 2:
                 rc = self.yh_conv_pack_weights_dgrad_phase(it.dtype, it.w, it.cout, it.cin, it.kh, it.kw, it.pad, it.pa, it.pb,
                                                            it.k_pad, it.m_pad, it.packed, None, None, stream)

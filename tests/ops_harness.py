@@ -289,8 +289,9 @@ def stem_wgrad(lib, code, x, dz, cout, stride=1, pad=1):
     return dw
 
 
-def dgrad(lib, code, dz, w, in_hw, stride, pad, acc=None):
-    """Data gradient through yh_conv2d_fwd on the dgrad weight image (stride 2: four parity phases, ups = 3 scatter).
+def dgrad(lib, code, dz, w, in_hw, stride, pad, acc=None, fused=False):
+    """Data gradient through yh_conv2d_fwd on the dgrad weight image (stride 2: four parity phases, ups = 3 scatter, or with
+    ``fused`` all four in one 2x2-tap pass, ups = 4).
     dz (N,Ho,Wo,cout_phys), w (cout,cin,k,k) fp32 -> dx (N,H,W,cin_phys); ``acc`` (same shape) is accumulated into."""
     cout, cin, k, _ = w.shape
     N, Ho, Wo, cphys = dz.shape
@@ -306,6 +307,21 @@ def dgrad(lib, code, dz, w, in_hw, stride, pad, acc=None):
     common = dict(x=P(dz), bias=P(zero_bias), res=P(acc), y=P(dx), n=N, h=Ho, w_in=Wo, cin=cphys, cout=cin_phys, stride=1,
                   ldx=cphys, ldr=0 if acc is None else cin_phys, ldy=cin_phys, cin_k=cout_k, m_pad=dm_pad, act=0, slope=0.0,
                   out_f32=0, dtype=code, tile=0)
+    if stride == 2 and fused:
+        from engine.hiplib import PackItem
+        fm_pad = round_up(4 * cin_phys, 128)
+        img = torch.empty(fm_pad * 4 * cout_k, device=dz.device, dtype=tdtype(code))
+        item = PackItem(w=P(w), packed=P(img), mode=5, dtype=code, cout=cout, cin=cin, kh=k, kw=k, k_pad=cout_k, m_pad=fm_pad,
+                        pad=pad, cout_pad=cin_phys)
+        table = torch.frombuffer(bytearray(bytes(item)), dtype=torch.uint8).to(dz.device)
+        rc = lib.yh_pack_batch(P(table), 1, stream())
+        assert rc == 0, rc
+        zb = torch.zeros(fm_pad, device=dz.device, dtype=torch.float32)
+        call(lib, 'yh_conv2d_fwd', ConvDesc(w=P(img), ho=(H + 1) // 2, wo=(W + 1) // 2, kh=2, kw=2, pad=0, ups=4, y_h=H, y_w=W,
+                                            **dict(common, bias=P(zb), cout=4 * cin_phys, m_pad=fm_pad)))
+        if dz.is_cuda:
+            torch.cuda.synchronize()   # the pack table and image must outlive the launches
+        return dx
     if stride == 2:   # four parity phases, scattered onto every other pixel
         keep = []
         for a in (0, 1):

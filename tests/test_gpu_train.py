@@ -234,6 +234,38 @@ def test_dgrad_matches_autograd(libs, code, accumulate, case):
 
 
 @pytest.mark.parametrize('code', [F32, F16], ids=['fp32', 'fp16'])
+@pytest.mark.parametrize('accumulate', [False, True], ids=['write', 'acc'])
+@pytest.mark.parametrize('case', [(2, 32, 32, 32, 64), (1, 25, 27, 32, 64), (3, 19, 22, 16, 40), (1, 9, 9, 24, 64)],
+                         ids=lambda c: 'n%d_%dx%d_c%d-%d' % c)
+def test_fused_stride2_dgrad_matches_autograd_and_the_phase_form(libs, code, accumulate, case):
+    """ups = 4: the four parity phases of a 3x3 / stride-2 data gradient as one 2x2-tap pass with 4 * cin rows (the form the
+    engine uses for layers with <= 32 input channels), against autograd and against the four-launch phase form, odd sizes
+    included; also through the host emulation."""
+    lib, fake = libs
+    N, H, W, cin, cout = case
+    g = torch.Generator().manual_seed(sum(case))
+    dt = oh.tdtype(code)
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    cphys = oh.round_up(cout, 8)
+    w = torch.randn(cout, cin, 3, 3, generator=g) * (cout * 9) ** -0.5
+    dz = torch.randn(N, Ho, Wo, cphys, generator=g).to(dt)
+    dz[..., cout:] = 0
+    acc0 = torch.randn(N, H, W, cin, generator=g).to(dt) if accumulate else None
+    outs = []
+    for L, dev, fused in ((lib, GPU, True), (lib, GPU, False), (fake, 'cpu', True)):
+        acc = None if acc0 is None else acc0.to(dev).clone()
+        outs.append(oh.dgrad(L, code, dz.to(dev), w.to(dev), (H, W), 2, 1, acc=acc, fused=fused).float().cpu())
+        _sync()
+    ref = torch.nn.grad.conv2d_input((N, cin, H, W), w.to(dt).float(), dz[..., :cout].float().permute(0, 3, 1, 2), stride=2, padding=1)
+    ref = ref.permute(0, 2, 3, 1)
+    if accumulate:
+        ref = ref + acc0.float()
+    tol = 2e-5 if code == F32 else 2.5e-3
+    for got in outs:
+        assert (got - ref).abs().max().item() <= tol * ref.abs().max().item()
+
+
+@pytest.mark.parametrize('code', [F32, F16], ids=['fp32', 'fp16'])
 def test_resample_and_cast_kernels(libs, code):
     lib, fake = libs
     g = torch.Generator().manual_seed(9)

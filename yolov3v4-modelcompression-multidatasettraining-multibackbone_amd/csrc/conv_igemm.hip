@@ -612,7 +612,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm_glds_kernel(const 
         const long p = p0 + wn * TN * 16 + j * 16 + pc;
         if (p >= a.P) continue;
         long opix = p;
-        int wo2 = 0;
+        int wo2 = 0, ho4 = 0, wo4 = 0;
         if (a.ups == 2) {
             const int n = (int)(p / HoWo);
             const int rem = (int)(p - (long)n * HoWo);
@@ -624,11 +624,25 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm_glds_kernel(const 
             const int rem = (int)(p - (long)n * HoWo);
             const int ho = rem / a.Wo, wo = rem - ho * a.Wo;
             opix = ((long)n * a.y_h + 2 * ho + a.y_off_h) * a.y_w + 2 * wo + a.y_off_w;
+        } else if (a.ups == 4) {  // all four phases: the 2x2 output block of (n, ho, wo); the row group picks the corner
+            const int n = (int)(p / HoWo);
+            const int rem = (int)(p - (long)n * HoWo);
+            ho4 = rem / a.Wo;
+            wo4 = rem - ho4 * a.Wo;
+            opix = ((long)n * a.y_h + 2 * ho4) * a.y_w + 2 * wo4;
         }
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             const int m = m0 + wm * TM * 16 + i * 16 + mq;
             if (m >= a.Cout) continue;
+            int mc = m;          // channel within the destination row
+            long pix = opix;     // destination pixel
+            if (a.ups == 4) {
+                const int cpp = a.Cout >> 2, ph = m / cpp;
+                mc = m - ph * cpp;
+                if (2 * ho4 + (ph >> 1) >= a.y_h || 2 * wo4 + (ph & 1) >= a.y_w) continue;
+                pix = opix + (long)(ph >> 1) * a.y_w + (ph & 1);
+            }
             const f32x4 bv = *reinterpret_cast<const f32x4*>(a.bias + m);
             float v[4];
             if constexpr (sizeof(T) == 1) {
@@ -653,12 +667,12 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm_glds_kernel(const 
                 }
                 if (rg != nullptr) {
                     float r4[4];
-                    load4<T>(rg + (a.ups == 3 ? opix : p) * a.ldr + m, r4);
+                    load4<T>(rg + (a.ups >= 3 ? pix : p) * a.ldr + mc, r4);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] += r4[e];
                 }
             }
-            OutT* dst = yg + opix * a.ldy + m;
+            OutT* dst = yg + pix * a.ldy + mc;
             store4<OutT>(dst, v[0], v[1], v[2], v[3]);
             if (a.ups == 2) {
                 store4<OutT>(dst + a.ldy, v[0], v[1], v[2], v[3]);
@@ -1111,7 +1125,14 @@ extern "C" int yh_conv2d_fwd(const yh_conv_desc* d, void* stream) {
     if (d->cin % vec || d->ldx % vec || d->cin_k % bk || d->cin_k < d->cin || d->m_pad % 128 || d->m_pad < d->cout) return YH_EALIGN;
     if (d->cout % 4 || d->ldy % 4 || (d->res && d->ldr % 4)) return YH_EALIGN;
     if (!aligned16(d->x) || !aligned16(d->w) || !aligned16(d->bias) || (((uintptr_t)d->y) & 7u) || (((uintptr_t)d->res) & 7u)) return YH_EALIGN;
-    if (d->ups != 1 && d->ups != 2 && d->ups != 3) return YH_EINVAL;
+    if (d->ups < 1 || d->ups > 4) return YH_EINVAL;
+    if (d->ups == 4) {
+        // the four phases of a stride-2 data gradient in one pass: LDS-DMA tiles only (>= 64 rows), 2x2 window
+        if (d->dtype == YH_I8 || d->cout % 16 || d->cout < 64 || d->kh != 2 || d->kw != 2 || d->stride != 1 || d->pad != 0) return YH_EINVAL;
+        if (d->tile != 0 && !(d->tile >= 21 && d->tile <= 35)) return YH_EINVAL;
+        if (d->y_h <= 0 || d->y_w <= 0 || 2 * d->ho < d->y_h || 2 * d->wo < d->y_w || 2 * (d->ho - 1) >= d->y_h || 2 * (d->wo - 1) >= d->y_w) return YH_EINVAL;
+        if (d->stats_ws) return YH_EINVAL;
+    } else
     if (d->ups == 3) {
         // phase scatter: free window geometry (taps beyond the input read zeros), destination must hold every pixel
         if (d->dtype == YH_I8 || (d->tile >= 40 && d->tile < 50)) return YH_EINVAL;
@@ -1141,11 +1162,16 @@ extern "C" int yh_conv2d_fwd(const yh_conv_desc* d, void* stream) {
         a.stats_part = d->stats_ws;
     }
     hipStream_t s = (hipStream_t)stream;
+    int tile = d->tile;
+    if (d->ups == 4 && tile == 0) {   // only the LDS-DMA kernels carry the four-phase epilogue
+        tile = yh_conv2d_tile(d);
+        if (!(tile >= 21 && tile <= 35)) tile = 24;
+    }
     if (d->dtype == YH_F16) {
-        return d->out_f32 ? dispatch_tile<f16, float>(a, d->tile, s) : dispatch_tile<f16, f16>(a, d->tile, s);
+        return d->out_f32 ? dispatch_tile<f16, float>(a, tile, s) : dispatch_tile<f16, f16>(a, tile, s);
     }
     if (d->dtype == YH_I8) {
         return d->out_f32 ? dispatch_tile_i8<float>(a, d->tile, s) : dispatch_tile_i8<int8_t>(a, d->tile, s);
     }
-    return dispatch_tile<float, float>(a, d->tile, s);
+    return dispatch_tile<float, float>(a, tile, s);
 }

@@ -664,6 +664,20 @@ __device__ __forceinline__ void pack_item_elems(const yh_pack_item& it) {
             const int tap = (int)(r % taps), m = (int)(r / taps);
             out[i] = (m < it.cout && c < it.cin) ? (T)it.w[((long)m * it.cin + c) * taps + tap] : (T)0.f;
         }
+    } else if (it.mode == 5) {
+        // all four parity phases of a stride-2 data gradient: row = phase * cout_pad + ci, taps (t, u) of a 2x2 window
+        const long total = (long)it.m_pad * 4 * it.k_pad;
+        for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+            const int co = (int)(i % it.k_pad);
+            const long r = i / it.k_pad;
+            const int tap = (int)(r & 3), m = (int)(r >> 2);
+            const int ph = m / it.cout_pad, ci = m - ph * it.cout_pad;
+            const int fr = (ph >> 1) + it.pad - 2 * (tap >> 1), fs = (ph & 1) + it.pad - 2 * (tap & 1);
+            float v = 0.f;
+            if (ph < 4 && ci < it.cin && co < it.cout && fr >= 0 && fr < it.kh && fs >= 0 && fs < it.kw)
+                v = it.w[(((long)co * it.cin + ci) * it.kh + fr) * it.kw + fs];
+            out[i] = (T)v;
+        }
     } else {
         const int khp = it.mode == 2 ? (it.pa + it.pad) / 2 + 1 : it.kh, kwp = it.mode == 2 ? (it.pb + it.pad) / 2 + 1 : it.kw;
         const long total = (long)it.m_pad * khp * kwp * it.k_pad;

@@ -124,7 +124,10 @@ class TrainEngine(DarknetEngine):
                 continue
             items.append(PackItem(w=w, bias=cb, packed=P(pk['w']), bias_out=P(pk['b']), mode=0, k_pad=pk['cin_k'], m_pad=pk['m_pad'],
                                   **geo))
-            if v.stride == 2:
+            if v.stride == 2 and 'wt_fused' in pk:
+                items.append(PackItem(w=w, packed=P(pk['wt_fused']), mode=5, k_pad=pk['cout_k'], m_pad=pk['fused_m_pad'],
+                                      cout_pad=v.src.c_phys, **geo))
+            elif v.stride == 2:
                 for (a, b), img in zip(((0, 0), (0, 1), (1, 0), (1, 1)), pk['wt_phase']):
                     items.append(PackItem(w=w, packed=P(img), mode=2, k_pad=pk['cout_k'], m_pad=pk['dm_pad'], pa=a, pb=b, **geo))
             else:
@@ -294,7 +297,13 @@ class TrainEngine(DarknetEngine):
                                b=torch.empty(m_pad, device=dev, dtype=torch.float32), cin_k=cin_k, m_pad=m_pad,
                                wt=None if v.stride == 2 else torch.empty(dm_pad * taps * cout_k, device=dev, dtype=self.dtype),
                                cout_k=cout_k, dm_pad=dm_pad)
-                if v.stride == 2:
+                if v.stride == 2 and 16 <= v.src.c_phys <= 32 and v.src.c_phys % 4 == 0:
+                    # few input channels: the data gradient is bound by reading dz and writing dx, so all four parity phases
+                    # run as ONE 2x2-tap GEMM with 4 * cin rows (16 tap-GEMMs instead of 9, but dz is read once, not four
+                    # times, and each workgroup writes whole rows of dx): yh_conv2d_fwd ups = 4
+                    v.tpack['fused_m_pad'] = _round_up(4 * v.src.c_phys, 128)
+                    v.tpack['wt_fused'] = torch.empty(v.tpack['fused_m_pad'] * 4 * cout_k, device=dev, dtype=self.dtype)
+                elif v.stride == 2:
                     # parity (a, b) sees ((a + pad) // 2 + 1) x ((b + pad) // 2 + 1) taps
                     v.tpack['phase_taps'] = [((a + v.pad) // 2 + 1, (b + v.pad) // 2 + 1) for a in (0, 1) for b in (0, 1)]
                     v.tpack['wt_phase'] = [torch.empty(dm_pad * th * tw * cout_k, device=dev, dtype=self.dtype)
@@ -623,7 +632,15 @@ class TrainEngine(DarknetEngine):
             common = dict(bias=P(zero_bias), n=N, cin=v.c_phys, cout=s.c_phys, stride=1, ldx=lddz, ldr=s.ld if mode == 'acc' else 0,
                           ldy=s.ld, cin_k=pk['cout_k'], m_pad=pk['dm_pad'], act=LINEAR, slope=0.0, out_f32=0, dtype=self.code,
                           tile=self.force_tile if self.force_tile < 40 else 0, acc_scale=0.0, out_scale=0.0)
-            if v.stride == 2:
+            if v.stride == 2 and 'wt_fused' in pk:
+                fused = dict(common, cout=4 * s.c_phys, m_pad=pk['fused_m_pad'])
+                if zero_bias.numel() < pk['fused_m_pad']:
+                    raise RuntimeError('zero bias row is shorter than the fused data-gradient image')
+                add(bwd, plan['bwd_ops'],
+                    ConvDesc(x=dzp, w=P(pk['wt_fused']), res=gptr(s) if mode == 'acc' else None, y=gptr(s), h=v.Ho, w_in=v.Wo,
+                             ho=(s.H + 1) // 2, wo=(s.W + 1) // 2, kh=2, kw=2, pad=0, ups=4, y_h=s.H, y_w=s.W, **fused),
+                    'dgrad%d' % v.block)
+            elif v.stride == 2:
                 # input pixels of parity (a, b) only see the taps r = a + pad - 2t, s = b + pad - 2u: four small
                 # correlations of dz scattered onto every other pixel, 9 tap-GEMMs in total (a dilated pass runs 36)
                 for (a, b), (th, tw), img in zip(((0, 0), (0, 1), (1, 0), (1, 1)), pk['phase_taps'], pk['wt_phase']):
