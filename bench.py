@@ -361,9 +361,11 @@ def train_roofline(eng, x, precision):
     traffic = None
     try:   # HBM bytes per launch from the committed rocprofv3 FETCH_SIZE / WRITE_SIZE passes of this command
         hbm = json.load(open(os.path.join(REPO, 'profiles', 'hbm_traffic.json'))).get('train_batch%d' % x.shape[0], {})
-        key = {'conv_wgrad_dma': 'void yh::conv_wgrad_dma_kernel<4, 2>', 'conv_igemm_fp16_dma3_256x128': 'conv_igemm_glds<f16,f16,256x128,S3>',
-               'conv_igemm_fp16_dma3_128x256': 'conv_igemm_glds<f16,f16,128x256,S3>'}.get(top)
-        if key in hbm and precision == 'fp16':
+        keys = {'conv_wgrad_dma': ['void yh::conv_wgrad_dma_kernel<8, 2>', 'void yh::conv_wgrad_dma_kernel<4, 2>'],
+                'conv_igemm_fp16_dma3_256x128': ['conv_igemm_glds<f16,f16,256x128,S3>'],
+                'conv_igemm_fp16_dma3_128x256': ['conv_igemm_glds<f16,f16,128x256,S3>']}.get(top, [])
+        key = next((k for k in keys if k in hbm), None)
+        if key is not None and precision == 'fp16':
             traffic = {'hbm_bytes_per_launch': hbm[key]['hbm_bytes_per_dispatch'], 'kernel': key, 'source': 'profiles/hbm_traffic.json'}
     except Exception:
         traffic = None
@@ -450,8 +452,15 @@ def main():
                 dist.destroy_process_group()
             return
     if args.mode in ('detect', 'both'):
-        det = detect_main(args, device, dist, world, rank, cpu_baseline_leg=(args.mode == 'detect'))
-        if rank == 0:
+        try:
+            det = detect_main(args, device, dist, world, rank, cpu_baseline_leg=(args.mode == 'detect'))
+        except Exception as e:   # the rider must not take the headline line down with it
+            if args.mode == 'detect' or out is None and rank == 0 and world == 1:
+                raise
+            det = None
+            if rank == 0:
+                out['detect_error'] = '%s: %s' % (type(e).__name__, e)
+        if rank == 0 and det is not None:
             if out is None:
                 out = det
             else:   # the second headline metric of BASELINE.json, measured in the same run

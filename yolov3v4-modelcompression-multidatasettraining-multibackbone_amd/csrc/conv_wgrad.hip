@@ -873,7 +873,7 @@ extern "C" int yh_conv_pack_weights_dgrad_phase(int dtype, const float* w, int c
 
 extern "C" int yh_pack_batch(const yh_pack_item* items, int n_items, void* stream) {
     if (!items || n_items <= 0 || n_items > 65535) return YH_EINVAL;
-    hipLaunchKernelGGL(pack_batch_kernel, dim3(128, n_items), dim3(256), 0, (hipStream_t)stream, items);
+    hipLaunchKernelGGL(pack_batch_kernel, dim3(512, n_items), dim3(256), 0, (hipStream_t)stream, items);
     return check_launch();
 }
 

@@ -152,6 +152,7 @@ class DarknetEngine:
         self.graph_max_batch = int(os.environ.get('YOLO_HIP_GRAPH_BATCH', '0'))
         self.max_plans = max(1, int(os.environ.get('YOLO_HIP_MAX_PLANS', '6')))   # input shapes kept resident
         self._plans = {}
+        self._plans_with_features = False
         self._packed = {}  # block index -> dict(w=, b=, ...)
         self._signature = None
         self.device = None
@@ -693,7 +694,10 @@ class DarknetEngine:
                     self.refresh_weights()
 
         N, Cin, H, W = x.shape
-        key = (N, Cin, H, W, bool(self.return_features))
+        if bool(self.return_features) != self._plans_with_features:   # feature_out plans are built without epilogue fusion
+            self._drop_plans()
+            self._plans_with_features = bool(self.return_features)
+        key = (N, Cin, H, W)
         plan = self._plans.get(key)
         if plan is None:
             # every plan owns the activation buffers of its input shape; rectangular evaluation (test.py rect=True) walks
