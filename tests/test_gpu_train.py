@@ -560,6 +560,19 @@ def test_mini_train_step_fp32_matches_eager_autograd(libs, mini, size):
             assert (a.cpu() - b).abs().max().item() <= 1e-5 * (b.abs().max().item() + 1), k
 
 
+def test_single_channel_train_step_matches_eager(libs):
+    """Gray-scale input (reference cfg/yolov3-singlechannel, is_gray_scale=True) through the stem and its MFMA weight gradient."""
+    import test_train_emulated as tte
+    model = tte._gray_model()
+    x = torch.rand(4, 1, 64, 64, generator=torch.Generator().manual_seed(3))
+    raws_ref, grads_ref, _, ws = th.eager_step(model, x)
+    raws, grads, _ = th.engine_step(model, x, ws, 'fp32', lib=_engine_lib(), device=GPU)
+    for a, b in zip(raws, raws_ref):
+        assert (a - b).abs().max().item() <= 2e-5 * b.abs().max().item()
+    for k in grads_ref:
+        assert th.rel_l2(grads[k], grads_ref[k]) < 5e-5, k
+
+
 def test_mini_train_step_fp16_close_to_emulated_fp16(libs, mini):
     """fp16 kernels vs the fp16 emulation of the same plan (same rounding points): statistical, kinks flip."""
     model = th.build(mini, 64)

@@ -55,6 +55,30 @@ def test_mini_fp16_storage_stays_close(mini):
         assert th.cosine(grads[k], grads_ref[k]) > 0.97, k
 
 
+def _gray_model():
+    import models
+    path = th.write_cfg(th.mini_cfg_text().replace('channels=3', 'channels=1'))
+    torch.manual_seed(0)
+    model = models.Darknet(path, (64, 64), is_gray_scale=True)
+    state = model.state_dict()
+    synth.randomize_bn_(state, seed=1)
+    model.load_state_dict(state)
+    return model.train()
+
+
+def test_single_channel_input_trains_on_the_hip_path():
+    """cfg/yolov3-singlechannel (Darknet(..., is_gray_scale=True)): the first conv reads one image channel; its weight
+    gradient runs through the 8-channel NHWC copy with cin_w = 1."""
+    model = _gray_model()
+    x = torch.rand(4, 1, 64, 64, generator=torch.Generator().manual_seed(3))
+    raws_ref, grads_ref, _, ws = th.eager_step(model, x)
+    raws, grads, _ = th.engine_step(model, x, ws, 'fp32', lib=fakelib.FakeLib())
+    for a, b in zip(raws, raws_ref):
+        assert (a - b).abs().max().item() <= 2e-5 * b.abs().max().item()
+    for k in grads_ref:
+        assert th.rel_l2(grads[k], grads_ref[k]) < 2e-5, k
+
+
 def test_gradient_accumulation_and_stale_backward(mini):
     from engine.train import TrainEngine
     model = th.build(mini, 64)

@@ -159,8 +159,8 @@ class TrainEngine(DarknetEngine):
                     raise NotImplementedError('HIP training path: channel counts must be multiples of %d' % ALIGN_C)
                 if not v.fp32 and v.C % ALIGN_C:
                     raise NotImplementedError('HIP training path: channel counts must be multiples of %d' % ALIGN_C)
-                if v.src.kind == 'input' and (v.src.C != 3 or v.k != 3):
-                    raise NotImplementedError('HIP training path: the first conv must be 3x3 over 3 channels')
+                if v.src.kind == 'input' and (v.src.C > 4 or v.src.C > ALIGN_C):
+                    raise NotImplementedError('HIP training path: the first conv reads at most 4 image channels')
                 if v.stride == 2 and not (v.k == 3 and v.pad == 1):
                     raise NotImplementedError('HIP training path: stride-2 convs must be 3x3 pad 1')
                 if v.stride not in (1, 2):
