@@ -148,6 +148,8 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const yh_bn_desc d, con
     load8<VN>(d.beta, c0, be, 0.f);
     load8<VN>(d.gamma ? d.mean : nullptr, c0, mu, 0.f);
     load8<VN>(d.gamma ? d.invstd : nullptr, c0, is, 1.f);
+    // one 16-byte load per thread per trip at full occupancy; hoisting four pixels' loads ahead of their use was measured
+    // slower (VGPRs 114-160, occupancy 8 -> 3-4 waves per SIMD: reduce kernel 4.7 -> 5.9 ms per step)
     for (long p = p0 + prow; p < p1; p += gm.rows) {
         const V v = *reinterpret_cast<const V*>(z + p * d.ldz);
         float o[VN];
