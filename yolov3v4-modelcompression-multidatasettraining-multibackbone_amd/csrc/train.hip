@@ -17,10 +17,12 @@ __device__ __forceinline__ float act_grad(float u, int act, float slope) {
         case YH_ACT_RELU6: return (u > 0.f && u < 6.f) ? 1.f : 0.f;
         case YH_ACT_HSWISH: return u <= -3.f ? 0.f : (u >= 3.f ? 1.f : (2.f * u + 3.f) / 6.f);
         case YH_ACT_MISH: {
+            // one exp and two hardware reciprocals (1 ulp) per element: the reduce and apply kernels both evaluate this,
+            // and with two exps and two IEEE divides they were ALU bound on the mish networks (YOLOv4)
             const float e = expf(fminf(u, 20.f));
             const float n = e * (e + 2.f);
-            const float t = u > 20.f ? 1.f : n / (n + 2.f);          // tanh(softplus(u))
-            const float sg = 1.f / (1.f + expf(-u));
+            const float t = u > 20.f ? 1.f : n * __builtin_amdgcn_rcpf(n + 2.f);          // tanh(softplus(u))
+            const float sg = u > 20.f ? 1.f : e * __builtin_amdgcn_rcpf(e + 1.f);         // sigmoid(u) = e^u / (e^u + 1)
             return t + u * sg * (1.f - t * t);
         }
         default: return 1.f;
