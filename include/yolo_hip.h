@@ -346,10 +346,13 @@ int yh_bn_act_bwd_apply(const yh_bn_desc* d, void* stream);
  *                    yh_conv_pack_weights_dgrad builds [m_pad rows = cin][kh*kw flipped][cout_k] from the fp32 OIHW
  *                    parameter; call yh_conv2d_fwd with x = dz, stride 1, pad = k-1-pad, act linear, res = y = the
  *                    gradient buffer of the input when it already holds another consumer's contribution.
- *                    Stride-2 layers first scatter dz onto the even positions of a zeroed (n, 2ho, 2wo, c) buffer
- *                    (yh_dilate2; odd positions stay zero forever).
+ *                    Stride-2 layers run as four parity-phase correlations of dz (yh_conv_pack_weights_dgrad_phase +
+ *                    ups = 3), or as one four-phase pass when they are memory bound (yh_pack_batch mode 5 + ups = 4);
+ *                    yh_dilate2 (dz scattered onto the even positions of a zeroed 2x buffer) remains for callers that
+ *                    want the plain dilated form.
  *  weight gradient = yh_conv2d_wgrad: dw[co][ci][r][s] += sum_pixels dz[p][co] * x[p shifted by tap][ci], fp32 OIHW,
- *                    accumulated with atomics over pixel splits (caller zeroes dw).  MFMA with the pixel index as K.
+ *                    accumulated (caller zeroes dw): per-split partial tiles in the workspace summed by a second
+ *                    launch, or fp32 atomics without a workspace.  MFMA with the pixel index as K.
  *  yh_stem_wgrad   the same for the first layer straight from the fp32 NCHW image (cin = 3, 3x3; scalar kernel).  The engine
  *                  prefers yh_nchw_to_nhwc + yh_conv2d_wgrad(cin_w = 3), which runs the layer on the MFMA kernel (6x faster).
  *  yh_upsample2_bwd  dx[n,h,w,c] = sum of the 2x2 block of dy (backward of the fused nearest-neighbour store).
@@ -455,9 +458,12 @@ typedef struct yh_wgrad_desc {
     int64_t ws_floats;      /* size from yh_conv2d_wgrad_workspace().  NULL / too small -> fp32 atomics.                  */
 } yh_wgrad_desc;
 int64_t yh_conv2d_wgrad_workspace(const yh_wgrad_desc* d);
-/* Tuning knobs read from the environment by yh_conv2d_wgrad (A/B measurements only): YH_WGRAD_TARGET = workgroups the
- * pixel split aims for (default 1024; negative = round the split count down), YH_WGRAD_BN = 256 selects the 8-wave
- * 128 x 256 tile.  splits = -1 in the descriptor selects the register-staged fp16 kernel.                          */
+/* The fp16 kernel splits the pixel axis over about one resident wave of workgroups (768 for the 128-row tile, 512 for the
+ * 256-row tile it uses on K-heavy layers with cout % 256 == 0, 1024 for the 64-row tile) and hands consecutive splits to
+ * the same XCD so that all tiles of a split share one L2.  Tuning knobs read from the environment (A/B measurements
+ * only): YH_WGRAD_TARGET = workgroups aimed for (negative = round the split count down), YH_WGRAD_BM = 128 / 256 forces the
+ * row tile, YH_WGRAD_BN = 256 selects the 8-wave 128 x 256 tile, YH_WGRAD_XCD = 0 restores the plain (tile, split) grid.
+ * splits = -1 in the descriptor selects the register-staged fp16 kernel.                                            */
 int yh_conv2d_wgrad(const yh_wgrad_desc* d, void* stream);
 int yh_stem_wgrad(const yh_wgrad_desc* d, void* stream);
 typedef struct yh_resample_desc {
