@@ -569,8 +569,7 @@ def test_single_channel_train_step_matches_eager(libs):
     raws, grads, _ = th.engine_step(model, x, ws, 'fp32', lib=_engine_lib(), device=GPU)
     for a, b in zip(raws, raws_ref):
         assert (a - b).abs().max().item() <= 2e-5 * b.abs().max().item()
-    for k in grads_ref:
-        assert th.rel_l2(grads[k], grads_ref[k]) < 5e-5, k
+    tte.assert_grads_close(grads, grads_ref, 5e-5)
 
 
 def test_mini_train_step_fp16_close_to_emulated_fp16(libs, mini):

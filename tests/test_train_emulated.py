@@ -57,7 +57,9 @@ def test_mini_fp16_storage_stays_close(mini):
 
 def _gray_model():
     import models
-    path = th.write_cfg(th.mini_cfg_text().replace('channels=3', 'channels=1'))
+    # linear activations: a leaky kink that flips under a different fp32 summation order moves every upstream gradient by
+    # ~1e-3, which would hide what this cfg is for (the 1-channel stem and its weight gradient)
+    path = th.write_cfg(th.mini_cfg_text('linear').replace('channels=3', 'channels=1'))
     torch.manual_seed(0)
     model = models.Darknet(path, (64, 64), is_gray_scale=True)
     state = model.state_dict()
@@ -75,8 +77,18 @@ def test_single_channel_input_trains_on_the_hip_path():
     raws, grads, _ = th.engine_step(model, x, ws, 'fp32', lib=fakelib.FakeLib())
     for a, b in zip(raws, raws_ref):
         assert (a - b).abs().max().item() <= 2e-5 * b.abs().max().item()
-    for k in grads_ref:
-        assert th.rel_l2(grads[k], grads_ref[k]) < 2e-5, k
+    assert_grads_close(grads, grads_ref, 2e-5)
+
+
+def assert_grads_close(grads, grads_ref, tol):
+    """rel-l2 per parameter; gradients that are analytically zero (a BatchNorm bias feeding another BatchNorm through linear
+    layers) are compared against the scale of the largest gradient instead of their own round-off."""
+    top = max(g.norm().item() for g in grads_ref.values())
+    for k, ref in grads_ref.items():
+        if ref.norm().item() < 1e-4 * top:
+            assert (grads[k] - ref).norm().item() < tol * top, k
+        else:
+            assert th.rel_l2(grads[k], ref) < tol, k
 
 
 def test_gradient_accumulation_and_stale_backward(mini):
