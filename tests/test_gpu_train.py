@@ -748,3 +748,45 @@ def test_fused_loss_defers_the_label_check_without_a_host_sync(libs):
     hip_loss.flush_label_check()
     ref, ref_items = U.compute_loss([r.cpu() for r in raws], targets, model, fused=False)
     assert torch.allclose(items.cpu(), ref_items, rtol=1e-5, atol=1e-6)
+
+
+def test_device_target_assignment_matches_build_targets_on_edge_cases(libs):
+    """The loss kernels redo build_targets (reference utils.py:725-779) per candidate in fp32.  Labels sitting exactly on
+    cell borders, boxes whose wh-IoU with an anchor is within one ulp of iou_t, many labels in one cell, tiny and
+    image-sized boxes: loss items and gradients must equal the torch path on the CPU over many seeds."""
+    if DRY:
+        pytest.skip('the emulator reuses the torch assignment')
+    from models import Darknet
+    from utils import utils as U
+    torch.manual_seed(0)
+    model = Darknet(os.path.join(conftest.PKG, 'cfg', 'yolov3tiny/yolov3-tiny-hand.cfg'), (416, 416))
+    model.nc, model.gr = 1, 0.5
+    anchors = [model.module_list[j].anchor_vec.clone() for j in model.yolo_layers]
+    grids = [416 // int(model.module_list[j].stride) for j in model.yolo_layers]
+    for seed in range(12):
+        model.hyp = {'giou': 3.54, 'cls': 37.4, 'cls_pw': 1.0, 'obj': 64.3, 'obj_pw': 1.0, 'iou_t': 0.20, 'fl_gamma': 0.0}
+        g = torch.Generator().manual_seed(seed)
+        raws, targets = synth.loss_inputs(model, 416, batch=3, seed=100 + seed, labels_per_image=10)
+        t = targets.clone()
+        n = t.shape[0]
+        k = torch.randint(0, n, (8,), generator=g)
+        cell = torch.randint(0, grids[seed % 2], (8, 2), generator=g).float()
+        t[k, 2:4] = cell / grids[seed % 2]                       # centres exactly on cell corners
+        t[k[:3], 2:4] = t[k[0], 2:4]                              # three labels in the same cell
+        a = anchors[seed % 2][seed % 3] / grids[seed % 2]         # a box equal to an anchor (IoU exactly 1) ...
+        t[k[3], 4:6] = a
+        t[k[4], 4:6] = a * torch.tensor([0.2, 1.0])               # ... and one whose wh-IoU is iou_t up to rounding
+        t[k[5], 4:6] = torch.tensor([1e-3, 1e-3])
+        t[k[6], 4:6] = torch.tensor([0.999, 0.999])
+        t[k[6], 2:4] = 0.5
+        outs = []
+        for dev, fused in ((GPU, True), (torch.device('cpu'), False)):
+            ps = [r.clone().to(dev).requires_grad_() for r in raws]
+            loss, items = U.compute_loss(ps, t.to(dev), model, fused=fused)
+            loss.backward()
+            outs.append((items.cpu(), [p.grad.cpu() for p in ps]))
+        from engine import loss as hip_loss
+        hip_loss.flush_label_check()
+        assert torch.allclose(outs[0][0], outs[1][0], rtol=2e-5, atol=1e-6), (seed, outs[0][0], outs[1][0])
+        for ga, gb in zip(outs[0][1], outs[1][1]):
+            assert (ga - gb).abs().max().item() <= 1e-4 * gb.abs().max().item(), seed
