@@ -147,3 +147,30 @@ def test_train_and_test_on_the_gpu_path(dataset_dir, tiny_cfg, tmp_path, monkeyp
     test_mod.opt = None
     (mp, mr, m_ap, mf1, *losses), maps = test_mod.test(tiny_cfg, str(dataset_dir / 'synth.data'), 'weights/last.pt', batch_size=2, imgsz=64, plot=False)
     assert 0.0 <= m_ap <= 1.0 and all(np.isfinite(losses))
+
+
+def test_ptq_entry_point_calibrates_and_saves(dataset_dir, tiny_cfg, tmp_path, monkeypatch):
+    """PTQ.py (reference PTQ.py:12-131): float evaluation, calibration over the train split, quantised evaluation, PTQ.pt."""
+    monkeypatch.chdir(tmp_path)
+    import sys
+    for name in ('utils.quantized.quantized_ptq_cos', 'utils.quantized'):   # tests/test_ptq.py may have left its stand-in there
+        mod = sys.modules.get(name)
+        if mod is not None and not getattr(mod, '__file__', '').startswith(conftest.PKG):
+            del sys.modules[name]
+    import models
+    import PTQ as ptq_mod
+    import test as test_mod
+    torch.manual_seed(0)
+    fm = models.Darknet(tiny_cfg, (64, 64))
+    os.makedirs('weights', exist_ok=True)
+    models.save_weights(fm, 'weights/float.weights')
+    test_mod.opt = None
+    opt = ptq_mod.make_parser().parse_args(['--cfg', tiny_cfg, '--data', str(dataset_dir / 'synth.data'), '--weights', 'weights/float.weights',
+                                            '--batch-size', '4', '--img-size', '64', '--device', 'cpu'])
+    before, after = ptq_mod.PTQ(opt)
+    assert len(before[0]) == 7 and len(after[0]) == 7 and all(np.isfinite(after[0]))
+    ckpt = torch.load('weights/PTQ.pt', map_location='cpu', weights_only=False)
+    qm = models.Darknet(tiny_cfg, (64, 64), quantized=3, shortcut_way=1)
+    qm.load_state_dict(ckpt['model'])
+    scales = [v for k, v in ckpt['model'].items() if k.endswith('activation_quantizer.scale')]
+    assert scales and all(float(s) > 0 for s in scales)

@@ -1,0 +1,156 @@
+"""COS-PTQ calibration with this package's own ``utils/quantized/quantized_ptq_cos.py``.
+
+* everywhere: the recipe of ``tests/golden/make_golden_ptq.py`` (which ran the REFERENCE's calibration) repeated with the
+  native modules must reproduce the stored scales, grid weights / biases and eval outputs bit for bit;
+* everywhere: nets the reference cannot calibrate (max-pools: yolov3-tiny, yolov4-tiny) calibrate here and the calibrated
+  graph lowers to the int8 engine (host emulation of the C ABI);
+* build container only: side by side with the reference's module on the same weights and batches, every tensor of the
+  ``state_dict`` (incl. the bias-corrected float biases and all ranges) and the eval output are identical.
+"""
+import copy
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import conftest
+import fakelib
+import refharness
+import synth
+from ptq_minicfg import SIZE, mini_cfg
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'ptq_mini.npz')
+
+
+@pytest.fixture(autouse=True)
+def _native_module():
+    """tests/test_ptq.py installs an eval-only stand-in under the same module name; make sure the package's own is used."""
+    import sys
+    for name in ('utils.quantized.quantized_ptq_cos', 'utils.quantized'):
+        mod = sys.modules.get(name)
+        if mod is not None and not getattr(mod, '__file__', '').startswith(conftest.PKG):
+            del sys.modules[name]
+    import utils
+    if hasattr(utils, 'quantized') and not getattr(utils.quantized, '__file__', '').startswith(conftest.PKG):
+        del utils.quantized
+    import utils.quantized.quantized_ptq_cos as q
+    assert q.__file__.startswith(conftest.PKG)
+    yield
+
+
+def _copy_float_weights(fm, qm):
+    """What load_darknet_weights(quant=True) does (reference models.py:610-628): BN tensors land on the conv itself."""
+    for f, q in zip(fm.module_list, qm.module_list):
+        if isinstance(f, torch.nn.Sequential) and len(f) and isinstance(f[0], torch.nn.Conv2d):
+            qc = q[0]
+            qc.weight.data.copy_(f[0].weight.data)
+            if len(f) > 1 and isinstance(f[1], torch.nn.BatchNorm2d):
+                qc.gamma.data.copy_(f[1].weight.data)
+                qc.beta.data.copy_(f[1].bias.data)
+                qc.running_mean.copy_(f[1].running_mean)
+                qc.running_var.copy_(f[1].running_var)
+            else:
+                qc.bias.data.copy_(f[0].bias.data)
+                qc.gamma.data.zero_()
+                qc.beta.data.zero_()
+
+
+def test_native_calibration_reproduces_the_reference_fixture():
+    import models
+    fx = np.load(GOLD)
+    torch.set_num_threads(8)
+    torch.manual_seed(0)
+    fm = models.Darknet(mini_cfg(), (SIZE, SIZE))
+    state = synth.randomize_bn_(fm.state_dict(), seed=1)
+    synth.trained_like_heads_(state, fm.module_defs)
+    fm.load_state_dict(state)
+    qm = models.Darknet(mini_cfg(), (SIZE, SIZE), quantized=3, a_bit=8, w_bit=8, shortcut_way=1)
+    _copy_float_weights(fm, qm)
+    qm.train()
+    with torch.no_grad():
+        for it in range(6):
+            qm(synth.image_batch(4, SIZE, seed=100 + it))
+    qm.eval()
+    sd = qm.state_dict()
+    keys = [k[3:] for k in fx.files if k.startswith('sd.')]
+    assert len(keys) > 40
+    for k in keys:
+        assert np.array_equal(sd[k].numpy(), fx['sd.' + k].reshape(sd[k].shape)), k
+    with torch.no_grad():
+        inf, raws, _ = qm(synth.image_batch(2, SIZE, seed=7))
+    assert torch.equal(inf, torch.from_numpy(fx['inf']))
+    for i, r in enumerate(raws):
+        assert torch.equal(r, torch.from_numpy(fx['raw%d' % i]))
+
+
+@pytest.mark.parametrize('rel', ['yolov3tiny/yolov3-tiny.cfg', 'yolov4tiny/yolov4-tiny.cfg'])
+def test_maxpool_nets_calibrate_and_lower_to_int8(rel, cfg_dir):
+    """The reference raises on these (max_pool2d gets the [quantised, float] list)."""
+    import models
+    from engine.plan import DarknetEngine
+    cfg = os.path.join(cfg_dir, rel)
+    torch.manual_seed(0)
+    fm = models.Darknet(cfg, (96, 96))
+    fm.load_state_dict(synth.randomize_bn_(fm.state_dict(), seed=1))
+    qm = models.Darknet(cfg, (96, 96), quantized=3, a_bit=8, w_bit=8, shortcut_way=1)
+    _copy_float_weights(fm, qm)
+    qm.train()
+    with torch.no_grad():
+        for it in range(3):
+            out = qm(synth.image_batch(2, 96, seed=10 + it))
+    assert len(out[0]) == 2 and all(torch.isfinite(p).all() for p in out[0])
+    qm.eval()
+    x = synth.image_batch(2, 96, seed=99)
+    with torch.no_grad():
+        want = qm(x)[0]
+        flt = fm.eval()(x)[0]
+    assert torch.isfinite(want).all()
+    assert (want[..., 4:] - flt[..., 4:]).abs().max().item() < 0.1         # a sane int8 version of the float detector
+    io = DarknetEngine(qm, precision='int8', lib=fakelib.FakeLib())(x)[0]
+    d = (io - want).abs()
+    assert (d[..., :4] > 0.05).float().mean().item() <= 0.02 and (d[..., 4:] > 2e-3).float().mean().item() <= 0.02
+
+
+@pytest.mark.skipif(not refharness.available(), reason='needs the reference tree (build container only)')
+@pytest.mark.parametrize('way', [1, 2])
+def test_native_calibration_matches_the_reference_module(way):
+    import models
+    ref = refharness.load()
+    torch.manual_seed(0)
+    theirs = ref.models.Darknet(mini_cfg(), (SIZE, SIZE), quantized=3, a_bit=8, w_bit=8, shortcut_way=way)
+    ours = models.Darknet(mini_cfg(), (SIZE, SIZE), quantized=3, a_bit=8, w_bit=8, shortcut_way=way)
+    assert type(theirs.module_list[0][0]).__module__ != type(ours.module_list[0][0]).__module__ or \
+        type(theirs.module_list[0][0]) is not type(ours.module_list[0][0])
+    assert list(ours.state_dict()) == list(theirs.state_dict())
+    g = torch.Generator().manual_seed(1)
+    sd = theirs.state_dict()
+    for k, v in sd.items():
+        if v.dtype.is_floating_point:
+            if k.endswith('gamma'):
+                v.copy_(torch.rand(v.shape, generator=g) + 0.5)
+            elif k.endswith('beta') or k.endswith('running_mean'):
+                v.copy_(torch.randn(v.shape, generator=g) * 0.1)
+            elif k.endswith('running_var'):
+                v.copy_(torch.rand(v.shape, generator=g) + 0.5)
+    theirs.load_state_dict(sd)
+    ours.load_state_dict(copy.deepcopy(sd))
+    theirs.train()
+    ours.train()
+    with torch.no_grad():
+        for it in range(4):
+            x = synth.image_batch(2, SIZE, seed=200 + it)
+            theirs(x)
+            ours(x)
+    a, b = theirs.state_dict(), ours.state_dict()
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
+    for m1, m2 in zip(theirs.modules(), ours.modules()):      # the vote histograms are not in the state_dict
+        for name in ('scale_list', 'scale_list_x', 'scale_list_a', 'scale_list_sum'):
+            if hasattr(m1, name):
+                assert getattr(m1, name) == getattr(m2, name), name
+    theirs.eval()
+    ours.eval()
+    x = synth.image_batch(2, SIZE, seed=7)
+    with torch.no_grad():
+        assert torch.equal(theirs(x)[0], ours(x)[0])

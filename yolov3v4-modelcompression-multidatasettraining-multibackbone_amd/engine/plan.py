@@ -560,6 +560,9 @@ class DarknetEngine:
                     s = v.src
                     if s.fp32 and self.code == hiplib.YH_F16:
                         raise NotImplementedError('HIP engine: block %d consumes a yolo-head tensor' % v.block)
+                    if self.q and s.scale is None:
+                        raise NotImplementedError('HIP int8 engine: block %d reads a tensor that is not on an int8 grid (%s output)'
+                                                  % (v.block, s.kind))
                     tile = self.force_tile
                     if 10 <= tile < 20 and pk['cin_k'] % (2 * self.kstep):
                         tile -= 10  # the 8-unit K step needs cin_k to be a multiple of it

@@ -54,6 +54,11 @@ def _activation(name, maxabsscaler):
     return None
 
 
+def _takes_stream_pair(module):
+    """Conv blocks of a quantised graph consume the calibration-mode [quantised, float] pair themselves."""
+    return isinstance(module, nn.Sequential) and len(module) > 0 and hasattr(module[0], 'activation_quantizer')
+
+
 def _quantized_namespace(quantized):
     """Lazy import of the reference's fake-quant operator classes (they run unmodified on top)."""
     if quantized == 1:
@@ -478,7 +483,10 @@ class Darknet(nn.Module):
             elif name == 'YOLOLayer':
                 yolo_out.append(module(x, out))
             else:
-                if name == 'Upsample' and isinstance(x, list):
+                if isinstance(x, list) and not _takes_stream_pair(module):
+                    # COS-PTQ calibration: [quantised, float] streams through a module that knows nothing about pairs.  The
+                    # reference does this for Upsample only (models.py:537-539) and raises on max-pool / zero-pad, which is
+                    # why it cannot calibrate YOLOv4 or the tiny nets
                     x = [module(x[0]), module(x[1])]
                 else:
                     x = module(x)

@@ -1,0 +1,438 @@
+"""COS-PTQ: post-training quantisation with power-of-two scales chosen by cosine similarity.
+
+Fresh implementation of the module family the reference keeps in ``utils/quantized/quantized_ptq_cos.py`` (same class
+names, constructor signatures, buffers and ``state_dict`` keys, so calibrated checkpoints are interchangeable):
+
+* ``Quantizer`` (reference :23-113) — one power-of-two scale ``2^k / 2^(bits-1)`` per tensor.  In calibration
+  (``train()``) every call tries k = -5 .. bits+1, keeps a histogram of the k whose fake-quantised tensor has the highest
+  cosine similarity with the input, and uses the histogram's mode.
+* ``BNFold_COSPTQuantizedConv2d_For_FPGA`` (:131-721) — conv with BatchNorm folded into weight and bias on first use,
+  int8-grid weight / bias / output.  Calibration runs a float and a quantised stream side by side (modules exchange
+  ``[quantised, float]`` pairs) and nudges the bias towards the float conv's channel means until the signal-to-noise
+  estimate stops improving (:230-275).
+* ``COSPTQuantizedShortcut_min / _max`` (:741-1340) and ``COSPTQuantizedFeatureConcat`` (:1364-1553) — the re-scaling
+  data-movement blocks.
+
+``eval()`` arithmetic is what ``engine/plan.py`` lowers to the int8 MFMA kernels.  The reference's text / binary dumps
+for its FPGA flow (``quantizer_output=True``) are not part of this package.
+
+Two deliberate differences, both in calibration only: a tensor arriving where a ``[quantised, float]`` pair is expected
+(after a linear conv) is used for both streams — the reference indexes the batch axis there (:822-823, :1405-1406:
+image 1 becomes the float stream, batch size 1 raises) — and data-movement modules that know nothing about pairs
+(max-pool, zero-pad) are mapped over both streams by ``models.Darknet`` — the reference passes them the list and raises
+(YOLOv4 / tiny cannot be calibrated there).
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+from torch.autograd import Function
+from torch.nn.parameter import Parameter
+
+
+def _round_half_away(t):
+    return torch.sign(t) * torch.floor(torch.abs(t) + 0.5)
+
+
+class Round(Function):
+    """Round half away from zero (reference :14-20); calibration never differentiates through it."""
+
+    @staticmethod
+    def forward(ctx, t):
+        return _round_half_away(t)
+
+
+def _limits(bits):
+    return -(1 << (bits - 1)), (1 << (bits - 1)) - 1
+
+
+def _fake_quant(t, scale, bits, clamp=True):
+    q = _round_half_away(t / scale)
+    if clamp:
+        lo, hi = _limits(bits)
+        q = torch.clamp(q, lo, hi)
+    return q * scale
+
+
+def _cosine(a, b):
+    return torch.cosine_similarity(a.reshape(-1), b.reshape(-1), dim=0)
+
+
+def _split(x):
+    """(quantised stream, float stream) of a calibration-mode input."""
+    if isinstance(x, (list, tuple)):
+        return x[0], x[1]
+    return x, x
+
+
+class Quantizer(nn.Module):
+    def __init__(self, bits, out_channels):
+        super().__init__()
+        self.bits = bits
+        shape = (1,) if out_channels == -1 else (out_channels, 1, 1, 1)
+        self.register_buffer('scale', torch.zeros(shape))
+        self.register_buffer('float_range', torch.zeros(shape))
+        self.scale_list = [0] * (bits + 7)      # votes for k = index - 5
+
+    def update_params(self, step):
+        self.float_range.zero_().add_(2 ** step)
+        self.scale = self.float_range / float(1 << (self.bits - 1))
+
+    def quantize(self, t):
+        return t / self.scale
+
+    def round(self, t):
+        return Round.apply(t)
+
+    def clamp(self, t):
+        lo, hi = _limits(self.bits)
+        return torch.clamp(t, lo, hi)
+
+    def dequantize(self, t):
+        return t * self.scale
+
+    def forward(self, t):
+        if self.bits == 32:
+            return t
+        assert self.bits != 1, 'binary quantisation is not supported'
+        if self.training:
+            best, best_i = -1, 0
+            for i in range(self.bits + 7):
+                self.update_params(i - 5)
+                c = _cosine(t, _fake_quant(t, self.scale, self.bits))
+                if c > best:
+                    best, best_i = c, i
+            self.scale_list[best_i] += 1
+            self.update_params(self.scale_list.index(max(self.scale_list)) - 5)
+        return _fake_quant(t, self.scale, self.bits)
+
+    def get_quantize_value(self, t):
+        if self.bits == 32:
+            return t
+        assert self.bits != 1, 'binary quantisation is not supported'
+        return self.clamp(self.round(self.quantize(t)))
+
+    def get_scale(self):
+        return np.array(math.log2(self.scale)).reshape(1, -1)
+
+
+def reshape_to_activation(t):
+    return t.reshape(1, -1, 1, 1)
+
+
+def reshape_to_weight(t):
+    return t.reshape(-1, 1, 1, 1)
+
+
+def reshape_to_bias(t):
+    return t.reshape(-1)
+
+
+def _no_fpga_dump(flag):
+    if flag:
+        raise NotImplementedError('quantizer_output: the FPGA text / binary dumps are not part of this package')
+
+
+class BNFold_COSPTQuantizedConv2d_For_FPGA(nn.Conv2d):
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1, bias=False, eps=1e-5,
+                 momentum=0.1, a_bits=8, w_bits=8, bn=0, activate='leaky', quantizer_output=False, reorder=False, TM=32, TN=32,
+                 name='', layer_idx=-1, maxabsscaler=False):
+        super().__init__(in_channels=in_channels, out_channels=out_channels, kernel_size=kernel_size, stride=stride,
+                         padding=padding, dilation=dilation, groups=groups, bias=bias)
+        self.bn = bn
+        if not bias:
+            self.bias = Parameter(torch.zeros(out_channels))
+        self.activate = activate
+        self.eps = eps
+        self.momentum = momentum
+        self.gamma = Parameter(torch.Tensor(out_channels))
+        self.beta = Parameter(torch.Tensor(out_channels))
+        self.register_buffer('running_mean', torch.zeros(out_channels))
+        self.register_buffer('running_var', torch.zeros(out_channels))
+        self.register_buffer('q_bias', torch.zeros(out_channels))
+        self.register_buffer('q_weight', torch.zeros(self.weight.shape))
+        self.efficency = 0          # running signal-to-noise estimate of the quantised conv (name as in the reference)
+        self.deviation = 0
+        self.stop = False           # bias correction has converged
+        self.quantized = False      # BN folded and weights on the grid
+        self.quantizer_output = quantizer_output
+        self.reorder, self.TM, self.TN = reorder, TM, TN
+        self.name, self.layer_idx = name, layer_idx
+        self.maxabsscaler = maxabsscaler
+        self.a_bits, self.w_bits = a_bits, w_bits
+        self.activation_quantizer = Quantizer(bits=a_bits, out_channels=-1)
+        self.weight_quantizer = Quantizer(bits=w_bits, out_channels=-1)
+        self.bias_quantizer = Quantizer(bits=w_bits, out_channels=-1)
+
+    def BN_fuse(self):
+        if not self.bn:
+            return self.weight, self.bias
+        k = self.gamma / torch.sqrt(self.running_var + self.eps)
+        bias = self.beta + ((self.bias if self.bias is not None else 0) - self.running_mean) * k
+        return self.weight * reshape_to_weight(k), reshape_to_bias(bias)
+
+    def _conv(self, x, w, b):
+        return F.conv2d(x, w, b, self.stride, self.padding, self.dilation, self.groups)
+
+    def _act(self, t):
+        a = self.activate
+        if a == 'leaky':
+            return F.leaky_relu(t, 0.25 if self.maxabsscaler else 0.1)
+        if a == 'relu6':
+            return F.relu6(t)
+        if a == 'h_swish':
+            return t * (F.relu6(t + 3.0) / 6.0)
+        if a == 'relu':
+            return F.relu(t)
+        if a == 'mish':
+            return t * F.softplus(t).tanh()
+        if a != 'linear':
+            print(a + ' is not supported !')
+        return t
+
+    def _correct_bias(self, xq):
+        """One step of the bias correction (:230-275): move the bias against the mean error of the quantised conv."""
+        out_q = self._conv(xq, self.q_weight, self.q_bias)
+        out_f = self._conv(xq, self.weight, self.bias)
+        rate = 0.05
+        error = (out_q - out_f).data
+        noise = error.pow(2).mean()
+        if not noise > 0:
+            self.stop = True
+            return
+        eff = 1.25 * out_f.pow(2).mean().div(noise).log10().detach().cpu().numpy()
+        dev = math.fabs(eff - self.efficency)
+        if not dev > 0:
+            self.stop = True
+            return
+        self.efficency = (self.efficency * 4 + eff) * 0.2
+        self.deviation = (self.deviation * 4 + dev) * 0.2
+        if self.efficency > 4.0:
+            rate *= 0.5
+        if self.efficency > 4.3 or self.deviation / self.efficency < 0.05 or math.fabs(dev - self.deviation / dev) < 0.05:
+            self.stop = True
+            return
+        self.bias.data = torch.sub(self.bias.data, error.mean(dim=[0, 2, 3]), alpha=rate)
+        self.q_bias = self.bias_quantizer(self.bias)
+
+    def forward(self, x):
+        _no_fpga_dump(self.quantizer_output)
+        if not self.quantized:
+            if self.bn:
+                w, b = self.BN_fuse()
+                self.bias.data = b.data
+                self.weight.data = w.data
+            self.q_weight = self.weight_quantizer(self.weight)
+            self.q_bias = self.bias_quantizer(self.bias)
+            self.quantized = True
+        if not self.training:
+            return self.activation_quantizer(self._act(self._conv(x, self.q_weight, self.q_bias)))
+        xq, xf = _split(x)
+        out_f = self._conv(xf, self.weight, self.bias)
+        if not self.stop:
+            self._correct_bias(xq)
+        out = self._act(self._conv(xq, self.q_weight, self.q_bias))
+        # the float stream: the reference multiplies the QUANTISED pre-activation by the float gate for h_swish and mish
+        # (:556, :564); the calibrated scales depend on it, so it is kept
+        if self.activate == 'h_swish':
+            out_f = out * (F.relu6(out_f + 3.0) / 6.0)
+        elif self.activate == 'mish':
+            out_f = out * F.softplus(out_f).tanh()
+        else:
+            out_f = self._act(out_f)
+        out = self.activation_quantizer(out)
+        return out if self.activate == 'linear' else [out, out_f]
+
+
+class _ShortcutBase(nn.Module):
+    """x + outputs[layer] with x, the routed tensor and the sum each on its own power-of-two grid (k = 0 .. bits-1)."""
+
+    def __init__(self, layers, weight=False, bits=8, quantizer_output=False, reorder=False, TM=32, TN=32, name='', layer_idx=-1):
+        super().__init__()
+        self.layers, self.weight, self.n, self.bits = layers, weight, len(layers) + 1, bits
+        for tag in ('x', 'a', 'sum'):
+            self.register_buffer('scale_' + tag, torch.zeros(1))
+            self.register_buffer('float_range_' + tag, torch.zeros(1))
+        self.quantizer_output = quantizer_output
+        self.reorder, self.TM, self.TN, self.name, self.layer_idx = reorder, TM, TN, name, layer_idx
+        if weight:
+            self.w = nn.Parameter(torch.zeros(self.n), requires_grad=True)
+
+    def update_params(self, step, type):
+        rng = getattr(self, 'float_range_' + type)
+        rng.zero_().add_(2 ** step)
+        setattr(self, 'scale_' + type, rng / float(1 << (self.bits - 1)))
+
+    def quantize(self, t, type):
+        return t / getattr(self, 'scale_' + type)
+
+    def round(self, t):
+        return Round.apply(t)
+
+    def clamp(self, t):
+        lo, hi = _limits(self.bits)
+        return torch.clamp(t, lo, hi)
+
+    def dequantize(self, t, type):
+        return t * getattr(self, 'scale_' + type)
+
+    def _fq(self, t, type, clamp=True):
+        return _fake_quant(t, getattr(self, 'scale_' + type), self.bits, clamp)
+
+    @staticmethod
+    def _add(x, a):
+        nx, na = x.shape[1], a.shape[1]
+        if nx == na:
+            return x + a
+        if nx > na:
+            x[:, :na] = x[:, :na] + a
+            return x
+        return x + a[:, :nx]
+
+    def _calibrate_operands(self, x, a):
+        raise NotImplementedError
+
+    def _calibrate_sum(self, s):
+        pass
+
+    def forward(self, x, outputs):
+        _no_fpga_dump(self.quantizer_output)
+        xf = None
+        if self.training:
+            x, xf = _split(x)
+        w = torch.sigmoid(self.w) * (2 / self.n) if self.weight else None
+        if w is not None:
+            x = x * w[0]
+        for i, layer in enumerate(self.layers):
+            a = _split(outputs[layer])[0] if self.training else outputs[layer]
+            if w is not None:
+                a = a * w[i + 1]
+            if self.training:
+                self._calibrate_operands(x, a)
+            x = self._add(self._fq(x, 'x', clamp=False), self._fq(a, 'a', clamp=False))   # operands are not clamped (:877-885)
+            if self.training:
+                self._calibrate_sum(x)
+            x = self._fq(x, 'sum')
+        if not self.training:
+            return x
+        if w is not None:
+            xf = xf * w[0]
+        for i, layer in enumerate(self.layers):
+            a = _split(outputs[layer])[1]
+            xf = self._add(xf, a * w[i + 1] if w is not None else a)
+        return [x, xf]
+
+
+class COSPTQuantizedShortcut_min(_ShortcutBase):
+    """Operands searched separately, then both put on the finer of the two grids; the sum has its own search (:838-912)."""
+
+    def __init__(self, *args, **kw):
+        super().__init__(*args, **kw)
+        self.scale_list_x, self.scale_list_a, self.scale_list_sum = ([0] * self.bits for _ in range(3))
+
+    def _vote(self, t, type):
+        votes = getattr(self, 'scale_list_' + type)
+        best, best_i = -1, 0
+        for i in range(self.bits):
+            self.update_params(i, type)
+            c = _cosine(t, self._fq(t, type))
+            if c > best:
+                best, best_i = c, i
+        votes[best_i] += 1
+        self.update_params(votes.index(max(votes)), type)
+
+    def _calibrate_operands(self, x, a):
+        self._vote(a, 'a')
+        self._vote(x, 'x')
+        k = min(self.float_range_a, self.float_range_x).log2()
+        self.update_params(k, 'a')
+        self.update_params(k, 'x')
+
+    def _calibrate_sum(self, s):
+        self._vote(s, 'sum')
+
+
+class COSPTQuantizedShortcut_max(_ShortcutBase):
+    """One common grid for x, the routed tensor and their sum: the k maximising the three cosines together (:1153-1197)."""
+
+    def __init__(self, *args, **kw):
+        super().__init__(*args, **kw)
+        self.scale_list = [0] * self.bits
+
+    def _calibrate_operands(self, x, a):
+        best, best_i = -1, 0
+        for i in range(self.bits):
+            for tag in ('a', 'x', 'sum'):
+                self.update_params(i, tag)
+            s = self._add(x.clone() if x.shape[1] > a.shape[1] else x, a)
+            c = _cosine(a, self._fq(a, 'a')) + _cosine(x, self._fq(x, 'x')) + _cosine(s, self._fq(s, 'sum'))
+            if c > best:
+                best, best_i = c, i
+        self.scale_list[best_i] += 1
+        k = self.scale_list.index(max(self.scale_list))
+        for tag in ('x', 'a', 'sum'):
+            self.update_params(k, tag)
+
+
+class COSPTQuantizedFeatureConcat(nn.Module):
+    """route: every routed tensor re-quantised to one shared power-of-two grid (the one nearest to the running abs-max of the
+    inputs, momentum 0.1), then concatenated; single-input and ``groups`` routes pass through (:1403-1553)."""
+
+    def __init__(self, layers, groups, bits=8, quantizer_output=False, reorder=False, TM=32, TN=32, name='', layer_idx=-1):
+        super().__init__()
+        self.layers, self.groups, self.multiple, self.bits = layers, groups, len(layers) > 1, bits
+        self.register_buffer('scale', torch.zeros(1))
+        self.register_buffer('float_max_list', torch.zeros(len(layers)))
+        self.momentum = 0.1
+        self.quantizer_output = quantizer_output
+        self.reorder, self.TM, self.TN, self.name, self.layer_idx = reorder, TM, TN, name, layer_idx
+
+    def quantize(self, t):
+        return t / self.scale
+
+    def round(self, t):
+        return Round.apply(t)
+
+    def clamp(self, t):
+        lo, hi = _limits(self.bits)
+        return torch.clamp(t, lo, hi)
+
+    def dequantize(self, t):
+        return t * self.scale
+
+    def _track(self, outputs):
+        for j, layer in enumerate(self.layers):
+            t = _split(outputs[layer])[0].detach()
+            peak = torch.max(torch.max(t), torch.abs(torch.min(t)))
+            if self.float_max_list[j] == 0:
+                self.float_max_list[j].add_(peak)
+            else:
+                self.float_max_list[j].mul_(1 - self.momentum).add_(peak * self.momentum)
+        top = max(self.float_max_list).unsqueeze(0)
+        if not top > 0:      # every routed tensor is exactly zero: the reference's log2 makes the scale NaN; use the finest grid
+            top = top + 2.0 ** -5
+        lo, hi = 2 ** top.log2().floor(), 2 ** top.log2().ceil()
+        self.scale = (hi if abs(hi - top) < abs(lo - top) else lo) / float(1 << (self.bits - 1))
+
+    def forward(self, x, outputs):
+        _no_fpga_dump(self.quantizer_output)
+        if self.multiple:
+            if self.training:
+                self._track(outputs)
+                floats = []
+                for layer in self.layers:      # the cached outputs are re-quantised in place, like the reference (:1531-1535)
+                    q, f = _split(outputs[layer])
+                    outputs[layer] = [_fake_quant(q, self.scale, self.bits), f]
+                    floats.append(f)
+                return [torch.cat([outputs[layer][0] for layer in self.layers], 1), torch.cat(floats, 1)]
+            for layer in self.layers:
+                outputs[layer] = _fake_quant(outputs[layer], self.scale, self.bits)
+            return torch.cat([outputs[layer] for layer in self.layers], 1)
+        if self.groups:
+            if self.training:
+                q, f = _split(x)
+                return [q[:, q.shape[1] // 2:], f[:, q.shape[1] // 2:]]
+            return x[:, x.shape[1] // 2:]
+        return outputs[self.layers[0]]
