@@ -154,3 +154,34 @@ def test_native_calibration_matches_the_reference_module(way):
     x = synth.image_batch(2, SIZE, seed=7)
     with torch.no_grad():
         assert torch.equal(theirs(x)[0], ours(x)[0])
+
+
+@pytest.mark.gpu
+def test_calibration_on_the_gpu_then_int8_engine(cfg_dir):
+    """The PTQ.py flow on a GPU: calibrate a max-pool net with train-mode forwards on CUDA tensors, switch to eval (the int8
+    MFMA engine takes over) and compare with the same calibrated modules evaluated on the CPU."""
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU')
+    import models
+    cfg = os.path.join(cfg_dir, 'yolov3tiny/yolov3-tiny.cfg')
+    torch.manual_seed(0)
+    fm = models.Darknet(cfg, (96, 96))
+    fm.load_state_dict(synth.randomize_bn_(fm.state_dict(), seed=1))
+    qm = models.Darknet(cfg, (96, 96), quantized=3, a_bit=8, w_bit=8, shortcut_way=1)
+    _copy_float_weights(fm, qm)
+    qm.cuda().train()
+    with torch.no_grad():
+        for it in range(3):
+            qm(synth.image_batch(2, 96, seed=10 + it).cuda())
+    qm.eval()
+    x = synth.image_batch(2, 96, seed=99)
+    with torch.no_grad():
+        got = qm(x.cuda())[0].cpu()
+    eng = qm.__dict__['_hip_engine']
+    assert eng is not None and eng.precision == 'int8'
+    cpu = copy.deepcopy(qm).cpu()
+    cpu.__dict__['_hip_engine'] = None
+    with torch.no_grad():
+        want = cpu(x)[0]
+    d = (got - want).abs()
+    assert (d[..., :4] > 0.05).float().mean().item() <= 0.02 and (d[..., 4:] > 2e-3).float().mean().item() <= 0.02
