@@ -71,19 +71,13 @@ def build_qmodel_synthetic(cfg, size, device):
     """A COS-PTQ graph (Darknet(quantized=3)) with a synthetic calibrated state, for int8 *timing* only.
 
     Weight/bias grids come from the BN-folded seeded float weights with power-of-two max-abs scales; every
-    activation, shortcut and concat scale is a fixed power of two.  The module classes are the reference's
-    utils/quantized/quantized_ptq_cos.py when a reference checkout is present, otherwise the eval stand-ins of
-    tests/ptq_standin.py (same names, buffers and eval arithmetic; pinned to the reference in tests/test_ptq.py).
-    Only the HIP int8 engine is timed."""
+    activation, shortcut and concat scale is a fixed power of two.  The module classes are this package's
+    utils/quantized/quantized_ptq_cos.py (same names, buffers and eval arithmetic as the reference's; pinned to it in
+    tests/test_ptq.py and tests/test_ptq_calibration.py).  Only the HIP int8 engine is timed."""
     import math
     import models
     from utils.torch_utils import fold_bn
-    try:
-        import utils.quantized.quantized_ptq_cos  # noqa: F401
-    except Exception:
-        sys.path.insert(0, os.path.join(REPO, 'tests'))
-        import ptq_standin
-        ptq_standin.install()
+    import utils.quantized.quantized_ptq_cos  # noqa: F401  (this package's COS-PTQ modules; models.py selects them for quantized=3)
     fm = build_model(cfg, size, 'fp16', 'cpu')
     torch.manual_seed(0)
     qm = models.Darknet(cfg, (size, size), quantized=3, a_bit=8, w_bit=8, shortcut_way=1)
@@ -402,6 +396,42 @@ def cpu_train_baseline(cfg, budget_s):
                 sample='%d images of YOLOv3-608, batch 2, fp32 eager forward + loss + backward + SGD step, %.1f s' % (n, dt))
 
 
+def self_launch(n):
+    """Re-run this command as `n` ranks under torch.distributed.run on this node; returns the launcher's exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=%d' % n, '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, OMP_NUM_THREADS=os.environ.get('OMP_NUM_THREADS', '8'))
+    return subprocess.call(cmd, env=env)
+
+
+def dry_main(args, world, rank):
+    """--dry-run: the N-rank contract without a GPU (gloo): barrier-bracketed timing, MAX over ranks, rank 0 prints."""
+    from engine import distutil
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('gloo')
+    for _ in range(args.warmup):
+        time.sleep(0.001)
+    elapsed = distutil.timed_region(lambda: time.sleep(0.002 * (rank + 1)), args.steps, dist, torch.device('cpu'))
+    if rank == 0:
+        print(json.dumps({'metric': 'dry run (no kernels)', 'value': round(world * args.batch * args.steps / elapsed, 2),
+                          'unit': 'images/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+                          'ms_per_step': round(elapsed / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
+                          'vs_baseline': None, 'dtype': 'none', 'data': 'none', 'dry_run': True,
+                          'config': {'workload': 'launcher contract only', 'global_batch': world * args.batch,
+                                     'parallelism': 'dp%d' % world}}))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -417,21 +447,43 @@ def main():
     ap.add_argument('--no-nms', action='store_true')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=12.0)
+    ap.add_argument('--share-gpu', action='store_true',
+                    help='let ranks share GPUs when fewer than --gpus are visible (smoke runs of the N > 1 path on a 1-GPU box; '
+                         'RCCL itself refuses two ranks on one device, so combine with --dist-backend gloo there)')
+    ap.add_argument('--dist-backend', default='nccl', choices=['nccl', 'gloo'], help='nccl = RCCL over xGMI (the product path)')
+    ap.add_argument('--dry-run', action='store_true',
+                    help='launcher / rendezvous / timing contract only, on CPU over gloo: no kernels run, the value is meaningless')
     args = ap.parse_args()
 
+    if args.gpus > 1 and 'RANK' not in os.environ:
+        # called the way the driver calls it (`python bench.py --gpus N`): start one rank per GPU ourselves, the same
+        # way `python -m torch.distributed.run --nproc-per-node N bench.py ...` would (reference train.py:94-107 is
+        # started by torch.distributed.launch); rank 0's JSON line is the only thing printed on stdout
+        raise SystemExit(self_launch(args.gpus))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    if args.gpus > 1 and world != args.gpus:
-        raise SystemExit('launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)' % (args.gpus, world))
+    if args.gpus != world:
+        raise SystemExit('--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d' % (args.gpus, world, args.gpus))
+    if args.dry_run:
+        return dry_main(args, world, rank)
     assert torch.cuda.is_available(), 'bench.py needs a GPU'
-    torch.cuda.set_device(local_rank)
-    device = torch.device('cuda', local_rank)
+    ndev = torch.cuda.device_count()
+    if local_rank >= ndev and not args.share_gpu:
+        raise SystemExit('rank %d has no GPU of its own (%d visible); --share-gpu lets ranks share a device (smoke runs only)'
+                         % (local_rank, ndev))
+    dev_index = local_rank % ndev
+    torch.cuda.set_device(dev_index)
+    device = torch.device('cuda', dev_index)
+    local_rank = dev_index
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=device)
+        if args.dist_backend == 'nccl':
+            dist.init_process_group('nccl', device_id=device)
+        else:   # gloo moves the gradient buckets through host memory: DDP smoke runs on a shared GPU only
+            dist.init_process_group(args.dist_backend)
 
     if args.precision == 'int8' and args.mode == 'both':
         args.mode = 'detect'   # the int8 PTQ graph is an inference path
