@@ -174,3 +174,83 @@ def test_ptq_entry_point_calibrates_and_saves(dataset_dir, tiny_cfg, tmp_path, m
     qm.load_state_dict(ckpt['model'])
     scales = [v for k, v in ckpt['model'].items() if k.endswith('activation_quantizer.scale')]
     assert scales and all(float(s) > 0 for s in scales)
+
+
+# ---------------------------------------------------------------------------- train.py setup pieces (reference train.py:120-262)
+def _opt(**kw):
+    import argparse
+    base = dict(adam=False, quantized=-1)
+    base.update(kw)
+    return argparse.Namespace(**base)
+
+
+def test_teacher_gets_its_weights(tiny_cfg, tmp_path):
+    """--t_weights must reach the teacher (reference train.py:185-192): .weights and .pt both, anything else raises."""
+    import models
+    import train as train_module
+    torch.manual_seed(3)
+    src = models.Darknet(tiny_cfg)
+    with torch.no_grad():
+        for p in src.parameters():
+            p.add_(torch.randn_like(p) * 0.05)
+    wfile, ptfile = str(tmp_path / 'teacher.weights'), str(tmp_path / 'teacher.pt')
+    models.save_weights(src, wfile)
+    torch.save({'model': src.state_dict()}, ptfile)
+    for f in (wfile, ptfile):
+        torch.manual_seed(11)   # a different initialisation than the file's
+        t = train_module.load_teacher(tiny_cfg, f, torch.device('cpu'))
+        assert not t.training
+        for (k, a), (_, b) in zip(t.named_parameters(), src.named_parameters()):
+            assert torch.equal(a, b), k
+    with pytest.raises(Exception, match='teacher weights'):
+        train_module.load_teacher(tiny_cfg, '', torch.device('cpu'))
+
+
+def test_optimizer_recipe_matches_reference(tiny_cfg):
+    import models
+    import train as train_module
+    model = models.Darknet(tiny_cfg)
+    hyp = dict(train_module.hyp)
+    sgd = train_module.build_optimizer(model, _opt(), hyp, torch.device('cpu'))
+    assert isinstance(sgd, torch.optim.SGD) and sgd.param_groups[0]['lr'] == hyp['lr0'] and sgd.param_groups[0]['nesterov']
+    assert [g['weight_decay'] for g in sgd.param_groups] == [0, hyp['weight_decay'], 0]
+    names = dict(model.named_parameters())
+    n_bias = sum('.bias' in k for k in names)
+    n_convw = sum('Conv2d.weight' in k and '.bias' not in k for k in names)
+    assert [len(g['params']) for g in sgd.param_groups] == [len(names) - n_bias - n_convw, n_convw, n_bias]
+    for o in (_opt(adam=True), _opt(quantized=3)):   # train.py:135: Adam at lr0 * 0.005 for --adam or any quantised graph
+        adam = train_module.build_optimizer(model, o, hyp, torch.device('cpu'))
+        assert isinstance(adam, torch.optim.Adam) and abs(adam.param_groups[0]['lr'] - hyp['lr0'] * 0.005) < 1e-12
+
+
+@pytest.mark.skipif(not os.path.isdir('/root/reference/utils'), reason='needs the reference checkout (utils.prune_utils)')
+@pytest.mark.parametrize('mode', [0, 1, 2])
+def test_sparsity_layer_selection_per_prune_mode(mode):
+    """--prune 0 / 1 / 2 pick their BN layers with parse_module_defs / parse_module_defs2 (5 returns) / parse_module_defs4."""
+    import models
+    import train as train_module
+    import utils.prune_utils as pu
+    defs = models.Darknet(os.path.join(conftest.PKG, 'cfg', 'yolov3', 'yolov3.cfg')).module_defs
+    idx = train_module.sparsity_layers(mode, defs)
+    want = {0: lambda: pu.parse_module_defs(defs)[2], 1: lambda: pu.parse_module_defs2(defs)[2], 2: lambda: pu.parse_module_defs4(defs)[2]}[mode]()
+    assert list(idx) == list(want) and len(idx) > 0
+
+
+def test_model_with_engine_attrs_deepcopies_and_pickles(tiny_cfg, tmp_path):
+    """deepcopy / torch.save(model) after a HIP forward: the engine attributes (ctypes handles) must not travel."""
+    import copy
+    import ctypes
+    import models
+    model = models.Darknet(tiny_cfg)
+    handle = ctypes.CDLL(None)   # stands in for the engines: ctypes objects refuse to pickle
+    model.__dict__['_hip_engine'] = handle
+    model.__dict__['_hip_train_engine'] = handle
+    clone = copy.deepcopy(model)
+    assert clone.__dict__['_hip_engine'] is None and clone.__dict__['_hip_train_engine'] is None
+    path = str(tmp_path / 'whole_model.pt')
+    torch.save(model, path)
+    back = torch.load(path, weights_only=False)
+    assert back.__dict__['_hip_engine'] is None and back.__dict__['_hip_train_engine'] is None
+    assert model.__dict__['_hip_engine'] is handle   # the live model keeps its engines
+    for (k, a), (_, b) in zip(back.named_parameters(), model.named_parameters()):
+        assert torch.equal(a, b), k

@@ -320,6 +320,16 @@ def ptr(t, elem_offset=0):
     return t.data_ptr() + elem_offset * t.element_size()
 
 
+def on_device(t):
+    """Context that makes ``t``'s GPU the current one: every launch goes to torch's *current* device and stream, so an entry
+    point handed a tensor of another GPU must switch first (a no-op for CPU tensors in the host-emulation tests)."""
+    import contextlib
+    import torch
+    if t is not None and getattr(t, 'is_cuda', False):
+        return torch.cuda.device(t.device)
+    return contextlib.nullcontext()
+
+
 def stream_ptr():
     """Current torch HIP stream as a void* (NULL stream when torch has no GPU: host-emulation tests)."""
     import torch

@@ -107,7 +107,8 @@ class _YoloLoss(torch.autograd.Function):
             g = torch.empty_strided(p.shape, p.stride(), device=p.device, dtype=torch.float32)
             d.grad, d.scale = hiplib.ptr(g), hiplib.ptr(scale)
             d.gb, d.ga, d.gy, d.gx = g.stride(0), g.stride(1), g.stride(2), g.stride(3)
-            hiplib.check(lib.yh_yolo_loss_bwd(C.byref(d), hiplib.stream_ptr()), 'yh_yolo_loss_bwd')
+            with hiplib.on_device(p):
+                hiplib.check(lib.yh_yolo_loss_bwd(C.byref(d), hiplib.stream_ptr()), 'yh_yolo_loss_bwd')
             grads.append(g)
         ctx.keep = scale
         return (None,) + tuple(grads)
@@ -123,5 +124,6 @@ def compute_loss(p, targets, model, yolo_modules, smooth_bce):
     meta = dict(targets=targets.to(device=dev, dtype=torch.float32).contiguous(), anchors=anchors, iou_t=float(h['iou_t']),
                 gr=float(model.gr), cp=float(cp), cn=float(cn), cls_pw=float(h['cls_pw']),
                 obj_pw=float(h['obj_pw']), giou=float(h['giou']), obj=float(h['obj']), cls=float(h['cls']))
-    loss, lbox, lobj, lcls = _YoloLoss.apply(meta, *p)
+    with hiplib.on_device(p[0]):
+        loss, lbox, lobj, lcls = _YoloLoss.apply(meta, *p)
     return loss.reshape(1), torch.stack((lbox, lobj, lcls, loss.detach())).detach()

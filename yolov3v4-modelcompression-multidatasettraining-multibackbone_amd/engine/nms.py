@@ -11,6 +11,11 @@ MERGE_LO, MERGE_HI = 1, 3000  # merge-NMS applies for 1 < n < 3000 (utils.py:845
 
 
 def non_max_suppression(prediction, conf_thres=0.1, iou_thres=0.6, multi_label=True, classes=None, agnostic=False):
+    with hiplib.on_device(prediction):
+        return _non_max_suppression(prediction, conf_thres, iou_thres, multi_label, classes, agnostic)
+
+
+def _non_max_suppression(prediction, conf_thres, iou_thres, multi_label, classes, agnostic):
     lib = hiplib.load()
     if prediction.dim() != 3:
         raise ValueError('expected (N, rows, 5 + nc)')

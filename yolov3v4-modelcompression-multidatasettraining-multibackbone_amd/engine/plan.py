@@ -695,6 +695,10 @@ class DarknetEngine:
                 self._signature = sig
                 if self._plans:
                     self.refresh_weights()
+        elif self._plans and os.environ.get('YOLO_HIP_SAFE', '0') == '1':
+            # edits through `param.data` views (`p.data.mul_(...)`) do not bump `param._version`: with YOLO_HIP_SAFE=1 every
+            # eval call re-packs from the live tensors (one pack launch per conv) instead of trusting the signature
+            self.refresh_weights()
 
         N, Cin, H, W = x.shape
         if bool(self.return_features) != self._plans_with_features:   # feature_out plans are built without epilogue fusion

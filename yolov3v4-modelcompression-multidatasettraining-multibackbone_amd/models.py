@@ -333,7 +333,8 @@ class _HipTrainSegment(torch.autograd.Function):
     @staticmethod
     def forward(ctx, engine, k, token, *params):
         if k == 0:
-            engine.step_heads = engine.forward(token)       # token of range 0 is the input batch
+            with torch.cuda.device(token.device):            # kernels launch on the current device: make it the batch's
+                engine.step_heads = engine.forward(token)    # token of range 0 is the input batch
         plan = engine._current
         ctx.engine, ctx.k, ctx.step = engine, k, engine.steps
         heads = [engine.step_heads[j] for j in plan['segments'][k]['heads']]
@@ -346,8 +347,12 @@ class _HipTrainSegment(torch.autograd.Function):
         if eng.steps != ctx.step:
             raise RuntimeError('HIP training path: backward() of a forward whose buffers were overwritten by a later '
                                'forward (one forward per backward, like gradient checkpointing-free eager training)')
-        grads = eng.backward_segment(ctx.k, head_grads)
+        with torch.cuda.device(eng.device):
+            grads = eng.backward_segment(ctx.k, head_grads)
         return (None, None, None) + tuple(grads)
+
+
+_ENGINE_ATTRS = ('_hip_engine', '_hip_train_engine')   # ctypes handles + device buffers: never copied or pickled
 
 
 class Darknet(nn.Module):
@@ -466,7 +471,8 @@ class Darknet(nn.Module):
             eng = DarknetEngine(self, precision=precision)
             self.__dict__['_hip_engine'] = eng
         eng.return_features = bool(self.__dict__.get('hip_return_features', False))
-        return eng(x)
+        with torch.cuda.device(x.device):   # kernels launch on the current device / stream: make it the input's
+            return eng(x)
 
     def _forward_eager(self, x, augment=False, verbose=False):
         img_size = x.shape[-2:]
@@ -554,8 +560,16 @@ class Darknet(nn.Module):
         new = cls.__new__(cls)
         memo[id(self)] = new
         for k, v in self.__dict__.items():
-            new.__dict__[k] = None if k == '_hip_engine' else copy.deepcopy(v, memo)
+            new.__dict__[k] = None if k in _ENGINE_ATTRS else copy.deepcopy(v, memo)
         return new
+
+    def __getstate__(self):
+        # torch.save(model) / pickling: the engines are rebuilt on the next CUDA forward
+        state = dict(self.__dict__)
+        for k in _ENGINE_ATTRS:
+            if k in state:
+                state[k] = None
+        return state
 
 
 def get_yolo_layers(model):

@@ -52,6 +52,60 @@ def _is_main(rank):
     return rank in (-1, 0)
 
 
+def load_teacher(t_cfg, t_weights, device):
+    """The knowledge-distillation teacher with its weights (reference train.py:185-192): .pt checkpoint or darknet .weights;
+    anything else is an error (distilling from a randomly initialised teacher is never what was meant)."""
+    t_model = Darknet(t_cfg).to(device)
+    if t_weights.endswith('.pt'):
+        t_model.load_state_dict(torch.load(t_weights, map_location=device, weights_only=False)['model'])
+    elif t_weights.endswith('.weights'):
+        load_darknet_weights(t_model, t_weights)
+    else:
+        raise Exception('pls provide proper teacher weights for knowledge distillation')
+    return t_model.eval()
+
+
+def build_optimizer(model, opt, hyp, device):
+    """Parameter groups and update rule of reference train.py:120-146: biases / decayed conv weights / the rest (+ learned
+    quantiser scales for quantized == 2); nesterov SGD at lr0, or Adam at lr0 * 0.005 for --adam and every quantised graph."""
+    pg0, pg1, pg2, pg3 = [], [], [], []
+    for k, v in dict(model.named_parameters()).items():
+        if '.bias' in k:
+            pg2.append(v)
+        elif 'Conv2d.weight' in k:
+            pg1.append(v)
+        elif 'scale' in k and opt.quantized == 2:
+            pg3.append(v)
+        else:
+            pg0.append(v)
+    # on a GPU torch's single-launch multi-tensor kernels do the update (with GradScaler's unscale folded in): the default
+    # per-op foreach form costs ~5 ms of a 72 ms YOLOv3-608 step
+    fused = {'fused': True} if device.type == 'cuda' else {}
+    if opt.adam or opt.quantized != -1:
+        optimizer = optim.Adam(pg0, lr=hyp['lr0'] * 0.005, **fused)
+        if opt.quantized == 2:
+            optimizer.add_param_group({'params': pg3})
+    else:
+        optimizer = optim.SGD(pg0, lr=hyp['lr0'], momentum=hyp['momentum'], nesterov=True, **fused)
+    optimizer.add_param_group({'params': pg1, 'weight_decay': hyp['weight_decay']})
+    optimizer.add_param_group({'params': pg2})
+    return optimizer
+
+
+def sparsity_layers(prune, module_defs):
+    """BN layers under the L1 sparsity penalty for --prune 0 / 1 / 2 (reference train.py:237-262)."""
+    from utils.prune_utils import parse_module_defs, parse_module_defs2, parse_module_defs4
+    if prune == 0:      # regular prune: convs outside shortcuts
+        _, _, prune_idx = parse_module_defs(module_defs)
+    elif prune == 1:    # shortcut prune
+        _, _, prune_idx, _, _ = parse_module_defs2(module_defs)
+    elif prune == 2:    # layer prune
+        _, _, prune_idx = parse_module_defs4(module_defs)
+    else:
+        raise ValueError('--prune must be 0, 1 or 2')
+    return prune_idx
+
+
 def train(opt, hyp):
     cfg, data, epochs, batch_size, weights = opt.cfg, opt.data, opt.epochs, opt.batch_size, opt.weights
     imgsz_min, imgsz_max, imgsz_test = opt.img_size
@@ -93,26 +147,9 @@ def train(opt, hyp):
     steps = math.ceil(len(open(train_path).readlines()) / batch_size) * epochs if os.path.isfile(train_path) else 0
     model = Darknet(cfg, quantized=opt.quantized, a_bit=opt.a_bit, w_bit=opt.w_bit, steps=steps, is_gray_scale=opt.gray_scale,
                     maxabsscaler=opt.maxabsscaler, shortcut_way=opt.shortcut_way).to(device)
-    t_model = Darknet(opt.t_cfg).to(device).eval() if opt.t_cfg else None
+    t_model = load_teacher(opt.t_cfg, opt.t_weights, device) if opt.t_cfg else None
 
-    pg0, pg1, pg2 = [], [], []            # everything else / conv weights (decayed) / biases (train.py:112-124)
-    for k, v in dict(model.named_parameters()).items():
-        if '.bias' in k:
-            pg2.append(v)
-        elif 'Conv2d.weight' in k:
-            pg1.append(v)
-        else:
-            pg0.append(v)
-    # same update rules as the reference (train.py:119-122); on a GPU torch's single-launch multi-tensor kernels do them
-    # (with GradScaler's unscale folded in): the default per-op foreach form costs ~5 ms of a 72 ms YOLOv3-608 step
-    fused = {'fused': True} if device.type == 'cuda' else {}
-    if opt.adam:
-        optimizer = optim.Adam(pg0, lr=hyp['lr0'], **fused)
-    else:
-        optimizer = optim.SGD(pg0, lr=hyp['lr0'], momentum=hyp['momentum'], nesterov=True, **fused)
-    optimizer.add_param_group({'params': pg1, 'weight_decay': hyp['weight_decay']})
-    optimizer.add_param_group({'params': pg2})
-    del pg0, pg1, pg2
+    optimizer = build_optimizer(model, opt, hyp, device)
 
     start_epoch, best_fitness = 0, 0.0
     if weights:
@@ -131,7 +168,7 @@ def train(opt, hyp):
                 start_epoch = ckpt.get('epoch', -1) + 1
             del ckpt
         else:
-            load_darknet_weights(model, weights, pt=opt.pt)
+            load_darknet_weights(model, weights, pt=opt.pt, quant=(opt.quantized != -1))
 
     lf = lambda x: (((1 + math.cos(x * math.pi / epochs)) / 2) ** 1.0) * 0.95 + 0.05      # cosine (train.py:198-203)
     if opt.quantized != -1:
@@ -166,11 +203,8 @@ def train(opt, hyp):
 
     prune_idx = None
     if opt.prune != -1:   # BN-gamma sparsity (network slimming) needs the reference's utils.prune_utils
-        from utils.prune_utils import BNOptimizer, parse_module_defs, parse_module_defs2   # noqa: F401
-        if opt.prune == 0:
-            _, _, prune_idx = parse_module_defs(core.module_defs)
-        else:
-            _, _, prune_idx = parse_module_defs2(core.module_defs)
+        prune_idx = sparsity_layers(opt.prune, core.module_defs)
+        from utils.prune_utils import BNOptimizer
 
     nb = len(dataloader)
     n_burn = max(3 * nb, 500)
