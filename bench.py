@@ -74,35 +74,12 @@ def build_qmodel_synthetic(cfg, size, device):
     activation, shortcut and concat scale is a fixed power of two.  The module classes are this package's
     utils/quantized/quantized_ptq_cos.py (same names, buffers and eval arithmetic as the reference's; pinned to it in
     tests/test_ptq.py and tests/test_ptq_calibration.py).  Only the HIP int8 engine is timed."""
-    import math
     import models
-    from utils.torch_utils import fold_bn
-    import utils.quantized.quantized_ptq_cos  # noqa: F401  (this package's COS-PTQ modules; models.py selects them for quantized=3)
+    from tools.synthetic_ptq import fill_synthetic_state
     fm = build_model(cfg, size, 'fp16', 'cpu')
     torch.manual_seed(0)
     qm = models.Darknet(cfg, (size, size), quantized=3, a_bit=8, w_bit=8, shortcut_way=1)
-    pow2 = lambda t: 2.0 ** math.ceil(math.log2(max(float(t), 1e-12) / 127.0))
-    with torch.no_grad():
-        for f, q in zip(fm.module_list, qm.module_list):
-            name = q.__class__.__name__
-            if isinstance(f, torch.nn.Sequential) and len(f) and isinstance(f[0], torch.nn.Conv2d):
-                conv, bn = f[0], (f[1] if len(f) > 1 and isinstance(f[1], torch.nn.BatchNorm2d) else None)
-                w, b = (conv.weight, conv.bias) if bn is None else fold_bn(conv.weight, conv.bias, bn.weight, bn.bias,
-                                                                           bn.running_mean, bn.running_var, bn.eps)
-                qc = q[0]
-                sw, sb = pow2(w.abs().max()), pow2(b.abs().max())
-                qc.weight_quantizer.scale.fill_(sw)
-                qc.bias_quantizer.scale.fill_(sb)
-                qc.activation_quantizer.scale.fill_(2.0 ** -4)
-                qc.q_weight.copy_((torch.sign(w) * torch.floor(w.abs() / sw + 0.5)).clamp(-128, 127) * sw)
-                qc.q_bias.copy_((torch.sign(b) * torch.floor(b.abs() / sb + 0.5)).clamp(-128, 127) * sb)
-                qc.quantized = True
-            elif name.startswith('COSPTQuantizedShortcut'):
-                q.scale_x.fill_(2.0 ** -4)
-                q.scale_a.fill_(2.0 ** -4)
-                q.scale_sum.fill_(2.0 ** -3)
-            elif name == 'COSPTQuantizedFeatureConcat':
-                q.scale.fill_(2.0 ** -4)
+    fill_synthetic_state(fm, qm)
     return qm.to(device).eval()
 
 

@@ -33,6 +33,9 @@ NET_CASES = [
     ('yolov3_608', 'yolov3/yolov3.cfg', 608, 1, 64),
     ('mobilenet_224', 'yolov3-mobilenet/yolov3-mobilenet-coco.cfg', 224, 2, 4),
     ('yolov4tiny_416', 'yolov4tiny/yolov4-tiny.cfg', 416, 2, 2),
+    # the remaining BASELINE.json shapes (configs 4 and 5): YOLOv4 at 640, YOLOv3-Mobilenetv3 at 416
+    ('yolov4_640', 'yolov4/yolov4.cfg', 640, 1, 64),
+    ('mobilenet_416', 'yolov3-mobilenet/yolov3-mobilenet-coco.cfg', 416, 1, 16),
 ]
 
 

@@ -36,7 +36,8 @@ def _hip_forward(model, x, precision):
     return out
 
 
-@pytest.mark.parametrize('name', ['tiny_hand_416', 'yolov3_320', 'yolov4_320', 'yolov3_608', 'mobilenet_224', 'yolov4tiny_416'])
+@pytest.mark.parametrize('name', ['tiny_hand_416', 'yolov3_320', 'yolov4_320', 'yolov3_608', 'mobilenet_224', 'yolov4tiny_416',
+                                  'yolov4_640', 'mobilenet_416'])
 def test_fp32_engine_matches_reference_golden_and_oracle(name, cfg_dir):
     fx = np.load(os.path.join(GOLD, 'net_%s.npz' % name))
     rel, size, batch, rs = str(fx['cfg']), int(fx['size']), int(fx['batch']), int(fx['row_stride'])
@@ -57,19 +58,30 @@ def test_fp32_engine_matches_reference_golden_and_oracle(name, cfg_dir):
         assert (r.cpu() - ro).abs().max().item() <= 5e-4
 
 
-@pytest.mark.parametrize('name', ['tiny_hand_416', 'yolov3_320', 'yolov4_320', 'mobilenet_224', 'yolov4tiny_416'])
+@pytest.mark.parametrize('name', ['tiny_hand_416', 'yolov3_320', 'yolov4_320', 'mobilenet_224', 'yolov4tiny_416',
+                                  'yolov3_608', 'yolov4_640', 'mobilenet_416'])
 def test_fp16_engine_bounded_drift(name, cfg_dir):
+    """fp16 storage / MFMA with fp32 accumulation against the reference's fp32 rows, incl. the three BASELINE shapes the bench
+    times (YOLOv3-608, YOLOv4-640, Mobilenet-416).  xy / small boxes: 0.5 px; wh = anchor * exp(t) carries the logit's fp16
+    rounding as a RELATIVE error, so large boxes get 0.5 px + 0.4 % of their size."""
     fx = np.load(os.path.join(GOLD, 'net_%s.npz' % name))
     rel, size, batch, rs = str(fx['cfg']), int(fx['size']), int(fx['batch']), int(fx['row_stride'])
     model = build_mirror(cfg_dir, rel, size).cuda()
     x = synth.image_batch(batch, size, seed=0)
     inf, raws, _ = _hip_forward(model, x, 'fp16')
-    d = (inf.cpu()[:, ::rs] - torch.from_numpy(fx['inf_rows'])).abs()
-    assert d[..., :4].max().item() <= 0.5, 'fp16 box drift %g px' % d[..., :4].max().item()
+    ref = torch.from_numpy(fx['inf_rows'])
+    d = (inf.cpu()[:, ::rs] - ref).abs()
+    bound = 0.5 + 0.004 * ref[..., 2:4].abs().max(-1, keepdim=True)[0]
+    print('fp16 drift %s: box %.3g px (worst vs bound %.3g), conf %.3g' % (name, d[..., :4].max().item(),
+                                                                          (d[..., :4] / bound).max().item(), d[..., 4:].max().item()))
+    assert (d[..., :4] <= bound).all(), 'fp16 box drift %g px' % d[..., :4].max().item()
     assert d[..., 4:].max().item() <= 5e-3, 'fp16 conf drift %g' % d[..., 4:].max().item()
 
 
-@pytest.mark.parametrize('rel,size,batch', [('yolov3tiny/yolov3-tiny-hand.cfg', 416, 4), ('yolov3/yolov3.cfg', 320, 4)])
+@pytest.mark.parametrize('rel,size,batch', [('yolov3tiny/yolov3-tiny-hand.cfg', 416, 4), ('yolov3/yolov3.cfg', 320, 4),
+                                            # the BASELINE shapes (configs 2, 4, 5)
+                                            ('yolov3/yolov3.cfg', 608, 2), ('yolov4/yolov4.cfg', 640, 2),
+                                            ('yolov3-mobilenet/yolov3-mobilenet-coco.cfg', 416, 2)])
 @pytest.mark.parametrize('precision', ['fp32', 'fp16'])
 def test_synthetic_map_protocol(rel, size, batch, precision, cfg_dir):
     """mAP@0.5 of the HIP path against the CPU fp32 oracle's detections (must stay within 0.2 pt of 1.0)."""
@@ -90,6 +102,7 @@ def test_synthetic_map_protocol(rel, size, batch, precision, cfg_dir):
     # the reference's 101-point AP (utils.py:243-246) scores a perfect detector 0.995, not 1.0: compare with
     # the score the reference detections obtain against themselves; north star: within 0.2 pt
     perfect = map50(gt, gt)
+    print('synthetic mAP@0.5 %s %d %s: %.4f (reference vs itself %.4f)' % (rel, size, precision, score, perfect))
     assert abs(score - perfect) <= 0.002, 'synthetic mAP@0.5 = %.4f vs %.4f for the reference itself' % (score, perfect)
 
 

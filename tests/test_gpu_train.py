@@ -700,6 +700,62 @@ def test_training_step_protocol_loss_and_grad_norm(libs, precision, loss_tol, no
     assert abs(norm - norm_ref) <= norm_tol * norm_ref, (norm, norm_ref)
 
 
+def test_headline_shape_fp16_step_against_the_fp32_engine(libs):
+    """The bench's headline shape itself — YOLOv3-608, batch 64, fp16 (autocast recipe) — against the fp32 engine on the same
+    inputs and weights (the fp32 engine is pinned to eager autograd / the reference goldens by the tests above; an eager CPU step
+    at this size takes minutes).  SURVEY 8(d) fp16 tolerances: loss items 1e-2 relative, global gradient norm 5e-2 relative;
+    additionally every head tensor's drift is bounded and the per-parameter gradient direction agrees (cosine >= 0.98 on the
+    parameters that carry 99 % of the gradient energy)."""
+    if DRY:
+        pytest.skip('needs the GPU (27 TFLOP per step)')
+    import copy
+    from models import Darknet
+    from utils.utils import compute_loss
+    hyp = {'giou': 3.54, 'cls': 37.4, 'cls_pw': 1.0, 'obj': 64.3, 'obj_pw': 1.0, 'iou_t': 0.20, 'fl_gamma': 0.0}
+    torch.manual_seed(0)
+    model = Darknet(os.path.join(conftest.PKG, 'cfg', 'yolov3', 'yolov3.cfg'), (608, 608)).train()
+    model.nc, model.hyp, model.gr = 80, hyp, 1.0
+    batch = 64
+    x = synth.image_batch(batch, 608, seed=3).to(GPU)
+    targets = _protocol_targets(batch).to(GPU)
+    out = {}
+    for precision in ('fp32', 'fp16'):
+        dev = copy.deepcopy(model).to(GPU)
+        os.environ['YOLO_HIP_TRAIN_PRECISION'] = precision
+        try:
+            pred, _ = dev(x)
+            loss, items = compute_loss(pred, targets, dev)
+            loss.backward()
+            torch.cuda.synchronize()
+        finally:
+            del os.environ['YOLO_HIP_TRAIN_PRECISION']
+        eng = dev.__dict__.get('_hip_train_engine')
+        assert eng is not None and eng.precision == precision
+        out[precision] = dict(items=items.cpu(), pred=[p.detach().float().cpu() for p in pred],
+                              grads={k: p.grad.detach().cpu() for k, p in dev.named_parameters()})
+        dev.__dict__['_hip_train_engine'] = None
+        del dev, eng, pred, loss
+        torch.cuda.empty_cache()
+    a, b = out['fp16'], out['fp32']
+    rel = ((a['items'] - b['items']).abs() / b['items'].abs().clamp(min=1e-6)).max().item()
+    na = sum(g.norm().item() ** 2 for g in a['grads'].values()) ** 0.5
+    nb = sum(g.norm().item() ** 2 for g in b['grads'].values()) ** 0.5
+    drift = max((p - q).abs().max().item() / q.abs().max().item() for p, q in zip(a['pred'], b['pred']))
+    energy = sorted(((g.norm().item() ** 2, k) for k, g in b['grads'].items()), reverse=True)
+    acc, top = 0.0, []
+    for e, k in energy:
+        top.append(k)
+        acc += e
+        if acc >= 0.99 * nb ** 2:
+            break
+    cos = min(torch.nn.functional.cosine_similarity(a['grads'][k].flatten(), b['grads'][k].flatten(), dim=0).item() for k in top)
+    print('608 b64 fp16 vs fp32 engine: loss items rel %.3g, grad norm %.6g vs %.6g (rel %.3g), head drift %.3g, min cosine over %d '
+          'dominant parameters %.4f' % (rel, na, nb, abs(na - nb) / nb, drift, len(top), cos))
+    assert rel <= 1e-2, (a['items'], b['items'])
+    assert abs(na - nb) <= 5e-2 * nb, (na, nb)
+    assert drift <= 2e-2 and cos >= 0.98
+
+
 @pytest.mark.parametrize('tag,rel,size,nc', [('tinyhand', 'yolov3tiny/yolov3-tiny-hand.cfg', 128, 1), ('v4tiny', 'yolov4tiny/yolov4-tiny.cfg', 128, 80)],
                          ids=['tinyhand', 'v4tiny'])
 def test_training_step_on_gpu_matches_reference_golden(libs, tag, rel, size, nc):

@@ -1,0 +1,171 @@
+"""int8 PTQ eval path on the BASELINE graphs (YOLOv3-608, YOLOv4-640: BASELINE.json configs 2 and 4) and with both shortcut forms.
+
+Goldens come from the REFERENCE's own modules (tests/golden/make_golden_ptq.py):
+* ptq_eval_<net>.npz — reference `Darknet(quantized=3)` in EVAL mode on the full graph with the synthetic power-of-two state of
+  tools/synthetic_ptq.py (scales from a one-batch max-abs range measurement; the reference cannot calibrate max-pool cfgs, but
+  its eval arithmetic, quantized_ptq_cos.py:288-296,717, runs with any scale buffers);
+* ptq_mini_max.npz — the mini net calibrated BY the reference with shortcut_way=2 (COSPTQuantizedShortcut_max,
+  quantized_ptq_cos.py:1058-1340); ptq_mini.npz is the shortcut_way=1 twin used by tests/test_ptq.py.
+
+Tolerance: the int8 engine accumulates exactly (int32) where the reference's fake-quant conv accumulates in fp32, so outputs
+may differ by one grid step at rounding ties; through 75-110 layers a flipped step can move a few later values.  Boxes are
+compared in pixels, confidences absolutely, and detections through the synthetic mAP protocol.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import conftest
+import fakelib
+import synth
+
+GOLD = os.path.join(conftest.REPO, 'tests', 'golden')
+
+
+def build_pair(rel, size, batch):
+    """This package's float + quantized=3 graphs of cfg `rel` in the state the golden generator gave the reference's."""
+    import models
+    from tools.synthetic_ptq import fill_synthetic_state, measure_ranges
+    cfg = os.path.join(conftest.PKG, 'cfg', rel)
+    torch.manual_seed(0)
+    fm = models.Darknet(cfg, (size, size))
+    state = synth.randomize_bn_(fm.state_dict(), seed=1)
+    synth.trained_like_heads_(state, fm.module_defs)
+    fm.load_state_dict(state)
+    torch.manual_seed(0)
+    qm = models.Darknet(cfg, (size, size), quantized=3, a_bit=8, w_bit=8, shortcut_way=1)
+    x = synth.image_batch(batch, size, seed=0)
+    fill_synthetic_state(fm, qm, ranges=measure_ranges(fm, x))
+    return fm, qm, x
+
+
+def compare(io, fx, box_px, conf_abs, frac_allowed):
+    rs = int(fx['row_stride'])
+    ref = torch.from_numpy(fx['inf_rows'])
+    got = io[:, ::rs]
+    assert got.shape == ref.shape
+    db, dc = (got[..., :4] - ref[..., :4]).abs(), (got[..., 4:] - ref[..., 4:]).abs()
+    stats = dict(box_max=db.max().item(), conf_max=dc.max().item(), box_frac=(db > 0.05).float().mean().item(),
+                 conf_frac=(dc > 2e-3).float().mean().item())
+    print('int8 vs reference eval:', {k: round(v, 5) for k, v in stats.items()})
+    assert stats['box_max'] <= box_px and stats['conf_max'] <= conf_abs, stats
+    assert stats['box_frac'] <= frac_allowed and stats['conf_frac'] <= frac_allowed, stats
+    return stats
+
+
+@pytest.mark.parametrize('name', ['yolov3_608', 'yolov4_640'])
+def test_eager_eval_of_this_package_equals_reference_eval(name):
+    """The package's own COS-PTQ modules in eval mode reproduce the reference's outputs on the full graphs bit for bit."""
+    fx = np.load(os.path.join(GOLD, 'ptq_eval_%s.npz' % name))
+    fm, qm, x = build_pair(str(fx['cfg']), int(fx['size']), int(fx['batch']))
+    torch.set_num_threads(min(8, os.cpu_count() or 1))
+    with torch.no_grad():
+        inf, raws, _ = qm(x)
+    rs = int(fx['row_stride'])
+    assert torch.equal(inf[:, ::rs], torch.from_numpy(fx['inf_rows']))
+    for i, r in enumerate(raws):
+        assert torch.equal(r.reshape(-1)[::997], torch.from_numpy(fx['raw%d_rows' % i]))
+
+
+@pytest.mark.parametrize('name', ['yolov3_608', 'yolov4_640'])
+def test_int8_lowering_of_baseline_graphs_on_the_emulated_engine(name):
+    """The int8 plan (fused epilogues, concat placement, qadd / qcopy / qpool re-scaling, SPP pools, CSP group routes, Mish) replayed
+    through the host emulation of the C ABI against the reference's eval outputs.  Measured: identical on the stored rows."""
+    from engine.plan import DarknetEngine
+    fx = np.load(os.path.join(GOLD, 'ptq_eval_%s.npz' % name))
+    fm, qm, x = build_pair(str(fx['cfg']), int(fx['size']), int(fx['batch']))
+    eng = DarknetEngine(qm, precision='int8', lib=fakelib.FakeLib())
+    io, raws, _ = eng(x)
+    compare(io, fx, box_px=0.05, conf_abs=2e-3, frac_allowed=0.0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('name', ['yolov3_608', 'yolov4_640'])
+def test_hip_int8_engine_matches_reference_eval_on_baseline_graphs(name):
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU')
+    from map_protocol import map50
+    from utils.utils import non_max_suppression
+    fx = np.load(os.path.join(GOLD, 'ptq_eval_%s.npz' % name))
+    fm, qm, x = build_pair(str(fx['cfg']), int(fx['size']), int(fx['batch']))
+    with torch.no_grad():
+        ref_full = qm(x)[0]            # eager eval of this package == the reference's (test above): every row, not a subset
+    qm.cuda()
+    with torch.no_grad():
+        io, raws, _ = qm(x.cuda())
+    torch.cuda.synchronize()
+    eng = qm.__dict__['_hip_engine']
+    assert eng is not None and eng.precision == 'int8'
+    io = io.cpu()
+    compare(io, fx, box_px=1.5, conf_abs=0.05, frac_allowed=0.02)
+    conf = float(torch.quantile(ref_full[..., 4].flatten(), 0.985)) * 0.999
+    gt = non_max_suppression(ref_full.clone(), conf, 0.6, multi_label=False)
+    assert sum(0 if g is None else len(g) for g in gt) >= 10
+    det = non_max_suppression(io.cuda(), conf * 0.9, 0.6, multi_label=False)
+    score, perfect = map50(gt, det), map50(gt, gt)
+    print('synthetic mAP@0.5 int8 %s: %.4f (reference vs itself %.4f)' % (name, score, perfect))
+    assert abs(score - perfect) <= 0.002
+
+
+# ------------------------------------------------------------------------------- shortcut_way = 2 (COSPTQuantizedShortcut_max)
+def build_mini(way):
+    import models
+    from ptq_minicfg import SIZE, mini_cfg
+    torch.manual_seed(0)
+    m = models.Darknet(mini_cfg(), (SIZE, SIZE), quantized=3, a_bit=8, w_bit=8, shortcut_way=way)
+    fx = np.load(os.path.join(GOLD, 'ptq_mini_max.npz' if way == 2 else 'ptq_mini.npz'))
+    sd = m.state_dict()
+    for k in sd:                      # the calibrated tensors the reference stored (scales, grid weights / biases)
+        if 'sd.' + k in fx:
+            sd[k].copy_(torch.from_numpy(fx['sd.' + k]).reshape(sd[k].shape))
+    m.load_state_dict(sd)
+    for mod in m.modules():
+        if hasattr(mod, 'q_weight'):
+            mod.quantized = True      # BN folded and on the grid already: eval must use q_weight / q_bias as stored
+    return m.eval(), fx, SIZE
+
+
+def test_shortcut_max_modules_are_selected_and_reproduce_reference_eval():
+    m, fx, size = build_mini(2)
+    names = [b.__class__.__name__ for b in m.module_list]
+    assert names.count('COSPTQuantizedShortcut_max') == 3 and 'COSPTQuantizedShortcut_min' not in names
+    with torch.no_grad():
+        inf, raws, _ = m(synth.image_batch(2, size, seed=7))
+    assert torch.equal(inf, torch.from_numpy(fx['inf']))
+    # a _max shortcut keeps x, the routed tensor and the sum on ONE grid; the fixture must really exercise that
+    for k in fx.files:
+        if k.endswith('scale_x'):
+            assert fx[k] == fx[k.replace('scale_x', 'scale_a')] == fx[k.replace('scale_x', 'scale_sum')]
+
+
+def _mini_tolerances(io, ref):
+    d = (io - ref).abs()
+    mxb, frb = d[..., :4].max().item(), (d[..., :4] > 0.05).float().mean().item()
+    mxc, frc = d[..., 4:].max().item(), (d[..., 4:] > 2e-3).float().mean().item()
+    assert mxb <= 1.5 and frb <= 0.02 and mxc <= 0.05 and frc <= 0.02, (mxb, frb, mxc, frc)
+
+
+def test_shortcut_max_lowering_on_the_emulated_engine():
+    from engine.plan import DarknetEngine
+    m, fx, size = build_mini(2)
+    eng = DarknetEngine(m, precision='int8', lib=fakelib.FakeLib())
+    io, raws, _ = eng(synth.image_batch(2, size, seed=7))
+    _mini_tolerances(io, torch.from_numpy(fx['inf']))
+    plan = next(iter(eng._plans.values()))
+    kinds = [''.join(c for c in w if not c.isdigit()) for w, _ in plan['ops']]
+    assert kinds.count('qadd') == 3
+
+
+@pytest.mark.gpu
+def test_shortcut_max_on_the_hip_int8_engine():
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU')
+    m, fx, size = build_mini(2)
+    m.cuda()
+    with torch.no_grad():
+        io, raws, _ = m(synth.image_batch(2, size, seed=7).cuda())
+    torch.cuda.synchronize()
+    assert m.__dict__['_hip_engine'].precision == 'int8'
+    _mini_tolerances(io.cpu(), torch.from_numpy(fx['inf']))

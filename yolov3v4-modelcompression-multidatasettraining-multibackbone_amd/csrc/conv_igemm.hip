@@ -21,77 +21,9 @@
 // Workgroup -> tile mapping is XCD-aware: the 8 XCDs each take a contiguous range of tiles, ordered so
 // that the channel tiles of one pixel tile are adjacent (the activation tile is fetched from HBM once
 // per XCD L2, weights are small and stay resident).
-#include <type_traits>
-
-#include "common.h"
+#include "conv_igemm.h"
 
 namespace yh {
-
-struct ConvArgs {
-    const void* x;
-    const void* w;
-    const float* bias;
-    const void* res;
-    void* y;
-    int N, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad;
-    int ldx, ldr, ldy;
-    int cin_k;       // padded per-tap K (multiple of BK)
-    int ktot;        // R*S*cin_k
-    long P;          // N*Ho*Wo
-    int m_tiles, p_tiles;
-    int m_pad;
-    float acc_scale, out_scale, inv_out_scale;  // int8 path: s_w*s_x, s_a, 1/s_a (all powers of two)
-    int act;
-    float slope;
-    int ups;
-    float* stats_part;   // training forward: per (pixel tile, wave column) partial sums of y and y^2 per channel, or NULL
-    int y_h, y_w, y_off_h, y_off_w;  // ups == 3: output pixel (n, ho, wo) is stored at (n, 2 ho + y_off_h, 2 wo + y_off_w) of a y_h x y_w tensor
-};
-
-template <int CTRL> __device__ __forceinline__ float dpp_shr_add(float v) {
-    const int t = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true);
-    return v + __builtin_bit_cast(float, t);
-}
-// inclusive scan step pattern over a 16-lane DPP row; lane 15 of the row holds the sum of all 16 lanes
-__device__ __forceinline__ float row16_sum(float v) {
-    v = dpp_shr_add<0x111>(v);   // row_shr:1
-    v = dpp_shr_add<0x112>(v);   // row_shr:2
-    v = dpp_shr_add<0x114>(v);   // row_shr:4
-    v = dpp_shr_add<0x118>(v);   // row_shr:8
-    return v;
-}
-
-// compile-time unrolled loop: every array index below is a constant, so staging registers never
-// fall back to scratch (runtime-indexed private arrays do on this compiler)
-template <int N, typename F> __device__ __forceinline__ void static_for(F&& f) {
-    if constexpr (N > 0) {
-        static_for<N - 1>(f);
-        f(std::integral_constant<int, N - 1>{});
-    }
-}
-
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));  // one 16-byte LDS cell / global vector
-
-template <typename T> struct Prec;
-template <> struct Prec<f16> {
-    static constexpr int VEC = 8;   // elements per 16-byte unit
-};
-template <> struct Prec<float> {
-    static constexpr int VEC = 4;
-};
-template <> struct Prec<int8_t> {
-    static constexpr int VEC = 16;  // int8 PTQ path: 64 channels per K step on v_mfma_i32_16x16x64_i8
-};
-
-typedef int i32x4 __attribute__((ext_vector_type(4)));
-template <typename T> struct AccOf { typedef f32x4 type; };
-template <> struct AccOf<int8_t> { typedef i32x4 type; };
-
-// PTQ rounding (utils/quantized/quantized_ptq_cos.py:14-20): half away from zero, then clamp to int8
-__device__ __forceinline__ float round_clamp_i8(float t) {
-    const float r = copysignf(floorf(fabsf(t) + 0.5f), t);
-    return fminf(fmaxf(r, -128.f), 127.f);
-}
 
 // One K step (KU units of 16 bytes per row) of MFMAs for a wave: TM x TN fragments of 16x16.
 template <typename T, int TM, int TN, int KU> struct MmaStep;
@@ -144,37 +76,6 @@ template <int TM, int TN, int KU> struct MmaStep<float, TM, TN, KU> {
         }
     }
 };
-
-template <typename OutT> __device__ __forceinline__ void store4(OutT* p, float a, float b, float c, float d);
-template <> __device__ __forceinline__ void store4<f16>(f16* p, float a, float b, float c, float d) {
-    f16x4 v = {(f16)a, (f16)b, (f16)c, (f16)d};
-    *reinterpret_cast<f16x4*>(p) = v;
-}
-template <> __device__ __forceinline__ void store4<float>(float* p, float a, float b, float c, float d) {
-    f32x4 v = {a, b, c, d};
-    *reinterpret_cast<f32x4*>(p) = v;
-}
-
-template <> __device__ __forceinline__ void store4<int8_t>(int8_t* p, float a, float b, float c, float d) {
-    const unsigned v = ((unsigned)(int)a & 0xffu) | (((unsigned)(int)b & 0xffu) << 8) | (((unsigned)(int)c & 0xffu) << 16) |
-                       (((unsigned)(int)d & 0xffu) << 24);
-    *reinterpret_cast<unsigned*>(p) = v;
-}
-
-template <typename T> __device__ __forceinline__ void load4(const T* p, float (&o)[4]);
-template <> __device__ __forceinline__ void load4<f16>(const f16* p, float (&o)[4]) {
-    f16x4 v = *reinterpret_cast<const f16x4*>(p);
-    o[0] = (float)v[0]; o[1] = (float)v[1]; o[2] = (float)v[2]; o[3] = (float)v[3];
-}
-template <> __device__ __forceinline__ void load4<int8_t>(const int8_t* p, float (&o)[4]) {
-    const unsigned v = *reinterpret_cast<const unsigned*>(p);
-    o[0] = (float)(int8_t)(v & 0xff); o[1] = (float)(int8_t)((v >> 8) & 0xff);
-    o[2] = (float)(int8_t)((v >> 16) & 0xff); o[3] = (float)(int8_t)(v >> 24);
-}
-template <> __device__ __forceinline__ void load4<float>(const float* p, float (&o)[4]) {
-    f32x4 v = *reinterpret_cast<const f32x4*>(p);
-    o[0] = v[0]; o[1] = v[1]; o[2] = v[2]; o[3] = v[3];
-}
 
 template <typename T, typename OutT, int BM, int BN, int WM, int WN, int KU>
 __global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm_kernel(const ConvArgs a) {
@@ -394,22 +295,6 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm_kernel(const ConvA
 // removed by permuting the 4 cells of a row with f[(row >> 2) & 3], f = {0,2,3,1}: the *source* unit a
 // lane fetches is (lane & 3) ^ f, the reader looks unit u up at cell u ^ f (both sides, same involution).
 // Out-of-image taps and channel tails read a 16-byte zero page instead of branching.
-__device__ __attribute__((aligned(16))) unsigned int g_zero_page[4];
-
-template <int N> __device__ __forceinline__ void wait_vmcnt() {
-    // counted wait on this wave's vector-memory queue (LDS-DMA included); literal operand, compiler barrier
-#define YH_VMCNT_CASE(K) else if constexpr (N == K) asm volatile("s_waitcnt vmcnt(" #K ")" ::: "memory")
-    if constexpr (N < 0) {}
-    YH_VMCNT_CASE(0); YH_VMCNT_CASE(1); YH_VMCNT_CASE(2); YH_VMCNT_CASE(3); YH_VMCNT_CASE(4); YH_VMCNT_CASE(5);
-    YH_VMCNT_CASE(6); YH_VMCNT_CASE(7); YH_VMCNT_CASE(8); YH_VMCNT_CASE(9); YH_VMCNT_CASE(10); YH_VMCNT_CASE(11);
-    YH_VMCNT_CASE(12); YH_VMCNT_CASE(13); YH_VMCNT_CASE(14); YH_VMCNT_CASE(15); YH_VMCNT_CASE(16); YH_VMCNT_CASE(18);
-    YH_VMCNT_CASE(20); YH_VMCNT_CASE(24);
-    else static_assert(N < 0, "add the literal");
-#undef YH_VMCNT_CASE
-}
-
-__device__ __forceinline__ int swz_f(int g) { return (0x78 >> (2 * (g & 3))) & 3; }  // {0,2,3,1}
-
 template <typename T, int TM, int TN> struct MmaStepRM;  // row-major swizzled image, 4 units per row
 template <int TM, int TN> struct MmaStepRM<f16, TM, TN> {
     static __device__ __forceinline__ void run(const u32x4* As, const u32x4* Bs, int arow, int brow, int lane,
@@ -598,106 +483,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm_glds_kernel(const 
         st_write = st_write + 1 == STAGES ? 0 : st_write + 1;
     }
 
-    // ---- epilogue (same mapping as the register-staged kernel)
-    const int mq = (lane >> 4) << 2, pc = lane & 15;
-    OutT* const yg = reinterpret_cast<OutT*>(a.y);
-    const T* const rg = reinterpret_cast<const T*>(a.res);
-    float st1[TM][4], st2[TM][4];   // BatchNorm batch statistics of this wave's outputs (training forward only)
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) st1[i][e] = st2[i][e] = 0.f;
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const long p = p0 + wn * TN * 16 + j * 16 + pc;
-        if (p >= a.P) continue;
-        long opix = p;
-        int wo2 = 0, ho4 = 0, wo4 = 0;
-        if (a.ups == 2) {
-            const int n = (int)(p / HoWo);
-            const int rem = (int)(p - (long)n * HoWo);
-            const int ho = rem / a.Wo, wo = rem - ho * a.Wo;
-            wo2 = 2 * a.Wo;
-            opix = ((long)n * 2 * a.Ho + 2 * ho) * wo2 + 2 * wo;
-        } else if (a.ups == 3) {  // phase scatter (stride-2 data gradient): every other pixel of a y_h x y_w tensor
-            const int n = (int)(p / HoWo);
-            const int rem = (int)(p - (long)n * HoWo);
-            const int ho = rem / a.Wo, wo = rem - ho * a.Wo;
-            opix = ((long)n * a.y_h + 2 * ho + a.y_off_h) * a.y_w + 2 * wo + a.y_off_w;
-        } else if (a.ups == 4) {  // all four phases: the 2x2 output block of (n, ho, wo); the row group picks the corner
-            const int n = (int)(p / HoWo);
-            const int rem = (int)(p - (long)n * HoWo);
-            ho4 = rem / a.Wo;
-            wo4 = rem - ho4 * a.Wo;
-            opix = ((long)n * a.y_h + 2 * ho4) * a.y_w + 2 * wo4;
-        }
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const int m = m0 + wm * TM * 16 + i * 16 + mq;
-            if (m >= a.Cout) continue;
-            int mc = m;          // channel within the destination row
-            long pix = opix;     // destination pixel
-            if (a.ups == 4) {
-                const int cpp = a.Cout >> 2, ph = m / cpp;
-                mc = m - ph * cpp;
-                if (2 * ho4 + (ph >> 1) >= a.y_h || 2 * wo4 + (ph & 1) >= a.y_w) continue;
-                pix = opix + (long)(ph >> 1) * a.y_w + (ph & 1);
-            }
-            const f32x4 bv = *reinterpret_cast<const f32x4*>(a.bias + m);
-            float v[4];
-            if constexpr (sizeof(T) == 1) {
-                // PTQ eval arithmetic (quantized_ptq_cos.py:288-296,543-567,717): dequantised conv + quantised bias,
-                // activation in fp32, then round-half-away/clamp onto the activation grid
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float y = activate((float)acc[i][j][e] * a.acc_scale + bv[e], a.act, a.slope);
-                    const float q = round_clamp_i8(y * a.inv_out_scale);
-                    v[e] = sizeof(OutT) == 1 ? q : q * a.out_scale;
-                }
-            } else {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = activate((float)acc[i][j][e] + bv[e], a.act, a.slope);
-                if (a.stats_part != nullptr) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float q = (float)(OutT)v[e];
-                        st1[i][e] += q;
-                        st2[i][e] = fmaf(q, q, st2[i][e]);
-                    }
-                }
-                if (rg != nullptr) {
-                    float r4[4];
-                    load4<T>(rg + (a.ups >= 3 ? pix : p) * a.ldr + mc, r4);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] += r4[e];
-                }
-            }
-            OutT* dst = yg + pix * a.ldy + mc;
-            store4<OutT>(dst, v[0], v[1], v[2], v[3]);
-            if (a.ups == 2) {
-                store4<OutT>(dst + a.ldy, v[0], v[1], v[2], v[3]);
-                store4<OutT>(dst + (long)wo2 * a.ldy, v[0], v[1], v[2], v[3]);
-                store4<OutT>(dst + (long)(wo2 + 1) * a.ldy, v[0], v[1], v[2], v[3]);
-            }
-        }
-    }
-    if (a.stats_part != nullptr) {
-        // sum over the 16 pixel lanes (lane & 15) of every channel quad, then one row of partials per (pixel tile, wn)
-        float* const row = a.stats_part + ((long)(p0 / BN) * WN + wn) * 2 * a.Cout;
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                // 16-lane row sums on the DPP path (row_shr 1, 2, 4, 8 with zero fill): lane 15 of each row ends with the total
-                const float s1 = row16_sum(st1[i][e]), s2 = row16_sum(st2[i][e]);
-                const int m = m0 + wm * TM * 16 + i * 16 + mq + e;
-                if (pc == 15 && m < a.Cout) {
-                    row[m] = s1;
-                    row[a.Cout + m] = s2;
-                }
-            }
-        }
-    }
+    conv_epilogue<T, OutT, TM, TN, BN, WN>(a, acc, m0, p0, wm, wn, lane);
 }
 
 template <typename T, typename OutT, int BM, int BN, int WM, int WN, int STAGES, int ABL = 0>
@@ -1034,6 +820,11 @@ template <typename T, typename OutT> static int dispatch_tile(const ConvArgs& a,
         case 41: return launch_halo<T, OutT, 128>(a, s);   // 3x3 s1 halo kernel, 128 channels x 256 virtual pixels
         case 42: return launch_halo<T, OutT, 256>(a, s);
         case 31: return launch_glds<T, OutT, 128, 128, 2, 2, 4>(a, s);
+        // full-line K step (64 f16 channels), 128 x 64 per wave: 61 = 256 x 256, 62 = 128 x 512 (8 waves, 2 stages),
+        // 63 = 256 x 128 (4 waves, 3 stages)
+        case 61: case 62: case 63:
+            if constexpr (sizeof(T) == 2) return launch_k64_tile(a, tile, YH_F16, std::is_same<OutT, float>::value ? 1 : 0, s);
+            else return YH_EINVAL;
         case 32: return launch_glds<T, OutT, 64, 256, 1, 4, 4>(a, s);
         case 34: return launch_glds<T, OutT, 64, 128, 2, 2, 4>(a, s);
         case 35: return launch_glds<T, OutT, 128, 64, 2, 2, 4>(a, s);
@@ -1101,7 +892,9 @@ static bool tile_geometry(int tile, int* bn, int* wn) {
         case 4: case 14: case 24: case 34: *bn = 128; *wn = 2; return true;
         case 5: case 15: case 25: case 35: *bn = 64; *wn = 2; return true;
         case 6: case 16: case 26: case 51: case 52: *bn = 128; *wn = 2; return true;
-        case 27: *bn = 256; *wn = 4; return true;
+        case 27: case 61: *bn = 256; *wn = 4; return true;
+        case 62: *bn = 512; *wn = 8; return true;
+        case 63: *bn = 128; *wn = 2; return true;
         default: return false;
     }
 }

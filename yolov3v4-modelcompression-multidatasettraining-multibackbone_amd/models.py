@@ -321,6 +321,14 @@ class YOLOLayer(nn.Module):
 
 
 # ------------------------------------------------------------------------------------------- network
+def _on_device(device):
+    """Make ``device`` the current GPU for the launches inside (a no-op for the CPU tensors of the host-emulation tests)."""
+    import contextlib
+    if device is not None and torch.device(device).type == 'cuda':
+        return torch.cuda.device(device)
+    return contextlib.nullcontext()
+
+
 class _HipTrainSegment(torch.autograd.Function):
     """Autograd node of one backward RANGE of a training step on the HIP engine.
 
@@ -333,7 +341,7 @@ class _HipTrainSegment(torch.autograd.Function):
     @staticmethod
     def forward(ctx, engine, k, token, *params):
         if k == 0:
-            with torch.cuda.device(token.device):            # kernels launch on the current device: make it the batch's
+            with _on_device(token.device):                   # kernels launch on the current device: make it the batch's
                 engine.step_heads = engine.forward(token)    # token of range 0 is the input batch
         plan = engine._current
         ctx.engine, ctx.k, ctx.step = engine, k, engine.steps
@@ -347,7 +355,7 @@ class _HipTrainSegment(torch.autograd.Function):
         if eng.steps != ctx.step:
             raise RuntimeError('HIP training path: backward() of a forward whose buffers were overwritten by a later '
                                'forward (one forward per backward, like gradient checkpointing-free eager training)')
-        with torch.cuda.device(eng.device):
+        with _on_device(eng.device):
             grads = eng.backward_segment(ctx.k, head_grads)
         return (None, None, None) + tuple(grads)
 
@@ -471,7 +479,7 @@ class Darknet(nn.Module):
             eng = DarknetEngine(self, precision=precision)
             self.__dict__['_hip_engine'] = eng
         eng.return_features = bool(self.__dict__.get('hip_return_features', False))
-        with torch.cuda.device(x.device):   # kernels launch on the current device / stream: make it the input's
+        with _on_device(x.device):   # kernels launch on the current device / stream: make it the input's
             return eng(x)
 
     def _forward_eager(self, x, augment=False, verbose=False):
