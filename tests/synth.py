@@ -45,6 +45,47 @@ def trained_like_heads_(state, module_defs, margin=8.0):
     return state
 
 
+def equalize_bn_gain_(model, x):
+    """Rescale every BatchNorm's (gamma, beta) by ONE factor per layer so that its eval-mode output has unit standard deviation
+    on the batch ``x`` (single forward pass, in place).  Deep random-weight nets with arbitrary eval statistics lose the signal
+    layer by layer (YOLOv4's 110 convs end with every cell of an anchor within 1e-4 of the same objectness, so any rounding
+    reorders the whole score ranking); with the layer gains equalised the activations stay O(1) and the outputs vary over the
+    image like a trained detector's, while the per-channel statistics keep the well-conditioned ranges of ``randomize_bn_``."""
+    import torch.nn as nn
+    hooks = []
+
+    def hook(mod, inp, out):
+        s = out.std().clamp(min=1e-6)
+        mod.weight.data.div_(s)
+        mod.bias.data.div_(s)
+        return out / s
+    for m in model.modules():
+        if isinstance(m, nn.modules.batchnorm._BatchNorm):
+            hooks.append(m.register_forward_hook(hook))
+    was_training = model.training
+    model.eval()
+    with torch.no_grad():
+        model._forward_eager(x) if hasattr(model, '_forward_eager') else model(x)
+    for h in hooks:
+        h.remove()
+    model.train(was_training)
+    return model
+
+
+def spread_objectness_(state, module_defs, gain=40.0):
+    """Scale the objectness rows of every head conv: a random-weight detector's objectness logits sit within +-0.15 of the
+    -4.5 bias (all scores within 30 % of each other), so rounding-level drift reorders the whole ranking and the mAP protocol
+    would measure tie-breaking.  With the rows scaled the logits spread over several units, like a trained head's."""
+    defs = [d for d in module_defs if d['type'] != 'net']
+    for i, d in enumerate(defs):
+        if d['type'] != 'yolo':
+            continue
+        nc = int(d['classes'])
+        w = state['module_list.%d.Conv2d.weight' % (i - 1)]
+        w.view(len(d['mask']), nc + 5, -1)[:, 4] *= gain
+    return state
+
+
 def image_batch(n, size, seed=0, channels=3):
     g = torch.Generator().manual_seed(seed)
     return torch.rand(n, channels, size, size, generator=g)

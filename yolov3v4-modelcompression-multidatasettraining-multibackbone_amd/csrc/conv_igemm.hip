@@ -822,7 +822,7 @@ template <typename T, typename OutT> static int dispatch_tile(const ConvArgs& a,
         case 31: return launch_glds<T, OutT, 128, 128, 2, 2, 4>(a, s);
         // full-line K step (64 f16 channels), 128 x 64 per wave: 61 = 256 x 256, 62 = 128 x 512 (8 waves, 2 stages),
         // 63 = 256 x 128 (4 waves, 3 stages)
-        case 61: case 62: case 63:
+        case 61: case 62: case 63: case 64: case 65: case 66:
             if constexpr (sizeof(T) == 2) return launch_k64_tile(a, tile, YH_F16, std::is_same<OutT, float>::value ? 1 : 0, s);
             else return YH_EINVAL;
         case 32: return launch_glds<T, OutT, 64, 256, 1, 4, 4>(a, s);
@@ -892,9 +892,9 @@ static bool tile_geometry(int tile, int* bn, int* wn) {
         case 4: case 14: case 24: case 34: *bn = 128; *wn = 2; return true;
         case 5: case 15: case 25: case 35: *bn = 64; *wn = 2; return true;
         case 6: case 16: case 26: case 51: case 52: *bn = 128; *wn = 2; return true;
-        case 27: case 61: *bn = 256; *wn = 4; return true;
-        case 62: *bn = 512; *wn = 8; return true;
-        case 63: *bn = 128; *wn = 2; return true;
+        case 27: case 61: case 64: *bn = 256; *wn = 4; return true;
+        case 62: case 65: *bn = 512; *wn = 8; return true;
+        case 63: case 66: *bn = 128; *wn = 2; return true;
         default: return false;
     }
 }

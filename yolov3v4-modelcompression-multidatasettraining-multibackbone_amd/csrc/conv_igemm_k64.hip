@@ -204,11 +204,260 @@ static int launch_k64(const ConvArgs& a0, hipStream_t stream) {
 }
 
 
+// ---------------------------------------------------------------------------------------------------
+// "Ping-pong" form of the full-line kernel: the two waves that share a SIMD alternate between a LOAD segment (fragment
+// reads from LDS + LDS-DMA issue for the next K tile) and an MFMA segment (16 MFMAs on one 64 x 32 quadrant of the wave's
+// 128 x 64 outputs), so each SIMD's matrix pipe always has one wave in its MFMA segment while the other wave's LDS / VMEM
+// issue runs beside it (MI355X_MICROARCH.md "Two waves per SIMD"; the 8-phase GEMM schedule of the programming guide).
+//
+//   waves 0-3 (group 0) and 4-7 (group 1) sit pairwise on the 4 SIMDs; group 1 runs one barrier interval behind group 0:
+//       interval:   0     1     2     3     4     5     6     7     8 ...
+//       group 0:    L1    M1    L2    M2    L3    M3    L4    M4    L1' ...
+//       group 1:    -     L1    M1    L2    M2    L3    M3    L4    M4 ...
+//   every interval ends with one s_barrier executed by all 8 waves (group 1 executes one extra at the start, group 0 one
+//   extra at the end, so the counts match).
+//
+// K tile = 64 channels of one tap = 4 phases (quadrants (a0,b0) (a0,b1) (a1,b1) (a1,b0) of the wave tile; a = 64-row half of
+// the wave's A rows, b = 32-pixel half of its B rows).  Phase 1 reads A[a0] + B[b0] (12 ds_read_b128), phase 2 B[b1] (4),
+// phase 3 A[a1] (8), phase 4 nothing (B[b0] is still in registers).  The LDS-DMA of K tile t+1 is issued during tile t in
+// first-use order - A[a0] rows of all waves in phase 1, B[b0] rows in phase 2, B[b1] in phase 3, A[a1] in phase 4 - into the
+// other LDS stage, so every piece has three phase intervals (~1500 cycles) to land: two stages of (BM + BN) x 128 B suffice.
+// A wave waits for ITS pieces with a counted vmcnt at the end of the load segment that precedes the consumer phase; the
+// barrier that ends that interval (and, for the other group, the next one) makes them visible to the readers.
+// Write-after-read: a region of the other stage was last read two or more phases before its refill is issued.
+template <typename T, typename OutT, int WM, int WN>
+__global__ __launch_bounds__(512, 2) void conv_igemm_pp_kernel(const ConvArgs a) {
+    static_assert(WM * WN == 8 && sizeof(T) == 2, "8 waves, f16");
+    constexpr int VEC = Prec<T>::VEC, BK = VEC * 8;
+    constexpr int BM = WM * 128, BN = WN * 64;
+    constexpr int TM = 8, TN = 4;
+    constexpr int NA = WM, NB = WN / 2;               // LDS-DMA instructions per wave per piece set (A half / B half)
+    static_assert(WN % 2 == 0, "B piece sets must split over 8 waves");
+    constexpr int STAGE_CELLS = 8 * (BM + BN);
+    __shared__ u32x4 smem[2 * STAGE_CELLS];           // the only LDS object of the kernel
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int group = wave >> 2;
+
+    int m_tile, p_tile;
+    {
+        const int nb = gridDim.x, bid = blockIdx.x;
+        const int q = nb >> 3, rr = nb & 7, xcd = bid & 7;
+        const int logical = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (bid >> 3);
+        p_tile = logical / a.m_tiles;
+        m_tile = logical - p_tile * a.m_tiles;
+    }
+    const int m0 = m_tile * BM;
+    const long p0 = (long)p_tile * BN;
+
+    // ---- loader.  Piece set X in {A0, A1, B0, B1} = the rows every wave needs first in phase 1 / 3 / 1 / 2:
+    //      A_h: tile rows (q >> 6) * 128 + h * 64 + (q & 63), q < 64 WM;   B_h: (q >> 5) * 64 + h * 32 + (q & 31), q < 32 WN.
+    //      This wave issues the 8-row groups q0 = (wave * N + i) * 8 of each set; lane -> row q0 + (lane >> 3), position lane & 7.
+    const int lrow = lane >> 3;
+    const T* const xg = reinterpret_cast<const T*>(a.x);
+    const T* const zero = reinterpret_cast<const T*>(g_zero_page);
+    const T* wsrc[2][NA];
+    int adst[2][NA];
+    static_for<2 * NA>([&](auto c) {
+        constexpr int h = decltype(c)::value / NA, i = decltype(c)::value % NA;
+        const int q0 = (wave * NA + i) * 8;
+        const int trow0 = (q0 >> 6) * 128 + h * 64 + (q0 & 63);
+        const int trow = trow0 + lrow;
+        const int lu = (lane & 7) ^ ((trow >> 1) & 7);
+        const int row = min(m0 + trow, a.m_pad - 1);
+        wsrc[h][i] = reinterpret_cast<const T*>(a.w) + (long)row * a.ktot + lu * VEC;
+        adst[h][i] = trow0 * 8;
+    });
+    long bbase[2][NB];
+    int bhw[2][NB], bcell[2][NB], bdst[2][NB];
+    const int HoWo = a.Ho * a.Wo;
+    static_for<2 * NB>([&](auto c) {
+        constexpr int h = decltype(c)::value / NB, i = decltype(c)::value % NB;
+        const int q0 = (wave * NB + i) * 8;
+        const int trow0 = (q0 >> 5) * 64 + h * 32 + (q0 & 31);
+        const int trow = trow0 + lrow;
+        const int lu = (lane & 7) ^ ((trow >> 1) & 7);
+        bcell[h][i] = lu * VEC;
+        bdst[h][i] = (BM + trow0) * 8;
+        const long p = p0 + trow;
+        if (p < a.P) {
+            const int n = (int)(p / HoWo);
+            const int rem = (int)(p - (long)n * HoWo);
+            const int ho = rem / a.Wo, wo = rem - ho * a.Wo;
+            const int hi = ho * a.stride - a.pad, wi = wo * a.stride - a.pad;
+            bhw[h][i] = (hi << 16) | (wi & 0xffff);     // both fit 16 signed bits (images up to 32k pixels a side)
+            bbase[h][i] = (((long)n * a.H + hi) * a.W + wi) * a.ldx + lu * VEC;
+        } else {
+            bhw[h][i] = (int)0x80008000;                // far outside every image: every tap reads the zero page
+            bbase[h][i] = 0;
+        }
+    });
+
+    int kr = 0, ks = 0, kc = 0, kofs = 0;   // tap / channel offset of the K tile being FETCHED
+    long tap = 0;
+    auto advance = [&]() {
+        kofs += BK;
+        kc += BK;
+        if (kc >= a.cin_k) {
+            kc = 0;
+            if (++ks == a.S) { ks = 0; ++kr; }
+        }
+        tap = ((long)kr * a.W + ks) * a.ldx + kc;
+    };
+    auto issue_a = [&](u32x4* base, auto hc) {
+        constexpr int h = decltype(hc)::value;
+        static_for<NA>([&](auto c) {
+            constexpr int i = decltype(c)::value;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc[h][i] + kofs),
+                                             (__attribute__((address_space(3))) void*)(base + adst[h][i]), 16, 0, 0);
+        });
+    };
+    auto issue_b = [&](u32x4* base, auto hc) {
+        constexpr int h = decltype(hc)::value;
+        static_for<NB>([&](auto c) {
+            constexpr int i = decltype(c)::value;
+            const int hi = bhw[h][i] >> 16, wi = (int)(short)(bhw[h][i] & 0xffff);
+            const bool ok = kc + bcell[h][i] < a.Cin && (unsigned)(hi + kr) < (unsigned)a.H && (unsigned)(wi + ks) < (unsigned)a.W;
+            const T* src = ok ? xg + bbase[h][i] + tap : zero;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(base + bdst[h][i]), 16, 0, 0);
+        });
+    };
+    typedef std::integral_constant<int, 0> H0;
+    typedef std::integral_constant<int, 1> H1;
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // fragment registers: A half (4 fragments x 2 K halves), both B halves (2 fragments x 2 K halves each)
+    f16x8 fa[2][4], fb[2][2][2];
+    const int r16 = lane & 15, kq = lane >> 4, fsw = (r16 >> 1) & 7;
+    const int off0 = r16 * 8 + ((0 + kq) ^ fsw), off1 = r16 * 8 + ((4 + kq) ^ fsw);
+    const int arow = wm * 128, brow = BM + wn * 64;
+    auto read_a = [&](const u32x4* st, int half) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            u32x4 v0 = st[(arow + half * 64 + i * 16) * 8 + off0];
+            u32x4 v1 = st[(arow + half * 64 + i * 16) * 8 + off1];
+            fa[0][i] = *reinterpret_cast<f16x8*>(&v0);
+            fa[1][i] = *reinterpret_cast<f16x8*>(&v1);
+        }
+    };
+    auto read_b = [&](const u32x4* st, auto hc) {
+        constexpr int h = decltype(hc)::value;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            u32x4 v0 = st[(brow + h * 32 + j * 16) * 8 + off0];
+            u32x4 v1 = st[(brow + h * 32 + j * 16) * 8 + off1];
+            fb[h][0][j] = *reinterpret_cast<f16x8*>(&v0);
+            fb[h][1][j] = *reinterpret_cast<f16x8*>(&v1);
+        }
+    };
+    auto mma = [&](auto ac, auto bc) {   // quadrant (a, b): 4 x 2 fragments x 2 K halves, channel order within the line
+        constexpr int ah = decltype(ac)::value, bh = decltype(bc)::value;
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[ah * 4 + i][bh * 2 + j] =
+                        __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[k][i], fb[bh][k][j], acc[ah * 4 + i][bh * 2 + j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+    };
+    // end of an interval: all of this wave's LDS reads have returned (they feed the MFMAs after the barrier), then the barrier
+#define YH_PP_SYNC()                                        \
+    do {                                                    \
+        __builtin_amdgcn_sched_barrier(0);                  \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
+        __builtin_amdgcn_s_barrier();                       \
+        __builtin_amdgcn_sched_barrier(0);                  \
+    } while (0)
+#define YH_PP_BARRIER()                      \
+    do {                                     \
+        __builtin_amdgcn_sched_barrier(0);   \
+        __builtin_amdgcn_s_barrier();        \
+        __builtin_amdgcn_sched_barrier(0);   \
+    } while (0)
+
+    const int nk = a.ktot / BK;
+    // prologue: K tile 0 into stage 0 (all four piece sets), everyone waits for everything
+    issue_a(smem, H0{});
+    issue_b(smem, H0{});
+    issue_b(smem, H1{});
+    issue_a(smem, H1{});
+    wait_vmcnt<0>();
+    YH_PP_BARRIER();
+    if (group == 1) YH_PP_BARRIER();   // stagger: group 1 starts one interval late
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const u32x4* cur = smem + (kt & 1) * STAGE_CELLS;
+        u32x4* nxt = smem + ((kt + 1) & 1) * STAGE_CELLS;
+        const bool more = kt + 1 < nk;
+        // ---- phase 1: quadrant (a0, b0)
+        read_a(cur, 0);
+        read_b(cur, H0{});
+        if (more) { advance(); issue_a(nxt, H0{}); }
+        // B[b1] of THIS tile must have landed before phase 2 reads it: at most A[a1](kt) and A[a0](kt+1) stay in flight
+        if (more) wait_vmcnt<2 * NA>(); else wait_vmcnt<NA>();
+        YH_PP_SYNC();
+        mma(H0{}, H0{});
+        YH_PP_BARRIER();
+        // ---- phase 2: quadrant (a0, b1)
+        read_b(cur, H1{});
+        if (more) issue_b(nxt, H0{});
+        // A[a1] of this tile before phase 3: A[a0], B[b0] of the next tile stay in flight
+        if (more) wait_vmcnt<NA + NB>(); else wait_vmcnt<0>();
+        YH_PP_SYNC();
+        mma(H0{}, H1{});
+        YH_PP_BARRIER();
+        // ---- phase 3: quadrant (a1, b1)
+        read_a(cur, 1);
+        if (more) issue_b(nxt, H1{});
+        YH_PP_SYNC();
+        mma(H1{}, H1{});
+        YH_PP_BARRIER();
+        // ---- phase 4: quadrant (a1, b0); no reads.  A[a0], B[b0] of the next tile before its phase 1: B[b1], A[a1] stay in flight
+        if (more) { issue_a(nxt, H1{}); wait_vmcnt<NA + NB>(); }
+        YH_PP_BARRIER();
+        mma(H1{}, H0{});
+        YH_PP_BARRIER();
+    }
+    if (group == 0) YH_PP_BARRIER();   // matches group 1's extra barrier at the start
+#undef YH_PP_SYNC
+#undef YH_PP_BARRIER
+
+    conv_epilogue<T, OutT, TM, TN, BN, WN>(a, acc, m0, p0, wm, wn, lane);
+}
+
+template <typename T, typename OutT, int WM, int WN>
+static int launch_pp(const ConvArgs& a0, hipStream_t stream) {
+    constexpr int BM = WM * 128, BN = WN * 64;
+    ConvArgs a = a0;
+    if (a.cin_k % (Prec<T>::VEC * 8)) return YH_EALIGN;
+    if (a.H >= 32768 || a.W >= 32768) return YH_EUNSUPPORTED;
+    a.m_tiles = (a.Cout + BM - 1) / BM;
+    a.p_tiles = (int)((a.P + BN - 1) / BN);
+    const long blocks = (long)a.m_tiles * a.p_tiles;
+    if (blocks <= 0 || blocks > 0x7fffffffL) return YH_EINVAL;
+    hipLaunchKernelGGL((conv_igemm_pp_kernel<T, OutT, WM, WN>), dim3((unsigned)blocks), dim3(512), 0, stream, a);
+    return check_launch();
+}
+
 template <typename T, typename OutT> static int dispatch_k64(const ConvArgs& a, int tile, hipStream_t s) {
     switch (tile) {
         case 61: return launch_k64<T, OutT, 256, 256, 2, 4, 2>(a, s);   // 8 waves, 128 KB of LDS
         case 62: return launch_k64<T, OutT, 128, 512, 1, 8, 2>(a, s);   // 8 waves, 160 KB
         case 63: return launch_k64<T, OutT, 256, 128, 2, 2, 3>(a, s);   // 4 waves (one per SIMD), 144 KB, 3 stages
+        case 64: return launch_pp<T, OutT, 2, 4>(a, s);                 // ping-pong 256 x 256
+        case 65: return launch_pp<T, OutT, 1, 8>(a, s);                 // ping-pong 128 x 512
+        case 66: return launch_pp<T, OutT, 4, 2>(a, s);                 // ping-pong 512 x 128
         default: return YH_EINVAL;
     }
 }
