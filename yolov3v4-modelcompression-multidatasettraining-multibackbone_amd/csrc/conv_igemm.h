@@ -123,6 +123,129 @@ __device__ __forceinline__ int swz_f(int g) { return (0x78 >> (2 * (g & 3))) & 3
 // 16 x 16 fragment (i, j) of its wave tile: bias + activation (+ residual) -> one 8-byte (f16) / 16-byte (f32) / 4-byte (i8)
 // NHWC store; optional 2x nearest store, stride-2 data-gradient phase scatter (ups 3 / 4), int8 requantisation, and the
 // per-tile BatchNorm partial sums of the training forward.
+template <typename T> struct ResVec { typedef f16x4 type; };
+template <> struct ResVec<float> { typedef f32x4 type; };
+template <> struct ResVec<int8_t> { typedef unsigned type; };
+
+// residual columns loaded ahead of their stores: about 16 registers' worth (the 4-waves-per-SIMD kernels have 128 in all)
+template <typename T, int TM, int TN> struct ResChunk {
+    static constexpr int value = sizeof(T) == 2 ? (8 / TM >= TN ? TN : (8 / TM >= 1 ? 8 / TM : 1)) : 1;
+};
+
+template <int ACT> __device__ __forceinline__ float activate_c(float v, float slope) {
+    if constexpr (ACT == YH_ACT_LEAKY) return v > 0.f ? v : v * slope;
+    else if constexpr (ACT == YH_ACT_RELU) return fmaxf(v, 0.f);
+    else if constexpr (ACT == YH_ACT_RELU6) return fminf(fmaxf(v, 0.f), 6.f);
+    else if constexpr (ACT == YH_ACT_HSWISH) return v * (fminf(fmaxf(v + 3.f, 0.f), 6.f) / 6.f);
+    else if constexpr (ACT == YH_ACT_MISH) return activate(v, YH_ACT_MISH, slope);
+    else return v;
+}
+
+// The common case of the epilogue - plain dense NHWC store (ups == 1) - with the activation fixed at compile time: the code a
+// wave executes for its 32 fragments is then ~1.5 k instructions instead of a 40 k-instruction body with every activation and
+// every store form unrolled per fragment (instruction-cache misses dominated the generic form on the 128 x 64 wave tiles).
+template <typename T, typename OutT, int TM, int TN, int BN, int WN, int ACT, typename AccT>
+__device__ __forceinline__ void conv_epilogue_plain(const ConvArgs& a, AccT (&acc)[TM][TN], const f32x4 (&bvs)[TM], const int m0,
+                                                    const long p0, const int wm, const int wn, const int lane) {
+    const int mq = (lane >> 4) << 2, pc = lane & 15;
+    OutT* const yg = reinterpret_cast<OutT*>(a.y);
+    const T* const rg = reinterpret_cast<const T*>(a.res);
+    const int mbase = m0 + wm * TM * 16 + mq;
+    const long pbase = p0 + wn * TN * 16 + pc;
+    auto value = [&](auto ic, auto jc, int e) {
+        constexpr int i = decltype(ic)::value, j = decltype(jc)::value;
+        if constexpr (sizeof(T) == 1) {
+            const float y = activate_c<ACT>((float)acc[i][j][e] * a.acc_scale + bvs[i][e], a.slope);
+            const float q = round_clamp_i8(y * a.inv_out_scale);
+            return sizeof(OutT) == 1 ? q : q * a.out_scale;
+        } else {
+            return activate_c<ACT>((float)acc[i][j][e] + bvs[i][e], a.slope);
+        }
+    };
+    if constexpr (sizeof(T) != 1) {
+        if (a.stats_part != nullptr) {   // BatchNorm partial sums (see conv_epilogue): one channel quad at a time
+            float* const row = a.stats_part + ((long)(p0 / BN) * WN + wn) * 2 * a.Cout;
+            static_for<TM>([&](auto ic) {
+                constexpr int i = decltype(ic)::value;
+                float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+                static_for<TN>([&](auto jc) {
+                    constexpr int j = decltype(jc)::value;
+                    if (pbase + j * 16 < a.P) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float q = (float)(OutT)value(ic, jc, e);
+                            s1[e] += q;
+                            s2[e] = fmaf(q, q, s2[e]);
+                        }
+                    }
+                });
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float t1 = row16_sum(s1[e]), t2 = row16_sum(s2[e]);
+                    const int m = mbase + i * 16 + e;
+                    if (pc == 15 && m < a.Cout) {
+                        row[m] = t1;
+                        row[a.Cout + m] = t2;
+                    }
+                }
+            });
+        }
+    }
+    typedef typename ResVec<T>::type res_t;
+    constexpr int JCH = ResChunk<T, TM, TN>::value;
+    static_assert(TN % JCH == 0, "column chunks must tile the wave tile");
+    static_for<TN / JCH>([&](auto cc) {
+        constexpr int j0 = decltype(cc)::value * JCH;
+        res_t rv[JCH][TM];
+        bool have_res = false;
+        if constexpr (sizeof(T) != 1) {
+            have_res = rg != nullptr;
+            if (have_res) {
+                static_for<JCH>([&](auto jc) {
+                    constexpr int jj = decltype(jc)::value;
+                    const long p = pbase + (j0 + jj) * 16;
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) {
+                        rv[jj][i] = res_t{};
+                        if (p < a.P && mbase + i * 16 < a.Cout) rv[jj][i] = *reinterpret_cast<const res_t*>(rg + p * a.ldr + mbase + i * 16);
+                    }
+                });
+                static_for<JCH>([&](auto jc) {   // one wait for the whole chunk, before its first store
+                    constexpr int jj = decltype(jc)::value;
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) {
+                        res_t t = rv[jj][i];
+                        asm volatile("" : "+v"(t));
+                        rv[jj][i] = t;
+                    }
+                });
+            }
+        }
+        static_for<JCH>([&](auto jc) {
+            constexpr int jj = decltype(jc)::value;
+            typedef std::integral_constant<int, j0 + jj> J;
+            const long p = pbase + (j0 + jj) * 16;
+            if (p >= a.P) return;
+            OutT* const prow = yg + p * a.ldy;
+            static_for<TM>([&](auto ic) {
+                constexpr int i = decltype(ic)::value;
+                const int m = mbase + i * 16;
+                if (m >= a.Cout) return;
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = value(ic, J{}, e);
+                if constexpr (sizeof(T) != 1) {
+                    if (have_res) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] += (float)rv[jj][i][e];
+                    }
+                }
+                store4<OutT>(prow + m, v[0], v[1], v[2], v[3]);
+            });
+        });
+    });
+}
+
 template <typename T, typename OutT, int TM, int TN, int BN, int WN, typename AccT>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, AccT (&acc)[TM][TN], const int m0, const long p0, const int wm,
                                               const int wn, const int lane) {
@@ -130,104 +253,177 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, AccT (&acc)[TM]
     const int mq = (lane >> 4) << 2, pc = lane & 15;
     OutT* const yg = reinterpret_cast<OutT*>(a.y);
     const T* const rg = reinterpret_cast<const T*>(a.res);
-    float st1[TM][4], st2[TM][4];   // BatchNorm batch statistics of this wave's outputs (training forward only)
+    // Every LOAD of the epilogue is issued before the first STORE: loads and stores share one in-order counter (vmcnt), so a
+    // bias or residual load placed after a store has to wait for that store's write acknowledgement (~2000 cycles under load;
+    // measured with s_memtime stamps: 70 000 cycles for the 32 fragments of a 128 x 64 wave tile, as long as 21 K tiles).
+    // Bias (TM x 4 floats) up front; residual fragments in chunks of pixel columns (~32 registers), loads of a chunk before its stores.
+    f32x4 bvs[TM];
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+    for (int i = 0; i < TM; ++i) {
+        const int m = m0 + wm * TM * 16 + i * 16 + mq;
+        bvs[i] = m < a.Cout ? *reinterpret_cast<const f32x4*>(a.bias + m) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    // consume the loaded registers HERE, on the straight-line path: the compiler then waits for the loads once, now; left to
+    // their first uses inside the branchy code below, it re-waits (vmcnt(0), i.e. also for every store issued so far) in each
+    // conditional block because some path around the previous wait exists
 #pragma unroll
-        for (int e = 0; e < 4; ++e) st1[i][e] = st2[i][e] = 0.f;
-    // compile-time j (template recursion): with 8 x 4 fragments per wave the plain `#pragma unroll` form is left rolled and the
-    // accumulators would be indexed at run time, i.e. live in scratch
-    static_for<TN>([&](auto jc) {
-        constexpr int j = decltype(jc)::value;
-        const long p = p0 + wn * TN * 16 + j * 16 + pc;
-        if (p >= a.P) return;
-        long opix = p;
-        int wo2 = 0, ho4 = 0, wo4 = 0;
-        if (a.ups == 2) {
-            const int n = (int)(p / HoWo);
-            const int rem = (int)(p - (long)n * HoWo);
-            const int ho = rem / a.Wo, wo = rem - ho * a.Wo;
-            wo2 = 2 * a.Wo;
-            opix = ((long)n * 2 * a.Ho + 2 * ho) * wo2 + 2 * wo;
-        } else if (a.ups == 3) {  // phase scatter (stride-2 data gradient): every other pixel of a y_h x y_w tensor
-            const int n = (int)(p / HoWo);
-            const int rem = (int)(p - (long)n * HoWo);
-            const int ho = rem / a.Wo, wo = rem - ho * a.Wo;
-            opix = ((long)n * a.y_h + 2 * ho + a.y_off_h) * a.y_w + 2 * wo + a.y_off_w;
-        } else if (a.ups == 4) {  // all four phases: the 2x2 output block of (n, ho, wo); the row group picks the corner
-            const int n = (int)(p / HoWo);
-            const int rem = (int)(p - (long)n * HoWo);
-            ho4 = rem / a.Wo;
-            wo4 = rem - ho4 * a.Wo;
-            opix = ((long)n * a.y_h + 2 * ho4) * a.y_w + 2 * wo4;
-        }
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const int m = m0 + wm * TM * 16 + i * 16 + mq;
-            if (m >= a.Cout) continue;
-            int mc = m;          // channel within the destination row
-            long pix = opix;     // destination pixel
-            if (a.ups == 4) {
-                const int cpp = a.Cout >> 2, ph = m / cpp;
-                mc = m - ph * cpp;
-                if (2 * ho4 + (ph >> 1) >= a.y_h || 2 * wo4 + (ph & 1) >= a.y_w) continue;
-                pix = opix + (long)(ph >> 1) * a.y_w + (ph & 1);
-            }
-            const f32x4 bv = *reinterpret_cast<const f32x4*>(a.bias + m);
-            float v[4];
-            if constexpr (sizeof(T) == 1) {
-                // PTQ eval arithmetic (quantized_ptq_cos.py:288-296,543-567,717): dequantised conv + quantised bias,
-                // activation in fp32, then round-half-away/clamp onto the activation grid
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float y = activate((float)acc[i][j][e] * a.acc_scale + bv[e], a.act, a.slope);
-                    const float q = round_clamp_i8(y * a.inv_out_scale);
-                    v[e] = sizeof(OutT) == 1 ? q : q * a.out_scale;
-                }
-            } else {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = activate((float)acc[i][j][e] + bv[e], a.act, a.slope);
-                if (a.stats_part != nullptr) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float q = (float)(OutT)v[e];
-                        st1[i][e] += q;
-                        st2[i][e] = fmaf(q, q, st2[i][e]);
-                    }
-                }
-                if (rg != nullptr) {
-                    float r4[4];
-                    load4<T>(rg + (a.ups >= 3 ? pix : p) * a.ldr + mc, r4);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] += r4[e];
-                }
-            }
-            OutT* dst = yg + pix * a.ldy + mc;
-            store4<OutT>(dst, v[0], v[1], v[2], v[3]);
-            if (a.ups == 2) {
-                store4<OutT>(dst + a.ldy, v[0], v[1], v[2], v[3]);
-                store4<OutT>(dst + (long)wo2 * a.ldy, v[0], v[1], v[2], v[3]);
-                store4<OutT>(dst + (long)(wo2 + 1) * a.ldy, v[0], v[1], v[2], v[3]);
-            }
-        }
-        });
-    if (a.stats_part != nullptr) {
-        // sum over the 16 pixel lanes (lane & 15) of every channel quad, then one row of partials per (pixel tile, wn)
-        float* const row = a.stats_part + ((long)(p0 / BN) * WN + wn) * 2 * a.Cout;
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                // 16-lane row sums on the DPP path (row_shr 1, 2, 4, 8 with zero fill): lane 15 of each row ends with the total
-                const float s1 = row16_sum(st1[i][e]), s2 = row16_sum(st2[i][e]);
-                const int m = m0 + wm * TM * 16 + i * 16 + mq + e;
-                if (pc == 15 && m < a.Cout) {
-                    row[m] = s1;
-                    row[a.Cout + m] = s2;
-                }
-            }
+    for (int i = 0; i < TM; ++i) asm volatile("" ::"v"(bvs[i]));
+    if (a.ups == 1) {
+        switch (a.act) {
+#define YH_PLAIN(A) case A: conv_epilogue_plain<T, OutT, TM, TN, BN, WN, A>(a, acc, bvs, m0, p0, wm, wn, lane); return
+            YH_PLAIN(YH_ACT_LINEAR); YH_PLAIN(YH_ACT_LEAKY); YH_PLAIN(YH_ACT_RELU); YH_PLAIN(YH_ACT_RELU6); YH_PLAIN(YH_ACT_HSWISH);
+            YH_PLAIN(YH_ACT_MISH);
+#undef YH_PLAIN
+            default: break;
         }
     }
+    // ---- the other store forms (2x nearest store, stride-2 data-gradient scatters), run-time activation
+    struct Col { bool ok; long p, opix; int wo2, ho4, wo4; };
+    auto column = [&](int j) {   // destination geometry of pixel column j of the wave tile
+        Col c;
+        c.p = p0 + wn * TN * 16 + j * 16 + pc;
+        c.ok = c.p < a.P;
+        c.opix = c.p;
+        c.wo2 = c.ho4 = c.wo4 = 0;
+        if (!c.ok) return c;
+        if (a.ups == 2) {
+            const int n = (int)(c.p / HoWo);
+            const int rem = (int)(c.p - (long)n * HoWo);
+            const int ho = rem / a.Wo, wo = rem - ho * a.Wo;
+            c.wo2 = 2 * a.Wo;
+            c.opix = ((long)n * 2 * a.Ho + 2 * ho) * c.wo2 + 2 * wo;
+        } else if (a.ups == 3) {  // phase scatter (stride-2 data gradient): every other pixel of a y_h x y_w tensor
+            const int n = (int)(c.p / HoWo);
+            const int rem = (int)(c.p - (long)n * HoWo);
+            const int ho = rem / a.Wo, wo = rem - ho * a.Wo;
+            c.opix = ((long)n * a.y_h + 2 * ho + a.y_off_h) * a.y_w + 2 * wo + a.y_off_w;
+        } else if (a.ups == 4) {  // all four phases: the 2x2 output block of (n, ho, wo); the row group picks the corner
+            const int n = (int)(c.p / HoWo);
+            const int rem = (int)(c.p - (long)n * HoWo);
+            c.ho4 = rem / a.Wo;
+            c.wo4 = rem - c.ho4 * a.Wo;
+            c.opix = ((long)n * a.y_h + 2 * c.ho4) * a.y_w + 2 * c.wo4;
+        }
+        return c;
+    };
+    struct Row { bool ok; int mc; long pix; };
+    auto channel = [&](const Col& c, int i) {   // destination of channel quad i in column c
+        Row r;
+        const int m = m0 + wm * TM * 16 + i * 16 + mq;
+        r.ok = c.ok && m < a.Cout;
+        r.mc = m;
+        r.pix = c.opix;
+        if (a.ups == 4 && r.ok) {
+            const int cpp = a.Cout >> 2, ph = m / cpp;
+            r.mc = m - ph * cpp;
+            if (2 * c.ho4 + (ph >> 1) >= a.y_h || 2 * c.wo4 + (ph & 1) >= a.y_w) r.ok = false;
+            r.pix = c.opix + (long)(ph >> 1) * a.y_w + (ph & 1);
+        }
+        return r;
+    };
+
+    if constexpr (sizeof(T) != 1) {
+        if (a.stats_part != nullptr) {
+            // BatchNorm batch statistics of this wave's outputs (training forward: plain dense store, no residual), one channel
+            // quad at a time so that only 8 sums are live: values as stored (rounded to the output type), summed over the wave's
+            // pixel columns in column order, then over the 16 pixel lanes on the DPP path (row_shr 1, 2, 4, 8 with zero fill:
+            // lane 15 of each row ends with the total); one row of partials per (pixel tile, wave column)
+            float* const row = a.stats_part + ((long)(p0 / BN) * WN + wn) * 2 * a.Cout;
+            static_for<TM>([&](auto ic) {
+                constexpr int i = decltype(ic)::value;
+                float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+                static_for<TN>([&](auto jc) {
+                    constexpr int j = decltype(jc)::value;
+                    if (p0 + wn * TN * 16 + j * 16 + pc < a.P) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float q = (float)(OutT)activate((float)acc[i][j][e] + bvs[i][e], a.act, a.slope);
+                            s1[e] += q;
+                            s2[e] = fmaf(q, q, s2[e]);
+                        }
+                    }
+                });
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float t1 = row16_sum(s1[e]), t2 = row16_sum(s2[e]);
+                    const int m = m0 + wm * TM * 16 + i * 16 + mq + e;
+                    if (pc == 15 && m < a.Cout) {
+                        row[m] = t1;
+                        row[a.Cout + m] = t2;
+                    }
+                }
+            });
+        }
+    }
+
+    typedef typename ResVec<T>::type res_t;
+    constexpr int JCH = ResChunk<T, TM, TN>::value;
+    static_assert(TN % JCH == 0, "column chunks must tile the wave tile");
+    static_for<TN / JCH>([&](auto cc) {
+        constexpr int j0 = decltype(cc)::value * JCH;
+        res_t rv[JCH][TM];
+        if constexpr (sizeof(T) != 1) {
+            if (rg != nullptr) {
+                static_for<JCH>([&](auto jc) {
+                    constexpr int jj = decltype(jc)::value;
+                    const Col c = column(j0 + jj);
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) {
+                        const Row r = channel(c, i);
+                        rv[jj][i] = res_t{};
+                        if (r.ok) rv[jj][i] = *reinterpret_cast<const res_t*>(rg + (a.ups >= 3 ? r.pix : c.p) * a.ldr + r.mc);
+                    }
+                });
+                static_for<JCH>([&](auto jc) {   // one wait for the whole chunk, before its first store (see the bias above)
+                    constexpr int jj = decltype(jc)::value;
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) {
+                        res_t t = rv[jj][i];
+                        asm volatile("" : "+v"(t));
+                        rv[jj][i] = t;
+                    }
+                });
+            }
+        }
+        // compile-time j (template recursion): with 8 x 4 fragments per wave a plain `#pragma unroll` is left rolled and the
+        // accumulators would be indexed at run time, i.e. live in scratch
+        static_for<JCH>([&](auto jc) {
+            constexpr int jj = decltype(jc)::value, j = j0 + jj;
+            const Col c = column(j);
+            if (!c.ok) return;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const Row r = channel(c, i);
+                if (!r.ok) continue;
+                const f32x4 bv = bvs[i];
+                float v[4];
+                if constexpr (sizeof(T) == 1) {
+                    // PTQ eval arithmetic (quantized_ptq_cos.py:288-296,543-567,717): dequantised conv + quantised bias,
+                    // activation in fp32, then round-half-away/clamp onto the activation grid
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float y = activate((float)acc[i][j][e] * a.acc_scale + bv[e], a.act, a.slope);
+                        const float q = round_clamp_i8(y * a.inv_out_scale);
+                        v[e] = sizeof(OutT) == 1 ? q : q * a.out_scale;
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = activate((float)acc[i][j][e] + bv[e], a.act, a.slope);
+                    if (rg != nullptr) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] += (float)rv[jj][i][e];
+                    }
+                }
+                OutT* dst = yg + r.pix * a.ldy + r.mc;
+                store4<OutT>(dst, v[0], v[1], v[2], v[3]);
+                if (a.ups == 2) {
+                    store4<OutT>(dst + a.ldy, v[0], v[1], v[2], v[3]);
+                    store4<OutT>(dst + (long)c.wo2 * a.ldy, v[0], v[1], v[2], v[3]);
+                    store4<OutT>(dst + (long)(c.wo2 + 1) * a.ldy, v[0], v[1], v[2], v[3]);
+                }
+            }
+        });
+    });
 }
 
 // conv_igemm_k64.hip: full-line K step kernels (tile codes 61 - 63); f16 and int8, OutT by out_f32

@@ -367,8 +367,10 @@ template <int TM, int TN> struct MmaStepRM<int8_t, TM, TN> {
     }
 };
 
+// two workgroups per CU are the design point of these kernels (73.7 KB of LDS for the 8-wave tiles): 8 waves -> 4 per SIMD, i.e. at
+// most 128 registers; 4 waves -> 2 per SIMD
 template <typename T, typename OutT, int BM, int BN, int WM, int WN, int STAGES, int ABL = 0>
-__global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm_glds_kernel(const ConvArgs a) {
+__global__ __launch_bounds__(WM * WN * 64, (WM * WN * 2) / 4) void conv_igemm_glds_kernel(const ConvArgs a) {
     constexpr int VEC = Prec<T>::VEC, BK = VEC * 4;
     constexpr int NW = WM * WN;
     constexpr int TM = BM / WM / 16, TN = BN / WN / 16;

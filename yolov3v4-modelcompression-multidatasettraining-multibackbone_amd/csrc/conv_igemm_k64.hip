@@ -1,6 +1,21 @@
 // Full-line K step implicit-GEMM convolution kernels (tile codes 61 - 63) - see the comment block below.
 #include "conv_igemm.h"
 
+// Profiling build only (`make timing` -> libyolo_hip_timing.so, loaded through YOLO_HIP_LIB): thread 0 of every workgroup of the
+// ping-pong kernel stores s_memtime at five points (start, loader set up, first K tile landed, K loop done, epilogue done).
+#ifdef YH_PP_TIMING
+__device__ unsigned long long* g_pp_stamps;
+extern "C" int yh_debug_set_pp_stamps(void* p) {
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_pp_stamps), &p, sizeof(p));
+}
+#define YH_STAMP(k)                                                                                   \
+    do {                                                                                              \
+        if (threadIdx.x == 0 && g_pp_stamps) g_pp_stamps[(size_t)blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+#else
+#define YH_STAMP(k) do {} while (0)
+#endif
+
 namespace yh {
 
 // ---------------------------------------------------------------------------------------------------
@@ -236,6 +251,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_pp_kernel(const ConvArgs a)
     constexpr int STAGE_CELLS = 8 * (BM + BN);
     __shared__ u32x4 smem[2 * STAGE_CELLS];           // the only LDS object of the kernel
 
+    YH_STAMP(0);
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wm = wave / WN, wn = wave % WN;
@@ -388,12 +404,14 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_pp_kernel(const ConvArgs a)
 
     const int nk = a.ktot / BK;
     // prologue: K tile 0 into stage 0 (all four piece sets), everyone waits for everything
+    YH_STAMP(1);
     issue_a(smem, H0{});
     issue_b(smem, H0{});
     issue_b(smem, H1{});
     issue_a(smem, H1{});
     wait_vmcnt<0>();
     YH_PP_BARRIER();
+    YH_STAMP(2);
     if (group == 1) YH_PP_BARRIER();   // stagger: group 1 starts one interval late
 
     for (int kt = 0; kt < nk; ++kt) {
@@ -432,8 +450,13 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_pp_kernel(const ConvArgs a)
     if (group == 0) YH_PP_BARRIER();   // matches group 1's extra barrier at the start
 #undef YH_PP_SYNC
 #undef YH_PP_BARRIER
+    YH_STAMP(3);
 
     conv_epilogue<T, OutT, TM, TN, BN, WN>(a, acc, m0, p0, wm, wn, lane);
+#ifdef YH_PP_TIMING
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the wave's stores have left
+    YH_STAMP(4);
+#endif
 }
 
 template <typename T, typename OutT, int WM, int WN>

@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), 'libyolo_hip.so')
+# YOLO_HIP_LIB: another build of the same library (profiling builds of csrc/Makefile); never a different implementation
+LIB_PATH = os.environ.get('YOLO_HIP_LIB') or os.path.join(os.path.dirname(_HERE), 'libyolo_hip.so')
 
 YH_F16, YH_F32, YH_I8 = 0, 1, 2
 ACT_CODES = {'linear': 0, 'leaky': 1, 'relu': 2, 'relu6': 3, 'h_swish': 4, 'mish': 5}
