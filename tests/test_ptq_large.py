@@ -7,9 +7,12 @@ Goldens come from the REFERENCE's own modules (tests/golden/make_golden_ptq.py):
 * ptq_mini_max.npz — the mini net calibrated BY the reference with shortcut_way=2 (COSPTQuantizedShortcut_max,
   quantized_ptq_cos.py:1058-1340); ptq_mini.npz is the shortcut_way=1 twin used by tests/test_ptq.py.
 
-Tolerance: the int8 engine accumulates exactly (int32) where the reference's fake-quant conv accumulates in fp32, so outputs
-may differ by one grid step at rounding ties; through 75-110 layers a flipped step can move a few later values.  Boxes are
-compared in pixels, confidences absolutely, and detections through the synthetic mAP protocol.
+Tolerance: the int8 engine accumulates exactly (int32) where the reference's fake-quant conv accumulates in fp32 (sums of up to
+9216 products of magnitude <= 127^2 are not exact in fp32), so values that sit on a rounding tie may land one grid step apart, and
+through 75-110 layers a flipped step can move a few later values.  The raw head tensors are therefore compared in units of the
+head conv's activation grid (at most one step, a few percent of the values), decoded boxes with the matching relative bound
+(one step of the log-size logit scales w / h by exp(step)), and detections through the synthetic mAP protocol.  The host
+emulation of the same plan, which accumulates in fp32 like the reference, matches the stored rows exactly (CPU tier).
 """
 import os
 
@@ -41,18 +44,24 @@ def build_pair(rel, size, batch):
     return fm, qm, x
 
 
-def compare(io, fx, box_px, conf_abs, frac_allowed):
+def compare(io, fx, box_px, conf_abs, frac_allowed, box_rel=0.0):
     rs = int(fx['row_stride'])
     ref = torch.from_numpy(fx['inf_rows'])
     got = io[:, ::rs]
     assert got.shape == ref.shape
     db, dc = (got[..., :4] - ref[..., :4]).abs(), (got[..., 4:] - ref[..., 4:]).abs()
-    stats = dict(box_max=db.max().item(), conf_max=dc.max().item(), box_frac=(db > 0.05).float().mean().item(),
-                 conf_frac=(dc > 2e-3).float().mean().item())
+    bound = box_px + box_rel * ref[..., 2:4].abs().max(-1, keepdim=True)[0]
+    stats = dict(box_max=db.max().item(), box_worst_vs_bound=(db / bound).max().item(), conf_max=dc.max().item(),
+                 box_frac=(db > 0.05).float().mean().item(), conf_frac=(dc > 2e-3).float().mean().item())
     print('int8 vs reference eval:', {k: round(v, 5) for k, v in stats.items()})
-    assert stats['box_max'] <= box_px and stats['conf_max'] <= conf_abs, stats
+    assert stats['box_worst_vs_bound'] <= 1.0 and stats['conf_max'] <= conf_abs, stats
     assert stats['box_frac'] <= frac_allowed and stats['conf_frac'] <= frac_allowed, stats
     return stats
+
+
+def head_steps(qm):
+    """Activation-grid step of every yolo head conv (the conv right before each YOLOLayer)."""
+    return [float(qm.module_list[i - 1][0].activation_quantizer.scale) for i in qm.yolo_layers]
 
 
 @pytest.mark.parametrize('name', ['yolov3_608', 'yolov4_640'])
@@ -99,7 +108,16 @@ def test_hip_int8_engine_matches_reference_eval_on_baseline_graphs(name):
     eng = qm.__dict__['_hip_engine']
     assert eng is not None and eng.precision == 'int8'
     io = io.cpu()
-    compare(io, fx, box_px=1.5, conf_abs=0.05, frac_allowed=0.02)
+    steps = head_steps(qm)
+    # raw head logits in grid steps (the head conv's output is on its activation grid in both implementations)
+    worst, frac = 0.0, 0.0
+    for i, (r, step) in enumerate(zip(raws, steps)):
+        d = (r.cpu().reshape(-1)[::997] - torch.from_numpy(fx['raw%d_rows' % i])).abs() / step
+        worst, frac = max(worst, d.max().item()), max(frac, (d > 0.5).float().mean().item())
+    print('raw heads: worst %.3f grid steps, %.4f of the sampled values off by a step' % (worst, frac))
+    assert worst <= 1.001 and frac <= 0.05
+    # decoded rows: xy / small boxes within 1.5 px; w, h scale by exp(one step of the log-size logit)
+    compare(io, fx, box_px=1.5, conf_abs=0.05, frac_allowed=0.05, box_rel=float(np.expm1(max(steps))))
     conf = float(torch.quantile(ref_full[..., 4].flatten(), 0.985)) * 0.999
     gt = non_max_suppression(ref_full.clone(), conf, 0.6, multi_label=False)
     assert sum(0 if g is None else len(g) for g in gt) >= 10

@@ -824,7 +824,7 @@ template <typename T, typename OutT> static int dispatch_tile(const ConvArgs& a,
         case 31: return launch_glds<T, OutT, 128, 128, 2, 2, 4>(a, s);
         // full-line K step (64 f16 channels), 128 x 64 per wave: 61 = 256 x 256, 62 = 128 x 512 (8 waves, 2 stages),
         // 63 = 256 x 128 (4 waves, 3 stages)
-        case 61: case 62: case 63: case 64: case 65: case 66:
+        case 61: case 62: case 63: case 64: case 65: case 66: case 67: case 68: case 69:
             if constexpr (sizeof(T) == 2) return launch_k64_tile(a, tile, YH_F16, std::is_same<OutT, float>::value ? 1 : 0, s);
             else return YH_EINVAL;
         case 32: return launch_glds<T, OutT, 64, 256, 1, 4, 4>(a, s);
@@ -879,9 +879,39 @@ extern "C" int yh_qconv_pack_weights(const float* q_weight, float w_scale, const
     return check_launch();
 }
 
+// The ping-pong kernels (conv_igemm_k64.hip) against the ring kernels, by a cost model fitted to per-layer A/B runs on MI355X
+// (profiles/r02_conv_tile_ab.txt, in-kernel stamps profiles/r02_pp_timing.txt):
+//   ping-pong: one 8-wave workgroup per CU; per workgroup ~20 000 cycles of set-up, first-tile latency and epilogue plus 3 300 per
+//              64-channel K tile (the global -> LDS delivery of a CU saturates at ~20 B/clk: 64 KB per K tile of a 256 x 256 tile);
+//   ring:      ~420 kFLOP per cycle chip-wide on 3x3 layers (880 TFLOP/s at 2.1 GHz), two workgroups per CU hiding each other's
+//              prologue and epilogue.
+// Long K (3x3 over >= 256 channels) with a workgroup count that fills whole rounds of 256 CUs goes to ping-pong; 1x1 layers
+// (4 - 16 K tiles: the fixed cost dominates) and everything else stay on the ring kernels.
+static int pick_pp_tile(const yh_conv_desc* d) {
+    if (d->dtype != YH_F16 || d->ups == 4 || d->cin != d->cin_k || d->cin_k % 64) return 0;
+    const int taps = d->kh * d->kw;
+    if (taps < 4 || d->cout < 256) return 0;
+    const long P = (long)d->n * d->ho * d->wo;
+    // 32-bit element offsets inside the kernel
+    if ((long)d->n * d->h * d->w_in * d->ldx + (long)(d->kh + 1) * d->w_in * d->ldx >= 0x7fffffffL) return 0;
+    if ((long)d->m_pad * taps * d->cin_k >= 0x7fffffffL || d->h >= 32768 || d->w_in >= 32768) return 0;
+    const double flops = 2.0 * (double)P * d->cout * taps * d->cin;
+    const double ring = flops / 420e3;
+    const long nk = (long)taps * d->cin_k / 64;
+    auto pp = [&](int bm, int bn) {
+        const long blocks = (long)((d->cout + bm - 1) / bm) * ((P + bn - 1) / bn);
+        return (double)((blocks + 255) / 256) * (20000.0 + 3300.0 * nk);
+    };
+    const double c64 = pp(256, 256), c66 = d->cout >= 512 ? pp(512, 128) : 1e30;
+    const double best = c64 < c66 ? c64 : c66;
+    if (best > 0.95 * ring) return 0;
+    return c66 <= c64 ? 66 : 64;
+}
+
 extern "C" int yh_conv2d_tile(const yh_conv_desc* d) {
     if (!d) return YH_EINVAL;
     if (d->tile != 0) return d->tile;
+    if (const int pp = pick_pp_tile(d)) return pp;
     const int t = yh::pick_tile(d->cout, (long)d->n * d->ho * d->wo, d->cin_k, d->dtype == YH_F16 ? 8 : 4, d->kh * d->kw);
     return (d->dtype == YH_I8 && t == 3) ? 24 : t;
 }
@@ -894,9 +924,9 @@ static bool tile_geometry(int tile, int* bn, int* wn) {
         case 4: case 14: case 24: case 34: *bn = 128; *wn = 2; return true;
         case 5: case 15: case 25: case 35: *bn = 64; *wn = 2; return true;
         case 6: case 16: case 26: case 51: case 52: *bn = 128; *wn = 2; return true;
-        case 27: case 61: case 64: *bn = 256; *wn = 4; return true;
-        case 62: case 65: *bn = 512; *wn = 8; return true;
-        case 63: case 66: *bn = 128; *wn = 2; return true;
+        case 27: case 61: case 64: case 67: *bn = 256; *wn = 4; return true;
+        case 62: case 65: case 68: *bn = 512; *wn = 8; return true;
+        case 63: case 66: case 69: *bn = 128; *wn = 2; return true;
         default: return false;
     }
 }
@@ -958,9 +988,9 @@ extern "C" int yh_conv2d_fwd(const yh_conv_desc* d, void* stream) {
     }
     hipStream_t s = (hipStream_t)stream;
     int tile = d->tile;
-    if (d->ups == 4 && tile == 0) {   // only the LDS-DMA kernels carry the four-phase epilogue
+    if (tile == 0) {
         tile = yh_conv2d_tile(d);
-        if (!(tile >= 21 && tile <= 35)) tile = 24;
+        if (d->ups == 4 && !(tile >= 21 && tile <= 35)) tile = 24;   // only the LDS-DMA ring kernels are used for the four-phase scatter
     }
     if (d->dtype == YH_F16) {
         return d->out_f32 ? dispatch_tile<f16, float>(a, tile, s) : dispatch_tile<f16, f16>(a, tile, s);

@@ -10,10 +10,17 @@ extern "C" int yh_debug_set_pp_stamps(void* p) {
 }
 #define YH_STAMP(k)                                                                                   \
     do {                                                                                              \
-        if (threadIdx.x == 0 && g_pp_stamps) g_pp_stamps[(size_t)blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memtime(); \
+        if (threadIdx.x == 0 && g_pp_stamps) g_pp_stamps[(size_t)blockIdx.x * 64 + (k)] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+// per-segment stamps of one K tile (kt == 4) for wave 0 (group 0) and wave 4 (group 1): slot 8 + 24 * group + 6 * phase + point
+#define YH_FINE(kt, phase, point)                                                                     \
+    do {                                                                                              \
+        if ((kt) == 4 && (threadIdx.x & 255) == 0 && g_pp_stamps)                                     \
+            g_pp_stamps[(size_t)blockIdx.x * 64 + 8 + 24 * (threadIdx.x >> 8) + 6 * (phase) + (point)] = __builtin_amdgcn_s_memtime(); \
     } while (0)
 #else
 #define YH_STAMP(k) do {} while (0)
+#define YH_FINE(kt, phase, point) do {} while (0)
 #endif
 
 namespace yh {
@@ -418,34 +425,35 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_pp_kernel(const ConvArgs a)
         const u32x4* cur = smem + (kt & 1) * STAGE_CELLS;
         u32x4* nxt = smem + ((kt + 1) & 1) * STAGE_CELLS;
         const bool more = kt + 1 < nk;
-        // ---- phase 1: quadrant (a0, b0)
-        read_a(cur, 0);
-        read_b(cur, H0{});
-        if (more) { advance(); issue_a(nxt, H0{}); }
-        // B[b1] of THIS tile must have landed before phase 2 reads it: at most A[a1](kt) and A[a0](kt+1) stay in flight
-        if (more) wait_vmcnt<2 * NA>(); else wait_vmcnt<NA>();
-        YH_PP_SYNC();
-        mma(H0{}, H0{});
-        YH_PP_BARRIER();
-        // ---- phase 2: quadrant (a0, b1)
-        read_b(cur, H1{});
-        if (more) issue_b(nxt, H0{});
-        // A[a1] of this tile before phase 3: A[a0], B[b0] of the next tile stay in flight
-        if (more) wait_vmcnt<NA + NB>(); else wait_vmcnt<0>();
-        YH_PP_SYNC();
-        mma(H0{}, H1{});
-        YH_PP_BARRIER();
+        // one phase = LOAD segment, barrier, MFMA segment, barrier (YH_FINE: profiling-build timestamps, no code otherwise)
+#define YH_PP_PHASE(P, LOADS, MMA)                                  \
+        YH_FINE(kt, P, 0);                                          \
+        LOADS;                                                      \
+        __builtin_amdgcn_sched_barrier(0);                          \
+        YH_FINE(kt, P, 1);                                          \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         \
+        YH_FINE(kt, P, 2);                                          \
+        __builtin_amdgcn_s_barrier();                               \
+        __builtin_amdgcn_sched_barrier(0);                          \
+        YH_FINE(kt, P, 3);                                          \
+        MMA;                                                        \
+        __builtin_amdgcn_sched_barrier(0);                          \
+        YH_FINE(kt, P, 4);                                          \
+        __builtin_amdgcn_s_barrier();                               \
+        __builtin_amdgcn_sched_barrier(0);                          \
+        YH_FINE(kt, P, 5)
+        // ---- phase 1: quadrant (a0, b0).  B[b1] of THIS tile must have landed before phase 2 reads it: at most A[a1](kt) and
+        // A[a0](kt+1) stay in flight
+        YH_PP_PHASE(0, { read_a(cur, 0); read_b(cur, H0{}); if (more) { advance(); issue_a(nxt, H0{}); }
+                         if (more) wait_vmcnt<2 * NA>(); else wait_vmcnt<NA>(); }, mma(H0{}, H0{}));
+        // ---- phase 2: quadrant (a0, b1).  A[a1] of this tile before phase 3: A[a0], B[b0] of the next tile stay in flight
+        YH_PP_PHASE(1, { read_b(cur, H1{}); if (more) issue_b(nxt, H0{});
+                         if (more) wait_vmcnt<NA + NB>(); else wait_vmcnt<0>(); }, mma(H0{}, H1{}));
         // ---- phase 3: quadrant (a1, b1)
-        read_a(cur, 1);
-        if (more) issue_b(nxt, H1{});
-        YH_PP_SYNC();
-        mma(H1{}, H1{});
-        YH_PP_BARRIER();
+        YH_PP_PHASE(2, { read_a(cur, 1); if (more) issue_b(nxt, H1{}); }, mma(H1{}, H1{}));
         // ---- phase 4: quadrant (a1, b0); no reads.  A[a0], B[b0] of the next tile before its phase 1: B[b1], A[a1] stay in flight
-        if (more) { issue_a(nxt, H1{}); wait_vmcnt<NA + NB>(); }
-        YH_PP_BARRIER();
-        mma(H1{}, H0{});
-        YH_PP_BARRIER();
+        YH_PP_PHASE(3, { if (more) { issue_a(nxt, H1{}); wait_vmcnt<NA + NB>(); } }, mma(H1{}, H0{}));
+#undef YH_PP_PHASE
     }
     if (group == 0) YH_PP_BARRIER();   // matches group 1's extra barrier at the start
 #undef YH_PP_SYNC
@@ -473,6 +481,276 @@ static int launch_pp(const ConvArgs& a0, hipStream_t stream) {
     return check_launch();
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Ping-pong kernel, second schedule ("pp2"): balanced load segments and a two-tile-deep LDS-DMA pipeline in the same two stages.
+//
+// Measured on the first schedule (s_memtime stamps, profiles/r02_pp_timing.txt): 3300 cycles per K tile against 2048 of MFMA
+// work - every barrier interval lasts max(load segment, 256-cycle MFMA segment) and the load segments were 12 / 4 / 8 / 0
+// fragment reads.  Here the A fragments are double buffered in registers (a0 / a1 halves of the wave's rows), only one B half
+// is resident, and the reads are spread 8 / 8 / 4 / 8 over the four phases:
+//     L1: B[b0], A[a1] lo        M1: (a0, b0)
+//     L2: B[b1], A[a1] hi        M2: (a0, b1)
+//     L3: next tile's A[a0] lo   M3: (a1, b1)
+//     L4: B[b0], next A[a0] hi   M4: (a1, b0)
+// A region of an LDS stage is refilled as soon as its last reader phase is over, for the tile that will use that stage next:
+//     L1(t): A[a0] of tile t+2 -> this stage      L2(t): B[b0] of tile t+1 -> other stage
+//     L3(t): A[a1] of tile t+2 -> this stage      L4(t): B[b1] of tile t+2 -> this stage
+// so every piece has 4 - 6 phase intervals to land, and one counted vmcnt per K tile (end of L4: B[b0] of the next tile and,
+// being older in the in-order queue, everything else the next tile's first three phases read) is the only wait on memory.
+template <typename T, typename OutT, int WM, int WN>
+__global__ __launch_bounds__(512, 2) void conv_igemm_pp2_kernel(const ConvArgs a) {
+    static_assert(WM * WN == 8 && sizeof(T) == 2, "8 waves, f16");
+    constexpr int VEC = Prec<T>::VEC, BK = VEC * 8;
+    constexpr int BM = WM * 128, BN = WN * 64;
+    constexpr int TM = 8, TN = 4;
+    constexpr int NA = WM, NB = WN / 2;               // LDS-DMA instructions per wave per piece set (A half / B half)
+    static_assert(WN % 2 == 0, "B piece sets must split over 8 waves");
+    constexpr int STAGE_CELLS = 8 * (BM + BN);
+    __shared__ u32x4 smem[2 * STAGE_CELLS];           // the only LDS object of the kernel
+
+    YH_STAMP(0);
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int group = wave >> 2;
+
+    int m_tile, p_tile;
+    {
+        const int nb = gridDim.x, bid = blockIdx.x;
+        const int q = nb >> 3, rr = nb & 7, xcd = bid & 7;
+        const int logical = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (bid >> 3);
+        p_tile = logical / a.m_tiles;
+        m_tile = logical - p_tile * a.m_tiles;
+    }
+    const int m0 = m_tile * BM;
+    const long p0 = (long)p_tile * BN;
+
+    // ---- loader (same piece sets as the first schedule)
+    const int lrow = lane >> 3;
+    const T* const xg = reinterpret_cast<const T*>(a.x);
+    const T* const wg = reinterpret_cast<const T*>(a.w);
+    const T* const zero = reinterpret_cast<const T*>(g_zero_page);
+    int wsrc[2][NA];     // 32-bit element offsets (launch_pp2 checks that both operands stay below 2^31 elements)
+    int adst[2][NA];
+    static_for<2 * NA>([&](auto c) {
+        constexpr int h = decltype(c)::value / NA, i = decltype(c)::value % NA;
+        const int q0 = (wave * NA + i) * 8;
+        const int trow0 = (q0 >> 6) * 128 + h * 64 + (q0 & 63);
+        const int trow = trow0 + lrow;
+        const int lu = (lane & 7) ^ ((trow >> 1) & 7);
+        const int row = min(m0 + trow, a.m_pad - 1);
+        wsrc[h][i] = row * a.ktot + lu * VEC;
+        adst[h][i] = trow0 * 8;
+    });
+    // the source cell of a lane is ((lane & 7) ^ (lane >> 4)) ^ 4 u with u = bit 3 of the (wave-uniform) first row of its
+    // 8-row group: one register for all pieces plus a scalar per piece
+    int bbase[2][NB];
+    int bhw[2][NB], bflip[2][NB], bdst[2][NB];
+    const int cell0 = ((lane & 7) ^ (lane >> 4)) * VEC;
+    const int HoWo = a.Ho * a.Wo;
+    static_for<2 * NB>([&](auto c) {
+        constexpr int h = decltype(c)::value / NB, i = decltype(c)::value % NB;
+        const int q0 = (wave * NB + i) * 8;
+        const int trow0 = (q0 >> 5) * 64 + h * 32 + (q0 & 31);
+        const int trow = trow0 + lrow;
+        const int lu = (lane & 7) ^ ((trow >> 1) & 7);
+        bflip[h][i] = ((trow0 >> 3) & 1) * 4 * VEC;
+        bdst[h][i] = (BM + trow0) * 8;
+        const long p = p0 + trow;
+        if (p < a.P) {
+            const int n = (int)(p / HoWo);
+            const int rem = (int)(p - (long)n * HoWo);
+            const int ho = rem / a.Wo, wo = rem - ho * a.Wo;
+            const int hi = ho * a.stride - a.pad, wi = wo * a.stride - a.pad;
+            bhw[h][i] = (hi << 16) | (wi & 0xffff);
+            bbase[h][i] = (int)((((long)n * a.H + hi) * a.W + wi) * a.ldx) + lu * VEC;
+        } else {
+            bhw[h][i] = (int)0x80008000;
+            bbase[h][i] = 0;
+        }
+    });
+
+    struct Tap { int kr, ks, kc, kofs, tap; };   // filter tap / channel offset of a K tile (wave-uniform)
+    auto next_tap = [&](Tap t) {
+        t.kofs += BK;
+        t.kc += BK;
+        if (t.kc >= a.cin_k) {
+            t.kc = 0;
+            if (++t.ks == a.S) { t.ks = 0; ++t.kr; }
+        }
+        t.tap = (t.kr * a.W + t.ks) * a.ldx + t.kc;
+        return t;
+    };
+    auto issue_a = [&](u32x4* base, const Tap& t, auto hc) {
+        constexpr int h = decltype(hc)::value;
+        static_for<NA>([&](auto c) {
+            constexpr int i = decltype(c)::value;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wg + (wsrc[h][i] + t.kofs)),
+                                             (__attribute__((address_space(3))) void*)(base + adst[h][i]), 16, 0, 0);
+        });
+    };
+    auto issue_b = [&](u32x4* base, const Tap& t, auto hc) {
+        constexpr int h = decltype(hc)::value;
+        static_for<NB>([&](auto c) {
+            constexpr int i = decltype(c)::value;
+            const int hi = bhw[h][i] >> 16, wi = (int)(short)(bhw[h][i] & 0xffff);
+            const bool ok = t.kc + (cell0 ^ bflip[h][i]) < a.Cin && (unsigned)(hi + t.kr) < (unsigned)a.H &&
+                            (unsigned)(wi + t.ks) < (unsigned)a.W;
+            const T* src = ok ? xg + (bbase[h][i] + t.tap) : zero;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(base + bdst[h][i]), 16, 0, 0);
+        });
+    };
+    typedef std::integral_constant<int, 0> H0;
+    typedef std::integral_constant<int, 1> H1;
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // fragment registers: both A halves (4 fragments x 2 K halves each), one B half (2 fragments x 2 K halves)
+    f16x8 fa[2][2][4], fb[2][2];
+    const int r16 = lane & 15, kq = lane >> 4, fsw = (r16 >> 1) & 7;
+    const int off0 = r16 * 8 + ((0 + kq) ^ fsw), off1 = r16 * 8 + ((4 + kq) ^ fsw);
+    const int arow = wm * 128, brow = BM + wn * 64;
+    auto read_a = [&](const u32x4* st, auto hc, auto pc_) {   // A half hc, fragments 2 part .. 2 part + 1
+        constexpr int h = decltype(hc)::value, part = decltype(pc_)::value;
+#pragma unroll
+        for (int i = 2 * part; i < 2 * part + 2; ++i) {
+            u32x4 v0 = st[(arow + h * 64 + i * 16) * 8 + off0];
+            u32x4 v1 = st[(arow + h * 64 + i * 16) * 8 + off1];
+            fa[h][0][i] = *reinterpret_cast<f16x8*>(&v0);
+            fa[h][1][i] = *reinterpret_cast<f16x8*>(&v1);
+        }
+    };
+    auto read_b = [&](const u32x4* st, auto hc) {
+        constexpr int h = decltype(hc)::value;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            u32x4 v0 = st[(brow + h * 32 + j * 16) * 8 + off0];
+            u32x4 v1 = st[(brow + h * 32 + j * 16) * 8 + off1];
+            fb[0][j] = *reinterpret_cast<f16x8*>(&v0);
+            fb[1][j] = *reinterpret_cast<f16x8*>(&v1);
+        }
+    };
+    auto mma = [&](auto ac, auto bc) {   // quadrant (a, b): 4 x 2 fragments x 2 K halves, channel order within the line
+        constexpr int ah = decltype(ac)::value, bh = decltype(bc)::value;
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[ah * 4 + i][bh * 2 + j] =
+                        __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[ah][k][i], fb[k][j], acc[ah * 4 + i][bh * 2 + j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+    };
+#define YH_PP_SYNC()                                        \
+    do {                                                    \
+        __builtin_amdgcn_sched_barrier(0);                  \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
+        __builtin_amdgcn_s_barrier();                       \
+        __builtin_amdgcn_sched_barrier(0);                  \
+    } while (0)
+#define YH_PP_BARRIER()                      \
+    do {                                     \
+        __builtin_amdgcn_sched_barrier(0);   \
+        __builtin_amdgcn_s_barrier();        \
+        __builtin_amdgcn_sched_barrier(0);   \
+    } while (0)
+
+    const int nk = a.ktot / BK;
+    u32x4* const stage0 = smem;
+    u32x4* const stage1 = smem + STAGE_CELLS;
+    // prologue: all of K tile 0 into stage 0; of tile 1 what the steady state would already have issued (A[a0], A[a1], B[b1])
+    Tap t1{0, 0, 0, 0, 0};          // tile 0 for now
+    YH_STAMP(1);
+    issue_a(stage0, t1, H0{});
+    issue_b(stage0, t1, H0{});
+    issue_b(stage0, t1, H1{});
+    issue_a(stage0, t1, H1{});
+    t1 = next_tap(t1);              // tile 1
+    if (nk > 1) {
+        issue_a(stage1, t1, H0{});
+        issue_a(stage1, t1, H1{});
+        issue_b(stage1, t1, H1{});
+    }
+    Tap t2 = next_tap(t1);          // tile 2
+    wait_vmcnt<0>();
+    YH_PP_BARRIER();
+    read_a(stage0, H0{}, H0{});     // A[a0] of tile 0 (later tiles get it in L3 / L4 of their predecessor)
+    read_a(stage0, H0{}, H1{});
+    YH_PP_SYNC();                   // everyone holds A[a0](0): its LDS region may be refilled from L1(0) on
+    YH_STAMP(2);
+    if (group == 1) YH_PP_BARRIER();   // stagger: group 1 starts one interval late
+
+    for (int kt = 0; kt < nk; ++kt) {
+        u32x4* const cur = (kt & 1) ? stage1 : stage0;
+        u32x4* const nxt = (kt & 1) ? stage0 : stage1;
+        const bool more1 = kt + 1 < nk, more2 = kt + 2 < nk;
+        // ---- phase 1: quadrant (a0, b0)
+        read_b(cur, H0{});
+        read_a(cur, H1{}, H0{});
+        if (more2) issue_a(cur, t2, H0{});
+        YH_PP_SYNC();
+        mma(H0{}, H0{});
+        YH_PP_BARRIER();
+        // ---- phase 2: quadrant (a0, b1)
+        read_b(cur, H1{});
+        read_a(cur, H1{}, H1{});
+        if (more1) issue_b(nxt, t1, H0{});
+        YH_PP_SYNC();
+        mma(H0{}, H1{});
+        YH_PP_BARRIER();
+        // ---- phase 3: quadrant (a1, b1); the next tile's A[a0] starts to move into the registers M1 / M2 are done with
+        if (more1) read_a(nxt, H0{}, H0{});
+        if (more2) issue_a(cur, t2, H1{});
+        YH_PP_SYNC();
+        mma(H1{}, H1{});
+        YH_PP_BARRIER();
+        // ---- phase 4: quadrant (a1, b0)
+        read_b(cur, H0{});
+        if (more1) read_a(nxt, H0{}, H1{});
+        if (more2) issue_b(cur, t2, H1{});
+        // B[b0] of the next tile (issued in L2) must have landed before its L1; A[a1] / B[b1] of tile t+2 stay in flight
+        if (more2) wait_vmcnt<NA + NB>(); else wait_vmcnt<0>();
+        YH_PP_SYNC();
+        mma(H1{}, H0{});
+        YH_PP_BARRIER();
+        t1 = t2;
+        t2 = next_tap(t2);
+    }
+    if (group == 0) YH_PP_BARRIER();   // matches group 1's extra barrier at the start
+#undef YH_PP_SYNC
+#undef YH_PP_BARRIER
+    YH_STAMP(3);
+
+    conv_epilogue<T, OutT, TM, TN, BN, WN>(a, acc, m0, p0, wm, wn, lane);
+#ifdef YH_PP_TIMING
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    YH_STAMP(4);
+#endif
+}
+
+template <typename T, typename OutT, int WM, int WN>
+static int launch_pp2(const ConvArgs& a0, hipStream_t stream) {
+    constexpr int BM = WM * 128, BN = WN * 64;
+    ConvArgs a = a0;
+    if (a.cin_k % (Prec<T>::VEC * 8)) return YH_EALIGN;
+    if (a.H >= 32768 || a.W >= 32768) return YH_EUNSUPPORTED;
+    // 32-bit element offsets inside the kernel (the far corner of the last tap of the last pixel included)
+    if ((long)a.N * a.H * a.W * a.ldx + (long)(a.R + 1) * a.W * a.ldx >= 0x7fffffffL || (long)a.m_pad * a.ktot >= 0x7fffffffL) return YH_EUNSUPPORTED;
+    a.m_tiles = (a.Cout + BM - 1) / BM;
+    a.p_tiles = (int)((a.P + BN - 1) / BN);
+    const long blocks = (long)a.m_tiles * a.p_tiles;
+    if (blocks <= 0 || blocks > 0x7fffffffL) return YH_EINVAL;
+    hipLaunchKernelGGL((conv_igemm_pp2_kernel<T, OutT, WM, WN>), dim3((unsigned)blocks), dim3(512), 0, stream, a);
+    return check_launch();
+}
+
 template <typename T, typename OutT> static int dispatch_k64(const ConvArgs& a, int tile, hipStream_t s) {
     switch (tile) {
         case 61: return launch_k64<T, OutT, 256, 256, 2, 4, 2>(a, s);   // 8 waves, 128 KB of LDS
@@ -481,6 +759,9 @@ template <typename T, typename OutT> static int dispatch_k64(const ConvArgs& a, 
         case 64: return launch_pp<T, OutT, 2, 4>(a, s);                 // ping-pong 256 x 256
         case 65: return launch_pp<T, OutT, 1, 8>(a, s);                 // ping-pong 128 x 512
         case 66: return launch_pp<T, OutT, 4, 2>(a, s);                 // ping-pong 512 x 128
+        case 67: return launch_pp2<T, OutT, 2, 4>(a, s);                // second schedule, 256 x 256
+        case 68: return launch_pp2<T, OutT, 1, 8>(a, s);                // 128 x 512
+        case 69: return launch_pp2<T, OutT, 4, 2>(a, s);                // 512 x 128
         default: return YH_EINVAL;
     }
 }
