@@ -24,7 +24,8 @@ driver contract it carries
                 per image for training);
   cpu_baseline  the same step on this host's cores (eager fp32 torch modules, bit-equal to the reference's) on a bounded
                 sample (N = 1 only);
-  detect        metric/value/roofline of the detection leg.
+  detect        metric/value/roofline of the fp16 detection leg;
+  detect_int8   the same for the int8 COS-PTQ graph (synthetic power-of-two calibration state, tools/synthetic_ptq.py).
 If the training leg cannot run, the detection leg becomes the headline and "train_error" says why.
 """
 import argparse
@@ -226,7 +227,12 @@ def train_main(args, device, dist, world, rank, local_rank):
     opt.add_param_group({'params': pg2})
     core = model
     if world > 1:
-        model = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank], output_device=local_rank)
+        model = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank], output_device=local_rank,
+                                                          bucket_cap_mb=args.bucket_mb, gradient_as_bucket_view=True)
+        if args.grad_compress == 'fp16':
+            # halve the xGMI payload (248 MB -> 124 MB per step for YOLOv3): buckets are cast to fp16 for the all-reduce and back
+            from torch.distributed.algorithms.ddp_comm_hooks import default_hooks
+            model.register_comm_hook(None, default_hooks.fp16_compress_hook)
         model.yolo_layers = core.yolo_layers
     for m in {model, core}:
         m.nc, m.hyp, m.gr = 80, HYP, 1.0
@@ -425,6 +431,9 @@ def main():
     ap.add_argument('--no-nms', action='store_true')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=12.0)
+    ap.add_argument('--grad-compress', default='none', choices=['none', 'fp16'],
+                    help='DDP communication hook: fp16 = gradient buckets all-reduced in fp16 (half the xGMI bytes), fp32 master grads')
+    ap.add_argument('--bucket-mb', type=int, default=25, help='DDP bucket size; the backward runs in 8 ranges of ~31 MB of gradients each')
     ap.add_argument('--share-gpu', action='store_true',
                     help='let ranks share GPUs when fewer than --gpus are visible (smoke runs of the N > 1 path on a 1-GPU box; '
                          'RCCL itself refuses two ranks on one device, so combine with --dist-backend gloo there)')
@@ -495,6 +504,18 @@ def main():
                 out = det
             else:   # the second headline metric of BASELINE.json, measured in the same run
                 out['detect'] = {k: det[k] for k in ('metric', 'value', 'unit', 'ms_per_step', 'dtype', 'config', 'roofline_net', 'roofline')}
+        if args.mode == 'both' and args.precision == 'fp16' and (out is not None or rank != 0):
+            # third headline metric ("detect int8 FPS"): the COS-PTQ graph on the MFMA-i8 engine, same frames, same NMS
+            import copy
+            iargs = copy.copy(args)
+            iargs.precision = 'int8'
+            try:
+                det8 = detect_main(iargs, device, dist, world, rank, cpu_baseline_leg=False)
+                if rank == 0 and det8 is not None:
+                    out['detect_int8'] = {k: det8[k] for k in ('metric', 'value', 'unit', 'ms_per_step', 'dtype', 'config', 'roofline_net', 'roofline')}
+            except Exception as e:
+                if rank == 0:
+                    out['detect_int8_error'] = '%s: %s' % (type(e).__name__, e)
     if rank == 0:
         print(json.dumps(out))
     if dist is not None:

@@ -863,3 +863,44 @@ def test_device_target_assignment_matches_build_targets_on_edge_cases(libs):
         assert torch.allclose(outs[0][0], outs[1][0], rtol=2e-5, atol=1e-6), (seed, outs[0][0], outs[1][0])
         for ga, gb in zip(outs[0][1], outs[1][1]):
             assert (ga - gb).abs().max().item() <= 1e-4 * gb.abs().max().item(), seed
+
+
+# ------------------------------------------------------------------------------------------- widths that are not multiples of 8
+@pytest.mark.parametrize('which', ['pruned_mini', 'odd', 'odd_mobile'])
+@pytest.mark.parametrize('precision', ['fp32', 'fp16'])
+def test_odd_width_graphs_train_on_the_hip_path(libs, which, precision):
+    """slim_prune-style graphs (arbitrary channel counts, incl. depthwise + squeeze-excite) train on the HIP kernels through the
+    channel-padded twin (engine/padded.py) and match eager fp32 autograd on the unpadded modules; no eager fallback exists."""
+    import models
+    import test_plan_emulated as tpe
+    import test_train_emulated as tte
+    from engine.padded import PaddedTrainEngine
+    if which == 'pruned_mini':
+        path = th.write_cfg(tte._pruned_like_cfg_text())
+        model = th.build(path, 64)
+        os.unlink(path)
+    else:
+        defs = {'odd': tpe._odd_cfg, 'odd_mobile': tpe._odd_mobile_cfg}[which]()
+        torch.manual_seed(5)
+        model = models.Darknet(defs, (64, 64))
+        model.load_state_dict(synth.randomize_bn_(model.state_dict(), seed=6))
+        model.train()
+    x = synth.image_batch(3, 64, seed=0 if which == 'pruned_mini' else 7)   # samples on which no activation sits on a kink
+    raws_ref, grads_ref, m_ref, ws = th.eager_step(model, x)
+    raws, grads, m = th.engine_step(model, x, ws, precision, lib=fakelib.FakeLib() if DRY else None, device=GPU)
+    assert isinstance(m.__dict__['_hip_train_engine'], PaddedTrainEngine)
+    total = sum(g.norm().item() ** 2 for g in grads_ref.values()) ** 0.5
+    if precision == 'fp32':
+        for a, b in zip(raws, raws_ref):
+            assert (a - b).abs().max().item() <= 5e-5 * b.abs().max().item()
+        for k in grads_ref:
+            # random-weight leaky / relu6 nets: a kink that flips under another fp32 summation order moves upstream gradients by 1e-3
+            assert (grads[k] - grads_ref[k]).norm().item() <= 5e-3 * grads_ref[k].norm().item() + 1e-5 * total, k
+        num = sum((grads[k] - grads_ref[k]).norm().item() ** 2 for k in grads_ref) ** 0.5
+        assert num <= 2e-3 * total, (num, total)
+        for (k, a), (_, b) in zip(m.state_dict().items(), m_ref.state_dict().items()):
+            if 'running' in k:
+                assert (a.cpu() - b).abs().max().item() <= 1e-5 * (b.abs().max().item() + 1), k
+    else:
+        num = sum((grads[k] - grads_ref[k]).norm().item() ** 2 for k in grads_ref) ** 0.5
+        assert num <= 0.05 * total, (num, total)

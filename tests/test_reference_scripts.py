@@ -92,7 +92,22 @@ def test_reference_slim_prune_runs_unmodified(tmp_path, tiny_cfg, dataset_dir):
     assert 'Compact model has been saved' in out
     compact = _check_outputs(tmp_path, model, 'slim_prune_0.5', 'slim_prune_0.5')
     widths = [m[0].out_channels for m in compact.module_list if isinstance(m, torch.nn.Sequential) and hasattr(m[0], 'out_channels')]
-    assert any(w % 8 for w in widths), 'slim_prune leaves arbitrary channel counts (%s): the odd-width paths are exercised' % widths
+    assert any(w % 8 for w in widths[:-1]), 'slim_prune leaves arbitrary channel counts (%s): the odd-width paths are exercised' % widths
+    # BASELINE config 5 continues with a fine-tune of exactly this graph: it must train on the HIP path (through the channel-padded
+    # twin, here on the host emulation of the C ABI) and agree with eager autograd on the compact modules
+    sys.path.insert(0, os.path.join(conftest.REPO, 'tests'))
+    import fakelib
+    import synth
+    import train_harness as th
+    from engine.padded import PaddedTrainEngine
+    compact.train()
+    x = synth.image_batch(3, 64, seed=3)
+    raws_ref, grads_ref, m_ref, ws = th.eager_step(compact, x)
+    raws, grads, m = th.engine_step(compact, x, ws, 'fp32', lib=fakelib.FakeLib())
+    assert isinstance(m.__dict__['_hip_train_engine'], PaddedTrainEngine)
+    total = sum(g.norm().item() ** 2 for g in grads_ref.values()) ** 0.5
+    for k in grads_ref:
+        assert (grads[k] - grads_ref[k]).norm().item() <= 1e-4 * grads_ref[k].norm().item() + 1e-6 * total, k
 
 
 def test_reference_layer_prune_runs_unmodified(tmp_path, tiny_cfg, dataset_dir):

@@ -285,3 +285,98 @@ def test_training_step_matches_reference_golden(tag, rel, size, nc, path):
     assert [str(n) for n in gold[tag + '_running_names']] == list(rs)
     for v, want in zip(rs.values(), gold[tag + '_running_checks']):
         assert abs(chk(v)[1] - want[1]) <= 1e-5 * want[1] + 1e-9
+
+
+# ------------------------------------------------------------------------------------------- widths that are not multiples of 8
+def _pruned_like_cfg_text():
+    """The mini cfg after a slim_prune-style channel prune: arbitrary widths (>= 1), shortcut-connected layers pruned alike
+    (prune_utils.merge_mask), route + upsample + concat of two odd-width tensors."""
+    c = lambda f, k, s: th._CONV % (f, k, s, 'leaky')
+    sc = '[shortcut]\nfrom=-3\nactivation=linear\n\n'
+    return ('[net]\nbatch=1\nwidth=64\nheight=64\nchannels=3\n\n'
+            + c(5, 3, 1) + c(13, 3, 2) + c(3, 1, 1) + c(13, 3, 1) + sc            # 0-4
+            + c(27, 3, 2) + c(9, 1, 1) + c(27, 3, 1) + sc                         # 5-8
+            + c(11, 1, 1) + c(30, 3, 1) + th._HEAD + th._YOLO % '3,4,5'           # 9-12
+            + '[route]\nlayers = -4\n\n' + c(6, 1, 1) + '[upsample]\nstride=2\n\n'  # 13-15
+            + '[route]\nlayers = -1, 4\n\n' + c(10, 1, 1) + c(19, 3, 1) + th._HEAD + th._YOLO % '0,1,2')
+
+
+def test_odd_width_graph_trains_through_the_padded_twin():
+    from engine.padded import PaddedTrainEngine
+    path = th.write_cfg(_pruned_like_cfg_text())
+    try:
+        model = th.build(path, 64)
+        x = synth.image_batch(3, 64, seed=0)
+        raws_ref, grads_ref, m_ref, ws = th.eager_step(model, x)
+        raws, grads, m = th.engine_step(model, x, ws, 'fp32', lib=fakelib.FakeLib())
+        assert isinstance(m.__dict__['_hip_train_engine'], PaddedTrainEngine)
+        for a, b in zip(raws, raws_ref):
+            assert a.shape == b.shape
+            assert (a - b).abs().max().item() <= 2e-5 * b.abs().max().item()
+        assert set(grads) == set(grads_ref)
+        for k in grads_ref:
+            assert grads[k].shape == grads_ref[k].shape
+            assert th.rel_l2(grads[k], grads_ref[k]) < 5e-5, k
+        for (k, a), (_, b) in zip(m.state_dict().items(), m_ref.state_dict().items()):
+            if 'running' in k:
+                assert (a - b).abs().max().item() <= 1e-5 * (b.abs().max().item() + 1), k
+            if 'num_batches_tracked' in k:
+                assert int(a) == int(b) == 1, k
+        # pad lanes of the twin stay exact zeros after the step (weights, biases, BatchNorm shifts)
+        pad = m.__dict__['_hip_train_engine'].pad
+        mask = torch.ones(pad.twin_flat.numel(), dtype=torch.bool)
+        mask[(pad.push_index < pad.real_numel).cpu()] = False
+        assert pad.twin_flat.cpu()[mask].abs().max().item() == 0.0
+    finally:
+        os.unlink(path)
+
+
+def test_two_sgd_steps_on_an_odd_width_graph_track_eager():
+    import copy
+    path = th.write_cfg(_pruned_like_cfg_text())
+    try:
+        model = th.build(path, 64)
+        ref = copy.deepcopy(model)
+        from engine.padded import make_train_engine
+        dev = copy.deepcopy(model)
+        opt_r = torch.optim.SGD(ref.parameters(), lr=1e-3, momentum=0.9)
+        opt_d = torch.optim.SGD(dev.parameters(), lr=1e-3, momentum=0.9)
+        os.environ['YOLO_HIP_TRAIN_PRECISION'] = 'fp32'
+        try:
+            for step in range(2):
+                x = synth.image_batch(3, 64, seed=10 + step)
+                raws = ref._forward_eager(x)[0]
+                ws = th.loss_weights(raws)
+                opt_r.zero_grad()
+                th.toy_loss(raws, ws).backward()
+                opt_r.step()
+                if dev.__dict__.get('_hip_train_engine') is None:
+                    dev.__dict__['_hip_train_engine'] = make_train_engine(dev, 'fp32', x, lib=fakelib.FakeLib())
+                raws_d, _ = dev._forward_hip_train(x)
+                opt_d.zero_grad()
+                th.toy_loss(raws_d, ws).backward()
+                opt_d.step()
+        finally:
+            del os.environ['YOLO_HIP_TRAIN_PRECISION']
+        for (k, a), (_, b) in zip(dev.state_dict().items(), ref.state_dict().items()):
+            if a.dtype.is_floating_point:
+                assert (a - b).abs().max().item() <= 1e-3 * (b.abs().max().item() + 1e-3), k
+    finally:
+        os.unlink(path)
+
+
+def test_shortcut_between_different_padded_layouts_raises():
+    """GhostNet-style: a 12 + 12 channel concat added to a 24-channel conv - no twin layout exists and there is no eager fallback."""
+    import models
+    from engine.padded import make_train_engine
+    c = lambda f, k, s: th._CONV % (f, k, s, 'leaky')
+    text = ('[net]\nbatch=1\nwidth=32\nheight=32\nchannels=3\n\n' + c(24, 3, 1) + c(12, 1, 1) + c(12, 3, 1) + '[route]\nlayers = -1, -2\n\n'
+            + '[shortcut]\nfrom=-4\nactivation=linear\n\n' + th._HEAD + th._YOLO % '0,1,2')
+    path = th.write_cfg(text)
+    try:
+        torch.manual_seed(0)
+        model = models.Darknet(path, (32, 32)).train()
+        with pytest.raises(NotImplementedError, match='layouts'):
+            make_train_engine(model, 'fp32', synth.image_batch(2, 32), lib=fakelib.FakeLib())
+    finally:
+        os.unlink(path)

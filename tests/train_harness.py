@@ -73,14 +73,14 @@ def eager_step(model, x, ws=None, dtype=torch.float32):
 
 def engine_step(model, x, ws, precision, lib=None, device='cpu'):
     """The HIP training path through ``Darknet._forward_hip_train`` (``lib`` = FakeLib on CPU, None = the real library)."""
-    from engine.train import TrainEngine
+    from engine.padded import make_train_engine
     m = copy.deepcopy(model).to(device).train()
     for p in m.parameters():
         p.grad = None
     os.environ['YOLO_HIP_TRAIN_PRECISION'] = precision
     try:
         if lib is not None:
-            m.__dict__['_hip_train_engine'] = TrainEngine(m, precision, lib=lib)
+            m.__dict__['_hip_train_engine'] = make_train_engine(m, precision, x.to(device), lib=lib)
         raws, feats = m._forward_hip_train(x.to(device))
         toy_loss(raws, ws).backward()
     finally:

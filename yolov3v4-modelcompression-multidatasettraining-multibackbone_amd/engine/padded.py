@@ -1,0 +1,311 @@
+"""HIP training for graphs whose channel counts are not multiples of 8 (every ``slim_prune.py`` output: reference
+slim_prune.py:25-30 keeps any number of channels >= 1 per layer, utils/prune_utils.py:212-258 builds the compact model).
+
+The training kernels move channels in 16-byte vectors (8 f16), so the lowering of ``engine/train.py`` wants every tensor width
+to be a multiple of 8.  Instead of teaching each kernel about ragged widths, an odd-width model trains through a
+**channel-padded twin**: the same cfg with every conv width rounded up to 8 (``Darknet(padded defs)``), living only inside the
+engine.  Per step
+
+    live parameters --(one gather launch)--> twin parameters (pad rows / columns / BN lanes are exact zeros)
+    twin forward + backward on the HIP training plan (unchanged kernels; pad channels carry zeros end to end)
+    twin gradients --(one gather per backward range)--> gradients of the live parameters
+    twin BatchNorm running statistics --(one gather)--> the live buffers
+
+so optimizers, GradScaler, EMA, DDP hooks and checkpoints keep seeing the model the user built.  Pad lanes are inert: a padded
+output channel has zero weights and zero bias, hence z = 0, batch mean = var = 0, x_hat = 0, y = beta_pad = 0 and every
+activation maps 0 -> 0; a padded input column multiplies zeros.  The result equals the unpadded computation exactly in exact
+arithmetic and to summation order in floating point (tests/test_gpu_train.py, tests/test_train_emulated.py).
+
+Layouts: each layer's output is described by ``pos`` (physical channel of every logical channel) and the physical width.  Convs
+produce ``arange(C)`` padded at the end, depthwise convs / BN / SE / pools / upsample keep their input's layout, routes
+concatenate layouts.  What the twin cannot express raises ``NotImplementedError`` (there is no eager fallback): shortcuts
+between tensors whose layouts differ (GhostNet adds a 12 + 12 channel concat to a 24-channel conv), group-split routes of a
+padded tensor, grouped convs other than depthwise.
+"""
+import copy
+import types
+
+import torch
+import torch.nn as nn
+
+ALIGN = 8
+
+
+def _ru(n, a=ALIGN):
+    return (n + a - 1) // a * a
+
+
+class _Layout:
+    __slots__ = ('pos', 'phys')
+
+    def __init__(self, pos, phys):
+        self.pos, self.phys = pos, phys     # LongTensor [C_logical], int
+
+    @property
+    def logical(self):
+        return int(self.pos.numel())
+
+    def dense(self):
+        return self.phys == self.logical
+
+    def same(self, other):
+        return self.phys == other.phys and self.logical == other.logical and bool(torch.equal(self.pos, other.pos))
+
+
+def plan_layouts(module_defs, in_channels):
+    """(padded block dicts, per-layer layouts).  ``module_defs``: ``Darknet.module_defs`` (the blocks after ``[net]``)."""
+    defs = copy.deepcopy(list(module_defs))
+    body = defs
+    layouts = []
+    prev = _Layout(torch.arange(in_channels), in_channels)
+    for i, d in enumerate(body):
+        t = d['type']
+        src = layouts[i - 1] if i else prev
+        if t == 'convolutional':
+            filters, groups = int(d['filters']), int(d.get('groups', 1))
+            if groups == 1:
+                lay = _Layout(torch.arange(filters), _ru(filters))
+                d['filters'] = lay.phys
+            elif groups == src.logical and filters == src.logical:       # depthwise spelled as a grouped conv (GhostNet cfgs)
+                lay = _Layout(src.pos.clone(), src.phys)
+                d['filters'], d['groups'] = src.phys, src.phys
+            else:
+                raise NotImplementedError('HIP training path: grouped conv (groups=%d) in a padded graph, block %d' % (groups, i))
+        elif t == 'depthwise':
+            lay = _Layout(src.pos.clone(), src.phys)
+            d['filters'] = src.phys
+        elif t == 'se':
+            lay = _Layout(src.pos.clone(), src.phys)
+            if 'filters' in d:
+                d['filters'] = src.phys
+        elif t == 'shortcut':
+            lay = src
+            for l in d['from']:
+                other = layouts[i + l if l < 0 else l]
+                if not other.same(src):
+                    raise NotImplementedError('HIP training path: shortcut (block %d) between tensors whose padded channel layouts '
+                                              'differ (%d of %d vs %d of %d channels)' % (i, src.logical, src.phys, other.logical, other.phys))
+        elif t == 'route':
+            parts = [layouts[i + l if l < 0 else l] for l in d['layers']]
+            if int(d.get('groups', 0) or 0):
+                p = parts[0]
+                if len(parts) != 1 or not p.dense() or (p.logical // 2) % ALIGN:
+                    raise NotImplementedError('HIP training path: group-split route (block %d) of a padded tensor' % i)
+                lay = _Layout(torch.arange(p.logical // 2), p.logical // 2)
+            else:
+                off, pos = 0, []
+                for p in parts:
+                    pos.append(p.pos + off)
+                    off += p.phys
+                lay = _Layout(torch.cat(pos), off)
+        else:    # upsample, maxpool, yolo, ...: width and layout of the input
+            lay = src
+        layouts.append(lay)
+    return defs, layouts
+
+
+class PaddedTwin:
+    """The padded twin of ``model`` plus the index maps between the two parameter / buffer sets."""
+
+    def __init__(self, model, ordered_parameters):
+        import models
+        real_defs = model.module_defs
+        in_ch = None
+        for block in model.module_list:
+            if isinstance(block, nn.Sequential) and len(block) and isinstance(block[0], nn.Conv2d):
+                in_ch = block[0].in_channels
+                break
+        defs, layouts = plan_layouts(real_defs, in_ch)
+        self.layouts = layouts
+        dev = next(model.parameters()).device
+        with torch.random.fork_rng(devices=[]):      # building the twin must not advance the user's RNG stream
+            # a list cfg is [hyperparams] + blocks, the form the prune scripts use (slim_prune.py:147-149)
+            twin = models.Darknet([copy.deepcopy(model.hyperparams)] + defs, verbose=False)
+        self.twin = twin.to(dev).train()
+        for attr in ('nc', 'hyp', 'gr'):
+            if hasattr(model, attr):
+                setattr(self.twin, attr, getattr(model, attr))
+        self.real_params = ordered_parameters(model)
+        self.twin_params = ordered_parameters(self.twin)
+        assert len(self.real_params) == len(self.twin_params)
+        self._build_maps(model, in_ch, dev)
+
+    # ------------------------------------------------------------------------------------------------ index maps
+    def _build_maps(self, model, in_ch, dev):
+        real_off, off = {}, 0
+        for p in self.real_params:
+            real_off[id(p)] = off
+            off += p.numel()
+        zero_slot = off                                   # real flat = [all parameters | one zero]
+        self.real_numel = off
+        to_twin = {}                                      # id(twin param) -> LongTensor(twin.shape) of real-flat positions
+        to_real = {}                                      # id(real param) -> LongTensor(real.shape) of positions inside the twin tensor
+        buf_pairs = []                                    # (real buffer, twin buffer, pos)
+        self._bn_pairs = []
+        inputs = _Layout(torch.arange(in_ch), in_ch)
+
+        def link(rp, tp, index):
+            """index: tuple of broadcastable LongTensors addressing, inside ``tp``, the block that holds ``rp``."""
+            src = torch.full(tuple(tp.shape), zero_slot, dtype=torch.long)
+            src[index] = real_off[id(rp)] + torch.arange(rp.numel()).view(tuple(rp.shape))
+            to_twin[id(tp)] = src
+            to_real[id(rp)] = torch.arange(tp.numel()).view(tuple(tp.shape))[index].reshape(tuple(rp.shape))
+
+        for i, (rb, tb) in enumerate(zip(model.module_list, self.twin.module_list)):
+            lay = self.layouts[i]
+            src = self.layouts[i - 1] if i else inputs
+            if isinstance(rb, nn.Sequential) and len(rb) and isinstance(rb[0], nn.Conv2d):
+                rc, tc = rb[0], tb[0]
+                o = lay.pos
+                if rc.groups == 1:
+                    link(rc.weight, tc.weight, (o[:, None], src.pos[None, :]))
+                else:                                      # depthwise: one filter per channel, rows follow the input layout
+                    link(rc.weight, tc.weight, (o,))
+                if rc.bias is not None:
+                    link(rc.bias, tc.bias, (o,))
+                for rk, tk in zip(list(rb.children())[1:], list(tb.children())[1:]):
+                    if isinstance(rk, nn.modules.batchnorm.BatchNorm2d):
+                        link(rk.weight, tk.weight, (o,))
+                        link(rk.bias, tk.bias, (o,))
+                        buf_pairs.append((rk.running_mean, tk.running_mean, o))
+                        buf_pairs.append((rk.running_var, tk.running_var, o))
+                        self._bn_pairs.append((rk, tk))
+            elif isinstance(rb, nn.Sequential) and len(rb) and rb[0].__class__.__name__ == 'SE':
+                r0, r2, t0, t2 = rb[0].fc[0], rb[0].fc[2], tb[0].fc[0], tb[0].fc[2]
+                hid = torch.arange(r0.weight.shape[0])
+                link(r0.weight, t0.weight, (hid[:, None], src.pos[None, :]))
+                link(r2.weight, t2.weight, (src.pos[:, None], hid[None, :]))
+        missing = [k for k, p in enumerate(self.real_params) if id(p) not in to_real]
+        if missing:
+            raise NotImplementedError('HIP training path: %d parameters of the padded graph have no layout rule' % len(missing))
+        # twin parameters become views of one flat buffer filled by ONE gather per step
+        total = sum(p.numel() for p in self.twin_params)
+        self.twin_flat = torch.zeros(total, device=dev, dtype=torch.float32)
+        gather, t_off = [], 0
+        with torch.no_grad():
+            for tp in self.twin_params:
+                n = tp.numel()
+                tp.data = self.twin_flat[t_off:t_off + n].view(tuple(tp.shape))
+                gather.append(to_twin[id(tp)].reshape(-1))
+                t_off += n
+        self.push_index = torch.cat(gather).to(dev)
+        self.real_flat = torch.zeros(self.real_numel + 1, device=dev, dtype=torch.float32)
+        self.real_views = []
+        r_off = 0
+        for p in self.real_params:
+            self.real_views.append(self.real_flat[r_off:r_off + p.numel()].view(tuple(p.shape)))
+            r_off += p.numel()
+        self.grad_index = {id(rp): to_real[id(rp)].reshape(-1) for rp in self.real_params}
+        # BatchNorm running statistics: twin buffers as views of one flat tensor; one gather brings them home
+        nbuf = sum(t.numel() for _, t, _ in buf_pairs)
+        self.buf_flat = torch.zeros(max(nbuf, 1), device=dev, dtype=torch.float32)
+        idx, b_off = [], 0
+        self.real_bufs = []
+        with torch.no_grad():
+            for rbuf, tbuf, pos in buf_pairs:
+                n = tbuf.numel()
+                init = tbuf.detach().clone()
+                tbuf.data = self.buf_flat[b_off:b_off + n]
+                tbuf.copy_(init)          # pad lanes keep BatchNorm's defaults (mean 0, variance 1)
+                tbuf[pos.to(dev)] = rbuf  # the twin starts from the live statistics and is authoritative from then on
+                idx.append(pos + b_off)
+                self.real_bufs.append(rbuf)
+                b_off += n
+        self.pull_index = torch.cat(idx).to(dev) if idx else torch.zeros(0, dtype=torch.long, device=dev)
+        self.pull_sizes = [rb.numel() for rb in self.real_bufs]
+        self.buf_pairs = buf_pairs
+
+    # ------------------------------------------------------------------------------------------------ per step
+    @torch.no_grad()
+    def push(self):
+        """Live parameters -> twin, one gather (pad rows / columns / lanes read the zero slot).  Running statistics were taken over
+        at construction; ``Darknet`` drops the engine whenever they are replaced from outside (load_state_dict, .to(), ...)."""
+        torch._foreach_copy_(self.real_views, [p.detach() for p in self.real_params])
+        torch.index_select(self.real_flat, 0, self.push_index, out=self.twin_flat)
+
+    @torch.no_grad()
+    def pull_stats(self):
+        if not self.real_bufs:
+            return
+        got = torch.index_select(self.buf_flat, 0, self.pull_index)
+        torch._foreach_copy_(self.real_bufs, list(torch.split(got, self.pull_sizes)))
+        for rk, tk in self._bn_pairs:
+            if rk.num_batches_tracked is not None:
+                rk.num_batches_tracked.copy_(tk.num_batches_tracked)
+
+    def map_grads(self, real_subset, twin_grads):
+        """Gradients of the twin parameters of one backward range -> gradients of the matching live parameters."""
+        if not twin_grads:
+            return []
+        flat = torch.cat([g.reshape(-1) for g in twin_grads])
+        key = tuple(id(p) for p in real_subset)
+        cache = self.__dict__.setdefault('_range_index', {})
+        if key not in cache:
+            idx, off = [], 0
+            for rp, tg in zip(real_subset, twin_grads):
+                idx.append(self.grad_index[id(rp)].to(flat.device) + off)
+                off += tg.numel()
+            cache[key] = torch.cat(idx)
+        out = torch.index_select(flat, 0, cache[key])
+        return [t.view(tuple(p.shape)) for t, p in zip(torch.split(out, [p.numel() for p in real_subset]), real_subset)]
+
+
+class PaddedTrainEngine:
+    """``TrainEngine`` of the padded twin behind the interface ``models.Darknet`` drives (forward / backward ranges)."""
+
+    def __init__(self, model, precision='fp16', lib=None):
+        from .train import TrainEngine
+        order = lambda m: TrainEngine.parameters(types.SimpleNamespace(model=m))
+        self.pad = PaddedTwin(model, order)
+        self.inner = TrainEngine(self.pad.twin, precision, lib)
+        self.model = model
+        self.precision = precision
+        self.step_heads = None
+        self._twin_to_real = {id(t): r for t, r in zip(self.pad.twin_params, self.pad.real_params)}
+
+    # the attributes models.Darknet / bench.py read
+    device = property(lambda self: self.inner.device)
+    steps = property(lambda self: self.inner.steps)
+    _current = property(lambda self: self.inner._current)
+    lib = property(lambda self: self.inner.lib)
+
+    def _get_plan(self, x):
+        return self.inner._get_plan(x)
+
+    def parameters(self):
+        return list(self.pad.real_params)
+
+    def segment_parameters(self, plan):
+        return [[self._twin_to_real[id(t)] for t in seg] for seg in self.inner.segment_parameters(plan)]
+
+    def forward(self, x):
+        self.pad.push()
+        heads = self.inner.forward(x)
+        self.pad.pull_stats()
+        return heads
+
+    def backward_segment(self, k, head_grads):
+        plan = self.inner._current
+        twin_grads = self.inner.backward_segment(k, head_grads)
+        real_subset = self.segment_parameters(plan)[k]
+        return self.pad.map_grads(real_subset, twin_grads)
+
+    def backward(self, head_grads):
+        plan = self.inner._current
+        out = [None] * len(plan['segments'])
+        for k in reversed(range(len(plan['segments']))):
+            out[k] = self.backward_segment(k, [head_grads[j] for j in plan['segments'][k]['heads']])
+        return [g for seg in out for g in seg]
+
+
+def make_train_engine(model, precision, x, lib=None):
+    """The training engine for ``model`` and input batch ``x``: the aligned lowering when every width is a multiple of 8, the
+    padded twin otherwise.  Plan build errors (NotImplementedError) surface here, before any state changes."""
+    from .train import TrainEngine, ChannelAlignmentError
+    try:
+        eng = TrainEngine(model, precision, lib)
+        eng._get_plan(x)
+    except ChannelAlignmentError:
+        eng = PaddedTrainEngine(model, precision, lib)
+        eng._get_plan(x)
+    return eng

@@ -24,8 +24,10 @@ and the backward plan, walking the values in reverse,
     grad(input) (+)= conv(dz, W^T flipped)     yh_conv2d_fwd on the dgrad weight image (stride 2: four parity phases)
 
 Every activation, z and gradient buffer is kept for the whole step (288 GB of HBM: YOLOv3-608 batch 64 needs ~40 GB).
-Blocks this path does not lower yet (depthwise, SE, group-split routes, weighted shortcuts) raise NotImplementedError at plan
-build; ``models.Darknet`` then keeps such cfgs on its eager torch path for training.
+Depthwise blocks, squeeze-excite, max-pools (incl. SPP) and CSP group-split routes are lowered too (csrc/depthwise.hip,
+csrc/train.hip).  Graphs whose widths are not multiples of 8 (slim-pruned nets) train through the channel-padded twin of
+``engine/padded.py``; what neither form covers (weighted shortcuts, grouped convs other than depthwise, shortcuts between
+different padded layouts) raises NotImplementedError at plan build - ``models.Darknet`` has no eager fallback for training.
 """
 import ctypes as C
 import os
@@ -43,6 +45,11 @@ SLOT_INPUT = 0
 SLOT_WS = 1          # shared fp32 workspace of the two-stage reductions
 SLOT_HEAD0 = 2       # forward: head output tensors; backward: head gradient tensors (fp32 NHWC)
 LINEAR = hiplib.ACT_CODES['linear']
+
+
+class ChannelAlignmentError(NotImplementedError):
+    """The aligned lowering wants every tensor width to be a multiple of 8: ``engine/padded.py`` trains such graphs through a
+    channel-padded twin."""
 
 
 class _Arena:
@@ -151,14 +158,14 @@ class TrainEngine(DarknetEngine):
     def _check_supported(self, values):
         for v in values:
             if v.kind in ('dw', 'se') and v.c_phys != v.C:
-                raise NotImplementedError('HIP training path: depthwise / SE blocks need channel counts that are multiples of %d' % ALIGN_C)
+                raise ChannelAlignmentError('HIP training path: depthwise / SE blocks need channel counts that are multiples of %d' % ALIGN_C)
             if v.kind in ('qadd',):
                 raise NotImplementedError('HIP training path: %s blocks are not lowered yet (block %s)' % (v.kind, v.block))
             if v.kind == 'conv':
                 if v.src.kind != 'input' and (v.src.C % ALIGN_C or v.src.c_phys != v.src.C):
-                    raise NotImplementedError('HIP training path: channel counts must be multiples of %d' % ALIGN_C)
+                    raise ChannelAlignmentError('HIP training path: channel counts must be multiples of %d' % ALIGN_C)
                 if not v.fp32 and v.C % ALIGN_C:
-                    raise NotImplementedError('HIP training path: channel counts must be multiples of %d' % ALIGN_C)
+                    raise ChannelAlignmentError('HIP training path: channel counts must be multiples of %d' % ALIGN_C)
                 if v.src.kind == 'input' and (v.src.C > 4 or v.src.C > ALIGN_C):
                     raise NotImplementedError('HIP training path: the first conv reads at most 4 image channels')
                 if v.stride == 2 and not (v.k == 3 and v.pad == 1):

@@ -427,9 +427,10 @@ class Darknet(nn.Module):
         return x.is_cuda and not self.training and self.quantized in (-1, 3)
 
     def _use_hip_train(self, x):
-        # training step on the HIP kernels (engine/train.py): float graphs only; cfgs with blocks that path does
-        # not lower yet are remembered and stay on the eager modules
-        return (x.is_cuda and self.training and self.quantized == -1 and not self.__dict__.get('_hip_train_unsupported')
+        # training step on the HIP kernels (engine/train.py, engine/padded.py): every float graph on a GPU.  A cfg that path
+        # cannot lower raises - there is no eager fallback.  (YOLO_HIP_TRAIN=0 is a debugging switch; feature-distillation
+        # losses ask for the eager modules explicitly through hip_return_features.)
+        return (x.is_cuda and self.training and self.quantized == -1
                 and not self.__dict__.get('hip_return_features', False) and os.environ.get('YOLO_HIP_TRAIN', '1') != '0')
 
     def forward_once(self, x, augment=False, verbose=False):
@@ -437,24 +438,21 @@ class Darknet(nn.Module):
             if self._use_hip(x):
                 return self._forward_hip(x)
             if self._use_hip_train(x):
-                try:
-                    return self._forward_hip_train(x)
-                except NotImplementedError as e:
-                    print('HIP training path unavailable for this cfg (%s); using the eager modules' % e)
-                    self.__dict__['_hip_train_unsupported'] = True
+                return self._forward_hip_train(x)
         return self._forward_eager(x, augment=augment, verbose=verbose)
 
     def _forward_hip_train(self, x):
         """Train-mode forward on the HIP engine; returns ``(raw_p_list, [])`` like the eager path (models.py:336-340:
         raw p is the (bs, na, ny, nx, no) view of the head conv).  fp16 compute under ``torch.autocast`` (the -mpt
         recipe), fp32 otherwise; ``YOLO_HIP_TRAIN_PRECISION`` overrides."""
-        from engine.train import TrainEngine  # raises if libyolo_hip.so is missing: no fallback
+        from engine.padded import make_train_engine  # raises if libyolo_hip.so is missing: no fallback
         precision = os.environ.get('YOLO_HIP_TRAIN_PRECISION') or \
             ('fp16' if torch.is_autocast_enabled() else 'fp32')
         eng = self.__dict__.get('_hip_train_engine')
         if eng is None or eng.precision != precision:
-            eng = TrainEngine(self, precision=precision)
-            eng._get_plan(x)  # NotImplementedError surfaces here, before any state changes
+            # aligned widths: engine/train.py; widths that are not multiples of 8 (slim-pruned graphs): the same kernels through a
+            # channel-padded twin (engine/padded.py).  NotImplementedError surfaces here, before any state changes
+            eng = make_train_engine(self, precision, x)
             self.__dict__['_hip_train_engine'] = eng
         plan = eng._get_plan(x)
         heads = [None] * len(self.yolo_layers)

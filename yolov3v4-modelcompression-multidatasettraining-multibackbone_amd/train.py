@@ -181,6 +181,9 @@ def train(opt, hyp):
     if distributed:
         model = torch.nn.parallel.DistributedDataParallel(model, device_ids=[rank] if device.type != 'cpu' else None,
                                                           output_device=rank if device.type != 'cpu' else None)
+        if opt.grad_compress == 'fp16':   # gradient buckets cross xGMI as fp16 (half the bytes), master gradients stay fp32
+            from torch.distributed.algorithms.ddp_comm_hooks import default_hooks
+            model.register_comm_hook(None, default_hooks.fp16_compress_hook)
         model.yolo_layers = core.yolo_layers
 
     dataset = LoadImagesAndLabels(train_path, img_size, batch_size, augment=True, hyp=hyp, rect=opt.rect, cache_images=opt.cache_images,
@@ -367,6 +370,7 @@ def make_parser():
     parser.add_argument('--gray-scale', action='store_true', help='gray scale training')
     parser.add_argument('--maxabsscaler', '-mas', action='store_true', help='standardise input to (-1, 1)')
     parser.add_argument('--rank', default=0, help='rank of current process')
+    parser.add_argument('--grad-compress', default='none', choices=['none', 'fp16'], help='DDP comm hook: all-reduce gradient buckets in fp16')
     parser.add_argument('--local_rank', type=int, default=int(os.environ.get('LOCAL_RANK', '-1')), help='set by the launcher')
     return parser
 
