@@ -494,6 +494,31 @@ int yh_maxpool2d_bwd(const yh_pool_bwd_desc* d, void* stream);
 int yh_nchw_to_nhwc(const float* x, void* y, int n, int c, int h, int w, int c_pad, int ldy, int dtype, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------
+ * Input pipeline on the device (first slice): letterbox of ONE uint8 HWC frame into its slot of the fp32 NCHW batch.
+ * Replaces utils/datasets.py letterbox (reference datasets.py:611-646: resize + constant border), the BGR->RGB / HWC->CHW shuffle
+ * (datasets.py:112-113) and `torch.from_numpy(img).to(device).float() / 256.0` (detect.py:99-101).
+ *   tmp[y][x][ch]     = clip8(2^21 + sum_i src[y][hbounds[2x] + i][ch] * hk[x * hksize + i]),  i < hbounds[2x+1]   (horizontal pass)
+ *   v(Y, X, ch)       = clip8(2^21 + sum_i tmp[vbounds[2y] + i][x][ch] * vk[y * vksize + i])  for (y, x) = (Y - top, X - left) inside
+ *                       the new_h x new_w image area, pad_value elsewhere                                         (vertical pass)
+ *   dst[ch'][Y][X]    = scale * v + shift,  ch' = 2 - ch when swap_rb (3 channels), else ch
+ * with clip8(s) = min(max(s >> 22, 0), 255): Pillow's 8-bit resampling; the bounds / coefficient tables come from the host
+ * (engine/preprocess.py restates precompute_coeffs / normalize_coeffs_8bpc).  All pointers are device pointers.             */
+typedef struct yh_letterbox_desc {
+    const uint8_t* src;          /* [h0][src_pitch bytes], c interleaved channels                                   */
+    uint8_t* tmp;                /* [h0][new_w][c] scratch                                                          */
+    float* dst;                  /* [c][out_h][out_w] planes of this frame                                          */
+    const int32_t* hbounds;      /* [new_w][2]  (first source column, count)                                        */
+    const int32_t* hk;           /* [new_w][hksize] fixed-point coefficients (22 fractional bits)                   */
+    const int32_t* vbounds;      /* [new_h][2]                                                                      */
+    const int32_t* vk;           /* [new_h][vksize]                                                                 */
+    int32_t h0, w0, c, src_pitch, hksize, vksize;
+    int32_t new_h, new_w, out_h, out_w, top, left;
+    int32_t pad_value, swap_rb;
+    float scale, shift;          /* detect.py:101: 1/256, 0;  --maxabsscaler: 2/256, -1                              */
+} yh_letterbox_desc;
+int yh_letterbox_fwd(const yh_letterbox_desc* d, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------
  * Plans: a recorded sequence of the launches above, replayed by one native call per forward (the
  * replacement for the per-layer Python dispatch loop of models.py:524-545).  Pointers that change
  * from call to call (network input, per-call outputs) are "slots": a fixup patches one pointer field

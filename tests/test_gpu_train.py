@@ -611,7 +611,9 @@ def test_mini_sgd_steps_track_eager(libs, mini):
         ob.step()
     for (k, pa), (_, pb) in zip(a.state_dict().items(), b.state_dict().items()):
         if pa.dtype.is_floating_point:
-            assert (pa - pb.cpu()).abs().max().item() <= 1e-4 * (pa.abs().max().item() + 1e-3), k
+            # 3e-4: the wgrad split sums meet in fp32 atomics whose order varies run to run; over five steps one leaky-ReLU kink that
+            # flips on that last-bit difference moves a weight by ~1e-4 relative (seen once in ~5 runs at 1e-4)
+            assert (pa - pb.cpu()).abs().max().item() <= 3e-4 * (pa.abs().max().item() + 1e-3), k
 
 
 @pytest.mark.parametrize('rel', ['yolov3tiny/yolov3-tiny.cfg', 'yolov4/yolov4.cfg', 'yolov4tiny/yolov4-tiny.cfg',

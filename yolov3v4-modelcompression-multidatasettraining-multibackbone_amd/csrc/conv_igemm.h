@@ -271,8 +271,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, AccT (&acc)[TM]
     if (a.ups == 1) {
         switch (a.act) {
 #define YH_PLAIN(A) case A: conv_epilogue_plain<T, OutT, TM, TN, BN, WN, A>(a, acc, bvs, m0, p0, wm, wn, lane); return
-            YH_PLAIN(YH_ACT_LINEAR); YH_PLAIN(YH_ACT_LEAKY); YH_PLAIN(YH_ACT_RELU); YH_PLAIN(YH_ACT_RELU6); YH_PLAIN(YH_ACT_HSWISH);
-            YH_PLAIN(YH_ACT_MISH);
+            // the activations of the YOLOv3 / v4 graphs; the Mobilenet ones (relu, relu6, h-swish) take the general form below
+            YH_PLAIN(YH_ACT_LINEAR); YH_PLAIN(YH_ACT_LEAKY); YH_PLAIN(YH_ACT_MISH);
 #undef YH_PLAIN
             default: break;
         }

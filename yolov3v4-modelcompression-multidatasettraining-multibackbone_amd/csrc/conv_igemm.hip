@@ -680,17 +680,27 @@ __global__ __launch_bounds__(512, (BM <= 128 ? 4 : 2)) void conv3x3_halo_kernel(
         if (++tap == 9) { tap = 0; ++chunk; }
     }
 
-    // ---- epilogue: virtual position -> real pixel (padding positions are dropped)
+    // ---- epilogue: virtual position -> real pixel (padding positions are dropped).  Bias and the residual column are loaded
+    // BEFORE the stores they precede (one in-order memory counter: a load behind a store waits for the store's acknowledgement)
     const int mq = (lane >> 4) << 2;
     OutT* const yg = reinterpret_cast<OutT*>(a.y);
     const T* const rg = reinterpret_cast<const T*>(a.res);
+    f32x4 bvs[TM];
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
+    for (int i = 0; i < TM; ++i) {
+        const int m = m0 + wm * TM * 16 + i * 16 + mq;
+        bvs[i] = m < a.Cout ? *reinterpret_cast<const f32x4*>(a.bias + m) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i) asm volatile("" ::"v"(bvs[i]));
+    typedef typename ResVec<T>::type res_t;
+    static_for<TN>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
         const long q = q0 + wn * TN * 16 + j * 16 + r16;
         const long n = q / IMG;
         const int rem = (int)(q - n * IMG);
         const int yy = rem / Wp - 1, xx = rem - (rem / Wp) * Wp - 1;
-        if (n >= a.N || yy < 0 || xx < 0 || xx >= a.W) continue;
+        const bool ok = !(n >= a.N || yy < 0 || xx < 0 || xx >= a.W);
         const long p = (n * a.H + yy) * (long)a.W + xx;
         long opix = p;
         int wo2 = 0;
@@ -698,19 +708,33 @@ __global__ __launch_bounds__(512, (BM <= 128 ? 4 : 2)) void conv3x3_halo_kernel(
             wo2 = 2 * a.W;
             opix = (n * 2 * a.H + 2 * yy) * (long)wo2 + 2 * xx;
         }
+        res_t rv[TM];
+        const bool have_res = rg != nullptr;
+        if (have_res) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int m = m0 + wm * TM * 16 + i * 16 + mq;
+                rv[i] = res_t{};
+                if (ok && m < a.Cout) rv[i] = *reinterpret_cast<const res_t*>(rg + p * a.ldr + m);
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                res_t t = rv[i];
+                asm volatile("" : "+v"(t));
+                rv[i] = t;
+            }
+        }
+        if (!ok) return;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             const int m = m0 + wm * TM * 16 + i * 16 + mq;
             if (m >= a.Cout) continue;
-            const f32x4 bv = *reinterpret_cast<const f32x4*>(a.bias + m);
             float v[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = activate(acc[i][j][e] + bv[e], a.act, a.slope);
-            if (rg != nullptr) {
-                float r4[4];
-                load4<T>(rg + (a.ups == 3 ? opix : p) * a.ldr + m, r4);
+            for (int e = 0; e < 4; ++e) v[e] = activate(acc[i][j][e] + bvs[i][e], a.act, a.slope);
+            if (have_res) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] += r4[e];
+                for (int e = 0; e < 4; ++e) v[e] += (float)rv[i][e];
             }
             OutT* dst = yg + opix * a.ldy + m;
             store4<OutT>(dst, v[0], v[1], v[2], v[3]);
@@ -720,7 +744,7 @@ __global__ __launch_bounds__(512, (BM <= 128 ? 4 : 2)) void conv3x3_halo_kernel(
                 store4<OutT>(dst + (long)(wo2 + 1) * a.ldy, v[0], v[1], v[2], v[3]);
             }
         }
-    }
+    });
 }
 
 template <typename T, typename OutT, int BM> static int launch_halo(const ConvArgs& a0, hipStream_t stream) {

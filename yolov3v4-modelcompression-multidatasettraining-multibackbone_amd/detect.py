@@ -41,7 +41,8 @@ def detect(opt, save_img=True):
             load_darknet_weights(model, weights)
     model.to(device).eval()
 
-    dataset = LoadImages(source, img_size=imgsz, is_gray_scale=opt.gray_scale, rect=opt.rect)
+    device_letterbox = device.type == 'cuda' and not getattr(opt, 'host_letterbox', False)
+    dataset = LoadImages(source, img_size=imgsz, is_gray_scale=opt.gray_scale, rect=opt.rect, host_letterbox=not device_letterbox)
     names = load_classes(opt.names) if opt.names and os.path.isfile(opt.names) else [str(i) for i in range(1000)]
     rng = random.Random(0)
     colors = [[rng.randint(0, 255) for _ in range(3)] for _ in range(len(names))]
@@ -49,9 +50,15 @@ def detect(opt, save_img=True):
     t0 = time.time()
     results = []
     for path, img, im0, _ in dataset:
-        x = torch.from_numpy(img).to(device).float() / 256.0      # uint8 -> [0, 1) like detect.py:101
-        if opt.maxabsscaler:
-            x = x * 2 - 1
+        if device_letterbox:
+            # the decoded frame goes to the GPU as it is; resize + border + x / 256 + HWC -> CHW run there (csrc/preprocess.hip),
+            # bit-identical to the loader's host letterbox (tests/test_preprocess.py)
+            from engine.preprocess import letterbox_to_device
+            x, _, _ = letterbox_to_device(im0, imgsz, device, auto=opt.rect, maxabsscaler=opt.maxabsscaler)
+        else:
+            x = torch.from_numpy(img).to(device).float() / 256.0      # uint8 -> [0, 1) like detect.py:101
+            if opt.maxabsscaler:
+                x = x * 2 - 1
         if x.ndimension() == 3:
             x = x.unsqueeze(0)
         t1 = torch_utils.time_synchronized()
@@ -102,6 +109,7 @@ def make_parser():
     parser.add_argument('--fourcc', type=str, default='mp4v', help='output video codec (unused: no video I/O here)')
     parser.add_argument('--device', default='', help='device id (i.e. 0 or 0,1) or cpu')
     parser.add_argument('--rect', action='store_true', help='rectangular detecting')
+    parser.add_argument('--host-letterbox', action='store_true', help='letterbox on the host (default on a GPU: on the device)')
     parser.add_argument('--view-img', action='store_true', help='display results (unused: headless)')
     parser.add_argument('--save-txt', action='store_true', help='save results to *.txt')
     parser.add_argument('--classes', nargs='+', type=int, help='filter by class')

@@ -142,6 +142,13 @@ class UpsampleBwdDesc(ResampleDesc):
     pass
 
 
+class LetterboxDesc(C.Structure):
+    _fields_ = [('src', _vp), ('tmp', _vp), ('dst', _vp), ('hbounds', _vp), ('hk', _vp), ('vbounds', _vp), ('vk', _vp),
+                ('h0', _i32), ('w0', _i32), ('c', _i32), ('src_pitch', _i32), ('hksize', _i32), ('vksize', _i32),
+                ('new_h', _i32), ('new_w', _i32), ('out_h', _i32), ('out_w', _i32), ('top', _i32), ('left', _i32),
+                ('pad_value', _i32), ('swap_rb', _i32), ('scale', _f32), ('shift', _f32)]
+
+
 class LayoutDesc(C.Structure):
     _fields_ = [('x', _vp), ('y', _vp), ('n', _i32), ('c', _i32), ('h', _i32), ('w_in', _i32), ('c_pad', _i32), ('ldy', _i32),
                 ('dtype', _i32)]
@@ -259,6 +266,7 @@ _SIGNATURES = {
     'yh_yolo_loss_fwd': (C.c_int, [C.POINTER(LossDesc), _vp]),
     'yh_yolo_loss_bwd': (C.c_int, [C.POINTER(LossDesc), _vp]),
     'yh_nchw_to_nhwc': (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
+    'yh_letterbox_fwd': (C.c_int, [C.POINTER(LetterboxDesc), _vp]),
     'yh_plan_create': (_vp, []),
     'yh_plan_destroy': (None, [_vp]),
     'yh_plan_add': (C.c_int, [_vp, C.c_int, _vp, C.c_int]),

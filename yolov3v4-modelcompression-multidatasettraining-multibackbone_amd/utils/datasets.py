@@ -88,7 +88,7 @@ def letterbox(img, new_shape=(416, 416), color=(PAD_VALUE,) * 3, auto=True, scal
 class LoadImages:
     """Iterate image files for inference (datasets.py:43-124): yields ``(path, chw_uint8_rgb, im0_hwc_rgb, None)``."""
 
-    def __init__(self, path, img_size=416, is_gray_scale=False, rect=False):
+    def __init__(self, path, img_size=416, is_gray_scale=False, rect=False, host_letterbox=True):
         path = str(Path(path))
         if os.path.isdir(path):
             files = sorted(glob.glob(os.path.join(path, '*.*')))
@@ -102,6 +102,7 @@ class LoadImages:
             raise NotImplementedError('video input needs OpenCV, which this image does not ship: %s' % videos[0])
         assert self.files, 'No images found in %s. Supported formats: %s' % (path, img_formats)
         self.img_size, self.is_gray_scale, self.rect = img_size, is_gray_scale, rect
+        self.host_letterbox = host_letterbox   # False: the caller letterboxes on the GPU (engine/preprocess.py); img is None
         self.nF, self.mode, self.cap = len(self.files), 'images', None
 
     def __iter__(self):
@@ -115,6 +116,8 @@ class LoadImages:
         self.count += 1
         im0 = _read(path, self.is_gray_scale)
         print('image %g/%g %s: ' % (self.count, self.nF, path), end='')
+        if not self.host_letterbox:
+            return path, None, im0, self.cap
         img = letterbox(im0, new_shape=self.img_size, auto=self.rect, is_gray_scale=self.is_gray_scale)[0]
         return path, np.ascontiguousarray(img.transpose(2, 0, 1)), im0, self.cap
 
