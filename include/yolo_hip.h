@@ -110,6 +110,11 @@ typedef struct yh_conv_desc {
     float* stats_ws;              /* training forward: when set, the epilogue also emits per-channel partial sums of  */
     int64_t stats_ws_floats;      /* y and y*y (as stored) — yh_conv2d_stats_rows(d) rows of [2][cout] floats — which  */
                                   /* yh_bn_finalize (nparts) turns into the batch statistics: no separate pass over y */
+    /* int8 only, with res != NULL: the quantised shortcut that follows the conv (COSPTQuantizedShortcut_min / _max eval,
+     * quantized_ptq_cos.py:877-912) in the same epilogue, exactly yh_qadd's arithmetic on the value q the conv would have stored:
+     *   y = clamp(round((round(q * q_rx) * q_scale_x + round(res * q_ra) * q_scale_a) * q_inv_scale_sum))
+     * q_rx = conv activation scale / scale_x, q_ra = scale of the routed tensor / scale_a; res is int8 NHWC (pitch ldr).  */
+    float q_rx, q_ra, q_scale_x, q_scale_a, q_inv_scale_sum;
 } yh_conv_desc;
 int64_t yh_conv2d_stats_rows(const yh_conv_desc* d);
 

@@ -179,7 +179,7 @@ class FakeLib:
         return 0
 
     def _qconv(self, d):
-        assert d.cin % 16 == 0 and d.ldx % 16 == 0 and d.cin_k % 64 == 0 and not _addr(d.res)
+        assert d.cin % 16 == 0 and d.ldx % 16 == 0 and d.cin_k % 64 == 0
         x = torch.from_numpy(pitched(d.x, d.n * d.h * d.w_in, d.cin, d.ldx, np.int8).astype(np.float64))
         x = x.view(d.n, d.h, d.w_in, d.cin).permute(0, 3, 1, 2)
         taps = d.kh * d.kw
@@ -190,6 +190,12 @@ class FakeLib:
         y = (acc.float() * d.acc_scale + b.view(1, -1, 1, 1))
         y = _act(y, d.act, d.slope)
         q = rnd_away(y / d.out_scale).clamp(-128, 127)
+        if _addr(d.res):   # fused quantised shortcut (yh_qadd on the value the conv would have stored)
+            assert d.ups == 1 and not d.out_f32 and d.act in (0, 1, 5) and d.q_rx > 0 and d.q_inv_scale_sum > 0
+            r = torch.from_numpy(pitched(d.res, d.n * d.ho * d.wo, d.cout, d.ldr, np.int8).astype(np.float32))
+            r = r.view(d.n, d.ho, d.wo, d.cout).permute(0, 3, 1, 2)
+            ssum = rnd_away(q * d.q_rx) * d.q_scale_x + rnd_away(r * d.q_ra) * d.q_scale_a
+            q = rnd_away(ssum * d.q_inv_scale_sum).clamp(-128, 127)
         if d.ups == 2:
             q = q.repeat_interleave(2, 2).repeat_interleave(2, 3)
         if d.out_f32:

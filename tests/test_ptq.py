@@ -58,7 +58,9 @@ def test_int8_lowering_tracks_reference_eval():
     assert mx <= 0.05 and frac <= 0.02, (mx, frac)
     plan = next(iter(eng._plans.values()))
     kinds = [''.join(c for c in w if not c.isdigit()) for w, _ in plan['ops']]
-    assert kinds.count('qadd') == 3 and 'stem' in kinds and 'yolo' in kinds
+    # the three quantised shortcuts ride in their producing convs' epilogues (YOLO_HIP_FUSE_QADD=0 keeps them as yh_qadd launches)
+    fused = [d for w, d in plan['ops'] if w.startswith('conv') and d.res]
+    assert kinds.count('qadd') == 0 and len(fused) == 3 and 'stem' in kinds and 'yolo' in kinds
 
 
 @pytest.mark.gpu
@@ -87,3 +89,23 @@ def test_hip_int8_engine_matches_reference_eval():
     assert sum(0 if g is None else len(g) for g in gt) >= 10
     det = non_max_suppression(io.cuda(), conf * 0.9, 0.6, multi_label=False)
     assert abs(map50(gt, det) - map50(gt, gt)) <= 0.002
+
+
+def test_fused_and_unfused_shortcut_lowerings_agree(monkeypatch):
+    """The quantised shortcut inside the conv epilogue is yh_qadd's arithmetic on the value the conv would have stored: both plans
+    must produce identical int8 graphs (host emulation)."""
+    from engine.plan import DarknetEngine
+    x = synth.image_batch(2, SIZE, seed=7)
+    outs = {}
+    for flag in ('1', '0'):
+        monkeypatch.setenv('YOLO_HIP_FUSE_QADD', flag)
+        m, fx = build_qmodel()
+        eng = DarknetEngine(m, precision='int8', lib=fakelib.FakeLib())
+        io, raws, _ = eng(x)
+        plan = next(iter(eng._plans.values()))
+        kinds = [''.join(c for c in w if not c.isdigit()) for w, _ in plan['ops']]
+        assert kinds.count('qadd') == (0 if flag == '1' else 3)
+        outs[flag] = (io, raws)
+    assert torch.equal(outs['1'][0], outs['0'][0])
+    for a, b in zip(outs['1'][1], outs['0'][1]):
+        assert torch.equal(a, b)

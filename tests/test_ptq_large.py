@@ -173,7 +173,7 @@ def test_shortcut_max_lowering_on_the_emulated_engine():
     _mini_tolerances(io, torch.from_numpy(fx['inf']))
     plan = next(iter(eng._plans.values()))
     kinds = [''.join(c for c in w if not c.isdigit()) for w, _ in plan['ops']]
-    assert kinds.count('qadd') == 3
+    assert kinds.count('qadd') == 0 and len([d for w, d in plan['ops'] if w.startswith('conv') and d.res]) == 3
 
 
 @pytest.mark.gpu

@@ -25,6 +25,7 @@ struct ConvArgs {
     int ups;
     float* stats_part;   // training forward: per (pixel tile, wave column) partial sums of y and y^2 per channel, or NULL
     int y_h, y_w, y_off_h, y_off_w;  // ups == 3: output pixel (n, ho, wo) is stored at (n, 2 ho + y_off_h, 2 wo + y_off_w) of a y_h x y_w tensor
+    float q_rx, q_ra, q_scale_x, q_scale_a, q_inv_scale_sum;   // int8 + res: fused quantised shortcut (yh_qadd arithmetic)
 };
 
 template <int CTRL> __device__ __forceinline__ float dpp_shr_add(float v) {
@@ -123,6 +124,14 @@ __device__ __forceinline__ int swz_f(int g) { return (0x78 >> (2 * (g & 3))) & 3
 // 16 x 16 fragment (i, j) of its wave tile: bias + activation (+ residual) -> one 8-byte (f16) / 16-byte (f32) / 4-byte (i8)
 // NHWC store; optional 2x nearest store, stride-2 data-gradient phase scatter (ups 3 / 4), int8 requantisation, and the
 // per-tile BatchNorm partial sums of the training forward.
+// Quantised shortcut on a conv output grid value q and a routed int8 value r (csrc/quant.hip qadd_kernel, operation for
+// operation; __fmul_rn / __fadd_rn keep the products and the sum from being contracted into an fma)
+__device__ __forceinline__ float qadd_value(float q, float r, const ConvArgs& a) {
+    const float xq = __fmul_rn(copysignf(floorf(fabsf(__fmul_rn(q, a.q_rx)) + 0.5f), __fmul_rn(q, a.q_rx)), a.q_scale_x);
+    const float aq = __fmul_rn(copysignf(floorf(fabsf(__fmul_rn(r, a.q_ra)) + 0.5f), __fmul_rn(r, a.q_ra)), a.q_scale_a);
+    return round_clamp_i8(__fmul_rn(__fadd_rn(xq, aq), a.q_inv_scale_sum));
+}
+
 template <typename T> struct ResVec { typedef f16x4 type; };
 template <> struct ResVec<float> { typedef f32x4 type; };
 template <> struct ResVec<int8_t> { typedef unsigned type; };
@@ -198,7 +207,7 @@ __device__ __forceinline__ void conv_epilogue_plain(const ConvArgs& a, AccT (&ac
         constexpr int j0 = decltype(cc)::value * JCH;
         res_t rv[JCH][TM];
         bool have_res = false;
-        if constexpr (sizeof(T) != 1) {
+        {
             have_res = rg != nullptr;
             if (have_res) {
                 static_for<JCH>([&](auto jc) {
@@ -238,6 +247,11 @@ __device__ __forceinline__ void conv_epilogue_plain(const ConvArgs& a, AccT (&ac
                     if (have_res) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[e] += (float)rv[jj][i][e];
+                    }
+                } else if constexpr (sizeof(OutT) == 1) {
+                    if (have_res) {   // fused quantised shortcut: v holds the grid values the conv would have stored
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = qadd_value(v[e], (float)(int8_t)((rv[jj][i] >> (8 * e)) & 0xff), a);
                     }
                 }
                 store4<OutT>(prow + m, v[0], v[1], v[2], v[3]);

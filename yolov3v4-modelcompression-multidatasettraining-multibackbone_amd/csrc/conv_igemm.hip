@@ -869,6 +869,7 @@ template <typename OutT> static int dispatch_tile_i8(const ConvArgs& a, int tile
         case 25: return launch_glds<int8_t, OutT, 128, 64, 2, 2, 3>(a, s);
         case 26: return launch_glds<int8_t, OutT, 256, 128, 4, 2, 3>(a, s);
         case 27: return launch_glds<int8_t, OutT, 128, 256, 2, 4, 3>(a, s);
+        case 64: case 65: case 66: return launch_k64_tile(a, tile, YH_I8, std::is_same<OutT, float>::value ? 1 : 0, s);
         default: return YH_EINVAL;
     }
 }
@@ -912,7 +913,8 @@ extern "C" int yh_qconv_pack_weights(const float* q_weight, float w_scale, const
 // Long K (3x3 over >= 256 channels) with a workgroup count that fills whole rounds of 256 CUs goes to ping-pong; 1x1 layers
 // (4 - 16 K tiles: the fixed cost dominates) and everything else stay on the ring kernels.
 static int pick_pp_tile(const yh_conv_desc* d) {
-    if (d->dtype != YH_F16 || d->ups == 4 || d->cin != d->cin_k || d->cin_k % 64) return 0;
+    const int line = d->dtype == YH_I8 ? 128 : 64;          // channels per 128-byte line
+    if ((d->dtype != YH_F16 && d->dtype != YH_I8) || d->ups == 4 || d->cin != d->cin_k || d->cin_k % line) return 0;
     const int taps = d->kh * d->kw;
     if (taps < 4 || d->cout < 256) return 0;
     const long P = (long)d->n * d->ho * d->wo;
@@ -920,8 +922,8 @@ static int pick_pp_tile(const yh_conv_desc* d) {
     if ((long)d->n * d->h * d->w_in * d->ldx + (long)(d->kh + 1) * d->w_in * d->ldx >= 0x7fffffffL) return 0;
     if ((long)d->m_pad * taps * d->cin_k >= 0x7fffffffL || d->h >= 32768 || d->w_in >= 32768) return 0;
     const double flops = 2.0 * (double)P * d->cout * taps * d->cin;
-    const double ring = flops / 420e3;
-    const long nk = (long)taps * d->cin_k / 64;
+    const double ring = flops / (d->dtype == YH_I8 ? 760e3 : 420e3);     // int8 ring kernels: ~1.6 POP/s on 3x3 layers
+    const long nk = (long)taps * d->cin_k / line;
     auto pp = [&](int bm, int bn) {
         const long blocks = (long)((d->cout + bm - 1) / bm) * ((P + bn - 1) / bn);
         return (double)((blocks + 255) / 256) * (20000.0 + 3300.0 * nk);
@@ -970,7 +972,13 @@ extern "C" int yh_conv2d_fwd(const yh_conv_desc* d, void* stream) {
     if (d->kh <= 0 || d->kw <= 0 || d->stride <= 0 || d->pad < 0) return YH_EINVAL;
     if (d->dtype != YH_F16 && d->dtype != YH_F32 && d->dtype != YH_I8) return YH_EINVAL;
     const int bk = d->dtype == YH_F16 ? 32 : (d->dtype == YH_I8 ? 64 : 16), vec = d->dtype == YH_F16 ? 8 : (d->dtype == YH_I8 ? 16 : 4);
-    if (d->dtype == YH_I8 && (d->res || !(d->acc_scale > 0.f) || !(d->out_scale > 0.f))) return YH_EINVAL;
+    if (d->dtype == YH_I8 && (!(d->acc_scale > 0.f) || !(d->out_scale > 0.f))) return YH_EINVAL;
+    if (d->dtype == YH_I8 && d->res) {
+        // fused quantised shortcut: plain int8 store with one of the compile-time activations, positive scales, int8 residual rows
+        if (d->ups != 1 || d->out_f32 || !(d->q_rx > 0.f) || !(d->q_ra > 0.f) || !(d->q_scale_x > 0.f) || !(d->q_scale_a > 0.f) ||
+            !(d->q_inv_scale_sum > 0.f) || d->ldr % 16 || (((uintptr_t)d->res) & 3u)) return YH_EINVAL;
+        if (d->act != YH_ACT_LINEAR && d->act != YH_ACT_LEAKY && d->act != YH_ACT_MISH) return YH_EUNSUPPORTED;
+    }
     if (d->cin % vec || d->ldx % vec || d->cin_k % bk || d->cin_k < d->cin || d->m_pad % 128 || d->m_pad < d->cout) return YH_EALIGN;
     if (d->cout % 4 || d->ldy % 4 || (d->res && d->ldr % 4)) return YH_EALIGN;
     if (!aligned16(d->x) || !aligned16(d->w) || !aligned16(d->bias) || (((uintptr_t)d->y) & 7u) || (((uintptr_t)d->res) & 7u)) return YH_EALIGN;
@@ -1002,6 +1010,7 @@ extern "C" int yh_conv2d_fwd(const yh_conv_desc* d, void* stream) {
     a.acc_scale = d->acc_scale; a.out_scale = d->out_scale; a.inv_out_scale = d->out_scale > 0.f ? 1.f / d->out_scale : 0.f;
     a.act = d->act; a.slope = d->slope; a.ups = d->ups;
     a.y_h = d->y_h; a.y_w = d->y_w; a.y_off_h = d->y_off_h; a.y_off_w = d->y_off_w;
+    a.q_rx = d->q_rx; a.q_ra = d->q_ra; a.q_scale_x = d->q_scale_x; a.q_scale_a = d->q_scale_a; a.q_inv_scale_sum = d->q_inv_scale_sum;
     a.stats_part = nullptr;
     if (d->stats_ws) {
         // fused BatchNorm statistics: plain dense output only, and never on the halo kernels
@@ -1020,7 +1029,7 @@ extern "C" int yh_conv2d_fwd(const yh_conv_desc* d, void* stream) {
         return d->out_f32 ? dispatch_tile<f16, float>(a, tile, s) : dispatch_tile<f16, f16>(a, tile, s);
     }
     if (d->dtype == YH_I8) {
-        return d->out_f32 ? dispatch_tile_i8<float>(a, d->tile, s) : dispatch_tile_i8<int8_t>(a, d->tile, s);
+        return d->out_f32 ? dispatch_tile_i8<float>(a, tile, s) : dispatch_tile_i8<int8_t>(a, tile, s);
     }
     return dispatch_tile<float, float>(a, tile, s);
 }

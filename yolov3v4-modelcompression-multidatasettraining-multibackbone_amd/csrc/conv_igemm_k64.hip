@@ -249,7 +249,7 @@ static int launch_k64(const ConvArgs& a0, hipStream_t stream) {
 // Write-after-read: a region of the other stage was last read two or more phases before its refill is issued.
 template <typename T, typename OutT, int WM, int WN>
 __global__ __launch_bounds__(512, 2) void conv_igemm_pp_kernel(const ConvArgs a) {
-    static_assert(WM * WN == 8 && sizeof(T) == 2, "8 waves, f16");
+    static_assert(WM * WN == 8 && sizeof(T) <= 2, "8 waves; f16 (64 channels per line) or int8 (128 channels per line)");
     constexpr int VEC = Prec<T>::VEC, BK = VEC * 8;
     constexpr int BM = WM * 128, BN = WN * 64;
     constexpr int TM = 8, TN = 4;
@@ -351,14 +351,17 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_pp_kernel(const ConvArgs a)
     typedef std::integral_constant<int, 0> H0;
     typedef std::integral_constant<int, 1> H1;
 
-    f32x4 acc[TM][TN];
+    typedef typename AccOf<T>::type acc_t;
+    acc_t acc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < TN; ++j) acc[i][j] = acc_t{0, 0, 0, 0};
 
-    // fragment registers: A half (4 fragments x 2 K halves), both B halves (2 fragments x 2 K halves each)
-    f16x8 fa[2][4], fb[2][2][2];
+    // fragment registers: A half (4 fragments x 2 K halves), both B halves (2 fragments x 2 K halves each); a fragment is one
+    // 16-byte cell per lane: 8 f16 (v_mfma_f32_16x16x32_f16) or 16 int8 (v_mfma_i32_16x16x64_i8)
+    typedef typename std::conditional<sizeof(T) == 2, f16x8, i32x4>::type frag_t;
+    frag_t fa[2][4], fb[2][2][2];
     const int r16 = lane & 15, kq = lane >> 4, fsw = (r16 >> 1) & 7;
     const int off0 = r16 * 8 + ((0 + kq) ^ fsw), off1 = r16 * 8 + ((4 + kq) ^ fsw);
     const int arow = wm * 128, brow = BM + wn * 64;
@@ -367,8 +370,8 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_pp_kernel(const ConvArgs a)
         for (int i = 0; i < 4; ++i) {
             u32x4 v0 = st[(arow + half * 64 + i * 16) * 8 + off0];
             u32x4 v1 = st[(arow + half * 64 + i * 16) * 8 + off1];
-            fa[0][i] = *reinterpret_cast<f16x8*>(&v0);
-            fa[1][i] = *reinterpret_cast<f16x8*>(&v1);
+            fa[0][i] = *reinterpret_cast<frag_t*>(&v0);
+            fa[1][i] = *reinterpret_cast<frag_t*>(&v1);
         }
     };
     auto read_b = [&](const u32x4* st, auto hc) {
@@ -377,8 +380,8 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_pp_kernel(const ConvArgs a)
         for (int j = 0; j < 2; ++j) {
             u32x4 v0 = st[(brow + h * 32 + j * 16) * 8 + off0];
             u32x4 v1 = st[(brow + h * 32 + j * 16) * 8 + off1];
-            fb[h][0][j] = *reinterpret_cast<f16x8*>(&v0);
-            fb[h][1][j] = *reinterpret_cast<f16x8*>(&v1);
+            fb[h][0][j] = *reinterpret_cast<frag_t*>(&v0);
+            fb[h][1][j] = *reinterpret_cast<frag_t*>(&v1);
         }
     };
     auto mma = [&](auto ac, auto bc) {   // quadrant (a, b): 4 x 2 fragments x 2 K halves, channel order within the line
@@ -390,8 +393,12 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_pp_kernel(const ConvArgs a)
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
-                    acc[ah * 4 + i][bh * 2 + j] =
-                        __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[k][i], fb[bh][k][j], acc[ah * 4 + i][bh * 2 + j], 0, 0, 0);
+                    if constexpr (sizeof(T) == 2)
+                        acc[ah * 4 + i][bh * 2 + j] =
+                            __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[k][i], fb[bh][k][j], acc[ah * 4 + i][bh * 2 + j], 0, 0, 0);
+                    else
+                        acc[ah * 4 + i][bh * 2 + j] =
+                            __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[k][i], fb[bh][k][j], acc[ah * 4 + i][bh * 2 + j], 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
     };
     // end of an interval: all of this wave's LDS reads have returned (they feed the MFMAs after the barrier), then the barrier
@@ -766,8 +773,18 @@ template <typename T, typename OutT> static int dispatch_k64(const ConvArgs& a, 
     }
 }
 
+template <typename OutT> static int dispatch_pp_i8(const ConvArgs& a, int tile, hipStream_t s) {
+    switch (tile) {   // int8: one line = 128 channels of a tap
+        case 64: return launch_pp<int8_t, OutT, 2, 4>(a, s);
+        case 65: return launch_pp<int8_t, OutT, 1, 8>(a, s);
+        case 66: return launch_pp<int8_t, OutT, 4, 2>(a, s);
+        default: return YH_EINVAL;
+    }
+}
+
 int launch_k64_tile(const ConvArgs& a, int tile, int dtype, int out_f32, hipStream_t stream) {
     if (dtype == YH_F16) return out_f32 ? dispatch_k64<f16, float>(a, tile, stream) : dispatch_k64<f16, f16>(a, tile, stream);
+    if (dtype == YH_I8) return out_f32 ? dispatch_pp_i8<float>(a, tile, stream) : dispatch_pp_i8<int8_t>(a, tile, stream);
     return YH_EINVAL;
 }
 

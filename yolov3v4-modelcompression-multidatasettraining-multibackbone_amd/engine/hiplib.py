@@ -27,7 +27,8 @@ class ConvDesc(C.Structure):
                 ('cin_k', _i32), ('m_pad', _i32),
                 ('act', _i32), ('slope', _f32), ('ups', _i32), ('out_f32', _i32), ('dtype', _i32), ('tile', _i32),
                 ('acc_scale', _f32), ('out_scale', _f32),
-                ('y_h', _i32), ('y_w', _i32), ('y_off_h', _i32), ('y_off_w', _i32), ('stats_ws', _vp), ('stats_ws_floats', _i64)]
+                ('y_h', _i32), ('y_w', _i32), ('y_off_h', _i32), ('y_off_w', _i32), ('stats_ws', _vp), ('stats_ws_floats', _i64),
+                ('q_rx', _f32), ('q_ra', _f32), ('q_scale_x', _f32), ('q_scale_a', _f32), ('q_inv_scale_sum', _f32)]
 
 
 class StemDesc(C.Structure):

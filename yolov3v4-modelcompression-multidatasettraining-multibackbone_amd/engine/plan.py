@@ -217,6 +217,10 @@ class DarknetEngine:
                     v.res = ref(i + 1, mods[i + 1].layers[0])
                     skip.add(i + 1)
                     hidden = True
+                    if self.q:   # quantised shortcut in the conv epilogue: the value leaves on the SUM grid
+                        sc = mods[i + 1]
+                        v.qadd = (float(sc.scale_x), float(sc.scale_a), float(sc.scale_sum))
+                        v.act_scale, v.scale = v.scale, float(sc.scale_sum)
                 elif nxt == 'upsample' and not routs[i] and not keep and int(defs[i + 1]['stride']) == 2:
                     v.ups = 2
                     v.H, v.W = 2 * Ho, 2 * Wo
@@ -331,12 +335,18 @@ class DarknetEngine:
 
     def _fusable_shortcut(self, j, conv_value, outs):
         module = self.model.module_list[j]
-        if module.__class__.__name__ != 'Shortcut' or getattr(module, 'weight', False) or len(module.layers) != 1:
+        names = ('COSPTQuantizedShortcut_min', 'COSPTQuantizedShortcut_max') if self.q else ('Shortcut',)
+        if module.__class__.__name__ not in names or getattr(module, 'weight', False) or len(module.layers) != 1:
             return False
         l = module.layers[0]
         other = outs[j + l if l < 0 else l]
-        return (other is not None and other.C == conv_value.C and (other.H, other.W) == (conv_value.H, conv_value.W)
-                and other.is_dense())
+        ok = (other is not None and other.C == conv_value.C and (other.H, other.W) == (conv_value.H, conv_value.W)
+              and other.is_dense())
+        if ok and self.q:
+            # the int8 epilogue carries the shortcut for the compile-time activations only; the routed tensor must be on a grid
+            ok = (conv_value.act in (hiplib.ACT_CODES['linear'], hiplib.ACT_CODES['leaky'], hiplib.ACT_CODES['mish'])
+                  and other.scale is not None and conv_value.C % 16 == 0 and os.environ.get('YOLO_HIP_FUSE_QADD', '1') != '0')
+        return ok
 
     def _place(self, values):
         """Decide which values are produced directly into a concat buffer's channel slice."""
@@ -575,6 +585,10 @@ class DarknetEngine:
                                  ldr=0 if v.res is None else v.res.ld, ldy=v.ld, cin_k=pk['cin_k'], m_pad=pk['m_pad'],
                                  act=v.act, slope=v.slope, ups=v.ups, out_f32=1 if v.fp32 else 0, dtype=self.code, tile=tile,
                                  acc_scale=(v.s_w * s.scale) if self.q else 0.0, out_scale=v.scale if self.q else 0.0)
+                    if self.q and v.res is not None:
+                        sx, sa, ssum = v.qadd
+                        d.out_scale = v.act_scale
+                        d.q_rx, d.q_ra, d.q_scale_x, d.q_scale_a, d.q_inv_scale_sum = v.act_scale / sx, v.res.scale / sa, sx, sa, 1.0 / ssum
                     add(d, 'conv%d' % v.block)
             elif v.kind == 'dw':
                 pk = self._packed.get(v.block) or self._pack_dw(v)
