@@ -65,12 +65,14 @@ def mini_fixture(ref, way, fname):
 
 
 EVAL_CASES = [   # name, cfg, size, batch, row stride: the BASELINE graphs the int8 bench times (configs 2 and 4)
-    ('yolov3_608', 'yolov3/yolov3.cfg', 608, 1, 64),
-    ('yolov4_640', 'yolov4/yolov4.cfg', 640, 1, 64),
+    ('yolov3_608', 'yolov3/yolov3.cfg', 608, 1, 64, 'plain'),
+    # plain seeded BN statistics collapse YOLOv4's 110 convs (every cell of an anchor within 1e-4 of the same objectness): the layer
+    # gains are equalised first (synth.equalize_bn_gain_), as in the fp16 mAP protocol
+    ('yolov4_640', 'yolov4/yolov4.cfg', 640, 1, 64, 'equalized'),
 ]
 
 
-def eval_fixture(ref, name, rel, size, batch, row_stride):
+def eval_fixture(ref, name, rel, size, batch, row_stride, conditioning):
     """EVAL-mode int8 golden on a full BASELINE graph: the reference's quantized=3 modules with the synthetic power-of-two state
     of tools/synthetic_ptq.py (the reference cannot CALIBRATE max-pool cfgs, SURVEY 8c, but its eval branch
     quantized_ptq_cos.py:288-296,717 runs with any scale buffers).  Stored: row subset + whole-tensor checksums."""
@@ -80,17 +82,20 @@ def eval_fixture(ref, name, rel, size, batch, row_stride):
     torch.manual_seed(0)
     fm = ref.models.Darknet(cfg, (size, size))
     state = synth.randomize_bn_(fm.state_dict(), seed=1)
-    synth.trained_like_heads_(state, fm.module_defs)
+    fm.load_state_dict(state)
+    x = synth.image_batch(batch, size, seed=0)
+    if conditioning == 'equalized':
+        synth.equalize_bn_gain_(fm.eval(), x)
+    state = synth.trained_like_heads_(fm.state_dict(), fm.module_defs)
     fm.load_state_dict(state)
     torch.manual_seed(0)
     qm = ref.models.Darknet(cfg, (size, size), quantized=3, a_bit=8, w_bit=8, shortcut_way=1)
-    x = synth.image_batch(batch, size, seed=0)
     fill_synthetic_state(fm, qm, ranges=measure_ranges(fm, x))
     with torch.no_grad():
         inf, raws, _ = qm(x)
         inf_float = fm.eval()(x)[0]
-    out = dict(cfg=rel, size=size, batch=batch, row_stride=row_stride, inf_rows=inf[:, ::row_stride].numpy().astype(np.float32),
-               inf_checks=checks(inf), inf_shape=np.array(inf.shape))
+    out = dict(cfg=rel, size=size, batch=batch, row_stride=row_stride, conditioning=conditioning,
+               inf_rows=inf[:, ::row_stride].numpy().astype(np.float32), inf_checks=checks(inf), inf_shape=np.array(inf.shape))
     for i, r in enumerate(raws):
         out['raw%d_checks' % i] = checks(r)
         out['raw%d_rows' % i] = r.reshape(-1)[::997].numpy().astype(np.float32)

@@ -27,7 +27,7 @@ import synth
 GOLD = os.path.join(conftest.REPO, 'tests', 'golden')
 
 
-def build_pair(rel, size, batch):
+def build_pair(rel, size, batch, conditioning='plain'):
     """This package's float + quantized=3 graphs of cfg `rel` in the state the golden generator gave the reference's."""
     import models
     from tools.synthetic_ptq import fill_synthetic_state, measure_ranges
@@ -35,11 +35,14 @@ def build_pair(rel, size, batch):
     torch.manual_seed(0)
     fm = models.Darknet(cfg, (size, size))
     state = synth.randomize_bn_(fm.state_dict(), seed=1)
-    synth.trained_like_heads_(state, fm.module_defs)
+    fm.load_state_dict(state)
+    x = synth.image_batch(batch, size, seed=0)
+    if conditioning == 'equalized':      # the state the golden generator gave the reference's model (make_golden_ptq.py)
+        synth.equalize_bn_gain_(fm.eval(), x)
+    state = synth.trained_like_heads_(fm.state_dict(), fm.module_defs)
     fm.load_state_dict(state)
     torch.manual_seed(0)
     qm = models.Darknet(cfg, (size, size), quantized=3, a_bit=8, w_bit=8, shortcut_way=1)
-    x = synth.image_batch(batch, size, seed=0)
     fill_synthetic_state(fm, qm, ranges=measure_ranges(fm, x))
     return fm, qm, x
 
@@ -68,7 +71,7 @@ def head_steps(qm):
 def test_eager_eval_of_this_package_equals_reference_eval(name):
     """The package's own COS-PTQ modules in eval mode reproduce the reference's outputs on the full graphs bit for bit."""
     fx = np.load(os.path.join(GOLD, 'ptq_eval_%s.npz' % name))
-    fm, qm, x = build_pair(str(fx['cfg']), int(fx['size']), int(fx['batch']))
+    fm, qm, x = build_pair(str(fx['cfg']), int(fx['size']), int(fx['batch']), str(fx['conditioning']))
     torch.set_num_threads(min(8, os.cpu_count() or 1))
     with torch.no_grad():
         inf, raws, _ = qm(x)
@@ -84,7 +87,7 @@ def test_int8_lowering_of_baseline_graphs_on_the_emulated_engine(name):
     through the host emulation of the C ABI against the reference's eval outputs.  Measured: identical on the stored rows."""
     from engine.plan import DarknetEngine
     fx = np.load(os.path.join(GOLD, 'ptq_eval_%s.npz' % name))
-    fm, qm, x = build_pair(str(fx['cfg']), int(fx['size']), int(fx['batch']))
+    fm, qm, x = build_pair(str(fx['cfg']), int(fx['size']), int(fx['batch']), str(fx['conditioning']))
     eng = DarknetEngine(qm, precision='int8', lib=fakelib.FakeLib())
     io, raws, _ = eng(x)
     compare(io, fx, box_px=0.05, conf_abs=2e-3, frac_allowed=0.0)
@@ -98,7 +101,7 @@ def test_hip_int8_engine_matches_reference_eval_on_baseline_graphs(name):
     from map_protocol import map50
     from utils.utils import non_max_suppression
     fx = np.load(os.path.join(GOLD, 'ptq_eval_%s.npz' % name))
-    fm, qm, x = build_pair(str(fx['cfg']), int(fx['size']), int(fx['batch']))
+    fm, qm, x = build_pair(str(fx['cfg']), int(fx['size']), int(fx['batch']), str(fx['conditioning']))
     with torch.no_grad():
         ref_full = qm(x)[0]            # eager eval of this package == the reference's (test above): every row, not a subset
     qm.cuda()

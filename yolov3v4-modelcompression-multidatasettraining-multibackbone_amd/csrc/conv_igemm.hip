@@ -934,9 +934,20 @@ static int pick_pp_tile(const yh_conv_desc* d) {
     return c66 <= c64 ? 66 : 64;
 }
 
+// The 3x3 halo kernel (activations fetched once per 32-channel chunk instead of once per tap) against the ring / ping-pong kernels
+// after the epilogue fix (profiles/r02_conv_tile_ab.txt): ahead only on the 76 x 76 layers with 128- or 256-row weight tiles -
+// data gradient 256 -> 128: 936 vs 809 TFLOP/s, forward 128 -> 256: 894 vs 850 - behind on the 152, 38 and 19 grids.  It has no
+// statistics epilogue, so the training forward never takes it.
+static bool pick_halo_tile(const yh_conv_desc* d) {
+    if (d->dtype != YH_F16 || d->kh != 3 || d->kw != 3 || d->stride != 1 || d->pad != 1 || d->stats_ws || d->ups > 2) return false;
+    if (d->cout != 128 && d->cout != 256) return false;
+    return d->cin >= 128 && d->cin % 32 == 0 && d->w_in >= 48 && d->w_in <= 96 && (long)d->n * d->h * d->w_in >= 131072;
+}
+
 extern "C" int yh_conv2d_tile(const yh_conv_desc* d) {
     if (!d) return YH_EINVAL;
     if (d->tile != 0) return d->tile;
+    if (pick_halo_tile(d)) return 41;
     if (const int pp = pick_pp_tile(d)) return pp;
     const int t = yh::pick_tile(d->cout, (long)d->n * d->ho * d->wo, d->cin_k, d->dtype == YH_F16 ? 8 : 4, d->kh * d->kw);
     return (d->dtype == YH_I8 && t == 3) ? 24 : t;
@@ -960,7 +971,11 @@ static bool tile_geometry(int tile, int* bn, int* wn) {
 extern "C" int64_t yh_conv2d_stats_rows(const yh_conv_desc* d) {
     if (!d || d->n <= 0 || d->ho <= 0 || d->wo <= 0 || d->dtype == YH_I8) return 0;
     int bn, wn;
-    if (!tile_geometry(yh_conv2d_tile(d), &bn, &wn)) return 0;
+    // the geometry of the launch that WILL carry the statistics: the workspace is attached after this query, and kernels without
+    // a statistics epilogue (halo) must not be chosen on its account
+    yh_conv_desc q = *d;
+    if (!q.stats_ws) q.stats_ws = reinterpret_cast<float*>(sizeof(float));
+    if (!tile_geometry(yh_conv2d_tile(&q), &bn, &wn)) return 0;
     const long P = (long)d->n * d->ho * d->wo;
     return (int64_t)((P + bn - 1) / bn) * wn;
 }

@@ -15,8 +15,10 @@ What is new: for a CUDA input in eval mode ``forward`` hands the whole graph to 
 (``engine/plan.py`` -> ``libyolo_hip.so``).  The engine keeps a packed NHWC/MFMA-tiled copy of the
 weights keyed on every source tensor's ``_version`` so in-place edits by the prune/PTQ scripts are
 picked up.  There is no silent fallback on that path: if the library cannot be loaded, or the graph
-holds a block the engine cannot lower, it raises.  CPU tensors (and train mode, until the training
-kernels land) run the eager module-by-module semantics below.
+holds a block the engine cannot lower, it raises.  A CUDA input in train mode runs the HIP training plans
+(``engine/train.py``; widths that are not multiples of 8 through the channel-padded twin of ``engine/padded.py``) behind
+one autograd node per backward range - again without an eager fallback.  CPU tensors run the eager module-by-module
+semantics below (bit-equal to the reference; what the host-side scripts and the CPU test tier use).
 """
 import copy
 import math
