@@ -804,6 +804,11 @@ static bool wgrad_xcd_mapping() {
     return !e || atoi(e) != 0;
 }
 
+static bool wgrad_big_default(const yh_wgrad_desc* d, int ncols) {
+    (void)d; (void)ncols;
+    return false;   // see the measurement above
+}
+
 static void wgrad_geometry(const yh_wgrad_desc* d, WgradArgs* pa, int* psplits) {
     WgradArgs& a = *pa;
     const int bk = d->dtype == YH_F16 ? 32 : 16;
@@ -826,6 +831,15 @@ static void wgrad_geometry(const yh_wgrad_desc* d, WgradArgs* pa, int* psplits) 
         const int splits256 = tiles256 >= 512 ? 1 : 512 / tiles256;
         if (force == 256 || (force != 128 && d->kh * d->kw > 1 && ksteps / splits256 >= 64)) bm = 256;
     }
+    // 256 x 256 tiles on 8 waves (128 x 64 per wave, 96 KB of LDS, one workgroup per CU): 32 KB per K step for 256 MFMAs instead
+    // of 2 x 24 KB - the bytes-per-FLOP argument of the forward ping-pong kernel.  Measured (profiles/r02_wgrad_tile_ab.txt):
+    // not faster - 76x76 128 -> 256: 678 vs 752 TFLOP/s, 38x38 / 19x19: equal within noise; one workgroup per CU loses the overlap
+    // of two.  Kept behind YH_WGRAD_BIG=1 as the A/B baseline; never chosen automatically.
+    if (a.dma && bm == 256 && a.bn == 128) {
+        const char* e = getenv("YH_WGRAD_BIG");
+        const int big = e ? atoi(e) : -1;
+        if (big == 1 || (big == -1 && wgrad_big_default(d, a.ncols))) a.bn = 256;
+    }
     a.bm = bm;
     a.tiles_m = (d->cout + bm - 1) / bm;
     a.tiles_n = (a.ncols + a.bn - 1) / a.bn;
@@ -839,7 +853,7 @@ static void wgrad_geometry(const yh_wgrad_desc* d, WgradArgs* pa, int* psplits) 
         // one resident wave of workgroups (3 per CU at 48 KB of LDS, 4 for the 64-row tiles; 256 CUs), rounded DOWN: a
         // partly filled second wave costs 10-20 % (measured: 1024 -> 768 workgroups, 76x76 128 -> 256: 0.324 -> 0.287 ms),
         // and every extra split costs a partial tile of traffic
-        int target = bm == 64 ? -1024 : (bm == 256 ? -512 : -768);
+        int target = bm == 64 ? -1024 : (bm == 256 ? (a.bn == 256 ? -256 : -512) : -768);
         { const char* e = getenv("YH_WGRAD_TARGET"); if (e) target = atoi(e); }
         splits = target > 0 ? (target + tiles - 1) / tiles : (-target) / tiles;   // negative: round down (one wave of workgroups)
         if (splits < 1) splits = 1;
@@ -899,6 +913,7 @@ extern "C" int yh_conv2d_wgrad(const yh_wgrad_desc* d, void* stream) {
     }
     if (a.dma) {
         if (narrow) hipLaunchKernelGGL((conv_wgrad_dma_kernel<2, 2>), grid, dim3(256), 0, st, a);
+        else if (a.bm == 256 && a.bn == 256) hipLaunchKernelGGL((conv_wgrad_dma_kernel<8, 4>), grid, dim3(512), 0, st, a);
         else if (a.bm == 256) hipLaunchKernelGGL((conv_wgrad_dma_kernel<8, 2>), grid, dim3(256), 0, st, a);
         else if (a.bn == 256) hipLaunchKernelGGL((conv_wgrad_dma_kernel<4, 4>), grid, dim3(512), 0, st, a);
         else hipLaunchKernelGGL((conv_wgrad_dma_kernel<4, 2>), grid, dim3(256), 0, st, a);
@@ -915,6 +930,7 @@ extern "C" int yh_conv2d_wgrad(const yh_wgrad_desc* d, void* stream) {
         const int per_group = (splits + groups - 1) / groups;
         groups = (splits + per_group - 1) / per_group;
         if (narrow) hipLaunchKernelGGL((wgrad_reduce_kernel<2, 2>), dim3(tiles * 8, groups), dim3(256), 0, st, a, splits, per_group);
+        else if (a.bm == 256 && a.bn == 256) hipLaunchKernelGGL((wgrad_reduce_kernel<8, 4>), dim3(tiles * 32, groups), dim3(512), 0, st, a, splits, per_group);
         else if (a.bm == 256) hipLaunchKernelGGL((wgrad_reduce_kernel<8, 2>), dim3(tiles * 32, groups), dim3(256), 0, st, a, splits, per_group);
         else if (a.bn == 256) hipLaunchKernelGGL((wgrad_reduce_kernel<4, 4>), dim3(tiles * 16, groups), dim3(512), 0, st, a, splits, per_group);
         else hipLaunchKernelGGL((wgrad_reduce_kernel<4, 2>), dim3(tiles * 16, groups), dim3(256), 0, st, a, splits, per_group);
