@@ -69,6 +69,10 @@ EVAL_CASES = [   # name, cfg, size, batch, row stride: the BASELINE graphs the i
     # plain seeded BN statistics collapse YOLOv4's 110 convs (every cell of an anchor within 1e-4 of the same objectness): the layer
     # gains are equalised first (synth.equalize_bn_gain_), as in the fp16 mAP protocol
     ('yolov4_640', 'yolov4/yolov4.cfg', 640, 1, 64, 'equalized'),
+    # the same two graphs on DYADIC frames (k / 256, synth.dyadic_frames): the stem conv - the only fp32 convolution of the path - is
+    # then exact in any summation order, and the int8 engine must reproduce the reference BIT FOR BIT (whole-tensor digests stored)
+    ('yolov3_608_dyadic', 'yolov3/yolov3.cfg', 608, 1, 64, 'plain'),
+    ('yolov4_640_dyadic', 'yolov4/yolov4.cfg', 640, 1, 64, 'equalized'),
 ]
 
 
@@ -84,6 +88,9 @@ def eval_fixture(ref, name, rel, size, batch, row_stride, conditioning):
     state = synth.randomize_bn_(fm.state_dict(), seed=1)
     fm.load_state_dict(state)
     x = synth.image_batch(batch, size, seed=0)
+    frames = 'dyadic' if name.endswith('_dyadic') else 'float'
+    if frames == 'dyadic':
+        x = synth.dyadic_frames(x)
     if conditioning == 'equalized':
         synth.equalize_bn_gain_(fm.eval(), x)
     state = synth.trained_like_heads_(fm.state_dict(), fm.module_defs)
@@ -94,11 +101,12 @@ def eval_fixture(ref, name, rel, size, batch, row_stride, conditioning):
     with torch.no_grad():
         inf, raws, _ = qm(x)
         inf_float = fm.eval()(x)[0]
-    out = dict(cfg=rel, size=size, batch=batch, row_stride=row_stride, conditioning=conditioning,
+    out = dict(cfg=rel, size=size, batch=batch, row_stride=row_stride, conditioning=conditioning, frames=frames,
                inf_rows=inf[:, ::row_stride].numpy().astype(np.float32), inf_checks=checks(inf), inf_shape=np.array(inf.shape))
     for i, r in enumerate(raws):
         out['raw%d_checks' % i] = checks(r)
         out['raw%d_rows' % i] = r.reshape(-1)[::997].numpy().astype(np.float32)
+        out['raw%d_sha256' % i] = synth.tensor_digest(r)
     np.savez_compressed(os.path.join(HERE, 'ptq_eval_%s.npz' % name), **out)
     print('eval fixture', name, tuple(inf.shape), 'obj range %.3g..%.3g; int8-vs-float: box %.3g px, obj %.3g' % (
         inf[..., 4].min().item(), inf[..., 4].max().item(), (inf[..., :4] - inf_float[..., :4]).abs().max().item(),

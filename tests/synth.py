@@ -50,12 +50,14 @@ def equalize_bn_gain_(model, x):
     on the batch ``x`` (single forward pass, in place).  Deep random-weight nets with arbitrary eval statistics lose the signal
     layer by layer (YOLOv4's 110 convs end with every cell of an anchor within 1e-4 of the same objectness, so any rounding
     reorders the whole score ranking); with the layer gains equalised the activations stay O(1) and the outputs vary over the
-    image like a trained detector's, while the per-channel statistics keep the well-conditioned ranges of ``randomize_bn_``."""
+    image like a trained detector's, while the per-channel statistics keep the well-conditioned ranges of ``randomize_bn_``.
+    The factor is rounded to a power of two: the rescaled parameters are then the same bits on every host (the measured standard
+    deviation differs in the last bits between CPUs, and goldens built from this state must be reproducible on the GPU box)."""
     import torch.nn as nn
     hooks = []
 
     def hook(mod, inp, out):
-        s = out.std().clamp(min=1e-6)
+        s = 2.0 ** torch.log2(out.double().std().clamp(min=1e-6)).round().item()
         mod.weight.data.div_(s)
         mod.bias.data.div_(s)
         return out / s
@@ -89,6 +91,19 @@ def spread_objectness_(state, module_defs, gain=40.0):
 def image_batch(n, size, seed=0, channels=3):
     g = torch.Generator().manual_seed(seed)
     return torch.rand(n, channels, size, size, generator=g)
+
+
+def dyadic_frames(x, bits=8):
+    """Frames on the grid k / 2**bits (what an 8-bit image scaled by 1/256 is).  With the PTQ weight / bias grids (powers of two)
+    every product and partial sum of the stem's fp32 convolution is then exactly representable, so ANY summation order gives the
+    same bits: the one fp32 conv of the int8 path stops being implementation-defined and the whole path can be compared bit for bit."""
+    return (x * 2 ** bits).round() / 2 ** bits
+
+
+def tensor_digest(t):
+    """sha256 of a tensor's fp32 bytes (+0.0 first: -0.0 and 0.0 are the same value)."""
+    import hashlib
+    return hashlib.sha256((t.detach().float().cpu() + 0.0).contiguous().numpy().tobytes()).hexdigest()
 
 
 def nms_candidates(n_img, rows, nc, seed, n_clusters=12, img=608, hot=0.35):

@@ -7,12 +7,19 @@ Goldens come from the REFERENCE's own modules (tests/golden/make_golden_ptq.py):
 * ptq_mini_max.npz — the mini net calibrated BY the reference with shortcut_way=2 (COSPTQuantizedShortcut_max,
   quantized_ptq_cos.py:1058-1340); ptq_mini.npz is the shortcut_way=1 twin used by tests/test_ptq.py.
 
-Tolerance: the int8 engine accumulates exactly (int32) where the reference's fake-quant conv accumulates in fp32 (sums of up to
-9216 products of magnitude <= 127^2 are not exact in fp32), so values that sit on a rounding tie may land one grid step apart, and
-through 75-110 layers a flipped step can move a few later values.  The raw head tensors are therefore compared in units of the
-head conv's activation grid (at most one step, a few percent of the values), decoded boxes with the matching relative bound
-(one step of the log-size logit scales w / h by exp(step)), and detections through the synthetic mAP protocol.  The host
-emulation of the same plan, which accumulates in fp32 like the reference, matches the stored rows exactly (CPU tier).
+Parity bar (measured per block on the MI355X, profiles/r02_int8_layer_parity.txt):
+* The int8 path is integer work after the first layer, and it is BIT-EXACT: on dyadic frames (`*_dyadic` goldens, frames on the
+  k / 256 grid, synth.dyadic_frames) every block of YOLOv3-608 and YOLOv4-640 - int8 MFMA convs, fused Mish / leaky epilogues,
+  fused and stand-alone quantised shortcuts, routes, SPP pools, upsamples, heads - equals the reference's eval output bit for bit
+  (whole-tensor sha256 of the raw heads, generated from the reference's own modules).
+* The first layer consumes float frames and is an fp32 convolution in the reference (float x, de-quantised weights,
+  quantized_ptq_cos.py:288-296): its result depends on the summation order of the implementation (oneDNN on the host, FMA chain
+  in the stem kernel), a few ulp apart, and 3e-6 of its outputs land on the other side of a rounding tie.  A quantised network
+  amplifies such a flip (one step in one input moves ~5 % of the outputs that see it): by the heads 1 % (YOLOv3, 75 convs) to
+  45 % (YOLOv4, 110 convs, equalised gains) of the values sit one grid step apart.  On arbitrary float frames the comparison is
+  therefore statistical - grid steps on the raw heads, decoded boxes with the matching relative bound, detections through the
+  synthetic mAP protocol - while the dyadic frames carry the bit-exact claim.
+The host emulation of the same plan matches the reference exactly on both kinds of frames (CPU tier).
 """
 import os
 
@@ -27,7 +34,7 @@ import synth
 GOLD = os.path.join(conftest.REPO, 'tests', 'golden')
 
 
-def build_pair(rel, size, batch, conditioning='plain'):
+def build_pair(rel, size, batch, conditioning='plain', frames='float'):
     """This package's float + quantized=3 graphs of cfg `rel` in the state the golden generator gave the reference's."""
     import models
     from tools.synthetic_ptq import fill_synthetic_state, measure_ranges
@@ -37,6 +44,8 @@ def build_pair(rel, size, batch, conditioning='plain'):
     state = synth.randomize_bn_(fm.state_dict(), seed=1)
     fm.load_state_dict(state)
     x = synth.image_batch(batch, size, seed=0)
+    if frames == 'dyadic':
+        x = synth.dyadic_frames(x)
     if conditioning == 'equalized':      # the state the golden generator gave the reference's model (make_golden_ptq.py)
         synth.equalize_bn_gain_(fm.eval(), x)
     state = synth.trained_like_heads_(fm.state_dict(), fm.module_defs)
@@ -67,43 +76,99 @@ def head_steps(qm):
     return [float(qm.module_list[i - 1][0].activation_quantizer.scale) for i in qm.yolo_layers]
 
 
-@pytest.mark.parametrize('name', ['yolov3_608', 'yolov4_640'])
+ALL_CASES = ['yolov3_608', 'yolov4_640', 'yolov3_608_dyadic', 'yolov4_640_dyadic']
+
+
+def load_case(name):
+    fx = np.load(os.path.join(GOLD, 'ptq_eval_%s.npz' % name))
+    fm, qm, x = build_pair(str(fx['cfg']), int(fx['size']), int(fx['batch']), str(fx['conditioning']), str(fx['frames']))
+    return fx, fm, qm, x
+
+
+def assert_raws_bit_exact(raws, fx):
+    """Whole raw head tensors against the reference's: sha256 of the fp32 bytes, plus the sampled values for a readable failure."""
+    for i, r in enumerate(raws):
+        r = r.detach().float().cpu()
+        ref_rows = torch.from_numpy(fx['raw%d_rows' % i])
+        got_rows = r.reshape(-1)[::997]
+        assert torch.equal(got_rows, ref_rows), 'head %d: %d of %d sampled values differ' % (
+            i, (got_rows != ref_rows).sum().item(), ref_rows.numel())
+        assert synth.tensor_digest(r) == str(fx['raw%d_sha256' % i]), 'head %d: sampled values equal but the whole tensor differs' % i
+
+
+@pytest.mark.parametrize('name', ALL_CASES)
 def test_eager_eval_of_this_package_equals_reference_eval(name):
     """The package's own COS-PTQ modules in eval mode reproduce the reference's outputs on the full graphs bit for bit."""
-    fx = np.load(os.path.join(GOLD, 'ptq_eval_%s.npz' % name))
-    fm, qm, x = build_pair(str(fx['cfg']), int(fx['size']), int(fx['batch']), str(fx['conditioning']))
+    fx, fm, qm, x = load_case(name)
     torch.set_num_threads(min(8, os.cpu_count() or 1))
     with torch.no_grad():
         inf, raws, _ = qm(x)
     rs = int(fx['row_stride'])
     assert torch.equal(inf[:, ::rs], torch.from_numpy(fx['inf_rows']))
-    for i, r in enumerate(raws):
-        assert torch.equal(r.reshape(-1)[::997], torch.from_numpy(fx['raw%d_rows' % i]))
+    assert_raws_bit_exact(raws, fx)
 
 
-@pytest.mark.parametrize('name', ['yolov3_608', 'yolov4_640'])
+@pytest.mark.parametrize('name', ALL_CASES)
 def test_int8_lowering_of_baseline_graphs_on_the_emulated_engine(name):
     """The int8 plan (fused epilogues, concat placement, qadd / qcopy / qpool re-scaling, SPP pools, CSP group routes, Mish) replayed
-    through the host emulation of the C ABI against the reference's eval outputs.  Measured: identical on the stored rows."""
+    through the host emulation of the C ABI against the reference's eval outputs: the raw heads are identical (whole tensors)."""
     from engine.plan import DarknetEngine
-    fx = np.load(os.path.join(GOLD, 'ptq_eval_%s.npz' % name))
-    fm, qm, x = build_pair(str(fx['cfg']), int(fx['size']), int(fx['batch']), str(fx['conditioning']))
+    fx, fm, qm, x = load_case(name)
     eng = DarknetEngine(qm, precision='int8', lib=fakelib.FakeLib())
     io, raws, _ = eng(x)
+    assert_raws_bit_exact(raws, fx)
     compare(io, fx, box_px=0.05, conf_abs=2e-3, frac_allowed=0.0)
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('name', ['yolov3_608_dyadic', 'yolov4_640_dyadic'])
+def test_hip_int8_engine_is_bit_exact_against_the_reference(name):
+    """The parity claim of the int8 path: on frames whose stem convolution is exact in any order, the HIP engine's raw heads equal
+    the REFERENCE's (golden digests from the reference's modules) bit for bit; the decoded rows differ only by the fp32 exp /
+    sigmoid of the decode (compared against the stored reference rows at 1e-5 relative)."""
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU')
+    fx, fm, qm, x = load_case(name)
+    qm.cuda()
+    with torch.no_grad():
+        io, raws, _ = qm(x.cuda())
+    torch.cuda.synchronize()
+    eng = qm.__dict__['_hip_engine']
+    assert eng is not None and eng.precision == 'int8'
+    assert_raws_bit_exact(raws, fx)
+    rs = int(fx['row_stride'])
+    got, ref = io.cpu()[:, ::rs], torch.from_numpy(fx['inf_rows'])
+    assert torch.allclose(got, ref, rtol=1e-5, atol=1e-6), (got - ref).abs().max().item()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('name', ['yolov3_608', 'yolov4_640'])
-def test_hip_int8_engine_matches_reference_eval_on_baseline_graphs(name):
+def test_hip_int8_engine_matches_reference_eval_on_float_frames(name):
+    """Arbitrary float frames: the stem's fp32 conv is summation-order dependent (module docstring), so the comparison is
+    statistical, against a yardstick measured in the test: the REFERENCE arithmetic (this package's eager modules, equal to the
+    reference's on the goldens) on the same frames moved by one fp32 ulp (torch.nextafter).  That changes the stem sums by about
+    as much as a different summation order does.  Measured: YOLOv3-608 1-2 % of the head values one step apart, mAP protocol
+    0.995 / 0.995; YOLOv4-640 (110 convs, equalised gains) 23-35 % up to two steps apart, mAP 0.84 / 0.995 - the engine lands in
+    the same place (1-2 %, 0.995; 38 %, 0.83).  Asserted: the engine is no further from the reference than twice that yardstick,
+    and on YOLOv3 additionally the absolute bounds (one step, 5 %, decoded rows)."""
     if not torch.cuda.is_available():
         pytest.skip('no GPU')
     from map_protocol import map50
     from utils.utils import non_max_suppression
-    fx = np.load(os.path.join(GOLD, 'ptq_eval_%s.npz' % name))
-    fm, qm, x = build_pair(str(fx['cfg']), int(fx['size']), int(fx['batch']), str(fx['conditioning']))
+    fx, fm, qm, x = load_case(name)
+    steps = head_steps(qm)
+
+    def step_stats(raws_a, raws_b):
+        worst, frac = 0.0, 0.0
+        for ra, rb, step in zip(raws_a, raws_b, steps):
+            d = (ra.float().cpu().reshape(-1) - rb.float().cpu().reshape(-1)).abs() / step
+            worst, frac = max(worst, d.max().item()), max(frac, (d > 0.5).float().mean().item())
+        return worst, frac
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
     with torch.no_grad():
-        ref_full = qm(x)[0]            # eager eval of this package == the reference's (test above): every row, not a subset
+        ref_full, ref_raws, _ = qm(x)            # eager eval of this package == the reference's (tests above)
+        alt_full, alt_raws, _ = qm(torch.nextafter(x, torch.full_like(x, 2.0)))
+    floor_worst, floor_frac = step_stats(ref_raws, alt_raws)
     qm.cuda()
     with torch.no_grad():
         io, raws, _ = qm(x.cuda())
@@ -111,23 +176,24 @@ def test_hip_int8_engine_matches_reference_eval_on_baseline_graphs(name):
     eng = qm.__dict__['_hip_engine']
     assert eng is not None and eng.precision == 'int8'
     io = io.cpu()
-    steps = head_steps(qm)
-    # raw head logits in grid steps (the head conv's output is on its activation grid in both implementations)
-    worst, frac = 0.0, 0.0
-    for i, (r, step) in enumerate(zip(raws, steps)):
-        d = (r.cpu().reshape(-1)[::997] - torch.from_numpy(fx['raw%d_rows' % i])).abs() / step
-        worst, frac = max(worst, d.max().item()), max(frac, (d > 0.5).float().mean().item())
-    print('raw heads: worst %.3f grid steps, %.4f of the sampled values off by a step' % (worst, frac))
-    assert worst <= 1.001 and frac <= 0.05
-    # decoded rows: xy / small boxes within 1.5 px; w, h scale by exp(one step of the log-size logit)
-    compare(io, fx, box_px=1.5, conf_abs=0.05, frac_allowed=0.05, box_rel=float(np.expm1(max(steps))))
+    worst, frac = step_stats(ref_raws, raws)
+    print('raw heads %s: engine worst %.0f grid steps, %.4f of the values off by a step; reference on frames + 1 ulp: worst %.0f, %.4f'
+          % (name, worst, frac, floor_worst, floor_frac))
+    assert worst <= floor_worst + 1.001 and frac <= 2 * floor_frac + 0.01
+    if name == 'yolov3_608':
+        assert worst <= 1.001 and frac <= 0.05
+        # decoded rows: xy / small boxes within 1.5 px; w, h scale by exp(one step of the log-size logit)
+        compare(io, fx, box_px=1.5, conf_abs=0.05, frac_allowed=0.05, box_rel=float(np.expm1(max(steps))))
     conf = float(torch.quantile(ref_full[..., 4].flatten(), 0.985)) * 0.999
     gt = non_max_suppression(ref_full.clone(), conf, 0.6, multi_label=False)
     assert sum(0 if g is None else len(g) for g in gt) >= 10
     det = non_max_suppression(io.cuda(), conf * 0.9, 0.6, multi_label=False)
-    score, perfect = map50(gt, det), map50(gt, gt)
-    print('synthetic mAP@0.5 int8 %s: %.4f (reference vs itself %.4f)' % (name, score, perfect))
-    assert abs(score - perfect) <= 0.002
+    det_alt = non_max_suppression(alt_full.cuda(), conf * 0.9, 0.6, multi_label=False)
+    score, floor, perfect = map50(gt, det), map50(gt, det_alt), map50(gt, gt)
+    print('synthetic mAP@0.5 int8 %s: engine %.4f, reference on frames + 1 ulp %.4f, reference vs itself %.4f' % (name, score, floor, perfect))
+    assert score >= floor - max(0.02, 0.5 * (perfect - floor))   # another draw of the same noise, not a systematic loss
+    if name == 'yolov3_608':
+        assert abs(score - perfect) <= 0.002
 
 
 # ------------------------------------------------------------------------------- shortcut_way = 2 (COSPTQuantizedShortcut_max)

@@ -13,9 +13,20 @@ import torch
 
 
 def _fold(w, b, g, beta, mean, var, eps):
+    """BN folded into the conv, in float64: the grid decisions below (floor(|w| / s + 0.5)) then do not depend on the last fp32
+    bit of the fold, which differs between hosts (measured: the fp32 fold gave different grid weights on an EPYC 9575F and on the
+    build container - same float state, same scales - and the goldens stopped being reproducible on the GPU box)."""
+    w, g, beta, mean, var = (t.detach().double() for t in (w, g, beta, mean, var))
     s = g / torch.sqrt(var + eps)
     shift = beta - mean * s
-    return w * s.view(-1, 1, 1, 1), (shift if b is None else shift + b * s)
+    return w * s.view(-1, 1, 1, 1), (shift if b is None else shift + b.detach().double() * s)
+
+
+def _to_grid(t, scale):
+    """Round-half-away onto the int8 grid of ``scale`` (reference quantized_ptq_cos.py:14-20), computed in float64, stored as fp32
+    (grid values k * 2^e with |k| <= 128 are exact in fp32)."""
+    t = t.detach().double()
+    return ((torch.sign(t) * torch.floor(t.abs() / scale + 0.5)).clamp(-128, 127) * scale).float()
 
 
 def pow2_scale(t, levels=127.0):
@@ -58,15 +69,15 @@ def fill_synthetic_state(float_model, q_model, act_scale=2.0 ** -4, sum_scale=2.
             if isinstance(f, torch.nn.Sequential) and len(f) and isinstance(f[0], torch.nn.Conv2d):
                 conv = f[0]
                 bn = f[1] if len(f) > 1 and isinstance(f[1], torch.nn.modules.batchnorm.BatchNorm2d) else None
-                w, b = (conv.weight, conv.bias) if bn is None else _fold(conv.weight, conv.bias, bn.weight, bn.bias,
+                w, b = (conv.weight.detach().double(), conv.bias.detach().double()) if bn is None else _fold(conv.weight, conv.bias, bn.weight, bn.bias,
                                                                          bn.running_mean, bn.running_var, bn.eps)
                 qc = q[0]
                 sw, sb = pow2_scale(w.abs().max()), pow2_scale(b.abs().max())
                 qc.weight_quantizer.scale.fill_(sw)
                 qc.bias_quantizer.scale.fill_(sb)
                 qc.activation_quantizer.scale.fill_(grid(i))
-                qc.q_weight.copy_((torch.sign(w) * torch.floor(w.abs() / sw + 0.5)).clamp(-128, 127) * sw)
-                qc.q_bias.copy_((torch.sign(b) * torch.floor(b.abs() / sb + 0.5)).clamp(-128, 127) * sb)
+                qc.q_weight.copy_(_to_grid(w, sw))
+                qc.q_bias.copy_(_to_grid(b, sb))
                 qc.quantized = True      # BN already folded, grids in place: eval uses q_weight / q_bias as they are
             elif name.startswith('COSPTQuantizedShortcut'):
                 if ranges is None:
