@@ -154,11 +154,21 @@ def hbm_traffic(kernel, batch):
         table = json.load(open(path))
     except Exception:
         return None
-    m = {'dma3_256x128': 'conv_igemm_glds<f16,f16,256x128,S3>', 'dma3_128x256': 'conv_igemm_glds<f16,f16,128x256,S3>',
-         'dma3_128x128': 'conv_igemm_glds<f16,f16,128x128,S3>'}
-    key = m.get(kernel.replace('conv_igemm_fp16_', ''))
-    ent = table.get('batch%d' % batch, {}).get(key) if key else None
-    return None if ent is None else {'hbm_bytes_per_launch': ent['hbm_bytes_per_dispatch'], 'source': 'profiles/hbm_traffic.json'}
+    key = rocprof_kernel_name(kernel)
+    section = 'batch%d%s' % (batch, '_int8' if '_int8_' in kernel else '')
+    ent = table.get(section, {}).get(key) if key else None
+    return None if ent is None else {'hbm_bytes_per_launch': ent['hbm_bytes_per_dispatch'], 'kernel': key,
+                                     'source': 'profiles/hbm_traffic.json[%s]' % section}
+
+
+def rocprof_kernel_name(kernel):
+    """bench.py's kernel label (conv_igemm_<precision>_<tile name>) -> the name tools/rocprof_summary.py prints for that instantiation."""
+    import re
+    m = re.match(r'conv_igemm_(fp16|int8|fp32)_(dma3|halo|pp)_(\d+x\d+)$', kernel)
+    if not m:
+        return None
+    t = {'fp16': 'f16', 'int8': 'i8', 'fp32': 'f32'}[m.group(1)]
+    return {'dma3': 'conv_igemm_glds<%s,%s,%s,S3>', 'halo': 'conv3x3_halo<%s,%s,%s>', 'pp': 'conv_igemm_pp<%s,%s,%s>'}[m.group(2)] % (t, t, m.group(3))
 
 
 def cpu_baseline(cfg, size, budget_s):
@@ -339,9 +349,8 @@ def train_roofline(eng, x, precision):
     traffic = None
     try:   # HBM bytes per launch from the committed rocprofv3 FETCH_SIZE / WRITE_SIZE passes of this command
         hbm = json.load(open(os.path.join(REPO, 'profiles', 'hbm_traffic.json'))).get('train_batch%d' % x.shape[0], {})
-        keys = {'conv_wgrad_dma': ['void yh::conv_wgrad_dma_kernel<8, 2>', 'void yh::conv_wgrad_dma_kernel<4, 2>'],
-                'conv_igemm_fp16_dma3_256x128': ['conv_igemm_glds<f16,f16,256x128,S3>'],
-                'conv_igemm_fp16_dma3_128x256': ['conv_igemm_glds<f16,f16,128x256,S3>']}.get(top, [])
+        keys = ['void yh::conv_wgrad_dma_kernel<8, 2>', 'void yh::conv_wgrad_dma_kernel<4, 2>'] if top == 'conv_wgrad_dma' \
+            else [rocprof_kernel_name(top)]
         key = next((k for k in keys if k in hbm), None)
         if key is not None and precision == 'fp16':
             traffic = {'hbm_bytes_per_launch': hbm[key]['hbm_bytes_per_dispatch'], 'kernel': key, 'source': 'profiles/hbm_traffic.json'}

@@ -868,7 +868,7 @@ def test_device_target_assignment_matches_build_targets_on_edge_cases(libs):
 
 
 # ------------------------------------------------------------------------------------------- widths that are not multiples of 8
-@pytest.mark.parametrize('which', ['pruned_mini', 'odd', 'odd_mobile'])
+@pytest.mark.parametrize('which', ['pruned_mini', 'odd', 'odd_mobile', 'ghost_like'])
 @pytest.mark.parametrize('precision', ['fp32', 'fp16'])
 def test_odd_width_graphs_train_on_the_hip_path(libs, which, precision):
     """slim_prune-style graphs (arbitrary channel counts, incl. depthwise + squeeze-excite) train on the HIP kernels through the
@@ -877,8 +877,8 @@ def test_odd_width_graphs_train_on_the_hip_path(libs, which, precision):
     import test_plan_emulated as tpe
     import test_train_emulated as tte
     from engine.padded import PaddedTrainEngine
-    if which == 'pruned_mini':
-        path = th.write_cfg(tte._pruned_like_cfg_text())
+    if which in ('pruned_mini', 'ghost_like'):   # ghost_like: a 24-channel conv added to a 12 + 12 concat (GhostNet's join)
+        path = th.write_cfg(tte._pruned_like_cfg_text() if which == 'pruned_mini' else tte._ghost_like_text())
         model = th.build(path, 64)
         os.unlink(path)
     else:
@@ -909,3 +909,20 @@ def test_odd_width_graphs_train_on_the_hip_path(libs, which, precision):
         mine = sum(g.double().norm().item() ** 2 for g in grads.values()) ** 0.5
         # fp16 storage of every activation / gradient on a tiny 13 - 30 channel net: direction and size of the whole gradient
         assert dot / (mine * total) >= 0.99 and num <= 0.15 * total, (num, total, dot / (mine * total))
+
+
+def test_training_forward_has_no_eager_fallback(libs):
+    """A GPU training forward either runs on the HIP step or raises: feature_out (the feature-distillation losses, out of
+    scope) is refused instead of switching to the eager modules; a cfg the step cannot lower raises too (GhostNet-style gathered
+    shortcuts between differently padded tensors)."""
+    if DRY:
+        pytest.skip('needs a GPU')
+    import models
+    model = models.Darknet(os.path.join(conftest.PKG, 'cfg', 'yolov3tiny', 'yolov3-tiny-hand.cfg'), (64, 64)).cuda().train()
+    x = synth.image_batch(2, 64, seed=1).cuda()
+    model.hip_return_features = True
+    with pytest.raises(NotImplementedError, match='feature_out'):
+        model(x)
+    model.hip_return_features = False
+    out, feats = model(x)
+    assert feats == [] and model.__dict__['_hip_train_engine'] is not None

@@ -365,18 +365,73 @@ def test_two_sgd_steps_on_an_odd_width_graph_track_eager():
         os.unlink(path)
 
 
-def test_shortcut_between_different_padded_layouts_raises():
-    """GhostNet-style: a 12 + 12 channel concat added to a 24-channel conv - no twin layout exists and there is no eager fallback."""
-    import models
-    from engine.padded import make_train_engine
+def _ghost_like_text(second_join=False):
     c = lambda f, k, s: th._CONV % (f, k, s, 'leaky')
     text = ('[net]\nbatch=1\nwidth=32\nheight=32\nchannels=3\n\n' + c(24, 3, 1) + c(12, 1, 1) + c(12, 3, 1) + '[route]\nlayers = -1, -2\n\n'
-            + '[shortcut]\nfrom=-4\nactivation=linear\n\n' + th._HEAD + th._YOLO % '0,1,2')
-    path = th.write_cfg(text)
+            + '[shortcut]\nfrom=-4\nactivation=linear\n\n')
+    if second_join:   # the same 24-channel conv (block 0) joined to an 8 + 16 concat as well: it cannot have both layouts
+        text += c(8, 1, 1) + c(16, 3, 1) + '[route]\nlayers = -1, -2\n\n' + '[shortcut]\nfrom=0\nactivation=linear\n\n'
+    return text + th._HEAD + th._YOLO % '0,1,2'
+
+
+def test_conv_adopts_the_layout_of_the_concat_it_is_added_to():
+    """GhostNet-style: a 12 + 12 channel concat (24 of 32 padded lanes) added to a 24-channel conv.  The conv's output layout is
+    free, so the twin gives it the concat's layout (engine/padded.py plan_layouts); gradients match eager autograd."""
+    import models
+    from engine.padded import PaddedTrainEngine
+    path = th.write_cfg(_ghost_like_text())
+    try:
+        torch.manual_seed(0)
+        model = models.Darknet(path, (32, 32))
+        model.load_state_dict(synth.randomize_bn_(model.state_dict(), seed=2))
+        model.train()
+        x = synth.image_batch(3, 32, seed=3)
+        raws_ref, grads_ref, m_ref, ws = th.eager_step(model, x)
+        raws, grads, m = th.engine_step(model, x, ws, 'fp32', lib=fakelib.FakeLib())
+        eng = m.__dict__['_hip_train_engine']
+        assert isinstance(eng, PaddedTrainEngine)
+        total = sum(g.norm().item() ** 2 for g in grads_ref.values()) ** 0.5
+        for a, b in zip(raws, raws_ref):
+            assert (a - b).abs().max().item() <= 5e-5 * b.abs().max().item()
+        for k in grads_ref:
+            assert (grads[k] - grads_ref[k]).norm().item() <= 1e-4 * grads_ref[k].norm().item() + 1e-6 * total, k
+    finally:
+        os.unlink(path)
+
+
+def test_shortcut_between_different_padded_layouts_raises():
+    """A conv that two shortcuts would need in two different padded layouts: no twin exists and there is no eager fallback."""
+    import models
+    from engine.padded import make_train_engine
+    path = th.write_cfg(_ghost_like_text(second_join=True))
     try:
         torch.manual_seed(0)
         model = models.Darknet(path, (32, 32)).train()
         with pytest.raises(NotImplementedError, match='layouts'):
             make_train_engine(model, 'fp32', synth.image_batch(2, 32), lib=fakelib.FakeLib())
+    finally:
+        os.unlink(path)
+
+
+def test_shortcut_whose_operand_is_a_concat_keeps_the_parts_gradients():
+    """conv added to a route of two convs (GhostNet's ghost-module join, here with aligned widths).  The step shares the residual's
+    gradient buffer with dy when it can; a concat's gradient buffer is also addressed by the parts produced into it and must not
+    be re-pointed (regression: the parts read a stale buffer and every upstream gradient was wrong by O(1))."""
+    import models
+    c = lambda f, k, s: th._CONV % (f, k, s, 'leaky')
+    text = ('[net]\nbatch=1\nwidth=32\nheight=32\nchannels=3\n\n' + c(16, 3, 1) + c(16, 1, 1) + c(16, 3, 1) + '[route]\nlayers = -1, -2\n\n'
+            + c(32, 3, 1) + '[shortcut]\nfrom=-2\nactivation=linear\n\n' + th._HEAD + th._YOLO % '0,1,2')
+    path = th.write_cfg(text)
+    try:
+        torch.manual_seed(0)
+        model = models.Darknet(path, (32, 32))
+        model.load_state_dict(synth.randomize_bn_(model.state_dict(), seed=2))
+        model.train()
+        x = synth.image_batch(3, 32, seed=3)
+        raws_ref, grads_ref, m_ref, ws = th.eager_step(model, x)
+        raws, grads, m = th.engine_step(model, x, ws, 'fp32', lib=fakelib.FakeLib())
+        total = sum(g.norm().item() ** 2 for g in grads_ref.values()) ** 0.5
+        for k in grads_ref:
+            assert (grads[k] - grads_ref[k]).norm().item() <= 1e-4 * grads_ref[k].norm().item() + 1e-6 * total, k
     finally:
         os.unlink(path)

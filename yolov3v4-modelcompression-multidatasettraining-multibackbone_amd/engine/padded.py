@@ -36,10 +36,11 @@ def _ru(n, a=ALIGN):
 
 
 class _Layout:
-    __slots__ = ('pos', 'phys')
+    __slots__ = ('pos', 'phys', 'origin')
 
-    def __init__(self, pos, phys):
+    def __init__(self, pos, phys, origin=None):
         self.pos, self.phys = pos, phys     # LongTensor [C_logical], int
+        self.origin = origin                # block index of the dense conv whose (free) output layout this still is, or None
 
     @property
     def logical(self):
@@ -52,8 +53,28 @@ class _Layout:
         return self.phys == other.phys and self.logical == other.logical and bool(torch.equal(self.pos, other.pos))
 
 
+class _Relayout(Exception):
+    def __init__(self, block, layout):
+        self.block, self.layout = block, layout
+
+
 def plan_layouts(module_defs, in_channels):
-    """(padded block dicts, per-layer layouts).  ``module_defs``: ``Darknet.module_defs`` (the blocks after ``[net]``)."""
+    """(padded block dicts, per-layer layouts).  ``module_defs``: ``Darknet.module_defs`` (the blocks after ``[net]``).
+
+    A dense conv is free to put its output channels anywhere in a padded tensor, a concat is not (its parts sit at 8-aligned
+    offsets).  When a shortcut joins the two (GhostNet: a 24-channel conv added to a 12 + 12 channel concat, 24 of 32 lanes), the
+    conv is re-planned with the concat's layout and the walk restarts; a conv asked for two different layouts raises."""
+    forced = {}
+    while True:
+        try:
+            return _plan_layouts(module_defs, in_channels, forced)
+        except _Relayout as r:
+            if r.block in forced:
+                raise NotImplementedError('HIP training path: conv block %d would need two different padded output layouts' % r.block)
+            forced[r.block] = r.layout
+
+
+def _plan_layouts(module_defs, in_channels, forced):
     defs = copy.deepcopy(list(module_defs))
     body = defs
     layouts = []
@@ -64,24 +85,33 @@ def plan_layouts(module_defs, in_channels):
         if t == 'convolutional':
             filters, groups = int(d['filters']), int(d.get('groups', 1))
             if groups == 1:
-                lay = _Layout(torch.arange(filters), _ru(filters))
+                lay = _Layout(torch.arange(filters), _ru(filters), origin=i)
+                if i in forced:
+                    assert forced[i].logical == filters
+                    lay = _Layout(forced[i].pos.clone(), forced[i].phys, origin=i)
                 d['filters'] = lay.phys
             elif groups == src.logical and filters == src.logical:       # depthwise spelled as a grouped conv (GhostNet cfgs)
-                lay = _Layout(src.pos.clone(), src.phys)
+                lay = _Layout(src.pos.clone(), src.phys, src.origin)
                 d['filters'], d['groups'] = src.phys, src.phys
             else:
                 raise NotImplementedError('HIP training path: grouped conv (groups=%d) in a padded graph, block %d' % (groups, i))
         elif t == 'depthwise':
-            lay = _Layout(src.pos.clone(), src.phys)
+            lay = _Layout(src.pos.clone(), src.phys, src.origin)
             d['filters'] = src.phys
         elif t == 'se':
-            lay = _Layout(src.pos.clone(), src.phys)
+            lay = _Layout(src.pos.clone(), src.phys, src.origin)
             if 'filters' in d:
                 d['filters'] = src.phys
         elif t == 'shortcut':
             lay = src
             for l in d['from']:
                 other = layouts[i + l if l < 0 else l]
+                if not other.same(src) and other.logical == src.logical:
+                    # one side still carries a dense conv's own (free) layout: give that conv the other side's layout
+                    if src.origin is not None and src.origin not in forced:
+                        raise _Relayout(src.origin, other)
+                    if other.origin is not None and other.origin not in forced:
+                        raise _Relayout(other.origin, src)
                 if not other.same(src):
                     raise NotImplementedError('HIP training path: shortcut (block %d) between tensors whose padded channel layouts '
                                               'differ (%d of %d vs %d of %d channels)' % (i, src.logical, src.phys, other.logical, other.phys))

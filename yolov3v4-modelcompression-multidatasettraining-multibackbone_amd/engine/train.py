@@ -458,6 +458,12 @@ class TrainEngine(DarknetEngine):
         # ---- pass 3: backward ops.  A gradient storage's first writer must cover it entirely; otherwise the
         # storage is zeroed before the backward plan runs and every contribution accumulates.
         initialised = set()
+        # gradient buffers addressed by more than one value (a concat and the parts produced into it, a tensor and its channel
+        # slices): the residual-gradient aliasing below re-points ONE value's buffer and must leave these alone
+        holders = {}
+        for u in values:
+            if getattr(u, 'gstorage', None) is not None:
+                holders[id(u.gstorage)] = holders.get(id(u.gstorage), 0) + 1
 
         def contribution_mode(t, full_width):
             key = id(t.gstorage)
@@ -590,7 +596,7 @@ class TrainEngine(DarknetEngine):
                     dyp, lddy = P(small), v.c_phys
                 if v.res is not None:
                     t = v.res
-                    own = lambda u: u.parent is None and u.c_off == 0 and u.ld == u.c_phys
+                    own = lambda u: u.parent is None and u.c_off == 0 and u.ld == u.c_phys and holders.get(id(u.gstorage), 0) == 1
                     if (id(t.gstorage) not in initialised and v.ups == 1 and own(t) and own(v) and not t.fp32
                             and (t.H, t.W, t.c_phys) == (v.H, v.W, v.c_phys) and not getattr(t, 'galias', False)):
                         # first contribution to the residual source is dy itself: share the buffer instead of copying it.

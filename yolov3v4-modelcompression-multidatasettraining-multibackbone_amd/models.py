@@ -402,7 +402,8 @@ class Darknet(nn.Module):
         self.hip_precision = os.environ.get('YOLO_HIP_PRECISION', 'fp16')
         # feature_out (models.py:540-543: every conv block not feeding a yolo layer, used by the feature-distillation
         # losses KD4 / KD5) costs an NCHW fp32 copy of ~70 tensors per forward, so the HIP paths return [] unless asked:
-        # eval copies them out of the engine's buffers, train falls back to the eager modules
+        # eval copies them out of the engine's buffers; the training step does not carry them (the feature-distillation
+        # strategies are out of scope) and raises when asked
         self.hip_return_features = False
         if quantized == -1:
             self.info(verbose)
@@ -430,10 +431,12 @@ class Darknet(nn.Module):
 
     def _use_hip_train(self, x):
         # training step on the HIP kernels (engine/train.py, engine/padded.py): every float graph on a GPU.  A cfg that path
-        # cannot lower raises - there is no eager fallback.  (YOLO_HIP_TRAIN=0 is a debugging switch; feature-distillation
-        # losses ask for the eager modules explicitly through hip_return_features.)
-        return (x.is_cuda and self.training and self.quantized == -1
-                and not self.__dict__.get('hip_return_features', False) and os.environ.get('YOLO_HIP_TRAIN', '1') != '0')
+        # cannot lower raises - there is no eager fallback.  (YOLO_HIP_TRAIN=0 is a debugging switch.)
+        use = x.is_cuda and self.training and self.quantized == -1 and os.environ.get('YOLO_HIP_TRAIN', '1') != '0'
+        if use and self.__dict__.get('hip_return_features', False):
+            raise NotImplementedError('feature_out is not produced by the HIP training step: the feature-distillation losses '
+                                      '(reference train.py KDstr 2-5) are out of scope; clear hip_return_features')
+        return use
 
     def forward_once(self, x, augment=False, verbose=False):
         if not verbose and not augment:

@@ -10,6 +10,13 @@ import sys
 
 def short(name):
     import re
+    ty = {'DF16_': 'f16', 'f': 'f32', 'a': 'i8'}
+    m = re.match(r'_ZN2yh2[0-9]conv_igemm_(pp2?|k64)_kernelI(DF16_|f|a)(DF16_|f|a)Li(\d+)ELi(\d+)E', name)
+    if m:   # wave grid WM x WN of 128 x 64 (f16) / 128 x 64 (int8) wave tiles: 2x4 = 256 x 256, 4x2 = 512 x 128, 1x8 = 128 x 512
+        return 'conv_igemm_%s<%s,%s,%dx%d>' % (m.group(1), ty[m.group(2)], ty[m.group(3)], 128 * int(m.group(4)), 64 * int(m.group(5)))
+    m = re.match(r'_ZN2yh22conv_igemm_glds_kernelIaaLi(\d+)ELi(\d+)ELi\d+ELi\d+ELi(\d+)ELi(\d+)E', name)
+    if m:
+        return 'conv_igemm_glds<i8,i8,%sx%s,S%s>' % (m.group(1), m.group(2), m.group(3))
     m = re.match(r'_ZN2yh17conv_igemm_kernelI(DF16_|f)(DF16_|f)Li(\d+)ELi(\d+)E', name)
     if m:
         return 'conv_igemm<%s,%s,%sx%s>' % ('f16' if m.group(1) != 'f' else 'f32', 'f16' if m.group(2) != 'f' else 'f32',
