@@ -16,11 +16,13 @@ output channel has zero weights and zero bias, hence z = 0, batch mean = var = 0
 activation maps 0 -> 0; a padded input column multiplies zeros.  The result equals the unpadded computation exactly in exact
 arithmetic and to summation order in floating point (tests/test_gpu_train.py, tests/test_train_emulated.py).
 
-Layouts: each layer's output is described by ``pos`` (physical channel of every logical channel) and the physical width.  Convs
-produce ``arange(C)`` padded at the end, depthwise convs / BN / SE / pools / upsample keep their input's layout, routes
-concatenate layouts.  What the twin cannot express raises ``NotImplementedError`` (there is no eager fallback): shortcuts
-between tensors whose layouts differ (GhostNet adds a 12 + 12 channel concat to a 24-channel conv), group-split routes of a
-padded tensor, grouped convs other than depthwise.
+Layouts: each layer's output is described by ``pos`` (physical channel of every logical channel) and the physical width.  Dense
+convs are free to place their output channels (default ``arange(C)`` padded at the end), depthwise convs / BN / SE / pools /
+upsample keep their input's layout, routes concatenate layouts at 8-aligned offsets.  A shortcut needs both operands in one
+layout: when a dense conv meets a concat (GhostNet adds a 24-channel conv to a 12 + 12 channel concat = 24 of 32 lanes) the conv
+adopts the concat's layout (``plan_layouts``).  What the twin cannot express raises ``NotImplementedError`` (there is no eager
+fallback): a conv that two shortcuts would need in two layouts, group-split routes of a padded tensor, grouped convs other than
+depthwise.  All 39 cfgs of the reference tree that the reference itself can run lower (tests/test_reference_cfgs.py).
 """
 import copy
 import types

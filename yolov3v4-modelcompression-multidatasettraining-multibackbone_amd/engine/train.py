@@ -25,9 +25,9 @@ and the backward plan, walking the values in reverse,
 
 Every activation, z and gradient buffer is kept for the whole step (288 GB of HBM: YOLOv3-608 batch 64 needs ~40 GB).
 Depthwise blocks, squeeze-excite, max-pools (incl. SPP) and CSP group-split routes are lowered too (csrc/depthwise.hip,
-csrc/train.hip).  Graphs whose widths are not multiples of 8 (slim-pruned nets) train through the channel-padded twin of
-``engine/padded.py``; what neither form covers (weighted shortcuts, grouped convs other than depthwise, shortcuts between
-different padded layouts) raises NotImplementedError at plan build - ``models.Darknet`` has no eager fallback for training.
+csrc/train.hip).  Graphs whose widths are not multiples of 8 (slim-pruned nets, GhostNet) train through the channel-padded twin
+of ``engine/padded.py``; what neither form covers (weighted shortcuts, grouped convs other than depthwise) raises
+NotImplementedError at plan build - ``models.Darknet`` has no eager fallback for training.
 """
 import ctypes as C
 import os
