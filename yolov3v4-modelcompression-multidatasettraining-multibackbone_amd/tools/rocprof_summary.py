@@ -17,6 +17,14 @@ def short(name):
     m = re.match(r'_ZN2yh22conv_igemm_glds_kernelIaaLi(\d+)ELi(\d+)ELi\d+ELi\d+ELi(\d+)ELi(\d+)E', name)
     if m:
         return 'conv_igemm_glds<i8,i8,%sx%s,S%s>' % (m.group(1), m.group(2), m.group(3))
+    # rocprofv3 demangles the int8 instantiations itself ("void yh::conv_igemm_glds_kernel<signed char, signed char, 256, 128, ...")
+    dty = {'signed char': 'i8', 'float': 'f32', '_Float16': 'f16'}
+    m = re.match(r'void yh::conv_igemm_glds_kernel<(signed char|float|_Float16), (signed char|float|_Float16), (\d+), (\d+), \d+, \d+, (\d+), (\d+)>', name)
+    if m:
+        return 'conv_igemm_glds<%s,%s,%sx%s,S%s>' % (dty[m.group(1)], dty[m.group(2)], m.group(3), m.group(4), m.group(5))
+    m = re.match(r'void yh::conv_igemm_(pp2?|k64)_kernel<(signed char|float|_Float16), (signed char|float|_Float16), (\d+), (\d+)>', name)
+    if m:
+        return 'conv_igemm_%s<%s,%s,%dx%d>' % (m.group(1), dty[m.group(2)], dty[m.group(3)], 128 * int(m.group(4)), 64 * int(m.group(5)))
     m = re.match(r'_ZN2yh17conv_igemm_kernelI(DF16_|f)(DF16_|f)Li(\d+)ELi(\d+)E', name)
     if m:
         return 'conv_igemm<%s,%s,%sx%s>' % ('f16' if m.group(1) != 'f' else 'f32', 'f16' if m.group(2) != 'f' else 'f32',
