@@ -523,6 +523,31 @@ typedef struct yh_letterbox_desc {
 } yh_letterbox_desc;
 int yh_letterbox_fwd(const yh_letterbox_desc* d, void* stream);
 
+/* Input pipeline on the device, second slice: ONE training item = 4-image mosaic -> random affine warp (bilinear, constant
+ * border) -> HSV augmentation -> left-right flip -> planar CHW uint8 or x / divisor float.  Replaces utils/datasets.py
+ * load_mosaic + random_affine + augment_hsv + the flip / transpose of __getitem__ (reference datasets.py:553-608, 649-715, 534-550,
+ * 470-505) and `imgs.float() / 256.0` (train.py:345).  The random draws, the label geometry and the decode stay on the host
+ * (engine/preprocess.py); the arithmetic is the host loader's operation for operation (Pillow's double-precision bilinear
+ * transform, numpy's float32 / float64 HSV formulas), so the output is bit-identical to it.
+ *   canvas(cy, cx)  = src[k][y1b[k] + cy - y1a[k]][x1b[k] + cx - x1a[k]] for the rectangle k with x1a <= cx < x2a, y1a <= cy < y2a,
+ *                     pad_value where no rectangle covers (the canvas is never materialised); empty rectangles are skipped
+ *   warp(Y, X)      = bilinear sample of canvas at (inv[0] (X'+.5) + inv[1] (Y+.5) + inv[2], inv[3] (X'+.5) + inv[4] (Y+.5) + inv[5])
+ *                     with X' = out_w - 1 - X when flip_lr; pad_value when that point is outside the canvas
+ *   dst[ch][Y][X]   = hsv(warp) (3 channels and hsv != 0; gains hsv_gain[0..2] on hue / saturation / value)                  */
+enum { YH_MOSAIC_U8 = 0, YH_MOSAIC_F32 = 1, YH_MOSAIC_F16 = 2 };
+typedef struct yh_mosaic_desc {
+    const uint8_t* src[4];       /* decoded frames, [src_h][src_pitch bytes], c interleaved channels (device pointers)    */
+    void* dst;                   /* [c][out_h][out_w]: uint8, or float / half holding value / divisor                      */
+    double inv[6];               /* output pixel centre -> canvas point (rows of the inverse affine matrix)                */
+    double hsv_gain[3];
+    int32_t src_h[4], src_w[4], src_pitch[4];
+    int32_t x1a[4], y1a[4], x2a[4], y2a[4];   /* placement rectangle on the canvas                                        */
+    int32_t x1b[4], y1b[4];                   /* its top-left corner in the source frame                                   */
+    int32_t canvas_h, canvas_w, out_h, out_w, c, pad_value, hsv, flip_lr, out_dtype;
+    float divisor;               /* train.py:345: 256                                                                      */
+} yh_mosaic_desc;
+int yh_mosaic_affine_hsv(const yh_mosaic_desc* d, void* stream);
+
 /* ---------------------------------------------------------------------------------------------------
  * Plans: a recorded sequence of the launches above, replayed by one native call per forward (the
  * replacement for the per-layer Python dispatch loop of models.py:524-545).  Pointers that change

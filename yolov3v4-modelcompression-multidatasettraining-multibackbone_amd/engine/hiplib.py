@@ -150,6 +150,14 @@ class LetterboxDesc(C.Structure):
                 ('pad_value', _i32), ('swap_rb', _i32), ('scale', _f32), ('shift', _f32)]
 
 
+class MosaicDesc(C.Structure):
+    _fields_ = [('src', _vp * 4), ('dst', _vp), ('inv', C.c_double * 6), ('hsv_gain', C.c_double * 3),
+                ('src_h', _i32 * 4), ('src_w', _i32 * 4), ('src_pitch', _i32 * 4),
+                ('x1a', _i32 * 4), ('y1a', _i32 * 4), ('x2a', _i32 * 4), ('y2a', _i32 * 4), ('x1b', _i32 * 4), ('y1b', _i32 * 4),
+                ('canvas_h', _i32), ('canvas_w', _i32), ('out_h', _i32), ('out_w', _i32), ('c', _i32), ('pad_value', _i32),
+                ('hsv', _i32), ('flip_lr', _i32), ('out_dtype', _i32), ('divisor', _f32)]
+
+
 class LayoutDesc(C.Structure):
     _fields_ = [('x', _vp), ('y', _vp), ('n', _i32), ('c', _i32), ('h', _i32), ('w_in', _i32), ('c_pad', _i32), ('ldy', _i32),
                 ('dtype', _i32)]
@@ -268,6 +276,7 @@ _SIGNATURES = {
     'yh_yolo_loss_bwd': (C.c_int, [C.POINTER(LossDesc), _vp]),
     'yh_nchw_to_nhwc': (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
     'yh_letterbox_fwd': (C.c_int, [C.POINTER(LetterboxDesc), _vp]),
+    'yh_mosaic_affine_hsv': (C.c_int, [C.POINTER(MosaicDesc), _vp]),
     'yh_plan_create': (_vp, []),
     'yh_plan_destroy': (None, [_vp]),
     'yh_plan_add': (C.c_int, [_vp, C.c_int, _vp, C.c_int]),

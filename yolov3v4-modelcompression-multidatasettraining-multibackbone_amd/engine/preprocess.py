@@ -148,3 +148,85 @@ def resample_reference(img, out_hw):
         acc = (1 << (PRECISION_BITS - 1)) + (tmp[y0:y0 + n] * vk[y, :n].astype(np.int64)[:, None, None]).sum(0)
         out[y] = np.clip(acc >> PRECISION_BITS, 0, 255).astype(np.uint8)
     return out
+
+
+# ----------------------------------------------------------------------------------------------- training items (second slice)
+def render_mosaic_items(items, device, out=None, dtype=torch.float32, divisor=256.0, lib=None):
+    """A batch of ``utils.datasets.MosaicItem`` recipes (a ``MosaicBatch`` from the loader's ``collate_fn``, or a plain list) ->
+    the network input on ``device``: ``(n, c, h, w)`` float (value / divisor, what ``imgs.to(device).float() / 256.0`` of
+    train.py:345 produces from the host loader's items) or uint8 (the host loader's items themselves).  One upload of the cropped
+    source frames per batch, one ``yh_mosaic_affine_hsv`` launch per item."""
+    from utils.datasets import MosaicBatch
+    from .hiplib import MosaicDesc
+    lib = lib or hiplib.load()
+    batch = items if isinstance(items, MosaicBatch) else MosaicBatch(items)
+    items = batch.items
+    n = len(items)
+    h, w = items[0].out_hw
+    c = items[0].channels
+    code = {torch.uint8: 0, torch.float32: 1, torch.float16: 2}[dtype]
+    if out is None:
+        out = torch.empty((n, c, h, w), device=device, dtype=dtype)
+    assert out.is_contiguous() and tuple(out.shape) == (n, c, h, w) and out.dtype == dtype
+    dev_buf = batch.blob.to(device, non_blocking=True)
+    base, offs = dev_buf.data_ptr(), batch.offsets
+    k = 0
+    with hiplib.on_device(dev_buf):
+        for i, it in enumerate(items):
+            d = MosaicDesc()
+            for j, (shape, (x1a, y1a, x2a, y2a), (x1b, y1b)) in enumerate(it.parts):
+                if shape is not None:
+                    d.src[j] = base + int(offs[k])
+                    d.src_h[j], d.src_w[j], d.src_pitch[j] = shape[0], shape[1], shape[1] * c
+                d.x1a[j], d.y1a[j], d.x2a[j], d.y2a[j], d.x1b[j], d.y1b[j] = x1a, y1a, x2a, y2a, x1b, y1b
+                k += 1
+            d.dst = out[i].data_ptr()
+            for q in range(6):
+                d.inv[q] = float(it.inv[q])
+            d.hsv = 0 if it.hsv_gains is None else 1
+            for q in range(3):
+                d.hsv_gain[q] = 1.0 if it.hsv_gains is None else float(it.hsv_gains[q])
+            d.canvas_h, d.canvas_w = it.canvas
+            d.out_h, d.out_w, d.c, d.pad_value = h, w, c, PAD_VALUE
+            d.flip_lr, d.out_dtype, d.divisor = int(bool(it.flip)), code, float(divisor)
+            hiplib.check(lib.yh_mosaic_affine_hsv(C.byref(d), hiplib.stream_ptr()), 'yh_mosaic_affine_hsv')
+    # dev_buf may die here: the caching allocator only hands its memory to later work on this stream
+    return out
+
+
+def mosaic_reference(item):
+    """Host restatement (numpy, float64 / float32 exactly as the kernel) of one item -> uint8 CHW.  Test infrastructure: pins the
+    kernel's arithmetic to the host loader (Pillow transform + utils.datasets.augment_hsv) on the CPU tier."""
+    from utils.datasets import _rgb_to_hsv, _hsv_to_rgb
+    H, W = item.canvas
+    c = item.channels
+    canvas = np.full((H, W, c), PAD_VALUE, dtype=np.uint8)
+    for crop, (x1a, y1a, x2a, y2a), (x1b, y1b) in item.parts:   # an item as the dataset returns it (before collation)
+        if crop is not None:
+            canvas[y1a:y2a, x1a:x2a] = crop[y1b:y1b + y2a - y1a, x1b:x1b + x2a - x1a].reshape(y2a - y1a, x2a - x1a, c)
+    oh, ow = item.out_hw
+    yo, xo = np.mgrid[0:oh, 0:ow].astype(np.float64)
+    a = item.inv
+    xin = a[0] * (xo + 0.5) + a[1] * (yo + 0.5) + a[2]
+    yin = a[3] * (xo + 0.5) + a[4] * (yo + 0.5) + a[5]
+    inside = ~((xin < 0) | (yin < 0) | (xin >= W) | (yin >= H))
+    xin, yin = xin - 0.5, yin - 0.5
+    x, y = np.floor(xin).astype(np.int64), np.floor(yin).astype(np.int64)
+    dx, dy = xin - x, yin - y
+    yc, x0, x1 = np.clip(y, 0, H - 1), np.clip(x, 0, W - 1), np.clip(x + 1, 0, W - 1)
+    second = (y + 1 >= 0) & (y + 1 < H)
+    y1c = np.clip(y + 1, 0, H - 1)
+    img = np.empty((oh, ow, c), dtype=np.uint8)
+    f = canvas.astype(np.float64)
+    for ch in range(c):
+        p = f[..., ch]
+        v1 = p[yc, x0] + (p[yc, x1] - p[yc, x0]) * dx
+        v2 = np.where(second, p[y1c, x0] + (p[y1c, x1] - p[y1c, x0]) * dx, v1)
+        img[..., ch] = np.where(inside, (v1 + (v2 - v1) * dy).astype(np.uint8), PAD_VALUE)
+    if item.hsv_gains is not None:
+        h, s, v = _rgb_to_hsv(img)
+        g = item.hsv_gains
+        img = _hsv_to_rgb((h * g[0]) % 1.0, np.clip(s * g[1], 0, 1), np.clip(v * g[2], 0, 1))
+    if item.flip:
+        img = np.fliplr(img)
+    return np.ascontiguousarray(img.transpose(2, 0, 1))

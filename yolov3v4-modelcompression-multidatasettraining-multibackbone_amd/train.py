@@ -186,8 +186,10 @@ def train(opt, hyp):
             model.register_comm_hook(None, default_hooks.fp16_compress_hook)
         model.yolo_layers = core.yolo_layers
 
+    # --device-augment: items arrive as recipes (cropped source frames + geometry + gains) and one HIP kernel per item does the
+    # mosaic, warp, HSV, flip, transpose and /256 on the GPU (engine/preprocess.py render_mosaic_items, csrc/augment.hip)
     dataset = LoadImagesAndLabels(train_path, img_size, batch_size, augment=True, hyp=hyp, rect=opt.rect, cache_images=opt.cache_images,
-                                  rank=rank, is_gray_scale=opt.gray_scale)
+                                  rank=rank, is_gray_scale=opt.gray_scale, device_augment=opt.device_augment and device.type == 'cuda')
     nw = min([os.cpu_count() or 1, batch_size if batch_size > 1 else 0, 8])
     sampler = torch.utils.data.distributed.DistributedSampler(dataset) if distributed else None
     dataloader = DataLoader(dataset, batch_size=batch_size, num_workers=nw, shuffle=(sampler is None and not opt.rect), sampler=sampler,
@@ -235,7 +237,11 @@ def train(opt, hyp):
             pbar = tqdm(pbar, total=nb)
         for i, (imgs, targets, paths, _) in pbar:
             ni = i + nb * epoch
-            imgs = imgs.to(device).float() / 256.0       # uint8 -> [0, 1) (train.py:346-350)
+            if not torch.is_tensor(imgs):                # recipes (MosaicBatch): rendered on the device, bit-identical to the host items / 256
+                from engine.preprocess import render_mosaic_items
+                imgs = render_mosaic_items(imgs, device, dtype=torch.float32, divisor=256.0)
+            else:
+                imgs = imgs.to(device).float() / 256.0   # uint8 -> [0, 1) (train.py:346-350)
             if opt.maxabsscaler:
                 imgs = imgs * 2 - 1
             targets = targets.to(device)
@@ -352,6 +358,8 @@ def make_parser():
     parser.add_argument('--nosave', action='store_true', help='only save final checkpoint')
     parser.add_argument('--notest', action='store_true', help='only test final epoch')
     parser.add_argument('--cache-images', action='store_true', help='cache images for faster training')
+    parser.add_argument('--device-augment', action='store_true',
+                        help='mosaic / affine / HSV / flip of the training items on the GPU (same random streams, same pixels as the host loader)')
     parser.add_argument('--weights', type=str, default='', help='initial weights path')
     parser.add_argument('--t_weights', type=str, default='', help='teacher model weights')
     parser.add_argument('--KDstr', type=int, default=-1, help='KD strategy')

@@ -183,29 +183,26 @@ def augment_hsv(img, hgain=0.5, sgain=0.5, vgain=0.5):
     img[:] = _hsv_to_rgb((h * gains[0]) % 1.0, np.clip(s * gains[1], 0, 1), np.clip(v * gains[2], 0, 1))
 
 
-def random_affine(img, targets=(), degrees=10, translate=.1, scale=.1, shear=10, border=0):
-    """Random rotation / scale / translation / shear about the image centre, then crop ``border`` (negative = the mosaic's
-    centre crop); boxes follow their transformed corners and degenerate ones are dropped (datasets.py:649-715)."""
-    height, width = img.shape[0] + border * 2, img.shape[1] + border * 2
+def affine_matrix(img_hw, degrees=10, translate=.1, scale=.1, shear=10, border=0):
+    """The random draws of ``random_affine`` (six ``random.uniform`` calls, in the reference's order, datasets.py:655-674):
+    returns ``(M, s, (width, height))`` - the 3x3 forward matrix, the scale factor and the output size."""
+    height, width = img_hw[0] + border * 2, img_hw[1] + border * 2
     a = math.radians(random.uniform(-degrees, degrees))
     s = random.uniform(1 - scale, 1 + scale)
-    cx, cy = img.shape[1] / 2, img.shape[0] / 2
+    cx, cy = img_hw[1] / 2, img_hw[0] / 2
     R = np.array([[s * math.cos(a), s * math.sin(a), (1 - s * math.cos(a)) * cx - s * math.sin(a) * cy],
                   [-s * math.sin(a), s * math.cos(a), s * math.sin(a) * cx + (1 - s * math.cos(a)) * cy], [0, 0, 1]])
     T = np.eye(3)
-    T[0, 2] = random.uniform(-translate, translate) * img.shape[1] + border
-    T[1, 2] = random.uniform(-translate, translate) * img.shape[0] + border
+    T[0, 2] = random.uniform(-translate, translate) * img_hw[1] + border
+    T[1, 2] = random.uniform(-translate, translate) * img_hw[0] + border
     S = np.eye(3)
     S[0, 1] = math.tan(math.radians(random.uniform(-shear, shear)))
     S[1, 0] = math.tan(math.radians(random.uniform(-shear, shear)))
-    M = S @ T @ R
-    if border != 0 or (M != np.eye(3)).any():
-        inv = np.linalg.inv(M)
-        gray = img.shape[2] == 1
-        pil = Image.fromarray(img[:, :, 0] if gray else img)
-        fill = PAD_VALUE if gray else (PAD_VALUE,) * 3
-        out = np.asarray(pil.transform((width, height), Image.AFFINE, tuple(inv[:2].reshape(-1)), Image.BILINEAR, fillcolor=fill))
-        img = out[:, :, None] if gray else out
+    return S @ T @ R, s, (width, height)
+
+
+def affine_targets(targets, M, s, width, height):
+    """Boxes follow their transformed corners; degenerate ones are dropped (datasets.py:688-715)."""
     n = len(targets)
     if n:
         xy = np.ones((n * 4, 3))
@@ -221,18 +218,31 @@ def random_affine(img, targets=(), degrees=10, translate=.1, scale=.1, shear=10,
         keep = (w > 4) & (h > 4) & (w * h / (area0 * s + 1e-16) > 0.2) & (ar < 10)
         targets = targets[keep]
         targets[:, 1:5] = box[keep]
-    return img, targets
+    return targets
 
 
-def load_mosaic(self, index, is_gray_scale=False):
-    """Four images around a random centre of a 2s x 2s canvas, labels shifted with them, centre s x s kept
-    (datasets.py:553-608)."""
+def random_affine(img, targets=(), degrees=10, translate=.1, scale=.1, shear=10, border=0):
+    """Random rotation / scale / translation / shear about the image centre, then crop ``border`` (negative = the mosaic's
+    centre crop); boxes follow their transformed corners and degenerate ones are dropped (datasets.py:649-715)."""
+    M, s, (width, height) = affine_matrix(img.shape[:2], degrees, translate, scale, shear, border)
+    if border != 0 or (M != np.eye(3)).any():
+        inv = np.linalg.inv(M)
+        gray = img.shape[2] == 1
+        pil = Image.fromarray(img[:, :, 0] if gray else img)
+        fill = PAD_VALUE if gray else (PAD_VALUE,) * 3
+        out = np.asarray(pil.transform((width, height), Image.AFFINE, tuple(inv[:2].reshape(-1)), Image.BILINEAR, fillcolor=fill))
+        img = out[:, :, None] if gray else out
+    return img, affine_targets(targets, M, s, width, height)
+
+
+def mosaic_layout(self, index, is_gray_scale=False):
+    """The random draws and the geometry of ``load_mosaic`` without touching a canvas (datasets.py:553-600): the mosaic centre,
+    the three extra image indices, and per image the placement rectangle ``(x1a, y1a, x2a, y2a)`` on the 2s x 2s canvas, the
+    matching source corner ``(x1b, y1b)``, the loaded image and its labels in canvas pixels."""
     s = self.img_size
     xc, yc = [int(random.uniform(s * 0.5, s * 1.5)) for _ in range(2)]
     indices = [index] + [random.randint(0, len(self.labels) - 1) for _ in range(3)]
-    c = 1 if is_gray_scale else 3
-    canvas = np.full((s * 2, s * 2, c), PAD_VALUE, dtype=np.uint8)
-    labels4 = []
+    parts, labels4 = [], []
     for i, idx in enumerate(indices):
         img, _, (h, w) = load_image(self, idx, is_gray_scale)
         if i == 0:    # top left of the centre
@@ -247,7 +257,7 @@ def load_mosaic(self, index, is_gray_scale=False):
         else:         # bottom right
             x1a, y1a, x2a, y2a = xc, yc, min(xc + w, s * 2), min(s * 2, yc + h)
             x1b, y1b, x2b, y2b = 0, 0, min(w, x2a - x1a), min(y2a - y1a, h)
-        canvas[y1a:y2a, x1a:x2a] = img[y1b:y2b, x1b:x2b]
+        parts.append((img, (x1a, y1a, x2a, y2a), (x1b, y1b, x2b, y2b)))
         padw, padh = x1a - x1b, y1a - y1b
         x = self.labels[idx]
         if x.size:
@@ -260,9 +270,99 @@ def load_mosaic(self, index, is_gray_scale=False):
     labels4 = np.concatenate(labels4, 0) if labels4 else np.zeros((0, 5), dtype=np.float32)
     if len(labels4):
         np.clip(labels4[:, 1:], 0, 2 * s, out=labels4[:, 1:])
+    return parts, labels4
+
+
+def load_mosaic(self, index, is_gray_scale=False):
+    """Four images around a random centre of a 2s x 2s canvas, labels shifted with them, centre s x s kept
+    (datasets.py:553-608)."""
+    s = self.img_size
+    parts, labels4 = mosaic_layout(self, index, is_gray_scale)
+    c = 1 if is_gray_scale else 3
+    canvas = np.full((s * 2, s * 2, c), PAD_VALUE, dtype=np.uint8)
+    for img, (x1a, y1a, x2a, y2a), (x1b, y1b, x2b, y2b) in parts:
+        canvas[y1a:y2a, x1a:x2a] = img[y1b:y2b, x1b:x2b]
     hyp = self.hyp or {}
     return random_affine(canvas, labels4, degrees=hyp.get('degrees', 0), translate=hyp.get('translate', 0),
                          scale=hyp.get('scale', 0), shear=hyp.get('shear', 0), border=-s // 2)
+
+
+class MosaicItem:
+    """One training item with the pixel work left undone: everything ``yh_mosaic_affine_hsv`` needs (csrc/augment.hip) plus the
+    finished labels.  Produced by ``LoadImagesAndLabels.__getitem__`` when ``device_augment`` is set; consumes the random streams
+    exactly like the host path, so the same seeds give the same item."""
+    __slots__ = ('parts', 'canvas', 'out_hw', 'inv', 'identity', 'hsv_gains', 'flip', 'channels', 'labels', 'path')
+
+
+class MosaicBatch:
+    """A collated batch of recipes: every source crop of the batch in ONE uint8 tensor (built in the loader worker, pinned by the
+    DataLoader's pin-memory thread through ``pin_memory()``, uploaded with one copy) plus the per-item geometry."""
+
+    def __init__(self, items):
+        self.items = list(items)
+        sizes = [(0 if p[0] is None else p[0].size) for it in self.items for p in it.parts]
+        self.offsets = np.concatenate([[0], np.cumsum([(n + 15) // 16 * 16 for n in sizes])]).astype(np.int64)
+        self.blob = torch.empty(int(self.offsets[-1]) + 16, dtype=torch.uint8)
+        flat = self.blob.numpy()
+        k = 0
+        for it in self.items:
+            parts = []
+            for crop, rect, corner in it.parts:
+                if crop is not None:
+                    flat[self.offsets[k]:self.offsets[k] + crop.size] = crop.reshape(-1)
+                parts.append((None if crop is None else crop.shape[:2], rect, corner))
+                k += 1
+            it.parts = parts          # shapes only from here on: the pixels live in the blob
+
+    def pin_memory(self):
+        self.blob = self.blob.pin_memory()
+        return self
+
+    def __len__(self):
+        return len(self.items)
+
+
+def mosaic_item(self, index):
+    """``__getitem__`` of the augmenting mosaic path (datasets.py:470-505) with the image left as a recipe."""
+    hyp = self.hyp or {}
+    s = self.img_size
+    it = MosaicItem()
+    it.channels = 1 if self.is_gray_scale else 3
+    parts, labels4 = mosaic_layout(self, index, self.is_gray_scale)
+    M, sc, (width, height) = affine_matrix((2 * s, 2 * s), hyp.get('degrees', 0), hyp.get('translate', 0), hyp.get('scale', 0),
+                                           hyp.get('shear', 0), border=-s // 2)
+    labels = affine_targets(labels4, M, sc, width, height)
+    it.inv = np.linalg.inv(M)[:2].reshape(-1).astype(np.float64)
+    it.canvas, it.out_hw = (2 * s, 2 * s), (height, width)
+    it.hsv_gains = None
+    if not self.is_gray_scale:   # augment_hsv: one np.random.uniform(-1, 1, 3)
+        it.hsv_gains = np.random.uniform(-1, 1, 3) * [hyp.get('hsv_h', 0), hyp.get('hsv_s', 0), hyp.get('hsv_v', 0)] + 1
+    n_l = len(labels)
+    if n_l:
+        labels[:, 1:5] = xyxy2xywh(labels[:, 1:5])
+        labels[:, [2, 4]] /= height
+        labels[:, [1, 3]] /= width
+    it.flip = random.random() < 0.5
+    if it.flip and n_l:
+        labels[:, 1] = 1 - labels[:, 1]
+    it.labels = torch.zeros((n_l, 6))
+    if n_l:
+        it.labels[:, 1:] = torch.from_numpy(np.ascontiguousarray(labels))
+    it.path = self.img_files[index]
+    # ship only the pixels the warp can touch: the footprint of the output rectangle on the canvas (+ the bilinear neighbour)
+    inv = np.vstack([it.inv.reshape(2, 3), [0, 0, 1]])
+    corners = inv @ np.array([[0, width, 0, width], [0, 0, height, height], [1, 1, 1, 1]], dtype=np.float64)
+    fx0, fx1 = int(math.floor(corners[0].min())) - 2, int(math.ceil(corners[0].max())) + 2
+    fy0, fy1 = int(math.floor(corners[1].min())) - 2, int(math.ceil(corners[1].max())) + 2
+    it.parts = []
+    for img, (x1a, y1a, x2a, y2a), (x1b, y1b, x2b, y2b) in parts:
+        cx0, cy0, cx1, cy1 = max(x1a, fx0), max(y1a, fy0), min(x2a, fx1), min(y2a, fy1)
+        if cx1 <= cx0 or cy1 <= cy0:
+            it.parts.append((None, (0, 0, 0, 0), (0, 0)))
+            continue
+        crop = np.ascontiguousarray(img[y1b + cy0 - y1a:y1b + cy1 - y1a, x1b + cx0 - x1a:x1b + cx1 - x1a])
+        it.parts.append((crop, (cx0, cy0, cx1, cy1), (0, 0)))
+    return it
 
 
 class LoadImagesAndLabels(Dataset):
@@ -275,7 +375,7 @@ class LoadImagesAndLabels(Dataset):
     ``collate_fn`` writes the image index into column 0, the format ``build_targets`` expects."""
 
     def __init__(self, path, img_size=416, batch_size=16, augment=False, hyp=None, rect=False, image_weights=False,
-                 cache_images=False, rank=-1, is_gray_scale=False, subset_len=-1, single_cls=False, pad=0.0):
+                 cache_images=False, rank=-1, is_gray_scale=False, subset_len=-1, single_cls=False, pad=0.0, device_augment=False):
         path = str(Path(path))
         if os.path.isdir(path):
             files = sorted(glob.glob(os.path.join(path, '*.*')))
@@ -295,6 +395,8 @@ class LoadImagesAndLabels(Dataset):
         self.augment, self.hyp, self.image_weights = augment, hyp, image_weights
         self.rect = False if image_weights else rect
         self.mosaic = self.augment and not self.rect
+        # the mosaic / warp / HSV / flip pixel work on the GPU (engine/preprocess.py render_mosaic_items): items are recipes
+        self.device_augment = bool(device_augment) and self.mosaic
         self.is_gray_scale = is_gray_scale
         self.label_files = [x.replace('images', 'labels').replace(os.path.splitext(x)[-1], '.txt') for x in self.img_files]
 
@@ -352,6 +454,8 @@ class LoadImagesAndLabels(Dataset):
         if self.image_weights:
             index = self.indices[index]
         hyp = self.hyp or {}
+        if self.device_augment:
+            return mosaic_item(self, index)
         if self.mosaic:
             img, labels = load_mosaic(self, index, self.is_gray_scale)
             shapes = None
@@ -392,6 +496,10 @@ class LoadImagesAndLabels(Dataset):
 
     @staticmethod
     def collate_fn(batch):
+        if batch and isinstance(batch[0], MosaicItem):   # device_augment: (MosaicBatch, labels, paths, shapes); the train loop renders
+            for i, it in enumerate(batch):
+                it.labels[:, 0] = i
+            return MosaicBatch(batch), torch.cat([it.labels for it in batch], 0), tuple(it.path for it in batch), (None,) * len(batch)
         img, label, path, shapes = zip(*batch)
         for i, l in enumerate(label):
             l[:, 0] = i   # image index within the batch, for build_targets()
