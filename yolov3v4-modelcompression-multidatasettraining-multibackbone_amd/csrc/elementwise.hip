@@ -97,7 +97,10 @@ template <int CO> struct StemStore<int8_t, CO> {
 
 // (Round 2 tried this layer on the matrix cores - 16 pixels x 32 channels per v_mfma_f32_16x16x32_f16 with the im2col fragment
 // gathered by 8 scalar loads per lane from the NCHW planes: 1.19 ms against 0.97 ms here.  The gather touches 64 scattered
-// addresses per load instruction and is address-path bound; an MFMA stem needs the image staged through LDS first.)
+// addresses per load instruction and is address-path bound; an MFMA stem needs the image staged through LDS first.
+// A fully unrolled 3x3x3 form with 432 v_pk_fma_f32 per thread - two output channels per instruction, weights in scalar register
+// pairs - compiled as intended and was bit-identical, but ran 4.76 ms: 50 KB of straight-line code per kernel does not live in
+// the instruction cache.  The rolled loop below stays.)
 template <typename T, int CO>
 __global__ __launch_bounds__(256) void conv_stem_kernel(const yh_stem_desc d) {
     const long P = (long)d.n * d.ho * d.wo;
