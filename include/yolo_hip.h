@@ -571,6 +571,13 @@ int yh_plan_num_ops(const yh_plan* p);
 int yh_plan_run(yh_plan* p, void* stream);
 /* run ops [first, last) only (profiling / per-layer tests) */
 int yh_plan_run_range(yh_plan* p, int first, int last, void* stream);
+/* Two lanes.  Ops are replayed in index order on the caller's stream (lane 0) unless marked lane 1, which runs on a stream owned
+ * by the plan; across lanes the only ordering is what yh_plan_add_dep states (op waits for the completion of dep, dep < op), and
+ * every yh_plan_run / yh_plan_run_range call joins the side lane into the caller's stream before it returns.  The training
+ * backward puts the weight gradients on lane 1: they only feed the optimizer, so the HBM-bound BatchNorm backward passes of the
+ * next layer run underneath them (engine/train.py).                                                                        */
+int yh_plan_set_lane(yh_plan* p, int op_index, int lane);
+int yh_plan_add_dep(yh_plan* p, int op_index, int dep_index);
 /* Per-op HIP-event timing on the launch stream: when enabled every replay brackets each op with a pair of
  * events; after the caller has synchronised the stream, yh_plan_get_timings writes the last replay's
  * per-op durations in milliseconds to the HOST array ms_out[n], n == yh_plan_num_ops.                    */

@@ -784,6 +784,18 @@ class FakeLib:
     def yh_plan_num_ops(self, h):
         return len(self.plans[_addr(h)]['ops'])
 
+    # lanes: the emulation replays the LATEST schedule the declared dependencies allow - a side-lane op runs only when a
+    # main-lane op that waits for it comes up, or at the join at the end of the range - so a missing write-after-read dependency
+    # (a main-lane op overwriting what a side-lane op still has to read) shows up as wrong numbers on the CPU tier
+    def yh_plan_set_lane(self, h, op, lane):
+        self.plans[_addr(h)].setdefault('lane', {})[op] = lane
+        return 0
+
+    def yh_plan_add_dep(self, h, op, dep):
+        assert 0 <= dep < op
+        self.plans[_addr(h)].setdefault('deps', {}).setdefault(op, []).append(dep)
+        return 0
+
     def yh_plan_run(self, h, stream):
         return self.yh_plan_run_range(h, 0, self.yh_plan_num_ops(h), stream)
 
@@ -802,12 +814,39 @@ class FakeLib:
                hiplib.OP_NCHW_TO_NHWC: self._layout, hiplib.OP_POOL_BWD: self.yh_maxpool2d_bwd,
                hiplib.OP_PACK_BATCH: lambda d, st: self.yh_pack_batch(d.items, d.n_items, st),
                hiplib.OP_DW_WGRAD: self.yh_dw_wgrad, hiplib.OP_DW_DGRAD: self.yh_dw_dgrad, hiplib.OP_SE_BWD: self.yh_se_bwd}
-        for kind, desc, fixups in plan['ops'][first:last]:
+        lanes, deps = plan.get('lane', {}), plan.get('deps', {})
+        pending, done_main = [], set()
+
+        def execute(i):
+            kind, desc, fixups = plan['ops'][i]
             d = type(desc).from_buffer_copy(bytes(desc))
             for off, slot, boff in fixups:
                 C.c_void_p.from_address(C.addressof(d) + off).value = plan['slots'][slot] + boff
             rc = run[kind](d, stream)
+            self.calls.append(kind)
+            return rc
+
+        def flush(upto):
+            """Run the queued side-lane ops up to and including op `upto` (the side lane is a stream: in order)."""
+            while pending and pending[0] <= upto:
+                i = pending.pop(0)
+                for dep in deps.get(i, []):
+                    assert dep < first or lanes.get(dep, 0) == 1 or dep in done_main, 'side op %d runs before its dependency %d' % (i, dep)
+                rc = execute(i)
+                if rc:
+                    return rc
+            return 0
+        for i in range(first, last):
+            if lanes.get(i, 0) == 1:
+                pending.append(i)
+                continue
+            for dep in deps.get(i, []):
+                if dep >= first and lanes.get(dep, 0) == 1:
+                    rc = flush(dep)
+                    if rc:
+                        return rc
+            rc = execute(i)
             if rc:
                 return rc
-            self.calls.append(kind)
-        return 0
+            done_main.add(i)
+        return flush(last)

@@ -435,3 +435,33 @@ def test_shortcut_whose_operand_is_a_concat_keeps_the_parts_gradients():
             assert (grads[k] - grads_ref[k]).norm().item() <= 1e-4 * grads_ref[k].norm().item() + 1e-6 * total, k
     finally:
         os.unlink(path)
+
+
+def test_two_lane_backward_declares_its_dependencies(monkeypatch):
+    """The backward plan can run the weight gradients on a side lane (yh_plan_set_lane / yh_plan_add_dep; YOLO_HIP_WGRAD_LANE=1,
+    off by default: measured gain < 1 %).  The host emulation
+    replays the LATEST schedule the declared dependencies allow; with them the step matches eager autograd, and with the
+    write-after-read dependencies of the alternating dz buffers dropped it does not - so the check has teeth."""
+    path = th.write_cfg(th.mini_cfg_text())
+    try:
+        model = th.build(path, 64)
+        x = synth.image_batch(3, 64, seed=3)
+        raws_ref, grads_ref, m_ref, ws = th.eager_step(model, x)
+        total = sum(g.norm().item() ** 2 for g in grads_ref.values()) ** 0.5
+        errs = {}
+        for mode in ('declared', 'dropped', 'one_lane'):
+            lib = fakelib.FakeLib()
+            if mode == 'dropped':
+                orig = lib.yh_plan_add_dep
+                lib.yh_plan_add_dep = lambda h, op, dep, orig=orig, lib=lib: \
+                    orig(h, op, dep) if lib.plans[fakelib._addr(h)].get('lane', {}).get(op, 0) == 1 else 0
+            monkeypatch.setenv('YOLO_HIP_WGRAD_LANE', '0' if mode == 'one_lane' else '1')
+            raws, grads, m = th.engine_step(model, x, ws, 'fp32', lib=lib)
+            errs[mode] = sum((grads[k] - grads_ref[k]).norm().item() ** 2 for k in grads_ref) ** 0.5 / total
+            eng = m.__dict__['_hip_train_engine']
+            plan = eng._current
+            lanes = lib.plans[fakelib._addr(plan['bwd'])].get('lane', {})
+            assert (sum(lanes.values()) > 0) == (mode != 'one_lane')
+        assert errs['declared'] <= 1e-5 and errs['one_lane'] <= 1e-5 and errs['dropped'] >= 1e-2, errs
+    finally:
+        os.unlink(path)

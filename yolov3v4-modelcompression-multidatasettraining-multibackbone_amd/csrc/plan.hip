@@ -42,6 +42,9 @@ struct Op {
     int kind;
     AnyDesc d;
     std::vector<Fixup> fixups;
+    int lane = 0;                 // 0: the caller's stream; 1: the plan's side stream (yh_plan_set_lane)
+    std::vector<int> deps;        // ops of the OTHER lane this one waits for (yh_plan_add_dep); same-lane order is the stream's
+    bool has_dependents = false;  // some op of the other lane waits for this one: record its event
 };
 
 size_t desc_size(int kind) {
@@ -117,6 +120,11 @@ struct yh_plan {
     // optional hipGraph of one replay (launch-bound small batches): valid for the slot pointers bound at capture
     hipGraph_t graph = nullptr;
     hipGraphExec_t graph_exec = nullptr;
+    // second lane: ops the planner marked as independent of the main chain (the weight gradients of the training backward) run
+    // on this stream, ordered against the main lane by explicit dependencies only; every range joins before it returns
+    hipStream_t side = nullptr;
+    std::vector<hipEvent_t> done;   // done[i]: recorded after op i when has_dependents (created lazily, timing disabled)
+    hipEvent_t join = nullptr;
     void drop_graph() {
         if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
         if (graph) (void)hipGraphDestroy(graph);
@@ -125,6 +133,9 @@ struct yh_plan {
     }
     ~yh_plan() {
         for (hipEvent_t e : events) (void)hipEventDestroy(e);
+        for (hipEvent_t e : done) if (e) (void)hipEventDestroy(e);
+        if (join) (void)hipEventDestroy(join);
+        if (side) (void)hipStreamDestroy(side);
         drop_graph();
     }
 };
@@ -191,9 +202,30 @@ extern "C" int yh_plan_bind_slot(yh_plan* p, int slot, void* ptr) {
 
 extern "C" int yh_plan_num_ops(const yh_plan* p) { return p ? (int)p->ops.size() : YH_EINVAL; }
 
+extern "C" int yh_plan_set_lane(yh_plan* p, int op_index, int lane) {
+    if (!p) return YH_EINVAL;
+    if (op_index < 0 || op_index >= (int)p->ops.size() || lane < 0 || lane > 1) return YH_ERANGE;
+    p->ops[op_index].lane = lane;
+    return YH_OK;
+}
+
+extern "C" int yh_plan_add_dep(yh_plan* p, int op_index, int dep_index) {
+    if (!p) return YH_EINVAL;
+    if (op_index < 0 || op_index >= (int)p->ops.size() || dep_index < 0 || dep_index >= op_index) return YH_ERANGE;
+    try {
+        p->ops[op_index].deps.push_back(dep_index);
+    } catch (...) {
+        return YH_ENOMEM;
+    }
+    p->ops[dep_index].has_dependents = true;
+    return YH_OK;
+}
+
 extern "C" int yh_plan_run_range(yh_plan* p, int first, int last, void* stream) {
     if (!p) return YH_EINVAL;
     if (first < 0 || last > (int)p->ops.size() || first > last) return YH_ERANGE;
+    hipStream_t main_s = (hipStream_t)stream;
+    bool side_used = false;
     for (int i = first; i < last; ++i) {
         const Op& op = p->ops[i];
         AnyDesc d = op.d;
@@ -203,10 +235,49 @@ extern "C" int yh_plan_run_range(yh_plan* p, int first, int last, void* stream) 
             void* v = (char*)base + f.byte_offset;
             memcpy((char*)&d + f.field_offset, &v, sizeof(void*));
         }
-        if (p->timing) (void)hipEventRecord(p->events[2 * i], (hipStream_t)stream);
-        const int rc = launch(op.kind, d, stream);
-        if (p->timing) (void)hipEventRecord(p->events[2 * i + 1], (hipStream_t)stream);
+        hipStream_t s = main_s;
+        if (op.lane == 1) {
+            if (!p->side) {
+                const hipError_t e = hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking);
+                if (e != hipSuccess) return (int)e;
+            }
+            s = p->side;
+            side_used = true;
+        }
+        for (int dep : op.deps) {
+            // dependencies reaching into an earlier range are already satisfied: every range joins its lanes before returning
+            if (dep < first || p->ops[dep].lane == op.lane) continue;
+            const hipError_t e = hipStreamWaitEvent(s, p->done[dep], 0);
+            if (e != hipSuccess) return (int)e;
+        }
+        if (p->timing) (void)hipEventRecord(p->events[2 * i], s);
+        const int rc = launch(op.kind, d, s);
+        if (p->timing) (void)hipEventRecord(p->events[2 * i + 1], s);
         if (rc != YH_OK) return rc;
+        if (op.has_dependents) {
+            if (p->done.size() < p->ops.size()) {
+                try {
+                    p->done.resize(p->ops.size(), nullptr);
+                } catch (...) {
+                    return YH_ENOMEM;
+                }
+            }
+            if (!p->done[i]) {
+                const hipError_t e = hipEventCreateWithFlags(&p->done[i], hipEventDisableTiming);
+                if (e != hipSuccess) return (int)e;
+            }
+            const hipError_t e = hipEventRecord(p->done[i], s);
+            if (e != hipSuccess) return (int)e;
+        }
+    }
+    if (side_used) {   // join: whatever follows on the caller's stream sees the side lane's results
+        if (!p->join) {
+            const hipError_t e = hipEventCreateWithFlags(&p->join, hipEventDisableTiming);
+            if (e != hipSuccess) return (int)e;
+        }
+        hipError_t e = hipEventRecord(p->join, p->side);
+        if (e == hipSuccess) e = hipStreamWaitEvent(main_s, p->join, 0);
+        if (e != hipSuccess) return (int)e;
     }
     return YH_OK;
 }

@@ -285,6 +285,8 @@ _SIGNATURES = {
     'yh_plan_num_ops': (C.c_int, [_vp]),
     'yh_plan_run': (C.c_int, [_vp, _vp]),
     'yh_plan_run_range': (C.c_int, [_vp, C.c_int, C.c_int, _vp]),
+    'yh_plan_set_lane': (C.c_int, [_vp, C.c_int, C.c_int]),
+    'yh_plan_add_dep': (C.c_int, [_vp, C.c_int, C.c_int]),
     'yh_plan_set_timing': (C.c_int, [_vp, C.c_int]),
     'yh_plan_get_timings': (C.c_int, [_vp, C.POINTER(C.c_float), C.c_int]),
     'yh_plan_graph_capture': (C.c_int, [_vp, _vp]),

@@ -43,6 +43,7 @@ from .plan import DarknetEngine, ALIGN_C, _round_up
 
 SLOT_INPUT = 0
 SLOT_WS = 1          # shared fp32 workspace of the two-stage reductions
+SLOT_WS2 = 63        # the same for the ops of the side lane (weight gradients): the two lanes run concurrently
 SLOT_HEAD0 = 2       # forward: head output tensors; backward: head gradient tensors (fp32 NHWC)
 LINEAR = hiplib.ACT_CODES['linear']
 
@@ -180,7 +181,7 @@ class TrainEngine(DarknetEngine):
         self._check_supported(values)
         self._place(values)
         lib, dev, P = self.lib, self.device, hiplib.ptr
-        plan = dict(values=values, heads=heads, N=N, storages=[], fwd_ops=[], bwd_ops=[], zero_list=[], ws_floats=0)
+        plan = dict(values=values, heads=heads, N=N, storages=[], fwd_ops=[], bwd_ops=[], zero_list=[], ws_floats=0, ws2_floats=0)
         fwd = plan['fwd'] = lib.yh_plan_create()
         bwd = plan['bwd'] = lib.yh_plan_create()
         if not fwd or not bwd:
@@ -199,16 +200,18 @@ class TrainEngine(DarknetEngine):
         def fixup(handle, op, desc_type, field, slot):
             hiplib.check(lib.yh_plan_add_fixup(handle, op, getattr(desc_type, field).offset, slot, 0), 'fixup')
 
-        def add_reduction(handle, log, desc, what):
-            """Reductions get the shared workspace (bound to SLOT_WS at run time) sized by the library's own query."""
+        def add_reduction(handle, log, desc, what, side=False):
+            """Reductions get the shared workspace (bound to SLOT_WS at run time) sized by the library's own query; ops of the
+            side lane have their own (SLOT_WS2)."""
             query = lib.yh_conv2d_wgrad_workspace if isinstance(desc, WgradDesc) and not isinstance(desc, StemWgradDesc) \
                 else lib.yh_bn_reduce_workspace
             need = int(query(C.byref(desc)))
             desc.ws_floats = need
-            plan['ws_floats'] = max(plan['ws_floats'], need)
+            key = 'ws2_floats' if side else 'ws_floats'
+            plan[key] = max(plan[key], need)
             op = add(handle, log, desc, what)
             if need:
-                fixup(handle, op, type(desc), 'ws', SLOT_WS)
+                fixup(handle, op, type(desc), 'ws', SLOT_WS2 if side else SLOT_WS)
             return op
 
         def alloc(shape, fp32=False, zero=False):
@@ -333,7 +336,36 @@ class TrainEngine(DarknetEngine):
         zero_bias = alloc((max([_round_up(v.src.c_phys, 128) for v in values if v.kind == 'conv' and v.src.kind != 'input']
                                + [128]),), fp32=True, zero=True)
         dz_elems = max(N * v.Ho * v.Wo * v.c_phys for v in values if v.kind in ('conv', 'dw'))
-        dz_scratch = alloc((dz_elems,))
+        # Two lanes in the backward plan (include/yolo_hip.h yh_plan_set_lane), OFF by default: the weight gradient of a layer only
+        # feeds the optimizer, so it can run on the plan's side stream, issued after the layer's data gradient, while the main chain
+        # goes on with the HBM-bound BatchNorm backward passes of the next layer.  What the two lanes share is the dz scratch
+        # (written by a layer's BN-backward apply pass, read by its weight AND data gradient): two buffers alternate, and the writer
+        # of a buffer waits for the weight gradient that read it two layers earlier (the host emulation replays the latest schedule
+        # these dependencies allow, tests/test_train_emulated.py).  Measured on the MI355X (YOLOv3-608 b64 fp16): 63.3 vs 63.8 ms
+        # per step - the two kernels do not co-reside (a weight-gradient workgroup pair holds the whole vector register file of its
+        # CU), they time-slice: every kernel takes about twice as long while the other lane is busy.  YOLO_HIP_WGRAD_LANE=1 enables.
+        two_lanes = os.environ.get('YOLO_HIP_WGRAD_LANE', '0') == '1'
+        dz_bufs = [alloc((dz_elems,)) for _ in range(2 if two_lanes else 1)]
+        dz_state = dict(k=0, reader=[None] * len(dz_bufs))
+
+        def next_dz():
+            dz_state['k'] = (dz_state['k'] + 1) % len(dz_bufs)
+            return dz_state['k']
+
+        def dz_written_by(op, k):
+            """op is the first writer of dz buffer k for a new layer: it must not overtake the side-lane reader of the old contents."""
+            r = dz_state['reader'][k]
+            if r is not None:
+                hiplib.check(lib.yh_plan_add_dep(bwd, op, r), 'yh_plan_add_dep')
+                dz_state['reader'][k] = None
+
+        def on_side_lane(op, k):
+            """op (a weight gradient reading dz buffer k) runs on the side lane, after everything emitted so far on the main lane."""
+            if not two_lanes:
+                return
+            hiplib.check(lib.yh_plan_set_lane(bwd, op, 1), 'yh_plan_set_lane')
+            hiplib.check(lib.yh_plan_add_dep(bwd, op, op - 1), 'yh_plan_add_dep')
+            dz_state['reader'][k] = op
         head_index = {id(h.src): k for k, h in enumerate(heads)}
 
         raw, n_items = self._pack_items(plan)
@@ -530,7 +562,8 @@ class TrainEngine(DarknetEngine):
                 if v.plain:
                     dzp, lddz = dyp, lddy
                 else:
-                    dzp, lddz = P(dz_scratch), v.c_phys
+                    kz = next_dz()
+                    dzp, lddz = P(dz_bufs[kz]), v.c_phys
                     base, bnp = v.bn_args
                     if v.bn is not None:
                         acc = dict(bnp, sum=grads.ptr(v.g_beta), sumsq=grads.ptr(v.g_gamma))
@@ -538,7 +571,8 @@ class TrainEngine(DarknetEngine):
                         acc = dict(sum=grads.ptr(v.g_b if v.g_b is not None else self._junk(plan, grads, v.c_phys)),
                                    sumsq=grads.ptr(self._junk(plan, grads, v.c_phys)))
                     add_reduction(bwd, plan['bwd_ops'], BnBwdReduceDesc(**base, **acc, dy=dyp, lddy=lddy), 'dbn%d' % v.block)
-                    add(bwd, plan['bwd_ops'], BnBwdApplyDesc(**base, **acc, dy=dyp, lddy=lddy, out=dzp, ldo=v.c_phys), 'dbnx%d' % v.block)
+                    op = add(bwd, plan['bwd_ops'], BnBwdApplyDesc(**base, **acc, dy=dyp, lddy=lddy, out=dzp, ldo=v.c_phys), 'dbnx%d' % v.block)
+                    dz_written_by(op, kz)
                 geo = dict(n=N, h=s.H, w_in=s.W, c=v.c_phys, ho=v.H, wo=v.W, k=v.k, stride=v.stride, pad=v.pad, ldx=s.ld, lddz=lddz,
                            dtype=self.code)
                 add(bwd, plan['bwd_ops'], DwWgradDesc(x=P(s.storage, s.c_off), dz=dzp, dw=grads.ptr(v.g_w), lddx=0, accumulate=0, **geo),
@@ -576,11 +610,14 @@ class TrainEngine(DarknetEngine):
                 continue                      # dead branch: its parameters get zero gradients
             s, pk = v.src, v.tpack
             pixels = N * v.Ho * v.Wo
-            dzp, lddz = P(dz_scratch), v.c_phys
+            kz = next_dz()
+            dzp, lddz = P(dz_bufs[kz]), v.c_phys
+            dz_private = True                 # dz is the scratch buffer (False: dz is dy itself, which the main lane may still change)
             if v.fp32:                        # head: fp32 gradient from autograd -> dtype
                 op = add(bwd, plan['bwd_ops'], CastDesc(x=None, y=dzp, pixels=pixels, c=v.c_phys, ldx=v.c_phys, ldy=v.c_phys,
                                                         dtype=self.code), 'dhead%d' % v.block)
                 fixup(bwd, op, CastDesc, 'x', SLOT_HEAD0 + head_index[id(v)])
+                dz_written_by(op, kz)
                 if v.g_b is not None:         # bias gradient = sum over pixels of dz
                     add_reduction(bwd, plan['bwd_ops'],
                         BnBwdReduceDesc(z=dzp, dy=dzp, pixels=pixels, n=N, h=v.Ho, w_in=v.Wo, c=v.c_phys, ldz=v.c_phys,
@@ -608,6 +645,7 @@ class TrainEngine(DarknetEngine):
                         contribute(t, dyp, lddy, None, 'dres%d' % v.block)
                 if v.plain:                   # no BN, linear: dz is dy itself
                     dzp, lddz = dyp, lddy
+                    dz_private = False
                     if v.g_b is not None:
                         add_reduction(bwd, plan['bwd_ops'],
                             BnBwdReduceDesc(z=dyp, dy=dyp, pixels=pixels, n=N, h=v.Ho, w_in=v.Wo, c=v.c_phys, ldz=lddy,
@@ -622,8 +660,9 @@ class TrainEngine(DarknetEngine):
                         acc = dict(sum=grads.ptr(v.g_b if v.g_b is not None else self._junk(plan, grads, v.c_phys)),
                                    sumsq=grads.ptr(self._junk(plan, grads, v.c_phys)))
                     add_reduction(bwd, plan['bwd_ops'], BnBwdReduceDesc(**base, **acc, dy=dyp, lddy=lddy), 'dbn%d' % v.block)
-                    add(bwd, plan['bwd_ops'], BnBwdApplyDesc(**base, **acc, dy=dyp, lddy=lddy, out=dzp, ldo=v.c_phys),
-                        'dbnx%d' % v.block)
+                    op = add(bwd, plan['bwd_ops'], BnBwdApplyDesc(**base, **acc, dy=dyp, lddy=lddy, out=dzp, ldo=v.c_phys),
+                             'dbnx%d' % v.block)
+                    dz_written_by(op, kz)
             # weight gradient
             if s.kind == 'input':
                 # the image as NHWC dtype with 8 channels (3..7 zero): the first layer then uses the MFMA wgrad kernel
@@ -631,16 +670,27 @@ class TrainEngine(DarknetEngine):
                 op = add(bwd, plan['bwd_ops'], LayoutDesc(x=None, y=P(img), n=N, c=s.C, h=s.H, w_in=s.W, c_pad=ALIGN_C, ldy=ALIGN_C,
                                                           dtype=self.code), 'image%d' % v.block)
                 fixup(bwd, op, LayoutDesc, 'x', SLOT_INPUT)
-                add_reduction(bwd, plan['bwd_ops'],
-                              WgradDesc(x=P(img), dz=dzp, dw=grads.ptr(v.g_w), n=N, h=s.H, w_in=s.W, cin=ALIGN_C, ho=v.Ho, wo=v.Wo,
-                                        cout=v.C, kh=v.k, kw=v.k, stride=v.stride, pad=v.pad, ldx=ALIGN_C, lddz=lddz,
-                                        dtype=self.code, splits=0, cin_w=s.C), 'wgrad%d' % v.block)
+                side = two_lanes and dz_private
+                op = add_reduction(bwd, plan['bwd_ops'],
+                                   WgradDesc(x=P(img), dz=dzp, dw=grads.ptr(v.g_w), n=N, h=s.H, w_in=s.W, cin=ALIGN_C, ho=v.Ho, wo=v.Wo,
+                                             cout=v.C, kh=v.k, kw=v.k, stride=v.stride, pad=v.pad, ldx=ALIGN_C, lddz=lddz,
+                                             dtype=self.code, splits=0, cin_w=s.C), 'wgrad%d' % v.block, side=side)
+                if side:
+                    on_side_lane(op, kz)
                 continue
-            add_reduction(bwd, plan['bwd_ops'],
-                WgradDesc(x=P(s.storage, s.c_off), dz=dzp, dw=grads.ptr(v.g_w), n=N, h=s.H, w_in=s.W, cin=s.C, ho=v.Ho,
-                          wo=v.Wo, cout=v.C, kh=v.k, kw=v.k, stride=v.stride, pad=v.pad, ldx=s.ld, lddz=lddz, dtype=self.code,
-                          splits=0), 'wgrad%d' % v.block)
-            # data gradient into grad(src)
+            side = two_lanes and dz_private
+
+            def emit_wgrad(v=v, s=s, dzp=dzp, lddz=lddz, kz=kz, side=side):
+                op = add_reduction(bwd, plan['bwd_ops'],
+                                   WgradDesc(x=P(s.storage, s.c_off), dz=dzp, dw=grads.ptr(v.g_w), n=N, h=s.H, w_in=s.W, cin=s.C, ho=v.Ho,
+                                             wo=v.Wo, cout=v.C, kh=v.k, kw=v.k, stride=v.stride, pad=v.pad, ldx=s.ld, lddz=lddz,
+                                             dtype=self.code, splits=0), 'wgrad%d' % v.block, side=side)
+                if side:
+                    on_side_lane(op, kz)
+            if not side:
+                emit_wgrad()
+            # data gradient into grad(src).  With two lanes the weight gradient is issued AFTER it and waits for it: two MFMA-bound
+            # kernels gain nothing from sharing the CUs, the pairing that pays is weight gradient x the next layer's BatchNorm passes
             mode = contribution_mode(s, True)
             common = dict(bias=P(zero_bias), n=N, cin=v.c_phys, cout=s.c_phys, stride=1, ldx=lddz, ldr=s.ld if mode == 'acc' else 0,
                           ldy=s.ld, cin_k=pk['cout_k'], m_pad=pk['dm_pad'], act=LINEAR, slope=0.0, out_f32=0, dtype=self.code,
@@ -668,11 +718,15 @@ class TrainEngine(DarknetEngine):
                 add(bwd, plan['bwd_ops'],
                     ConvDesc(x=dzp, w=P(pk['wt']), res=gptr(s) if mode == 'acc' else None, y=gptr(s), h=v.Ho, w_in=v.Wo, ho=s.H,
                              wo=s.W, kh=v.k, kw=v.k, pad=v.k - 1 - v.pad, ups=1, **common), 'dgrad%d' % v.block)
+            if side:
+                emit_wgrad()
         plan['head_shapes'] = [(N, h.src.H, h.src.W, h.src.c_phys) for h in heads]
         plan['segments'] = self._make_segments(plan, values, heads, bwd_pos)
         plan['ws'] = alloc((max(plan['ws_floats'], 4),), fp32=True)
+        plan['ws2'] = alloc((max(plan['ws2_floats'], 4),), fp32=True)
         for handle in (fwd, bwd):
             lib.yh_plan_bind_slot(handle, SLOT_WS, plan['ws'].data_ptr())
+        lib.yh_plan_bind_slot(bwd, SLOT_WS2, plan['ws2'].data_ptr())
         return plan
 
     @staticmethod
