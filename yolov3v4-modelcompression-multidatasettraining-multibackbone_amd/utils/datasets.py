@@ -299,7 +299,8 @@ class MosaicBatch:
     DataLoader's pin-memory thread through ``pin_memory()``, uploaded with one copy) plus the per-item geometry."""
 
     def __init__(self, items):
-        self.items = list(items)
+        import copy
+        self.items = [copy.copy(it) for it in items]      # the caller's items keep their crops
         sizes = [(0 if p[0] is None else p[0].size) for it in self.items for p in it.parts]
         self.offsets = np.concatenate([[0], np.cumsum([(n + 15) // 16 * 16 for n in sizes])]).astype(np.int64)
         self.blob = torch.empty(int(self.offsets[-1]) + 16, dtype=torch.uint8)
@@ -310,9 +311,9 @@ class MosaicBatch:
             for crop, rect, corner in it.parts:
                 if crop is not None:
                     flat[self.offsets[k]:self.offsets[k] + crop.size] = crop.reshape(-1)
-                parts.append((None if crop is None else crop.shape[:2], rect, corner))
+                parts.append((None if crop is None else tuple(crop.shape[:2]), rect, corner))
                 k += 1
-            it.parts = parts          # shapes only from here on: the pixels live in the blob
+            it.parts = parts          # shapes only: the pixels live in the blob
 
     def pin_memory(self):
         self.blob = self.blob.pin_memory()
