@@ -102,7 +102,7 @@ def test_cfg_lowers_into_the_hip_training_step(rel):
     make_train_engine(model, 'fp32', x, lib=fakelib.FakeLib())
 
 
-@pytest.mark.parametrize('rel', TRAIN_STEP_SUBSET)
+@pytest.mark.parametrize('rel', _cases() if os.environ.get('YOLO_TEST_ALL_CFGS_TRAIN') == '1' else TRAIN_STEP_SUBSET)
 def test_cfg_trains_like_eager_autograd(rel):
     """One forward + backward of the lowered step (host emulation of the C ABI) against eager autograd on the same modules.
 
@@ -111,7 +111,8 @@ def test_cfg_trains_like_eager_autograd(rel):
     by 1e-3 .. 1e-2; eager fp32 against eager fp64 jumps the same way on most samples.  So the GRAPH lowering (routes, shortcuts,
     padded layouts, depthwise, squeeze-excite, gray stem) is checked on the cfg with its kinked activations swapped for Mish -
     there the step agrees with fp64 autograd as closely as fp32 autograd does (~2e-5) - and the original cfg gets the bound that
-    still catches a wrong gradient path (those are O(1) on the parameters they touch)."""
+    still catches a wrong gradient path (those are O(1) on the parameters they touch).  Five families by default; all 39 cfgs
+    with YOLO_TEST_ALL_CFGS_TRAIN=1 (3 minutes; the table of that run is profiles/r02_train_lowering_sweep.txt)."""
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     import copy
     import train_harness as th
