@@ -140,3 +140,38 @@ def test_cfg_trains_like_eager_autograd(rel):
         for (k, a), (_, b) in zip(m.state_dict().items(), m_ref.state_dict().items()):
             if 'running' in k:
                 assert (a - b).abs().max().item() <= 1e-5 * (b.abs().max().item() + 1), k
+
+
+# ------------------------------------------------------------------------------------------------- the int8 eval graph (rows Q / Q2)
+INT8_NOT_LOWERED = ('yolov3-ghostnet/', 'yolov3-mobilenet/', 'yolov3tiny-mobilenet-small/')   # depthwise / squeeze-excite on int8 grids
+
+
+@pytest.mark.parametrize('rel', _cases())
+def test_cfg_int8_lowering_is_bit_exact(rel):
+    """COS-PTQ eval graph of every runnable cfg (synthetic power-of-two state, tools/synthetic_ptq.py; dyadic frames so that the
+    fp32 first layer is exact in any order): the int8 plan replayed through the host emulation equals the eager modules - which
+    equal the reference's (tests/test_ptq_large.py, test_ptq_calibration.py) - bit for bit on the raw heads.  Covers the quantised
+    concat's side effect (quantized_ptq_cos.py:1531-1545 re-quantises the cached outputs IN PLACE: in yolov4-tiny block 23 feeds
+    two routes and the second one sees the first one's coarser grid).  The Mobilenet / GhostNet families raise: no depthwise /
+    squeeze-excite kernels on int8 grids yet."""
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import synth
+    from tools.synthetic_ptq import fill_synthetic_state, measure_ranges
+    kw = {'is_gray_scale': True} if 'singlechannel' in rel else {}
+    cfg = os.path.join(ROOT, rel)
+    torch.manual_seed(0)
+    fm = models.Darknet(cfg, (64, 64), verbose=False, **kw)
+    _randomize_bn(fm, 1)
+    x = synth.dyadic_frames(torch.rand(2, 1 if kw else 3, 64, 64, generator=torch.Generator().manual_seed(4)))
+    torch.manual_seed(0)
+    qm = models.Darknet(cfg, (64, 64), quantized=3, a_bit=8, w_bit=8, shortcut_way=1, **kw)
+    fill_synthetic_state(fm, qm, ranges=measure_ranges(fm, x))
+    if rel.startswith(INT8_NOT_LOWERED):
+        with pytest.raises(NotImplementedError):
+            DarknetEngine(qm, precision='int8', lib=fakelib.FakeLib())(x)
+        return
+    with torch.no_grad():
+        inf, raws, _ = qm(x)
+    io, raws_e, _ = DarknetEngine(qm, precision='int8', lib=fakelib.FakeLib())(x)
+    for a, b in zip(raws, raws_e):
+        assert torch.equal(a, b), 'int8 plan differs from the eager COS-PTQ modules by %.3g' % (a - b).abs().max().item()

@@ -282,6 +282,18 @@ class DarknetEngine:
                             raise RuntimeError('HIP int8 engine: route %d has no calibrated scale' % i)
                     values.append(v)
                     cur = v
+                    if self.q:
+                        # ... and the reference re-quantises the CACHED outputs in place (quantized_ptq_cos.py:1531-1545:
+                        # `outputs[layer] = quantize(outputs[layer])`), so whatever reads block `layer` through `outputs` after
+                        # this route - a later route or shortcut - sees it on THIS concat's grid (yolov4-tiny: block 23 feeds
+                        # the routes 24 and 34).  Later references resolve to the re-quantised slice of the concat buffer.
+                        for l, s_, off_ in zip(layers, srcs, v.offsets):
+                            if s_.scale != v.scale:
+                                j = i + l if l < 0 else l
+                                sl = Value('slice', s_.C, s_.H, s_.W, block=j, src=v, first=off_)
+                                sl.segs, sl.c_phys, sl.scale = list(s_.segs), s_.c_phys, v.scale
+                                values.append(sl)
+                                outs[j] = sl
                 elif getattr(module, 'groups', False):
                     half = cur.C // 2
                     if not cur.is_dense() or half % self.align or (cur.C - half) % self.align:
