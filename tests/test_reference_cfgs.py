@@ -146,8 +146,9 @@ def test_cfg_trains_like_eager_autograd(rel):
 INT8_NOT_LOWERED = ('yolov3-ghostnet/', 'yolov3-mobilenet/', 'yolov3tiny-mobilenet-small/')   # depthwise / squeeze-excite on int8 grids
 
 
+@pytest.mark.parametrize('way', [1, 2], ids=['shortcut_min', 'shortcut_max'])
 @pytest.mark.parametrize('rel', _cases())
-def test_cfg_int8_lowering_is_bit_exact(rel):
+def test_cfg_int8_lowering_is_bit_exact(rel, way):
     """COS-PTQ eval graph of every runnable cfg (synthetic power-of-two state, tools/synthetic_ptq.py; dyadic frames so that the
     fp32 first layer is exact in any order): the int8 plan replayed through the host emulation equals the eager modules - which
     equal the reference's (tests/test_ptq_large.py, test_ptq_calibration.py) - bit for bit on the raw heads.  Covers the quantised
@@ -164,7 +165,7 @@ def test_cfg_int8_lowering_is_bit_exact(rel):
     _randomize_bn(fm, 1)
     x = synth.dyadic_frames(torch.rand(2, 1 if kw else 3, 64, 64, generator=torch.Generator().manual_seed(4)))
     torch.manual_seed(0)
-    qm = models.Darknet(cfg, (64, 64), quantized=3, a_bit=8, w_bit=8, shortcut_way=1, **kw)
+    qm = models.Darknet(cfg, (64, 64), quantized=3, a_bit=8, w_bit=8, shortcut_way=way, **kw)
     fill_synthetic_state(fm, qm, ranges=measure_ranges(fm, x))
     if rel.startswith(INT8_NOT_LOWERED):
         with pytest.raises(NotImplementedError):
