@@ -106,6 +106,13 @@ CONV_CASES = [
     (5, 7, 5, 64, 256, 3, 1, 1, True, 1, False, 41, 0, 0),         # tiny images: many images per tile
     (2, 19, 19, 64, 256, 3, 1, 1, True, 1, False, 42, 0, 0),
     (1, 40, 40, 128, 512, 3, 1, 1, False, 1, False, 42, 0, 0),
+    # LDS-free streaming 1x1 kernel (tile 71): every (16-row groups, K steps) form, pixel / channel tails, channel-slice operands
+    (3, 37, 41, 32, 24, 1, 1, 1, False, 1, False, 71, 0, 0),        # (2, 1), cout tail -> direct stores
+    (2, 45, 45, 64, 64, 1, 1, 5, False, 1, False, 71, 0, 0),        # (4, 2) mish, row stores through LDS
+    (2, 33, 31, 128, 32, 1, 1, 0, False, 1, False, 71, 0, 0),       # (2, 4) linear + conv bias
+    (2, 29, 30, 64, 40, 1, 1, 1, False, 1, False, 71, 32, 24),      # (4, 2) cout 40, x and y are channel slices
+    (2, 29, 30, 32, 128, 1, 1, 1, False, 1, False, 71, 0, 0),       # (8, 1)
+    (1, 20, 20, 64, 255, 1, 1, 0, False, 1, True, 0, 0, 0),         # cout > 128 never takes it (auto)
 ]
 
 
@@ -114,8 +121,8 @@ CONV_CASES = [
 def test_conv_matches_emulation(libs, code, case):
     lib, fake = libs
     N, H, W, cin, cout, k, s, act, use_res, ups, out_f32, tile, xe, ye = case
-    if code == F32 and 61 <= tile <= 69:
-        pytest.skip('the full-line K step kernels are fp16 kernels')
+    if code == F32 and (61 <= tile <= 69 or tile == 71):
+        pytest.skip('the full-line K step kernels and the streaming 1x1 kernel are fp16 / int8 kernels')
     g = torch.Generator().manual_seed(hash(case) % (2 ** 31))
     dt = oh.tdtype(code)
     cin_phys, cout_phys = oh.round_up(cin, 8), oh.round_up(cout, 8)
@@ -304,6 +311,10 @@ QCONV_CASES = [
     (3, 13, 13, 192, 256, 3, 1, 1, 1, False, 26),
     (2, 24, 24, 128, 128, 1, 1, 3, 1, False, 27),
     (1, 10, 10, 512, 1024, 3, 1, 1, 1, False, 25),    # K = 4608: |acc| stays below 2^24
+    (3, 37, 41, 64, 64, 1, 1, 1, 1, False, 71),       # streaming 1x1 kernel: (4, 1), row stores through LDS
+    (2, 33, 31, 128, 32, 1, 1, 5, 1, False, 71),      # (2, 2) mish
+    (2, 29, 30, 64, 112, 1, 1, 0, 1, True, 71),       # (8, 1) dequantised fp32 output
+    (2, 29, 30, 128, 48, 1, 1, 1, 1, False, 71),      # (4, 2), cout 48
 ]
 
 

@@ -26,6 +26,7 @@ struct ConvArgs {
     float* stats_part;   // training forward: per (pixel tile, wave column) partial sums of y and y^2 per channel, or NULL
     int y_h, y_w, y_off_h, y_off_w;  // ups == 3: output pixel (n, ho, wo) is stored at (n, 2 ho + y_off_h, 2 wo + y_off_w) of a y_h x y_w tensor
     float q_rx, q_ra, q_scale_x, q_scale_a, q_inv_scale_sum;   // int8 + res: fused quantised shortcut (yh_qadd arithmetic)
+    int no_lds_store;    // conv_pointwise.hip A/B switch: direct 4-channel stores instead of row stores through LDS
 };
 
 template <int CTRL> __device__ __forceinline__ float dpp_shr_add(float v) {
@@ -442,5 +443,6 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, AccT (&acc)[TM]
 
 // conv_igemm_k64.hip: full-line K step kernels (tile codes 61 - 63); f16 and int8, OutT by out_f32
 int launch_k64_tile(const ConvArgs& a, int tile, int dtype, int out_f32, hipStream_t stream);
+int launch_pointwise_tile(const ConvArgs& a, int dtype, int out_f32, hipStream_t stream);   // conv_pointwise.hip, tile code 71
 
 }  // namespace yh

@@ -944,9 +944,25 @@ static bool pick_halo_tile(const yh_conv_desc* d) {
     return d->cin >= 128 && d->cin % 32 == 0 && d->w_in >= 48 && d->w_in <= 96 && (long)d->n * d->h * d->w_in >= 131072;
 }
 
+// The LDS-free streaming kernel (conv_pointwise.hip) for 1x1 convolutions over few channels on large grids, where a ring-kernel
+// tile lives for one or two K steps: whole-K weights in registers, (MT, KS) = (16-row channel groups, MFMA K steps) within its
+// register budget, plain dense store without residual / statistics / upsample.
+static bool pick_pointwise_tile(const yh_conv_desc* d) {
+    static const bool off = getenv("YH_NO_POINTWISE") != nullptr;
+    if (off || (d->dtype != YH_F16 && d->dtype != YH_I8)) return false;
+    if (d->kh != 1 || d->kw != 1 || d->stride != 1 || d->pad != 0 || d->ups != 1 || d->res || d->stats_ws) return false;
+    if (d->act != YH_ACT_LINEAR && d->act != YH_ACT_LEAKY && d->act != YH_ACT_MISH) return false;
+    const int k = d->dtype == YH_I8 ? 64 : 32;
+    if (d->cin != d->cin_k || d->cin_k % k || d->cout > 128) return false;
+    const int mt = d->cout <= 32 ? 2 : (d->cout <= 64 ? 4 : 8), ks = d->cin_k / k;
+    if (!((mt == 2 && (ks == 1 || ks == 2 || ks == 4)) || (mt == 4 && (ks == 1 || ks == 2)) || (mt == 8 && ks == 1))) return false;
+    return (long)d->n * d->ho * d->wo >= 262144;     // the high-resolution stages; smaller grids keep the ring kernels
+}
+
 extern "C" int yh_conv2d_tile(const yh_conv_desc* d) {
     if (!d) return YH_EINVAL;
     if (d->tile != 0) return d->tile;
+    if (pick_pointwise_tile(d)) return 71;
     if (pick_halo_tile(d)) return 41;
     if (const int pp = pick_pp_tile(d)) return pp;
     const int t = yh::pick_tile(d->cout, (long)d->n * d->ho * d->wo, d->cin_k, d->dtype == YH_F16 ? 8 : 4, d->kh * d->kw);
@@ -1026,6 +1042,7 @@ extern "C" int yh_conv2d_fwd(const yh_conv_desc* d, void* stream) {
     a.act = d->act; a.slope = d->slope; a.ups = d->ups;
     a.y_h = d->y_h; a.y_w = d->y_w; a.y_off_h = d->y_off_h; a.y_off_w = d->y_off_w;
     a.q_rx = d->q_rx; a.q_ra = d->q_ra; a.q_scale_x = d->q_scale_x; a.q_scale_a = d->q_scale_a; a.q_inv_scale_sum = d->q_inv_scale_sum;
+    a.no_lds_store = getenv("YH_PW_DIRECT") != nullptr;
     a.stats_part = nullptr;
     if (d->stats_ws) {
         // fused BatchNorm statistics: plain dense output only, and never on the halo kernels
@@ -1039,6 +1056,12 @@ extern "C" int yh_conv2d_fwd(const yh_conv_desc* d, void* stream) {
     if (tile == 0) {
         tile = yh_conv2d_tile(d);
         if (d->ups == 4 && !(tile >= 21 && tile <= 35)) tile = 24;   // only the LDS-DMA ring kernels are used for the four-phase scatter
+    }
+    if (tile == 71) {
+        // explicit requests are validated like the automatic choice (the kernel has no residual / statistics / upsample forms)
+        if (d->kh != 1 || d->kw != 1 || d->stride != 1 || d->pad != 0 || d->ups != 1 || d->res || d->stats_ws || d->cin != d->cin_k ||
+            d->cout > 128 || d->dtype == YH_F32) return YH_EUNSUPPORTED;
+        return launch_pointwise_tile(a, d->dtype, d->out_f32, s);
     }
     if (d->dtype == YH_F16) {
         return d->out_f32 ? dispatch_tile<f16, float>(a, tile, s) : dispatch_tile<f16, f16>(a, tile, s);
