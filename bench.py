@@ -53,6 +53,19 @@ TILE_NAMES = {1: '128x128', 2: '64x256', 3: '32x256', 4: '64x128', 5: '128x64', 
               66: 'pp_512x128', 67: 'pp2_256x256', 68: 'pp2_128x512', 69: 'pp2_512x128', 71: 'pw_stream'}
 
 
+def model_label(cfg, size):
+    """'YOLOv3-608' for cfg/yolov3/yolov3.cfg at 608: the label follows --cfg / --size, whatever they are."""
+    base = os.path.splitext(os.path.basename(cfg))[0]
+    pretty = {'yolov3': 'YOLOv3', 'yolov4': 'YOLOv4', 'yolov3-tiny': 'YOLOv3-tiny', 'yolov4-tiny': 'YOLOv4-tiny',
+              'yolov3-mobilenet-coco': 'YOLOv3-Mobilenetv3', 'yolov3-spp': 'YOLOv3-SPP'}.get(base, base)
+    return '%s-%d' % (pretty, size)
+
+
+def model_family(cfg):
+    base = os.path.splitext(os.path.basename(cfg))[0]
+    return {'yolov3': 'YOLOv3 Darknet-53', 'yolov4': 'YOLOv4 CSPDarknet53 + Mish + SPP/PAN'}.get(base, base)
+
+
 def build_model(cfg, size, precision, device):
     import models
     torch.manual_seed(0)
@@ -69,7 +82,7 @@ def build_model(cfg, size, precision, device):
     return model.to(device).eval()
 
 
-def build_qmodel_synthetic(cfg, size, device):
+def build_qmodel_synthetic(cfg, size, device, float_model=None):
     """A COS-PTQ graph (Darknet(quantized=3)) with a synthetic calibrated state, for int8 *timing* only.
 
     Weight/bias grids come from the BN-folded seeded float weights with power-of-two max-abs scales; every
@@ -78,7 +91,7 @@ def build_qmodel_synthetic(cfg, size, device):
     tests/test_ptq.py and tests/test_ptq_calibration.py).  Only the HIP int8 engine is timed."""
     import models
     from tools.synthetic_ptq import fill_synthetic_state
-    fm = build_model(cfg, size, 'fp16', 'cpu')
+    fm = float_model.cpu() if float_model is not None else build_model(cfg, size, 'fp16', 'cpu')
     torch.manual_seed(0)
     qm = models.Darknet(cfg, (size, size), quantized=3, a_bit=8, w_bit=8, shortcut_way=1)
     fill_synthetic_state(fm, qm)
@@ -179,9 +192,7 @@ def cpu_baseline(cfg, size, budget_s):
     m = models.Darknet(cfg, (size, size)).eval()
     state = m.state_dict()
     x = torch.rand(1, 3, size, size)
-    # one thread per physical core up to 64: batch-1 oneDNN convolutions get slower, not faster, when every
-    # SMT sibling of a 2-socket host joins in (measured: 256 threads -> 80 s/image on the GPU node)
-    torch.set_num_threads(max(1, min((os.cpu_count() or 2) // 2, 64)))
+    torch.set_num_threads(os.cpu_count() or 1)   # every host core
     with torch.no_grad():
         oracle.forward(m.module_defs, state, x)  # warm-up (page-in, thread pool)
         n, t0 = 0, time.perf_counter()
@@ -192,7 +203,8 @@ def cpu_baseline(cfg, size, budget_s):
             if dt >= budget_s or n >= 64:
                 break
     return dict(value=round(n / dt, 3), unit='images/s', cores=torch.get_num_threads(), kind='port',
-                sample='%d images of YOLOv3-%d, batch 1, fp32, oracle.forward (BN folded), %.1f s' % (n, size, dt))
+                sample='%d images of %s, batch 1, fp32, oracle.forward (BN folded), %.1f s on %d of %d host CPUs'
+                       % (n, model_label(cfg, size), dt, torch.get_num_threads(), os.cpu_count() or 1))
 
 
 HYP = {'giou': 3.54, 'cls': 37.4, 'cls_pw': 1.0, 'obj': 64.3, 'obj_pw': 1.0, 'iou_t': 0.20, 'lr0': 0.01, 'momentum': 0.937,
@@ -281,21 +293,22 @@ def train_main(args, device, dist, world, rank, local_rank):
         peak = PEAK_TFLOPS[args.precision]
         net = value / world * gflop_img / 1e3
         out = {
-            'metric': 'images/sec YOLOv3-608 train %s' % args.precision, 'value': round(value, 2), 'unit': 'images/s',
+            'metric': 'images/sec %s train %s' % (model_label(args.cfg, args.size), args.precision), 'value': round(value, 2), 'unit': 'images/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(elapsed / args.steps * 1e3, 3),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': {'fp16': 'f16', 'fp32': 'f32'}[args.precision], 'data': 'synthetic',
-            'config': {'workload': 'YOLOv3 Darknet-53 %d COCO (80 classes) %s training step, batch %d/GPU: train-mode forward '
+            'config': {'workload': '%s %d COCO (80 classes) %s training step, batch %d/GPU: train-mode forward '
                                    '(batch-stat BN) + compute_loss + backward + nesterov SGD, %s'
-                                   % (args.size, args.precision, args.batch,
-                                      'DDP gradient all-reduce over RCCL' if world > 1 else 'single GPU'),
+                                   % (model_family(args.cfg), args.size, args.precision, args.batch,
+                                      ('DDP gradient all-reduce over %s' % ('RCCL' if args.dist_backend == 'nccl' else 'gloo (host memory)'))
+                                      if world > 1 else 'single GPU'),
                        'global_batch': world * args.batch, 'parallelism': 'dp%d' % world, 'gflop_per_image': round(gflop_img, 2),
                        'loss': [round(float(v), 4) for v in state['loss']]},
             'roofline_net': {'bound': 'mfma', 'achieved': round(net, 2), 'peak': peak, 'unit': 'TFLOP/s',
                              'frac': round(net / peak, 4), 'per': 'GPU, whole step incl. loss, optimizer and host gaps'},
         }
         out['roofline'] = train_roofline(eng, x, args.precision)
-        out['cpu_baseline'] = None if (world > 1 or args.no_cpu_baseline) else cpu_train_baseline(args.cfg, args.cpu_seconds)
+        out['cpu_baseline'] = None if (world > 1 or args.no_cpu_baseline) else cpu_train_baseline(args.cfg, args.cpu_seconds, args.size)
     else:
         out = None
     distutil.barrier(dist)
@@ -362,42 +375,50 @@ def train_roofline(eng, x, precision):
             'by_kernel': table, 'by_role_ms': {k: round(v[0], 3) for k, v in sorted(roles.items(), key=lambda kv: -kv[1][0])}}
 
 
-def cpu_train_baseline(cfg, budget_s):
-    """Eager fp32 training step of the same cfg on the host cores (this package's eager modules, bit-equal to the reference's)."""
+def cpu_train_baseline(cfg, budget_s, size=608):
+    """Eager fp32 training step of the same cfg on ALL host cores (this package's eager modules, bit-equal to the reference's;
+    BASELINE.md 3: torch.set_num_threads(os.cpu_count()), batch 2, per image).  The first step (thread-pool start, page-in)
+    is a warm-up unless it alone exhausts the budget."""
     from models import Darknet
     from utils.utils import compute_loss
-    torch.set_num_threads(min(64, max(1, (os.cpu_count() or 2) // 2)))
+    torch.set_num_threads(os.cpu_count() or 1)
     torch.manual_seed(0)
-    size = 608
     model = Darknet(cfg, (size, size)).train()
     model.nc, model.hyp, model.gr = 80, HYP, 1.0
     x = torch.rand(2, 3, size, size)
     targets = synthetic_labels(2, 8, 80, 7, 'cpu')
     opt = torch.optim.SGD(model.parameters(), lr=HYP['lr0'] * 0.01, momentum=HYP['momentum'], nesterov=True)
-    t0, n = time.time(), 0
-    while True:
+    def one():
         pred, _ = model(x)
         loss, _ = compute_loss(pred, targets, model)
         opt.zero_grad()
         loss.backward()
         opt.step()
-        n += 2
-        dt = time.time() - t0
-        if dt >= budget_s or n >= 32:
-            break
+
+    t0 = time.time()
+    one()
+    warm = time.time() - t0
+    n, dt = 2, warm
+    if warm < budget_s:      # otherwise the warm-up step IS the bounded sample
+        t0, n = time.time(), 0
+        while True:
+            one()
+            n += 2
+            dt = time.time() - t0
+            if dt >= budget_s or n >= 32:
+                break
     return dict(value=round(n / dt, 3), unit='images/s', cores=torch.get_num_threads(), kind='port',
-                sample='%d images of YOLOv3-608, batch 2, fp32 eager forward + loss + backward + SGD step, %.1f s' % (n, dt))
+                sample='%d images of %s, batch 2, fp32 eager forward + loss + backward + SGD step, %.1f s on %d of %d host CPUs'
+                       % (n, model_label(cfg, size), dt, torch.get_num_threads(), os.cpu_count() or 1))
 
 
 def self_launch(n):
     """Re-run this command as `n` ranks under torch.distributed.run on this node; returns the launcher's exit code."""
-    import socket
     import subprocess
-    with socket.socket() as sk:
-        sk.bind(('127.0.0.1', 0))
-        port = sk.getsockname()[1]
-    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=%d' % n, '--master-addr', '127.0.0.1',
-           '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    # c10d rendezvous on 127.0.0.1 with port 0: the launcher's store binds a free port itself and hands it to the ranks as
+    # MASTER_PORT (no bind-then-close probe that another process could race for)
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=%d' % n, '--rdzv-backend', 'c10d',
+           '--rdzv-endpoint', '127.0.0.1:0', '--local-addr', '127.0.0.1', os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ, OMP_NUM_THREADS=os.environ.get('OMP_NUM_THREADS', '8'))
     return subprocess.call(cmd, env=env)
 
@@ -438,6 +459,9 @@ def main():
                     help='train: forward + loss + backward + SGD step (BASELINE metric "train fp16", configs[2] at N GPUs); '
                          'detect: forward + NMS (configs[1]); both (default): train is the headline value, detect rides along')
     ap.add_argument('--no-nms', action='store_true')
+    ap.add_argument('--raw-heads', action='store_true', help='keep the random head weights (no NMS candidates at conf 0.3): forward-only timing')
+    ap.add_argument('--nms-candidates', type=int, default=100, help='objectness candidates per image the synthetic heads are calibrated to')
+    ap.add_argument('--no-v4', action='store_true', help='skip the YOLOv4-640 fp16 / int8 rider legs of the default run')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=12.0)
     ap.add_argument('--grad-compress', default='none', choices=['none', 'fp16'],
@@ -500,44 +524,106 @@ def main():
                 dist.destroy_process_group()
             return
     if args.mode in ('detect', 'both'):
-        try:
-            det = detect_main(args, device, dist, world, rank, cpu_baseline_leg=(args.mode == 'detect'))
-        except Exception as e:   # the rider must not take the headline line down with it
-            if args.mode == 'detect' or out is None and rank == 0 and world == 1:
-                raise
-            det = None
+        keys = ('metric', 'value', 'unit', 'ms_per_step', 'dtype', 'config', 'roofline_net', 'roofline', 'nms')
+
+        def rider(name, rargs):
+            """A detection leg that rides on the headline line; detect_main raises on every rank together, so catching here
+            keeps the ranks in step."""
+            try:
+                d = detect_main(rargs, device, dist, world, rank, cpu_baseline_leg=False)
+                if rank == 0 and d is not None:
+                    out[name] = {k: d[k] for k in keys if k in d}
+            except Exception as e:   # noqa: BLE001 - the rider must not take the headline line down with it
+                if rank == 0:
+                    out[name + '_error'] = '%s: %s' % (type(e).__name__, str(e)[:300])
+
+        if args.mode == 'detect':
+            det = detect_main(args, device, dist, world, rank, cpu_baseline_leg=True)
             if rank == 0:
-                out['detect_error'] = '%s: %s' % (type(e).__name__, e)
-        if rank == 0 and det is not None:
-            if out is None:
                 out = det
-            else:   # the second headline metric of BASELINE.json, measured in the same run
-                out['detect'] = {k: det[k] for k in ('metric', 'value', 'unit', 'ms_per_step', 'dtype', 'config', 'roofline_net', 'roofline')}
-        if args.mode == 'both' and args.precision == 'fp16' and (out is not None or rank != 0):
-            # third headline metric ("detect int8 FPS"): the COS-PTQ graph on the MFMA-i8 engine, same frames, same NMS
+        else:
+            rider('detect', args)      # the second headline metric of BASELINE.json, measured in the same run
+        if args.mode == 'both' and args.precision == 'fp16':
             import copy
+            # third headline metric ("detect int8 FPS"): the COS-PTQ graph on the MFMA-i8 engine, same frames, same NMS
             iargs = copy.copy(args)
             iargs.precision = 'int8'
-            try:
-                det8 = detect_main(iargs, device, dist, world, rank, cpu_baseline_leg=False)
-                if rank == 0 and det8 is not None:
-                    out['detect_int8'] = {k: det8[k] for k in ('metric', 'value', 'unit', 'ms_per_step', 'dtype', 'config', 'roofline_net', 'roofline')}
-            except Exception as e:
-                if rank == 0:
-                    out['detect_int8_error'] = '%s: %s' % (type(e).__name__, e)
+            rider('detect_int8', iargs)
+            if not args.no_v4 and os.path.basename(args.cfg) == 'yolov3.cfg':
+                # BASELINE.json configs[3]: YOLOv4 640 (CSPDarknet53 + Mish + SPP/PAN) on the int8 PTQ path, batch 32, with its
+                # fp16 twin beside it
+                for prec, name in (('fp16', 'detect_v4_640'), ('int8', 'detect_int8_v4_640')):
+                    vargs = copy.copy(args)
+                    vargs.cfg = os.path.join(PKG, 'cfg', 'yolov4', 'yolov4.cfg')
+                    vargs.size, vargs.batch, vargs.precision = 640, min(args.batch, 32), prec
+                    rider(name, vargs)
     if rank == 0:
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
 
 
-def detect_main(args, device, dist, world, rank, cpu_baseline_leg=True):
-    """configs[1]: forward + NMS on a resident synthetic batch; returns the JSON dict on rank 0 (None elsewhere)."""
+def all_ranks_ok(ok, dist, device):
+    """True on every rank only if ``ok`` is true on every rank (one MIN all-reduce; no-op for a single process)."""
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return bool(ok)
+    t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return bool(int(t.item()))
+
+
+def nms_leg(inf, steps):
+    """NMS alone on one decoded batch (HIP events on the launch stream): ms per call, candidates and survivors per image."""
+    from engine import hiplib
     from utils.utils import non_max_suppression
-    model = build_qmodel_synthetic(args.cfg, args.size, device) if args.precision == 'int8' else \
-        build_model(args.cfg, args.size, args.precision, device)
+    lib = hiplib.load()
+    n, rows, no = inf.shape
+    count = torch.zeros(n, dtype=torch.int32, device=inf.device)
+    hiplib.check(lib.yh_nms_candidates(hiplib.ptr(inf), n, rows, no - 5, 0.3, 0, None, None, hiplib.ptr(count), 0,
+                                       hiplib.stream_ptr()), 'nms count')
+    det = non_max_suppression(inf, conf_thres=0.3, iou_thres=0.6, multi_label=False)   # also warms the candidate bound
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    for _ in range(steps):
+        non_max_suppression(inf, conf_thres=0.3, iou_thres=0.6, multi_label=False)
+    e1.record()
+    torch.cuda.synchronize()
+    wall = (time.perf_counter() - t0) / steps * 1e3
+    kept = [0 if d is None else int(d.shape[0]) for d in det]
+    return {'ms_per_call': round(wall, 4), 'gpu_ms_per_call': round(e0.elapsed_time(e1) / steps, 4),
+            'candidates_per_image': round(float(count.float().mean()), 1), 'max_candidates': int(count.max()),
+            'detections_per_image': round(sum(kept) / max(len(kept), 1), 1), 'settings': 'conf 0.3, iou 0.6, best class, merge'}
+
+
+def detect_main(args, device, dist, world, rank, cpu_baseline_leg=True):
+    """configs[1] / configs[3]: forward + NMS on a resident synthetic batch; returns the JSON dict on rank 0 (None elsewhere).
+
+    The model build (the step that can fail: lowering, memory) happens before any collective and is agreed on by all ranks, so
+    a rank that fails raises on EVERY rank instead of leaving the others in the timed region's barrier."""
+    from utils.utils import non_max_suppression
+    from tools.synthetic_heads import detector_like_heads_
     g = torch.Generator().manual_seed(100 + rank)
     x = torch.rand(args.batch, 3, args.size, args.size, generator=g).to(device)  # resident in HBM before timing
+    model, heads, err = None, None, None
+    try:
+        # a random-weight detector hands NMS nothing at conf 0.3: give the three head convs a trained head's statistics
+        # (tools/synthetic_heads.py; every other layer untouched), measured on the first frames of the bench batch
+        fm = build_model(args.cfg, args.size, 'fp16' if args.precision == 'int8' else args.precision, device)
+        if not args.raw_heads:
+            heads = detector_like_heads_(fm, x[:min(8, args.batch)], per_image=args.nms_candidates)
+        if args.precision == 'int8':
+            model = build_qmodel_synthetic(args.cfg, args.size, device, float_model=fm)
+        else:
+            model = fm
+        del fm
+        with torch.no_grad():
+            model(x)                      # builds the plan: lowering errors surface here
+        torch.cuda.synchronize()
+    except Exception as e:                # noqa: BLE001 - reported, then raised on every rank together
+        err = e
+    if not all_ranks_ok(err is None, dist, device):
+        raise err if err is not None else RuntimeError('detect leg failed on another rank')
 
     def step():
         with torch.no_grad():
@@ -546,10 +632,6 @@ def detect_main(args, device, dist, world, rank, cpu_baseline_leg=True):
             non_max_suppression(inf, conf_thres=0.3, iou_thres=0.6, multi_label=False)
 
     from engine import distutil
-
-    def barrier():
-        distutil.barrier(dist)
-
     for _ in range(args.warmup):
         step()
     # barrier + synchronize on both sides of exactly K steps; MAX over ranks (engine/distutil.py)
@@ -562,19 +644,27 @@ def detect_main(args, device, dist, world, rank, cpu_baseline_leg=True):
         gflop_img = sum(flops.values()) / args.batch / 1e9
         peak = PEAK_TFLOPS[args.precision]
         net_tflops = value / world * gflop_img / 1e3
+        label = model_label(args.cfg, args.size)
         out = {
-            'metric': 'images/sec YOLOv3-608 detect %s (forward + NMS)' % args.precision, 'value': round(value, 2), 'unit': 'images/s',
+            'metric': 'images/sec %s detect %s (%s)' % (label, args.precision, 'forward only' if args.no_nms else 'forward + NMS'),
+            'value': round(value, 2), 'unit': 'images/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(elapsed / args.steps * 1e3, 4),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': {'fp16': 'f16', 'fp32': 'f32', 'int8': 'i8'}[args.precision], 'data': 'synthetic',
-            'config': {'workload': 'YOLOv3 Darknet-53 %d COCO (80 classes) %s inference, batch %d/GPU, %s'
-                                   % (args.size, args.precision, args.batch,
+            'config': {'workload': '%s %d COCO (80 classes) %s inference, batch %d/GPU, %s'
+                                   % (model_family(args.cfg), args.size, args.precision, args.batch,
                                       'forward only' if args.no_nms else 'forward + NMS conf 0.3 iou 0.6'),
                        'global_batch': world * args.batch, 'parallelism': 'replicas x%d' % world,
-                       'gflop_per_image': round(gflop_img, 3)},
+                       'gflop_per_image': round(gflop_img, 3),
+                       'heads': 'random weights, default head bias (NMS sees no candidates)' if heads is None else
+                                dict(heads, note='head convs rescaled to a trained detector\'s objectness statistics, tools/synthetic_heads.py')},
             'roofline_net': {'bound': 'mfma', 'achieved': round(net_tflops, 2), 'peak': peak, 'unit': 'TFLOP/s',
                              'frac': round(net_tflops / peak, 4), 'per': 'GPU, whole step incl. NMS and host gaps'},
         }
+        if not args.no_nms:
+            with torch.no_grad():
+                inf, _, _ = model(x)
+            out['nms'] = nms_leg(inf, max(3, min(args.steps, 10)))
         out['roofline'] = roofline_leg(model, x, max(3, min(args.steps, 10)), args.precision)
         if world == 1 and not args.no_cpu_baseline and cpu_baseline_leg:
             out['cpu_baseline'] = cpu_baseline(args.cfg, args.size, args.cpu_seconds)
@@ -582,7 +672,7 @@ def detect_main(args, device, dist, world, rank, cpu_baseline_leg=True):
             out['cpu_baseline'] = None
     else:
         out = None
-    barrier()
+    distutil.barrier(dist)
     del model
     torch.cuda.empty_cache()
     return out

@@ -105,3 +105,93 @@ def test_two_rank_ddp_training_step_averages_hip_path_gradients():
         assert np.array_equal(g0[k], g1[k]), 'ranks disagree on %s after the all-reduce' % k
         mean = (l0[k] + l1[k]) / 2
         assert np.abs(g0[k] - mean).max() <= 1e-5 * (np.abs(mean).max() + 1e-12), k
+
+
+# ------------------------------------------------- the wrapper bench.py builds (bucket views, fp16 compression, overlap)
+def _ddp_bench_worker(rank, world, port, cfg_path, out):
+    """DDP exactly as bench.py:train_main builds it - gradient_as_bucket_view=True, a bucket cap that splits the gradients over
+    several buckets, torch's fp16 compression hook - over the chain of `_HipTrainSegment` autograd nodes, and a log of WHEN each
+    bucket's all-reduce is launched relative to the backward ranges (reference train.py:99-107,218-223 relies on DDP's default
+    overlap of bucket all-reduces with the rest of backward)."""
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, here)
+    import conftest  # noqa: F401
+    import fakelib
+    import synth
+    import train_harness as th
+    from engine.train import TrainEngine
+    from torch.distributed.algorithms.ddp_comm_hooks import default_hooks
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      YOLO_HIP_TRAIN_SEGMENTS='4', YOLO_HIP_TRAIN_PRECISION='fp32')
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    model = th.build(cfg_path, 64)
+    eng = TrainEngine(model, 'fp32', lib=fakelib.FakeLib())
+    model.__dict__['_hip_train_engine'] = eng
+    events = []
+    inner = eng.backward_segment
+
+    def logged_segment(k, head_grads):
+        events.append(('range_start', k))
+        res = inner(k, head_grads)
+        events.append(('range_done', k))
+        return res
+    eng.backward_segment = logged_segment
+    ddp = torch.nn.parallel.DistributedDataParallel(model, bucket_cap_mb=0.02, gradient_as_bucket_view=True)
+
+    def hook(state, bucket):
+        events.append(('bucket', bucket.index(), sum(g.numel() for g in bucket.gradients())))
+        return default_hooks.fp16_compress_hook(state, bucket)
+    ddp.register_comm_hook(None, hook)
+    model._use_hip_train = lambda inp: True
+    x = synth.image_batch(2, 64, seed=20 + rank)
+    for step in range(2):      # DDP rebuilds its buckets in gradient-ready order after the first step; check the steady state
+        del events[:]
+        for p in model.parameters():
+            p.grad = None
+        raws, _ = ddp(x)
+        ws = th.loss_weights(raws, seed=5)
+        th.toy_loss(raws, ws).backward()
+    grads = {k: p.grad.clone() for k, p in model.named_parameters()}
+    plan = eng._current
+    out.put((rank, list(events), len(plan['segments']), {k: v.numpy() for k, v in grads.items()}))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_ddp_as_bench_builds_it_launches_buckets_while_backward_is_still_running():
+    import numpy as np
+    import conftest
+    import train_harness as th
+    os.environ['PYTHONPATH'] = os.pathsep.join([conftest.PKG, conftest.REPO, os.environ.get('PYTHONPATH', '')])
+    cfg_path = th.write_cfg(th.mini_cfg_text())
+    ctx = mp.get_context('spawn')
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_ddp_bench_worker, args=(r, 2, port, cfg_path, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((out.get(timeout=300) for _ in procs), key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    os.unlink(cfg_path)
+    (_, ev0, nseg, g0), (_, ev1, _, g1) = res
+    for k in g0:     # fp16-compressed all-reduce: both ranks end with the same averaged gradients
+        assert np.array_equal(g0[k], g1[k]), k
+        assert np.isfinite(g0[k]).all()
+    assert nseg >= 3, 'the mini net must split into several backward ranges for this test to mean anything'
+    for ev in (ev0, ev1):
+        buckets = [i for i, e in enumerate(ev) if e[0] == 'bucket']
+        ranges_done = {e[1]: i for i, e in enumerate(ev) if e[0] == 'range_done'}
+        starts = {e[1]: i for i, e in enumerate(ev) if e[0] == 'range_start'}
+        assert len(buckets) >= 3, 'bucket cap must split the gradients: %s' % ev
+        # backward ranges run last -> first (range nseg-1 holds the heads' side of the net)
+        assert [e[1] for e in ev if e[0] == 'range_start'] == list(range(nseg - 1, -1, -1))
+        # overlap: the first bucket is launched before the LAST range (range 0) has even started, and every range but the
+        # last has had at least one bucket launched by the time the next one starts
+        assert buckets[0] < starts[0], 'no bucket was launched before the final backward range started: %s' % ev
+        launched_before_last = sum(1 for b in buckets if b < starts[0])
+        assert launched_before_last >= len(buckets) // 2, 'most buckets must be in flight while range 0 is still to run: %s' % ev
+        assert max(buckets) > ranges_done[0] or buckets[-1] > starts[0], 'the last bucket closes after the last range'

@@ -119,6 +119,30 @@ def test_synthetic_map_protocol(rel, size, batch, conditioning, precision, cfg_d
         'synthetic mAP@0.5 = %.4f vs %.4f (reference vs itself) / %.4f (perfect)' % (score, self_score, perfect)
 
 
+@pytest.mark.parametrize('rel,size', [('yolov3tiny/yolov3-tiny-hand.cfg', 416), ('yolov3/yolov3.cfg', 320)])
+def test_test_time_augmentation_on_the_hip_path(rel, size, cfg_dir):
+    """`model(x, augment=True)` (reference models.py:477-506: original + flipped 0.83x + 0.67x passes, de-augmented and
+    concatenated) with a CUDA tensor: three HIP plans of three input shapes, against the eager CPU modules (bit-equal to
+    the reference's, tests/test_reference_cfgs.py) on the same frames.  The scaled frames come from `F.interpolate` on the
+    GPU resp. the CPU (a few fp32 ulps apart), hence 2e-3 px instead of the 1e-3 of the plain forward."""
+    model = build_mirror(cfg_dir, rel, size)
+    x = synth.image_batch(2, size, seed=5)
+    with torch.no_grad():
+        want, none_ = model(x, augment=True)
+    assert none_ is None
+    model.cuda()
+    model.hip_precision = 'fp32'
+    with torch.no_grad():
+        got, none_ = model(x.cuda(), augment=True)
+    torch.cuda.synchronize()
+    eng = model.__dict__['_hip_engine']
+    assert eng is not None and len(eng._plans) == 3, 'one HIP plan per augmented input shape'
+    assert none_ is None and got.shape == want.shape
+    d = (got.cpu() - want).abs()
+    assert d[..., :4].max().item() <= 2e-3, 'TTA box drift %g px' % d[..., :4].max().item()
+    assert d[..., 4:].max().item() <= 2e-5, 'TTA conf drift %g' % d[..., 4:].max().item()
+
+
 def test_properties_at_baseline_size(cfg_dir):
     """YOLOv3-608 fp16: determinism and batch-permutation equivariance (no oracle needed at this size)."""
     model = build_mirror(cfg_dir, 'yolov3/yolov3.cfg', 608).cuda()

@@ -116,3 +116,27 @@ def test_reference_layer_prune_runs_unmodified(tmp_path, tiny_cfg, dataset_dir):
                                   '--img-size', '64', '--batch-size', '4'], tmp_path)
     assert 'Compact model has been saved' in out
     _check_outputs(tmp_path, model, 'layer_prune', 'layer_prune')
+
+
+def test_reference_ptq_runs_unmodified(tmp_path, tiny_cfg, dataset_dir):
+    """The reference's PTQ.py (PTQ.py:12-131), unmodified: float evaluation through this package's test.test, COS-PTQ calibration
+    by train-mode forwards of Darknet(quantized=3) (this package's utils/quantized/quantized_ptq_cos.py behind the reference's
+    class names), evaluation of the quantised graph, weights/PTQ.pt.  Its star imports (`from models import *`,
+    `from utils.datasets import *`, `from utils.utils import *`) must hand it every name it uses."""
+    model, cfg, wfile = _prepare(tmp_path, tiny_cfg, seed=4)
+    (tmp_path / 'data').mkdir()
+    (tmp_path / 'data' / 'synth.data').write_text((dataset_dir / 'synth.data').read_text())
+    out = _run('PTQ.py', ['--cfg', cfg, '--data', 'data/synth.data', '--weights', wfile, '--img-size', '64', '--batch-size', '4',
+                          '--device', 'cpu'], tmp_path)
+    assert 'test original model' in out and 'test quantized model' in out
+    saved = tmp_path / 'weights' / 'PTQ.pt'
+    assert saved.is_file()
+    import models
+    state = torch.load(str(saved), map_location='cpu', weights_only=False)['model']
+    q = models.Darknet(str(tmp_path / cfg), (64, 64), quantized=3, a_bit=8, w_bit=8, shortcut_way=1)
+    q.load_state_dict(state)
+    scales = {k: float(v) for k, v in state.items() if k.endswith('activation_quantizer.scale')}
+    assert scales and all(s > 0 for s in scales.values()), 'every activation quantiser settled on a scale'
+    with torch.no_grad():
+        inf, _, _ = q.eval()(torch.rand(1, 3, 64, 64))
+    assert torch.isfinite(inf).all()

@@ -365,6 +365,57 @@ def test_two_sgd_steps_on_an_odd_width_graph_track_eager():
         os.unlink(path)
 
 
+def test_gray_scale_odd_width_graph_trains_through_the_padded_twin():
+    """A slim-pruned single-channel net: the twin must be built gray-scale too (first conv reads ONE image channel); with a
+    3-channel twin the stem weight image, the layout descriptor and the first conv's gradient map would disagree."""
+    import models
+    from engine.padded import PaddedTrainEngine
+    text = _pruned_like_cfg_text().replace('channels=3', 'channels=1').replace('activation=leaky', 'activation=linear')
+    path = th.write_cfg(text)
+    try:
+        torch.manual_seed(0)
+        model = models.Darknet(path, (64, 64), is_gray_scale=True)
+        state = model.state_dict()
+        synth.randomize_bn_(state, seed=1)
+        model.load_state_dict(state)
+        model.train()
+        assert model.module_list[0][0].in_channels == 1
+        x = torch.rand(3, 1, 64, 64, generator=torch.Generator().manual_seed(3))
+        raws_ref, grads_ref, _, ws = th.eager_step(model, x)
+        raws, grads, m = th.engine_step(model, x, ws, 'fp32', lib=fakelib.FakeLib())
+        eng = m.__dict__['_hip_train_engine']
+        assert isinstance(eng, PaddedTrainEngine)
+        assert eng.pad.twin.is_gray_scale and eng.pad.twin.module_list[0][0].in_channels == 1
+        for a, b in zip(raws, raws_ref):
+            assert (a - b).abs().max().item() <= 2e-5 * b.abs().max().item()
+        assert_grads_close(grads, grads_ref, 5e-5)
+    finally:
+        os.unlink(path)
+
+
+def test_live_running_statistics_edited_between_steps_reach_the_padded_twin():
+    """DDP's broadcast_buffers (ranks > 0) and scripts that reset running_mean edit the LIVE buffers in place between steps;
+    the twin must start the next step from them instead of overwriting them with its own copy."""
+    from engine.padded import make_train_engine
+    path = th.write_cfg(_pruned_like_cfg_text())
+    try:
+        model = th.build(path, 64)
+        x = synth.image_batch(3, 64, seed=0)
+        model.__dict__['_hip_train_engine'] = make_train_engine(model, 'fp32', x, lib=fakelib.FakeLib())
+        model._forward_hip_train(x)
+        bn = model.module_list[0][1]
+        with torch.no_grad():
+            bn.running_mean.fill_(7.0)
+            bn.running_var.fill_(3.0)
+        ref_mean = 0.9 * bn.running_mean.clone()
+        model._forward_hip_train(x)
+        # new = 0.9 * edited + 0.1 * batch statistic: with the edit reverted it would sit near 0.1 * batch, far from 6.3
+        assert (bn.running_mean - ref_mean).abs().max().item() < 0.5
+        assert bn.running_var.min().item() > 2.0
+    finally:
+        os.unlink(path)
+
+
 def _ghost_like_text(second_join=False):
     c = lambda f, k, s: th._CONV % (f, k, s, 'leaky')
     text = ('[net]\nbatch=1\nwidth=32\nheight=32\nchannels=3\n\n' + c(24, 3, 1) + c(12, 1, 1) + c(12, 3, 1) + '[route]\nlayers = -1, -2\n\n'

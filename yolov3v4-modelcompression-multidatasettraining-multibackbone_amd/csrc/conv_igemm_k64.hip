@@ -474,12 +474,20 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_pp_kernel(const ConvArgs a)
 #endif
 }
 
+// The ping-pong kernels pack (hi, wi) into 16 signed bits each and (pp2) keep 32-bit element offsets: images below 32k pixels a
+// side, both operands below 2^31 elements (the far corner of the last tap of the last pixel included).  Checked by every launcher,
+// so an explicit tile code cannot reach the kernels with a tensor the automatic choice (pick_pp_tile) would have refused.
+static bool pp_offsets_fit(const ConvArgs& a) {
+    if (a.H >= 32768 || a.W >= 32768) return false;
+    return (long)a.N * a.H * a.W * a.ldx + (long)(a.R + 1) * a.W * a.ldx < 0x7fffffffL && (long)a.m_pad * a.ktot < 0x7fffffffL;
+}
+
 template <typename T, typename OutT, int WM, int WN>
 static int launch_pp(const ConvArgs& a0, hipStream_t stream) {
     constexpr int BM = WM * 128, BN = WN * 64;
     ConvArgs a = a0;
     if (a.cin_k % (Prec<T>::VEC * 8)) return YH_EALIGN;
-    if (a.H >= 32768 || a.W >= 32768) return YH_EUNSUPPORTED;
+    if (!pp_offsets_fit(a)) return YH_EUNSUPPORTED;
     a.m_tiles = (a.Cout + BM - 1) / BM;
     a.p_tiles = (int)((a.P + BN - 1) / BN);
     const long blocks = (long)a.m_tiles * a.p_tiles;
@@ -747,9 +755,7 @@ static int launch_pp2(const ConvArgs& a0, hipStream_t stream) {
     constexpr int BM = WM * 128, BN = WN * 64;
     ConvArgs a = a0;
     if (a.cin_k % (Prec<T>::VEC * 8)) return YH_EALIGN;
-    if (a.H >= 32768 || a.W >= 32768) return YH_EUNSUPPORTED;
-    // 32-bit element offsets inside the kernel (the far corner of the last tap of the last pixel included)
-    if ((long)a.N * a.H * a.W * a.ldx + (long)(a.R + 1) * a.W * a.ldx >= 0x7fffffffL || (long)a.m_pad * a.ktot >= 0x7fffffffL) return YH_EUNSUPPORTED;
+    if (!pp_offsets_fit(a)) return YH_EUNSUPPORTED;
     a.m_tiles = (a.Cout + BM - 1) / BM;
     a.p_tiles = (int)((a.P + BN - 1) / BN);
     const long blocks = (long)a.m_tiles * a.p_tiles;

@@ -1,18 +1,30 @@
 """Batched NMS on the HIP kernels of ``csrc/nms.hip`` (reference: utils/utils.py:782-860).
 
-Two host synchronisations are inherent to the reference's contract (a Python list of variable-length
-tensors): one to size the candidate buffers, one to learn how many boxes survived.
+The reference's contract is a Python list of variable-length tensors, so ONE device-to-host read is inherent (how many boxes
+survived per image).  The candidate buffers are therefore sized by an upper bound (a power of two that only grows, remembered per
+input shape) instead of by a first read-back of the exact counts; every kernel takes the per-image counts from device memory.
+The single read returns candidate counts and survivor counts together; only when an image had more candidates than the bound
+the pass is repeated with an exact bound (a second read, first call on a new workload at most).
 """
 import torch
 
 from . import hiplib
 
 MERGE_LO, MERGE_HI = 1, 3000  # merge-NMS applies for 1 < n < 3000 (utils.py:845)
+_CAP_MIN = 256
+_cap_hint = {}                # (n, rows, multi_label) -> candidate bound that sufficed so far
 
 
 def non_max_suppression(prediction, conf_thres=0.1, iou_thres=0.6, multi_label=True, classes=None, agnostic=False):
     with hiplib.on_device(prediction):
         return _non_max_suppression(prediction, conf_thres, iou_thres, multi_label, classes, agnostic)
+
+
+def _pow2_at_least(v):
+    c = _CAP_MIN
+    while c < v:
+        c *= 2
+    return c
 
 
 def _non_max_suppression(prediction, conf_thres, iou_thres, multi_label, classes, agnostic):
@@ -31,35 +43,37 @@ def _non_max_suppression(prediction, conf_thres, iou_thres, multi_label, classes
         cmask = torch.zeros(nc, dtype=torch.uint8, device=dev)
         cmask[torch.as_tensor(list(classes), dtype=torch.long, device=dev)] = 1
     ml = 1 if (multi_label and nc > 1) else 0
-
-    count = torch.zeros(n, dtype=torch.int32, device=dev)
-    hiplib.check(lib.yh_nms_candidates(P(pred), n, rows, nc, conf_thres, ml, P(cmask), None, P(count), 0, S), 'nms count')
-    counts = count.cpu()
-    mmax = int(counts.max())
+    most = rows * (nc if ml else 1)           # no image can emit more candidates than this
+    hint_key = (n, rows, ml)
+    cap = min(_cap_hint.get(hint_key, _CAP_MIN), _pow2_at_least(most))
+    ag = 1 if agnostic else 0
+    while True:
+        words = (cap + 63) // 64
+        counts = torch.zeros((2, n), dtype=torch.int32, device=dev)     # row 0: candidates per image, row 1: survivors
+        count, n_keep = counts[0], counts[1]
+        cand = torch.empty((n, cap, 8), dtype=torch.float32, device=dev)
+        hiplib.check(lib.yh_nms_candidates(P(pred), n, rows, nc, conf_thres, ml, P(cmask), P(cand), P(count), cap, S), 'nms cand')
+        srt = torch.empty_like(cand)
+        hiplib.check(lib.yh_nms_sort(P(cand), P(count), n, cap, cap, P(srt), S), 'nms sort')
+        mask = torch.empty((n, cap, words), dtype=torch.int64, device=dev)
+        hiplib.check(lib.yh_nms_mask(P(srt), P(count), n, cap, cap, iou_thres, ag, P(mask), S), 'nms mask')
+        keep_idx = torch.empty((n, cap), dtype=torch.int32, device=dev)
+        hiplib.check(lib.yh_nms_reduce(P(mask), P(count), n, cap, cap, P(keep_idx), P(n_keep), S), 'nms reduce')
+        res = torch.empty((n, cap, 6), dtype=torch.float32, device=dev)
+        hiplib.check(lib.yh_nms_merge(P(srt), P(count), P(keep_idx), P(n_keep), n, cap, cap, iou_thres, ag,
+                                      MERGE_LO, MERGE_HI, P(res), S), 'nms merge')
+        host = counts.cpu()                    # the one device-to-host read of the call
+        mmax = int(host[0].max())
+        if mmax <= cap:
+            break
+        cap = _pow2_at_least(mmax)             # an image overflowed the bound: repeat with one that holds every candidate
+    if 2 * mmax > cap:                         # head-room for the next call on this workload
+        _cap_hint[hint_key] = max(_cap_hint.get(hint_key, _CAP_MIN), _pow2_at_least(2 * mmax))
+    else:
+        _cap_hint.setdefault(hint_key, cap)
     out = [None] * n
-    if mmax == 0:
-        return out
-    cap = mmax
-    cand = torch.empty((n, cap, 8), dtype=torch.float32, device=dev)
-    count.zero_()
-    hiplib.check(lib.yh_nms_candidates(P(pred), n, rows, nc, conf_thres, ml, P(cmask), P(cand), P(count), cap, S), 'nms cand')
-    srt = torch.empty_like(cand)
-    hiplib.check(lib.yh_nms_sort(P(cand), P(count), n, cap, mmax, P(srt), S), 'nms sort')
-    words = (mmax + 63) // 64
-    mask = torch.empty((n, mmax, words), dtype=torch.int64, device=dev)
-    hiplib.check(lib.yh_nms_mask(P(srt), P(count), n, cap, mmax, iou_thres, 1 if agnostic else 0, P(mask), S), 'nms mask')
-    keep_idx = torch.empty((n, cap), dtype=torch.int32, device=dev)
-    n_keep = torch.zeros(n, dtype=torch.int32, device=dev)
-    hiplib.check(lib.yh_nms_reduce(P(mask), P(count), n, cap, mmax, P(keep_idx), P(n_keep), S), 'nms reduce')
-    kept = n_keep.cpu()
-    kmax = int(kept.max())
-    if kmax == 0:
-        return out
-    res = torch.empty((n, cap, 6), dtype=torch.float32, device=dev)
-    hiplib.check(lib.yh_nms_merge(P(srt), P(count), P(keep_idx), P(n_keep), n, cap, kmax, iou_thres, 1 if agnostic else 0,
-                                  MERGE_LO, MERGE_HI, P(res), S), 'nms merge')
     for i in range(n):
-        k = int(kept[i])
+        k = int(host[1, i])
         if k > 0:
             out[i] = res[i, :k]
     return out

@@ -152,7 +152,12 @@ class PaddedTwin:
         dev = next(model.parameters()).device
         with torch.random.fork_rng(devices=[]):      # building the twin must not advance the user's RNG stream
             # a list cfg is [hyperparams] + blocks, the form the prune scripts use (slim_prune.py:147-149)
-            twin = models.Darknet([copy.deepcopy(model.hyperparams)] + defs, verbose=False)
+            twin = models.Darknet([copy.deepcopy(model.hyperparams)] + defs, verbose=False,
+                                  is_gray_scale=bool(getattr(model, 'is_gray_scale', False)))
+        first = next(b[0] for b in twin.module_list if isinstance(b, nn.Sequential) and len(b) and isinstance(b[0], nn.Conv2d))
+        if first.in_channels != in_ch:
+            raise NotImplementedError('HIP training path: the padded twin reads %d input channels, the model %d'
+                                      % (first.in_channels, in_ch))
         self.twin = twin.to(dev).train()
         for attr in ('nc', 'hyp', 'gr'):
             if hasattr(model, attr):
@@ -250,10 +255,14 @@ class PaddedTwin:
     # ------------------------------------------------------------------------------------------------ per step
     @torch.no_grad()
     def push(self):
-        """Live parameters -> twin, one gather (pad rows / columns / lanes read the zero slot).  Running statistics were taken over
-        at construction; ``Darknet`` drops the engine whenever they are replaced from outside (load_state_dict, .to(), ...)."""
+        """Live parameters -> twin, one gather (pad rows / columns / lanes read the zero slot); live BatchNorm running
+        statistics -> twin, one scatter, so that in-place edits of the live buffers between steps (DDP's per-forward
+        ``broadcast_buffers`` on ranks > 0, a script resetting ``running_mean``) reach the kernels instead of being reverted by
+        the next ``pull_stats``."""
         torch._foreach_copy_(self.real_views, [p.detach() for p in self.real_params])
         torch.index_select(self.real_flat, 0, self.push_index, out=self.twin_flat)
+        if self.real_bufs:
+            self.buf_flat.index_copy_(0, self.pull_index, torch.cat([b.reshape(-1) for b in self.real_bufs]))
 
     @torch.no_grad()
     def pull_stats(self):
@@ -261,9 +270,9 @@ class PaddedTwin:
             return
         got = torch.index_select(self.buf_flat, 0, self.pull_index)
         torch._foreach_copy_(self.real_bufs, list(torch.split(got, self.pull_sizes)))
-        for rk, tk in self._bn_pairs:
-            if rk.num_batches_tracked is not None:
-                rk.num_batches_tracked.copy_(tk.num_batches_tracked)
+        pairs = [(rk.num_batches_tracked, tk.num_batches_tracked) for rk, tk in self._bn_pairs if rk.num_batches_tracked is not None]
+        if pairs:
+            torch._foreach_copy_([a for a, _ in pairs], [b for _, b in pairs])
 
     def map_grads(self, real_subset, twin_grads):
         """Gradients of the twin parameters of one backward range -> gradients of the matching live parameters."""

@@ -431,8 +431,9 @@ class Darknet(nn.Module):
 
     def _use_hip_train(self, x):
         # training step on the HIP kernels (engine/train.py, engine/padded.py): every float graph on a GPU.  A cfg that path
-        # cannot lower raises - there is no eager fallback.  (YOLO_HIP_TRAIN=0 is a debugging switch.)
-        use = x.is_cuda and self.training and self.quantized == -1 and os.environ.get('YOLO_HIP_TRAIN', '1') != '0'
+        # cannot lower raises - there is no eager fallback and no switch that selects one (tests that want the eager modules
+        # on a GPU call `_forward_eager` themselves).
+        use = x.is_cuda and self.training and self.quantized == -1
         if use and self.__dict__.get('hip_return_features', False):
             raise NotImplementedError('feature_out is not produced by the HIP training step: the feature-distillation losses '
                                       '(reference train.py KDstr 2-5) are out of scope; clear hip_return_features')
