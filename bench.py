@@ -48,9 +48,46 @@ import torch  # noqa: E402
 PEAK_TFLOPS = {'fp16': 2500.0, 'fp32': 157.3, 'int8': 5000.0}  # dense MFMA peaks (int8: TOP/s), MI355X_MICROARCH.md
 TILE_NAMES = {1: '128x128', 2: '64x256', 3: '32x256', 4: '64x128', 5: '128x64', 6: '256x128', 11: '128x128k8', 12: '64x256k8',
               14: '64x128k8', 15: '128x64k8', 16: '256x128k8', 21: 'dma3_128x128', 22: 'dma3_64x256', 24: 'dma3_64x128',
-              25: 'dma3_128x64', 26: 'dma3_256x128', 27: 'dma3_128x256', 41: 'halo_128x256', 51: 'abl_noload', 52: 'abl_nomfma', 42: 'halo_256x256', 31: 'dma4_128x128', 32: 'dma4_64x256', 34: 'dma4_64x128',
+              25: 'dma3_128x64', 26: 'dma3_256x128', 27: 'dma3_128x256', 41: 'halo_128x256', 43: 'hpp_128x512', 51: 'abl_noload', 52: 'abl_nomfma', 42: 'halo_256x256', 31: 'dma4_128x128', 32: 'dma4_64x256', 34: 'dma4_64x128',
               35: 'dma4_128x64', 61: 'k64_256x256', 62: 'k64_128x512', 63: 'k64_256x128w4', 64: 'pp_256x256', 65: 'pp_128x512',
               66: 'pp_512x128', 67: 'pp2_256x256', 68: 'pp2_128x512', 69: 'pp2_512x128', 71: 'pw_stream'}
+
+
+def tile_name(code):
+    return TILE_NAMES.get(code, 'tile%d' % code)
+
+
+def host_threads(budget_s=4.0):
+    """Thread count for the CPU baseline: BASELINE.md 3 asks for every host core, but on the 256-CPU GPU node a training step on all
+    256 threads took 222 s (oneDNN / OpenMP oversubscription behind the container's CPU quota) against 13 s on 64.  So the
+    candidates {all usable CPUs, 1/2, 1/4, 64, 32} are probed with one conv layer each and the FASTEST is used - the best this
+    host can do - with the probe table reported next to the number."""
+    import torch.nn.functional as F
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except AttributeError:
+        usable = os.cpu_count() or 1
+    try:   # cgroup v2 CPU quota
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()
+        if quota != 'max':
+            usable = max(1, min(usable, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    cands = sorted({c for c in (usable, usable // 2, usable // 4, 64, 32) if 1 <= c <= usable}, reverse=True)
+    x = torch.rand(2, 64, 152, 152)
+    w = torch.rand(128, 64, 3, 3)
+    table = {}
+    for c in cands:
+        torch.set_num_threads(c)
+        F.conv2d(x, w, padding=1)
+        n, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < budget_s / len(cands):
+            F.conv2d(x, w, padding=1)
+            n += 1
+        table[c] = round(n / (time.perf_counter() - t0), 1)
+    best = max(table, key=lambda c: table[c])
+    torch.set_num_threads(best)
+    return best, usable, table
 
 
 def model_label(cfg, size):
@@ -82,11 +119,13 @@ def build_model(cfg, size, precision, device):
     return model.to(device).eval()
 
 
-def build_qmodel_synthetic(cfg, size, device, float_model=None):
+def build_qmodel_synthetic(cfg, size, device, float_model=None, frames=None):
     """A COS-PTQ graph (Darknet(quantized=3)) with a synthetic calibrated state, for int8 *timing* only.
 
     Weight/bias grids come from the BN-folded seeded float weights with power-of-two max-abs scales; every
-    activation, shortcut and concat scale is a fixed power of two.  The module classes are this package's
+    activation, shortcut and concat scale is the power of two that just covers the float model's range of that block on
+    `frames` (what a one-batch max-abs calibration would see: a live int8 detector whose heads follow the float model's, so
+    that NMS gets the same kind of candidate set), or a fixed power of two when no frames are given.  The module classes are this package's
     utils/quantized/quantized_ptq_cos.py (same names, buffers and eval arithmetic as the reference's; pinned to it in
     tests/test_ptq.py and tests/test_ptq_calibration.py).  Only the HIP int8 engine is timed."""
     import models
@@ -94,7 +133,11 @@ def build_qmodel_synthetic(cfg, size, device, float_model=None):
     fm = float_model.cpu() if float_model is not None else build_model(cfg, size, 'fp16', 'cpu')
     torch.manual_seed(0)
     qm = models.Darknet(cfg, (size, size), quantized=3, a_bit=8, w_bit=8, shortcut_way=1)
-    fill_synthetic_state(fm, qm)
+    ranges = None
+    if frames is not None:
+        from tools.synthetic_ptq import measure_ranges
+        ranges = measure_ranges(fm, frames.detach().float().cpu())
+    fill_synthetic_state(fm, qm, ranges=ranges)
     return qm.to(device).eval()
 
 
@@ -134,7 +177,7 @@ def roofline_leg(model, x, steps, precision):
     for idx, (what, desc) in enumerate(plan['ops']):
         ms = total[idx] / steps
         if isinstance(desc, hiplib.ConvDesc):
-            name = 'conv_igemm_%s_%s' % (precision, TILE_NAMES[lib.yh_conv2d_tile(C.byref(desc))])
+            name = 'conv_igemm_%s_%s' % (precision, tile_name(lib.yh_conv2d_tile(C.byref(desc))))
         else:
             name = ''.join(c for c in what if not c.isdigit())
         g = groups.setdefault(name, dict(ms=0.0, flops=0.0, launches=0))
@@ -177,11 +220,12 @@ def hbm_traffic(kernel, batch):
 def rocprof_kernel_name(kernel):
     """bench.py's kernel label (conv_igemm_<precision>_<tile name>) -> the name tools/rocprof_summary.py prints for that instantiation."""
     import re
-    m = re.match(r'conv_igemm_(fp16|int8|fp32)_(dma3|halo|pp)_(\d+x\d+)$', kernel)
+    m = re.match(r'conv_igemm_(fp16|int8|fp32)_(dma3|halo|pp|hpp)_(\d+x\d+)$', kernel)
     if not m:
         return None
     t = {'fp16': 'f16', 'int8': 'i8', 'fp32': 'f32'}[m.group(1)]
-    return {'dma3': 'conv_igemm_glds<%s,%s,%s,S3>', 'halo': 'conv3x3_halo<%s,%s,%s>', 'pp': 'conv_igemm_pp<%s,%s,%s>'}[m.group(2)] % (t, t, m.group(3))
+    return {'dma3': 'conv_igemm_glds<%s,%s,%s,S3>', 'halo': 'conv3x3_halo<%s,%s,%s>', 'pp': 'conv_igemm_pp<%s,%s,%s>',
+            'hpp': 'conv3x3_hpp<%s,%s,%s>'}[m.group(2)] % (t, t, m.group(3))
 
 
 def cpu_baseline(cfg, size, budget_s):
@@ -192,7 +236,7 @@ def cpu_baseline(cfg, size, budget_s):
     m = models.Darknet(cfg, (size, size)).eval()
     state = m.state_dict()
     x = torch.rand(1, 3, size, size)
-    torch.set_num_threads(os.cpu_count() or 1)   # every host core
+    threads, usable, probe = host_threads()
     with torch.no_grad():
         oracle.forward(m.module_defs, state, x)  # warm-up (page-in, thread pool)
         n, t0 = 0, time.perf_counter()
@@ -203,8 +247,8 @@ def cpu_baseline(cfg, size, budget_s):
             if dt >= budget_s or n >= 64:
                 break
     return dict(value=round(n / dt, 3), unit='images/s', cores=torch.get_num_threads(), kind='port',
-                sample='%d images of %s, batch 1, fp32, oracle.forward (BN folded), %.1f s on %d of %d host CPUs'
-                       % (n, model_label(cfg, size), dt, torch.get_num_threads(), os.cpu_count() or 1))
+                sample='%d images of %s, batch 1, fp32, oracle.forward (BN folded), %.1f s on %d threads (host: %d CPUs, %d usable; '
+                       'conv probe it/s by thread count %s)' % (n, model_label(cfg, size), dt, threads, os.cpu_count() or 1, usable, probe))
 
 
 HYP = {'giou': 3.54, 'cls': 37.4, 'cls_pw': 1.0, 'obj': 64.3, 'obj_pw': 1.0, 'iou_t': 0.20, 'lr0': 0.01, 'momentum': 0.937,
@@ -342,7 +386,7 @@ def train_roofline(eng, x, precision):
             role = what.rstrip('0123456789')
             # group by KERNEL instantiation: the forward convs and the data gradients share the implicit-GEMM kernels
             if isinstance(desc, hiplib.ConvDesc):
-                name = 'conv_igemm_%s_%s' % (precision, TILE_NAMES.get(lib.yh_conv2d_tile(C.byref(desc)), '?'))
+                name = 'conv_igemm_%s_%s' % (precision, tile_name(lib.yh_conv2d_tile(C.byref(desc))))
             elif role == 'wgrad':
                 name = 'conv_wgrad_dma' if precision == 'fp16' else 'conv_wgrad'
             else:
@@ -376,12 +420,12 @@ def train_roofline(eng, x, precision):
 
 
 def cpu_train_baseline(cfg, budget_s, size=608):
-    """Eager fp32 training step of the same cfg on ALL host cores (this package's eager modules, bit-equal to the reference's;
-    BASELINE.md 3: torch.set_num_threads(os.cpu_count()), batch 2, per image).  The first step (thread-pool start, page-in)
-    is a warm-up unless it alone exhausts the budget."""
+    """Eager fp32 training step of the same cfg on the host cores (this package's eager modules, bit-equal to the reference's;
+    BASELINE.md 3: batch 2, per image; thread count: host_threads()).  The first step (thread-pool start, page-in) is a
+    warm-up unless it alone exhausts the budget."""
     from models import Darknet
     from utils.utils import compute_loss
-    torch.set_num_threads(os.cpu_count() or 1)
+    threads, usable, probe = host_threads()
     torch.manual_seed(0)
     model = Darknet(cfg, (size, size)).train()
     model.nc, model.hyp, model.gr = 80, HYP, 1.0
@@ -408,8 +452,8 @@ def cpu_train_baseline(cfg, budget_s, size=608):
             if dt >= budget_s or n >= 32:
                 break
     return dict(value=round(n / dt, 3), unit='images/s', cores=torch.get_num_threads(), kind='port',
-                sample='%d images of %s, batch 2, fp32 eager forward + loss + backward + SGD step, %.1f s on %d of %d host CPUs'
-                       % (n, model_label(cfg, size), dt, torch.get_num_threads(), os.cpu_count() or 1))
+                sample='%d images of %s, batch 2, fp32 eager forward + loss + backward + SGD step, %.1f s on %d threads (host: %d CPUs, '
+                       '%d usable; conv probe it/s by thread count %s)' % (n, model_label(cfg, size), dt, threads, os.cpu_count() or 1, usable, probe))
 
 
 def self_launch(n):
@@ -611,9 +655,9 @@ def detect_main(args, device, dist, world, rank, cpu_baseline_leg=True):
         # (tools/synthetic_heads.py; every other layer untouched), measured on the first frames of the bench batch
         fm = build_model(args.cfg, args.size, 'fp16' if args.precision == 'int8' else args.precision, device)
         if not args.raw_heads:
-            heads = detector_like_heads_(fm, x[:min(8, args.batch)], per_image=args.nms_candidates)
+            heads = detector_like_heads_(fm, x[:min(16, args.batch)], per_image=args.nms_candidates)
         if args.precision == 'int8':
-            model = build_qmodel_synthetic(args.cfg, args.size, device, float_model=fm)
+            model = build_qmodel_synthetic(args.cfg, args.size, device, float_model=fm, frames=None if args.raw_heads else x[:2])
         else:
             model = fm
         del fm

@@ -135,8 +135,10 @@ def test_test_time_augmentation_on_the_hip_path(rel, size, cfg_dir):
     with torch.no_grad():
         got, none_ = model(x.cuda(), augment=True)
     torch.cuda.synchronize()
+    from utils import torch_utils
+    shapes = {tuple(t.shape) for t in (x, torch_utils.scale_img(x.flip(3), 0.83, same_shape=False), torch_utils.scale_img(x, 0.67, same_shape=False))}
     eng = model.__dict__['_hip_engine']
-    assert eng is not None and len(eng._plans) == 3, 'one HIP plan per augmented input shape'
+    assert eng is not None and len(eng._plans) == len(shapes) >= 2, 'one HIP plan per distinct augmented input shape'
     assert none_ is None and got.shape == want.shape
     d = (got.cpu() - want).abs()
     assert d[..., :4].max().item() <= 2e-3, 'TTA box drift %g px' % d[..., :4].max().item()

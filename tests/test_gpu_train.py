@@ -336,12 +336,16 @@ def test_maxpool_backward_matches_autograd(libs, code, case):
 @pytest.mark.parametrize('code', [F32, F16], ids=['fp32', 'fp16'])
 @pytest.mark.parametrize('case', [(2, 20, 20, 32, 64, 3, 1, 0), (1, 33, 31, 64, 128, 3, 2, 0), (3, 19, 19, 128, 256, 1, 1, 0),
                                   (4, 32, 32, 32, 32, 3, 1, 3), (2, 26, 26, 128, 256, 3, 1, 26), (2, 40, 40, 64, 128, 1, 1, 27),
-                                  (2, 24, 24, 64, 64, 3, 1, 24), (2, 16, 16, 64, 128, 1, 1, 25), (2, 16, 16, 64, 128, 3, 1, 1)],
+                                  (2, 24, 24, 64, 64, 3, 1, 24), (2, 16, 16, 64, 128, 1, 1, 25), (2, 16, 16, 64, 128, 3, 1, 1),
+                                  # halo ping-pong kernel: partial rows per (512 VIRTUAL pixels, wave); padding positions must not count
+                                  (2, 26, 26, 128, 256, 3, 1, 43), (5, 9, 7, 64, 128, 3, 1, 43), (1, 76, 76, 32, 192, 3, 1, 43)],
                          ids=lambda c: 'n%d_%dx%d_c%d-%d_k%ds%d_t%d' % c)
 def test_conv_epilogue_batch_statistics(libs, code, case):
     """Training forward: the conv epilogue's partial sums + yh_bn_finalize(nparts) == statistics of the stored output."""
     lib, _ = libs
     N, H, W, cin, cout, k, s, tile = case
+    if code == F32 and tile == 43:
+        pytest.skip('fp16 / int8 kernel')
     g = torch.Generator().manual_seed(hash(case) % (2 ** 31))
     dt = oh.tdtype(code)
     pad = (k - 1) // 2
@@ -926,3 +930,40 @@ def test_training_forward_has_no_eager_fallback(libs):
     model.hip_return_features = False
     out, feats = model(x)
     assert feats == [] and model.__dict__['_hip_train_engine'] is not None
+
+
+# ------------------------------------------------------------------------- BASELINE config 5 at its real shape
+def test_reference_pruned_mobilenet_fine_tunes_at_416():
+    """The compact graph the reference's UNMODIFIED slim_prune.py --percent 0.5 wrote for yolov3-mobilenet-coco (tools/make_pruned.py;
+    cfg text in tests/golden/) - 70 conv blocks, 37 widths off the 8-channel grid, depthwise + squeeze-excite - trains at 416 px on
+    the HIP path through the channel-padded twin, against eager fp64 autograd (reference slim_prune.py:97-207 -> train.py fine-tune).
+
+    * Mish in place of the kinked activations (same graph, same weights): the lowering must agree with fp64 as closely as eager
+      fp32 autograd does (round-off).
+    * As pruned (relu6 / h-swish / leaky): a pre-activation within rounding distance of a kink lands on either side depending on
+      the summation order; the sample's own kink sensitivity - the change of the fp64 gradient when the frames move by one fp32
+      ulp - bounds what ANY fp32 implementation can promise.  Round 2 saw 8.55e-3 on one sample where eager fp32 had 1.1e-5:
+      that sample's sensitivity is of the same size (profiles/r03_pruned_mobilenet_finetune.txt), i.e. eager was lucky, the
+      twin is not defective."""
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU')
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                    'yolov3v4-modelcompression-multidatasettraining-multibackbone_amd', 'tools'))
+    import pruned_finetune as pf
+    from engine.padded import PaddedTrainEngine
+    size = 416
+    model = pf.build(pf.GOLD_CFG, '', size)
+    widths = [b[0].out_channels for b in model.module_list if isinstance(b, torch.nn.Sequential) and hasattr(b[0], 'out_channels')]
+    assert len(widths) == 70 and sum(1 for c in widths if c % 8) >= 30
+    smooth = pf.smooth_twin(model, pf.GOLD_CFG, size)
+    x = torch.rand(2, 3, size, size, generator=torch.Generator().manual_seed(4))
+    e32, ehip, sens, m = pf.sample_report(smooth, x, 'cuda')
+    assert isinstance(m.__dict__['_hip_train_engine'], PaddedTrainEngine)
+    print('pruned mobilenet 416, Mish twin: eager fp32 %.2e, HIP %.2e, sensitivity %.2e' % (e32, ehip, sens))
+    assert ehip <= 4 * e32 + 2e-5, (e32, ehip)
+    for seed in (4, 6):
+        x = torch.rand(2, 3, size, size, generator=torch.Generator().manual_seed(seed))
+        e32, ehip, sens, _ = pf.sample_report(model, x, 'cuda')
+        print('pruned mobilenet 416, as pruned, sample %d: eager fp32 %.2e, HIP %.2e, fp64 kink sensitivity %.2e' % (seed, e32, ehip, sens))
+        assert ehip <= 4 * max(e32, sens) + 2e-5, (seed, e32, ehip, sens)

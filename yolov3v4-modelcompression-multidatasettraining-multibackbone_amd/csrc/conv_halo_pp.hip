@@ -1,0 +1,446 @@
+// 3x3 / stride 1 / pad 1 convolution, "halo ping-pong" kernel (tile code 43): 128 channels x 512 virtual pixels per workgroup.
+//
+// Why this shape (round-2 measurements): every implicit-GEMM kernel of this library sits on the same wall, ~20 B/clk
+// per CU of global -> LDS delivery.  An im2col tile of BM x BN outputs has to be handed (BM + BN) rows per K step, whatever the
+// schedule does; the 3x3 halo form (conv_igemm.hip, tile 41) fetches the activation rows once per channel chunk instead of once
+// per tap, which leaves the WEIGHT rows as the delivery: at 128 x 256 that is still 11 KB per 512 MFMA cycles = 21 B/clk.  Here
+//   * the pixel tile is 512 wide, so a K step (one tap of one 64-byte channel chunk) needs 8 KB of weights + 1/9 of a
+//     ~43 KB halo image per 1024 MFMA cycles = 12.5 B/clk: below the wall with margin;
+//   * each of the 8 waves owns 128 channels x 64 pixels (12 fragment reads per 32 MFMAs, the ratio of the ping-pong kernels),
+//     every wave reads the whole weight tile;
+//   * the two waves of a SIMD alternate LOAD segments (fragment reads, LDS-DMA issue, counted vmcnt) and 16-MFMA segments
+//     between raw barriers, group 1 one interval behind group 0 - the schedule of conv_igemm_pp_kernel, two phases per K step.
+//
+// Virtual pixel space (one pad column and one pad row are SHARED between neighbours, so only (H+1)(W+1)/(HW) - 1 of the MFMA work
+// is padding: 2.7 % at 76 x 76, 10.8 % at 19 x 19): image n, row y, column x  <->  v = n (H+1)(W+1) + (y+1)(W+1) + (x+1).
+// Column 0 of a row is the zero to the left of x = 0 AND the zero to the right of x = W-1 of the row above; row 0 of an image
+// is its top padding AND the bottom padding of the image before.  Tap (r, s) of output v is input v + (r-1)(W+1) + (s-1): a
+// constant row offset into the staged image, which holds the consecutive inputs [v0 - (W+1) - 1, v0 + 512 + (W+1) + 1).
+//
+// LDS: weights in a 4-stage ring of 128 rows x 64 B (LDS-DMA of step s+3 issued in step s), halo image double-buffered per
+// channel chunk (the next chunk's image is fetched one 16-row piece per wave per tap during taps 0 .. LB-1), rows of 4 cells of
+// 16 B, cell c of row r stored at c ^ (2 * ((r >> 2) & 1)): ds_read_b128 fragment reads are conflict free for ANY row offset
+// (the rows r and r + 4, r + 12 that share an LDS cycle always differ in that bit).
+#include "conv_igemm.h"
+
+namespace yh {
+
+template <typename T> struct HppMma;
+template <> struct HppMma<f16> {
+    typedef f16x8 frag_t;
+    static __device__ __forceinline__ f32x4 mma(const frag_t& a, const frag_t& b, const f32x4& c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+    }
+};
+template <> struct HppMma<int8_t> {
+    typedef i32x4 frag_t;
+    static __device__ __forceinline__ i32x4 mma(const frag_t& a, const frag_t& b, const i32x4& c) {
+        return __builtin_amdgcn_mfma_i32_16x16x64_i8(a, b, c, 0, 0, 0);
+    }
+};
+
+// Epilogue of the 128 x 64 wave tile over virtual pixels: pix[j] = real NHWC pixel index of column j of this lane, or -1 for
+// a padding position.  Same arithmetic and the same load-before-store ordering as conv_epilogue_plain (conv_igemm.h).
+template <typename T, int ACT, typename AccT>
+__device__ __forceinline__ void hpp_epilogue(const ConvArgs& a, AccT (&acc)[8][4], const f32x4 (&bvs)[8], const long (&pix)[4],
+                                             const int m0, const long tile_row, const int lane) {
+    constexpr int TM = 8, TN = 4;
+    const int mq = (lane >> 4) << 2, pc = lane & 15;
+    T* const yg = reinterpret_cast<T*>(a.y);
+    const T* const rg = reinterpret_cast<const T*>(a.res);
+    const int mbase = m0 + mq;
+    auto value = [&](auto ic, auto jc, int e) {
+        constexpr int i = decltype(ic)::value, j = decltype(jc)::value;
+        if constexpr (sizeof(T) == 1) {
+            const float y = activate_c<ACT>((float)acc[i][j][e] * a.acc_scale + bvs[i][e], a.slope);
+            return round_clamp_i8(y * a.inv_out_scale);
+        } else {
+            return activate_c<ACT>((float)acc[i][j][e] + bvs[i][e], a.slope);
+        }
+    };
+    if constexpr (sizeof(T) != 1) {
+        if (a.stats_part != nullptr) {   // BatchNorm partial sums of the values as stored; one row per (pixel tile, wave)
+            float* const row = a.stats_part + tile_row * 2 * a.Cout;
+            static_for<TM>([&](auto ic) {
+                constexpr int i = decltype(ic)::value;
+                float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+                static_for<TN>([&](auto jc) {
+                    constexpr int j = decltype(jc)::value;
+                    if (pix[j] >= 0) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float q = (float)(T)value(ic, jc, e);
+                            s1[e] += q;
+                            s2[e] = fmaf(q, q, s2[e]);
+                        }
+                    }
+                });
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float t1 = row16_sum(s1[e]), t2 = row16_sum(s2[e]);
+                    const int m = mbase + i * 16 + e;
+                    if (pc == 15 && m < a.Cout) {
+                        row[m] = t1;
+                        row[a.Cout + m] = t2;
+                    }
+                }
+            });
+        }
+    }
+    // ---- stores, 8 consecutive channels per lane.  A 16 x 16 fragment leaves a lane (k = lane >> 4, pixel lane & 15) with channels
+    // 4k .. 4k+3; v_permlane16_swap exchanges the odd 16-lane rows of its first operand with the even rows of its second, so for a
+    // fragment pair (i, i+1), swapping the pair's values dword by dword leaves row k with channels 8 (k >> 1) .. +7 of fragment
+    // i + (k & 1): one 16-byte (f16) / 8-byte (int8) store per pair instead of two half-width ones (the store tail of a 128 x 64 wave
+    // tile is issue-bound: 32 -> 16 store instructions).  The swap moves the un-rounded fp32 values, the residual is added to them
+    // in the new layout, and the result is rounded once: bit-identical to the narrow form.
+    const int k4 = lane >> 4;
+    const int chan = ((k4 & 1) << 4) + ((k4 >> 1) << 3);      // channel offset of this lane's 8-group inside a fragment pair
+    const bool have_res = rg != nullptr;
+    static_for<TN>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        const long p = pix[j];
+        typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+        typedef typename std::conditional<sizeof(T) == 2, u32x4, u32x2>::type res8_t;   // 8 residual channels
+        res8_t rv[TM / 2];
+        if (have_res) {
+#pragma unroll
+            for (int i2 = 0; i2 < TM / 2; ++i2) {
+                rv[i2] = res8_t{};
+                const int m = m0 + i2 * 32 + chan;
+                if (p >= 0 && m < a.Cout) rv[i2] = *reinterpret_cast<const res8_t*>(rg + p * a.ldr + m);
+            }
+#pragma unroll
+            for (int i2 = 0; i2 < TM / 2; ++i2) {   // one wait for the column's residuals, before its first store
+                res8_t t = rv[i2];
+                asm volatile("" : "+v"(t));
+                rv[i2] = t;
+            }
+        }
+        T* const prow = yg + (p >= 0 ? p : 0) * a.ldy;
+        static_for<TM / 2>([&](auto ic) {
+            constexpr int i2 = decltype(ic)::value;
+            typedef std::integral_constant<int, 2 * i2> I0;
+            typedef std::integral_constant<int, 2 * i2 + 1> I1;
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const unsigned lo = __builtin_bit_cast(unsigned, (float)value(I0{}, jc, e));
+                const unsigned hi = __builtin_bit_cast(unsigned, (float)value(I1{}, jc, e));
+                const auto r = __builtin_amdgcn_permlane16_swap(lo, hi, false, false);
+                v[e] = __builtin_bit_cast(float, (unsigned)r[0]);
+                v[4 + e] = __builtin_bit_cast(float, (unsigned)r[1]);
+            }
+            const int m = m0 + i2 * 32 + chan;
+            if (p < 0 || m >= a.Cout) return;
+            if constexpr (sizeof(T) == 2) {
+                if (have_res) {
+                    const f16x8 r8 = __builtin_bit_cast(f16x8, rv[i2]);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] += (float)r8[e];
+                }
+                const f16x8 o = {(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3], (f16)v[4], (f16)v[5], (f16)v[6], (f16)v[7]};
+                *reinterpret_cast<f16x8*>(prow + m) = o;
+            } else {
+                if (have_res) {   // fused quantised shortcut: v holds the grid values the conv would have stored
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = qadd_value(v[e], (float)(int8_t)((rv[i2][e >> 2] >> (8 * (e & 3))) & 0xff), a);
+                }
+                u32x2 o;
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+                    o[h] = ((unsigned)(int)v[4 * h] & 0xffu) | (((unsigned)(int)v[4 * h + 1] & 0xffu) << 8) |
+                           (((unsigned)(int)v[4 * h + 2] & 0xffu) << 16) | (((unsigned)(int)v[4 * h + 3] & 0xffu) << 24);
+                *reinterpret_cast<u32x2*>(prow + m) = o;
+            }
+        });
+    });
+}
+
+// vmcnt allowance at the end of tap t's second load segment while the next chunk's halo image is being fetched: the two weight
+// tiles issued after the one the next step reads, plus the halo pieces issued after it (taps t-2 .. t that have a piece).  The
+// last tap allows the weight tiles only: every halo piece must have landed before the next chunk's first fragment read.
+template <int T9, int LB> struct HppAllow {
+    static constexpr int in(int t) { return (t >= 0 && t < LB) ? 1 : 0; }
+    static constexpr int value = T9 == 8 ? 2 : 2 + in(T9 - 2) + in(T9 - 1) + in(T9);
+};
+
+// PH = phases per K step: 2 = two 16-MFMA segments per wave (8 + 4 fragment reads), 1 = one 32-MFMA segment (12 reads): the
+// loading group then has 512 cycles of its partner's MFMAs to hide its read latency under, and a K step costs two barriers.
+template <typename T, int LB, int PH>
+__global__ __launch_bounds__(512, 2) void conv3x3_hpp_kernel(const ConvArgs a, const int rows_hp, const int hbufs) {
+    constexpr int VEC = Prec<T>::VEC, BK = VEC * 4;       // one 64-byte chunk per row per K step: 32 f16 / 64 int8 channels
+    constexpr int BM = 128, BN = 512, TM = 8, TN = 4, NW = 8, SA = 4;
+    constexpr int A_CELLS = BM * 4;
+    static_assert(sizeof(T) <= 2, "f16 / int8");
+    typedef typename HppMma<T>::frag_t frag_t;
+    typedef typename AccOf<T>::type acc_t;
+
+    extern __shared__ __attribute__((aligned(16))) u32x4 hsm[];   // the only LDS object of the kernel
+    u32x4* const Aring = hsm;                                     // [SA][128 rows x 4 cells]
+    u32x4* const Hbuf = hsm + SA * A_CELLS;                       // [hbufs][rows_hp x 4 cells]
+    u32x4* const dummy = Hbuf + hbufs * rows_hp * 4;              // [64] sink of the pieces beyond the image
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int group = wave >> 2;
+
+    int m_tile, p_tile;
+    {
+        const int nb = gridDim.x, bid = blockIdx.x;
+        const int q = nb >> 3, rr = nb & 7, xcd = bid & 7;
+        const int logical = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (bid >> 3);
+        p_tile = logical / a.m_tiles;
+        m_tile = logical - p_tile * a.m_tiles;
+    }
+    const int m0 = m_tile * BM;
+    const long q0 = (long)p_tile * BN;          // first virtual output position of the tile
+    const int Wp = a.W + 1;
+    const int IMG = (a.H + 1) * Wp;
+
+    // ---- loader: an LDS-DMA instruction fills 16 rows x 4 cells; lane -> row lane >> 2, destination cell lane & 3, which holds
+    // source cell (lane & 3) ^ 2 ((row >> 2) & 1) - the same for weight rows and halo rows (16-row pieces start on multiples of 16)
+    const int lrow = lane >> 2;
+    const int lu = (lane & 3) ^ (((lane >> 4) & 1) << 1);
+    const T* const xg = reinterpret_cast<const T*>(a.x);
+    const T* const zero = reinterpret_cast<const T*>(g_zero_page);
+    const T* const wsrc = reinterpret_cast<const T*>(a.w) + (long)min(m0 + wave * 16 + lrow, a.m_pad - 1) * a.ktot + lu * VEC;
+    int boff[LB];    // element offset of this lane's source cell in halo piece i, or -1: padding / beyond the batch
+    {
+        const int v0 = (int)q0 - Wp - 1;      // the launcher keeps the whole virtual space below 2^31
+        static_for<LB>([&](auto c) {
+            constexpr int i = decltype(c)::value;
+            const int j = (wave + i * NW) * 16 + lrow;
+            const int v = v0 + j;
+            int off = -1;
+            if (j < rows_hp && v >= 0) {
+                const int n = v / IMG;
+                const int rem = v - n * IMG;
+                const int yy = rem / Wp, xx = rem - yy * Wp;
+                if (n < a.N && yy >= 1 && xx >= 1) off = ((n * a.H + yy - 1) * a.W + xx - 1) * a.ldx + lu * VEC;
+            }
+            boff[i] = off;
+        });
+    }
+    auto issue_a = [&](int stage, int tap, int kc) {
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc + (tap * a.cin_k + kc)),
+                                         (__attribute__((address_space(3))) void*)(Aring + stage * A_CELLS + wave * 64), 16, 0, 0);
+    };
+    auto issue_h = [&](int buf, int kc, auto ic) {      // piece i of this wave for the chunk at channel offset kc
+        constexpr int i = decltype(ic)::value;
+        const int g = wave + i * NW;                    // wave-uniform
+        const bool ok = boff[i] >= 0 && kc + lu * VEC < a.Cin;
+        const T* src = ok ? xg + (boff[i] + kc) : zero;
+        u32x4* dst = (g * 16 < rows_hp) ? Hbuf + buf * (rows_hp * 4) + g * 64 : dummy;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+    };
+
+    acc_t acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = acc_t{0, 0, 0, 0};
+
+    // ---- fragment addressing.  Weights: row i 16 + r16 of the stage (rows 64 .. 127 in the second phase), cell kq ^ f(row); the
+    // permutation bit of a row only depends on r16 there.  Halo: row wave 64 + j 16 + r16 + tapoff, whose bit depends on r16 + tapoff.
+    const int r16 = lane & 15, kq = lane >> 4;
+    const int a_off = r16 * 4 + (kq ^ (((r16 >> 2) & 1) << 1));
+    frag_t fa[PH == 1 ? 8 : 4], fb[4];
+    auto read_a = [&](const u32x4* st, int half) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            u32x4 v = st[(half * 64 + i * 16) * 4 + a_off];
+            fa[PH == 1 ? half * 4 + i : i] = *reinterpret_cast<frag_t*>(&v);
+        }
+    };
+    auto read_b = [&](const u32x4* hb, int tapoff) {
+        const int rt = r16 + tapoff;
+        const int off = (wave * 64 + rt) * 4 + (kq ^ (((rt >> 2) & 1) << 1));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            u32x4 v = hb[off + j * 64];
+            fb[j] = *reinterpret_cast<frag_t*>(&v);
+        }
+    };
+    auto mma = [&](auto hc) {
+        constexpr int h = decltype(hc)::value;
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[h * 4 + i][j] = HppMma<T>::mma(fa[PH == 1 ? h * 4 + i : i], fb[j], acc[h * 4 + i][j]);
+        __builtin_amdgcn_s_setprio(0);
+    };
+    typedef std::integral_constant<int, 0> H0;
+    typedef std::integral_constant<int, 1> H1;
+#define YH_HPP_BARRIER()                     \
+    do {                                     \
+        __builtin_amdgcn_sched_barrier(0);   \
+        __builtin_amdgcn_s_barrier();        \
+        __builtin_amdgcn_sched_barrier(0);   \
+    } while (0)
+    // one phase = LOAD segment (ends with: all of this wave's LDS reads returned), barrier, 16 MFMAs, barrier
+#define YH_HPP_PHASE(LOADS, MMA)                              \
+    do {                                                      \
+        LOADS;                                                \
+        __builtin_amdgcn_sched_barrier(0);                    \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   \
+        __builtin_amdgcn_s_barrier();                         \
+        __builtin_amdgcn_sched_barrier(0);                    \
+        MMA;                                                  \
+        YH_HPP_BARRIER();                                     \
+    } while (0)
+
+    const int nchunks = a.cin_k / BK;
+    const int nk = 9 * nchunks;
+    // ---- prologue: halo image of chunk 0, weight tiles of steps 0 .. 2; steps 1 and 2 stay in flight
+    static_for<LB>([&](auto ic) { issue_h(0, 0, ic); });
+    issue_a(0, 0, 0);
+    issue_a(1, 1, 0);
+    issue_a(2, 2, 0);
+    wait_vmcnt<2>();
+    YH_HPP_BARRIER();
+    if (group == 1) YH_HPP_BARRIER();   // stagger: group 1 runs one barrier interval behind group 0
+
+    int s = 0;                   // K step being computed
+    int st_r = 0, st_w = 3;      // ring stage of step s / of step s + 3
+    int ptap = 3, pkc = 0;       // tap / channel offset of step s + 3
+    for (int c = 0; c < nchunks; ++c) {
+        const bool more_h = c + 1 < nchunks;      // the next chunk's halo image is fetched during this chunk (LB <= 7 then)
+        const u32x4* const hb = Hbuf + (c & (hbufs - 1)) * (rows_hp * 4);
+        const int nbuf = (c + 1) & 1, nkc = (c + 1) * BK;
+        static_for<9>([&](auto tc) {
+            constexpr int t = decltype(tc)::value;
+            const u32x4* const st = Aring + st_r * A_CELLS;
+            const int tapoff = (t / 3) * Wp + (t % 3);
+            constexpr int allow = HppAllow<t, LB>::value;   // (a comma inside <> would split the macro argument)
+            if constexpr (PH == 2) {
+                // ---- phase X: channels 0 .. 63 of the tile x this wave's 64 pixels; weight tile of step s + 3 into the stage that
+                // step s - 1 was read from (both groups are past its last read: the barrier that ended the previous interval)
+                YH_HPP_PHASE({ read_a(st, 0); read_b(hb, tapoff); if (s + 3 < nk) issue_a(st_w, ptap, pkc); }, mma(H0{}));
+                // ---- phase Y: channels 64 .. 127; one piece of the next halo image; then this wave's share of step s + 1 (and of
+                // everything older) must have landed: the barrier after this segment, and for the other group the next one, publish it
+                YH_HPP_PHASE({
+                    read_a(st, 1);
+                    if constexpr (t < LB) { if (more_h) issue_h(nbuf, nkc, tc); }
+                    if (more_h) wait_vmcnt<allow>();
+                    else {
+                        const int rem = nk - 2 - s;
+                        if (rem >= 2) wait_vmcnt<2>(); else if (rem == 1) wait_vmcnt<1>(); else wait_vmcnt<0>();
+                    }
+                }, mma(H1{}));
+            } else {
+                // ---- one phase: all 12 fragments, the LDS-DMA issues and the counted wait in one load segment, then 32 MFMAs
+                YH_HPP_PHASE({
+                    read_b(hb, tapoff); read_a(st, 0); read_a(st, 1);
+                    if (s + 3 < nk) issue_a(st_w, ptap, pkc);
+                    if constexpr (t < LB) { if (more_h) issue_h(nbuf, nkc, tc); }
+                    if (more_h) wait_vmcnt<allow>();
+                    else {
+                        const int rem = nk - 2 - s;
+                        if (rem >= 2) wait_vmcnt<2>(); else if (rem == 1) wait_vmcnt<1>(); else wait_vmcnt<0>();
+                    }
+                }, { mma(H0{}); mma(H1{}); });
+            }
+            ++s;
+            st_r = (st_r + 1) & (SA - 1);
+            st_w = (st_w + 1) & (SA - 1);
+            if (++ptap == 9) { ptap = 0; pkc += BK; }
+        });
+    }
+    if (group == 0) YH_HPP_BARRIER();   // matches group 1's extra barrier at the start
+#undef YH_HPP_PHASE
+#undef YH_HPP_BARRIER
+
+    // ---- epilogue.  Every load before the first store (bias here; residual columns inside hpp_epilogue)
+    const int mq = (lane >> 4) << 2;
+    f32x4 bvs[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int m = m0 + i * 16 + mq;
+        bvs[i] = m < a.Cout ? *reinterpret_cast<const f32x4*>(a.bias + m) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i) asm volatile("" ::"v"(bvs[i]));
+    long pix[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int q = (int)q0 + wave * 64 + j * 16 + r16;
+        const int n = q / IMG;
+        const int rem = q - n * IMG;
+        const int yy = rem / Wp, xx = rem - yy * Wp;
+        pix[j] = (n < a.N && yy >= 1 && xx >= 1) ? ((long)n * a.H + yy - 1) * a.W + xx - 1 : -1;
+    }
+    const long tile_row = (long)p_tile * NW + wave;
+    switch (a.act) {
+        case YH_ACT_LEAKY: hpp_epilogue<T, YH_ACT_LEAKY>(a, acc, bvs, pix, m0, tile_row, lane); break;
+        case YH_ACT_MISH: hpp_epilogue<T, YH_ACT_MISH>(a, acc, bvs, pix, m0, tile_row, lane); break;
+        default: hpp_epilogue<T, YH_ACT_LINEAR>(a, acc, bvs, pix, m0, tile_row, lane); break;
+    }
+}
+
+// geometry shared by the launcher, the tile picker and the statistics-row query
+bool hpp_geometry(int W, int cin_k, int bk, int* rows_hp, int* lb, int* hbufs, size_t* lds) {
+    const int Wp = W + 1;
+    const int rows_h = 512 + 2 * Wp + 2;
+    *rows_hp = ((rows_h + 15) / 16) * 16;
+    const int groups = *rows_hp / 16;
+    int l = (groups + 7) / 8;
+    const int nchunks = cin_k / bk;
+    *hbufs = nchunks > 1 ? 2 : 1;
+    if (l == 8) l = 9;
+    if (l < 5 || l > 9 || (nchunks > 1 && l > 7)) return false;   // in-loop halo prefetch issues one piece per tap in taps 0 .. 6
+    *lb = l;
+    *lds = ((size_t)4 * 128 * 4 + (size_t)*hbufs * *rows_hp * 4 + 64) * 16;
+    return *lds <= 160 * 1024;
+}
+
+template <typename T> static int launch_hpp(const ConvArgs& a0, hipStream_t stream) {
+    constexpr int BK = Prec<T>::VEC * 4;
+    ConvArgs a = a0;
+    if (a.R != 3 || a.S != 3 || a.stride != 1 || a.pad != 1 || a.ups != 1) return YH_EUNSUPPORTED;
+    if (a.act != YH_ACT_LINEAR && a.act != YH_ACT_LEAKY && a.act != YH_ACT_MISH) return YH_EUNSUPPORTED;
+    if (a.cin_k % BK) return YH_EALIGN;
+    int rows_hp, lb, hbufs;
+    size_t lds;
+    if (!hpp_geometry(a.W, a.cin_k, BK, &rows_hp, &lb, &hbufs, &lds)) return YH_EUNSUPPORTED;
+    // 32-bit element offsets inside the kernel
+    if ((long)a.N * a.H * a.W * a.ldx + a.cin_k >= 0x7fffffffL || (long)a.m_pad * a.ktot >= 0x7fffffffL) return YH_EUNSUPPORTED;
+    if ((long)(a.N + 1) * (a.H + 1) * (a.W + 1) + 4096 >= 0x7fffffffL) return YH_EUNSUPPORTED;
+    // 8-channel (16-byte f16 / 8-byte int8) stores and residual loads
+    const unsigned amask = sizeof(T) == 2 ? 15u : 7u;
+    if (a.Cout % 8 || a.ldy % 8 || (((uintptr_t)a.y) & amask) || (a.res && (a.ldr % 8 || (((uintptr_t)a.res) & amask)))) return YH_EALIGN;
+    a.m_tiles = (a.Cout + 127) / 128;
+    const long Q = (long)a.N * (a.H + 1) * (a.W + 1);
+    a.p_tiles = (int)((Q + 511) / 512);
+    const long blocks = (long)a.m_tiles * a.p_tiles;
+    if (blocks <= 0 || blocks > 0x7fffffffL) return YH_EINVAL;
+    static const int phases = [] { const char* e = getenv("YH_HPP_PHASES"); return e && atoi(e) == 2 ? 2 : 1; }();   // A/B knob
+#define YH_HPP_CASE(LBV)                                                                                                       \
+    case LBV: {                                                                                                                \
+        auto kern = phases == 2 ? conv3x3_hpp_kernel<T, LBV, 2> : conv3x3_hpp_kernel<T, LBV, 1>;                              \
+        static size_t allowed = 64 * 1024;   /* per instantiation: raise the dynamic-LDS limit once per size */               \
+        if (lds > allowed) {                                                                                                   \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                               160 * 1024);                                                                    \
+            if (e != hipSuccess) return (int)e;                                                                                \
+            allowed = 160 * 1024;                                                                                              \
+        }                                                                                                                      \
+        hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(512), lds, stream, a, rows_hp, hbufs);                           \
+        break;                                                                                                                 \
+    }
+    switch (lb) {
+        YH_HPP_CASE(5) YH_HPP_CASE(6) YH_HPP_CASE(7) YH_HPP_CASE(9)
+        default: return YH_EUNSUPPORTED;
+    }
+#undef YH_HPP_CASE
+    return check_launch();
+}
+
+int launch_hpp_tile(const ConvArgs& a, int dtype, hipStream_t stream) {
+    if (dtype == YH_F16) return launch_hpp<f16>(a, stream);
+    if (dtype == YH_I8) return launch_hpp<int8_t>(a, stream);
+    return YH_EINVAL;
+}
+
+}  // namespace yh

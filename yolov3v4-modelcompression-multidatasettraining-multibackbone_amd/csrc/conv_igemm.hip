@@ -845,6 +845,9 @@ template <typename T, typename OutT> static int dispatch_tile(const ConvArgs& a,
         case 52: return launch_glds<T, OutT, 256, 128, 4, 2, 3, 2>(a, s);  // ablation: no MFMAs (results are garbage)
         case 41: return launch_halo<T, OutT, 128>(a, s);   // 3x3 s1 halo kernel, 128 channels x 256 virtual pixels
         case 42: return launch_halo<T, OutT, 256>(a, s);
+        case 43:   // halo ping-pong kernel (conv_halo_pp.hip): f16 in, f16 out
+            if constexpr (sizeof(T) == 2 && std::is_same<OutT, T>::value) return launch_hpp_tile(a, YH_F16, s);
+            else return YH_EUNSUPPORTED;
         case 31: return launch_glds<T, OutT, 128, 128, 2, 2, 4>(a, s);
         // full-line K step (64 f16 channels), 128 x 64 per wave: 61 = 256 x 256, 62 = 128 x 512 (8 waves, 2 stages),
         // 63 = 256 x 128 (4 waves, 3 stages)
@@ -870,6 +873,9 @@ template <typename OutT> static int dispatch_tile_i8(const ConvArgs& a, int tile
         case 26: return launch_glds<int8_t, OutT, 256, 128, 4, 2, 3>(a, s);
         case 27: return launch_glds<int8_t, OutT, 128, 256, 2, 4, 3>(a, s);
         case 64: case 65: case 66: return launch_k64_tile(a, tile, YH_I8, std::is_same<OutT, float>::value ? 1 : 0, s);
+        case 43:
+            if constexpr (std::is_same<OutT, int8_t>::value) return launch_hpp_tile(a, YH_I8, s);
+            else return YH_EUNSUPPORTED;
         default: return YH_EINVAL;
     }
 }
@@ -944,6 +950,32 @@ static bool pick_halo_tile(const yh_conv_desc* d) {
     return d->cin >= 128 && d->cin % 32 == 0 && d->w_in >= 48 && d->w_in <= 96 && (long)d->n * d->h * d->w_in >= 131072;
 }
 
+// The halo ping-pong kernel (conv_halo_pp.hip, tile 43): 3x3 / s1 / p1 with one of the compile-time activations, plain dense store
+// (residual and fused statistics included), input and output of the same type.  128-row weight tiles: the weight tile is re-read
+// by every pixel tile, so it takes the layers whose pixel axis is long enough to fill the chip with 512-pixel tiles.
+static bool pick_hpp_tile(const yh_conv_desc* d) {
+    static const bool off = getenv("YH_NO_HPP") != nullptr;
+    if (off || (d->dtype != YH_F16 && d->dtype != YH_I8) || d->out_f32) return false;
+    if (d->kh != 3 || d->kw != 3 || d->stride != 1 || d->pad != 1 || d->ups != 1) return false;
+    if (d->act != YH_ACT_LINEAR && d->act != YH_ACT_LEAKY && d->act != YH_ACT_MISH) return false;
+    const int bk = d->dtype == YH_I8 ? 64 : 32;
+    // measured (profiles/r03_hpp_sweep.txt, batch 64): ahead by 9 - 19 % on the 76 x 76 / 38 x 38 / 19 x 19 layers (4 or more
+    // channel chunks), behind on 152 x 152 64 -> 128 (two chunks: 18 K steps do not amortise the halo prologue) and on 64-row
+    // outputs (half-empty weight tile)
+    if (d->cin_k % bk || d->cout < 128 || d->cin_k / bk < (d->dtype == YH_I8 ? 2 : 3)) return false;
+    const unsigned amask = d->dtype == YH_F16 ? 15u : 7u;     // 8-channel stores / residual loads
+    if (d->cout % 8 || d->ldy % 8 || (((uintptr_t)d->y) & amask) || (d->res && (d->ldr % 8 || (((uintptr_t)d->res) & amask)))) return false;
+    if ((long)(d->n + 1) * (d->h + 1) * (d->w_in + 1) + 4096 >= 0x7fffffffL) return false;
+    int rows_hp, lb, hbufs;
+    size_t lds;
+    if (!yh::hpp_geometry(d->w_in, d->cin_k, bk, &rows_hp, &lb, &hbufs, &lds)) return false;
+    if ((long)d->n * d->h * d->w_in * d->ldx + d->cin_k >= 0x7fffffffL || (long)d->m_pad * 9 * d->cin_k >= 0x7fffffffL) return false;
+    const long blocks = (long)((d->cout + 127) / 128) * (((long)d->n * (d->h + 1) * (d->w_in + 1) + 511) / 512);
+    // one workgroup per CU: a partly filled last round of the 256 CUs is paid in full
+    const long rounds = (blocks + 255) / 256;
+    return blocks >= 192 && (rounds >= 5 || blocks * 100 >= rounds * 256 * 75);
+}
+
 // The LDS-free streaming kernel (conv_pointwise.hip) for 1x1 convolutions over few channels on large grids, where a ring-kernel
 // tile lives for one or two K steps: whole-K weights in registers, (MT, KS) = (16-row channel groups, MFMA K steps) within its
 // register budget, plain dense store without residual / statistics / upsample.
@@ -963,6 +995,7 @@ extern "C" int yh_conv2d_tile(const yh_conv_desc* d) {
     if (!d) return YH_EINVAL;
     if (d->tile != 0) return d->tile;
     if (pick_pointwise_tile(d)) return 71;
+    if (pick_hpp_tile(d)) return 43;
     if (pick_halo_tile(d)) return 41;
     if (const int pp = pick_pp_tile(d)) return pp;
     const int t = yh::pick_tile(d->cout, (long)d->n * d->ho * d->wo, d->cin_k, d->dtype == YH_F16 ? 8 : 4, d->kh * d->kw);
@@ -991,7 +1024,10 @@ extern "C" int64_t yh_conv2d_stats_rows(const yh_conv_desc* d) {
     // a statistics epilogue (halo) must not be chosen on its account
     yh_conv_desc q = *d;
     if (!q.stats_ws) q.stats_ws = reinterpret_cast<float*>(sizeof(float));
-    if (!tile_geometry(yh_conv2d_tile(&q), &bn, &wn)) return 0;
+    const int tile = yh_conv2d_tile(&q);
+    if (tile == 43)   // halo ping-pong kernel: 512 VIRTUAL pixels (one shared pad row / column) per tile, one row per wave
+        return (int64_t)(((long)d->n * (d->h + 1) * (d->w_in + 1) + 511) / 512) * 8;
+    if (!tile_geometry(tile, &bn, &wn)) return 0;
     const long P = (long)d->n * d->ho * d->wo;
     return (int64_t)((P + bn - 1) / bn) * wn;
 }
@@ -1046,7 +1082,7 @@ extern "C" int yh_conv2d_fwd(const yh_conv_desc* d, void* stream) {
     a.stats_part = nullptr;
     if (d->stats_ws) {
         // fused BatchNorm statistics: plain dense output only, and never on the halo kernels
-        if (d->ups != 1 || d->res || d->dtype == YH_I8 || (d->tile >= 40 && d->tile < 50)) return YH_EINVAL;
+        if (d->ups != 1 || d->res || d->dtype == YH_I8 || (d->tile >= 40 && d->tile < 50 && d->tile != 43)) return YH_EINVAL;
         const int64_t rows = yh_conv2d_stats_rows(d);
         if (rows <= 0 || d->stats_ws_floats < rows * 2 * d->cout) return YH_EINVAL;
         a.stats_part = d->stats_ws;

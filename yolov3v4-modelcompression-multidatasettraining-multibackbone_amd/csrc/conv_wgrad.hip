@@ -41,6 +41,7 @@ struct WgradArgs {
     int tiles_m, tiles_n, ksteps, ksteps_per_split, ncols;  // ncols = kh*kw*cin: the flattened (tap, ci) axis
     int two_stage, dma, bn, bm, cin_w;   // dma: the fp16 LDS-DMA kernel; bn / bm: its column / row tile
     int xcd_splits;                  // > 0: 1-D launch, consecutive pixel splits share an XCD (and its L2)
+    int pp;                          // 256 x 256 tile: ping-pong schedule (YH_WGRAD_BIG = 2)
     int rw, rh, qh;                  // bk = qw * wo + rw, qw = qh * ho + rh: per-step pixel advance without divisions
     long pixels;
 };
@@ -278,7 +279,12 @@ template <int N> __device__ __forceinline__ void wg_wait_vmcnt() {
 
 // WNW = waves along the (tap, ci) axis: 2 -> 128 columns on 4 waves, 4 -> 256 columns on 8 waves (24 KB per K step for
 // twice the MFMA work of the 16 KB 128 x 128 step: the L2 -> LDS stream is what bounds this kernel).
-template <int TM, int WNW>
+// PP (256 x 256 tile on 8 waves only): the ping-pong schedule of the forward kernels (conv_igemm_k64.hip) - a K step is two
+// phases of 16 MFMAs per wave (channel halves of the wave's 128 rows), each phase = LOAD segment (transposed fragment reads,
+// LDS-DMA issue, counted vmcnt), raw barrier, MFMA segment, raw barrier; waves 4 .. 7 run one barrier interval behind waves
+// 0 .. 3, so that every SIMD has one wave in its MFMA segment while its partner reads.  Same ring, same fragment layout, same
+// summation order as the plain form: results are bit-identical.
+template <int TM, int WNW, bool PP = false>
 __global__ __launch_bounds__(128 * WNW) void conv_wgrad_dma_kernel(const WgradArgs a) {
     constexpr int BK = 32, BM = TM * 32, BN = WNW * 64, NWAVES = 2 * WNW, NT = 64 * NWAVES, STAGES = 3;
     constexpr int A_UNITS = BM / 8;                    // 16-byte units per A row (16 or 8)
@@ -422,6 +428,94 @@ __global__ __launch_bounds__(128 * WNW) void conv_wgrad_dma_kernel(const WgradAr
     }
 
     const int nk = ks1 - ks0;
+    if constexpr (PP) {
+        static_assert(!PP || (TM == 8 && WNW == 4), "ping-pong form: 256 x 256 on 8 waves");
+        const int group = wave >> 2;
+#define YH_WPP_BARRIER()                     \
+        do {                                 \
+            __builtin_amdgcn_sched_barrier(0);   \
+            __builtin_amdgcn_s_barrier();        \
+            __builtin_amdgcn_sched_barrier(0);   \
+        } while (0)
+        issue(0);
+        if (nk > 1) { issue(1); wg_wait_vmcnt<GPW>(); } else wg_wait_vmcnt<0>();
+        YH_WPP_BARRIER();
+        if (group == 1) YH_WPP_BARRIER();   // stagger
+        int st_r = 0, st_w = 2;
+        for (int kt = 0; kt < nk; ++kt) {
+            const unsigned stage = lds0 + st_r * STAGE_BYTES;
+            wg_v2i ra[4][2], rb[4][2];
+            typedef int v4i __attribute__((ext_vector_type(4)));
+            f16x8 fa[4], fb[4];
+            // ---- phase X: channel rows 0 .. 63 of the wave tile; the tiles of step kt + 2 go into the stage step kt - 1 was read from
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) ra[i][h] = ds_read_tr16<0>(stage + (a_addr[h] ^ (i << 5)));
+#pragma unroll
+                for (int j = 0; j < 4; ++j) rb[j][h] = ds_read_tr16<0>(stage + (b_addr[h] ^ (j << 5)));
+            }
+            if (kt + 2 < nk) issue(st_w);
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+v"(ra[0][0]), "+v"(ra[0][1]), "+v"(ra[1][0]), "+v"(ra[1][1]), "+v"(ra[2][0]), "+v"(ra[2][1]),
+                           "+v"(ra[3][0]), "+v"(ra[3][1]), "+v"(rb[0][0]), "+v"(rb[0][1]), "+v"(rb[1][0]), "+v"(rb[1][1]),
+                           "+v"(rb[2][0]), "+v"(rb[2][1]), "+v"(rb[3][0]), "+v"(rb[3][1])
+                         :
+                         : "memory");
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const v4i t = {ra[i][0][0], ra[i][0][1], ra[i][1][0], ra[i][1][1]};
+                fa[i] = __builtin_bit_cast(f16x8, t);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const v4i t = {rb[j][0][0], rb[j][0][1], rb[j][1][0], rb[j][1][1]};
+                fb[j] = __builtin_bit_cast(f16x8, t);
+            }
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+            YH_WPP_BARRIER();
+            // ---- phase Y: channel rows 64 .. 127; this wave's share of step kt + 1 must have landed before the barrier
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) ra[i][h] = ds_read_tr16<0>(stage + (a_addr[h] ^ ((i + 4) << 5)));
+            if (kt + 2 < nk) wg_wait_vmcnt<GPW>(); else wg_wait_vmcnt<0>();
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+v"(ra[0][0]), "+v"(ra[0][1]), "+v"(ra[1][0]), "+v"(ra[1][1]), "+v"(ra[2][0]), "+v"(ra[2][1]),
+                           "+v"(ra[3][0]), "+v"(ra[3][1])
+                         :
+                         : "memory");
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const v4i t = {ra[i][0][0], ra[i][0][1], ra[i][1][0], ra[i][1][1]};
+                fa[i] = __builtin_bit_cast(f16x8, t);
+            }
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[i], fb[j], acc[4 + i][j], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+            YH_WPP_BARRIER();
+            st_r = st_r + 1 == STAGES ? 0 : st_r + 1;
+            st_w = st_w + 1 == STAGES ? 0 : st_w + 1;
+        }
+        if (group == 0) YH_WPP_BARRIER();
+#undef YH_WPP_BARRIER
+    } else {
 #pragma unroll
     for (int s = 0; s < STAGES - 1; ++s)
         if (s < nk) issue(s);
@@ -491,6 +585,7 @@ __global__ __launch_bounds__(128 * WNW) void conv_wgrad_dma_kernel(const WgradAr
         st_read = st_read + 1 == STAGES ? 0 : st_read + 1;
         st_write = st_write + 1 == STAGES ? 0 : st_write + 1;
     }
+    }   // !PP
 
     if (a.two_stage) {
         f32x4* part = reinterpret_cast<f32x4*>(d.ws) + ((long)split_id * (a.tiles_m * a.tiles_n) + tile_id) * (TM * 4 * NT);
@@ -813,6 +908,7 @@ static void wgrad_geometry(const yh_wgrad_desc* d, WgradArgs* pa, int* psplits) 
     WgradArgs& a = *pa;
     const int bk = d->dtype == YH_F16 ? 32 : 16;
     a.d = *d;
+    a.pp = 0;
     a.pixels = (long)d->n * d->ho * d->wo;
     int bm = d->cout <= 64 ? 64 : WG_TILE;        // 64-row tiles for the early, wide-resolution layers
     a.ncols = d->kh * d->kw * d->cin;
@@ -838,7 +934,8 @@ static void wgrad_geometry(const yh_wgrad_desc* d, WgradArgs* pa, int* psplits) 
     if (a.dma && bm == 256 && a.bn == 128) {
         const char* e = getenv("YH_WGRAD_BIG");
         const int big = e ? atoi(e) : -1;
-        if (big == 1 || (big == -1 && wgrad_big_default(d, a.ncols))) a.bn = 256;
+        if (big >= 1 || (big == -1 && wgrad_big_default(d, a.ncols))) a.bn = 256;
+        a.pp = big == 2 ? 1 : 0;    // YH_WGRAD_BIG = 2: the ping-pong schedule of the 256 x 256 tile
     }
     a.bm = bm;
     a.tiles_m = (d->cout + bm - 1) / bm;
@@ -913,6 +1010,7 @@ extern "C" int yh_conv2d_wgrad(const yh_wgrad_desc* d, void* stream) {
     }
     if (a.dma) {
         if (narrow) hipLaunchKernelGGL((conv_wgrad_dma_kernel<2, 2>), grid, dim3(256), 0, st, a);
+        else if (a.bm == 256 && a.bn == 256 && a.pp) hipLaunchKernelGGL((conv_wgrad_dma_kernel<8, 4, true>), grid, dim3(512), 0, st, a);
         else if (a.bm == 256 && a.bn == 256) hipLaunchKernelGGL((conv_wgrad_dma_kernel<8, 4>), grid, dim3(512), 0, st, a);
         else if (a.bm == 256) hipLaunchKernelGGL((conv_wgrad_dma_kernel<8, 2>), grid, dim3(256), 0, st, a);
         else if (a.bn == 256) hipLaunchKernelGGL((conv_wgrad_dma_kernel<4, 4>), grid, dim3(512), 0, st, a);

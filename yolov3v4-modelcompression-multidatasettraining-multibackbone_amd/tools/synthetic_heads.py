@@ -53,9 +53,13 @@ def detector_like_heads_(model, x, per_image=100, conf=0.3, spread=2.5, margin=8
     if hasattr(model, 'hip_refresh'):
         model.hip_refresh()
     lg = logits()
-    k = min(per_image, lg.shape[1])
-    kth = float(lg.topk(k, dim=1).values[:, -1].mean())
-    shift = math.log(conf / (1 - conf)) + 0.25 - kth
+    # the threshold goes BETWEEN the k-th and the (k+1)-th largest logit (pooled over the calibration frames): after the gain the
+    # nine (head, anchor) groups have different means, and the top of the distribution sits inside the densest group - a margin of
+    # a fraction of a logit above the k-th value already lets thousands of cells through
+    k = min(per_image * lg.shape[0], lg.numel() - 1)
+    top = lg.flatten().topk(k + 1).values
+    kth = float(top[-2] + top[-1]) / 2
+    shift = math.log(conf / (1 - conf)) - kth
     for h, ((i, d), conv) in enumerate(zip(heads, convs)):
         na, nc = len(d['mask']), int(d['classes'])
         b = conv.bias.data.view(na, nc + 5)
