@@ -549,6 +549,21 @@ typedef struct yh_mosaic_desc {
 int yh_mosaic_affine_hsv(const yh_mosaic_desc* d, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------
+ * COS-PTQ calibration on the device.  The scale search every quantiser of the reference runs per calibration batch
+ * (utils/quantized/quantized_ptq_cos.py:64-93 Quantizer.forward, training branch; :838-912 COSPTQuantizedShortcut_min and
+ * :1153-1197 _max; the weight / bias quantisers of BNFold_COSPTQuantizedConv2d_For_FPGA :193-212 use the same search):
+ *   for j in 0 .. n-1:  scale_j = scale0 * 2^j;  q_j = clamp(round_half_away(t / scale_j), lo, hi) * scale_j  (clamp iff do_clamp)
+ *   cos_out[j] = <t, q_j> / (|t| |q_j|)  (0 when a norm vanishes);  *best = the FIRST j with the largest cosine
+ * in ONE pass over t: fp32 element arithmetic exactly as the modules', sums in double.  t: fp32, `count` elements in any order (a
+ * dense tensor of any layout); n <= 16; ws: yh_ptq_search_workspace(count) bytes of device scratch; cos_out (double[n]) and best
+ * (int32) are DEVICE pointers - the caller reads them back when it needs the decision on the host.
+ * yh_absmax: max |t| - what COSPTQuantizedFeatureConcat tracks per routed tensor (:1403-1449, max(max(t), |min(t)|)).        */
+int64_t yh_ptq_search_workspace(int64_t count);
+int yh_ptq_cos_search(const float* t, int64_t count, float scale0, int n, float lo, float hi, int do_clamp, void* ws,
+                      int64_t ws_bytes, double* cos_out, int32_t* best, void* stream);
+int yh_absmax(const float* t, int64_t count, void* ws, int64_t ws_bytes, float* out, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------
  * Plans: a recorded sequence of the launches above, replayed by one native call per forward (the
  * replacement for the per-layer Python dispatch loop of models.py:524-545).  Pointers that change
  * from call to call (network input, per-call outputs) are "slots": a fixup patches one pointer field

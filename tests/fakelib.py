@@ -411,6 +411,33 @@ class FakeLib:
     def yh_conv2d_stats_rows(self, dref):
         return 1
 
+    # ---- COS-PTQ calibration services (csrc/calib.hip): fp32 element arithmetic, float64 sums
+    def yh_ptq_search_workspace(self, count):
+        return 8 * 33
+
+    def yh_ptq_cos_search(self, t, count, scale0, n, lo, hi, do_clamp, ws, ws_bytes, cos_out, best, stream):
+        v = torch.from_numpy(flat(t, int(count), np.float32).copy())
+        out = flat(cos_out, int(n), np.float64)
+        nt = float(v.double().pow(2).sum().sqrt())
+        top, arg = -1.0, 0
+        for j in range(int(n)):
+            s = torch.tensor(np.float32(scale0) * np.float32(2.0 ** j))
+            r = rnd_away(v / s)
+            if do_clamp:
+                r = r.clamp(lo, hi)
+            q = (r * s).double()
+            nq = float(q.pow(2).sum().sqrt())
+            c = float((v.double() * q).sum()) / (nt * nq) if nt > 0 and nq > 0 else 0.0
+            out[j] = c
+            if c > top:
+                top, arg = c, j
+        flat(best, 1, np.int32)[0] = arg
+        return 0
+
+    def yh_absmax(self, t, count, ws, ws_bytes, out, stream):
+        flat(out, 1, np.float32)[0] = np.abs(flat(t, int(count), np.float32)).max()
+        return 0
+
     def yh_bn_finalize(self, dref, stream):
         d = dref._obj if hasattr(dref, '_obj') else dref
         if d.nparts > 0:

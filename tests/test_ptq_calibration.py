@@ -198,3 +198,88 @@ def test_calibration_on_the_gpu_then_int8_engine(cfg_dir):
         want = cpu(x)[0]
     d = (got - want).abs()
     assert (d[..., :4] > 0.05).float().mean().item() <= 0.02 and (d[..., 4:] > 2e-3).float().mean().item() <= 0.02
+
+
+# ------------------------------------------------------------------------------ device calibration services (csrc/calib.hip)
+def _calibrate(qm, way_device, monkeypatch, batches=3):
+    import utils.quantized.quantized_ptq_cos as q
+    from engine import calib
+    if way_device:      # route the CPU tensors through the device services, on the host emulation of the C ABI
+        monkeypatch.setattr(q, '_on_device', lambda t: torch.is_tensor(t))
+        monkeypatch.setattr(calib, '_lib_override', fakelib.FakeLib())
+    qm.train()
+    with torch.no_grad():
+        for it in range(batches):
+            qm(synth.image_batch(2, SIZE, seed=10 + it))
+    monkeypatch.undo()
+    return qm
+
+
+@pytest.mark.parametrize('way', [1, 2], ids=['shortcut_min', 'shortcut_max'])
+def test_device_calibration_services_take_the_same_decisions(way, monkeypatch):
+    """The whole calibration (scale votes of every quantiser, shortcut searches, concat ranges, bias correction) through
+    engine/calib.py - one-pass cosine search with double sums, abs-max, fp32 HIP convolutions, here all on the emulated C ABI -
+    against the reference's loop on the same weights and batches: every scale decision identical."""
+    import models
+    torch.manual_seed(0)
+    fm = models.Darknet(mini_cfg(), (SIZE, SIZE))
+    fm.load_state_dict(synth.randomize_bn_(fm.state_dict(), seed=1))
+    qm = models.Darknet(mini_cfg(), (SIZE, SIZE), quantized=3, a_bit=8, w_bit=8, shortcut_way=way)
+    _copy_float_weights(fm, qm)
+    host = _calibrate(copy.deepcopy(qm), False, monkeypatch)
+    dev = _calibrate(copy.deepcopy(qm), True, monkeypatch)
+    sd_h, sd_d = host.state_dict(), dev.state_dict()
+    scales = [k for k in sd_h if k.endswith('scale') or 'scale_' in k.rsplit('.', 1)[-1] or 'float_range' in k]
+    assert len(scales) >= 20
+    for k in scales:
+        assert torch.equal(sd_h[k], sd_d[k]), k
+    for k in sd_h:      # grids and corrected biases follow (the emulated fp32 convolution is torch's own)
+        if sd_h[k].dtype.is_floating_point:
+            assert torch.allclose(sd_h[k], sd_d[k], rtol=1e-5, atol=1e-6), k
+
+
+@pytest.mark.gpu
+def test_cosine_search_kernel_against_the_reference_loop():
+    """yh_ptq_cos_search on the MI355X against the modules' own loop (fp32 torch on the CPU) on tensors of several sizes, layouts
+    and alignments: same winner unless the loop's two best cosines tie to within fp32 summation noise; cosines within 1e-6."""
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU')
+    import utils.quantized.quantized_ptq_cos as q
+    from engine import calib
+    g = torch.Generator().manual_seed(5)
+    cases = []
+    for shape, spread in (((2, 32, 52, 52), 1.0), ((1, 255, 13, 13), 6.0), ((3, 7, 5, 11), 0.02), ((1000003,), 3.0), ((2, 16, 40, 40), 40.0)):
+        cases.append(torch.randn(*shape, generator=g) * spread)
+    cases.append((torch.randn(2, 20, 20, 24, generator=g) * 2).permute(0, 3, 1, 2))     # NHWC-backed NCHW view (dense, not contiguous)
+    cases.append(torch.randn(4099, generator=g)[3:])                                     # 4-byte aligned only
+    cases.append(torch.zeros(2, 8, 4, 4))                                                # all zero: every cosine 0, first candidate wins
+    for t in cases:
+        for first, n, bits in ((-5, 15, 8), (0, 8, 8)):
+            want_j, want_cos = q._search(t, first, n, bits)
+            got_j, got_cos = calib.cos_search(t.cuda(), 2.0 ** first / 128.0, n, bits)
+            want_cos = [float(c) for c in want_cos]
+            assert max(abs(a - b) for a, b in zip(got_cos, want_cos)) <= 2e-6, (tuple(t.shape), first)
+            if got_j != want_j:     # only a near-tie of the fp32 loop may decide differently
+                assert abs(want_cos[got_j] - want_cos[want_j]) <= 2e-6, (tuple(t.shape), first, got_j, want_j)
+    t = torch.randn(3, 40, 17, 9, generator=g) * 5
+    assert float(calib.absmax(t.cuda())) == float(t.abs().max())
+
+
+@pytest.mark.gpu
+def test_calibration_convolution_runs_on_the_hip_kernels():
+    """engine.calib.conv2d (what the calibration-mode modules call for CUDA tensors) against torch's CPU convolution."""
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU')
+    import torch.nn.functional as F
+    from engine import calib
+    g = torch.Generator().manual_seed(9)
+    for (n, cin, cout, h, k, s) in ((2, 3, 16, 40, 3, 1), (2, 16, 32, 33, 3, 2), (1, 64, 21, 13, 1, 1), (2, 32, 64, 20, 3, 1)):
+        x = torch.randn(n, cin, h, h, generator=g)
+        w = torch.randn(cout, cin, k, k, generator=g) * (cin * k * k) ** -0.5
+        b = torch.randn(cout, generator=g)
+        want = F.conv2d(x, w, b, s, (k - 1) // 2)
+        got = calib.conv2d(x.cuda(), w.cuda(), b.cuda(), (s, s), ((k - 1) // 2,) * 2)
+        assert got.shape == want.shape
+        assert (got.cpu() - want).abs().max().item() <= 2e-5 * want.abs().max().item()
+    with pytest.raises(NotImplementedError):
+        calib.conv2d(torch.zeros(1, 8, 8, 8).cuda(), torch.zeros(8, 1, 3, 3).cuda(), None, 1, 1, 1, groups=8)

@@ -277,6 +277,9 @@ _SIGNATURES = {
     'yh_nchw_to_nhwc': (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
     'yh_letterbox_fwd': (C.c_int, [C.POINTER(LetterboxDesc), _vp]),
     'yh_mosaic_affine_hsv': (C.c_int, [C.POINTER(MosaicDesc), _vp]),
+    'yh_ptq_search_workspace': (_i64, [_i64]),
+    'yh_ptq_cos_search': (C.c_int, [_vp, _i64, _f32, C.c_int, _f32, _f32, C.c_int, _vp, _i64, _vp, _vp, _vp]),
+    'yh_absmax': (C.c_int, [_vp, _i64, _vp, _i64, _vp, _vp]),
     'yh_plan_create': (_vp, []),
     'yh_plan_destroy': (None, [_vp]),
     'yh_plan_add': (C.c_int, [_vp, C.c_int, _vp, C.c_int]),

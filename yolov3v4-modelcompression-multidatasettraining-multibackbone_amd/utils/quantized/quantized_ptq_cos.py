@@ -60,6 +60,28 @@ def _cosine(a, b):
     return torch.cosine_similarity(a.reshape(-1), b.reshape(-1), dim=0)
 
 
+def _on_device(t):
+    return torch.is_tensor(t) and t.is_cuda
+
+
+def _search(t, first_step, n, bits):
+    """Cosine vote over the candidates float_range = 2^(first_step + j), j < n (scale = float_range / 2^(bits-1)).
+
+    Host tensors: the reference's loop (:64-93) - fake-quantise, cosine, keep the first maximum.  Device tensors: the same search
+    as ONE kernel pass over the tensor (engine/calib.py -> csrc/calib.hip); returns (best j, [cos_j])."""
+    if _on_device(t):
+        from engine import calib
+        return calib.cos_search(t, 2.0 ** first_step / float(1 << (bits - 1)), n, bits)
+    best, best_j, cos = -1, 0, []
+    for j in range(n):
+        scale = torch.zeros(1).add_(2 ** (first_step + j)) / float(1 << (bits - 1))
+        c = _cosine(t, _fake_quant(t, scale.to(t.device), bits))
+        cos.append(c)
+        if c > best:
+            best, best_j = c, j
+    return best_j, cos
+
+
 def _split(x):
     """(quantised stream, float stream) of a calibration-mode input."""
     if isinstance(x, (list, tuple)):
@@ -98,12 +120,7 @@ class Quantizer(nn.Module):
             return t
         assert self.bits != 1, 'binary quantisation is not supported'
         if self.training:
-            best, best_i = -1, 0
-            for i in range(self.bits + 7):
-                self.update_params(i - 5)
-                c = _cosine(t, _fake_quant(t, self.scale, self.bits))
-                if c > best:
-                    best, best_i = c, i
+            best_i, _ = _search(t, -5, self.bits + 7, self.bits)
             self.scale_list[best_i] += 1
             self.update_params(self.scale_list.index(max(self.scale_list)) - 5)
         return _fake_quant(t, self.scale, self.bits)
@@ -174,6 +191,9 @@ class BNFold_COSPTQuantizedConv2d_For_FPGA(nn.Conv2d):
         return self.weight * reshape_to_weight(k), reshape_to_bias(bias)
 
     def _conv(self, x, w, b):
+        if _on_device(x):    # calibration / eager evaluation on a GPU: the HIP conv kernels, never ATen's (MIOpen) convolution
+            from engine import calib
+            return calib.conv2d(x, w, b, self.stride, self.padding, self.dilation, self.groups)
         return F.conv2d(x, w, b, self.stride, self.padding, self.dilation, self.groups)
 
     def _act(self, t):
@@ -334,12 +354,7 @@ class COSPTQuantizedShortcut_min(_ShortcutBase):
 
     def _vote(self, t, type):
         votes = getattr(self, 'scale_list_' + type)
-        best, best_i = -1, 0
-        for i in range(self.bits):
-            self.update_params(i, type)
-            c = _cosine(t, self._fq(t, type))
-            if c > best:
-                best, best_i = c, i
+        best_i, _ = _search(t, 0, self.bits, self.bits)
         votes[best_i] += 1
         self.update_params(votes.index(max(votes)), type)
 
@@ -362,12 +377,11 @@ class COSPTQuantizedShortcut_max(_ShortcutBase):
         self.scale_list = [0] * self.bits
 
     def _calibrate_operands(self, x, a):
+        s = self._add(x.clone() if x.shape[1] > a.shape[1] else x, a)
+        cos = [_search(t, 0, self.bits, self.bits)[1] for t in (a, x, s)]
         best, best_i = -1, 0
         for i in range(self.bits):
-            for tag in ('a', 'x', 'sum'):
-                self.update_params(i, tag)
-            s = self._add(x.clone() if x.shape[1] > a.shape[1] else x, a)
-            c = _cosine(a, self._fq(a, 'a')) + _cosine(x, self._fq(x, 'x')) + _cosine(s, self._fq(s, 'sum'))
+            c = cos[0][i] + cos[1][i] + cos[2][i]
             if c > best:
                 best, best_i = c, i
         self.scale_list[best_i] += 1
@@ -405,7 +419,11 @@ class COSPTQuantizedFeatureConcat(nn.Module):
     def _track(self, outputs):
         for j, layer in enumerate(self.layers):
             t = _split(outputs[layer])[0].detach()
-            peak = torch.max(torch.max(t), torch.abs(torch.min(t)))
+            if _on_device(t):
+                from engine import calib
+                peak = calib.absmax(t)
+            else:
+                peak = torch.max(torch.max(t), torch.abs(torch.min(t)))
             if self.float_max_list[j] == 0:
                 self.float_max_list[j].add_(peak)
             else:
