@@ -114,6 +114,13 @@ WGRAD_CASES = [
     (2, 18, 18, 24, 40, 3, 1, 0, 0),        # 64-row tile, 216 flattened (tap, ci) columns
     (2, 16, 16, 64, 32, 1, 1, 0, 0),
     (1, 38, 38, 32, 64, 3, 2, 8, 8),
+    # shapes the 3x3 / s1 halo form takes when YH_WGRAD_HALO=1 (fp16 with a workspace, cout % 256 == 0, cin % 32 == 0, W >= 16);
+    # test_wgrad_halo_form_is_exact_on_small_integers runs them through it, here they take the default kernels
+    (2, 20, 20, 64, 256, 3, 1, 0, 0),
+    (3, 19, 19, 32, 256, 3, 1, 0, 0),
+    (1, 38, 38, 128, 512, 3, 1, 0, 0),
+    (2, 17, 23, 96, 256, 3, 1, 32, 16),     # non-square, pitched slices, three ci tiles
+    (5, 16, 16, 32, 256, 3, 1, 0, 0),       # several images (and their shared pad rows) per 512-pixel chunk
 ]
 
 
@@ -164,6 +171,30 @@ def test_wgrad_row_tiles_agree(libs, monkeypatch, case, bm, use_ws):
     _sync()
     ref = torch.nn.grad.conv2d_weight(x.float().permute(0, 3, 1, 2), (cout, cin, k, k), dz.float().permute(0, 3, 1, 2),
                                       stride=s, padding=pad)
+    assert torch.equal(got.cpu(), ref)
+
+
+@pytest.mark.parametrize('wgs', ['', '4', '64'], ids=['auto', 'few_splits', 'many_splits'])
+@pytest.mark.parametrize('case', [(2, 21, 19, 64, 256), (7, 16, 40, 32, 512), (1, 76, 76, 128, 256), (3, 33, 152, 32, 256)],
+                         ids=lambda c: 'n%d_%dx%d_c%d-%d' % c)
+def test_wgrad_halo_form_is_exact_on_small_integers(libs, monkeypatch, case, wgs):
+    """The 3x3 halo weight-gradient kernel (csrc/conv_wgrad.hip: one shared pad row / column, dz in virtual pixel order, halo image
+    read as nine shifted views) on integer operands: every product and partial sum exact, so any mistake in the pad handling, the
+    tap offsets, the split ranges or the partial-tile reduction shows as a wrong integer.  Ragged last chunks, chunk counts that do
+    not divide by the splits, W = 152 (five halo pieces per wave)."""
+    if DRY:
+        pytest.skip('kernel-only property')
+    lib, _ = libs
+    monkeypatch.setenv('YH_WGRAD_HALO', '1')      # the halo form is an opt-in (slower than the im2col kernel so far)
+    if wgs:
+        monkeypatch.setenv('YH_WGRAD_HALO_WGS', wgs)
+    N, H, W, cin, cout = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randint(-3, 4, (N, H, W, cin), generator=g).half()
+    dz = torch.randint(-2, 3, (N, H, W, cout), generator=g).half()
+    got = oh.wgrad(lib, F16, x.to(GPU), dz.to(GPU), cin, cout, 3, 1, 1, use_ws=True)
+    _sync()
+    ref = torch.nn.grad.conv2d_weight(x.float().permute(0, 3, 1, 2), (cout, cin, 3, 3), dz.float().permute(0, 3, 1, 2), padding=1)
     assert torch.equal(got.cpu(), ref)
 
 

@@ -42,6 +42,7 @@ struct WgradArgs {
     int two_stage, dma, bn, bm, cin_w;   // dma: the fp16 LDS-DMA kernel; bn / bm: its column / row tile
     int xcd_splits;                  // > 0: 1-D launch, consecutive pixel splits share an XCD (and its L2)
     int pp;                          // 256 x 256 tile: ping-pong schedule (YH_WGRAD_BIG = 2)
+    int halo, h_rows, h_lbw, h_chunks, h_cps;   // 3x3 halo form: staged halo rows, pieces per wave, 512-pixel chunks (per split)
     int rw, rh, qh;                  // bk = qw * wo + rw, qw = qh * ho + rh: per-step pixel advance without divisions
     long pixels;
 };
@@ -272,7 +273,8 @@ template <int OFF> __device__ __forceinline__ wg_v2i ds_read_tr16(unsigned lds_b
 template <int N> __device__ __forceinline__ void wg_wait_vmcnt() {
 #define YH_WG_VMCNT(K) else if constexpr (N == K) asm volatile("s_waitcnt vmcnt(" #K ")" ::: "memory")
     if constexpr (N < 0) {}
-    YH_WG_VMCNT(0); YH_WG_VMCNT(2); YH_WG_VMCNT(3); YH_WG_VMCNT(4); YH_WG_VMCNT(6); YH_WG_VMCNT(8);
+    YH_WG_VMCNT(0); YH_WG_VMCNT(1); YH_WG_VMCNT(2); YH_WG_VMCNT(3); YH_WG_VMCNT(4); YH_WG_VMCNT(5); YH_WG_VMCNT(6); YH_WG_VMCNT(7); YH_WG_VMCNT(8);
+    YH_WG_VMCNT(9); YH_WG_VMCNT(10);
     else static_assert(N < 0, "add the literal");
 #undef YH_WG_VMCNT
 }
@@ -652,6 +654,314 @@ __global__ __launch_bounds__(128 * WNW) void wgrad_reduce_kernel(const WgradArgs
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// 3x3 / stride 1 / pad 1 weight gradient, "halo" form (fp16, cout % 256 == 0, cin % 32 == 0).
+//
+// The LDS-DMA kernel above is bound by global -> LDS delivery (round 2: 48 KB per 1024 MFMA cycles of a CU against the ~20 B/clk
+// a CU is handed): every (tap, ci) column tile fetches its own shifted copy of the x rows, nine times per layer, and dz once per
+// column tile.  Here ONE workgroup owns a 256 (co) x [9 taps x 32 ci] tile, so that
+//   * the x rows of a 256-pixel chunk (plus one image row and one pixel either side) are staged ONCE as a halo image in the
+//     virtual pixel space of conv_halo_pp.hip (one shared pad row / column: tap (r, s) = row offset r (W+1) + s) and all nine
+//     taps read it as shifted views - through ds_read_b64_tr_b16, which takes any row offset;
+//   * dz streams through the 3-stage ring in 32-pixel steps, in virtual pixel order (pad positions read the zero page): 16 KB
+//     per step for 256 x 288 x 32 MACs = 16 B/clk at the MFMA rate, below the delivery wall (5-stage ring: four steps in flight).
+// 12 waves (3 per SIMD): wave (wm, wn) owns channels 64 wm .. +63 x the three taps of filter row wn x 32 ci = 4 x 6 fragments
+// (96 accumulator registers), 20 transposed fragment reads per 24 MFMAs.  Pixel splits as above: partial tiles in the
+// workspace in MFMA-native order, summed by wgrad_halo_reduce_kernel.  LDS rows of the halo image are 64 B (4 cells); the two
+// 32-byte halves of row r are swapped when bit 3 of r is set, so that the 4-row blocks of the two lane groups that share an LDS
+// cycle (rows 8 apart) never meet in a bank, for any tap offset.
+// ABL (profiling only, results are garbage): 1 = no MFMAs, 2 = no fragment reads, 3 = no LDS-DMA
+template <int LBW, int ABL = 0>
+__global__ __launch_bounds__(768, 3) void conv_wgrad_halo_kernel(const WgradArgs a) {
+    constexpr int BM = 256, KP = 256, BK = 32, NWAVES = 12, NT = 64 * NWAVES, STAGES = 5, SUBS = KP / BK;
+    constexpr int A_BYTES = BK * BM * 2;       // one dz step: 32 pixel rows x 512 B
+    const yh_wgrad_desc& d = a.d;
+    extern __shared__ __attribute__((aligned(16))) unsigned char hsm[];   // the only LDS object
+    const int hbytes = a.h_rows * 64;
+    typedef const void __attribute__((address_space(1))) * gptr_t;
+    typedef void __attribute__((address_space(3))) * lptr_t;
+
+    const int tiles = a.tiles_m * a.tiles_n;
+    int tile_id, split_id;
+    {
+        const int nb = gridDim.x, bid = blockIdx.x;
+        const int q = nb >> 3, rr = nb & 7, xcd = bid & 7;
+        const int logical = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (bid >> 3);
+        split_id = logical / tiles;
+        tile_id = logical - split_id * tiles;
+    }
+    const int tm = tile_id % a.tiles_m, tn = tile_id / a.tiles_m;
+    const int co0 = tm * BM, ci0 = tn * 32;
+    const int c0 = split_id * a.h_cps, c1 = min(c0 + a.h_cps, a.h_chunks);
+    if (c0 >= c1) return;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / 3, wn = wave - wm * 3;
+    const f16* dz = reinterpret_cast<const f16*>(d.dz);
+    const f16* x = reinterpret_cast<const f16*>(d.x);
+    // the zero page's address as two SCALARS: a pointer select against it then costs no vector registers (the kernel sits at the
+    // 168-register cap; a spilled pointer would be reloaded by a scratch load, which drains the LDS-DMA queue - same counter)
+    const unsigned zlo = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)g_zero16);
+    const unsigned zhi = __builtin_amdgcn_readfirstlane((unsigned)((uintptr_t)g_zero16 >> 32));
+    auto pick = [&](bool ok, const f16* p) {
+        const unsigned long long u = (unsigned long long)(uintptr_t)p;
+        const unsigned lo = ok ? (unsigned)u : zlo, hi = ok ? (unsigned)(u >> 32) : zhi;
+        return ((unsigned long long)hi << 32) | lo;      // (an integer: a lambda returning an address-space pointer loses the host stub)
+    };
+    const int Wp = d.w_in + 1, IMG = (d.h + 1) * Wp;
+
+    // ---- pixel table.  Every virtual position this workgroup touches - its 256-pixel chunks plus a halo margin of W + 2 either
+    // side - is decoded ONCE into a 16-bit entry in LDS: real pixel index minus p_base, or 0xffff for a pad position / beyond the
+    // batch.  The LDS-DMA bookkeeping of a step is then a table read and a multiply per instruction instead of ~40 instructions
+    // of wrap arithmetic: a wave issues an instruction every ~4-5 cycles, and 150 instructions of bookkeeping per step in ONE
+    // group's interval cost 3 x 1200 cycles per step where the MFMAs need 3 x 384 (measured, profiles/r03_wgrad_halo.txt).
+    unsigned short* const tbl = reinterpret_cast<unsigned short*>(hsm + STAGES * A_BYTES + 2 * hbytes + 1024);
+    const int vstart = c0 * KP - Wp - 1;                       // virtual position of table entry 0
+    const int tbl_n = (c1 - c0) * KP + 2 * Wp + 2 + 16;        // + the rows that round the last halo image up to 16
+    int p_base;                                                // wave-uniform: first pixel of the image row vstart lies in
+    {
+        const int v = max(vstart, 0);
+        const int n = v / IMG;
+        const int yy = (v - n * IMG) / Wp;
+        p_base = (n * d.h + max(yy - 1, 0)) * d.w_in;
+    }
+    for (int t = tid; t < tbl_n; t += NT) {
+        const int v = vstart + t;
+        unsigned short e = 0xffffu;
+        if (v >= 0 && t < tbl_n - 16) {
+            const int n = v / IMG;
+            const int rem = v - n * IMG;
+            const int yy = rem / Wp, xx = rem - yy * Wp;
+            if (n < d.n && yy >= 1 && xx >= 1) e = (unsigned short)((n * d.h + yy - 1) * d.w_in + xx - 1 - p_base);
+        }
+        tbl[t] = e;
+    }
+    __syncthreads();       // no LDS-DMA is in flight yet: a plain barrier
+    const unsigned tbl_lds = (unsigned)(uintptr_t)(lptr_t)tbl;
+    auto lookup = [&](int idx) {       // table entry idx of this lane (inline asm: the compiler must not order it against the DMA queue)
+        unsigned e;
+        asm volatile("ds_read_u16 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(e) : "v"(tbl_lds + 2u * (unsigned)idx) : "memory");
+        return e;
+    };
+
+    // ---- dz loader: instruction q of a step covers pixel rows 2q, 2q+1 (512 B each); wave w issues q = w and, w < 4, q = w + 12
+    const bool two = wave < 4;                                                       // wave-uniform
+    int dz_idx = Wp + 1 + 2 * wave + (lane >> 5);       // table index of this lane's row in the step being issued
+    auto issue_dz = [&](int st) {
+        unsigned char* const base = hsm + st * A_BYTES;
+        const int hi = lane >> 5;
+        {
+            const unsigned e = lookup(dz_idx);
+            const unsigned off = (unsigned)(p_base + (int)e) * (unsigned)d.lddz + (unsigned)(co0 + (((lane & 31) ^ wg_swz<32>(2 * wave + hi)) << 3));
+            __builtin_amdgcn_global_load_lds((gptr_t)(uintptr_t)pick(e != 0xffffu, dz + off), (lptr_t)(base + wave * 1024), 16, 0, 0);
+        }
+        if (two) {
+            const unsigned e = lookup(dz_idx + 24);
+            const unsigned off = (unsigned)(p_base + (int)e) * (unsigned)d.lddz + (unsigned)(co0 + (((lane & 31) ^ wg_swz<32>(2 * (wave + 12) + hi)) << 3));
+            __builtin_amdgcn_global_load_lds((gptr_t)(uintptr_t)pick(e != 0xffffu, dz + off), (lptr_t)(base + (wave + 12) * 1024), 16, 0, 0);
+        }
+        dz_idx += BK;
+    };
+    // ---- halo loader: piece g = 16 rows x 64 B, lane -> row g 16 + (lane >> 2), LDS cell lane & 3 holding source cell
+    // (lane & 3) ^ 2 ((row >> 3) & 1); wave w issues pieces w, w + 12, ...; halo row j of chunk c is table entry (c - c0) KP + j
+    auto issue_halo = [&](int chunk, int i) {
+        const int h_cell = ((lane & 3) ^ (((lane >> 5) & 1) << 1)) * 8;
+        const int g = wave + NWAVES * i;                      // wave-uniform
+        const int j = g * 16 + (lane >> 2);
+        const bool in = g * 16 < a.h_rows;                    // wave-uniform: h_rows is a multiple of 16
+        const unsigned e = in ? lookup((chunk - c0) * KP + j) : 0xffffu;
+        const unsigned off = (unsigned)(p_base + (int)e) * (unsigned)d.ldx + (unsigned)(ci0 + h_cell);
+        unsigned char* dst = in ? hsm + STAGES * A_BYTES + (chunk & 1) * hbytes + g * 1024 : hsm + STAGES * A_BYTES + 2 * hbytes;
+        __builtin_amdgcn_global_load_lds((gptr_t)(uintptr_t)pick(e != 0xffffu, x + off), (lptr_t)dst, 16, 0, 0);
+    };
+
+    f32x4 acc[4][6];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 6; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // ---- fragment addressing (ds_read_b64_tr_b16: lane (q, g) supplies 4 consecutive channels of pixel row 8g + 4h + q/4 and
+    // receives 4 consecutive pixels of channel q of the 16-channel block)
+    const int q = lane & 15, g = lane >> 4;
+    const unsigned lds0 = (unsigned)(uintptr_t)(lptr_t)hsm;
+    unsigned a_addr0 = 0, b_addr[3][2];     // dz fragments: half 1 = half 0 + 4 rows (same permutation): immediate offset 2048
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int row = 8 * g + 4 * h + (q >> 2);
+        const int cha = wm * 64 + 4 * (q & 3);
+        if (h == 0) a_addr0 = row * (BM * 2) + ((((cha >> 3) ^ wg_swz<32>(row)) << 4) | ((cha & 7) * 2));
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+            const int hrow = row + wn * Wp + s;                 // tap (wn, s) of this wave
+            const int bit = (hrow >> 3) & 1;
+            // channel block 0 of the row; block 1 is the other 32-byte half (address ^ 32)
+            b_addr[s][h] = STAGES * A_BYTES + hrow * 64 + (((q & 3) >> 1) << 4) + ((q & 3) & 1) * 8 + 32 * bit;
+        }
+    }
+
+    // ---- K loop.  The 12 waves are three groups of one wave per SIMD (waves 0-3, 4-7, 8-11) that rotate through three roles,
+    // one barrier interval each: LOAD (20 transposed fragment reads + this wave's LDS-DMA issues + the counted wait), MFMA (24
+    // MFMAs), idle.  Group g runs g intervals behind group 0, so in every interval one group feeds the matrix pipes while
+    // another one reads: measured on the lock-step form (one barrier per step, everyone reads, then everyone multiplies), the
+    // read phase and the MFMA phase simply added up (MFMA busy 38 %, profiles/r03_wgrad_halo_ablation.txt).
+    const int nsteps = (c1 - c0) * SUBS;
+    const int nA = two ? 2 : 1;
+    const int grp = a.pp ? 0 : (wave >> 2);      // a.pp (profiling knob YH_WGRAD_HALO_NOSTAGGER): all groups in phase
+    auto wait_keep = [&](int keep) {      // counted wait with a run-time count: literal operands only
+        switch (keep) {
+            case 10: wg_wait_vmcnt<10>(); break;
+            case 9: wg_wait_vmcnt<9>(); break;
+            case 8: wg_wait_vmcnt<8>(); break;
+            case 7: wg_wait_vmcnt<7>(); break;
+            case 6: wg_wait_vmcnt<6>(); break;
+            case 5: wg_wait_vmcnt<5>(); break;
+            case 4: wg_wait_vmcnt<4>(); break;
+            case 3: wg_wait_vmcnt<3>(); break;
+            case 2: wg_wait_vmcnt<2>(); break;
+            case 1: wg_wait_vmcnt<1>(); break;
+            default: wg_wait_vmcnt<0>(); break;
+        }
+    };
+#define YH_WH_BARRIER()                      \
+    do {                                     \
+        __builtin_amdgcn_sched_barrier(0);   \
+        __builtin_amdgcn_s_barrier();        \
+        __builtin_amdgcn_sched_barrier(0);   \
+    } while (0)
+    if constexpr (ABL != 3) {
+#pragma unroll
+        for (int i = 0; i < LBW; ++i) issue_halo(c0, i);
+        for (int k = 0; k < STAGES - 1 && k < nsteps; ++k) issue_dz(k);
+        // steps 0, 1 and the halo image have landed when only the tiles of steps 2 .. 4 are in flight
+        wait_keep((nsteps > STAGES - 1 ? STAGES - 3 : max(0, nsteps - 2)) * nA);
+    }
+    YH_WH_BARRIER();
+    for (int k = 0; k < grp; ++k) YH_WH_BARRIER();      // stagger
+    int st_read = 0, st_write = STAGES - 1;
+    bool piece_before = false;        // a halo piece was issued in the previous step
+    for (int s = 0; s < nsteps; ++s) {
+        const int sub = s % SUBS, chunk = c0 + s / SUBS;
+        // ---- LOAD
+        const unsigned stage = lds0 + st_read * A_BYTES;
+        const unsigned hb = lds0 + (chunk & 1) * hbytes + sub * (BK * 64);
+        wg_v2i ra[4][2], rb[6][2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            ra[i][0] = ABL == 2 ? wg_v2i{(int)(stage + i), 0} : ds_read_tr16<0>(stage + (a_addr0 ^ (i << 5)));
+            ra[i][1] = ABL == 2 ? wg_v2i{(int)(stage + i), 1} : ds_read_tr16<2048>(stage + (a_addr0 ^ (i << 5)));
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+#pragma unroll
+            for (int sx = 0; sx < 3; ++sx) {
+                rb[2 * sx][h] = ABL == 2 ? wg_v2i{(int)hb, sx} : ds_read_tr16<0>(hb + b_addr[sx][h]);
+                rb[2 * sx + 1][h] = ABL == 2 ? wg_v2i{(int)hb + 1, sx} : ds_read_tr16<0>(hb + (b_addr[sx][h] ^ 32));
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(ra[0][0]), "+v"(ra[0][1]), "+v"(ra[1][0]), "+v"(ra[1][1]), "+v"(ra[2][0]), "+v"(ra[2][1]),
+                       "+v"(ra[3][0]), "+v"(ra[3][1]), "+v"(rb[0][0]), "+v"(rb[0][1]), "+v"(rb[1][0]), "+v"(rb[1][1]),
+                       "+v"(rb[2][0]), "+v"(rb[2][1]), "+v"(rb[3][0]), "+v"(rb[3][1]), "+v"(rb[4][0]), "+v"(rb[4][1]),
+                       "+v"(rb[5][0]), "+v"(rb[5][1])
+                     :
+                     : "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- MFMA
+        typedef int v4i __attribute__((ext_vector_type(4)));
+        f16x8 fa[4], fb[6];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const v4i t = {ra[i][0][0], ra[i][0][1], ra[i][1][0], ra[i][1][1]};
+            fa[i] = __builtin_bit_cast(f16x8, t);
+        }
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            const v4i t = {rb[j][0][0], rb[j][0][1], rb[j][1][0], rb[j][1][1]};
+            fb[j] = __builtin_bit_cast(f16x8, t);
+        }
+        if constexpr (ABL == 1) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) asm volatile("" ::"v"(fa[i]));
+#pragma unroll
+            for (int j = 0; j < 6; ++j) asm volatile("" ::"v"(fb[j]));
+        } else {
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 6; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+        }
+        YH_WH_BARRIER();
+        // ---- third interval (the other two groups read / multiply): this wave's LDS-DMA bookkeeping
+        if constexpr (ABL != 3) {
+            // tiles of step s + 5 into the stage step s - 1 was read from (its last reader, group 2, finished three intervals ago).
+            // Four steps (64 KB) stay in flight per CU: dz streams from HBM, and 16 B/clk at ~2 us of latency needs about that much
+            if (s + STAGES - 1 < nsteps) issue_dz(st_write);
+            const bool piece = sub < LBW && chunk + 1 < c1;
+            if (piece) issue_halo(chunk + 1, sub);
+            // this wave's share of step s + 2 (and everything older) has landed when only the tiles of steps s + 3 .. s + 5 and the
+            // halo pieces issued in this step and the previous one are still in flight: group 2 waits here two intervals before
+            // group 0 reads step s + 2, the barriers in between publish it
+            const int later = min(STAGES - 3, max(0, nsteps - 3 - s));
+            wait_keep(later * nA + (piece ? 1 : 0) + (piece_before ? 1 : 0));
+            piece_before = piece;
+        }
+        YH_WH_BARRIER();
+        st_read = st_read + 1 == STAGES ? 0 : st_read + 1;
+        st_write = st_write + 1 == STAGES ? 0 : st_write + 1;
+    }
+    for (int k = grp; k < 2; ++k) YH_WH_BARRIER();      // every wave has executed the same number of barriers
+#undef YH_WH_BARRIER
+
+    f32x4* part = reinterpret_cast<f32x4*>(d.ws) + ((long)split_id * tiles + tile_id) * (24 * NT);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 6; ++j) part[(i * 6 + j) * NT + tid] = acc[i][j];
+}
+
+// one thread per (tile, fragment, lane slot) and split group, as wgrad_reduce_kernel
+__global__ __launch_bounds__(768) void wgrad_halo_reduce_kernel(const WgradArgs a, int splits, int per_group) {
+    constexpr int NT = 768;
+    const yh_wgrad_desc& d = a.d;
+    const int tiles = a.tiles_m * a.tiles_n;
+    const int tile = blockIdx.x / 24, ij = blockIdx.x % 24;
+    const int i = ij / 6, j = ij % 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / 3, wn = wave - wm * 3;
+    const f32x4* part = reinterpret_cast<const f32x4*>(d.ws) + ((long)tile * 24 + ij) * NT + tid;
+    const long stride = (long)tiles * 24 * NT;
+    const int s0 = blockIdx.y * per_group, s1 = min(s0 + per_group, splits);
+    f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = v0, v2 = v0, v3 = v0;
+    int sp = s0;
+    for (; sp + 3 < s1; sp += 4) {
+        v0 += part[sp * stride];
+        v1 += part[(sp + 1) * stride];
+        v2 += part[(sp + 2) * stride];
+        v3 += part[(sp + 3) * stride];
+    }
+    for (; sp < s1; ++sp) v0 += part[sp * stride];
+    const f32x4 v = (v0 + v1) + (v2 + v3);
+    const int tm = tile % a.tiles_m, tn = tile / a.tiles_m;
+    const int tap = wn * 3 + (j >> 1);
+    const int ci = tn * 32 + (j & 1) * 16 + (lane & 15);
+    if (ci >= a.cin_w) return;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int co = tm * 256 + wm * 64 + i * 16 + 4 * (lane >> 4) + r;
+        if (co >= d.cout) continue;
+        float* dst = d.dw + ((long)co * a.cin_w + ci) * 9 + tap;
+        if (gridDim.y == 1) *dst += v[r];
+        else atomicAdd(dst, v[r]);
+    }
+}
+
 template <typename T>
 __global__ void nchw_to_nhwc_kernel(const float* x, T* y, int n, int c, int h, int w, int c_pad, int ldy) {
     const long total = (long)n * h * w;
@@ -904,11 +1214,60 @@ static bool wgrad_big_default(const yh_wgrad_desc* d, int ncols) {
     return false;   // see the measurement above
 }
 
-static void wgrad_geometry(const yh_wgrad_desc* d, WgradArgs* pa, int* psplits) {
+// geometry of the 3x3 halo form (conv_wgrad_halo_kernel); false when the layer does not qualify
+static bool wgrad_halo_geometry(const yh_wgrad_desc* d, WgradArgs* pa, int* psplits, size_t* plds) {
+    WgradArgs& a = *pa;
+    // OFF by default (YH_WGRAD_HALO=1 enables it): measured on MI355X it does not beat the im2col kernel yet - 690 / 759 / 707 vs
+    // 745 / 836 / 726 TFLOP/s on the 76 / 38 / 19 grids - although its compute side alone (LDS-DMA ablated) runs at 1550: the
+    // LDS-DMA stream of a 12-wave, one-workgroup-per-CU kernel does not keep up (profiles/r03_wgrad_halo.txt)
+    const char* mode_env = getenv("YH_WGRAD_HALO");
+    const int mode = mode_env ? atoi(mode_env) : 0;
+    if (!mode || d->dtype != YH_F16 || d->splits == -1) return false;
+    if (d->kh != 3 || d->kw != 3 || d->stride != 1 || d->pad != 1 || d->ho != d->h || d->wo != d->w_in) return false;
+    if (d->cout % 256 || d->cin % 32 || d->w_in < 16) return false;
+    const int Wp = d->w_in + 1;
+    const int rows_hp = ((256 + 2 * Wp + 2 + 15) / 16) * 16;
+    const int lbw = (rows_hp / 16 + 11) / 12;
+    if (lbw < 2 || lbw > 4) return false;
+    const long Q = (long)d->n * (d->h + 1) * Wp;
+    if (Q + 4096 >= 0x7fffffffL) return false;
+    a.halo = 1;
+    { const char* e = getenv("YH_WGRAD_HALO_NOSTAGGER"); a.pp = e && atoi(e) ? 1 : 0; }
+    a.h_rows = rows_hp;
+    a.h_lbw = lbw;
+    a.h_chunks = (int)((Q + 255) / 256);
+    a.bm = 256;
+    a.bn = 288;
+    a.tiles_m = d->cout / 256;
+    a.tiles_n = d->cin / 32;
+    const int tiles = a.tiles_m * a.tiles_n;
+    int splits = d->splits > 0 ? d->splits : 256 / tiles;      // one workgroup per CU (134 KB of LDS, 12 waves)
+    { const char* e = getenv("YH_WGRAD_HALO_WGS"); if (e && d->splits <= 0) splits = atoi(e) / tiles; }
+    if (splits < 1) splits = 1;
+    if (splits > a.h_chunks) splits = a.h_chunks;
+    a.h_cps = (a.h_chunks + splits - 1) / splits;
+    *psplits = (a.h_chunks + a.h_cps - 1) / a.h_cps;
+    // 5-stage dz ring + two halo images + sink + the 16-bit pixel table of one split (entries are relative to its first image row)
+    const size_t tbl = (((size_t)a.h_cps * 256 + 2 * Wp + 2 + 16) * 2 + 15) & ~(size_t)15;
+    const size_t lds = (size_t)5 * 16384 + (size_t)2 * rows_hp * 64 + 1024 + tbl;
+    if (lds > 160 * 1024 || (long)a.h_cps * 256 + 4L * Wp + 8 >= 65535) { a.halo = 0; return false; }
+    *plds = lds;
+    return true;
+}
+
+static void wgrad_geometry(const yh_wgrad_desc* d, WgradArgs* pa, int* psplits, bool allow_halo = true) {
     WgradArgs& a = *pa;
     const int bk = d->dtype == YH_F16 ? 32 : 16;
     a.d = *d;
     a.pp = 0;
+    a.halo = 0;
+    a.cin_w = d->cin_w > 0 ? d->cin_w : d->cin;
+    a.two_stage = 0;
+    a.dma = d->dtype == YH_F16 && d->splits != -1;
+    a.ncols = d->kh * d->kw * d->cin;
+    a.pixels = (long)d->n * d->ho * d->wo;
+    a.xcd_splits = 0;
+    { size_t lds; if (allow_halo && wgrad_halo_geometry(d, pa, psplits, &lds)) return; }
     a.pixels = (long)d->n * d->ho * d->wo;
     int bm = d->cout <= 64 ? 64 : WG_TILE;        // 64-row tiles for the early, wide-resolution layers
     a.ncols = d->kh * d->kw * d->cin;
@@ -998,11 +1357,44 @@ extern "C" int yh_conv2d_wgrad(const yh_wgrad_desc* d, void* stream) {
     WgradArgs a;
     int splits;
     wgrad_geometry(d, &a, &splits);
+    hipStream_t st = (hipStream_t)stream;
+    if (a.halo) {
+        const int htiles = a.tiles_m * a.tiles_n;
+        if (d->ws && d->ws_floats >= (int64_t)splits * htiles * a.bm * a.bn) {
+            size_t lds;
+            int s2;
+            wgrad_halo_geometry(d, &a, &s2, &lds);
+            a.two_stage = 1;
+            static bool raised[3] = {false, false, false};   // LBW 2, 3, 4
+#define YH_WH_CASE(L)                                                                                                          \
+            case L: {                                                                                                          \
+                auto kern = conv_wgrad_halo_kernel<L>;                                                                         \
+                if (!raised[L - 2]) {                                                                                          \
+                    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+                    if (e != hipSuccess) return (int)e;                                                                        \
+                    raised[L - 2] = true;                                                                                      \
+                }                                                                                                              \
+                hipLaunchKernelGGL(kern, dim3((unsigned)(htiles * splits)), dim3(768), lds, st, a);                            \
+                break;                                                                                                         \
+            }
+            switch (a.h_lbw) {
+                YH_WH_CASE(2) YH_WH_CASE(3) YH_WH_CASE(4)
+                default: return YH_EUNSUPPORTED;
+            }
+#undef YH_WH_CASE
+            int groups = (splits + 15) / 16;
+            if (groups > 32) groups = 32;
+            const int per_group = (splits + groups - 1) / groups;
+            groups = (splits + per_group - 1) / per_group;
+            hipLaunchKernelGGL(wgrad_halo_reduce_kernel, dim3(htiles * 24, groups), dim3(768), 0, st, a, splits, per_group);
+            return check_launch();
+        }
+        wgrad_geometry(d, &a, &splits, false);   // no workspace for the partial tiles: the im2col form
+    }
     const int tiles = a.tiles_m * a.tiles_n;
     const bool narrow = d->cout <= 64;
     a.two_stage = d->ws && d->ws_floats >= (int64_t)splits * tiles * a.bm * a.bn;
     dim3 grid(tiles, splits);
-    hipStream_t st = (hipStream_t)stream;
     a.xcd_splits = 0;
     if (a.dma && splits >= 2 && wgrad_xcd_mapping()) {
         a.xcd_splits = splits;
