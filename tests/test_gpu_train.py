@@ -114,8 +114,7 @@ WGRAD_CASES = [
     (2, 18, 18, 24, 40, 3, 1, 0, 0),        # 64-row tile, 216 flattened (tap, ci) columns
     (2, 16, 16, 64, 32, 1, 1, 0, 0),
     (1, 38, 38, 32, 64, 3, 2, 8, 8),
-    # shapes the 3x3 / s1 halo form takes when YH_WGRAD_HALO=1 (fp16 with a workspace, cout % 256 == 0, cin % 32 == 0, W >= 16);
-    # test_wgrad_halo_form_is_exact_on_small_integers runs them through it, here they take the default kernels
+    # 3x3 / s1 halo form (fp16 with a workspace, cout % 256 == 0, cin % 32 == 0, 16 <= W <= 126; otherwise the im2col kernels)
     (2, 20, 20, 64, 256, 3, 1, 0, 0),
     (3, 19, 19, 32, 256, 3, 1, 0, 0),
     (1, 38, 38, 128, 512, 3, 1, 0, 0),
@@ -185,7 +184,6 @@ def test_wgrad_halo_form_is_exact_on_small_integers(libs, monkeypatch, case, wgs
     if DRY:
         pytest.skip('kernel-only property')
     lib, _ = libs
-    monkeypatch.setenv('YH_WGRAD_HALO', '1')      # the halo form is an opt-in (slower than the im2col kernel so far)
     if wgs:
         monkeypatch.setenv('YH_WGRAD_HALO_WGS', wgs)
     N, H, W, cin, cout = case

@@ -253,14 +253,30 @@ def test_cosine_search_kernel_against_the_reference_loop():
     cases.append((torch.randn(2, 20, 20, 24, generator=g) * 2).permute(0, 3, 1, 2))     # NHWC-backed NCHW view (dense, not contiguous)
     cases.append(torch.randn(4099, generator=g)[3:])                                     # 4-byte aligned only
     cases.append(torch.zeros(2, 8, 4, 4))                                                # all zero: every cosine 0, first candidate wins
+    def exact_cosines(t, first, n, bits):
+        """The candidates' cosines with the modules' fp32 element arithmetic and float64 sums (what the kernel computes)."""
+        out = []
+        for j in range(n):
+            scale = torch.zeros(1).add_(2 ** (first + j)) / float(1 << (bits - 1))
+            qd = q._fake_quant(t, scale, bits).double().reshape(-1)
+            td = t.double().reshape(-1)
+            nq, nt = float(qd.norm()), float(td.norm())
+            out.append(float(td @ qd) / (nt * nq) if nt > 0 and nq > 0 else 0.0)
+        return out
+
     for t in cases:
         for first, n, bits in ((-5, 15, 8), (0, 8, 8)):
-            want_j, want_cos = q._search(t, first, n, bits)
+            loop_j, loop_cos = q._search(t, first, n, bits)             # the reference's loop: fp32 sums (torch.cosine_similarity)
+            loop_cos = [float(c) for c in loop_cos]
+            want_cos = exact_cosines(t, first, n, bits)
             got_j, got_cos = calib.cos_search(t.cuda(), 2.0 ** first / 128.0, n, bits)
-            want_cos = [float(c) for c in want_cos]
-            assert max(abs(a - b) for a, b in zip(got_cos, want_cos)) <= 2e-6, (tuple(t.shape), first)
-            if got_j != want_j:     # only a near-tie of the fp32 loop may decide differently
-                assert abs(want_cos[got_j] - want_cos[want_j]) <= 2e-6, (tuple(t.shape), first, got_j, want_j)
+            # the kernel against the exact sums: double round-off only
+            assert max(abs(a - b) for a, b in zip(got_cos, want_cos)) <= 1e-10, (tuple(t.shape), first)
+            assert got_j == max(range(n), key=lambda j: (want_cos[j], -j)), (tuple(t.shape), first)
+            # the fp32 loop itself is only accurate to its summation noise (measured: up to 6e-5 on 170 k elements); when it picks
+            # another candidate, the two must tie to within that noise
+            if got_j != loop_j:
+                assert abs(want_cos[got_j] - want_cos[loop_j]) <= 2e-4, (tuple(t.shape), first, got_j, loop_j)
     t = torch.randn(3, 40, 17, 9, generator=g) * 5
     assert float(calib.absmax(t.cuda())) == float(t.abs().max())
 

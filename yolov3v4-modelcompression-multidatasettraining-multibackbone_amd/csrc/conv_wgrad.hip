@@ -746,7 +746,10 @@ __global__ __launch_bounds__(768, 3) void conv_wgrad_halo_kernel(const WgradArgs
     };
 
     // ---- dz loader: instruction q of a step covers pixel rows 2q, 2q+1 (512 B each); wave w issues q = w and, w < 4, q = w + 12
-    const bool two = wave < 4;                                                       // wave-uniform
+    // Roles: waves 0 .. 7 stream dz (two instructions each per step), waves 8 .. 11 fetch the halo images - the counter that
+    // orders a wave's LDS-DMA returns is in-order, and a 16-row halo piece (16 scattered half lines) in front of the dz tiles
+    // held their counted wait up
+    const bool dz_wave = wave < 8;                                                   // wave-uniform
     int dz_idx = Wp + 1 + 2 * wave + (lane >> 5);       // table index of this lane's row in the step being issued
     auto issue_dz = [&](int st) {
         unsigned char* const base = hsm + st * A_BYTES;
@@ -756,18 +759,18 @@ __global__ __launch_bounds__(768, 3) void conv_wgrad_halo_kernel(const WgradArgs
             const unsigned off = (unsigned)(p_base + (int)e) * (unsigned)d.lddz + (unsigned)(co0 + (((lane & 31) ^ wg_swz<32>(2 * wave + hi)) << 3));
             __builtin_amdgcn_global_load_lds((gptr_t)(uintptr_t)pick(e != 0xffffu, dz + off), (lptr_t)(base + wave * 1024), 16, 0, 0);
         }
-        if (two) {
-            const unsigned e = lookup(dz_idx + 24);
-            const unsigned off = (unsigned)(p_base + (int)e) * (unsigned)d.lddz + (unsigned)(co0 + (((lane & 31) ^ wg_swz<32>(2 * (wave + 12) + hi)) << 3));
-            __builtin_amdgcn_global_load_lds((gptr_t)(uintptr_t)pick(e != 0xffffu, dz + off), (lptr_t)(base + (wave + 12) * 1024), 16, 0, 0);
+        {
+            const unsigned e = lookup(dz_idx + 16);
+            const unsigned off = (unsigned)(p_base + (int)e) * (unsigned)d.lddz + (unsigned)(co0 + (((lane & 31) ^ wg_swz<32>(2 * (wave + 8) + hi)) << 3));
+            __builtin_amdgcn_global_load_lds((gptr_t)(uintptr_t)pick(e != 0xffffu, dz + off), (lptr_t)(base + (wave + 8) * 1024), 16, 0, 0);
         }
         dz_idx += BK;
     };
     // ---- halo loader: piece g = 16 rows x 64 B, lane -> row g 16 + (lane >> 2), LDS cell lane & 3 holding source cell
-    // (lane & 3) ^ 2 ((row >> 3) & 1); wave w issues pieces w, w + 12, ...; halo row j of chunk c is table entry (c - c0) KP + j
+    // (lane & 3) ^ 2 ((row >> 3) & 1); wave 8 + w issues pieces w, w + 4, ...; halo row j of chunk c is table entry (c - c0) KP + j
     auto issue_halo = [&](int chunk, int i) {
         const int h_cell = ((lane & 3) ^ (((lane >> 5) & 1) << 1)) * 8;
-        const int g = wave + NWAVES * i;                      // wave-uniform
+        const int g = (wave - 8) + 4 * i;                     // wave-uniform
         const int j = g * 16 + (lane >> 2);
         const bool in = g * 16 < a.h_rows;                    // wave-uniform: h_rows is a multiple of 16
         const unsigned e = in ? lookup((chunk - c0) * KP + j) : 0xffffu;
@@ -807,7 +810,7 @@ __global__ __launch_bounds__(768, 3) void conv_wgrad_halo_kernel(const WgradArgs
     // another one reads: measured on the lock-step form (one barrier per step, everyone reads, then everyone multiplies), the
     // read phase and the MFMA phase simply added up (MFMA busy 38 %, profiles/r03_wgrad_halo_ablation.txt).
     const int nsteps = (c1 - c0) * SUBS;
-    const int nA = two ? 2 : 1;
+    const int nA = 2;
     const int grp = a.pp ? 0 : (wave >> 2);      // a.pp (profiling knob YH_WGRAD_HALO_NOSTAGGER): all groups in phase
     auto wait_keep = [&](int keep) {      // counted wait with a run-time count: literal operands only
         switch (keep) {
@@ -831,16 +834,19 @@ __global__ __launch_bounds__(768, 3) void conv_wgrad_halo_kernel(const WgradArgs
         __builtin_amdgcn_sched_barrier(0);   \
     } while (0)
     if constexpr (ABL != 3) {
+        if (dz_wave) {
+            for (int k = 0; k < STAGES - 1 && k < nsteps; ++k) issue_dz(k);
+            // steps 0 and 1 have landed when only the tiles of steps 2, 3 are in flight
+            wait_keep((nsteps > STAGES - 1 ? STAGES - 3 : max(0, nsteps - 2)) * nA);
+        } else {
 #pragma unroll
-        for (int i = 0; i < LBW; ++i) issue_halo(c0, i);
-        for (int k = 0; k < STAGES - 1 && k < nsteps; ++k) issue_dz(k);
-        // steps 0, 1 and the halo image have landed when only the tiles of steps 2 .. 4 are in flight
-        wait_keep((nsteps > STAGES - 1 ? STAGES - 3 : max(0, nsteps - 2)) * nA);
+            for (int i = 0; i < 8; ++i) issue_halo(c0, i);
+            wait_keep(0);
+        }
     }
     YH_WH_BARRIER();
     for (int k = 0; k < grp; ++k) YH_WH_BARRIER();      // stagger
     int st_read = 0, st_write = STAGES - 1;
-    bool piece_before = false;        // a halo piece was issued in the previous step
     for (int s = 0; s < nsteps; ++s) {
         const int sub = s % SUBS, chunk = c0 + s / SUBS;
         // ---- LOAD
@@ -902,15 +908,21 @@ __global__ __launch_bounds__(768, 3) void conv_wgrad_halo_kernel(const WgradArgs
         if constexpr (ABL != 3) {
             // tiles of step s + 5 into the stage step s - 1 was read from (its last reader, group 2, finished three intervals ago).
             // Four steps (64 KB) stay in flight per CU: dz streams from HBM, and 16 B/clk at ~2 us of latency needs about that much
-            if (s + STAGES - 1 < nsteps) issue_dz(st_write);
-            const bool piece = sub < LBW && chunk + 1 < c1;
-            if (piece) issue_halo(chunk + 1, sub);
-            // this wave's share of step s + 2 (and everything older) has landed when only the tiles of steps s + 3 .. s + 5 and the
-            // halo pieces issued in this step and the previous one are still in flight: group 2 waits here two intervals before
-            // group 0 reads step s + 2, the barriers in between publish it
-            const int later = min(STAGES - 3, max(0, nsteps - 3 - s));
-            wait_keep(later * nA + (piece ? 1 : 0) + (piece_before ? 1 : 0));
-            piece_before = piece;
+            if (dz_wave) {
+                // tiles of step s + 4 into the stage step s - 1 was read from (its last reader, group 2, finished three intervals
+                // ago).  (Issuing them in the LOAD segment instead - two more intervals to land - measured slower: the segment
+                // that the other groups' MFMAs have to cover grows by ~25 instructions.)
+                if (s + STAGES - 1 < nsteps) issue_dz(st_write);
+                // this wave's share of step s + 2 (and everything older) has landed when only the tiles of steps s + 3, s + 4 are
+                // still in flight: group 1 waits here two intervals before group 0 reads step s + 2, the barriers in between
+                // publish it.  (Letting group 0 wait for step s + 1 only - it reads it in the next interval - measured 6 % slower.)
+                wait_keep(min(STAGES - 3, max(0, nsteps - 3 - s)) * nA);
+            } else if (chunk + 1 < c1) {
+                // the next chunk's halo image: two pieces per wave in each of the chunk's first four steps, complete (and published
+                // by the following barriers) well before the chunk's last step ends
+                if (sub < 4) { issue_halo(chunk + 1, 2 * sub); issue_halo(chunk + 1, 2 * sub + 1); }
+                if (sub == 6) wait_keep(0);
+            }
         }
         YH_WH_BARRIER();
         st_read = st_read + 1 == STAGES ? 0 : st_read + 1;
@@ -1217,18 +1229,17 @@ static bool wgrad_big_default(const yh_wgrad_desc* d, int ncols) {
 // geometry of the 3x3 halo form (conv_wgrad_halo_kernel); false when the layer does not qualify
 static bool wgrad_halo_geometry(const yh_wgrad_desc* d, WgradArgs* pa, int* psplits, size_t* plds) {
     WgradArgs& a = *pa;
-    // OFF by default (YH_WGRAD_HALO=1 enables it): measured on MI355X it does not beat the im2col kernel yet - 690 / 759 / 707 vs
-    // 745 / 836 / 726 TFLOP/s on the 76 / 38 / 19 grids - although its compute side alone (LDS-DMA ablated) runs at 1550: the
-    // LDS-DMA stream of a 12-wave, one-workgroup-per-CU kernel does not keep up (profiles/r03_wgrad_halo.txt)
+    // On by default (YH_WGRAD_HALO=0 disables it): 807 / 916 / 856 vs 759 / 861 / 740 TFLOP/s for the im2col kernel on the
+    // 76 / 38 / 19 grids at batch 64 (profiles/r03_wgrad_halo.txt); its compute side alone (LDS-DMA ablated) runs at 1550
     const char* mode_env = getenv("YH_WGRAD_HALO");
-    const int mode = mode_env ? atoi(mode_env) : 0;
+    const int mode = mode_env ? atoi(mode_env) : 1;
     if (!mode || d->dtype != YH_F16 || d->splits == -1) return false;
     if (d->kh != 3 || d->kw != 3 || d->stride != 1 || d->pad != 1 || d->ho != d->h || d->wo != d->w_in) return false;
     if (d->cout % 256 || d->cin % 32 || d->w_in < 16) return false;
     const int Wp = d->w_in + 1;
     const int rows_hp = ((256 + 2 * Wp + 2 + 15) / 16) * 16;
     const int lbw = (rows_hp / 16 + 11) / 12;
-    if (lbw < 2 || lbw > 4) return false;
+    if (lbw < 2 || lbw > 4 || rows_hp > 512) return false;     // the four halo waves fetch 32 pieces per chunk
     const long Q = (long)d->n * (d->h + 1) * Wp;
     if (Q + 4096 >= 0x7fffffffL) return false;
     a.halo = 1;
