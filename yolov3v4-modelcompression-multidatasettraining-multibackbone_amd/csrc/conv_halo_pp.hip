@@ -164,21 +164,28 @@ template <int T9, int LB> struct HppAllow {
     static constexpr int value = T9 == 8 ? 2 : 2 + in(T9 - 2) + in(T9 - 1) + in(T9);
 };
 
-// PH = phases per K step: 2 = two 16-MFMA segments per wave (8 + 4 fragment reads), 1 = one 32-MFMA segment (12 reads): the
-// loading group then has 512 cycles of its partner's MFMAs to hide its read latency under, and a K step costs two barriers.
-template <typename T, int LB, int PH>
+// ROLE = how the LDS-DMA issue is shared out.  0: every wave issues one 16-row weight piece per K step and one halo piece per tap
+// (taps 0 .. LB-1).  1: the waves of group 0 issue the weight tiles (two pieces each per step), the waves of group 1 the halo images
+// (two pieces each per tap in taps 0 .. 5, offsets from a table in LDS).  A wave's LDS-DMA returns are counted IN ORDER, so with
+// ROLE 0 a 16-row halo piece (16 scattered half lines, slow) in front of the weight pieces holds every counted wait for the next
+// weight tile up - the weight-gradient halo kernel gained 20 % from separating the two streams (profiles/r03_wgrad_halo.txt).
+template <typename T, int LB, int ROLE>
 __global__ __launch_bounds__(512, 2) void conv3x3_hpp_kernel(const ConvArgs a, const int rows_hp, const int hbufs) {
     constexpr int VEC = Prec<T>::VEC, BK = VEC * 4;       // one 64-byte chunk per row per K step: 32 f16 / 64 int8 channels
     constexpr int BM = 128, BN = 512, TM = 8, TN = 4, NW = 8, SA = 4;
     constexpr int A_CELLS = BM * 4;
+    constexpr int LBR = ROLE ? 1 : LB;                    // per-lane halo offsets held in registers (ROLE 1: none, see the table)
     static_assert(sizeof(T) <= 2, "f16 / int8");
     typedef typename HppMma<T>::frag_t frag_t;
     typedef typename AccOf<T>::type acc_t;
+    typedef const void __attribute__((address_space(1))) * gptr_t;
+    typedef void __attribute__((address_space(3))) * lptr_t;
 
     extern __shared__ __attribute__((aligned(16))) u32x4 hsm[];   // the only LDS object of the kernel
     u32x4* const Aring = hsm;                                     // [SA][128 rows x 4 cells]
     u32x4* const Hbuf = hsm + SA * A_CELLS;                       // [hbufs][rows_hp x 4 cells]
     u32x4* const dummy = Hbuf + hbufs * rows_hp * 4;              // [64] sink of the pieces beyond the image
+    int* const htab = reinterpret_cast<int*>(dummy + 64);         // ROLE 1: [rows_hp] element offset of halo row j, or -1
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -202,37 +209,67 @@ __global__ __launch_bounds__(512, 2) void conv3x3_hpp_kernel(const ConvArgs a, c
     const int lrow = lane >> 2;
     const int lu = (lane & 3) ^ (((lane >> 4) & 1) << 1);
     const T* const xg = reinterpret_cast<const T*>(a.x);
-    const T* const zero = reinterpret_cast<const T*>(g_zero_page);
-    const T* const wsrc = reinterpret_cast<const T*>(a.w) + (long)min(m0 + wave * 16 + lrow, a.m_pad - 1) * a.ktot + lu * VEC;
-    int boff[LB];    // element offset of this lane's source cell in halo piece i, or -1: padding / beyond the batch
-    {
-        const int v0 = (int)q0 - Wp - 1;      // the launcher keeps the whole virtual space below 2^31
+    // weight piece of this wave: ROLE 0 rows 16 wave .., ROLE 1 (group 0 only) rows 32 wave .. and 16 further
+    const int wrow = (ROLE ? 2 * (wave & 3) : wave) * 16 + lrow;
+    const T* const wsrc = reinterpret_cast<const T*>(a.w) + (long)min(m0 + wrow, a.m_pad - 1) * a.ktot + lu * VEC;
+    const int wsrc2 = (min(m0 + wrow + 16, a.m_pad - 1) - min(m0 + wrow, a.m_pad - 1)) * a.ktot;   // ROLE 1: second piece (elements)
+    auto halo_offset = [&](int j) {      // element offset of halo row j (channel 0), or -1: padding / beyond the batch
+        const int v = (int)q0 - Wp - 1 + j;      // the launcher keeps the whole virtual space below 2^31
+        int off = -1;
+        if (j < rows_hp && v >= 0) {
+            const int n = v / IMG;
+            const int rem = v - n * IMG;
+            const int yy = rem / Wp, xx = rem - yy * Wp;
+            if (n < a.N && yy >= 1 && xx >= 1) off = ((n * a.H + yy - 1) * a.W + xx - 1) * a.ldx;
+        }
+        return off;
+    };
+    int boff[LBR];
+    if constexpr (ROLE == 0) {
         static_for<LB>([&](auto c) {
             constexpr int i = decltype(c)::value;
-            const int j = (wave + i * NW) * 16 + lrow;
-            const int v = v0 + j;
-            int off = -1;
-            if (j < rows_hp && v >= 0) {
-                const int n = v / IMG;
-                const int rem = v - n * IMG;
-                const int yy = rem / Wp, xx = rem - yy * Wp;
-                if (n < a.N && yy >= 1 && xx >= 1) off = ((n * a.H + yy - 1) * a.W + xx - 1) * a.ldx + lu * VEC;
-            }
-            boff[i] = off;
+            boff[i] = halo_offset((wave + i * NW) * 16 + lrow);
         });
+    } else {
+        boff[0] = 0;
+        for (int j = threadIdx.x; j < rows_hp; j += 512) htab[j] = halo_offset(j);
+        __syncthreads();       // no LDS-DMA in flight yet: a plain barrier
     }
+    const unsigned htab_lds = (unsigned)(uintptr_t)(lptr_t)htab;
     auto issue_a = [&](int stage, int tap, int kc) {
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc + (tap * a.cin_k + kc)),
-                                         (__attribute__((address_space(3))) void*)(Aring + stage * A_CELLS + wave * 64), 16, 0, 0);
+        if constexpr (ROLE == 0) {
+            __builtin_amdgcn_global_load_lds((gptr_t)(wsrc + (tap * a.cin_k + kc)), (lptr_t)(Aring + stage * A_CELLS + wave * 64), 16, 0, 0);
+        } else {
+            const T* const src = wsrc + (tap * a.cin_k + kc);
+            u32x4* const dst = Aring + stage * A_CELLS + (wave & 3) * 128;
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)dst, 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)(src + wsrc2), (lptr_t)(dst + 64), 16, 0, 0);
+        }
     };
-    auto issue_h = [&](int buf, int kc, auto ic) {      // piece i of this wave for the chunk at channel offset kc
-        constexpr int i = decltype(ic)::value;
-        const int g = wave + i * NW;                    // wave-uniform
-        const bool ok = boff[i] >= 0 && kc + lu * VEC < a.Cin;
-        const T* src = ok ? xg + (boff[i] + kc) : zero;
+    // the zero page's address as two scalars: the pointer select then holds no vector registers (a spilled value inside the K
+    // loop is reloaded by a scratch load, which drains the LDS-DMA queue: same counter)
+    const unsigned zlo = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)g_zero_page);
+    const unsigned zhi = __builtin_amdgcn_readfirstlane((unsigned)((uintptr_t)g_zero_page >> 32));
+    auto issue_piece = [&](int buf, int kc, int g, int off) {     // halo piece g (wave-uniform), this lane's row offset `off`
+        const bool ok = off >= 0 && kc + lu * VEC < a.Cin;
+        const unsigned long long u = (unsigned long long)(uintptr_t)(xg + (off + kc + lu * VEC));
+        const unsigned lo = ok ? (unsigned)u : zlo, hi = ok ? (unsigned)(u >> 32) : zhi;
         u32x4* dst = (g * 16 < rows_hp) ? Hbuf + buf * (rows_hp * 4) + g * 64 : dummy;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                         (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t)(uintptr_t)(((unsigned long long)hi << 32) | lo), (lptr_t)dst, 16, 0, 0);
+    };
+    auto issue_h = [&](int buf, int kc, auto ic) {      // ROLE 0: piece i of this wave for the chunk at channel offset kc
+        constexpr int i = decltype(ic)::value;
+        issue_piece(buf, kc, wave + i * NW, boff[i < LBR ? i : 0]);
+    };
+    auto issue_h2 = [&](int buf, int kc, int i) {       // ROLE 1 (group 1): pieces 2i, 2i+1 of this wave: g = (wave - 4) + 4 (2i + k)
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int g = (wave & 3) + 4 * (2 * i + k);
+            const int j = min(g * 16 + lrow, rows_hp - 1);
+            int off;   // inline asm: an ordinary LDS load would be ordered against the LDS-DMA queue by the compiler
+            asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(off) : "v"(htab_lds + 4u * (unsigned)j) : "memory");
+            issue_piece(buf, kc, g, off);
+        }
     };
 
     acc_t acc[TM][TN];
@@ -245,12 +282,12 @@ __global__ __launch_bounds__(512, 2) void conv3x3_hpp_kernel(const ConvArgs a, c
     // permutation bit of a row only depends on r16 there.  Halo: row wave 64 + j 16 + r16 + tapoff, whose bit depends on r16 + tapoff.
     const int r16 = lane & 15, kq = lane >> 4;
     const int a_off = r16 * 4 + (kq ^ (((r16 >> 2) & 1) << 1));
-    frag_t fa[PH == 1 ? 8 : 4], fb[4];
+    frag_t fa[4], fb[4];
     auto read_a = [&](const u32x4* st, int half) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             u32x4 v = st[(half * 64 + i * 16) * 4 + a_off];
-            fa[PH == 1 ? half * 4 + i : i] = *reinterpret_cast<frag_t*>(&v);
+            fa[i] = *reinterpret_cast<frag_t*>(&v);
         }
     };
     auto read_b = [&](const u32x4* hb, int tapoff) {
@@ -268,7 +305,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_hpp_kernel(const ConvArgs a, c
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[h * 4 + i][j] = HppMma<T>::mma(fa[PH == 1 ? h * 4 + i : i], fb[j], acc[h * 4 + i][j]);
+            for (int j = 0; j < 4; ++j) acc[h * 4 + i][j] = HppMma<T>::mma(fa[i], fb[j], acc[h * 4 + i][j]);
         __builtin_amdgcn_s_setprio(0);
     };
     typedef std::integral_constant<int, 0> H0;
@@ -294,11 +331,21 @@ __global__ __launch_bounds__(512, 2) void conv3x3_hpp_kernel(const ConvArgs a, c
     const int nchunks = a.cin_k / BK;
     const int nk = 9 * nchunks;
     // ---- prologue: halo image of chunk 0, weight tiles of steps 0 .. 2; steps 1 and 2 stay in flight
-    static_for<LB>([&](auto ic) { issue_h(0, 0, ic); });
-    issue_a(0, 0, 0);
-    issue_a(1, 1, 0);
-    issue_a(2, 2, 0);
-    wait_vmcnt<2>();
+    if constexpr (ROLE == 0) {
+        static_for<LB>([&](auto ic) { issue_h(0, 0, ic); });
+        issue_a(0, 0, 0);
+        issue_a(1, 1, 0);
+        issue_a(2, 2, 0);
+        wait_vmcnt<2>();
+    } else if (group == 0) {
+        issue_a(0, 0, 0);
+        issue_a(1, 1, 0);
+        issue_a(2, 2, 0);
+        wait_vmcnt<4>();
+    } else {
+        for (int i = 0; i < 6; ++i) issue_h2(0, 0, i);
+        wait_vmcnt<0>();
+    }
     YH_HPP_BARRIER();
     if (group == 1) YH_HPP_BARRIER();   // stagger: group 1 runs one barrier interval behind group 0
 
@@ -306,7 +353,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_hpp_kernel(const ConvArgs a, c
     int st_r = 0, st_w = 3;      // ring stage of step s / of step s + 3
     int ptap = 3, pkc = 0;       // tap / channel offset of step s + 3
     for (int c = 0; c < nchunks; ++c) {
-        const bool more_h = c + 1 < nchunks;      // the next chunk's halo image is fetched during this chunk (LB <= 7 then)
+        const bool more_h = c + 1 < nchunks;      // the next chunk's halo image is fetched during this chunk
         const u32x4* const hb = Hbuf + (c & (hbufs - 1)) * (rows_hp * 4);
         const int nbuf = (c + 1) & 1, nkc = (c + 1) * BK;
         static_for<9>([&](auto tc) {
@@ -314,34 +361,28 @@ __global__ __launch_bounds__(512, 2) void conv3x3_hpp_kernel(const ConvArgs a, c
             const u32x4* const st = Aring + st_r * A_CELLS;
             const int tapoff = (t / 3) * Wp + (t % 3);
             constexpr int allow = HppAllow<t, LB>::value;   // (a comma inside <> would split the macro argument)
-            if constexpr (PH == 2) {
-                // ---- phase X: channels 0 .. 63 of the tile x this wave's 64 pixels; weight tile of step s + 3 into the stage that
-                // step s - 1 was read from (both groups are past its last read: the barrier that ended the previous interval)
-                YH_HPP_PHASE({ read_a(st, 0); read_b(hb, tapoff); if (s + 3 < nk) issue_a(st_w, ptap, pkc); }, mma(H0{}));
-                // ---- phase Y: channels 64 .. 127; one piece of the next halo image; then this wave's share of step s + 1 (and of
-                // everything older) must have landed: the barrier after this segment, and for the other group the next one, publish it
-                YH_HPP_PHASE({
-                    read_a(st, 1);
+            // ---- phase X: channels 0 .. 63 of the tile x this wave's 64 pixels; weight tile of step s + 3 into the stage that
+            // step s - 1 was read from (both groups are past its last read: the barrier that ended the previous interval)
+            YH_HPP_PHASE({ read_a(st, 0); read_b(hb, tapoff); if ((ROLE == 0 || group == 0) && s + 3 < nk) issue_a(st_w, ptap, pkc); }, mma(H0{}));
+            // ---- phase Y: channels 64 .. 127; halo pieces of the next chunk; then this wave's share of step s + 1 (and of
+            // everything older) must have landed: the barrier after this segment, and for the other group the next one, publish it
+            YH_HPP_PHASE({
+                read_a(st, 1);
+                if constexpr (ROLE == 0) {
                     if constexpr (t < LB) { if (more_h) issue_h(nbuf, nkc, tc); }
                     if (more_h) wait_vmcnt<allow>();
                     else {
                         const int rem = nk - 2 - s;
                         if (rem >= 2) wait_vmcnt<2>(); else if (rem == 1) wait_vmcnt<1>(); else wait_vmcnt<0>();
                     }
-                }, mma(H1{}));
-            } else {
-                // ---- one phase: all 12 fragments, the LDS-DMA issues and the counted wait in one load segment, then 32 MFMAs
-                YH_HPP_PHASE({
-                    read_b(hb, tapoff); read_a(st, 0); read_a(st, 1);
-                    if (s + 3 < nk) issue_a(st_w, ptap, pkc);
-                    if constexpr (t < LB) { if (more_h) issue_h(nbuf, nkc, tc); }
-                    if (more_h) wait_vmcnt<allow>();
-                    else {
-                        const int rem = nk - 2 - s;
-                        if (rem >= 2) wait_vmcnt<2>(); else if (rem == 1) wait_vmcnt<1>(); else wait_vmcnt<0>();
-                    }
-                }, { mma(H0{}); mma(H1{}); });
-            }
+                } else if (group == 0) {      // weight waves: two pieces per step, steps s + 2 and s + 3 stay in flight
+                    const int rem = nk - 2 - s;
+                    if (rem >= 2) wait_vmcnt<4>(); else if (rem == 1) wait_vmcnt<2>(); else wait_vmcnt<0>();
+                } else if (more_h) {          // halo waves: the next chunk's image in taps 0 .. 5, complete two taps before its first read
+                    if constexpr (t < 6) issue_h2(nbuf, nkc, t);
+                    if constexpr (t == 7) wait_vmcnt<0>();
+                }
+            }, mma(H1{}));
             ++s;
             st_r = (st_r + 1) & (SA - 1);
             st_w = (st_w + 1) & (SA - 1);
@@ -391,7 +432,7 @@ bool hpp_geometry(int W, int cin_k, int bk, int* rows_hp, int* lb, int* hbufs, s
     if (l == 8) l = 9;
     if (l < 5 || l > 9 || (nchunks > 1 && l > 7)) return false;   // in-loop halo prefetch issues one piece per tap in taps 0 .. 6
     *lb = l;
-    *lds = ((size_t)4 * 128 * 4 + (size_t)*hbufs * *rows_hp * 4 + 64) * 16;
+    *lds = ((size_t)4 * 128 * 4 + (size_t)*hbufs * *rows_hp * 4 + 64) * 16 + (size_t)*rows_hp * 4;   // + the halo offset table
     return *lds <= 160 * 1024;
 }
 
@@ -415,10 +456,14 @@ template <typename T> static int launch_hpp(const ConvArgs& a0, hipStream_t stre
     a.p_tiles = (int)((Q + 511) / 512);
     const long blocks = (long)a.m_tiles * a.p_tiles;
     if (blocks <= 0 || blocks > 0x7fffffffL) return YH_EINVAL;
-    static const int phases = [] { const char* e = getenv("YH_HPP_PHASES"); return e && atoi(e) == 2 ? 2 : 1; }();   // A/B knob
+    // ROLE 1 (separate weight / halo waves; needs its 48 halo pieces to cover the image) is an A/B knob, YH_HPP_ROLE=1: measured
+    // 5 - 9 % SLOWER than the shared form here (profiles/r03_hpp_role_ab.txt) - the weight tiles are L2-resident and short, unlike
+    // the dz stream of the weight-gradient kernel where the same separation gained 20 %
+    static const int role_env = [] { const char* e = getenv("YH_HPP_ROLE"); return e ? atoi(e) : 0; }();
+    const int role = (role_env && rows_hp <= 768) ? 1 : 0;
 #define YH_HPP_CASE(LBV)                                                                                                       \
     case LBV: {                                                                                                                \
-        auto kern = phases == 2 ? conv3x3_hpp_kernel<T, LBV, 2> : conv3x3_hpp_kernel<T, LBV, 1>;                              \
+        auto kern = role ? conv3x3_hpp_kernel<T, LBV, 1> : conv3x3_hpp_kernel<T, LBV, 0>;                                     \
         static size_t allowed = 64 * 1024;   /* per instantiation: raise the dynamic-LDS limit once per size */               \
         if (lds > allowed) {                                                                                                   \
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, \

@@ -959,10 +959,10 @@ static bool pick_hpp_tile(const yh_conv_desc* d) {
     if (d->kh != 3 || d->kw != 3 || d->stride != 1 || d->pad != 1 || d->ups != 1) return false;
     if (d->act != YH_ACT_LINEAR && d->act != YH_ACT_LEAKY && d->act != YH_ACT_MISH) return false;
     const int bk = d->dtype == YH_I8 ? 64 : 32;
-    // measured (profiles/r03_hpp_sweep.txt, batch 64): ahead by 9 - 19 % on the 76 x 76 / 38 x 38 / 19 x 19 layers (4 or more
-    // channel chunks), behind on 152 x 152 64 -> 128 (two chunks: 18 K steps do not amortise the halo prologue) and on 64-row
-    // outputs (half-empty weight tile)
-    if (d->cin_k % bk || d->cout < 128 || d->cin_k / bk < (d->dtype == YH_I8 ? 2 : 3)) return false;
+    // measured (profiles/r03_hpp_sweep.txt, batch 64): ahead by 15 - 35 % on the 76 x 76 / 38 x 38 / 19 x 19 layers, by 5 - 13 % on
+    // the 152 x 152 layers (64 -> 128, and the data gradient 128 -> 64 with a half-empty weight tile); behind only with a single
+    // channel chunk (304 x 304 32 -> 64: 9 K steps do not amortise the halo prologue)
+    if (d->cin_k % bk || d->cout < 64 || d->cin_k / bk < 2) return false;
     const unsigned amask = d->dtype == YH_F16 ? 15u : 7u;     // 8-channel stores / residual loads
     if (d->cout % 8 || d->ldy % 8 || (((uintptr_t)d->y) & amask) || (d->res && (d->ldr % 8 || (((uintptr_t)d->res) & amask)))) return false;
     if ((long)(d->n + 1) * (d->h + 1) * (d->w_in + 1) + 4096 >= 0x7fffffffL) return false;
