@@ -406,8 +406,8 @@ def train_roofline(eng, x, precision):
     traffic = None
     try:   # HBM bytes per launch from the committed rocprofv3 FETCH_SIZE / WRITE_SIZE passes of this command
         hbm = json.load(open(os.path.join(REPO, 'profiles', 'hbm_traffic.json'))).get('train_batch%d' % x.shape[0], {})
-        keys = ['void yh::conv_wgrad_dma_kernel<8, 2>', 'void yh::conv_wgrad_dma_kernel<4, 2>'] if top == 'conv_wgrad_dma' \
-            else [rocprof_kernel_name(top)]
+        keys = ['conv_wgrad_dma<8,2>', 'conv_wgrad_halo', 'conv_wgrad_dma<4,2>', 'void yh::conv_wgrad_dma_kernel<8, 2>'] \
+            if top == 'conv_wgrad_dma' else [rocprof_kernel_name(top)]
         key = next((k for k in keys if k in hbm), None)
         if key is not None and precision == 'fp16':
             traffic = {'hbm_bytes_per_launch': hbm[key]['hbm_bytes_per_dispatch'], 'kernel': key, 'source': 'profiles/hbm_traffic.json'}

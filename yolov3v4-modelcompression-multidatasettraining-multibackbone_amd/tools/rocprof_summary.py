@@ -36,6 +36,18 @@ def short(name):
     m = re.match(r'_ZN2yh19conv3x3_halo_kernelI(DF16_|f)(DF16_|f)Li(\d+)E', name)
     if m:
         return 'conv3x3_halo<%s,%s,%sx256>' % ('f16' if m.group(1) != 'f' else 'f32', 'f16' if m.group(2) != 'f' else 'f32', m.group(3))
+    # halo ping-pong conv (all halo-piece counts / roles of one precision together) and the weight-gradient kernels
+    m = re.match(r'(?:void yh::conv3x3_hpp_kernel<(signed char|_Float16),|_ZN2yh18conv3x3_hpp_kernelI(DF16_|a))', name)
+    if m:
+        t = 'i8' if (m.group(1) == 'signed char' or m.group(2) == 'a') else 'f16'
+        return 'conv3x3_hpp<%s,%s,128x512>' % (t, t)
+    if 'conv_wgrad_halo_kernel' in name:
+        return 'conv_wgrad_halo'
+    if 'wgrad_halo_reduce_kernel' in name:
+        return 'wgrad_halo_reduce'
+    m = re.match(r'(?:void yh::conv_wgrad_dma_kernel<(\d+), (\d+)|_ZN2yh21conv_wgrad_dma_kernelILi(\d+)ELi(\d+))', name)
+    if m:
+        return 'conv_wgrad_dma<%s,%s>' % (m.group(1) or m.group(3), m.group(2) or m.group(4))
     m = re.match(r'_ZN2yh(\d+)([a-z_0-9]+)', name)
     if m:
         return m.group(2)[:int(m.group(1))]
