@@ -973,7 +973,8 @@ static bool pick_hpp_tile(const yh_conv_desc* d) {
     const long blocks = (long)((d->cout + 127) / 128) * (((long)d->n * (d->h + 1) * (d->w_in + 1) + 511) / 512);
     // one workgroup per CU: a partly filled last round of the 256 CUs is paid in full
     const long rounds = (blocks + 255) / 256;
-    return blocks >= 192 && (rounds >= 5 || blocks * 100 >= rounds * 256 * 75);
+    // (38 x 38 512 -> 256 at batch 64 fills 75 % of two rounds and is still 30 % ahead of the ring / ping-pong kernels)
+    return blocks >= 192 && (rounds >= 4 || blocks * 100 >= rounds * 256 * 60);
 }
 
 // The LDS-free streaming kernel (conv_pointwise.hip) for 1x1 convolutions over few channels on large grids, where a ring-kernel
