@@ -507,7 +507,19 @@ int yh_nchw_to_nhwc(const float* x, void* y, int n, int c, int h, int w, int c_p
  *                       the new_h x new_w image area, pad_value elsewhere                                         (vertical pass)
  *   dst[ch'][Y][X]    = scale * v + shift,  ch' = 2 - ch when swap_rb (3 channels), else ch
  * with clip8(s) = min(max(s >> 22, 0), 255): Pillow's 8-bit resampling; the bounds / coefficient tables come from the host
- * (engine/preprocess.py restates precompute_coeffs / normalize_coeffs_8bpc).  All pointers are device pointers.             */
+ * (engine/preprocess.py restates precompute_coeffs / normalize_coeffs_8bpc).  All pointers are device pointers.
+ *
+ * arith selects the resampling arithmetic.  The values other than YH_ARITH_PILLOW evaluate OpenCV's uint8 formulas - the library the
+ * reference's loaders call (cv2.resize, reference datasets.py:519-526, :637) - in one fused pass (tmp unused), tables from
+ * engine/imgtables.py:
+ *   YH_ARITH_CV2_LINEAR     hbounds / vbounds = the two source indices per output sample, hk / vk = their 11-bit weights (ksize 2):
+ *                           r_j = S[j][i0] a0 + S[j][i1] a1;  v = (((b0 (r_0 >> 4)) >> 16) + ((b1 (r_1 >> 4)) >> 16) + 2) >> 2
+ *   YH_ARITH_CV2_AREA       hbounds / vbounds = (first source sample, count), hk / vk = float32 weights [ksize] (bit pattern in the
+ *                           int32 array): buf = sum_u S[j][x0 + u] ka[u], sum (+)= kb[t] buf, all float32 in this order; round half even
+ *   YH_ARITH_CV2_AREA_FAST  integer decimation factors hksize x vksize, no tables: integer cell sums; (s + 2) >> 2 for 2 x 2,
+ *                           round(s * (1.f / area)) otherwise, ragged edge cells divided by their sample count
+ * out_u8 != 0 (cv2 arithmetics only) writes a uint8 HWC image [out_h][out_w][c] to dst instead of the scaled fp32 planes.     */
+enum { YH_ARITH_PILLOW = 0, YH_ARITH_CV2_LINEAR = 1, YH_ARITH_CV2_AREA = 2, YH_ARITH_CV2_AREA_FAST = 3 };
 typedef struct yh_letterbox_desc {
     const uint8_t* src;          /* [h0][src_pitch bytes], c interleaved channels                                   */
     uint8_t* tmp;                /* [h0][new_w][c] scratch                                                          */
@@ -520,6 +532,7 @@ typedef struct yh_letterbox_desc {
     int32_t new_h, new_w, out_h, out_w, top, left;
     int32_t pad_value, swap_rb;
     float scale, shift;          /* detect.py:101: 1/256, 0;  --maxabsscaler: 2/256, -1                              */
+    int32_t arith, out_u8;
 } yh_letterbox_desc;
 int yh_letterbox_fwd(const yh_letterbox_desc* d, void* stream);
 
@@ -533,7 +546,13 @@ int yh_letterbox_fwd(const yh_letterbox_desc* d, void* stream);
  *                     pad_value where no rectangle covers (the canvas is never materialised); empty rectangles are skipped
  *   warp(Y, X)      = bilinear sample of canvas at (inv[0] (X'+.5) + inv[1] (Y+.5) + inv[2], inv[3] (X'+.5) + inv[4] (Y+.5) + inv[5])
  *                     with X' = out_w - 1 - X when flip_lr; pad_value when that point is outside the canvas
- *   dst[ch][Y][X]   = hsv(warp) (3 channels and hsv != 0; gains hsv_gain[0..2] on hue / saturation / value)                  */
+ *   dst[ch][Y][X]   = hsv(warp) (3 channels and hsv != 0; gains hsv_gain[0..2] on hue / saturation / value)
+ *
+ * arith = YH_ARITH_CV2_LINEAR: the reference's own library calls instead, restated from OpenCV (3.x - 4.10) - warpAffine's fixed
+ * point bilinear (10-bit coordinates, 5-bit sub-pixel weights summing to 2^15, border = pad_value) with `inv` = OpenCV's inversion
+ * of the forward matrix (engine/imgtables.py cv2_invert_affine) and X' applied as above; cvtColor(BGR2HSV) in 12-bit fixed point,
+ * the three 256-entry tables `lut` = [hue][sat][val] of augment_hsv (datasets.py:539-542; hsv_gain is not read),
+ * cvtColor(HSV2BGR) in float32.  src[k] are then the images already resized by yh_letterbox_fwd (cv2 arithmetic, out_u8).          */
 enum { YH_MOSAIC_U8 = 0, YH_MOSAIC_F32 = 1, YH_MOSAIC_F16 = 2 };
 typedef struct yh_mosaic_desc {
     const uint8_t* src[4];       /* decoded frames, [src_h][src_pitch bytes], c interleaved channels (device pointers)    */
@@ -545,6 +564,8 @@ typedef struct yh_mosaic_desc {
     int32_t x1b[4], y1b[4];                   /* its top-left corner in the source frame                                   */
     int32_t canvas_h, canvas_w, out_h, out_w, c, pad_value, hsv, flip_lr, out_dtype;
     float divisor;               /* train.py:345: 256                                                                      */
+    int32_t arith;               /* YH_ARITH_PILLOW or YH_ARITH_CV2_LINEAR                                                 */
+    const uint8_t* lut;          /* [3][256] device table (cv2 arithmetic with hsv != 0)                                   */
 } yh_mosaic_desc;
 int yh_mosaic_affine_hsv(const yh_mosaic_desc* d, void* stream);
 

@@ -434,6 +434,133 @@ class FakeLib:
         flat(best, 1, np.int32)[0] = arg
         return 0
 
+    # ---------------------------------------------------------------- input pipeline (csrc/preprocess.hip, csrc/augment.hip)
+    def yh_letterbox_fwd(self, dref, stream):
+        """Every arithmetic of the kernel, formula for formula from the descriptor's tables (NOT via oracle/cv2_restated.py, which
+        computes the same images from the image sizes alone)."""
+        d = dref._obj if hasattr(dref, '_obj') else dref
+        c, nh, nw = d.c, d.new_h, d.new_w
+        src = np.lib.stride_tricks.as_strided(flat(d.src, (d.h0 - 1) * d.src_pitch + d.w0 * c, np.uint8), shape=(d.h0, d.w0, c),
+                                              strides=(d.src_pitch, c, 1)).astype(np.int64)
+        if d.arith == 0:
+            hb, vb = flat(d.hbounds, nw * 2, np.int32).reshape(nw, 2), flat(d.vbounds, nh * 2, np.int32).reshape(nh, 2)
+            hk, vk = flat(d.hk, nw * d.hksize, np.int32).reshape(nw, -1).astype(np.int64), flat(d.vk, nh * d.vksize, np.int32).reshape(nh, -1).astype(np.int64)
+            tmp = np.empty((d.h0, nw, c), dtype=np.int64)
+            for x in range(nw):
+                x0, n = hb[x]
+                tmp[:, x] = np.clip(((1 << 21) + (src[:, x0:x0 + n] * hk[x, :n][None, :, None]).sum(1)) >> 22, 0, 255)
+            img = np.empty((nh, nw, c), dtype=np.int64)
+            for y in range(nh):
+                y0, n = vb[y]
+                img[y] = np.clip(((1 << 21) + (tmp[y0:y0 + n] * vk[y, :n][:, None, None]).sum(0)) >> 22, 0, 255)
+        elif d.arith == 1:
+            assert d.hksize == 2 and d.vksize == 2
+            hb, vb = flat(d.hbounds, nw * 2, np.int32).reshape(nw, 2), flat(d.vbounds, nh * 2, np.int32).reshape(nh, 2)
+            hk, vk = flat(d.hk, nw * 2, np.int32).reshape(nw, 2).astype(np.int64), flat(d.vk, nh * 2, np.int32).reshape(nh, 2).astype(np.int64)
+            rows = src[:, hb[:, 0]] * hk[:, 0][None, :, None] + src[:, hb[:, 1]] * hk[:, 1][None, :, None]
+            r0, r1 = rows[vb[:, 0]], rows[vb[:, 1]]
+            img = np.clip((((vk[:, 0][:, None, None] * (r0 >> 4)) >> 16) + ((vk[:, 1][:, None, None] * (r1 >> 4)) >> 16) + 2) >> 2, 0, 255)
+        elif d.arith == 2:
+            hb, vb = flat(d.hbounds, nw * 2, np.int32).reshape(nw, 2), flat(d.vbounds, nh * 2, np.int32).reshape(nh, 2)
+            hk, vk = flat(d.hk, nw * d.hksize, np.float32).reshape(nw, -1), flat(d.vk, nh * d.vksize, np.float32).reshape(nh, -1)
+            f = src.astype(np.float32)
+            buf = np.zeros((d.h0, nw, c), dtype=np.float32)
+            for x in range(nw):
+                x0, n = hb[x]
+                for u in range(n):
+                    buf[:, x] = buf[:, x] + f[:, x0 + u] * hk[x, u]
+            img = np.empty((nh, nw, c), dtype=np.int64)
+            for y in range(nh):
+                y0, n = vb[y]
+                acc = vk[y, 0] * buf[y0]
+                for t in range(1, n):
+                    acc = acc + vk[y, t] * buf[y0 + t]
+                img[y] = np.clip(np.rint(acc), 0, 255)
+        else:
+            fx, fy = d.hksize, d.vksize
+            img = np.zeros((nh, nw, c), dtype=np.int64)
+            for y in range(nh):
+                for x in range(nw):
+                    cell = src[y * fy:min(y * fy + fy, d.h0), x * fx:min(x * fx + fx, d.w0)]
+                    if cell.size == 0:
+                        continue
+                    sm = cell.sum((0, 1))
+                    if y * fy + fy <= d.h0 and x < d.w0 // fx:
+                        img[y, x] = (sm + 2) >> 2 if (fx, fy) == (2, 2) else np.clip(np.rint(sm.astype(np.float32) * (np.float32(1) / np.float32(fx * fy))), 0, 255)
+                    else:
+                        img[y, x] = np.clip(np.rint(sm.astype(np.float32) / np.float32(cell.shape[0] * cell.shape[1])), 0, 255)
+        full = np.full((d.out_h, d.out_w, c), d.pad_value, dtype=np.int64)
+        full[d.top:d.top + nh, d.left:d.left + nw] = img
+        if d.out_u8:
+            flat(d.dst, d.out_h * d.out_w * c, np.uint8)[:] = full.astype(np.uint8).reshape(-1)
+        else:
+            chw = full.transpose(2, 0, 1)
+            if d.swap_rb and c == 3:
+                chw = chw[::-1]
+            flat(d.dst, c * d.out_h * d.out_w, np.float32)[:] = (chw.astype(np.float32) * np.float32(d.scale) + np.float32(d.shift)).reshape(-1)
+        return 0
+
+    def yh_mosaic_affine_hsv(self, dref, stream):
+        d = dref._obj if hasattr(dref, '_obj') else dref
+        if d.arith != 1:
+            raise NotImplementedError('the Pillow arithmetic of this kernel is restated by engine.preprocess.mosaic_reference')
+        c, H, W = d.c, d.canvas_h, d.canvas_w
+        canvas = np.full((H, W, c), d.pad_value, dtype=np.int64)
+        for k in range(4):
+            if d.x2a[k] > d.x1a[k] and d.y2a[k] > d.y1a[k]:
+                img = np.lib.stride_tricks.as_strided(flat(d.src[k], (d.src_h[k] - 1) * d.src_pitch[k] + d.src_w[k] * c, np.uint8),
+                                                      shape=(d.src_h[k], d.src_w[k], c), strides=(d.src_pitch[k], c, 1))
+                canvas[d.y1a[k]:d.y2a[k], d.x1a[k]:d.x2a[k]] = img[d.y1b[k]:d.y1b[k] + d.y2a[k] - d.y1a[k], d.x1b[k]:d.x1b[k] + d.x2a[k] - d.x1a[k]]
+        inv = [float(v) for v in d.inv]
+        X = np.arange(d.out_w)
+        xo = (d.out_w - 1 - X) if d.flip_lr else X
+        Y = np.arange(d.out_h)
+        rint = lambda v: np.rint(v).astype(np.int64)
+        ad, bd = rint(inv[0] * xo.astype(np.float64) * 1024.0), rint(inv[3] * xo.astype(np.float64) * 1024.0)
+        X0, Y0 = rint((inv[1] * Y.astype(np.float64) + inv[2]) * 1024.0) + 16, rint((inv[4] * Y.astype(np.float64) + inv[5]) * 1024.0) + 16
+        XX, YY = (X0[:, None] + ad[None, :]) >> 5, (Y0[:, None] + bd[None, :]) >> 5
+        sx, sy, fx, fy = np.clip(XX >> 5, -32768, 32767), np.clip(YY >> 5, -32768, 32767), XX & 31, YY & 31
+
+        def px(yy, xx):
+            ok = (yy >= 0) & (yy < H) & (xx >= 0) & (xx < W)
+            return np.where(ok[..., None], canvas[np.clip(yy, 0, H - 1), np.clip(xx, 0, W - 1)], d.pad_value)
+        acc = (px(sy, sx) * ((32 - fy) * (32 - fx) * 32)[..., None] + px(sy, sx + 1) * ((32 - fy) * fx * 32)[..., None] +
+               px(sy + 1, sx) * (fy * (32 - fx) * 32)[..., None] + px(sy + 1, sx + 1) * (fy * fx * 32)[..., None])
+        img = np.clip((acc + (1 << 14)) >> 15, 0, 255)
+        if d.hsv and c == 3:
+            lut = flat(d.lut, 768, np.uint8).reshape(3, 256).astype(np.int64)
+            r, g, b = img[..., 0], img[..., 1], img[..., 2]
+            v, vmin = np.maximum(np.maximum(b, g), r), np.minimum(np.minimum(b, g), r)
+            diff = v - vmin
+            sdiv = np.where(v > 0, rint(float(255 << 12) / np.maximum(v, 1).astype(np.float64)), 0)
+            hdiv = np.where(diff > 0, rint(float(180 << 12) / (6.0 * np.maximum(diff, 1).astype(np.float64))), 0)
+            s = (diff * sdiv + (1 << 11)) >> 12
+            h = np.where(v == r, g - b, np.where(v == g, b - r + 2 * diff, r - g + 4 * diff))
+            h = (h * hdiv + (1 << 11)) >> 12
+            h = np.where(h < 0, h + 180, h)
+            Hh, Ss, Vv = lut[0][np.clip(h, 0, 255)], lut[1][s], lut[2][v]
+            f32 = np.float32
+            fs, fv = Ss.astype(f32) * f32(1.0 / 255.0), Vv.astype(f32) * f32(1.0 / 255.0)
+            fh = np.fmod(Hh.astype(f32) * (f32(6.0) / f32(180.0)), f32(6.0)).astype(f32)
+            sector = np.floor(fh).astype(np.int64)
+            fh = (fh - sector.astype(f32)).astype(f32)
+            bad = (sector < 0) | (sector > 5)
+            sector, fh = np.where(bad, 0, sector), np.where(bad, f32(0), fh).astype(f32)
+            one = f32(1)
+            tab = np.stack([fv, fv * (one - fs), fv * (one - fs * fh), fv * (one - fs * (one - fh))], -1).astype(f32)
+            sel = np.array([[1, 3, 0], [1, 0, 2], [3, 0, 1], [0, 2, 1], [0, 1, 3], [2, 1, 0]])[sector]      # (b, g, r)
+            bgr = np.take_along_axis(tab, sel, -1)
+            bgr = np.where((Ss == 0)[..., None], fv[..., None], bgr).astype(f32)
+            img = np.clip(np.rint(bgr * f32(255.0)), 0, 255).astype(np.int64)[..., ::-1]
+        chw = img.transpose(2, 0, 1)
+        n = c * d.out_h * d.out_w
+        if d.out_dtype == 0:
+            flat(d.dst, n, np.uint8)[:] = chw.astype(np.uint8).reshape(-1)
+        else:
+            dt = np.float32 if d.out_dtype == 1 else np.float16
+            flat(d.dst, n, dt)[:] = (chw.astype(np.float32) / np.float32(d.divisor)).astype(dt).reshape(-1)
+        return 0
+
     def yh_absmax(self, t, count, ws, ws_bytes, out, stream):
         flat(out, 1, np.float32)[0] = np.abs(flat(t, int(count), np.float32)).max()
         return 0

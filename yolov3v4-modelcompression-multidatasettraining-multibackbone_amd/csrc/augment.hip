@@ -14,6 +14,16 @@
 //    pad value.
 //  * HSV: rgb -> hsv in float32 (numpy float32 arrays), gains and hsv -> rgb in float64 (numpy promotes float32 array * float64
 //    scalar), `(rgb * 255 + 0.5)` clipped and truncated; numpy's remainder semantics for the two `%`.
+//
+// arith = YH_ARITH_CV2_LINEAR evaluates the REFERENCE's library calls instead (OpenCV, restated from its sources and checked
+// against oracle/cv2_restated.py only - "third-party restated"):
+//  * warp: cv2.warpAffine(INTER_LINEAR, BORDER_CONSTANT 114) of OpenCV 3.x - 4.10 (reference datasets.py:677): `inv` is OpenCV's own
+//    inversion of M (engine/imgtables.py); X0 = round((inv1 y + inv2) 1024) + 16, adelta = round(inv0 x 1024) (round half even),
+//    X = (X0 + adelta) >> 5: integer part X >> 5, 5-bit fraction X & 31 (same for Y); weights (32-fy)(32-fx) 32 ... (BilinearTab_i,
+//    they sum to 2^15); v = (sum of the four neighbours, pad value where outside, times weights + 2^14) >> 15;
+//  * the four source images were resized on the device by yh_letterbox_fwd (arith cv2, uint8 output) before this kernel runs;
+//  * HSV: cv2.cvtColor(BGR2HSV) in 12-bit fixed point (RGB2HSV_b, hue range 180), the three 256-entry tables of augment_hsv
+//    (datasets.py:539-542, built on the host from the random gains), cv2.cvtColor(HSV2BGR) in float32 (HSV2RGB_native).
 // No fused multiply-adds anywhere: contraction is switched off for this file.
 #pragma clang fp contract(off)
 #include "common.h"
@@ -81,6 +91,74 @@ __device__ __forceinline__ void hsv_augment(const yh_mosaic_desc& d, int (&px)[3
     }
 }
 
+__device__ __forceinline__ int u8sat(int v) { return v < 0 ? 0 : (v > 255 ? 255 : v); }
+
+// cv2.cvtColor(BGR2HSV) -> cv2.LUT x 3 -> cv2.cvtColor(HSV2BGR) on one pixel held as (R, G, B)
+__device__ __forceinline__ void hsv_augment_cv2(const uint8_t* __restrict__ lut, int (&px)[3]) {
+    const int r = px[0], g = px[1], b = px[2];
+    const int v = max(max(b, g), r), vmin = min(min(b, g), r);
+    const int diff = v - vmin;
+    const int sdiv = v ? (int)rint((double)(255 << 12) / (1.0 * (double)v)) : 0;
+    const int hdiv = diff ? (int)rint((double)(180 << 12) / (6.0 * (double)diff)) : 0;
+    const int s = (diff * sdiv + (1 << 11)) >> 12;
+    int h = v == r ? g - b : (v == g ? b - r + 2 * diff : r - g + 4 * diff);
+    h = (h * hdiv + (1 << 11)) >> 12;
+    if (h < 0) h += 180;
+    const int H = lut[u8sat(h)], S = lut[256 + s], V = lut[512 + v];
+    const float fs = (float)S * (1.0f / 255.0f), fv = (float)V * (1.0f / 255.0f);
+    float ob = fv, og = fv, orr = fv;
+    if (S != 0) {
+        float fh = (float)H * (6.f / 180.f);
+        fh = fmodf(fh, 6.f);
+        int sector = (int)floorf(fh);
+        fh -= (float)sector;
+        if ((unsigned)sector >= 6u) { sector = 0; fh = 0.f; }
+        const float tab[4] = {fv, fv * (1.f - fs), fv * (1.f - fs * fh), fv * (1.f - fs * (1.f - fh))};
+        // tab index of (b, g, r) per sector: {1,3,0} {1,0,2} {3,0,1} {0,2,1} {0,1,3} {2,1,0}
+        const int ib = (0x200311 >> (4 * sector)) & 15, ig = (0x112003 >> (4 * sector)) & 15, ir = (0x031120 >> (4 * sector)) & 15;
+        ob = tab[ib]; og = tab[ig]; orr = tab[ir];
+    }
+    px[0] = u8sat((int)rintf(orr * 255.f));
+    px[1] = u8sat((int)rintf(og * 255.f));
+    px[2] = u8sat((int)rintf(ob * 255.f));
+}
+
+template <typename OutT>
+__device__ __forceinline__ void store_px(const yh_mosaic_desc& d, int Y, int X, const int (&px)[3]) {
+    OutT* const dst = reinterpret_cast<OutT*>(d.dst);
+    for (int ch = 0; ch < d.c; ++ch) {
+        const long o = ((long)ch * d.out_h + Y) * d.out_w + X;
+        if constexpr (sizeof(OutT) == 1) dst[o] = (OutT)px[ch];
+        else dst[o] = (OutT)((float)px[ch] / d.divisor);
+    }
+}
+
+template <typename OutT>
+__global__ __launch_bounds__(256) void mosaic_affine_hsv_cv2_kernel(const yh_mosaic_desc d) {
+    const long total = (long)d.out_h * d.out_w;
+    const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int X = (int)(i % d.out_w), Y = (int)(i / d.out_w);
+    const int xo = d.flip_lr ? d.out_w - 1 - X : X;
+    const int adelta = (int)rint(d.inv[0] * (double)xo * 1024.0), bdelta = (int)rint(d.inv[3] * (double)xo * 1024.0);
+    const int X0 = (int)rint((d.inv[1] * (double)Y + d.inv[2]) * 1024.0) + 16;
+    const int Y0 = (int)rint((d.inv[4] * (double)Y + d.inv[5]) * 1024.0) + 16;
+    const int XX = (X0 + adelta) >> 5, YY = (Y0 + bdelta) >> 5;
+    int sx = XX >> 5, sy = YY >> 5;
+    sx = sx < -32768 ? -32768 : (sx > 32767 ? 32767 : sx);
+    sy = sy < -32768 ? -32768 : (sy > 32767 ? 32767 : sy);
+    const int fx = XX & 31, fy = YY & 31;
+    const int w00 = (32 - fy) * (32 - fx) * 32, w01 = (32 - fy) * fx * 32, w10 = fy * (32 - fx) * 32, w11 = fy * fx * 32;
+    int px[3] = {d.pad_value, d.pad_value, d.pad_value};
+    for (int ch = 0; ch < d.c; ++ch) {
+        const int acc = canvas_px(d, sy, sx, ch) * w00 + canvas_px(d, sy, sx + 1, ch) * w01 + canvas_px(d, sy + 1, sx, ch) * w10 +
+                        canvas_px(d, sy + 1, sx + 1, ch) * w11;
+        px[ch] = u8sat((acc + (1 << 14)) >> 15);
+    }
+    if (d.hsv && d.c == 3) hsv_augment_cv2(d.lut, px);
+    store_px<OutT>(d, Y, X, px);
+}
+
 template <typename OutT>
 __global__ __launch_bounds__(256) void mosaic_affine_hsv_kernel(const yh_mosaic_desc d) {
     const long total = (long)d.out_h * d.out_w;
@@ -115,12 +193,7 @@ __global__ __launch_bounds__(256) void mosaic_affine_hsv_kernel(const yh_mosaic_
         }
     }
     if (d.hsv && d.c == 3) hsv_augment(d, px);
-    OutT* const dst = reinterpret_cast<OutT*>(d.dst);
-    for (int ch = 0; ch < d.c; ++ch) {
-        const long o = ((long)ch * d.out_h + Y) * d.out_w + X;
-        if constexpr (sizeof(OutT) == 1) dst[o] = (OutT)px[ch];
-        else dst[o] = (OutT)((float)px[ch] / d.divisor);
-    }
+    store_px<OutT>(d, Y, X, px);
 }
 
 }  // namespace yh
@@ -140,6 +213,17 @@ extern "C" int yh_mosaic_affine_hsv(const yh_mosaic_desc* d, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     const long total = (long)d->out_h * d->out_w;
     const unsigned blocks = (unsigned)((total + 255) / 256);
+    if (d->arith != YH_ARITH_PILLOW && d->arith != YH_ARITH_CV2_LINEAR) return YH_EINVAL;
+    if (d->arith == YH_ARITH_CV2_LINEAR) {
+        if (d->hsv && d->c == 3 && !d->lut) return YH_EINVAL;
+        switch (d->out_dtype) {
+            case YH_MOSAIC_U8: hipLaunchKernelGGL(mosaic_affine_hsv_cv2_kernel<uint8_t>, dim3(blocks), dim3(256), 0, s, *d); break;
+            case YH_MOSAIC_F32: hipLaunchKernelGGL(mosaic_affine_hsv_cv2_kernel<float>, dim3(blocks), dim3(256), 0, s, *d); break;
+            case YH_MOSAIC_F16: hipLaunchKernelGGL(mosaic_affine_hsv_cv2_kernel<f16>, dim3(blocks), dim3(256), 0, s, *d); break;
+            default: return YH_EINVAL;
+        }
+        return check_launch();
+    }
     switch (d->out_dtype) {
         case YH_MOSAIC_U8: hipLaunchKernelGGL(mosaic_affine_hsv_kernel<uint8_t>, dim3(blocks), dim3(256), 0, s, *d); break;
         case YH_MOSAIC_F32: hipLaunchKernelGGL(mosaic_affine_hsv_kernel<float>, dim3(blocks), dim3(256), 0, s, *d); break;

@@ -54,7 +54,8 @@ def detect(opt, save_img=True):
             # the decoded frame goes to the GPU as it is; resize + border + x / 256 + HWC -> CHW run there (csrc/preprocess.hip),
             # bit-identical to the loader's host letterbox (tests/test_preprocess.py)
             from engine.preprocess import letterbox_to_device
-            x, _, _ = letterbox_to_device(im0, imgsz, device, auto=opt.rect, maxabsscaler=opt.maxabsscaler)
+            x, _, _ = letterbox_to_device(im0, imgsz, device, auto=opt.rect, maxabsscaler=opt.maxabsscaler,
+                                          arith=getattr(opt, 'image_arith', None))
         else:
             x = torch.from_numpy(img).to(device).float() / 256.0      # uint8 -> [0, 1) like detect.py:101
             if opt.maxabsscaler:
@@ -110,6 +111,9 @@ def make_parser():
     parser.add_argument('--device', default='', help='device id (i.e. 0 or 0,1) or cpu')
     parser.add_argument('--rect', action='store_true', help='rectangular detecting')
     parser.add_argument('--host-letterbox', action='store_true', help='letterbox on the host (default on a GPU: on the device)')
+    parser.add_argument('--image-arith', choices=['pillow', 'cv2'], default=None,
+                        help="resize arithmetic of the device letterbox: 'pillow' = the host loader's, 'cv2' = the reference's cv2.resize "
+                             "restated; default: $YOLO_IMAGE_ARITH or pillow")
     parser.add_argument('--view-img', action='store_true', help='display results (unused: headless)')
     parser.add_argument('--save-txt', action='store_true', help='save results to *.txt')
     parser.add_argument('--classes', nargs='+', type=int, help='filter by class')

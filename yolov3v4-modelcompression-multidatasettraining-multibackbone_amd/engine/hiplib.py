@@ -147,7 +147,7 @@ class LetterboxDesc(C.Structure):
     _fields_ = [('src', _vp), ('tmp', _vp), ('dst', _vp), ('hbounds', _vp), ('hk', _vp), ('vbounds', _vp), ('vk', _vp),
                 ('h0', _i32), ('w0', _i32), ('c', _i32), ('src_pitch', _i32), ('hksize', _i32), ('vksize', _i32),
                 ('new_h', _i32), ('new_w', _i32), ('out_h', _i32), ('out_w', _i32), ('top', _i32), ('left', _i32),
-                ('pad_value', _i32), ('swap_rb', _i32), ('scale', _f32), ('shift', _f32)]
+                ('pad_value', _i32), ('swap_rb', _i32), ('scale', _f32), ('shift', _f32), ('arith', _i32), ('out_u8', _i32)]
 
 
 class MosaicDesc(C.Structure):
@@ -155,7 +155,7 @@ class MosaicDesc(C.Structure):
                 ('src_h', _i32 * 4), ('src_w', _i32 * 4), ('src_pitch', _i32 * 4),
                 ('x1a', _i32 * 4), ('y1a', _i32 * 4), ('x2a', _i32 * 4), ('y2a', _i32 * 4), ('x1b', _i32 * 4), ('y1b', _i32 * 4),
                 ('canvas_h', _i32), ('canvas_w', _i32), ('out_h', _i32), ('out_w', _i32), ('c', _i32), ('pad_value', _i32),
-                ('hsv', _i32), ('flip_lr', _i32), ('out_dtype', _i32), ('divisor', _f32)]
+                ('hsv', _i32), ('flip_lr', _i32), ('out_dtype', _i32), ('divisor', _f32), ('arith', _i32), ('lut', _vp)]
 
 
 class LayoutDesc(C.Structure):

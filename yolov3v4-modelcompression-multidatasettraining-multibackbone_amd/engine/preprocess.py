@@ -10,15 +10,28 @@ the kernel against the host loader on the GPU).
 """
 import ctypes as C
 import math
+import os
 
 import numpy as np
 import torch
 
-from . import hiplib
+from . import hiplib, imgtables
 from .hiplib import LetterboxDesc
 
 PRECISION_BITS = 32 - 8 - 2      # Pillow: 8-bit samples, 22 fractional coefficient bits
 PAD_VALUE = 114
+
+# Which library's uint8 arithmetic the device pipeline evaluates: 'pillow' (this package's host loader, bit-identical to it) or
+# 'cv2' (the reference's loader: OpenCV restated, engine/imgtables.py; there is no host twin of it in this package - OpenCV is not
+# installed - so this arithmetic exists on the GPU only).  Per call through ``arith=``, per process through YOLO_IMAGE_ARITH.
+ARITHMETICS = ('pillow', 'cv2')
+
+
+def default_arith():
+    a = os.environ.get('YOLO_IMAGE_ARITH', 'pillow')
+    if a not in ARITHMETICS:
+        raise ValueError('YOLO_IMAGE_ARITH must be one of %s, got %r' % (ARITHMETICS, a))
+    return a
 
 
 def resample_tables(in_size, out_size):
@@ -96,12 +109,31 @@ def _device_tables(in_size, out_size, device):
     return hit
 
 
-def letterbox_to_device(frame, new_shape, device, out=None, auto=True, scaleup=True, maxabsscaler=False, swap_rb=False):
+_cv2_cache = {}
+
+
+def _device_cv2_tables(in_size, out_size, horizontal, device):
+    key = (in_size, out_size, horizontal, str(device))
+    hit = _cv2_cache.get(key)
+    if hit is None:
+        idx, coef = imgtables.cv2_linear_tables(in_size, out_size, horizontal)
+        hit = (torch.from_numpy(idx).to(device), torch.from_numpy(coef).to(device))
+        if len(_cv2_cache) > 64:
+            _cv2_cache.clear()
+        _cv2_cache[key] = hit
+    return hit
+
+
+def letterbox_to_device(frame, new_shape, device, out=None, auto=True, scaleup=True, maxabsscaler=False, swap_rb=False, arith=None):
     """uint8 HWC frame (numpy array or tensor; RGB as this package's loaders deliver it, or BGR with ``swap_rb``) -> fp32 tensor
     ``(c, out_h, out_w)`` on ``device`` holding the letterboxed, scaled image; ``out`` may be a slot of a preallocated batch.
+    ``arith``: 'pillow' (default; the host loader's resize) or 'cv2' (the reference's cv2.resize INTER_LINEAR, one fused launch).
 
     Returns ``(tensor, ratio, (dw, dh))`` like ``utils.datasets.letterbox`` returns ``(image, ratio, pad)``."""
     lib = hiplib.load()
+    arith = arith or default_arith()
+    if arith not in ARITHMETICS:
+        raise ValueError('arith must be one of %s' % (ARITHMETICS,))
     if isinstance(frame, np.ndarray):
         frame = np.ascontiguousarray(frame)
         if any(st < 0 for st in frame.strides):     # a flipped size-1 axis counts as contiguous for numpy but not for torch
@@ -114,9 +146,13 @@ def letterbox_to_device(frame, new_shape, device, out=None, auto=True, scaleup=T
     device = torch.device(device)
     with hiplib.on_device(torch.empty(0, device=device)):
         src = src.to(device, non_blocking=True)
-        hb, hk, hks = _device_tables(w0, new_w, device)
-        vb, vk, vks = _device_tables(h0, new_h, device)
-        tmp = torch.empty((h0, new_w, c), dtype=torch.uint8, device=device)
+        if arith == 'cv2':
+            (hb, hk), (vb, vk), hks, vks = _device_cv2_tables(w0, new_w, True, device), _device_cv2_tables(h0, new_h, False, device), 2, 2
+            tmp = src                                  # unused by the fused kernel
+        else:
+            hb, hk, hks = _device_tables(w0, new_w, device)
+            vb, vk, vks = _device_tables(h0, new_h, device)
+            tmp = torch.empty((h0, new_w, c), dtype=torch.uint8, device=device)
         if out is None:
             out = torch.empty((c, out_h, out_w), dtype=torch.float32, device=device)
         elif tuple(out.shape) != (c, out_h, out_w) or out.dtype != torch.float32 or not out.is_contiguous():
@@ -125,9 +161,51 @@ def letterbox_to_device(frame, new_shape, device, out=None, auto=True, scaleup=T
         d = LetterboxDesc(src=P(src), tmp=P(tmp), dst=P(out), hbounds=P(hb), hk=P(hk), vbounds=P(vb), vk=P(vk), h0=h0, w0=w0, c=c,
                           src_pitch=w0 * c, hksize=hks, vksize=vks, new_h=new_h, new_w=new_w, out_h=out_h, out_w=out_w, top=top,
                           left=left, pad_value=PAD_VALUE, swap_rb=1 if swap_rb else 0,
-                          scale=(2.0 / 256.0) if maxabsscaler else (1.0 / 256.0), shift=-1.0 if maxabsscaler else 0.0)
+                          scale=(2.0 / 256.0) if maxabsscaler else (1.0 / 256.0), shift=-1.0 if maxabsscaler else 0.0,
+                          arith=imgtables.ARITH_CV2_LINEAR if arith == 'cv2' else imgtables.ARITH_PILLOW, out_u8=0)
         hiplib.check(lib.yh_letterbox_fwd(C.byref(d), hiplib.stream_ptr()), 'yh_letterbox_fwd')
     return out, ratio, pad
+
+
+def _cv2_axis_tables(in_size, out_size, horizontal, code):
+    """(bounds int32 [out][2], coefficients as int32 [out][ksize], ksize) for one axis of a cv2 resize of the given arithmetic."""
+    if code == imgtables.ARITH_CV2_AREA and in_size != out_size:
+        b, k, ksize = imgtables.cv2_area_tables(in_size, out_size)
+        return b, k.view(np.int32), ksize
+    if code == imgtables.ARITH_CV2_AREA:            # an axis that keeps its size inside an area resize: one unit weight
+        b = np.stack([np.arange(out_size, dtype=np.int32), np.ones(out_size, dtype=np.int32)], 1)
+        return b, np.ones((out_size, 1), dtype=np.float32).view(np.int32), 1
+    b, k = imgtables.cv2_linear_tables(in_size, out_size, horizontal)
+    return b, k, 2
+
+
+def resize_to_device(frame, out_hw, device, code=imgtables.ARITH_CV2_LINEAR, lib=None):
+    """cv2.resize of one uint8 HWC frame on the GPU -> uint8 HWC tensor (``code``: an ``imgtables.ARITH_CV2_*`` value; INTER_AREA with
+    integer factors needs no tables).  The reference calls it in load_image (datasets.py:519-526)."""
+    lib = lib or hiplib.load()
+    src = torch.as_tensor(np.ascontiguousarray(frame)) if isinstance(frame, np.ndarray) else frame.contiguous()
+    if src.dtype != torch.uint8 or src.dim() != 3:
+        raise ValueError('expected a uint8 HWC frame')
+    h0, w0, c = src.shape
+    new_h, new_w = out_hw
+    device = torch.device(device)
+    with hiplib.on_device(torch.empty(0, device=device)):
+        src = src.to(device, non_blocking=True)
+        out = torch.empty((new_h, new_w, c), dtype=torch.uint8, device=device)
+        P = hiplib.ptr
+        d = LetterboxDesc(src=P(src), tmp=P(src), dst=P(out), h0=h0, w0=w0, c=c, src_pitch=w0 * c, new_h=new_h, new_w=new_w, out_h=new_h,
+                          out_w=new_w, top=0, left=0, pad_value=PAD_VALUE, swap_rb=0, scale=1.0, shift=0.0, arith=code, out_u8=1)
+        keep = []
+        if code == imgtables.ARITH_CV2_AREA_FAST:
+            fx, fy = imgtables.cv2_area_is_fast((w0, h0), (new_w, new_h))
+            d.hksize, d.vksize = fx, fy
+        else:
+            hb, hk, d.hksize = _cv2_axis_tables(w0, new_w, True, code)
+            vb, vk, d.vksize = _cv2_axis_tables(h0, new_h, False, code)
+            keep = [torch.from_numpy(np.ascontiguousarray(t)).to(device) for t in (hb, hk, vb, vk)]
+            d.hbounds, d.hk, d.vbounds, d.vk = (P(t) for t in keep)
+        hiplib.check(lib.yh_letterbox_fwd(C.byref(d), hiplib.stream_ptr()), 'yh_letterbox_fwd')
+    return out
 
 
 def resample_reference(img, out_hw):
@@ -168,6 +246,8 @@ def render_mosaic_items(items, device, out=None, dtype=torch.float32, divisor=25
     if out is None:
         out = torch.empty((n, c, h, w), device=device, dtype=dtype)
     assert out.is_contiguous() and tuple(out.shape) == (n, c, h, w) and out.dtype == dtype
+    if getattr(items[0], 'arith', 'pillow') == 'cv2':
+        return _render_mosaic_items_cv2(batch, device, out, code, divisor, lib)
     dev_buf = batch.blob.to(device, non_blocking=True)
     base, offs = dev_buf.data_ptr(), batch.offsets
     k = 0
@@ -191,6 +271,87 @@ def render_mosaic_items(items, device, out=None, dtype=torch.float32, divisor=25
             d.flip_lr, d.out_dtype, d.divisor = int(bool(it.flip)), code, float(divisor)
             hiplib.check(lib.yh_mosaic_affine_hsv(C.byref(d), hiplib.stream_ptr()), 'yh_mosaic_affine_hsv')
     # dev_buf may die here: the caching allocator only hands its memory to later work on this stream
+    return out
+
+
+_host_cv2_cache = {}
+
+
+def _host_cv2_tables(in_size, out_size, horizontal):
+    key = (in_size, out_size, horizontal)
+    hit = _host_cv2_cache.get(key)
+    if hit is None:
+        if len(_host_cv2_cache) > 256:
+            _host_cv2_cache.clear()
+        hit = _host_cv2_cache[key] = imgtables.cv2_linear_tables(in_size, out_size, horizontal)
+    return hit
+
+
+def _render_mosaic_items_cv2(batch, device, out, code, divisor, lib):
+    """The reference's arithmetic: every source crop is resized on the device with cv2.resize's INTER_LINEAR formulas (one
+    ``yh_letterbox_fwd`` launch per part, uint8 output, only the window the warp can touch), then one ``yh_mosaic_affine_hsv``
+    launch per item warps / colour-augments with warpAffine's and cvtColor's.  One upload each for the crops, the per-part tables
+    and the HSV lookup tables of the batch."""
+    from .hiplib import MosaicDesc
+    items = batch.items
+    n = len(items)
+    h, w = items[0].out_hw
+    c = items[0].channels
+    tabs, tab_off, win_off, plan = [], 0, 0, []
+    k = 0
+    for it in items:
+        for shape, (x1a, y1a, x2a, y2a), _, spec in it.parts:
+            if shape is not None:
+                h0, w0, hr, wr, wx0, wy0, c0, r0 = spec
+                ww, wh = x2a - x1a, y2a - y1a
+                ix, kx = _host_cv2_tables(w0, wr, True)
+                iy, ky = _host_cv2_tables(h0, hr, False)
+                arrays = (ix[wx0:wx0 + ww] - c0, kx[wx0:wx0 + ww], iy[wy0:wy0 + wh] - r0, ky[wy0:wy0 + wh])
+                offs = []
+                for a in arrays:
+                    a = np.ascontiguousarray(a, dtype=np.int32).reshape(-1)
+                    tabs.append(a)
+                    offs.append(tab_off)
+                    tab_off += a.size
+                plan.append((k, shape, ww, wh, offs, win_off))
+                win_off += (ww * wh * c + 15) // 16 * 16
+            k += 1
+    luts = np.zeros((n, 3, 256), dtype=np.uint8)
+    for i, it in enumerate(items):
+        if it.hsv_gains is not None:
+            luts[i] = imgtables.hsv_luts(it.hsv_gains)
+    dev_buf = batch.blob.to(device, non_blocking=True)
+    dev_tab = torch.from_numpy(np.concatenate(tabs) if tabs else np.zeros(1, dtype=np.int32)).to(device, non_blocking=True)
+    dev_lut = torch.from_numpy(luts).to(device, non_blocking=True)
+    windows = torch.empty(max(win_off, 16), dtype=torch.uint8, device=device)
+    base, offs, tbase, wbase = dev_buf.data_ptr(), batch.offsets, dev_tab.data_ptr(), windows.data_ptr()
+    where = {}
+    with hiplib.on_device(dev_buf):
+        for k, (ch, cw), ww, wh, toffs, woff in plan:
+            d = LetterboxDesc(src=base + int(offs[k]), tmp=base, dst=wbase + woff, hbounds=tbase + 4 * toffs[0], hk=tbase + 4 * toffs[1],
+                              vbounds=tbase + 4 * toffs[2], vk=tbase + 4 * toffs[3], h0=ch, w0=cw, c=c, src_pitch=cw * c, hksize=2, vksize=2,
+                              new_h=wh, new_w=ww, out_h=wh, out_w=ww, top=0, left=0, pad_value=PAD_VALUE, swap_rb=0, scale=1.0, shift=0.0,
+                              arith=imgtables.ARITH_CV2_LINEAR, out_u8=1)
+            hiplib.check(lib.yh_letterbox_fwd(C.byref(d), hiplib.stream_ptr()), 'yh_letterbox_fwd')
+            where[k] = (wbase + woff, wh, ww)
+        k = 0
+        for i, it in enumerate(items):
+            d = MosaicDesc()
+            for j, (shape, (x1a, y1a, x2a, y2a), _, spec) in enumerate(it.parts):
+                if shape is not None:
+                    d.src[j], d.src_h[j], d.src_w[j] = where[k]
+                    d.src_pitch[j] = d.src_w[j] * c
+                d.x1a[j], d.y1a[j], d.x2a[j], d.y2a[j], d.x1b[j], d.y1b[j] = x1a, y1a, x2a, y2a, 0, 0
+                k += 1
+            d.dst = out[i].data_ptr()
+            for q in range(6):
+                d.inv[q] = float(it.inv[q])
+            d.hsv = 0 if it.hsv_gains is None else 1
+            d.lut = dev_lut[i].data_ptr()
+            d.canvas_h, d.canvas_w = it.canvas
+            d.out_h, d.out_w, d.c, d.pad_value = h, w, c, PAD_VALUE
+            d.flip_lr, d.out_dtype, d.divisor, d.arith = int(bool(it.flip)), code, float(divisor), imgtables.ARITH_CV2_LINEAR
+            hiplib.check(lib.yh_mosaic_affine_hsv(C.byref(d), hiplib.stream_ptr()), 'yh_mosaic_affine_hsv')
     return out
 
 

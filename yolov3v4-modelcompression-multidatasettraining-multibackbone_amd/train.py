@@ -189,7 +189,8 @@ def train(opt, hyp):
     # --device-augment: items arrive as recipes (cropped source frames + geometry + gains) and one HIP kernel per item does the
     # mosaic, warp, HSV, flip, transpose and /256 on the GPU (engine/preprocess.py render_mosaic_items, csrc/augment.hip)
     dataset = LoadImagesAndLabels(train_path, img_size, batch_size, augment=True, hyp=hyp, rect=opt.rect, cache_images=opt.cache_images,
-                                  rank=rank, is_gray_scale=opt.gray_scale, device_augment=opt.device_augment and device.type == 'cuda')
+                                  rank=rank, is_gray_scale=opt.gray_scale, device_augment=opt.device_augment and device.type == 'cuda',
+                                  arith=getattr(opt, 'image_arith', None))
     nw = min([os.cpu_count() or 1, batch_size if batch_size > 1 else 0, 8])
     sampler = torch.utils.data.distributed.DistributedSampler(dataset) if distributed else None
     dataloader = DataLoader(dataset, batch_size=batch_size, num_workers=nw, shuffle=(sampler is None and not opt.rect), sampler=sampler,
@@ -360,6 +361,9 @@ def make_parser():
     parser.add_argument('--cache-images', action='store_true', help='cache images for faster training')
     parser.add_argument('--device-augment', action='store_true',
                         help='mosaic / affine / HSV / flip of the training items on the GPU (same random streams, same pixels as the host loader)')
+    parser.add_argument('--image-arith', choices=['pillow', 'cv2'], default=None,
+                        help="uint8 arithmetic of the device input pipeline: 'pillow' = this package's host loader, 'cv2' = the reference's "
+                             "OpenCV calls restated (GPU only: needs --device-augment); default: $YOLO_IMAGE_ARITH or pillow")
     parser.add_argument('--weights', type=str, default='', help='initial weights path')
     parser.add_argument('--t_weights', type=str, default='', help='teacher model weights')
     parser.add_argument('--KDstr', type=int, default=-1, help='KD strategy')

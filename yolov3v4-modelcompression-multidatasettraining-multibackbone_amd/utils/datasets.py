@@ -148,6 +148,16 @@ def load_image(self, index, is_gray_scale=False):
     return img, (h0, w0), img.shape[:2]
 
 
+def load_image_lazy(self, index, is_gray_scale=False):
+    """load_image with the resize left to the GPU (``arith='cv2'``): ``(original image, (h0, w0), (h, w) after cv2.resize, code)``
+    where ``code`` is the OpenCV interpolation the reference would use (engine.imgtables.ARITH_CV2_*) or None for 'no resize'."""
+    from engine import imgtables
+    img = _read(self.img_files[index], is_gray_scale)
+    h0, w0 = img.shape[:2]
+    hw, code = imgtables.load_image_plan(h0, w0, self.img_size, self.augment)
+    return img, (h0, w0), hw, code
+
+
 def _rgb_to_hsv(img):
     x = img.astype(np.float32) / 255.0
     mx, mn = x.max(2), x.min(2)
@@ -235,16 +245,20 @@ def random_affine(img, targets=(), degrees=10, translate=.1, scale=.1, shear=10,
     return img, affine_targets(targets, M, s, width, height)
 
 
-def mosaic_layout(self, index, is_gray_scale=False):
+def mosaic_layout(self, index, is_gray_scale=False, lazy=False):
     """The random draws and the geometry of ``load_mosaic`` without touching a canvas (datasets.py:553-600): the mosaic centre,
     the three extra image indices, and per image the placement rectangle ``(x1a, y1a, x2a, y2a)`` on the 2s x 2s canvas, the
-    matching source corner ``(x1b, y1b)``, the loaded image and its labels in canvas pixels."""
+    matching source corner ``(x1b, y1b)``, the loaded image and its labels in canvas pixels.  ``lazy``: the images stay unresized
+    and every part carries ``(h0, w0, h, w)`` as a fourth entry (the geometry only needs the size after the resize)."""
     s = self.img_size
     xc, yc = [int(random.uniform(s * 0.5, s * 1.5)) for _ in range(2)]
     indices = [index] + [random.randint(0, len(self.labels) - 1) for _ in range(3)]
     parts, labels4 = [], []
     for i, idx in enumerate(indices):
-        img, _, (h, w) = load_image(self, idx, is_gray_scale)
+        if lazy:
+            img, (h0, w0), (h, w), _ = load_image_lazy(self, idx, is_gray_scale)
+        else:
+            img, _, (h, w) = load_image(self, idx, is_gray_scale)
         if i == 0:    # top left of the centre
             x1a, y1a, x2a, y2a = max(xc - w, 0), max(yc - h, 0), xc, yc
             x1b, y1b, x2b, y2b = w - (x2a - x1a), h - (y2a - y1a), w, h
@@ -257,7 +271,7 @@ def mosaic_layout(self, index, is_gray_scale=False):
         else:         # bottom right
             x1a, y1a, x2a, y2a = xc, yc, min(xc + w, s * 2), min(s * 2, yc + h)
             x1b, y1b, x2b, y2b = 0, 0, min(w, x2a - x1a), min(y2a - y1a, h)
-        parts.append((img, (x1a, y1a, x2a, y2a), (x1b, y1b, x2b, y2b)))
+        parts.append((img, (x1a, y1a, x2a, y2a), (x1b, y1b, x2b, y2b)) + (((h0, w0, h, w),) if lazy else ()))
         padw, padh = x1a - x1b, y1a - y1b
         x = self.labels[idx]
         if x.size:
@@ -291,7 +305,7 @@ class MosaicItem:
     """One training item with the pixel work left undone: everything ``yh_mosaic_affine_hsv`` needs (csrc/augment.hip) plus the
     finished labels.  Produced by ``LoadImagesAndLabels.__getitem__`` when ``device_augment`` is set; consumes the random streams
     exactly like the host path, so the same seeds give the same item."""
-    __slots__ = ('parts', 'canvas', 'out_hw', 'inv', 'identity', 'hsv_gains', 'flip', 'channels', 'labels', 'path')
+    __slots__ = ('parts', 'canvas', 'out_hw', 'inv', 'identity', 'hsv_gains', 'flip', 'channels', 'labels', 'path', 'arith')
 
 
 class MosaicBatch:
@@ -308,10 +322,11 @@ class MosaicBatch:
         k = 0
         for it in self.items:
             parts = []
-            for crop, rect, corner in it.parts:
+            for part in it.parts:
+                crop = part[0]
                 if crop is not None:
                     flat[self.offsets[k]:self.offsets[k] + crop.size] = crop.reshape(-1)
-                parts.append((None if crop is None else tuple(crop.shape[:2]), rect, corner))
+                parts.append((None if crop is None else tuple(crop.shape[:2]),) + tuple(part[1:]))
                 k += 1
             it.parts = parts          # shapes only: the pixels live in the blob
 
@@ -329,11 +344,17 @@ def mosaic_item(self, index):
     s = self.img_size
     it = MosaicItem()
     it.channels = 1 if self.is_gray_scale else 3
-    parts, labels4 = mosaic_layout(self, index, self.is_gray_scale)
+    it.arith = self.arith
+    cv2_arith = self.arith == 'cv2'
+    parts, labels4 = mosaic_layout(self, index, self.is_gray_scale, lazy=cv2_arith)
     M, sc, (width, height) = affine_matrix((2 * s, 2 * s), hyp.get('degrees', 0), hyp.get('translate', 0), hyp.get('scale', 0),
                                            hyp.get('shear', 0), border=-s // 2)
     labels = affine_targets(labels4, M, sc, width, height)
-    it.inv = np.linalg.inv(M)[:2].reshape(-1).astype(np.float64)
+    if cv2_arith:     # cv2.warpAffine inverts M itself, with its own sequence of operations
+        from engine import imgtables
+        it.inv = imgtables.cv2_invert_affine(M[:2])
+    else:
+        it.inv = np.linalg.inv(M)[:2].reshape(-1).astype(np.float64)
     it.canvas, it.out_hw = (2 * s, 2 * s), (height, width)
     it.hsv_gains = None
     if not self.is_gray_scale:   # augment_hsv: one np.random.uniform(-1, 1, 3)
@@ -356,14 +377,37 @@ def mosaic_item(self, index):
     fx0, fx1 = int(math.floor(corners[0].min())) - 2, int(math.ceil(corners[0].max())) + 2
     fy0, fy1 = int(math.floor(corners[1].min())) - 2, int(math.ceil(corners[1].max())) + 2
     it.parts = []
-    for img, (x1a, y1a, x2a, y2a), (x1b, y1b, x2b, y2b) in parts:
+    for part in parts:
+        img, (x1a, y1a, x2a, y2a), (x1b, y1b, x2b, y2b) = part[:3]
         cx0, cy0, cx1, cy1 = max(x1a, fx0), max(y1a, fy0), min(x2a, fx1), min(y2a, fy1)
         if cx1 <= cx0 or cy1 <= cy0:
-            it.parts.append((None, (0, 0, 0, 0), (0, 0)))
+            it.parts.append((None, (0, 0, 0, 0), (0, 0)) + ((None,) if cv2_arith else ()))
             continue
-        crop = np.ascontiguousarray(img[y1b + cy0 - y1a:y1b + cy1 - y1a, x1b + cx0 - x1a:x1b + cx1 - x1a])
-        it.parts.append((crop, (cx0, cy0, cx1, cy1), (0, 0)))
+        wx0, wy0, wx1, wy1 = x1b + cx0 - x1a, y1b + cy0 - y1a, x1b + cx1 - x1a, y1b + cy1 - y1a    # window of the resized image
+        if not cv2_arith:
+            it.parts.append((np.ascontiguousarray(img[wy0:wy1, wx0:wx1]), (cx0, cy0, cx1, cy1), (0, 0)))
+            continue
+        # the resize happens on the GPU: ship the source samples this window of the resized image reads
+        h0, w0, h, w = part[3]
+        ix = _cv2_axis_index(w0, w, True)[wx0:wx1]
+        iy = _cv2_axis_index(h0, h, False)[wy0:wy1]
+        c0, c1, r0, r1 = int(ix.min()), int(ix.max()) + 1, int(iy.min()), int(iy.max()) + 1
+        it.parts.append((np.ascontiguousarray(img[r0:r1, c0:c1]), (cx0, cy0, cx1, cy1), (0, 0), (h0, w0, h, w, wx0, wy0, c0, r0)))
     return it
+
+
+_axis_index_cache = {}
+
+
+def _cv2_axis_index(ssize, dsize, horizontal):
+    key = (ssize, dsize, horizontal)
+    hit = _axis_index_cache.get(key)
+    if hit is None:
+        from engine import imgtables
+        if len(_axis_index_cache) > 256:
+            _axis_index_cache.clear()
+        hit = _axis_index_cache[key] = imgtables.cv2_linear_tables(ssize, dsize, horizontal)[0]
+    return hit
 
 
 class LoadImagesAndLabels(Dataset):
@@ -376,7 +420,8 @@ class LoadImagesAndLabels(Dataset):
     ``collate_fn`` writes the image index into column 0, the format ``build_targets`` expects."""
 
     def __init__(self, path, img_size=416, batch_size=16, augment=False, hyp=None, rect=False, image_weights=False,
-                 cache_images=False, rank=-1, is_gray_scale=False, subset_len=-1, single_cls=False, pad=0.0, device_augment=False):
+                 cache_images=False, rank=-1, is_gray_scale=False, subset_len=-1, single_cls=False, pad=0.0, device_augment=False,
+                 arith=None):
         path = str(Path(path))
         if os.path.isdir(path):
             files = sorted(glob.glob(os.path.join(path, '*.*')))
@@ -398,6 +443,15 @@ class LoadImagesAndLabels(Dataset):
         self.mosaic = self.augment and not self.rect
         # the mosaic / warp / HSV / flip pixel work on the GPU (engine/preprocess.py render_mosaic_items): items are recipes
         self.device_augment = bool(device_augment) and self.mosaic
+        # 'cv2': the reference's OpenCV arithmetic (resize, warp, HSV) - evaluated by the GPU kernels only, so only for recipes
+        self.arith = arith or os.environ.get('YOLO_IMAGE_ARITH', 'pillow')
+        if self.arith not in ('pillow', 'cv2'):
+            raise ValueError("arith must be 'pillow' or 'cv2', got %r" % (self.arith,))
+        if self.arith == 'cv2' and not self.device_augment:
+            raise NotImplementedError("arith='cv2' (OpenCV's arithmetic) exists on the GPU only: it needs device_augment=True and the "
+                                      "mosaic training path; this package's host loader resizes with Pillow")
+        if self.arith == 'cv2' and cache_images:
+            raise NotImplementedError("arith='cv2' keeps the source frames unresized; cache_images is not supported with it")
         self.is_gray_scale = is_gray_scale
         self.label_files = [x.replace('images', 'labels').replace(os.path.splitext(x)[-1], '.txt') for x in self.img_files]
 
