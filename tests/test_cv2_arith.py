@@ -335,3 +335,68 @@ def test_kernel_mosaic_items_in_cv2_arithmetic(dataset_dir, hyp, size, gray):
     assert diff.max().item() == 0, 'uint8 items differ: %d pixels, worst %d' % ((diff > 0).sum().item(), diff.max().item())
     gotf = pp.render_mosaic_items(items, 'cuda', dtype=torch.float32)
     assert torch.equal(gotf.cpu(), want.float() / 256.0)
+
+
+# ------------------------------------------------------------------------------------------ evaluation / rect items as recipes
+def _reference_eval_batch(ds, idx):
+    """The reference's non-augmenting __getitem__ (datasets.py:480-505) on the restated cv2 calls: load_image (INTER_AREA when it
+    shrinks), letterbox to the batch rectangle (border only), HWC -> CHW."""
+    out = []
+    for i in idx:
+        img = datasets._read(ds.img_files[i], ds.is_gray_scale)
+        img = cv.load_image_resize(img, ds.img_size, False)
+        shape = ds.batch_shapes[ds.batch[i]]
+        lb, ratio, pad = cv.letterbox(img, tuple(int(v) for v in shape), auto=False, scaleup=False)
+        assert ratio == (1.0, 1.0)
+        out.append(np.ascontiguousarray(lb.transpose(2, 0, 1)))
+    return torch.from_numpy(np.stack(out)).float() / 256.0
+
+
+def _eval_batches(dataset_dir, size, gray, render):
+    common = dict(img_size=size, batch_size=4, rect=True, is_gray_scale=gray)
+    dev = datasets.LoadImagesAndLabels(str(dataset_dir / 'train.txt'), device_letterbox=True, arith='cv2', **common)
+    twin = datasets.LoadImagesAndLabels(str(dataset_dir / 'train.txt'), device_letterbox=True, arith='pillow', **common)
+    codes = set()
+    for b in sorted(set(dev.batch.tolist())):
+        idx = [i for i in range(len(dev)) if dev.batch[i] == b]
+        items = [dev[i] for i in idx]
+        codes |= {it.code for it in items}
+        batch, labels, paths, shapes = datasets.LoadImagesAndLabels.collate_fn(items)
+        _, labels_p, paths_p, shapes_p = datasets.LoadImagesAndLabels.collate_fn([twin[i] for i in idx])
+        assert torch.equal(labels, labels_p) and paths == paths_p and shapes == shapes_p      # geometry does not depend on the arithmetic
+        got = render(batch)
+        assert torch.equal(got.cpu(), _reference_eval_batch(dev, idx))
+    return codes
+
+
+@pytest.mark.parametrize('size,gray', [(64, False), (96, False), (96, True), (200, False)])
+def test_cv2_eval_recipes_on_the_emulated_abi_equal_the_restated_reference(dataset_dir, fake, size, gray):
+    codes = _eval_batches(dataset_dir, size, gray, lambda b: pp.render_letterbox_items(b, 'cpu', lib=fake))
+    assert (imgtables.ARITH_CV2_AREA in codes) if size < 160 else codes == {None}
+
+
+def test_cv2_eval_recipe_with_an_integer_factor(tmp_path, fake):
+    from PIL import Image
+    img = _img((128, 256, 3), 12)
+    (tmp_path / 'images').mkdir()
+    (tmp_path / 'labels').mkdir()
+    Image.fromarray(img).save(tmp_path / 'images' / 'a.png')
+    (tmp_path / 'labels' / 'a.txt').write_text('0 0.5 0.5 0.25 0.25\n')
+    (tmp_path / 'list.txt').write_text(str(tmp_path / 'images' / 'a.png') + '\n')
+    ds = datasets.LoadImagesAndLabels(str(tmp_path / 'list.txt'), img_size=128, batch_size=1, rect=True, device_letterbox=True, arith='cv2')
+    item = ds[0]
+    assert item.code == imgtables.ARITH_CV2_AREA_FAST and item.resized_hw == (64, 128)
+    got = pp.render_letterbox_items([item], 'cpu', lib=fake)
+    assert torch.equal(got, _reference_eval_batch(ds, [0]))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('size,gray', [(64, False), (96, False), (96, True), (200, False)])
+def test_kernel_eval_recipes_in_cv2_arithmetic(dataset_dir, size, gray):
+    _gpu()
+
+    def render(b):
+        out = pp.render_letterbox_items(b, 'cuda')
+        torch.cuda.synchronize()
+        return out
+    _eval_batches(dataset_dir, size, gray, render)

@@ -72,3 +72,57 @@ def test_device_letterbox_writes_into_a_batch_slot():
     for i, f in enumerate(frames):
         host = datasets.letterbox(f, 64, auto=False)[0]
         assert torch.equal(batch[i].cpu(), torch.from_numpy(np.ascontiguousarray(host.transpose(2, 0, 1))).float() / 256.0)
+
+
+# ------------------------------------------------------------------------------------------ evaluation / rect items as recipes
+def _eval_pair(dataset_dir, size, batch, gray=False, **kw):
+    common = dict(img_size=size, batch_size=batch, rect=True, is_gray_scale=gray)
+    host = datasets.LoadImagesAndLabels(str(dataset_dir / 'train.txt'), **common)
+    dev = datasets.LoadImagesAndLabels(str(dataset_dir / 'train.txt'), device_letterbox=True, **common, **kw)
+    assert dev.device_letterbox and not host.device_letterbox
+    return host, dev
+
+
+def _check_eval_batches(host, dev, render):
+    n = len(host)
+    for b0 in range(0, n, host.batch[1:].tolist().count(0) + 1 if n > 1 else 1):
+        idx = [i for i in range(n) if host.batch[i] == host.batch[b0]]
+        imgs, labels, paths, shapes = datasets.LoadImagesAndLabels.collate_fn([host[i] for i in idx])
+        batch, labels_d, paths_d, shapes_d = datasets.LoadImagesAndLabels.collate_fn([dev[i] for i in idx])
+        assert isinstance(batch, datasets.LetterboxBatch) and paths == paths_d and torch.equal(labels, labels_d)
+        assert [tuple(map(tuple, (s[0], s[1][0], s[1][1]))) for s in shapes] == [tuple(map(tuple, (s[0], s[1][0], s[1][1]))) for s in shapes_d]
+        got = render(batch)
+        want = imgs.float() / 256.0                       # test.py:95-96
+        assert tuple(got.shape) == tuple(want.shape) and torch.equal(got.cpu(), want)
+        got2 = render(batch, maxabsscaler=True)
+        assert torch.equal(got2.cpu(), want * 2 - 1)
+
+
+@pytest.mark.parametrize('size,gray', [(64, False), (96, False), (96, True), (200, False)])
+def test_eval_recipes_on_the_emulated_abi_equal_the_host_loader(dataset_dir, size, gray):
+    import fakelib
+    import pickle
+    lib = fakelib.FakeLib()
+    host, dev = _eval_pair(dataset_dir, size, 4, gray)
+    assert any(it is not None for it in [dev[0].code]) or size >= 160          # the small sizes shrink (Image.BOX), 200 does not
+    _check_eval_batches(host, dev, lambda b, **kw: pp.render_letterbox_items(pickle.loads(pickle.dumps(b)), 'cpu', lib=lib, **kw))
+
+
+def test_box_tables_reproduce_pillow_box():
+    for shape, out_hw in [((120, 160, 3), (96, 128)), ((97, 131, 3), (47, 64)), ((200, 90, 1), (100, 45)), ((64, 64, 3), (32, 32))]:
+        img = _img(shape, 4)
+        assert np.array_equal(pp.resample_reference(img, out_hw, 'box'), datasets._resize(img, (out_hw[1], out_hw[0]), area=True))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('size,gray', [(64, False), (96, False), (96, True), (200, False)])
+def test_device_eval_recipes_equal_the_host_loader(dataset_dir, size, gray):
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU')
+    host, dev = _eval_pair(dataset_dir, size, 4, gray)
+
+    def render(b, **kw):
+        out = pp.render_letterbox_items(b, 'cuda', **kw)
+        torch.cuda.synchronize()
+        return out
+    _check_eval_batches(host, dev, render)

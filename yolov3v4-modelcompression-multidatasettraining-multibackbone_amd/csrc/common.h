@@ -12,6 +12,7 @@ typedef f16 f16x8 __attribute__((ext_vector_type(8)));
 typedef f16 f16x4 __attribute__((ext_vector_type(4)));
 typedef f16 f16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // Activation of the conv epilogue (fp32 in, fp32 out).  `act` is wave-uniform.
 // mish(v) = v * tanh(softplus(v)) = v * n / (n + 2) with n = e^v (e^v + 2): one exp, one divide.

@@ -101,7 +101,7 @@ template <int CO> struct StemStore<int8_t, CO> {
 // A fully unrolled 3x3x3 form with 432 v_pk_fma_f32 per thread - two output channels per instruction, weights in scalar register
 // pairs - compiled as intended and was bit-identical, but ran 4.76 ms: 50 KB of straight-line code per kernel does not live in
 // the instruction cache.  The rolled loop below stays.)
-template <typename T, int CO>
+template <typename T, int CO, bool K33>
 __global__ __launch_bounds__(256) void conv_stem_kernel(const yh_stem_desc d) {
     const long P = (long)d.n * d.ho * d.wo;
     const long p = blockIdx.x * (long)blockDim.x + threadIdx.x;
@@ -112,25 +112,66 @@ __global__ __launch_bounds__(256) void conv_stem_kernel(const yh_stem_desc d) {
     const int rem = (int)(p - (long)n * hw);
     const int ho = rem / d.wo, wo = rem - ho * d.wo;
     const int hi0 = ho * d.stride - d.pad, wi0 = wo * d.stride - d.pad;
-    float acc[CO];
+    // two output channels per v_pk_fma_f32 (the rolled loop keeps the weights of one tap in scalar registers): the same fused
+    // multiply-adds in the same order as a scalar fmaf chain, at twice the VALU rate - this layer is VALU-bound (27 x cout FMAs per
+    // pixel against 12 input + 2 cout output bytes)
+    f32x2 acc2[CO / 2];
 #pragma unroll
-    for (int c = 0; c < CO; ++c) acc[c] = d.bias[co0 + c];
+    for (int c = 0; c < CO / 2; ++c) acc2[c] = *reinterpret_cast<const f32x2*>(d.bias + co0 + 2 * c);
     const float* xin = d.x + (long)n * d.cin * d.h * d.w_in;
-    for (int r = 0; r < d.kh; ++r) {
-        const int hi = hi0 + r;
-        for (int s = 0; s < d.kw; ++s) {
-            const int wi = wi0 + s;
-            const bool ok = (unsigned)hi < (unsigned)d.h && (unsigned)wi < (unsigned)d.w_in;
-            for (int ci = 0; ci < d.cin; ++ci) {
-                const float xv = ok ? xin[((long)ci * d.h + hi) * d.w_in + wi] : 0.f;
-                const float* wrow = d.w + ((r * d.kw + s) * d.cin + ci) * d.cout_pad + co0;
+    if constexpr (K33) {
+        // 3 x 3 taps of 3 planes (the RGB first layer): the nine samples of one filter row are loaded before their 9 x CO / 2 FMAs, so
+        // a wave waits for memory three times per pixel instead of 27; the order of the additions is the rolled loop's
+#pragma unroll 1
+        for (int r = 0; r < 3; ++r) {
+            const int hi = hi0 + r;
+            const bool rok = (unsigned)hi < (unsigned)d.h;
+            const int hc = min(max(hi, 0), d.h - 1);
+            f32x4 xa, xb;          // the nine samples in a register vector: the tap loop below stays rolled (one tap's weights in
+            float xc;              // scalar registers at a time) and picks its sample by index
 #pragma unroll
-                for (int c = 0; c < CO; ++c) acc[c] = fmaf(xv, wrow[c], acc[c]);
+            for (int s = 0; s < 3; ++s) {
+                const int wi = wi0 + s;
+                const bool ok = rok && (unsigned)wi < (unsigned)d.w_in;
+                const int wc = min(max(wi, 0), d.w_in - 1);
+#pragma unroll
+                for (int ci = 0; ci < 3; ++ci) {
+                    const float v = xin[((long)ci * d.h + hc) * d.w_in + wc];     // clamped address, value zeroed: no branch per load
+                    const float z = ok ? v : 0.f;
+                    const int t = s * 3 + ci;
+                    if (t < 4) xa[t] = z;
+                    else if (t < 8) xb[t - 4] = z;
+                    else xc = z;
+                }
+            }
+#pragma unroll 1
+            for (int t = 0; t < 9; ++t) {
+                const float x1 = t < 4 ? xa[t & 3] : (t < 8 ? xb[t & 3] : xc);
+                const f32x2 xx = {x1, x1};
+                const f32x2* wrow = reinterpret_cast<const f32x2*>(d.w + (r * 9 + t) * d.cout_pad + co0);
+#pragma unroll
+                for (int c = 0; c < CO / 2; ++c) acc2[c] = __builtin_elementwise_fma(xx, wrow[c], acc2[c]);
+            }
+        }
+    } else {
+        for (int r = 0; r < d.kh; ++r) {
+            const int hi = hi0 + r;
+            for (int s = 0; s < d.kw; ++s) {
+                const int wi = wi0 + s;
+                const bool ok = (unsigned)hi < (unsigned)d.h && (unsigned)wi < (unsigned)d.w_in;
+                for (int ci = 0; ci < d.cin; ++ci) {
+                    const float xv = ok ? xin[((long)ci * d.h + hi) * d.w_in + wi] : 0.f;
+                    const f32x2 xx = {xv, xv};
+                    const f32x2* wrow = reinterpret_cast<const f32x2*>(d.w + ((r * d.kw + s) * d.cin + ci) * d.cout_pad + co0);
+#pragma unroll
+                    for (int c = 0; c < CO / 2; ++c) acc2[c] = __builtin_elementwise_fma(xx, wrow[c], acc2[c]);
+                }
             }
         }
     }
+    float acc[CO];
 #pragma unroll
-    for (int c = 0; c < CO; ++c) acc[c] = activate(acc[c], d.act, d.slope);
+    for (int c = 0; c < CO; ++c) acc[c] = activate(acc2[c / 2][c & 1], d.act, d.slope);
     if constexpr (sizeof(T) == 1) {  // PTQ: quantise onto the activation grid (round half away, clamp)
         const float inv = 1.f / d.out_scale;
 #pragma unroll
@@ -355,16 +396,24 @@ extern "C" int yh_conv2d_stem_fwd(const yh_stem_desc* d, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     const bool wide = d->cout_pad % 32 == 0;
     const dim3 grid((unsigned)((P + 255) / 256), (unsigned)(d->cout_pad / (wide ? 32 : 16)));
+    static const bool rolled = getenv("YH_STEM_ROLLED") != nullptr;      // A/B: the tap-by-tap loop for every shape
+    const bool k33 = d->kh == 3 && d->kw == 3 && d->cin == 3 && !rolled;
+#define YH_STEM_LAUNCH(T, CO)                                                                              \
+    do {                                                                                                    \
+        if (k33) hipLaunchKernelGGL((conv_stem_kernel<T, CO, true>), grid, dim3(256), 0, s, *d);            \
+        else hipLaunchKernelGGL((conv_stem_kernel<T, CO, false>), grid, dim3(256), 0, s, *d);               \
+    } while (0)
     if (d->dtype == YH_F16) {
-        if (wide) hipLaunchKernelGGL((conv_stem_kernel<f16, 32>), grid, dim3(256), 0, s, *d);
-        else hipLaunchKernelGGL((conv_stem_kernel<f16, 16>), grid, dim3(256), 0, s, *d);
+        if (wide) YH_STEM_LAUNCH(f16, 32);
+        else YH_STEM_LAUNCH(f16, 16);
     } else if (d->dtype == YH_I8) {
-        if (wide) hipLaunchKernelGGL((conv_stem_kernel<int8_t, 32>), grid, dim3(256), 0, s, *d);
-        else hipLaunchKernelGGL((conv_stem_kernel<int8_t, 16>), grid, dim3(256), 0, s, *d);
+        if (wide) YH_STEM_LAUNCH(int8_t, 32);
+        else YH_STEM_LAUNCH(int8_t, 16);
     } else {
-        if (wide) hipLaunchKernelGGL((conv_stem_kernel<float, 32>), grid, dim3(256), 0, s, *d);
-        else hipLaunchKernelGGL((conv_stem_kernel<float, 16>), grid, dim3(256), 0, s, *d);
+        if (wide) YH_STEM_LAUNCH(float, 32);
+        else YH_STEM_LAUNCH(float, 16);
     }
+#undef YH_STEM_LAUNCH
     return check_launch();
 }
 

@@ -34,12 +34,14 @@ def default_arith():
     return a
 
 
-def resample_tables(in_size, out_size):
-    """(bounds int32 [out][2], coefficients int32 [out][ksize], ksize) of Pillow's bilinear filter for one axis."""
+def resample_tables(in_size, out_size, filt='bilinear'):
+    """(bounds int32 [out][2], coefficients int32 [out][ksize], ksize) of one of Pillow's filters for one axis: 'bilinear' (triangle,
+    support 1) or 'box' (support 0.5: what ``utils.datasets`` shrinks evaluation images with, Image.BOX)."""
     scale = filterscale = float(in_size) / out_size
     if filterscale < 1.0:
         filterscale = 1.0
-    support = 1.0 * filterscale                      # bilinear: support 1
+    box = filt == 'box'
+    support = (0.5 if box else 1.0) * filterscale
     ksize = int(math.ceil(support)) * 2 + 1
     bounds = np.zeros((out_size, 2), dtype=np.int32)
     kk = np.zeros((out_size, ksize), dtype=np.int32)
@@ -57,9 +59,12 @@ def resample_tables(in_size, out_size):
         ww = 0.0
         for x in range(xmax):
             v = (x + xmin - center + 0.5) * ss
-            if v < 0.0:
-                v = -v
-            wv = 1.0 - v if v < 1.0 else 0.0
+            if box:                                   # box_filter: 1 on (-0.5, 0.5]
+                wv = 1.0 if -0.5 < v <= 0.5 else 0.0
+            else:                                     # bilinear_filter
+                if v < 0.0:
+                    v = -v
+                wv = 1.0 - v if v < 1.0 else 0.0
             w[x] = wv
             ww += wv
         if ww != 0.0:
@@ -97,11 +102,11 @@ def letterbox_geometry(h0, w0, new_shape, auto=True, scaleup=True):
 _table_cache = {}
 
 
-def _device_tables(in_size, out_size, device):
-    key = (in_size, out_size, str(device))
+def _device_tables(in_size, out_size, device, filt='bilinear'):
+    key = (in_size, out_size, str(device), filt)
     hit = _table_cache.get(key)
     if hit is None:
-        b, k, ksize = identity_tables(in_size) if in_size == out_size else resample_tables(in_size, out_size)
+        b, k, ksize = identity_tables(in_size) if in_size == out_size else resample_tables(in_size, out_size, filt)
         hit = (torch.from_numpy(b).to(device), torch.from_numpy(np.ascontiguousarray(k)).to(device), ksize)
         if len(_table_cache) > 64:
             _table_cache.clear()
@@ -208,12 +213,12 @@ def resize_to_device(frame, out_hw, device, code=imgtables.ARITH_CV2_LINEAR, lib
     return out
 
 
-def resample_reference(img, out_hw):
+def resample_reference(img, out_hw, filt='bilinear'):
     """Integer restatement of the two passes on the host (numpy), used by the CPU tests to pin ``resample_tables`` to Pillow."""
     h0, w0, c = img.shape
     new_h, new_w = out_hw
-    hb, hk, _ = identity_tables(w0) if w0 == new_w else resample_tables(w0, new_w)
-    vb, vk, _ = identity_tables(h0) if h0 == new_h else resample_tables(h0, new_h)
+    hb, hk, _ = identity_tables(w0) if w0 == new_w else resample_tables(w0, new_w, filt)
+    vb, vk, _ = identity_tables(h0) if h0 == new_h else resample_tables(h0, new_h, filt)
     src = img.astype(np.int64)
     tmp = np.empty((h0, new_w, c), dtype=np.int64)
     for x in range(new_w):
@@ -226,6 +231,71 @@ def resample_reference(img, out_hw):
         acc = (1 << (PRECISION_BITS - 1)) + (tmp[y0:y0 + n] * vk[y, :n].astype(np.int64)[:, None, None]).sum(0)
         out[y] = np.clip(acc >> PRECISION_BITS, 0, 255).astype(np.uint8)
     return out
+
+
+# ------------------------------------------------------------------------------------- evaluation / rect items (first slice)
+def render_letterbox_items(batch, device, out=None, maxabsscaler=False, lib=None):
+    """A ``utils.datasets.LetterboxBatch`` (or a list of ``LetterboxItem``) -> the network input ``(n, c, H, W)`` fp32 on ``device``:
+    what ``imgs.to(device).float() / 256.0`` (test.py:95-96) makes of the host loader's items.  Per item ONE ``yh_letterbox_fwd``:
+    load_image's resize (datasets.py:519-526) + letterbox's border (:637-643) + scaling + HWC->CHW; one upload per batch.
+
+    Pillow arithmetic: Image.BOX when shrinking, as ``utils.datasets.load_image`` does for evaluation; cv2 arithmetic: INTER_AREA
+    (general or integer-factor form), or INTER_LINEAR where the reference's load_image would use it."""
+    from utils.datasets import LetterboxBatch
+    lib = lib or hiplib.load()
+    if not isinstance(batch, LetterboxBatch):
+        batch = LetterboxBatch(batch)
+    items = batch.items
+    n, c = len(items), items[0].channels
+    H, W = items[0].out_hw
+    if any(tuple(it.out_hw) != (H, W) for it in items):
+        raise ValueError('the items of a batch must share their rectangle')
+    device = torch.device(device)
+    if out is None:
+        out = torch.empty((n, c, H, W), dtype=torch.float32, device=device)
+    assert out.is_contiguous() and tuple(out.shape) == (n, c, H, W) and out.dtype == torch.float32
+    dev_buf = batch.blob.to(device, non_blocking=True)
+    base, P = dev_buf.data_ptr(), hiplib.ptr
+    keep = []
+    with hiplib.on_device(dev_buf):
+        for i, it in enumerate(items):
+            h0, w0 = it.frame
+            h, w = it.resized_hw
+            d = LetterboxDesc(src=base + int(batch.offsets[i]), tmp=base, dst=out[i].data_ptr(), h0=h0, w0=w0, c=c, src_pitch=w0 * c,
+                              new_h=h, new_w=w, out_h=H, out_w=W, top=it.top, left=it.left, pad_value=PAD_VALUE, swap_rb=0,
+                              scale=(2.0 / 256.0) if maxabsscaler else (1.0 / 256.0), shift=-1.0 if maxabsscaler else 0.0, out_u8=0)
+            if it.arith == 'cv2':
+                code = it.code if it.code is not None else imgtables.ARITH_CV2_LINEAR          # same size: the identity tables
+                d.arith = code
+                if code == imgtables.ARITH_CV2_AREA_FAST:
+                    d.hksize, d.vksize = imgtables.cv2_area_is_fast((w0, h0), (w, h))
+                else:
+                    tabs = _cv2_tables_on(device, w0, w, True, code) + _cv2_tables_on(device, h0, h, False, code)
+                    d.hbounds, d.hk, d.hksize, d.vbounds, d.vk, d.vksize = P(tabs[0]), P(tabs[1]), tabs[2], P(tabs[3]), P(tabs[4]), tabs[5]
+            else:
+                filt = 'box' if it.code in (imgtables.ARITH_CV2_AREA, imgtables.ARITH_CV2_AREA_FAST) else 'bilinear'
+                hb, hk, d.hksize = _device_tables(w0, w, device, filt)
+                vb, vk, d.vksize = _device_tables(h0, h, device, filt)
+                tmp = torch.empty((h0, w, c), dtype=torch.uint8, device=device)
+                keep.append(tmp)
+                d.arith, d.tmp, d.hbounds, d.hk, d.vbounds, d.vk = imgtables.ARITH_PILLOW, P(tmp), P(hb), P(hk), P(vb), P(vk)
+            hiplib.check(lib.yh_letterbox_fwd(C.byref(d), hiplib.stream_ptr()), 'yh_letterbox_fwd')
+    return out
+
+
+_cv2_axis_cache = {}
+
+
+def _cv2_tables_on(device, in_size, out_size, horizontal, code):
+    key = (in_size, out_size, horizontal, code, str(device))
+    hit = _cv2_axis_cache.get(key)
+    if hit is None:
+        b, k, ksize = _cv2_axis_tables(in_size, out_size, horizontal, code)
+        hit = (torch.from_numpy(np.ascontiguousarray(b)).to(device), torch.from_numpy(np.ascontiguousarray(k)).to(device), ksize)
+        if len(_cv2_axis_cache) > 128:
+            _cv2_axis_cache.clear()
+        _cv2_axis_cache[key] = hit
+    return hit
 
 
 # ----------------------------------------------------------------------------------------------- training items (second slice)

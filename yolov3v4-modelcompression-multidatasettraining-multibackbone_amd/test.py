@@ -17,7 +17,7 @@ from torch.utils.data import DataLoader
 
 from models import Darknet, attempt_download, load_darknet_weights
 from utils import torch_utils
-from utils.datasets import LoadImagesAndLabels
+from utils.datasets import LoadImagesAndLabels, LetterboxBatch
 from utils.parse_config import parse_data_cfg
 from utils.utils import (ap_per_class, box_iou, clip_coords, coco80_to_coco91_class, compute_loss, load_classes,
                          non_max_suppression, output_to_target, plot_images, scale_coords, xywh2xyxy, xyxy2xywh)
@@ -85,7 +85,11 @@ def test(cfg, data, weights=None, batch_size=16, imgsz=416, conf_thres=0.001, io
     niou = iouv.numel()
 
     if dataloader is None:
-        dataset = LoadImagesAndLabels(data['valid'], imgsz, batch_size, rect=True, is_gray_scale=is_gray_scale)
+        # on a GPU the items are recipes: load_image's resize, letterbox's border, / 256 and HWC -> CHW run there, bit-identical to
+        # the host loader's items (engine/preprocess.py render_letterbox_items; --host-letterbox restores the host path)
+        dataset = LoadImagesAndLabels(data['valid'], imgsz, batch_size, rect=True, is_gray_scale=is_gray_scale,
+                                      device_letterbox=device.type == 'cuda' and not getattr(opt, 'host_letterbox', False),
+                                      arith=getattr(opt, 'image_arith', None))
         batch_size = min(batch_size, len(dataset))
         dataloader = DataLoader(dataset, batch_size=batch_size, num_workers=min([os.cpu_count() or 1, batch_size if batch_size > 1 else 0, 8]),
                                 pin_memory=device.type != 'cpu', collate_fn=dataset.collate_fn)
@@ -99,9 +103,13 @@ def test(cfg, data, weights=None, batch_size=16, imgsz=416, conf_thres=0.001, io
     loss = torch.zeros(3, device=device)
     jdict, stats, ap, ap_class = [], [], [], []
     for batch_i, (imgs, targets, paths, shapes) in enumerate(tqdm(dataloader, desc=header) if rank in (-1, 0) else dataloader):
-        imgs = imgs.to(device).float() / 256.0          # uint8 -> [0, 1): the reference divides by 256 (test.py:96)
-        if maxabsscaler:
-            imgs = imgs * 2 - 1
+        if isinstance(imgs, LetterboxBatch):
+            from engine.preprocess import render_letterbox_items
+            imgs = render_letterbox_items(imgs, device, maxabsscaler=maxabsscaler)
+        else:
+            imgs = imgs.to(device).float() / 256.0      # uint8 -> [0, 1): the reference divides by 256 (test.py:96)
+            if maxabsscaler:
+                imgs = imgs * 2 - 1
         targets = targets.to(device)
         nb, _, height, width = imgs.shape
         whwh = torch.tensor([width, height, width, height], dtype=torch.float32, device=device)
@@ -190,6 +198,9 @@ if __name__ == '__main__':
     parser.add_argument('--task', default='test', help="'test', 'study', 'benchmark'")
     parser.add_argument('--device', default='', help='device id (i.e. 0 or 0,1) or cpu')
     parser.add_argument('--augment', action='store_true', help='augmented inference')
+    parser.add_argument('--host-letterbox', action='store_true', help='resize / letterbox the evaluation images on the host (default on a GPU: on the device)')
+    parser.add_argument('--image-arith', choices=['pillow', 'cv2'], default=None,
+                        help="uint8 arithmetic of the device loader: 'pillow' = the host loader's, 'cv2' = the reference's OpenCV calls restated")
     parser.add_argument('--quantized', type=int, default=-1, help='quantization way')
     parser.add_argument('--shortcut_way', type=int, default=1, help='--shortcut quantization way')
     parser.add_argument('--a-bit', type=int, default=8, help='a-bit')

@@ -198,7 +198,8 @@ def train(opt, hyp):
     testloader = None
     if _is_main(rank) or distributed:
         testset = LoadImagesAndLabels(test_path, imgsz_test, max(batch_size // 4, 1), hyp=hyp, rect=True, rank=rank,
-                                      is_gray_scale=opt.gray_scale)
+                                      is_gray_scale=opt.gray_scale, device_letterbox=device.type == 'cuda',
+                                      arith=getattr(opt, 'image_arith', None) if device.type == 'cuda' else None)
         testloader = DataLoader(testset, batch_size=max(batch_size // 4, 1), num_workers=nw, pin_memory=device.type != 'cpu',
                                 collate_fn=testset.collate_fn)
 

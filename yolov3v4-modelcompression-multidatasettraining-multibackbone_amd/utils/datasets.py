@@ -338,6 +338,78 @@ class MosaicBatch:
         return len(self.items)
 
 
+class LetterboxItem:
+    """One evaluation / rect item with the pixel work left undone (``device_letterbox``): the decoded frame, the size load_image
+    would resize it to and with which filter, and where letterbox would put it in the batch rectangle - what ``yh_letterbox_fwd``
+    needs - plus the finished labels and the ``shapes`` tuple test.py rescales boxes with."""
+    __slots__ = ('frame', 'resized_hw', 'code', 'out_hw', 'top', 'left', 'channels', 'labels', 'path', 'shapes', 'arith')
+
+
+class LetterboxBatch:
+    """A collated batch of ``LetterboxItem``: every frame in ONE uint8 tensor (pinned by the DataLoader, one upload)."""
+
+    def __init__(self, items):
+        import copy
+        self.items = [copy.copy(it) for it in items]
+        sizes = [it.frame.size for it in self.items]
+        self.offsets = np.concatenate([[0], np.cumsum([(n + 15) // 16 * 16 for n in sizes])]).astype(np.int64)
+        self.blob = torch.empty(int(self.offsets[-1]) + 16, dtype=torch.uint8)
+        flat = self.blob.numpy()
+        for k, it in enumerate(self.items):
+            flat[self.offsets[k]:self.offsets[k] + it.frame.size] = it.frame.reshape(-1)
+            it.frame = tuple(it.frame.shape[:2])       # shape only: the pixels live in the blob
+
+    def pin_memory(self):
+        self.blob = self.blob.pin_memory()
+        return self
+
+    def __len__(self):
+        return len(self.items)
+
+
+def letterbox_item(self, index):
+    """``__getitem__`` of the non-augmenting path (datasets.py:480-505: load_image + letterbox + label shift) as a recipe."""
+    from engine import imgtables
+    it = LetterboxItem()
+    it.arith, it.channels = self.arith, 1 if self.is_gray_scale else 3
+    img = _read(self.img_files[index], self.is_gray_scale)
+    h0, w0 = img.shape[:2]
+    (h, w), code = imgtables.load_image_plan(h0, w0, self.img_size, self.augment)
+    shape = self.batch_shapes[self.batch[index]] if self.rect else self.img_size
+    if isinstance(shape, int):
+        shape = (shape, shape)
+    # letterbox(img, shape, auto=False, scaleup=False): never enlarges; an image larger than its rectangle would be resized a
+    # second time - the rect batch shapes are built so that this cannot happen
+    r = min(min(shape[0] / h, shape[1] / w), 1.0)
+    if (int(round(w * r)), int(round(h * r))) != (w, h):
+        raise NotImplementedError('%s: %dx%d does not fit its batch rectangle %s after load_image; a second resize inside letterbox '
+                                  'is not built for device_letterbox' % (self.img_files[index], w, h, tuple(shape)))
+    dw, dh = (shape[1] - w) / 2, (shape[0] - h) / 2
+    top, bottom = int(round(dh - 0.1)), int(round(dh + 0.1))
+    left, right = int(round(dw - 0.1)), int(round(dw + 0.1))
+    it.frame, it.resized_hw, it.code = img, (h, w), code
+    it.out_hw, it.top, it.left = (h + top + bottom, w + left + right), top, left
+    it.shapes = (h0, w0), ((h / h0, w / w0), (dw, dh))
+    x = self.labels[index]
+    labels = np.zeros((0, 5), dtype=np.float32)
+    if x.size:
+        labels = x.copy()
+        labels[:, 1] = r * w * (x[:, 1] - x[:, 3] / 2) + dw
+        labels[:, 2] = r * h * (x[:, 2] - x[:, 4] / 2) + dh
+        labels[:, 3] = r * w * (x[:, 1] + x[:, 3] / 2) + dw
+        labels[:, 4] = r * h * (x[:, 2] + x[:, 4] / 2) + dh
+    n_l = len(labels)
+    if n_l:
+        labels[:, 1:5] = xyxy2xywh(labels[:, 1:5])
+        labels[:, [2, 4]] /= it.out_hw[0]
+        labels[:, [1, 3]] /= it.out_hw[1]
+    it.labels = torch.zeros((n_l, 6))
+    if n_l:
+        it.labels[:, 1:] = torch.from_numpy(np.ascontiguousarray(labels))
+    it.path = self.img_files[index]
+    return it
+
+
 def mosaic_item(self, index):
     """``__getitem__`` of the augmenting mosaic path (datasets.py:470-505) with the image left as a recipe."""
     hyp = self.hyp or {}
@@ -421,7 +493,7 @@ class LoadImagesAndLabels(Dataset):
 
     def __init__(self, path, img_size=416, batch_size=16, augment=False, hyp=None, rect=False, image_weights=False,
                  cache_images=False, rank=-1, is_gray_scale=False, subset_len=-1, single_cls=False, pad=0.0, device_augment=False,
-                 arith=None):
+                 arith=None, device_letterbox=False):
         path = str(Path(path))
         if os.path.isdir(path):
             files = sorted(glob.glob(os.path.join(path, '*.*')))
@@ -447,11 +519,14 @@ class LoadImagesAndLabels(Dataset):
         self.arith = arith or os.environ.get('YOLO_IMAGE_ARITH', 'pillow')
         if self.arith not in ('pillow', 'cv2'):
             raise ValueError("arith must be 'pillow' or 'cv2', got %r" % (self.arith,))
-        if self.arith == 'cv2' and not self.device_augment:
-            raise NotImplementedError("arith='cv2' (OpenCV's arithmetic) exists on the GPU only: it needs device_augment=True and the "
-                                      "mosaic training path; this package's host loader resizes with Pillow")
-        if self.arith == 'cv2' and cache_images:
-            raise NotImplementedError("arith='cv2' keeps the source frames unresized; cache_images is not supported with it")
+        # evaluation / rect items as recipes: resize (load_image) + border (letterbox) + /256 + HWC->CHW on the GPU
+        # (engine/preprocess.py render_letterbox_items); only without augmentation - rect TRAINING warps single images on the host
+        self.device_letterbox = bool(device_letterbox) and not self.mosaic and not self.augment
+        if self.arith == 'cv2' and not (self.device_augment or self.device_letterbox):
+            raise NotImplementedError("arith='cv2' (OpenCV's arithmetic) exists on the GPU only: it needs device_augment=True (mosaic "
+                                      "training) or device_letterbox=True (evaluation); this package's host loader resizes with Pillow")
+        if (self.arith == 'cv2' or self.device_letterbox) and cache_images:
+            raise NotImplementedError('the device recipes keep the source frames unresized; cache_images is not supported with them')
         self.is_gray_scale = is_gray_scale
         self.label_files = [x.replace('images', 'labels').replace(os.path.splitext(x)[-1], '.txt') for x in self.img_files]
 
@@ -511,6 +586,8 @@ class LoadImagesAndLabels(Dataset):
         hyp = self.hyp or {}
         if self.device_augment:
             return mosaic_item(self, index)
+        if self.device_letterbox:
+            return letterbox_item(self, index)
         if self.mosaic:
             img, labels = load_mosaic(self, index, self.is_gray_scale)
             shapes = None
@@ -555,6 +632,11 @@ class LoadImagesAndLabels(Dataset):
             for i, it in enumerate(batch):
                 it.labels[:, 0] = i
             return MosaicBatch(batch), torch.cat([it.labels for it in batch], 0), tuple(it.path for it in batch), (None,) * len(batch)
+        if batch and isinstance(batch[0], LetterboxItem):  # device_letterbox: (LetterboxBatch, labels, paths, shapes)
+            for i, it in enumerate(batch):
+                it.labels[:, 0] = i
+            return (LetterboxBatch(batch), torch.cat([it.labels for it in batch], 0), tuple(it.path for it in batch),
+                    tuple(it.shapes for it in batch))
         img, label, path, shapes = zip(*batch)
         for i, l in enumerate(label):
             l[:, 0] = i   # image index within the batch, for build_targets()
