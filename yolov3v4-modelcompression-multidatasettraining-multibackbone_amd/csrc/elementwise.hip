@@ -121,7 +121,10 @@ __global__ __launch_bounds__(256) void conv_stem_kernel(const yh_stem_desc d) {
     const float* xin = d.x + (long)n * d.cin * d.h * d.w_in;
     if constexpr (K33) {
         // 3 x 3 taps of 3 planes (the RGB first layer): the nine samples of one filter row are loaded before their 9 x CO / 2 FMAs, so
-        // a wave waits for memory three times per pixel instead of 27; the order of the additions is the rolled loop's
+        // a wave waits for memory three times per pixel instead of 27; the order of the additions is the rolled loop's.
+        // profiles/r03_stem_ab.txt (608 x 608, batch 64): 0.725 ms against 1.00 ms for the tap-by-tap loop (YH_STEM_ROLLED); two
+        // pixels per thread with the next tap's weights prefetched into a second scalar register set was bit-identical too but ran
+        // 1.00 ms again: 113 VGPRs / 106 SGPRs leave 4 waves per SIMD where this form keeps 7, and occupancy is what hides the loads
 #pragma unroll 1
         for (int r = 0; r < 3; ++r) {
             const int hi = hi0 + r;
