@@ -124,7 +124,8 @@ __global__ __launch_bounds__(256) void conv_stem_kernel(const yh_stem_desc d) {
         // a wave waits for memory three times per pixel instead of 27; the order of the additions is the rolled loop's.
         // profiles/r03_stem_ab.txt (608 x 608, batch 64): 0.725 ms against 1.00 ms for the tap-by-tap loop (YH_STEM_ROLLED); two
         // pixels per thread with the next tap's weights prefetched into a second scalar register set was bit-identical too but ran
-        // 1.00 ms again: 113 VGPRs / 106 SGPRs leave 4 waves per SIMD where this form keeps 7, and occupancy is what hides the loads
+        // 1.00 ms again: 113 VGPRs / 106 SGPRs leave 4 waves per SIMD where this form keeps 7, and occupancy is what hides the loads;
+        // 16 instead of 32 output channels per thread (twice the sample loads, more waves): 1.37 ms
 #pragma unroll 1
         for (int r = 0; r < 3; ++r) {
             const int hi = hi0 + r;
