@@ -90,3 +90,55 @@ def test_kernel_equals_the_host_loader(dataset_dir, hyp, size, gray):
     assert diff.max().item() == 0, 'uint8 items differ: %d pixels, worst %d' % ((diff > 0).sum().item(), diff.max().item())
     gotf = pp.render_mosaic_items(items, 'cuda', dtype=torch.float32)
     assert torch.equal(gotf.cpu(), want.float() / 256.0)          # train.py:345 on the host items
+
+
+# ----------------------------------------------------------------------------- rect training: one letterboxed image per item
+def _rect_pair(dataset_dir, size, hyp, gray=False):
+    kw = dict(img_size=size, batch_size=4, augment=True, hyp=hyp, rect=True, is_gray_scale=gray)
+    host = datasets.LoadImagesAndLabels(str(dataset_dir / 'train.txt'), **kw)
+    dev = datasets.LoadImagesAndLabels(str(dataset_dir / 'train.txt'), device_augment=True, **kw)
+    assert dev.device_rect_augment and not dev.mosaic and not dev.device_augment
+    return host, dev
+
+
+@pytest.mark.parametrize('hyp', HYPS, ids=['crop', 'train_hyp', 'wild'])
+@pytest.mark.parametrize('size,gray', [(96, False), (160, False), (128, True)])
+def test_rect_training_recipe_rendered_on_the_host_equals_the_host_loader(dataset_dir, hyp, size, gray):
+    host, dev = _rect_pair(dataset_dir, size, hyp, gray)
+    for seed in range(6):
+        index = seed % len(host)
+        (img, labels, path, shapes), tail_h = _items(host, index, seed)
+        item, tail_d = _items(dev, index, seed)
+        assert tail_h == tail_d, 'the recipe path consumed the random streams differently'
+        assert path == item.path and torch.equal(labels, item.labels)
+        got = pp.mosaic_reference(item)
+        assert got.shape == tuple(img.shape) and np.array_equal(got, img.numpy()), (seed, np.abs(got.astype(int) - img.numpy().astype(int)).max())
+    # a rect batch collates like a mosaic batch (one rectangle per batch)
+    random.seed(5)
+    np.random.seed(5)
+    idx = [i for i in range(len(dev)) if dev.batch[i] == 0]
+    batch, labels, paths, _ = datasets.LoadImagesAndLabels.collate_fn([dev[i] for i in idx])
+    assert len(batch) == len(idx) and len({tuple(it.out_hw) for it in batch.items}) == 1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('hyp', HYPS, ids=['crop', 'train_hyp', 'wild'])
+@pytest.mark.parametrize('size,gray', [(96, False), (160, False), (128, True)])
+def test_kernel_renders_rect_training_items_like_the_host_loader(dataset_dir, hyp, size, gray):
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU')
+    host, dev = _rect_pair(dataset_dir, size, hyp, gray)
+    for b in sorted(set(host.batch.tolist())):
+        idx = [i for i in range(len(host)) if host.batch[i] == b]
+        want, items = [], []
+        for k, index in enumerate(idx):
+            (img, labels, _, _), _ = _items(host, index, 10 * b + k)
+            item, _ = _items(dev, index, 10 * b + k)
+            assert torch.equal(labels, item.labels)
+            want.append(img)
+            items.append(item)
+        want = torch.stack(want)
+        got = pp.render_mosaic_items(items, 'cuda', dtype=torch.uint8)
+        torch.cuda.synchronize()
+        assert torch.equal(got.cpu(), want)
+        assert torch.equal(pp.render_mosaic_items(items, 'cuda', dtype=torch.float32).cpu(), want.float() / 256.0)

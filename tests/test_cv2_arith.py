@@ -400,3 +400,58 @@ def test_kernel_eval_recipes_in_cv2_arithmetic(dataset_dir, size, gray):
         torch.cuda.synchronize()
         return out
     _eval_batches(dataset_dir, size, gray, render)
+
+
+# ------------------------------------------------------------------------------------ rect training items in cv2 arithmetic
+def _reference_rect_item(ds, index, seed):
+    """The reference's augmenting non-mosaic __getitem__ (datasets.py:480-505): load_image (INTER_LINEAR), letterbox to the batch
+    rectangle, random_affine (border 0), augment_hsv, flip - on the restated cv2 calls."""
+    random.seed(seed)
+    np.random.seed(seed)
+    hyp = ds.hyp
+    img = cv.load_image_resize(datasets._read(ds.img_files[index], ds.is_gray_scale), ds.img_size, True)
+    shape = tuple(int(v) for v in ds.batch_shapes[ds.batch[index]])
+    img, ratio, pad = cv.letterbox(img, shape, auto=False, scaleup=True)
+    M, sc, (width, height) = datasets.affine_matrix(img.shape[:2], hyp['degrees'], hyp['translate'], hyp['scale'], hyp['shear'])
+    if (M != np.eye(3)).any():
+        img = cv.warp_affine(img, M[:2], (width, height), (114, 114, 114))
+    if not ds.is_gray_scale:
+        gains = np.random.uniform(-1, 1, 3) * [hyp['hsv_h'], hyp['hsv_s'], hyp['hsv_v']] + 1
+        img = cv.augment_hsv(img, gains, order='rgb')
+    if random.random() < 0.5:
+        img = np.fliplr(img)
+    return np.ascontiguousarray(img.transpose(2, 0, 1))
+
+
+def _rect_ds(dataset_dir, size, hyp, gray, arith):
+    return datasets.LoadImagesAndLabels(str(dataset_dir / 'train.txt'), img_size=size, batch_size=4, augment=True, hyp=hyp, rect=True,
+                                        is_gray_scale=gray, device_augment=True, arith=arith)
+
+
+@pytest.mark.parametrize('hyp', HYPS, ids=['crop', 'train_hyp', 'wild'])
+@pytest.mark.parametrize('size,gray', [(96, False), (160, False), (128, True)])
+def test_cv2_rect_training_recipes_on_the_emulated_abi(dataset_dir, fake, hyp, size, gray):
+    ds, twin = _rect_ds(dataset_dir, size, hyp, gray, 'cv2'), _rect_ds(dataset_dir, size, hyp, gray, 'pillow')
+    for seed in range(4):
+        index = seed % len(ds)
+        item, tail = _recipe(ds, index, seed)
+        item_p, tail_p = _recipe(twin, index, seed)
+        assert tail == tail_p and torch.equal(item.labels, item_p.labels)
+        want = _reference_rect_item(ds, index, seed)
+        got = pp.render_mosaic_items([item], 'cpu', dtype=torch.uint8, lib=fake)[0].numpy()
+        assert got.shape == want.shape and np.array_equal(got, want), (seed, int((got != want).sum()))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('hyp', HYPS, ids=['crop', 'train_hyp', 'wild'])
+@pytest.mark.parametrize('size,gray', [(96, False), (160, False)])
+def test_kernel_rect_training_items_in_cv2_arithmetic(dataset_dir, hyp, size, gray):
+    _gpu()
+    ds = _rect_ds(dataset_dir, size, hyp, gray, 'cv2')
+    for b in sorted(set(ds.batch.tolist())):
+        idx = [i for i in range(len(ds)) if ds.batch[i] == b]
+        items = [_recipe(ds, i, 7 * b + k)[0] for k, i in enumerate(idx)]
+        want = torch.from_numpy(np.stack([_reference_rect_item(ds, i, 7 * b + k) for k, i in enumerate(idx)]))
+        got = pp.render_mosaic_items(items, 'cuda', dtype=torch.uint8)
+        torch.cuda.synchronize()
+        assert torch.equal(got.cpu(), want)

@@ -338,6 +338,21 @@ class MosaicBatch:
         return len(self.items)
 
 
+def _letterbox_plan(h, w, new_shape, scaleup):
+    """The numbers ``letterbox(img, new_shape, auto=False, scaleup=...)`` derives from an h x w image, with the expressions (and
+    therefore the numpy / Python scalar types, which decide whether the label arithmetic below runs in float32 or float64) of
+    ``letterbox`` itself: ``(r, (new_w, new_h), (dw, dh), (top, bottom, left, right))``."""
+    if isinstance(new_shape, int):
+        new_shape = (new_shape, new_shape)
+    r = min(new_shape[0] / h, new_shape[1] / w)
+    if not scaleup:
+        r = min(r, 1.0)
+    unpad = (int(round(w * r)), int(round(h * r)))
+    dw, dh = new_shape[1] - unpad[0], new_shape[0] - unpad[1]
+    dw, dh = dw / 2, dh / 2
+    return r, unpad, (dw, dh), (int(round(dh - 0.1)), int(round(dh + 0.1)), int(round(dw - 0.1)), int(round(dw + 0.1)))
+
+
 class LetterboxItem:
     """One evaluation / rect item with the pixel work left undone (``device_letterbox``): the decoded frame, the size load_image
     would resize it to and with which filter, and where letterbox would put it in the batch rectangle - what ``yh_letterbox_fwd``
@@ -376,17 +391,12 @@ def letterbox_item(self, index):
     h0, w0 = img.shape[:2]
     (h, w), code = imgtables.load_image_plan(h0, w0, self.img_size, self.augment)
     shape = self.batch_shapes[self.batch[index]] if self.rect else self.img_size
-    if isinstance(shape, int):
-        shape = (shape, shape)
     # letterbox(img, shape, auto=False, scaleup=False): never enlarges; an image larger than its rectangle would be resized a
     # second time - the rect batch shapes are built so that this cannot happen
-    r = min(min(shape[0] / h, shape[1] / w), 1.0)
-    if (int(round(w * r)), int(round(h * r))) != (w, h):
+    r, unpad, (dw, dh), (top, bottom, left, right) = _letterbox_plan(h, w, shape, scaleup=False)
+    if unpad != (w, h):
         raise NotImplementedError('%s: %dx%d does not fit its batch rectangle %s after load_image; a second resize inside letterbox '
                                   'is not built for device_letterbox' % (self.img_files[index], w, h, tuple(shape)))
-    dw, dh = (shape[1] - w) / 2, (shape[0] - h) / 2
-    top, bottom = int(round(dh - 0.1)), int(round(dh + 0.1))
-    left, right = int(round(dw - 0.1)), int(round(dw + 0.1))
     it.frame, it.resized_hw, it.code = img, (h, w), code
     it.out_hw, it.top, it.left = (h + top + bottom, w + left + right), top, left
     it.shapes = (h0, w0), ((h / h0, w / w0), (dw, dh))
@@ -468,6 +478,67 @@ def mosaic_item(self, index):
     return it
 
 
+def rect_train_item(self, index):
+    """``__getitem__`` of the augmenting NON-mosaic path (rect training: datasets.py:480-505 with random_affine / augment_hsv / flip
+    of the single letterboxed image) as a recipe for the same kernel: a mosaic with one part on a canvas the size of the batch
+    rectangle, border 0.  Random draws in the host path's order (six ``random.uniform``, one ``np.random.uniform(-1, 1, 3)``, one
+    ``random.random``)."""
+    hyp = self.hyp or {}
+    it = MosaicItem()
+    it.channels, it.arith = 1 if self.is_gray_scale else 3, self.arith
+    cv2_arith = self.arith == 'cv2'
+    if cv2_arith:
+        img, (h0, w0), (h, w), _ = load_image_lazy(self, index, self.is_gray_scale)
+    else:
+        img, (h0, w0), (h, w) = load_image(self, index, self.is_gray_scale)
+    shape = self.batch_shapes[self.batch[index]] if self.rect else self.img_size
+    r, unpad, (dw, dh), (top, bottom, left, right) = _letterbox_plan(h, w, shape, scaleup=True)    # letterbox(..., auto=False, scaleup=True)
+    if unpad != (w, h):
+        raise NotImplementedError('%s: letterbox would resize the %dx%d image a second time for the rectangle %s; not built for '
+                                  'device_augment' % (self.img_files[index], w, h, tuple(shape)))
+    canvas = (h + top + bottom, w + left + right)
+    x = self.labels[index]
+    labels = np.zeros((0, 5), dtype=np.float32)
+    if x.size:
+        labels = x.copy()
+        labels[:, 1] = r * w * (x[:, 1] - x[:, 3] / 2) + dw
+        labels[:, 2] = r * h * (x[:, 2] - x[:, 4] / 2) + dh
+        labels[:, 3] = r * w * (x[:, 1] + x[:, 3] / 2) + dw
+        labels[:, 4] = r * h * (x[:, 2] + x[:, 4] / 2) + dh
+    M, sc, (width, height) = affine_matrix(canvas, hyp.get('degrees', 0), hyp.get('translate', 0), hyp.get('scale', 0), hyp.get('shear', 0))
+    labels = affine_targets(labels, M, sc, width, height)
+    if not (M != np.eye(3)).any():                          # random_affine leaves the image alone; the unit map is exact in both arithmetics
+        it.inv = np.array([1.0, 0.0, 0.0, 0.0, 1.0, 0.0])
+    elif cv2_arith:
+        from engine import imgtables
+        it.inv = imgtables.cv2_invert_affine(M[:2])
+    else:
+        it.inv = np.linalg.inv(M)[:2].reshape(-1).astype(np.float64)
+    it.canvas, it.out_hw = canvas, (height, width)
+    it.hsv_gains = None
+    if not self.is_gray_scale:
+        it.hsv_gains = np.random.uniform(-1, 1, 3) * [hyp.get('hsv_h', 0), hyp.get('hsv_s', 0), hyp.get('hsv_v', 0)] + 1
+    n_l = len(labels)
+    if n_l:
+        labels[:, 1:5] = xyxy2xywh(labels[:, 1:5])
+        labels[:, [2, 4]] /= height
+        labels[:, [1, 3]] /= width
+    it.flip = random.random() < 0.5
+    if it.flip and n_l:
+        labels[:, 1] = 1 - labels[:, 1]
+    it.labels = torch.zeros((n_l, 6))
+    if n_l:
+        it.labels[:, 1:] = torch.from_numpy(np.ascontiguousarray(labels))
+    it.path = self.img_files[index]
+    rect = (left, top, left + w, top + h)
+    empty = (None, (0, 0, 0, 0), (0, 0)) + ((None,) if cv2_arith else ())
+    if cv2_arith:
+        it.parts = [(np.ascontiguousarray(img), rect, (0, 0), (h0, w0, h, w, 0, 0, 0, 0))] + [empty] * 3
+    else:
+        it.parts = [(np.ascontiguousarray(img), rect, (0, 0))] + [empty] * 3
+    return it
+
+
 _axis_index_cache = {}
 
 
@@ -515,6 +586,8 @@ class LoadImagesAndLabels(Dataset):
         self.mosaic = self.augment and not self.rect
         # the mosaic / warp / HSV / flip pixel work on the GPU (engine/preprocess.py render_mosaic_items): items are recipes
         self.device_augment = bool(device_augment) and self.mosaic
+        # rect training (augment without mosaic): the same kernel renders the single letterboxed image - a one-part "mosaic"
+        self.device_rect_augment = bool(device_augment) and self.augment and not self.mosaic
         # 'cv2': the reference's OpenCV arithmetic (resize, warp, HSV) - evaluated by the GPU kernels only, so only for recipes
         self.arith = arith or os.environ.get('YOLO_IMAGE_ARITH', 'pillow')
         if self.arith not in ('pillow', 'cv2'):
@@ -522,9 +595,9 @@ class LoadImagesAndLabels(Dataset):
         # evaluation / rect items as recipes: resize (load_image) + border (letterbox) + /256 + HWC->CHW on the GPU
         # (engine/preprocess.py render_letterbox_items); only without augmentation - rect TRAINING warps single images on the host
         self.device_letterbox = bool(device_letterbox) and not self.mosaic and not self.augment
-        if self.arith == 'cv2' and not (self.device_augment or self.device_letterbox):
-            raise NotImplementedError("arith='cv2' (OpenCV's arithmetic) exists on the GPU only: it needs device_augment=True (mosaic "
-                                      "training) or device_letterbox=True (evaluation); this package's host loader resizes with Pillow")
+        if self.arith == 'cv2' and not (self.device_augment or self.device_rect_augment or self.device_letterbox):
+            raise NotImplementedError("arith='cv2' (OpenCV's arithmetic) exists on the GPU only: it needs device_augment=True (training) "
+                                      "or device_letterbox=True (evaluation); this package's host loader resizes with Pillow")
         if (self.arith == 'cv2' or self.device_letterbox) and cache_images:
             raise NotImplementedError('the device recipes keep the source frames unresized; cache_images is not supported with them')
         self.is_gray_scale = is_gray_scale
@@ -586,6 +659,8 @@ class LoadImagesAndLabels(Dataset):
         hyp = self.hyp or {}
         if self.device_augment:
             return mosaic_item(self, index)
+        if self.device_rect_augment:
+            return rect_train_item(self, index)
         if self.device_letterbox:
             return letterbox_item(self, index)
         if self.mosaic:
