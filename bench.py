@@ -661,6 +661,7 @@ def detect_main(args, device, dist, world, rank, cpu_baseline_leg=True):
         else:
             model = fm
         del fm
+        model.hip_return_raw = False      # as detect.py: it reads model(img)[0] only, the raw head maps are not copied out
         with torch.no_grad():
             model(x)                      # builds the plan: lowering errors surface here
         torch.cuda.synchronize()

@@ -603,6 +603,9 @@ void yh_plan_destroy(yh_plan* p);
 int yh_plan_add(yh_plan* p, int op_kind, const void* desc, int desc_bytes); /* returns op index or <0 */
 int yh_plan_add_fixup(yh_plan* p, int op_index, int field_offset, int slot, int64_t byte_offset);
 int yh_plan_bind_slot(yh_plan* p, int slot, void* ptr);
+/* Binding a slot to YH_SLOT_NULL makes its fixups write NULL into their fields: an optional output the caller does not want this
+ * call (the raw head copies of yh_yolo_decode).  A slot that was never bound still fails the run with YH_EINVAL.                   */
+#define YH_SLOT_NULL ((void*)(intptr_t)-1)
 int yh_plan_num_ops(const yh_plan* p);
 int yh_plan_run(yh_plan* p, void* stream);
 /* run ops [first, last) only (profiling / per-layer tests) */

@@ -932,7 +932,7 @@ class FakeLib:
         return 0
 
     def yh_plan_bind_slot(self, h, slot, p):
-        self.plans[_addr(h)]['slots'][slot] = _addr(p)
+        self.plans[_addr(h)]['slots'][slot] = _addr(p)      # hiplib.SLOT_NULL = 'bound to nothing': fixups then write NULL
         return 0
 
     def yh_plan_num_ops(self, h):
@@ -975,7 +975,9 @@ class FakeLib:
             kind, desc, fixups = plan['ops'][i]
             d = type(desc).from_buffer_copy(bytes(desc))
             for off, slot, boff in fixups:
-                C.c_void_p.from_address(C.addressof(d) + off).value = plan['slots'][slot] + boff
+                base = plan['slots'][slot]
+                assert base, 'slot %d was never bound' % slot
+                C.c_void_p.from_address(C.addressof(d) + off).value = None if base == hiplib.SLOT_NULL else base + boff
             rc = run[kind](d, stream)
             self.calls.append(kind)
             return rc

@@ -209,6 +209,28 @@ def test_graph_replay_equals_direct_replay(cfg_dir):
     assert not torch.equal(outs[8][0][0], outs[8][1][0]), 'graph must see the new frame'
 
 
+@pytest.mark.parametrize('graph', [0, 8], ids=['launches', 'hipgraph'])
+def test_raw_head_copies_can_be_switched_off_and_on(cfg_dir, graph):
+    """detect.py reads model(img)[0] only and sets Darknet.hip_return_raw = False: the decode kernel then skips its copy of the raw
+    head maps (slot bound to YH_SLOT_NULL); detections unchanged, and the copies come back when asked for again."""
+    model = build_mirror(cfg_dir, 'yolov3/yolov3.cfg', 320).cuda()
+    model.hip_precision = 'fp16'
+    x = synth.image_batch(2, 320, seed=52).cuda()
+    with torch.no_grad():
+        model(x)
+    model.__dict__['_hip_engine'].graph_max_batch = graph
+    with torch.no_grad():
+        inf, raws, _ = model(x)
+        inf, raws = inf.clone(), [r.clone() for r in raws]
+        model.hip_return_raw = False
+        inf2, raws2, _ = model(x)
+        inf2 = inf2.clone()
+        model.hip_return_raw = True
+        inf3, raws3, _ = model(x)
+    assert len(raws) == 3 and len(raws2) == 0 and torch.equal(inf, inf2) and torch.equal(inf, inf3)
+    assert all(torch.equal(a, b) for a, b in zip(raws, raws3))
+
+
 @pytest.mark.parametrize('which', ['odd', 'odd_mobile', 'ghost'])
 @pytest.mark.parametrize('precision', ['fp32', 'fp16'])
 def test_unfused_and_padded_forms_match_eager(which, precision):

@@ -177,6 +177,22 @@ def test_feature_out_on_request(cfg_dir):
         assert a.shape == b.shape and (a - b).abs().max().item() <= 2e-4 * max(1.0, b.abs().max().item())
 
 
+def test_raw_head_copies_only_on_request(cfg_dir):
+    """The second return value of an eval forward (the raw head maps) is a copy the decode kernel makes; detect.py reads
+    model(img)[0] only and switches it off (Darknet.hip_return_raw = False): same detections, no raw tensors, and back on again."""
+    model = build_mirror(cfg_dir, 'yolov3tiny/yolov3-tiny-hand.cfg', 64)
+    x = synth.image_batch(2, 64, seed=4)
+    eng = DarknetEngine(model, precision='fp32', lib=fakelib.FakeLib())
+    io, raws, _ = eng(x)
+    assert len(raws) == 2 and all(r.dim() == 5 for r in raws)
+    eng.want_raw = False
+    io2, raws2, _ = eng(x)
+    assert len(raws2) == 0 and torch.equal(io, io2)
+    eng.want_raw = True
+    io3, raws3, _ = eng(x)
+    assert torch.equal(io, io3) and all(torch.equal(a, b) for a, b in zip(raws, raws3))
+
+
 def test_weight_edits_are_picked_up():
     """In-place parameter updates (optimizer step, prune script) must reach the packed weights."""
     import models

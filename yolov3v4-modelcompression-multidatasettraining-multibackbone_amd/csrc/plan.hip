@@ -231,8 +231,8 @@ extern "C" int yh_plan_run_range(yh_plan* p, int first, int last, void* stream) 
         AnyDesc d = op.d;
         for (const Fixup& f : op.fixups) {
             void* base = p->slots[f.slot];
-            if (!base) return YH_EINVAL;
-            void* v = (char*)base + f.byte_offset;
+            if (!base) return YH_EINVAL;                                   // never bound: a bug in the caller
+            void* v = base == YH_SLOT_NULL ? nullptr : (void*)((char*)base + f.byte_offset);   // bound to "nothing": optional outputs
             memcpy((char*)&d + f.field_offset, &v, sizeof(void*));
         }
         hipStream_t s = main_s;

@@ -40,6 +40,7 @@ def detect(opt, save_img=True):
         else:
             load_darknet_weights(model, weights)
     model.to(device).eval()
+    model.hip_return_raw = False      # only model(img)[0] is read below (reference detect.py:104): no copies of the raw head maps
 
     device_letterbox = device.type == 'cuda' and not getattr(opt, 'host_letterbox', False)
     dataset = LoadImages(source, img_size=imgsz, is_gray_scale=opt.gray_scale, rect=opt.rect, host_letterbox=not device_letterbox)

@@ -337,6 +337,9 @@ def check(rc, what=''):
         raise RuntimeError('libyolo_hip %s failed: %s (code %d)' % (what, msg.decode() if msg else '?', rc))
 
 
+SLOT_NULL = C.c_void_p(-1).value     # yh_plan_bind_slot: 'bound to nothing' (include/yolo_hip.h YH_SLOT_NULL)
+
+
 def ptr(t, elem_offset=0):
     """Device address of a torch tensor (+ element offset) as an int usable for c_void_p fields."""
     if t is None:

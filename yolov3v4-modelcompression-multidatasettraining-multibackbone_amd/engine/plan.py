@@ -672,8 +672,7 @@ class DarknetEngine:
                 d.anchor_h[a] = float(h.anchor_vec[a, 1])
             op = add(d, 'yolo%d' % h.block)
             fixup(op, DecodeDesc, 'io', SLOT_IO)
-            if self.want_raw:
-                fixup(op, DecodeDesc, 'raw', SLOT_RAW0 + k)
+            fixup(op, DecodeDesc, 'raw', SLOT_RAW0 + k)      # bound to NULL per call when the caller does not want the copies
             plan['raw_shapes'].append((N, h.na, s.H, s.W, h.no))
             off += h.na * s.H * s.W
         plan['rows'], plan['no'] = rows, no
@@ -751,8 +750,8 @@ class DarknetEngine:
                 if self.want_raw else []
             lib.yh_plan_bind_slot(handle, SLOT_INPUT, x.data_ptr())
             lib.yh_plan_bind_slot(handle, SLOT_IO, io.data_ptr())
-            for k, r in enumerate(raws):
-                lib.yh_plan_bind_slot(handle, SLOT_RAW0 + k, r.data_ptr())
+            for k in range(len(plan['raw_shapes'])):
+                lib.yh_plan_bind_slot(handle, SLOT_RAW0 + k, raws[k].data_ptr() if raws else hiplib.SLOT_NULL)
             hiplib.check(lib.yh_plan_run(handle, hiplib.stream_ptr()), 'yh_plan_run')
         feats = self._features(plan) if self.return_features else []
         return io, tuple(raws), feats
@@ -779,8 +778,8 @@ class DarknetEngine:
                          if self.want_raw else [], want_raw=self.want_raw)
                 lib.yh_plan_bind_slot(handle, SLOT_INPUT, g['x'].data_ptr())
                 lib.yh_plan_bind_slot(handle, SLOT_IO, g['io'].data_ptr())
-                for k, r in enumerate(g['raws']):
-                    lib.yh_plan_bind_slot(handle, SLOT_RAW0 + k, r.data_ptr())
+                for k in range(len(plan['raw_shapes'])):
+                    lib.yh_plan_bind_slot(handle, SLOT_RAW0 + k, g['raws'][k].data_ptr() if g['raws'] else hiplib.SLOT_NULL)
                 g['x'].copy_(x)
                 hiplib.check(lib.yh_plan_run(handle, sp), 'yh_plan_run')   # warm (lazy code loads) before capturing
                 hiplib.check(lib.yh_plan_graph_capture(handle, sp), 'yh_plan_graph_capture')

@@ -483,6 +483,9 @@ class Darknet(nn.Module):
             eng = DarknetEngine(self, precision=precision)
             self.__dict__['_hip_engine'] = eng
         eng.return_features = bool(self.__dict__.get('hip_return_features', False))
+        # the second return value - the raw (bs, na, ny, nx, no) head maps, models.py:336-340 - is a copy the engine makes only for
+        # callers that read it (test.py's validation loss); detect.py reads model(img)[0] alone and switches it off
+        eng.want_raw = bool(self.__dict__.get('hip_return_raw', True))
         with _on_device(x.device):   # kernels launch on the current device / stream: make it the input's
             return eng(x)
 

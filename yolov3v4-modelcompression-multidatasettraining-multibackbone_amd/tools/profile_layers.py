@@ -18,14 +18,9 @@ sys.path.insert(0, os.path.dirname(PKG))
 
 import torch  # noqa: E402
 
-TILE = {1: '128x128', 2: '64x256', 3: '32x256', 4: '64x128', 5: '128x64', 6: '256x128', 11: '128x128k8', 12: '64x256k8',
-        14: '64x128k8', 15: '128x64k8', 16: '256x128k8', 21: 'dma3_128x128', 22: 'dma3_64x256', 24: 'dma3_64x128',
-        25: 'dma3_128x64', 26: 'dma3_256x128', 27: 'dma3_128x256', 41: 'halo_128x256', 51: 'abl_noload', 52: 'abl_nomfma', 42: 'halo_256x256', 31: 'dma4_128x128', 32: 'dma4_64x256', 34: 'dma4_64x128', 35: 'dma4_128x64', 61: 'k64_256x256', 62: 'k64_128x512', 63: 'k64_256x128w4', 64: 'pp_256x256', 65: 'pp_128x512',
-              66: 'pp_512x128', 67: 'pp2_256x256', 68: 'pp2_128x512', 69: 'pp2_512x128'}
-
 
 def main():
-    from bench import build_model, build_qmodel_synthetic
+    from bench import build_model, build_qmodel_synthetic, tile_name
     from engine import hiplib
     ap = argparse.ArgumentParser()
     ap.add_argument('--cfg', default=os.path.join(PKG, 'cfg', 'yolov3', 'yolov3.cfg'))
@@ -70,7 +65,7 @@ def main():
             shape = '%dx%d %d->%d k%d s%d%s%s' % (v.src.H, v.src.W, v.src.C, v.C, v.k, v.stride, ' +res' if v.res is not None else '',
                                                  ' ups' if v.ups == 2 else '')
             if isinstance(d, hiplib.ConvDesc):
-                name = 'igemm_' + TILE[lib.yh_conv2d_tile(C.byref(d))]
+                name = 'igemm_' + tile_name(lib.yh_conv2d_tile(C.byref(d)))
         f = fam.setdefault(name, [0.0, 0.0, 0])
         f[0] += ms
         f[1] += fl
