@@ -176,7 +176,7 @@ def se(lib, code, x, w1, w2, c, cmap=None):
 
 # ------------------------------------------------------------------------------------------------ int8 (PTQ eval)
 def qconv(lib, x, qw, w_scale, qbias, acc_scale, out_scale, k, stride, pad, act=1, slope=0.1, ups=1, out_f32=False, tile=0,
-          cin=None, x_off=0, y=None, y_off=0):
+          cin=None, x_off=0, y=None, y_off=0, res=None, qadd=None):
     """x int8 (N,H,W,ldx); qw fp32 (cout,cin,k,k) = int grid * w_scale; qbias fp32 (cout,) real units."""
     N, H, W, ldx = x.shape
     cout, cin_l = qw.shape[0], qw.shape[1]
@@ -196,6 +196,9 @@ def qconv(lib, x, qw, w_scale, qbias, acc_scale, out_scale, k, stride, pad, act=
                  cout=cout_phys, kh=k, kw=k, stride=stride, pad=pad, ldx=ldx, ldr=0, ldy=y.shape[3], cin_k=cin_k, m_pad=m_pad,
                  act=act, slope=slope, ups=ups, out_f32=1 if out_f32 else 0, dtype=hiplib.YH_I8, tile=tile,
                  acc_scale=float(acc_scale), out_scale=float(out_scale))
+    if res is not None:    # fused quantised shortcut: res int8 (N, Ho, Wo, ldr), qadd = (q_rx, q_ra, q_scale_x, q_scale_a, q_inv_scale_sum)
+        d.res, d.ldr = P(res), res.shape[3]
+        d.q_rx, d.q_ra, d.q_scale_x, d.q_scale_a, d.q_inv_scale_sum = (float(v) for v in qadd)
     rc = lib.yh_conv2d_fwd(C.byref(d), stream())
     assert rc == 0, 'yh_conv2d_fwd(i8) rc=%d' % rc
     return y, packed

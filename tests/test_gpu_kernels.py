@@ -125,6 +125,14 @@ CONV_CASES = [
     (2, 29, 30, 64, 40, 1, 1, 1, False, 1, False, 71, 32, 24),      # (4, 2) cout 40, x and y are channel slices
     (2, 29, 30, 32, 128, 1, 1, 1, False, 1, False, 71, 0, 0),       # (8, 1)
     (1, 20, 20, 64, 255, 1, 1, 0, False, 1, True, 0, 0, 0),         # cout > 128 never takes it (auto)
+    # streaming 3x3 kernel (tile 72): one K step of input channels, exactly 32 / 64 output channels; strides, residual, pixel tails
+    (3, 37, 41, 32, 64, 3, 1, 1, True, 1, False, 72, 0, 0),         # Darknet-53 conv3: 32 -> 64 + shortcut
+    (2, 45, 43, 32, 64, 3, 2, 1, False, 1, False, 72, 0, 0),        # conv1: stride 2, odd sizes
+    (2, 33, 31, 32, 32, 3, 1, 5, False, 1, False, 72, 0, 0),        # 32 output channels (6-wave form), mish
+    (2, 29, 30, 16, 32, 3, 1, 0, True, 1, False, 72, 0, 0),         # cin 16 (lanes past the channels read zeros), linear + conv bias, residual
+    (2, 29, 30, 32, 64, 3, 2, 1, True, 1, False, 72, 32, 64),       # x and y are channel slices, residual
+    (5, 7, 5, 32, 64, 3, 1, 1, False, 1, False, 72, 0, 0),          # tiny images: a block spans several; fewer blocks than waves
+    (1, 3, 5, 32, 32, 3, 1, 1, False, 1, False, 72, 0, 0),          # 15 pixels: less than one block
 ]
 
 
@@ -133,7 +141,7 @@ CONV_CASES = [
 def test_conv_matches_emulation(libs, code, case):
     lib, fake = libs
     N, H, W, cin, cout, k, s, act, use_res, ups, out_f32, tile, xe, ye = case
-    if code == F32 and (61 <= tile <= 69 or tile == 71 or tile == 43):
+    if code == F32 and (61 <= tile <= 69 or tile in (71, 72) or tile == 43):
         pytest.skip('the full-line K step kernels and the streaming 1x1 kernel are fp16 / int8 kernels')
     g = torch.Generator().manual_seed(hash(case) % (2 ** 31))
     dt = oh.tdtype(code)
@@ -379,6 +387,10 @@ QCONV_CASES = [
     (3, 38, 38, 64, 255, 3, 1, 5, 1, False, 43),      # single chunk, mish, cout 255 -> 256 over two weight tiles
     (1, 76, 76, 192, 64, 3, 1, 0, 1, False, 43),      # three chunks, LB 6, linear
     (4, 9, 11, 32, 128, 3, 1, 1, 1, False, 43),       # cin 32: channel tail of the 64-wide chunk, several images per tile
+    (3, 37, 41, 32, 64, 3, 1, 1, 1, False, 72),       # streaming 3x3 kernel on MFMA-i8: cin 32 in the 64-byte step
+    (2, 45, 43, 32, 64, 3, 2, 1, 1, False, 72),       # stride 2
+    (2, 33, 31, 64, 32, 3, 1, 5, 1, False, 72),       # cin 64 (a full step), 32 output channels, mish
+    (2, 29, 30, 48, 64, 3, 1, 0, 1, False, 72),       # cin 48, linear
 ]
 
 
@@ -403,6 +415,31 @@ def test_int8_conv_matches_emulation(libs, case):
     diff = (yg - yc).abs() / (out_scale if out_f32 else 1.0)
     # identical integer sums; a result can only differ by one grid step when the real value sits on a rounding tie
     assert diff.max().item() <= 1.0 and (diff > 0).float().mean().item() <= 1e-4, (diff.max().item(), (diff > 0).float().mean().item())
+
+
+@pytest.mark.parametrize('tile,stride,cout', [(0, 1, 64), (24, 1, 64), (72, 1, 64), (72, 2, 64), (72, 1, 32)],
+                         ids=['auto', 'ring', 'stream3', 'stream3_s2', 'stream3_c32'])
+def test_int8_fused_shortcut_matches_emulation(libs, tile, stride, cout):
+    """The quantised shortcut that follows a conv (COSPTQuantizedShortcut, quantized_ptq_cos.py:877-912) in the conv's epilogue: the
+    same integers from every kernel that carries it (ring, streaming 3x3) and from the emulation."""
+    lib, fake = libs
+    g = torch.Generator().manual_seed(100 + tile + stride + cout)
+    N, H, W, cin, k = 3, 37, 41, 32, 3
+    w_scale, x_scale, out_scale = 2.0 ** -9, 2.0 ** -5, 2.0 ** -4
+    qw = torch.randint(-127, 128, (cout, cin, k, k), generator=g).float() * (torch.rand(cout, cin, k, k, generator=g) < 0.5) * w_scale
+    x = torch.randint(-128, 128, (N, H, W, cin), generator=g).to(torch.int8)
+    qb = torch.randint(-128, 128, (cout,), generator=g).float() * 2.0 ** -6
+    Ho, Wo = (H + 2 - k) // stride + 1, (W + 2 - k) // stride + 1
+    res = torch.randint(-128, 128, (N, Ho, Wo, cout), generator=g).to(torch.int8)
+    qadd = (0.5, 2.0, 2.0 ** -4, 2.0 ** -6, 2.0 ** 3)
+    ys = []
+    for L, dev in ((lib, GPU), (fake, 'cpu')):
+        y, _ = oh.qconv(L, x.to(dev), qw.to(dev), w_scale, qb.to(dev), w_scale * x_scale, out_scale, k, stride, 1, act=1, tile=tile,
+                        res=res.to(dev), qadd=qadd)
+        ys.append(y.float().cpu())
+    diff = (ys[0] - ys[1]).abs()
+    assert diff.max().item() <= 1.0 and (diff > 0).float().mean().item() <= 1e-4, (diff.max().item(), (diff > 0).float().mean().item())
+    assert ys[1].abs().max().item() > 20 and (ys[1].abs() == 127).float().mean().item() < 0.5       # a meaningful range, not saturated
 
 
 def test_int8_movement_ops_match_emulation(libs):

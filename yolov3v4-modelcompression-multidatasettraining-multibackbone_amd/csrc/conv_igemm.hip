@@ -992,10 +992,28 @@ static bool pick_pointwise_tile(const yh_conv_desc* d) {
     return (long)d->n * d->ho * d->wo >= 262144;     // the high-resolution stages; smaller grids keep the ring kernels
 }
 
+// The streaming 3x3 kernel (conv_stream3.hip): one MFMA K step of input channels, at most 64 output channels, large grids; plain
+// dense fp16 / int8 store with or without residual (or fused quantised shortcut); no statistics, upsample or fp32 output.
+static bool stream3_supported(const yh_conv_desc* d) {
+    if (d->dtype != YH_F16 && d->dtype != YH_I8) return false;
+    if (d->kh != 3 || d->kw != 3 || d->pad != 1 || (d->stride != 1 && d->stride != 2) || d->ups != 1 || d->stats_ws || d->out_f32) return false;
+    if (d->act != YH_ACT_LINEAR && d->act != YH_ACT_LEAKY && d->act != YH_ACT_MISH) return false;
+    if (d->cin_k != (d->dtype == YH_I8 ? 64 : 32) || (d->cout != 32 && d->cout != 64)) return false;
+    const int esz = d->dtype == YH_I8 ? 1 : 2;
+    if ((d->ldy * esz) % 16 || (reinterpret_cast<uintptr_t>(d->y) & 15u)) return false;                    // whole 16-byte units per row
+    if ((long)d->n * d->ho * d->wo >= (1L << 31)) return false;                                              // 32-bit pixel index
+    return (long)d->n * d->h * d->w_in * d->ldx * esz < (1L << 31);                                          // 32-bit tap offsets
+}
+static bool pick_stream3_tile(const yh_conv_desc* d) {
+    static const bool off = getenv("YH_NO_STREAM3") != nullptr;
+    return !off && stream3_supported(d) && (long)d->n * d->ho * d->wo >= 262144;
+}
+
 extern "C" int yh_conv2d_tile(const yh_conv_desc* d) {
     if (!d) return YH_EINVAL;
     if (d->tile != 0) return d->tile;
     if (pick_pointwise_tile(d)) return 71;
+    if (pick_stream3_tile(d)) return 72;
     if (pick_hpp_tile(d)) return 43;
     if (pick_halo_tile(d)) return 41;
     if (const int pp = pick_pp_tile(d)) return pp;
@@ -1099,6 +1117,10 @@ extern "C" int yh_conv2d_fwd(const yh_conv_desc* d, void* stream) {
         if (d->kh != 1 || d->kw != 1 || d->stride != 1 || d->pad != 0 || d->ups != 1 || d->res || d->stats_ws || d->cin != d->cin_k ||
             d->cout > 128 || d->dtype == YH_F32) return YH_EUNSUPPORTED;
         return launch_pointwise_tile(a, d->dtype, d->out_f32, s);
+    }
+    if (tile == 72) {
+        if (!stream3_supported(d)) return YH_EUNSUPPORTED;
+        return launch_stream3_tile(a, d->dtype, s);
     }
     if (d->dtype == YH_F16) {
         return d->out_f32 ? dispatch_tile<f16, float>(a, tile, s) : dispatch_tile<f16, f16>(a, tile, s);
