@@ -128,7 +128,9 @@ int yh_conv2d_fwd(const yh_conv_desc* d, void* stream);
 int yh_qconv_pack_weights(const float* q_weight, float w_scale, const int32_t* cin_map, int cout, int cin, int kh, int kw,
                           int cin_k, int m_pad, void* packed, void* stream);
 /* Tile configuration yh_conv2d_fwd will use for this descriptor (1 = 128x128, 2 = 64x256, 3 = 32x256,
- * 4 = 64x128, 5 = 128x64, channels x pixels): lets a profiler attribute time to kernel instantiations. */
+ * 4 = 64x128, 5 = 128x64, channels x pixels; 2x = the LDS-DMA ring forms of the same tiles, 41 / 43 = halo kernels
+ * for 3x3 stride 1, 6x = ping-pong forms, 71 / 72 = the streaming 1x1 / 3x3 kernels for few-channel layers on
+ * large grids; bench.py TILE_NAMES has the full list): lets a profiler attribute time to kernel instantiations. */
 int yh_conv2d_tile(const yh_conv_desc* d);
 
 /* First-layer convolution straight from the caller's NCHW fp32 image batch (cin <= 4): fuses the
