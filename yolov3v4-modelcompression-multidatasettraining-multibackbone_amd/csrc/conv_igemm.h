@@ -445,6 +445,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, AccT (&acc)[TM]
 int launch_k64_tile(const ConvArgs& a, int tile, int dtype, int out_f32, hipStream_t stream);
 int launch_pointwise_tile(const ConvArgs& a, int dtype, int out_f32, hipStream_t stream);   // conv_pointwise.hip, tile code 71
 int launch_stream3_tile(const ConvArgs& a, int dtype, hipStream_t stream);                    // conv_stream3.hip, tile code 72
+long stream3_stats_rows(long P, int cout);                                                       // its statistics rows: one per wave
 // conv_halo_pp.hip, tile code 43: 3x3 / s1 / p1, 128 channels x 512 virtual pixels; f16 and int8, output type = input type
 int launch_hpp_tile(const ConvArgs& a, int dtype, hipStream_t stream);
 bool hpp_geometry(int W, int cin_k, int bk, int* rows_hp, int* lb, int* hbufs, size_t* lds);

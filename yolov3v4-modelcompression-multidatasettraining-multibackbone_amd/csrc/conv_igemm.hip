@@ -993,10 +993,11 @@ static bool pick_pointwise_tile(const yh_conv_desc* d) {
 }
 
 // The streaming 3x3 kernel (conv_stream3.hip): one MFMA K step of input channels, at most 64 output channels, large grids; plain
-// dense fp16 / int8 store with or without residual (or fused quantised shortcut); no statistics, upsample or fp32 output.
+// dense fp16 / int8 store with or without residual (or fused quantised shortcut), or with BatchNorm statistics; no upsample / fp32 output.
 static bool stream3_supported(const yh_conv_desc* d) {
     if (d->dtype != YH_F16 && d->dtype != YH_I8) return false;
-    if (d->kh != 3 || d->kw != 3 || d->pad != 1 || (d->stride != 1 && d->stride != 2) || d->ups != 1 || d->stats_ws || d->out_f32) return false;
+    if (d->kh != 3 || d->kw != 3 || d->pad != 1 || (d->stride != 1 && d->stride != 2) || d->ups != 1 || d->out_f32) return false;
+    if (d->stats_ws && (d->dtype != YH_F16 || d->res)) return false;
     if (d->act != YH_ACT_LINEAR && d->act != YH_ACT_LEAKY && d->act != YH_ACT_MISH) return false;
     if (d->cin_k != (d->dtype == YH_I8 ? 64 : 32) || (d->cout != 32 && d->cout != 64)) return false;
     const int esz = d->dtype == YH_I8 ? 1 : 2;
@@ -1044,6 +1045,7 @@ extern "C" int64_t yh_conv2d_stats_rows(const yh_conv_desc* d) {
     yh_conv_desc q = *d;
     if (!q.stats_ws) q.stats_ws = reinterpret_cast<float*>(sizeof(float));
     const int tile = yh_conv2d_tile(&q);
+    if (tile == 72) return (int64_t)yh::stream3_stats_rows((long)d->n * d->ho * d->wo, d->cout);       // one row per wave of the launch
     if (tile == 43)   // halo ping-pong kernel: 512 VIRTUAL pixels (one shared pad row / column) per tile, one row per wave
         return (int64_t)(((long)d->n * (d->h + 1) * (d->w_in + 1) + 511) / 512) * 8;
     if (!tile_geometry(tile, &bn, &wn)) return 0;

@@ -12,8 +12,8 @@
 //     padding taps are zero fragments;
 //   * the epilogue is the ring kernels' arithmetic operation for operation (bias, activation, fp16 residual, int8 requantisation and
 //     fused quantised shortcut), so results are bit-identical to them; rows leave through a per-wave LDS tile as whole 16-byte units.
-// Exactly 32 or 64 output channels on 16-byte aligned rows; no BatchNorm statistics (the training forward keeps the ring kernel), no
-// upsample, no fp32 output.
+// Exactly 32 or 64 output channels on 16-byte aligned rows; BatchNorm statistics of the training forward as one partial row per wave
+// (fp16, no residual); no upsample, no fp32 output.
 #include "conv_igemm.h"
 
 namespace yh {
@@ -42,7 +42,7 @@ template <> __device__ __forceinline__ i32x4 s3_mfma<int8_t>(const u32x4& a, con
 // in-order vmcnt queue exactly only through straight-line code; with `if (more)` / `if (p < P)` around the loads it fell back to the
 // conservative count at every join and the last taps of a block waited for the NEXT block's prefetches (vmcnt(0) at tap 8: 0.50 ms
 // instead of the numbers in profiles/r03_stream3_ab.txt).
-template <typename T, int MT, int ACT, bool HAS_RES, int S3_WAVES, int OCC>
+template <typename T, int MT, int ACT, bool HAS_RES, bool STATS, int S3_WAVES, int OCC>
 __global__ __launch_bounds__(S3_WAVES * 64, OCC) void conv3x3_stream_kernel(const ConvArgs a, const long nblocks) {
     typedef T OutT;
     typedef typename S3Frag<T>::type frag_t;
@@ -116,6 +116,14 @@ __global__ __launch_bounds__(S3_WAVES * 64, OCC) void conv3x3_stream_kernel(cons
     // soon as a tap's MFMAs have consumed fr[t], the NEXT block's tap t is loaded into it - a whole block (72 MFMAs + epilogue) of
     // distance between a load and its use, with no second set of registers.  (One tap of prefetch measured 1.7 us PER TAP: every tap
     // paid a memory latency.)  The residual of a block is loaded at its start for the same reason.
+    // training forward: this wave's sums of y and y * y (as stored) per channel over every pixel it produces; one row per wave
+    float st1[MT][4], st2[MT][4];
+    if constexpr (STATS) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) st1[i][e] = st2[i][e] = 0.f;
+    }
     long blk = wave;
     Geo g = geometry(blk);
     frag_t fr[9][TN];
@@ -167,6 +175,15 @@ __global__ __launch_bounds__(S3_WAVES * 64, OCC) void conv3x3_stream_kernel(cons
                         v[e] = y;
                     }
                 }
+                if constexpr (STATS) {
+                    const bool counted = p0 + j * 16 + pc < a.P;      // the tail's repeated last pixel counts once
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float q = counted ? (float)(OutT)v[e] : 0.f;
+                        st1[i][e] += q;
+                        st2[i][e] = fmaf(q, q, st2[i][e]);
+                    }
+                }
                 store4<OutT>(reinterpret_cast<OutT*>(tile + pc * PITCH) + i * 16 + mq, v[0], v[1], v[2], v[3]);
             }
             // rows leave as whole 16-byte units: lane -> (pixel row, unit) of the wave's [16 pixels][MT * 16 channels] tile
@@ -181,24 +198,48 @@ __global__ __launch_bounds__(S3_WAVES * 64, OCC) void conv3x3_stream_kernel(cons
             __builtin_amdgcn_wave_barrier();
         }
     }
+    if constexpr (STATS) {      // every wave writes its row (zeros when it had no block): yh_bn_finalize sums all of them
+        float* const row = a.stats_part + wave * 2 * a.Cout;
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float t1 = row16_sum(st1[i][e]), t2 = row16_sum(st2[i][e]);
+                if (pc == 15) {
+                    row[i * 16 + mq + e] = t1;
+                    row[a.Cout + i * 16 + mq + e] = t2;
+                }
+            }
+    }
 }
 
+// workgroups / waves of a launch: also the number of statistics rows (one per wave)
+template <int WAVES> static long s3_grid(long P) {
+    const long nblocks = (P + 31) / 32;
+    const long grid = (nblocks + WAVES - 1) / WAVES;
+    return grid > 512 ? 512 : grid;                      // two workgroups per CU
+}
+long stream3_stats_rows(long P, int cout) { return cout == 64 ? s3_grid<4>(P) * 4 : s3_grid<6>(P) * 6; }
+
 template <typename T, int MT, int WAVES, int OCC> static int launch_s3_act(const ConvArgs& a, hipStream_t s) {
-    constexpr int TN = 2;
-    const long nblocks = (a.P + TN * 16 - 1) / (TN * 16);
-    long grid = (nblocks + WAVES - 1) / WAVES;
-    const long cap = 256L * 2;                           // two workgroups per CU
-    if (grid > cap) grid = cap;
+    const long nblocks = (a.P + 31) / 32;
+    const long grid = s3_grid<WAVES>(a.P);
     const size_t shmem = (size_t)MT * 9 * 64 * 16 + (size_t)WAVES * 16 * (MT * 16 * sizeof(T) + 16);
-    const bool res = a.res != nullptr;
+    const bool res = a.res != nullptr, stats = a.stats_part != nullptr;
+    if (stats && (res || sizeof(T) == 1)) return YH_EINVAL;
+#define YH_S3_GO(A, R, S) hipLaunchKernelGGL((conv3x3_stream_kernel<T, MT, A, R, S, WAVES, OCC>), dim3((unsigned)grid), dim3(WAVES * 64), shmem, s, a, nblocks)
     switch (a.act) {
-#define YH_S3(A)                                                                                                                    \
-    case A:                                                                                                                          \
-        if (res) hipLaunchKernelGGL((conv3x3_stream_kernel<T, MT, A, true, WAVES, OCC>), dim3((unsigned)grid), dim3(WAVES * 64), shmem, s, a, nblocks); \
-        else hipLaunchKernelGGL((conv3x3_stream_kernel<T, MT, A, false, WAVES, OCC>), dim3((unsigned)grid), dim3(WAVES * 64), shmem, s, a, nblocks);    \
+#define YH_S3(A)                                                         \
+    case A:                                                               \
+        if constexpr (sizeof(T) == 2) {                                   \
+            if (stats) { YH_S3_GO(A, false, true); break; }               \
+        }                                                                 \
+        if (res) YH_S3_GO(A, true, false);                                \
+        else YH_S3_GO(A, false, false);                                   \
         break
         YH_S3(YH_ACT_LINEAR); YH_S3(YH_ACT_LEAKY); YH_S3(YH_ACT_MISH);
 #undef YH_S3
+#undef YH_S3_GO
         default: return YH_EUNSUPPORTED;
     }
     return check_launch();
