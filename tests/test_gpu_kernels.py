@@ -391,6 +391,8 @@ QCONV_CASES = [
     (2, 45, 43, 32, 64, 3, 2, 1, 1, False, 72),       # stride 2
     (2, 33, 31, 64, 32, 3, 1, 5, 1, False, 72),       # cin 64 (a full step), 32 output channels, mish
     (2, 29, 30, 48, 64, 3, 1, 0, 1, False, 72),       # cin 48, linear
+    (2, 37, 41, 64, 128, 3, 1, 1, 1, False, 72),      # 128 output channels (8-wave workgroups): Darknet-53 conv7 / conv10
+    (2, 45, 43, 64, 128, 3, 2, 1, 1, False, 72),      # conv5: stride 2
 ]
 
 
@@ -417,14 +419,14 @@ def test_int8_conv_matches_emulation(libs, case):
     assert diff.max().item() <= 1.0 and (diff > 0).float().mean().item() <= 1e-4, (diff.max().item(), (diff > 0).float().mean().item())
 
 
-@pytest.mark.parametrize('tile,stride,cout', [(0, 1, 64), (24, 1, 64), (72, 1, 64), (72, 2, 64), (72, 1, 32)],
-                         ids=['auto', 'ring', 'stream3', 'stream3_s2', 'stream3_c32'])
+@pytest.mark.parametrize('tile,stride,cout', [(0, 1, 64), (24, 1, 64), (72, 1, 64), (72, 2, 64), (72, 1, 32), (72, 1, 128)],
+                         ids=['auto', 'ring', 'stream3', 'stream3_s2', 'stream3_c32', 'stream3_c128'])
 def test_int8_fused_shortcut_matches_emulation(libs, tile, stride, cout):
     """The quantised shortcut that follows a conv (COSPTQuantizedShortcut, quantized_ptq_cos.py:877-912) in the conv's epilogue: the
     same integers from every kernel that carries it (ring, streaming 3x3) and from the emulation."""
     lib, fake = libs
     g = torch.Generator().manual_seed(100 + tile + stride + cout)
-    N, H, W, cin, k = 3, 37, 41, 32, 3
+    N, H, W, cin, k = 3, 37, 41, (64 if cout == 128 else 32), 3
     w_scale, x_scale, out_scale = 2.0 ** -9, 2.0 ** -5, 2.0 ** -4
     qw = torch.randint(-127, 128, (cout, cin, k, k), generator=g).float() * (torch.rand(cout, cin, k, k, generator=g) < 0.5) * w_scale
     x = torch.randint(-128, 128, (N, H, W, cin), generator=g).to(torch.int8)

@@ -999,7 +999,8 @@ static bool stream3_supported(const yh_conv_desc* d) {
     if (d->kh != 3 || d->kw != 3 || d->pad != 1 || (d->stride != 1 && d->stride != 2) || d->ups != 1 || d->out_f32) return false;
     if (d->stats_ws && (d->dtype != YH_F16 || d->res)) return false;
     if (d->act != YH_ACT_LINEAR && d->act != YH_ACT_LEAKY && d->act != YH_ACT_MISH) return false;
-    if (d->cin_k != (d->dtype == YH_I8 ? 64 : 32) || (d->cout != 32 && d->cout != 64)) return false;
+    if (d->cin_k != (d->dtype == YH_I8 ? 64 : 32)) return false;
+    if (d->cout != 32 && d->cout != 64 && !(d->cout == 128 && d->dtype == YH_I8)) return false;
     const int esz = d->dtype == YH_I8 ? 1 : 2;
     if ((d->ldy * esz) % 16 || (reinterpret_cast<uintptr_t>(d->y) & 15u)) return false;                    // whole 16-byte units per row
     if ((long)d->n * d->ho * d->wo >= (1L << 31)) return false;                                              // 32-bit pixel index

@@ -217,9 +217,10 @@ __global__ __launch_bounds__(S3_WAVES * 64, OCC) void conv3x3_stream_kernel(cons
 template <int WAVES> static long s3_grid(long P) {
     const long nblocks = (P + 31) / 32;
     const long grid = (nblocks + WAVES - 1) / WAVES;
-    return grid > 512 ? 512 : grid;                      // two workgroups per CU
+    const long cap = WAVES == 8 ? 256 : 512;             // two workgroups per CU (one of eight waves for the 128-channel int8 form)
+    return grid > cap ? cap : grid;
 }
-long stream3_stats_rows(long P, int cout) { return cout == 64 ? s3_grid<4>(P) * 4 : s3_grid<6>(P) * 6; }
+long stream3_stats_rows(long P, int cout) { return cout == 64 ? s3_grid<4>(P) * 4 : s3_grid<6>(P) * 6; }     // fp16 forms only
 
 template <typename T, int MT, int WAVES, int OCC> static int launch_s3_act(const ConvArgs& a, hipStream_t s) {
     const long nblocks = (a.P + 31) / 32;
@@ -245,7 +246,7 @@ template <typename T, int MT, int WAVES, int OCC> static int launch_s3_act(const
     return check_launch();
 }
 
-// tile code 72 (conv_igemm.hip yh_conv2d_tile): Cout 32 or 64 exactly
+// tile code 72 (conv_igemm.hip yh_conv2d_tile): Cout 32 or 64 exactly; int8 also 128 (64 -> 128 at 304^2 / 152^2 is one K step there)
 int launch_stream3_tile(const ConvArgs& a, int dtype, hipStream_t s) {
     if (dtype == YH_F16) {
         if (a.Cout == 32) return launch_s3_act<f16, 2, 6, 3>(a, s);
@@ -253,6 +254,7 @@ int launch_stream3_tile(const ConvArgs& a, int dtype, hipStream_t s) {
     } else if (dtype == YH_I8) {
         if (a.Cout == 32) return launch_s3_act<int8_t, 2, 6, 3>(a, s);
         if (a.Cout == 64) return launch_s3_act<int8_t, 4, 4, 2>(a, s);
+        if (a.Cout == 128) return launch_s3_act<int8_t, 8, 8, 2>(a, s);     // 74 KB of weights: ONE 8-wave workgroup per CU
     }
     return YH_EUNSUPPORTED;
 }
