@@ -172,10 +172,13 @@ def test_letterbox_in_cv2_arithmetic_on_the_emulated_abi(fake, shape, size, auto
         got_bgr, _, _ = pp.letterbox_to_device(np.ascontiguousarray(img[:, :, ::-1]), size, 'cpu', auto=auto, maxabsscaler=maxabs,
                                                swap_rb=True, arith='cv2')
         assert torch.equal(got_bgr, want)
-    # and the two arithmetics do differ (the switch is not a no-op), but only by resampling-filter noise
-    if host.shape[:2] != shape[:2] or True:
-        pil, _, _ = pp.letterbox_to_device(img, size, 'cpu', auto=auto, maxabsscaler=maxabs, arith='pillow')
-        assert pil.shape == got.shape
+    # the Pillow arithmetic of the same frame: same geometry; where a resize happens the pixels differ (the switch is not a no-op),
+    # but only by resampling-filter noise - random frames are the worst case, a few dozen levels at most
+    pil, _, _ = pp.letterbox_to_device(img, size, 'cpu', auto=auto, maxabsscaler=maxabs, arith='pillow')
+    assert pil.shape == got.shape
+    if host.shape[:2] != shape[:2] and max(shape[:2]) != size:
+        d = (pil - got).abs() * (128.0 if maxabs else 256.0)
+        assert 0 < d.max().item() < 160 and d.mean().item() < 12
 
 
 def test_arith_switches_fail_loudly(dataset_dir, monkeypatch):

@@ -77,6 +77,13 @@ def test_train_test_detect_round_trip(dataset_dir, tiny_cfg, tmp_path, monkeypat
                                                '--names', str(dataset_dir / 'synth.names'), '--save-txt'])
     res = detect_mod.detect(dopt)
     assert len(res) == 12 and len(os.listdir('out')) >= 12
+    # OpenCV's arithmetic exists in the device kernels only: asked for on a CPU run it raises instead of quietly using Pillow
+    dopt.image_arith = 'cv2'
+    with pytest.raises(NotImplementedError):
+        detect_mod.detect(dopt)
+    opt.image_arith, opt.epochs = 'cv2', 1
+    with pytest.raises(NotImplementedError):
+        train_mod.train(opt, train_mod.hyp)
 
 
 def test_terminaltables_shim_and_star_imports():

@@ -43,6 +43,9 @@ def detect(opt, save_img=True):
     model.hip_return_raw = False      # only model(img)[0] is read below (reference detect.py:104): no copies of the raw head maps
 
     device_letterbox = device.type == 'cuda' and not getattr(opt, 'host_letterbox', False)
+    if getattr(opt, 'image_arith', None) == 'cv2' and not device_letterbox:
+        raise NotImplementedError("--image-arith cv2 (OpenCV's arithmetic) exists in the device letterbox only: it needs a GPU and no "
+                                  "--host-letterbox; the host loader resizes with Pillow")
     dataset = LoadImages(source, img_size=imgsz, is_gray_scale=opt.gray_scale, rect=opt.rect, host_letterbox=not device_letterbox)
     names = load_classes(opt.names) if opt.names and os.path.isfile(opt.names) else [str(i) for i in range(1000)]
     rng = random.Random(0)
