@@ -1,0 +1,34 @@
+#!/bin/bash
+# Evidence run on a GPU box (what produced profiles/r03_*): full GPU test tier, smoke, the default bench line, rocprofv3 stats of the same
+# command, HBM traffic (FETCH_SIZE / WRITE_SIZE, one counter per pass) and SQ / TCC counters of the training step, per-layer tables.
+# Usage:  gpurun --timeout 2400 -- bash yolov3v4-modelcompression-multidatasettraining-multibackbone_amd/tools/evidence_run.sh TAG
+# Everything lands under gpurun_out/TAG_*; copy what is to be kept into profiles/.
+R="$GRAFT_REPO_ROOT"; cd "$R" || exit 1
+PKG=$R/yolov3v4-modelcompression-multidatasettraining-multibackbone_amd
+T=$PKG/tools
+TAG=${1:-evidence}
+mkdir -p gpurun_out
+export TMPDIR=/tmp
+( timeout 1500 python -m pytest tests -m gpu -q -s 2>&1 | grep -v "^Model Summary\|amdgpu.ids" | grep "passed\|failed\|FAILED\|Error\|int8 vs\|raw heads\|mAP\|608 b64\|drift\|pruned mobilenet\|calibration on" | tail -70 ) > gpurun_out/${TAG}_tests.log 2>&1
+( timeout 200 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | grep -v "^Model Summary\|amdgpu.ids" | tail -4 ) > gpurun_out/${TAG}_smoke.log 2>&1
+( timeout 900 python bench.py 2>&1 | tail -1 ) > gpurun_out/${TAG}_bench_default.json 2>&1
+cd /tmp
+timeout 500 rocprofv3 --kernel-trace --stats -d /tmp/prof_default -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $R/gpurun_out/${TAG}_bench_prof.log 2>&1
+for c in FETCH_SIZE WRITE_SIZE; do
+  timeout 300 rocprofv3 --kernel-trace --pmc $c -d /tmp/prof_train_$c -- python $R/bench.py --mode train --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+  timeout 300 rocprofv3 --kernel-trace --pmc $c -d /tmp/prof_det_$c -- python $R/bench.py --mode detect --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+  timeout 300 rocprofv3 --kernel-trace --pmc $c -d /tmp/prof_i8_$c -- python $R/bench.py --mode detect --precision int8 --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+done
+timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE -d /tmp/pmc_sq -- python $R/bench.py --mode train --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+timeout 300 rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum -d /tmp/pmc_tcc -- python $R/bench.py --mode train --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+cd $R
+python $T/rocprof_summary.py stats $(find /tmp/prof_default -name "*.db" | head -1) > gpurun_out/${TAG}_rocprof_stats.txt 2>&1
+python $T/rocprof_summary.py traffic gpurun_out/${TAG}_traffic_train.json $(find /tmp/prof_train_FETCH_SIZE /tmp/prof_train_WRITE_SIZE -name "*.db") > gpurun_out/${TAG}_traffic.log 2>&1
+python $T/rocprof_summary.py traffic gpurun_out/${TAG}_traffic_detect.json $(find /tmp/prof_det_FETCH_SIZE /tmp/prof_det_WRITE_SIZE -name "*.db") >> gpurun_out/${TAG}_traffic.log 2>&1
+python $T/rocprof_summary.py traffic gpurun_out/${TAG}_traffic_int8.json $(find /tmp/prof_i8_FETCH_SIZE /tmp/prof_i8_WRITE_SIZE -name "*.db") >> gpurun_out/${TAG}_traffic.log 2>&1
+python $T/rocprof_summary.py pmc $(find /tmp/pmc_sq /tmp/pmc_tcc -name "*.db") > gpurun_out/${TAG}_pmc_train.txt 2>&1
+timeout 300 python $T/profile_train.py --batch 64 --size 608 > gpurun_out/${TAG}_train_layers.txt 2>&1
+timeout 300 python $T/profile_layers.py --batch 64 --size 608 > gpurun_out/${TAG}_layers_fp16.txt 2>&1
+timeout 300 python $T/profile_layers.py --batch 64 --size 608 --precision int8 > gpurun_out/${TAG}_layers_int8.txt 2>&1
+timeout 600 python $T/pruned_finetune.py --bench > gpurun_out/${TAG}_pruned.txt 2>&1
+tail -12 gpurun_out/${TAG}_tests.log; cat gpurun_out/${TAG}_smoke.log; cut -c1-300 gpurun_out/${TAG}_bench_default.json; head -14 gpurun_out/${TAG}_rocprof_stats.txt; cat gpurun_out/${TAG}_traffic.log; tail -5 gpurun_out/${TAG}_pruned.txt
