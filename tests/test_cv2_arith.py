@@ -70,6 +70,25 @@ def test_area_resize_is_a_weighted_mean():
     assert np.array_equal(cv.resize_area(big, (12, 10)), _img((10, 12, 3), 2))
 
 
+def test_area_fast_and_table_forms_agree_on_integer_factors():
+    """resize() sends integer decimation factors to resizeAreaFast_ (integer cell sums) and everything else to the float-table form; on
+    an integer factor the table form computes the same means, so the two restatements must agree - exactly for 3x3 and 4x4 cells, within
+    one level for 2x2 ((s + 2) >> 2 rounds halves up, the float form rounds them to even)."""
+    img = _img((96, 120, 3), 3)
+    for (w, h), tol in [((60, 48), 1), ((40, 32), 0), ((30, 24), 0)]:
+        fast = cv.resize_area(img, (w, h))
+        xt, yt = cv._area_tab(120, w, 120 / w), cv._area_tab(96, h, 96 / h)
+        S = img.astype(np.float32)
+        rows = np.zeros((96, w, 3), np.float32)
+        for dx, sx, alpha in xt:
+            rows[:, dx] = rows[:, dx] + S[:, sx] * alpha
+        table = np.zeros((h, w, 3), np.float32)
+        for dy, sy, beta in yt:
+            table[dy] = table[dy] + beta * rows[sy]
+        d = np.abs(fast.astype(int) - np.clip(np.rint(table), 0, 255).astype(int))
+        assert d.max() <= tol, ((w, h), int(d.max()))
+
+
 def test_warp_affine_properties():
     img = _img((60, 80, 3), 3)
     eye = np.array([[1, 0, 0], [0, 1, 0]], float)
