@@ -63,3 +63,35 @@ def test_hip_nms_class_filter_and_idempotence():
     # kept boxes of one class do not overlap above the threshold (property of greedy NMS before merging)
     raw = non_max_suppression(pred.cuda(), 0.3, 0.6, multi_label=False)[0]
     assert raw is not None and torch.all(raw[:-1, 4] >= raw[1:, 4]), 'output must be in descending score order'
+
+
+def test_hip_nms_bound_forgets_outliers_and_respects_the_mask_budget(monkeypatch):
+    """the candidate bound used to be a grow-only power of two per input shape, so one dense batch pinned a
+    quadratic IoU mask for the rest of the process.  Now: (a) the bound follows the candidate density of the last few calls,
+    (b) a guessed bound whose mask exceeds the budget takes the count-first path - and every path returns the same boxes."""
+    from engine import nms as hnms
+    from utils.utils import non_max_suppression
+    monkeypatch.setattr(hnms, '_density', {})
+    dense = synth.nms_candidates(2, 4000, 20, 61, n_clusters=40, hot=0.9).cuda()
+    sparse = synth.nms_candidates(2, 4000, 20, 62, n_clusters=10, hot=0.02).cuda()
+    want_dense = oracle.non_max_suppression(dense.cpu().numpy(), 0.05, 0.6, multi_label=True)
+    want_sparse = oracle.non_max_suppression(sparse.cpu().numpy(), 0.3, 0.6, multi_label=False)
+    got = non_max_suppression(dense, 0.05, 0.6, multi_label=True)          # first call: overflow of the 256 default, repeated exactly
+    for i in range(2):
+        _compare(got[i], want_dense[i], 'dense img %d' % i)
+    d0 = max(hnms._density[1])
+    assert d0 > 0.5                                                           # thousands of candidates per image
+    for _ in range(hnms._HINT_WINDOW):                                        # sparse single-label calls never see the dense hint
+        got = non_max_suppression(sparse, 0.3, 0.6, multi_label=False)
+    for i in range(2):
+        _compare(got[i], want_sparse[i], 'sparse img %d' % i)
+    assert max(hnms._density[0]) < 0.1 and max(hnms._density[1]) == d0       # keyed by label mode
+    for _ in range(hnms._HINT_WINDOW):                                        # multi-label at a high threshold: the outlier ages out
+        non_max_suppression(sparse, 0.6, 0.6, multi_label=True)
+    assert max(hnms._density[1]) < d0
+    # budget path: a hint this dense with a tiny budget must count first and still agree
+    monkeypatch.setattr(hnms, '_MASK_BUDGET', 1 << 16)
+    hnms._density[1].append(d0)
+    got = non_max_suppression(dense, 0.05, 0.6, multi_label=True)
+    for i in range(2):
+        _compare(got[i], want_dense[i], 'budget path img %d' % i)

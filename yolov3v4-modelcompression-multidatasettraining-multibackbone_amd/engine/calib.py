@@ -5,7 +5,8 @@ on a GPU.  Three services, all on libyolo_hip.so (a missing library raises - the
                   (reference quantized_ptq_cos.py:64-93, :838-912, :1153-1197) - `yh_ptq_cos_search`;
 * ``absmax``      the range the quantised concat tracks (:1403-1449) - `yh_absmax`;
 * ``conv2d``      the float-stream / fake-quantised-stream convolutions of calibration mode (:230-275, :288-296) through
-                  `yh_conv2d_fwd` in fp32 (exact-product `v_mfma_f32_16x16x4_f32`, fp32 accumulation), NCHW in, NCHW view out.
+                  `yh_conv2d_fwd` in fp32 (exact-product `v_mfma_f32_16x16x4_f32`, fp32 accumulation), NCHW in, NCHW view out;
+                  depthwise blocks (groups == channels, the Mobilenet / GhostNet cfgs) through `yh_dwconv2d_fwd` in fp32.
 
 The decision (an index) is read back by the caller: the modules keep their vote histograms as Python lists, exactly like the
 reference, so one 4-byte device-to-host read per search is part of the contract.
@@ -71,9 +72,11 @@ def conv2d(x, w, b, stride, padding, dilation=(1, 1), groups=1):
     s, p, d = (v if isinstance(v, int) else v[0] for v in (stride, padding, dilation))
     sq = all(isinstance(v, int) or v[0] == v[-1] for v in (stride, padding, dilation))
     cout, cin, kh, kw = w.shape
+    if groups != 1 and groups == x.shape[1] == cout and cin == 1 and d == 1 and sq and kh == kw:
+        return _dwconv2d(x, w, b, s, p)      # the Mobilenet / GhostNet depthwise blocks (reference models.py:115-160 builds them with this class)
     if groups != 1 or d != 1 or not sq or kh != kw:
-        raise NotImplementedError('device calibration lowers dense square convolutions only (groups=%d, dilation=%s, kernel %dx%d): '
-                                  'calibrate this graph on the CPU' % (groups, dilation, kh, kw))
+        raise NotImplementedError('device calibration lowers dense square and depthwise convolutions only (groups=%d, dilation=%s, '
+                                  'kernel %dx%d): calibrate this graph on the CPU' % (groups, dilation, kh, kw))
     lib = _lib()
     F32 = hiplib.YH_F32
     x = x.detach().float().contiguous()
@@ -101,3 +104,31 @@ def conv2d(x, w, b, stride, padding, dilation=(1, 1), groups=1):
                                ups=1, out_f32=1, dtype=F32, tile=0)
         hiplib.check(lib.yh_conv2d_fwd(C.byref(desc), S), 'calibration conv')
     return y[..., :cout].permute(0, 3, 1, 2)
+
+
+def _dwconv2d(x, w, b, s, p):
+    """Depthwise (groups == channels) fp32 convolution of calibration mode on ``yh_dwconv2d_fwd`` (csrc/depthwise.hip): NCHW in,
+    NCHW view of the NHWC result out, like ``conv2d``."""
+    lib = _lib()
+    F32 = hiplib.YH_F32
+    x = x.detach().float().contiguous()
+    w = w.detach().float().contiguous()
+    n, c, h, wi = x.shape
+    k = w.shape[2]
+    ho, wo = (h + 2 * p - k) // s + 1, (wi + 2 * p - k) // s + 1
+    c_p = _round_up(c, 8)          # yh_dw_pack_weights packs 8-channel groups
+    dev = x.device
+    with hiplib.on_device(x):
+        S = hiplib.stream_ptr()
+        xh = torch.empty((n, h, wi, c_p), dtype=torch.float32, device=dev)
+        hiplib.check(lib.yh_nchw_to_nhwc(hiplib.ptr(x), hiplib.ptr(xh), n, c, h, wi, c_p, c_p, F32, S), 'nchw_to_nhwc')
+        packed = torch.empty(k * k * c_p, dtype=torch.float32, device=dev)
+        bias = torch.empty(c_p, dtype=torch.float32, device=dev)
+        cb = torch.zeros(c, dtype=torch.float32, device=dev) if b is None else b.detach().float().contiguous()
+        hiplib.check(lib.yh_dw_pack_weights(F32, hiplib.ptr(w), hiplib.ptr(cb), None, None, None, None, 0.0, None, c, k, c_p,
+                                            hiplib.ptr(packed), hiplib.ptr(bias), S), 'dw pack')
+        y = torch.empty((n, ho, wo, c_p), dtype=torch.float32, device=dev)
+        desc = hiplib.DwDesc(x=hiplib.ptr(xh), w=hiplib.ptr(packed), bias=hiplib.ptr(bias), y=hiplib.ptr(y), n=n, h=h, w_in=wi, c=c_p, ho=ho,
+                             wo=wo, k=k, stride=s, pad=p, ldx=c_p, ldy=c_p, act=0, slope=0.0, dtype=F32)
+        hiplib.check(lib.yh_dwconv2d_fwd(C.byref(desc), S), 'calibration depthwise conv')
+    return y[..., :c].permute(0, 3, 1, 2)

@@ -1,18 +1,27 @@
 """Batched NMS on the HIP kernels of ``csrc/nms.hip`` (reference: utils/utils.py:782-860).
 
 The reference's contract is a Python list of variable-length tensors, so ONE device-to-host read is inherent (how many boxes
-survived per image).  The candidate buffers are therefore sized by an upper bound (a power of two that only grows, remembered per
-input shape) instead of by a first read-back of the exact counts; every kernel takes the per-image counts from device memory.
-The single read returns candidate counts and survivor counts together; only when an image had more candidates than the bound
-the pass is repeated with an exact bound (a second read, first call on a new workload at most).
+survived per image).  The candidate buffers are therefore sized by an upper bound instead of by a first read-back of the exact
+counts; every kernel takes the per-image counts from device memory.  The single read returns candidate counts and survivor
+counts together; only when an image had more candidates than the bound the pass is repeated with an exact bound (a second read).
+
+The bound is a power of two with 2x head-room over the candidate DENSITY (candidates per prediction row) of the last few calls:
+keyed on the label mode only, so the rectangular shapes of an evaluation run share it, and windowed, so one outlier batch (or
+a test.py call at conf 0.001 before a detect.py call at conf 0.3) stops costing memory after ``_HINT_WINDOW`` calls.  The IoU
+bit mask is quadratic in the bound (n * cap * cap / 8 bytes); above ``_MASK_BUDGET`` the bound is not trusted and the call takes
+the exact path: a count-only pass, one extra read, buffers sized by the true maximum.
 """
+import collections
+
 import torch
 
 from . import hiplib
 
 MERGE_LO, MERGE_HI = 1, 3000  # merge-NMS applies for 1 < n < 3000 (utils.py:845)
 _CAP_MIN = 256
-_cap_hint = {}                # (n, rows, multi_label) -> candidate bound that sufficed so far
+_HINT_WINDOW = 8              # calls a density observation is remembered for
+_MASK_BUDGET = 256 << 20      # bytes of IoU bit mask a *guessed* bound may cost; above it the counts are read first
+_density = {}                 # multi_label -> deque of the last candidate densities (max candidates of an image / rows)
 
 
 def non_max_suppression(prediction, conf_thres=0.1, iou_thres=0.6, multi_label=True, classes=None, agnostic=False):
@@ -44,9 +53,16 @@ def _non_max_suppression(prediction, conf_thres, iou_thres, multi_label, classes
         cmask[torch.as_tensor(list(classes), dtype=torch.long, device=dev)] = 1
     ml = 1 if (multi_label and nc > 1) else 0
     most = rows * (nc if ml else 1)           # no image can emit more candidates than this
-    hint_key = (n, rows, ml)
-    cap = min(_cap_hint.get(hint_key, _CAP_MIN), _pow2_at_least(most))
+    seen = _density.get(ml)
+    guess = _CAP_MIN if not seen else _pow2_at_least(int(2 * max(seen) * rows) + 1)
+    cap = min(guess, _pow2_at_least(most))
     ag = 1 if agnostic else 0
+    exact = False
+    if n * cap * ((cap + 63) // 64) * 8 > _MASK_BUDGET:
+        # a guessed bound this large is not worth its mask: count first (one extra 4n-byte read), then size exactly
+        count = torch.zeros(n, dtype=torch.int32, device=dev)
+        hiplib.check(lib.yh_nms_candidates(P(pred), n, rows, nc, conf_thres, ml, P(cmask), None, P(count), 0, S), 'nms count')
+        cap, exact = _pow2_at_least(max(int(count.max()), 1)), True
     while True:
         words = (cap + 63) // 64
         counts = torch.zeros((2, n), dtype=torch.int32, device=dev)     # row 0: candidates per image, row 1: survivors
@@ -66,11 +82,9 @@ def _non_max_suppression(prediction, conf_thres, iou_thres, multi_label, classes
         mmax = int(host[0].max())
         if mmax <= cap:
             break
+        assert not exact, 'candidate count changed between the count pass and the emit pass'
         cap = _pow2_at_least(mmax)             # an image overflowed the bound: repeat with one that holds every candidate
-    if 2 * mmax > cap:                         # head-room for the next call on this workload
-        _cap_hint[hint_key] = max(_cap_hint.get(hint_key, _CAP_MIN), _pow2_at_least(2 * mmax))
-    else:
-        _cap_hint.setdefault(hint_key, cap)
+    _density.setdefault(ml, collections.deque(maxlen=_HINT_WINDOW)).append(mmax / float(rows))
     out = [None] * n
     for i in range(n):
         k = int(host[1, i])

@@ -25,6 +25,8 @@ image 1 becomes the float stream, batch size 1 raises) — and data-movement mod
 import math
 
 import numpy as np
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -68,8 +70,13 @@ def _search(t, first_step, n, bits):
     """Cosine vote over the candidates float_range = 2^(first_step + j), j < n (scale = float_range / 2^(bits-1)).
 
     Host tensors: the reference's loop (:64-93) - fake-quantise, cosine, keep the first maximum.  Device tensors: the same search
-    as ONE kernel pass over the tensor (engine/calib.py -> csrc/calib.hip); returns (best j, [cos_j])."""
-    if _on_device(t):
+    as ONE kernel pass over the tensor (engine/calib.py -> csrc/calib.hip); returns (best j, [cos_j]).
+
+    Known divergence: the kernel accumulates <t,q>, <q,q>, <t,t> in double, the loop below in fp32 through
+    ``torch.cosine_similarity`` - two candidates whose cosines agree to ~1e-7 can come out in the other order (2 of 41 decisions
+    on yolov3-tiny, 6 of 244 on yolov3-mobilenet).  ``YOLO_PTQ_HOST_SEARCH=1`` runs the reference's loop on device tensors too
+    (fp32 torch reductions on the GPU), for runs that must reproduce a host-calibrated state."""
+    if _on_device(t) and os.environ.get('YOLO_PTQ_HOST_SEARCH', '0') != '1':
         from engine import calib
         return calib.cos_search(t, 2.0 ** first_step / float(1 << (bits - 1)), n, bits)
     best, best_j, cos = -1, 0, []
