@@ -193,10 +193,12 @@ def roofline_leg(model, x, steps, precision):
             name = 'conv_igemm_%s_%s' % (precision, tile_name(conv_tile(lib, desc)))
         else:
             name = ''.join(c for c in what if not c.isdigit())
-        g = groups.setdefault(name, dict(ms=0.0, flops=0.0, launches=0))
+        g = groups.setdefault(name, dict(ms=0.0, flops=0.0, launches=0, bytes=[]))
         g['ms'] += ms
         g['flops'] += flops.get(idx, 0.0)
         g['launches'] += 1
+        if isinstance(desc, hiplib.ConvDesc):
+            g['bytes'].append(op_bytes('conv', desc, 1 if precision == 'int8' else (2 if precision == 'fp16' else 4)))
     dom_name = max((n for n in groups if n.startswith('conv_igemm')), key=lambda n: groups[n]['ms'])
     dom = groups[dom_name]
     achieved = dom['flops'] / (dom['ms'] * 1e-3) / 1e12
@@ -205,29 +207,18 @@ def roofline_leg(model, x, steps, precision):
                          tflops=round(g['flops'] / (g['ms'] * 1e-3) / 1e12, 1) if g['flops'] else None)
                  for n, g in sorted(groups.items(), key=lambda kv: -kv[1]['ms'])}
     return dict(bound='mfma', kernel=dom_name, achieved=round(achieved, 2), peak=peak, unit='TFLOP/s',
-                frac=round(achieved / peak, 4), traffic=hbm_traffic(dom_name, x.shape[0]), launches_per_step=dom['launches'],
+                frac=round(achieved / peak, 4), traffic=hbm_traffic(dom_name, x.shape[0], dom['bytes']), launches_per_step=dom['launches'],
                 avg_launch_ms=round(dom['ms'] / dom['launches'], 5),
                 gflop_per_launch=round(dom['flops'] / dom['launches'] / 1e9, 3),
                 gpu_ms_per_step_all_kernels=round(sum(g['ms'] for g in groups.values()), 4),
                 instrumented_ms_per_step=round(wall * 1e3, 4), kernels=breakdown)
 
 
-def hbm_traffic(kernel, batch):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes, or None.
-
-    PMC counters cannot be read from inside this process; they are collected with separate
-    `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of this same command and reduced by
-    tools/rocprof_summary.py traffic (gfx950 correction: read side doubled) into profiles/hbm_traffic.json."""
-    path = os.path.join(REPO, 'profiles', 'hbm_traffic.json')
-    try:
-        table = json.load(open(path))
-    except Exception:
-        return None
+def hbm_traffic(kernel, batch, alg_bytes=None):
+    """HBM bytes per launch of the dominant detect kernel from the committed rocprofv3 PMC passes (see traffic_of), or None."""
     key = rocprof_kernel_name(kernel)
     section = 'batch%d%s' % (batch, '_int8' if '_int8_' in kernel else '')
-    ent = table.get(section, {}).get(key) if key else None
-    return None if ent is None else {'hbm_bytes_per_launch': ent['hbm_bytes_per_dispatch'], 'kernel': key,
-                                     'source': 'profiles/hbm_traffic.json[%s]' % section}
+    return traffic_of(key, section, alg_bytes) if key else None
 
 
 def rocprof_kernel_name(kernel):
@@ -375,13 +366,58 @@ def train_main(args, device, dist, world, rank, local_rank):
     return out
 
 
+WGRAD_KERNELS = {90: 'conv_wgrad_halo', 22: 'conv_wgrad_dma<2,2>', 42: 'conv_wgrad_dma<4,2>', 44: 'conv_wgrad_dma<4,4>',
+                 82: 'conv_wgrad_dma<8,2>', 84: 'conv_wgrad_dma<8,4>', 1: 'conv_wgrad'}   # yh_conv2d_wgrad_kernel codes
+
+
+def op_bytes(role, desc, esz):
+    """Algorithmic HBM bytes of one conv-type launch: every operand once (activations in, residual, out, weights / fp32 dW)."""
+    if role == 'wgrad':
+        return (float(desc.n) * desc.h * desc.w_in * desc.cin + float(desc.n) * desc.ho * desc.wo * desc.cout) * esz \
+            + 4.0 * desc.cout * (desc.cin_w or desc.cin) * desc.kh * desc.kw
+    out_px = float(desc.n) * desc.ho * desc.wo * (4 if desc.ups == 2 else 1)
+    out_c = desc.cout // 4 if desc.ups == 4 else desc.cout
+    if desc.ups == 4:
+        out_px *= 4
+    b = float(desc.n) * desc.h * desc.w_in * desc.cin * esz + out_px * out_c * (4 if desc.out_f32 else esz)
+    if desc.res:
+        b += out_px * out_c * esz
+    return b + float(desc.cout) * desc.cin * desc.kh * desc.kw * esz
+
+
+def traffic_of(kernel, section, launches_alg_bytes=None):
+    """HBM counters of one kernel instantiation from the committed rocprofv3 PMC passes (profiles/hbm_traffic.json, written by
+    tools/rocprof_summary.py traffic from separate --pmc FETCH_SIZE / WRITE_SIZE runs of this command), with the algorithmic
+    bytes of the same launches next to it.  WRITE_SIZE is exact on this part (calibrated, profiles/r04_traffic_calibration.txt);
+    FETCH_SIZE counts a 128-byte request as 64 bytes and a 64-byte request as 64, so the truth lies between `fetch_raw` and
+    2 x `fetch_raw`: `hbm_bytes_per_launch` uses the guide's doubling (an upper bound for kernels that fetch 64-byte row pieces)."""
+    try:
+        table = json.load(open(os.path.join(REPO, 'profiles', 'hbm_traffic.json')))
+    except Exception:
+        return None
+    ent = table.get(section, {}).get(kernel) if kernel else None
+    if ent is None:
+        return None
+    out = {'kernel': kernel, 'hbm_bytes_per_launch': ent['hbm_bytes_per_dispatch'], 'write_bytes': int(ent['write_kib'] * 1024),
+           'fetch_bytes_raw': int(ent['fetch_kib_raw'] * 1024), 'launches_profiled': ent.get('dispatches'),
+           'source': 'profiles/hbm_traffic.json[%s]' % section}
+    if launches_alg_bytes:
+        alg = sum(launches_alg_bytes) / len(launches_alg_bytes)
+        out['algorithmic_bytes_per_launch'] = int(alg)
+        out['ratio_to_algorithmic'] = [round((out['write_bytes'] + out['fetch_bytes_raw']) / alg, 2), round(out['hbm_bytes_per_launch'] / alg, 2)]
+    return out
+
+
 def train_roofline(eng, x, precision):
-    """Per-op HIP-event timing of one forward + backward plan replay; the dominant kernel class by time."""
+    """Per-op HIP-event timing of one forward + backward plan replay.  Kernels are grouped by INSTANTIATION (`by_kernel`) and by
+    class (all weight-gradient kernels form one class; every implicit-GEMM tile is its own); `roofline` is quoted on the class
+    that takes the most time, names the instantiation that dominates inside it and attaches THAT kernel's counters."""
     import ctypes as C
     lib, plan = eng.lib, eng._current
     heads = eng.forward(x)
     torch.cuda.synchronize()
     from engine import hiplib
+    esz = 2 if precision == 'fp16' else 4
     groups, roles = {}, {}
     for key, log in (('fwd', plan['fwd_ops']), ('bwd', plan['bwd_ops'])):
         handle = plan[key]
@@ -400,35 +436,57 @@ def train_roofline(eng, x, precision):
             # group by KERNEL instantiation: the forward convs and the data gradients share the implicit-GEMM kernels
             if isinstance(desc, hiplib.ConvDesc):
                 name = 'conv_igemm_%s_%s' % (precision, tile_name(conv_tile(lib, desc)))
+                cls = name
             elif role == 'wgrad':
-                name = 'conv_wgrad_dma' if precision == 'fp16' else 'conv_wgrad'
+                code = int(lib.yh_conv2d_wgrad_kernel(C.byref(desc)))
+                name, cls = WGRAD_KERNELS.get(code, 'conv_wgrad_%d' % code), 'conv_wgrad'
             else:
-                name = role
-            grp = groups.setdefault(name, dict(ms=0.0, flops=0.0, n=0))
+                name = cls = role
+            grp = groups.setdefault(name, dict(ms=0.0, flops=0.0, n=0, cls=cls, bytes=[]))
             grp['ms'] += ms
             grp['n'] += 1
             if role in ('conv', 'dgrad', 'wgrad'):
                 grp['flops'] += 2.0 * desc.n * desc.ho * desc.wo * desc.cout * desc.cin * desc.kh * desc.kw
+                grp['bytes'].append(op_bytes(role, desc, esz))
             roles.setdefault(role, [0.0])[0] += ms
     total = sum(g['ms'] for g in groups.values())
-    table = {k: dict(ms=round(g['ms'], 3), n=g['n'], tflops=round(g['flops'] / g['ms'] / 1e9, 1) if g['ms'] > 0 else 0)
-             for k, g in sorted(groups.items(), key=lambda kv: -kv[1]['ms'])}
-    top = max((k for k in groups if groups[k]['flops'] > 0), key=lambda k: groups[k]['ms'])
-    ach = groups[top]['flops'] / groups[top]['ms'] / 1e9
+    section = 'train_batch%d' % x.shape[0]
+
+    def rocprof_name(k):
+        return k if k.startswith('conv_wgrad') else rocprof_kernel_name(k)
+
+    table = {}
+    for k, g in sorted(groups.items(), key=lambda kv: -kv[1]['ms']):
+        table[k] = dict(ms=round(g['ms'], 3), n=g['n'], tflops=round(g['flops'] / g['ms'] / 1e9, 1) if g['ms'] > 0 else 0)
+        if g['bytes']:
+            table[k]['algorithmic_mb_per_launch'] = round(sum(g['bytes']) / len(g['bytes']) / 1e6, 1)
+            table[k]['algorithmic_tb_s'] = round(sum(g['bytes']) / g['ms'] / 1e9, 2)
+    classes = {}
+    for k, g in groups.items():
+        c = classes.setdefault(g['cls'], dict(ms=0.0, flops=0.0, n=0, members=[]))
+        c['ms'] += g['ms']
+        c['flops'] += g['flops']
+        c['n'] += g['n']
+        c['members'].append(k)
+    top = max((c for c in classes if classes[c]['flops'] > 0), key=lambda c: classes[c]['ms'])
+    cg = classes[top]
+    dom = max(cg['members'], key=lambda k: groups[k]['ms'])          # the instantiation that dominates the class by time
+    ach = cg['flops'] / cg['ms'] / 1e9
     peak = PEAK_TFLOPS[precision]
-    traffic = None
-    try:   # HBM bytes per launch from the committed rocprofv3 FETCH_SIZE / WRITE_SIZE passes of this command
-        hbm = json.load(open(os.path.join(REPO, 'profiles', 'hbm_traffic.json'))).get('train_batch%d' % x.shape[0], {})
-        keys = ['conv_wgrad_dma<8,2>', 'conv_wgrad_halo', 'conv_wgrad_dma<4,2>', 'void yh::conv_wgrad_dma_kernel<8, 2>'] \
-            if top == 'conv_wgrad_dma' else [rocprof_kernel_name(top)]
-        key = next((k for k in keys if k in hbm), None)
-        if key is not None and precision == 'fp16':
-            traffic = {'hbm_bytes_per_launch': hbm[key]['hbm_bytes_per_dispatch'], 'kernel': key, 'source': 'profiles/hbm_traffic.json'}
-    except Exception:
-        traffic = None
-    return {'bound': 'mfma', 'kernel': top, 'achieved': round(ach, 1), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(ach / peak, 4),
-            'traffic': traffic, 'launches_per_step': groups[top]['n'], 'avg_launch_ms': round(groups[top]['ms'] / groups[top]['n'], 5),
-            'gflop_per_launch': round(groups[top]['flops'] / groups[top]['n'] / 1e9, 3), 'gpu_ms_per_step': round(total, 3),
+    dg = groups[dom]
+    traffic = traffic_of(rocprof_name(dom), section, dg['bytes']) if precision == 'fp16' else None
+    if traffic is not None and dom == 'conv_wgrad_halo':
+        companion = traffic_of('wgrad_halo_reduce', section)
+        if companion:
+            traffic['second_launch'] = {k: companion[k] for k in ('kernel', 'hbm_bytes_per_launch', 'write_bytes', 'fetch_bytes_raw')}
+    members = {k: dict(ms=round(groups[k]['ms'], 3), n=groups[k]['n'], tflops=round(groups[k]['flops'] / groups[k]['ms'] / 1e9, 1),
+                       frac=round(groups[k]['flops'] / groups[k]['ms'] / 1e9 / peak, 4)) for k in sorted(cg['members'], key=lambda k: -groups[k]['ms'])}
+    return {'bound': 'mfma', 'kernel': dom, 'kernel_class': top, 'class_members': members,
+            'achieved': round(ach, 1), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(ach / peak, 4),
+            'quoted_on': 'the kernel class with the largest share of the step (all its launches); `kernel` is the instantiation that '
+                         'dominates that class by time, `traffic` are that kernel\'s own counters',
+            'traffic': traffic, 'launches_per_step': cg['n'], 'avg_launch_ms': round(cg['ms'] / cg['n'], 5),
+            'gflop_per_launch': round(cg['flops'] / cg['n'] / 1e9, 3), 'gpu_ms_per_step': round(total, 3),
             'by_kernel': table, 'by_role_ms': {k: round(v[0], 3) for k, v in sorted(roles.items(), key=lambda kv: -kv[1][0])}}
 
 

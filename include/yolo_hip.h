@@ -472,6 +472,12 @@ int64_t yh_conv2d_wgrad_workspace(const yh_wgrad_desc* d);
  * row tile, YH_WGRAD_BN = 256 selects the 8-wave 128 x 256 tile, YH_WGRAD_XCD = 0 restores the plain (tile, split) grid.
  * splits = -1 in the descriptor selects the register-staged fp16 kernel.                                            */
 int yh_conv2d_wgrad(const yh_wgrad_desc* d, void* stream);
+/* Which kernel yh_conv2d_wgrad will launch for this descriptor (host code, no launch; with d->ws == NULL the answer assumes the
+ * workspace of yh_conv2d_wgrad_workspace() will be bound, as the training plan does): 90 = conv_wgrad_halo_kernel (3x3 / s1 halo
+ * form), 10 * TM + WNW for conv_wgrad_dma_kernel<TM, WNW> (22 = 64-row tile, 42 = 128 x 128, 44 = 128 x 256, 82 = 256 x 128,
+ * 84 = 256 x 256), 1 = the register-staged kernel (fp32, or splits == -1).  bench.py uses it to name the dominant kernel of
+ * the weight-gradient class and to attach that kernel's HBM counters.                                   */
+int yh_conv2d_wgrad_kernel(const yh_wgrad_desc* d);
 int yh_stem_wgrad(const yh_wgrad_desc* d, void* stream);
 typedef struct yh_resample_desc {
     const void* x; void* y;

@@ -817,6 +817,9 @@ class FakeLib:
     def yh_conv2d_wgrad_workspace(self, dref):
         return 0
 
+    def yh_conv2d_wgrad_kernel(self, dref):
+        return 1        # the emulation has one weight-gradient form
+
     def yh_bn_reduce_workspace(self, dref):
         return 0
 

@@ -3,6 +3,10 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <mutex>
+#include <set>
+#include <utility>
+
 #include "../../include/yolo_hip.h"
 
 namespace yh {
@@ -36,6 +40,22 @@ template <typename T> __device__ __forceinline__ float to_f32(T v) { return (flo
 inline int check_launch() {
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? YH_OK : (int)e;
+}
+
+// Dynamic LDS above 64 KB needs the function attribute raised - per DEVICE (a single process may drive several GPUs:
+// DataParallel, `--device 0,1`), so the "already raised" state is keyed by (kernel, current device).
+inline hipError_t ensure_dynamic_lds(const void* kern, size_t bytes) {
+    if (bytes <= 64 * 1024) return hipSuccess;
+    static std::mutex mu;
+    static std::set<std::pair<const void*, int>> raised;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    std::lock_guard<std::mutex> lock(mu);
+    if (raised.count({kern, dev})) return hipSuccess;
+    e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess) raised.insert({kern, dev});
+    return e;
 }
 
 inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15u) == 0; }

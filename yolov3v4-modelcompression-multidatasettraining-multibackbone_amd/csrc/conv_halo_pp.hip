@@ -353,7 +353,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_hpp_kernel(const ConvArgs a, c
     int st_r = 0, st_w = 3;      // ring stage of step s / of step s + 3
     int ptap = 3, pkc = 0;       // tap / channel offset of step s + 3
     for (int c = 0; c < nchunks; ++c) {
-        const bool more_h = c + 1 < nchunks;      // the next chunk's halo image is fetched during this chunk
+        // the next chunk's halo image is fetched during this chunk; LB 9 (W >= 262) is a single-chunk form (hpp_geometry), so its
+        // in-loop prefetch compiles out - with it the 9 per-lane piece offsets stayed live through the K loop and spilled
+        const bool more_h = LB <= 7 ? c + 1 < nchunks : false;
         const u32x4* const hb = Hbuf + (c & (hbufs - 1)) * (rows_hp * 4);
         const int nbuf = (c + 1) & 1, nkc = (c + 1) * BK;
         static_for<9>([&](auto tc) {
@@ -456,21 +458,22 @@ template <typename T> static int launch_hpp(const ConvArgs& a0, hipStream_t stre
     a.p_tiles = (int)((Q + 511) / 512);
     const long blocks = (long)a.m_tiles * a.p_tiles;
     if (blocks <= 0 || blocks > 0x7fffffffL) return YH_EINVAL;
-    // ROLE 1 (separate weight / halo waves; needs its 48 halo pieces to cover the image) is an A/B knob, YH_HPP_ROLE=1: measured
-    // 5 - 9 % SLOWER than the shared form here (profiles/r03_hpp_role_ab.txt) - the weight tiles are L2-resident and short, unlike
-    // the dz stream of the weight-gradient kernel where the same separation gained 20 %
+    // ROLE 1 (separate weight / halo waves; needs its 48 halo pieces to cover the image) is an A/B form, measured 5 - 9 % SLOWER
+    // than the shared form here (profiles/r03_hpp_role_ab.txt) - the weight tiles are L2-resident and short, unlike the dz stream
+    // of the weight-gradient kernel where the same separation gained 20 %.  Its instantiations spill 3 registers at the 256 cap,
+    // so they are only compiled into an A/B build (make CXXFLAGS+=-DYH_HPP_ROLE_AB; then YH_HPP_ROLE=1 selects them).
+#ifdef YH_HPP_ROLE_AB
     static const int role_env = [] { const char* e = getenv("YH_HPP_ROLE"); return e ? atoi(e) : 0; }();
     const int role = (role_env && rows_hp <= 768) ? 1 : 0;
+#define YH_HPP_KERN(LBV) (role ? conv3x3_hpp_kernel<T, LBV, 1> : conv3x3_hpp_kernel<T, LBV, 0>)
+#else
+#define YH_HPP_KERN(LBV) conv3x3_hpp_kernel<T, LBV, 0>
+#endif
 #define YH_HPP_CASE(LBV)                                                                                                       \
     case LBV: {                                                                                                                \
-        auto kern = role ? conv3x3_hpp_kernel<T, LBV, 1> : conv3x3_hpp_kernel<T, LBV, 0>;                                     \
-        static size_t allowed = 64 * 1024;   /* per instantiation: raise the dynamic-LDS limit once per size */               \
-        if (lds > allowed) {                                                                                                   \
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                               160 * 1024);                                                                    \
-            if (e != hipSuccess) return (int)e;                                                                                \
-            allowed = 160 * 1024;                                                                                              \
-        }                                                                                                                      \
+        auto kern = YH_HPP_KERN(LBV);                                                                                          \
+        hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds);   /* per (kernel, device) */                      \
+        if (e != hipSuccess) return (int)e;                                                                                    \
         hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(512), lds, stream, a, rows_hp, hbufs);                           \
         break;                                                                                                                 \
     }
@@ -479,6 +482,7 @@ template <typename T> static int launch_hpp(const ConvArgs& a0, hipStream_t stre
         default: return YH_EUNSUPPORTED;
     }
 #undef YH_HPP_CASE
+#undef YH_HPP_KERN
     return check_launch();
 }
 

@@ -765,8 +765,8 @@ template <typename T, typename OutT, int BM> static int launch_halo(const ConvAr
 #define YH_HALO_CASE(LBV)                                                                                             \
     case LBV: {                                                                                                       \
         auto kern = conv3x3_halo_kernel<T, OutT, BM, LBV>;                                                            \
-        if (lds > 64 * 1024) {                                                                                        \
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        {                                                                                                             \
+            hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds);                                  \
             if (e != hipSuccess) return (int)e;                                                                       \
         }                                                                                                             \
         hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(512), lds, stream, a, rows_h);                          \

@@ -228,7 +228,13 @@ template <typename T, int MT, int WAVES, int OCC> static int launch_s3_act(const
     const size_t shmem = (size_t)MT * 9 * 64 * 16 + (size_t)WAVES * 16 * (MT * 16 * sizeof(T) + 16);
     const bool res = a.res != nullptr, stats = a.stats_part != nullptr;
     if (stats && (res || sizeof(T) == 1)) return YH_EINVAL;
-#define YH_S3_GO(A, R, S) hipLaunchKernelGGL((conv3x3_stream_kernel<T, MT, A, R, S, WAVES, OCC>), dim3((unsigned)grid), dim3(WAVES * 64), shmem, s, a, nblocks)
+#define YH_S3_GO(A, R, S)                                                                                                      \
+    do {                                                                                                                       \
+        auto kern = conv3x3_stream_kernel<T, MT, A, R, S, WAVES, OCC>;                                                         \
+        const hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), shmem);   /* int8 Cout 128: ~92 KB */    \
+        if (e != hipSuccess) return (int)e;                                                                                    \
+        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(WAVES * 64), shmem, s, a, nblocks);                                \
+    } while (0)
     switch (a.act) {
 #define YH_S3(A)                                                         \
     case A:                                                               \

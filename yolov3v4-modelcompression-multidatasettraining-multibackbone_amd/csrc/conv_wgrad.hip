@@ -1376,14 +1376,12 @@ extern "C" int yh_conv2d_wgrad(const yh_wgrad_desc* d, void* stream) {
             int s2;
             wgrad_halo_geometry(d, &a, &s2, &lds);
             a.two_stage = 1;
-            static bool raised[3] = {false, false, false};   // LBW 2, 3, 4
 #define YH_WH_CASE(L)                                                                                                          \
             case L: {                                                                                                          \
                 auto kern = conv_wgrad_halo_kernel<L>;                                                                         \
-                if (!raised[L - 2]) {                                                                                          \
-                    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+                {                                                                                                              \
+                    hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds);                                   \
                     if (e != hipSuccess) return (int)e;                                                                        \
-                    raised[L - 2] = true;                                                                                      \
                 }                                                                                                              \
                 hipLaunchKernelGGL(kern, dim3((unsigned)(htiles * splits)), dim3(768), lds, st, a);                            \
                 break;                                                                                                         \
@@ -1437,6 +1435,17 @@ extern "C" int yh_conv2d_wgrad(const yh_wgrad_desc* d, void* stream) {
         else hipLaunchKernelGGL((wgrad_reduce_kernel<4, 2>), dim3(tiles * 16, groups), dim3(256), 0, st, a, splits, per_group);
     }
     return check_launch();
+}
+
+extern "C" int yh_conv2d_wgrad_kernel(const yh_wgrad_desc* d) {
+    if (!d || d->n <= 0 || d->cin <= 0 || d->cout <= 0 || (d->dtype != YH_F16 && d->dtype != YH_F32)) return YH_EINVAL;
+    WgradArgs a;
+    int splits;
+    wgrad_geometry(d, &a, &splits);
+    if (a.halo) return 90;
+    if (!a.dma) return 1;
+    if (d->cout <= 64) return 22;
+    return (a.bm == 256 ? 80 : 40) + (a.bn == 256 ? 4 : 2);
 }
 
 extern "C" int64_t yh_conv2d_wgrad_workspace(const yh_wgrad_desc* d) {

@@ -262,6 +262,7 @@ _SIGNATURES = {
                                                    C.c_int, C.c_int, _vp, C.POINTER(C.c_int), C.POINTER(C.c_int), _vp]),
     'yh_conv2d_wgrad': (C.c_int, [C.POINTER(WgradDesc), _vp]),
     'yh_conv2d_wgrad_workspace': (_i64, [C.POINTER(WgradDesc)]),
+    'yh_conv2d_wgrad_kernel': (C.c_int, [C.POINTER(WgradDesc)]),
     'yh_bn_reduce_workspace': (_i64, [C.POINTER(BnDesc)]),
     'yh_stem_wgrad': (C.c_int, [C.POINTER(WgradDesc), _vp]),
     'yh_dilate2': (C.c_int, [C.POINTER(ResampleDesc), _vp]),

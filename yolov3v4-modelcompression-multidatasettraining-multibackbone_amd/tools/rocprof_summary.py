@@ -3,6 +3,8 @@
 
     python tools/rocprof_summary.py stats  <results.db>              # like --stats: calls, total, avg, %
     python tools/rocprof_summary.py pmc    <results.db> [<more.db>]  # per kernel: sum / per-dispatch mean of every counter
+    python tools/rocprof_summary.py list   <results.db> [<more.db>]  # every dispatch in order with its counters
+    python tools/rocprof_summary.py traffic <out.json> <FETCH_SIZE.db> <WRITE_SIZE.db>   # HBM bytes per dispatch per kernel
 """
 import sqlite3
 import sys
@@ -82,23 +84,54 @@ def pmc(dbs):
                 print('    %-28s sum %.6g   per-dispatch %.6g   (profiled us/dispatch %.2f)' % (cn, s, s / cnt, dur / cnt / 1e3))
 
 
+def per_dispatch(db, counters):
+    """{dispatch_id: (short kernel name, grid, duration ns, {counter: value})}: a counter's rows of one dispatch are SUMMED (rocprofv3
+    may store one row per counter instance), dispatches are never averaged across kernels of different sizes here."""
+    c = sqlite3.connect(db)
+    rows = {}
+    q = 'select dispatch_id, kernel_name, grid_size, counter_name, value, duration from counters_collection'
+    for did, k, g, cn, v, dur in c.execute(q):
+        if counters and cn not in counters:
+            continue
+        r = rows.setdefault(did, [short(k), g, dur, {}])
+        r[3][cn] = r[3].get(cn, 0.0) + v
+    return rows
+
+
+def listing(dbs):
+    """Every dispatch in order: kernel, grid, duration, counters (the form the r04 calibration and per-layer traffic tables use)."""
+    for db in dbs:
+        print('==', db)
+        rows = per_dispatch(db, None)
+        for did in sorted(rows):
+            k, g, dur, cs = rows[did]
+            print('%5d %-44s grid %9d  %8.1f us  %s' % (did, k[:44], g, dur / 1e3, '  '.join('%s=%.6g' % kv for kv in sorted(cs.items()))))
+
+
 def traffic(dbs, out_path):
     """HBM bytes per dispatch per kernel from separate FETCH_SIZE / WRITE_SIZE passes.
 
-    Units and corrections follow MI355X_MICROARCH.md section HBM: both counters are in KiB; on gfx950 FETCH_SIZE
-    counts 128-byte read requests as 64 bytes, so the read side is doubled; WRITE_SIZE is used as reported."""
+    Units: both counters are KiB.  Calibration on this part (profiles/r04_traffic_calibration.txt: single launches with known
+    byte counts): WRITE_SIZE is exact (all requests 64 B); FETCH_SIZE = 64 B x TCC_EA0_RDREQ, i.e. a 128-byte request is
+    tallied at 64 bytes (wide coalesced streams read exactly half: MI355X_MICROARCH.md, HBM) while a 64-byte request (a
+    channel-slice row, an LDS-DMA row piece) is tallied in full.  `hbm_bytes_per_dispatch` applies the guide's doubling to the
+    read side - exact for streaming kernels, an upper bound for kernels that fetch 64-byte pieces; `fetch_kib_raw` is kept.
+    Means are taken over DISPATCHES of a kernel name (round 3 averaged rows of a merged-name group, which mis-stated
+    conv3x3_hpp's write side by 2.4x; per dispatch its WRITE_SIZE equals its output bytes exactly)."""
     import json
     agg = {}
     for db in dbs:
-        c = sqlite3.connect(db)
-        q = "select kernel_name, counter_name, sum(value), count(*) from counters_collection where counter_name in ('FETCH_SIZE','WRITE_SIZE') group by kernel_name, counter_name"
-        for k, cn, s, n in c.execute(q):
-            agg.setdefault(short(k), {})[cn] = s / n
+        for did, (k, g, dur, cs) in per_dispatch(db, ('FETCH_SIZE', 'WRITE_SIZE')).items():
+            for cn, v in cs.items():
+                a = agg.setdefault(k, {}).setdefault(cn, [0.0, 0])
+                a[0] += v
+                a[1] += 1
     res = {}
     for k, v in agg.items():
         if 'FETCH_SIZE' in v and 'WRITE_SIZE' in v:
-            res[k] = dict(fetch_kib_raw=round(v['FETCH_SIZE'], 1), write_kib=round(v['WRITE_SIZE'], 1),
-                          hbm_bytes_per_dispatch=int((2 * v['FETCH_SIZE'] + v['WRITE_SIZE']) * 1024))
+            f, w = v['FETCH_SIZE'][0] / v['FETCH_SIZE'][1], v['WRITE_SIZE'][0] / v['WRITE_SIZE'][1]
+            res[k] = dict(fetch_kib_raw=round(f, 1), write_kib=round(w, 1), dispatches=v['WRITE_SIZE'][1],
+                          hbm_bytes_per_dispatch=int((2 * f + w) * 1024))
     json.dump(res, open(out_path, 'w'), indent=1, sort_keys=True)
     print('wrote', out_path, len(res), 'kernels')
 
@@ -108,5 +141,7 @@ if __name__ == '__main__':
         stats(sys.argv[2])
     elif sys.argv[1] == 'traffic':
         traffic(sys.argv[3:], sys.argv[2])
+    elif sys.argv[1] == 'list':
+        listing(sys.argv[2:])
     else:
         pmc(sys.argv[2:])
