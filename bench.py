@@ -481,7 +481,9 @@ def train_roofline(eng, x, precision):
             traffic['second_launch'] = {k: companion[k] for k in ('kernel', 'hbm_bytes_per_launch', 'write_bytes', 'fetch_bytes_raw')}
     members = {k: dict(ms=round(groups[k]['ms'], 3), n=groups[k]['n'], tflops=round(groups[k]['flops'] / groups[k]['ms'] / 1e9, 1),
                        frac=round(groups[k]['flops'] / groups[k]['ms'] / 1e9 / peak, 4)) for k in sorted(cg['members'], key=lambda k: -groups[k]['ms'])}
-    return {'bound': 'mfma', 'kernel': dom, 'kernel_class': top, 'class_members': members,
+    by_class = {c: dict(ms=round(v['ms'], 3), n=v['n'], tflops=round(v['flops'] / v['ms'] / 1e9, 1), frac=round(v['flops'] / v['ms'] / 1e9 / peak, 4))
+                for c, v in sorted(classes.items(), key=lambda kv: -kv[1]['ms']) if v['flops'] > 0}
+    return {'bound': 'mfma', 'kernel': dom, 'kernel_class': top, 'class_members': members, 'by_class': by_class,
             'achieved': round(ach, 1), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(ach / peak, 4),
             'quoted_on': 'the kernel class with the largest share of the step (all its launches); `kernel` is the instantiation that '
                          'dominates that class by time, `traffic` are that kernel\'s own counters',

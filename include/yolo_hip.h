@@ -479,6 +479,32 @@ int yh_conv2d_wgrad(const yh_wgrad_desc* d, void* stream);
  * the weight-gradient class and to attach that kernel's HBM counters.                                   */
 int yh_conv2d_wgrad_kernel(const yh_wgrad_desc* d);
 int yh_stem_wgrad(const yh_wgrad_desc* d, void* stream);
+
+/* First conv block, whole backward in ONE pass over dy and z (round 4).  The first layer has no data gradient, so its dz is only
+ * ever read by its own weight gradient; reference: autograd through models.py:92-113 (Conv2d -> BatchNorm2d -> activation) of
+ * block 0, i.e. what yh_bn_act_bwd_reduce + yh_bn_act_bwd_apply + yh_nchw_to_nhwc + yh_conv2d_wgrad compute in four launches
+ * (reading dy and z twice, writing and re-reading dz: 9 bytes per element more than this form).  With g = dy * act'(u),
+ * xhat = (z - mean) invstd, X = im2col of the image:
+ *     dbeta = S1 = sum_p g,   dgamma = S2 = sum_p g xhat,
+ *     dz = gamma invstd (g - S1/P - xhat S2/P)                                   (batch-statistics BatchNorm backward)
+ *     dW[c][k] = sum_p dz[c][p] X[k][p] = gamma_c invstd_c (Q[c][k] - S1_c/P SX[k] - S2_c/P R[c][k])
+ * with Q = g X^T, R = xhat X^T, SX = sum_p X: all three are sums over pixels that one pass can take (fp16 MFMA operands, fp32
+ * accumulation, the final combination in double).  3x3 / stride 1 / pad 1, cin <= 3, cout 16 or 32, fp16 activations; other
+ * first layers keep the four-launch form.  dgamma / dbeta / dw are ADDED to (the gradient arena is zeroed per backward).      */
+typedef struct yh_stem_bwd_desc {
+    const float* x;         /* the fp32 NCHW image batch [n][cin][h][w]                                           */
+    const void* dy;         /* gradient of the block output, NHWC f16, pitch lddy                                 */
+    const void* z;          /* conv output before BatchNorm, NHWC f16, pitch ldz                                  */
+    const float* gamma; const float* beta; const float* mean; const float* invstd;   /* [cout] fp32               */
+    float* dgamma; float* dbeta;   /* [cout] fp32, added to                                                        */
+    float* dw;              /* [cout][cin][3][3] fp32, added to                                                   */
+    float* ws;              /* workspace of yh_stem_bwd_workspace() floats: per-workgroup partial rows            */
+    int64_t ws_floats;
+    int32_t n, cin, h, w_in, cout, lddy, ldz, act;
+    float slope;
+} yh_stem_bwd_desc;
+int64_t yh_stem_bwd_workspace(const yh_stem_bwd_desc* d);
+int yh_stem_bwd(const yh_stem_bwd_desc* d, void* stream);
 typedef struct yh_resample_desc {
     const void* x; void* y;
     int32_t n, h, w_in, c;  /* geometry of the SMALL tensor (dilate2: source; upsample2_bwd: destination)       */
@@ -602,7 +628,7 @@ enum { YH_OP_CONV = 1, YH_OP_STEM = 2, YH_OP_POOL = 3, YH_OP_COPY = 4, YH_OP_ADD
        YH_OP_SE = 8, YH_OP_QCOPY = 9, YH_OP_QPOOL = 10, YH_OP_QADD = 11, YH_OP_BN_STATS = 12, YH_OP_BN_FINALIZE = 13,
        YH_OP_BN_ACT_FWD = 14, YH_OP_BN_BWD_REDUCE = 15, YH_OP_BN_BWD_APPLY = 16, YH_OP_WGRAD = 17, YH_OP_STEM_WGRAD = 18,
        YH_OP_DILATE2 = 19, YH_OP_UPSAMPLE2_BWD = 20, YH_OP_CAST_F32 = 21, YH_OP_NCHW_TO_NHWC = 22, YH_OP_POOL_BWD = 23, YH_OP_PACK_BATCH = 24, YH_OP_DW_WGRAD = 25, YH_OP_DW_DGRAD = 26,
-       YH_OP_SE_BWD = 27 };
+       YH_OP_SE_BWD = 27, YH_OP_STEM_BWD = 28 };
 typedef struct yh_pack_batch_desc { const yh_pack_item* items; int32_t n_items; } yh_pack_batch_desc;
 typedef struct yh_layout_desc { const float* x; void* y; int32_t n, c, h, w_in, c_pad, ldy, dtype; } yh_layout_desc;
 

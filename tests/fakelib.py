@@ -15,7 +15,7 @@ import torch
 import torch.nn.functional as F
 
 from engine import hiplib
-from engine.hiplib import (ConvDesc, StemDesc, PoolDesc, CopyDesc, AddDesc, DecodeDesc, DwDesc, SeDesc, QCopyDesc, QPoolDesc,
+from engine.hiplib import (StemBwdDesc, ConvDesc, StemDesc, PoolDesc, CopyDesc, AddDesc, DecodeDesc, DwDesc, SeDesc, QCopyDesc, QPoolDesc,
                            QAddDesc, BnStatsDesc, BnFinalizeDesc, BnActFwdDesc, BnBwdReduceDesc, BnBwdApplyDesc, WgradDesc,
                            StemWgradDesc, DilateDesc, UpsampleBwdDesc, CastDesc, LayoutDesc, PoolBwdDesc, PackBatchDesc, PackItem, DwWgradDesc, DwDgradDesc, SeBwdDesc)
 
@@ -27,7 +27,7 @@ _DESC = {hiplib.OP_CONV: ConvDesc, hiplib.OP_STEM: StemDesc, hiplib.OP_POOL: Poo
          hiplib.OP_BN_BWD_REDUCE: BnBwdReduceDesc, hiplib.OP_BN_BWD_APPLY: BnBwdApplyDesc, hiplib.OP_WGRAD: WgradDesc,
          hiplib.OP_STEM_WGRAD: StemWgradDesc, hiplib.OP_DILATE2: DilateDesc, hiplib.OP_UPSAMPLE2_BWD: UpsampleBwdDesc,
          hiplib.OP_CAST_F32: CastDesc, hiplib.OP_NCHW_TO_NHWC: LayoutDesc, hiplib.OP_POOL_BWD: PoolBwdDesc, hiplib.OP_PACK_BATCH: PackBatchDesc, hiplib.OP_DW_WGRAD: DwWgradDesc, hiplib.OP_DW_DGRAD: DwDgradDesc,
-         hiplib.OP_SE_BWD: SeBwdDesc}
+         hiplib.OP_SE_BWD: SeBwdDesc, hiplib.OP_STEM_BWD: StemBwdDesc}
 
 
 def _addr(p):
@@ -617,6 +617,39 @@ class FakeLib:
         flat(d.sumsq, d.c, np.float32)[:] += (g * xh).sum(0).numpy()
         return 0
 
+    # ---- first block, whole backward in one pass (csrc/stem_bwd.hip): the kernel's sums, operand roundings included
+    @staticmethod
+    def _stem_bwd_ok(d):
+        return d.n > 0 and d.h > 0 and d.w_in > 0 and d.cin in (1, 3) and d.cout in (16, 32)
+
+    def yh_stem_bwd_workspace(self, dref):
+        d = dref._obj if hasattr(dref, '_obj') else dref
+        return 4 if self._stem_bwd_ok(d) else 0
+
+    def yh_stem_bwd(self, dref, stream):
+        d = dref._obj if hasattr(dref, '_obj') else dref
+        if not self._stem_bwd_ok(d):
+            return -3       # YH_EUNSUPPORTED
+        P, c = d.n * d.h * d.w_in, d.cout
+        ld = lambda p: torch.from_numpy(flat(p, c, np.float32).copy())
+        gamma, beta, mu, istd = ld(d.gamma), ld(d.beta), ld(d.mean), ld(d.invstd)
+        z = torch.from_numpy(pitched(d.z, P, c, d.ldz, np.float16).astype(np.float32))
+        dy = torch.from_numpy(pitched(d.dy, P, c, d.lddy, np.float16).astype(np.float32))
+        xh = (z - mu) * istd
+        g = dy * self._act_grad(gamma * xh + beta, d.act, d.slope)
+        s1, s2 = g.double().sum(0), (g * xh).double().sum(0)
+        x = torch.from_numpy(flat(d.x, d.n * d.cin * d.h * d.w_in, np.float32).copy()).view(d.n, d.cin, d.h, d.w_in)
+        # X[p][k], k = (r * 3 + s) * cin + ci, as f16 MFMA operands; g and xhat likewise
+        cols = F.unfold(x.half().float(), 3, padding=1).view(d.n, d.cin, 9, d.h * d.w_in).permute(0, 3, 2, 1).reshape(P, 9 * d.cin).double()
+        gq, xq = g.half().double(), xh.half().double()
+        Q, R, SX = gq.t() @ cols, xq.t() @ cols, cols.sum(0)
+        dw = (gamma * istd).double()[:, None] * (Q - (s1 / P)[:, None] * SX[None] - (s2 / P)[:, None] * R)      # [c][k]
+        dw = dw.view(c, 9, d.cin).permute(0, 2, 1).reshape(-1)                                                   # -> [c][ci][r][s]
+        flat(d.dw, c * d.cin * 9, np.float32)[:] += dw.float().numpy()
+        flat(d.dbeta, c, np.float32)[:] += s1.float().numpy()
+        flat(d.dgamma, c, np.float32)[:] += s2.float().numpy()
+        return 0
+
     def yh_bn_act_bwd_apply(self, dref, stream):
         d = dref._obj if hasattr(dref, '_obj') else dref
         npdt = _NP[d.dtype]
@@ -970,6 +1003,7 @@ class FakeLib:
                hiplib.OP_UPSAMPLE2_BWD: self.yh_upsample2_bwd, hiplib.OP_CAST_F32: self.yh_cast_f32,
                hiplib.OP_NCHW_TO_NHWC: self._layout, hiplib.OP_POOL_BWD: self.yh_maxpool2d_bwd,
                hiplib.OP_PACK_BATCH: lambda d, st: self.yh_pack_batch(d.items, d.n_items, st),
+               hiplib.OP_STEM_BWD: self.yh_stem_bwd,
                hiplib.OP_DW_WGRAD: self.yh_dw_wgrad, hiplib.OP_DW_DGRAD: self.yh_dw_dgrad, hiplib.OP_SE_BWD: self.yh_se_bwd}
         lanes, deps = plan.get('lane', {}), plan.get('deps', {})
         pending, done_main = [], set()

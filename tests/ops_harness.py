@@ -362,3 +362,24 @@ def stem_wgrad_mfma(lib, code, x, dz, cout, stride=1, pad=1):
         d.ws, d.ws_floats = P(ws), need
     call(lib, 'yh_conv2d_wgrad', d)
     return dw, img
+
+
+def stem_bwd(lib, x, dy, z, gamma, beta, mean, invstd, act=1, slope=0.1):
+    """yh_stem_bwd on x (N,cin,H,W) fp32, dy / z (N,H,W,ld) f16: returns (dw [c][cin][3][3], dgamma, dbeta), all fp32."""
+    from engine.hiplib import StemBwdDesc
+    N, cin, H, W = x.shape
+    c = gamma.numel()
+    dev = x.device
+    dw = torch.zeros(c, cin, 3, 3, device=dev)
+    dg, db = torch.zeros(c, device=dev), torch.zeros(c, device=dev)
+    d = StemBwdDesc(x=P(x), dy=P(dy), z=P(z), gamma=P(gamma), beta=P(beta), mean=P(mean), invstd=P(invstd), dgamma=P(dg), dbeta=P(db),
+                    dw=P(dw), n=N, cin=cin, h=H, w_in=W, cout=c, lddy=dy.shape[3], ldz=z.shape[3], act=act, slope=slope)
+    need = int(lib.yh_stem_bwd_workspace(C.byref(d)))
+    assert need > 0
+    ws = torch.full((need,), float('nan'), device=dev)
+    d.ws, d.ws_floats = P(ws), need
+    rc = lib.yh_stem_bwd(C.byref(d), stream())
+    assert rc == 0, rc
+    if x.is_cuda:
+        torch.cuda.synchronize()
+    return dw, dg, db

@@ -234,6 +234,45 @@ DGRAD_CASES = [(2, 16, 16, 64, 128, 1, 1), (2, 20, 20, 32, 64, 3, 1), (2, 32, 32
                (2, 13, 13, 128, 255, 1, 1), (1, 10, 10, 256, 512, 3, 1)]
 
 
+@pytest.mark.parametrize('case', [(2, 3, 40, 64, 32, 1), (1, 3, 21, 45, 32, 1), (3, 1, 17, 33, 16, 5), (2, 3, 9, 100, 16, 1), (1, 3, 96, 608, 32, 1)],
+                         ids=['c32', 'c32_tail', 'gray_c16_mish', 'c16_wide', 'row608'])
+def test_first_block_backward_in_one_pass(libs, case):
+    """csrc/stem_bwd.hip: dgamma, dbeta and dW of block 0 from ONE pass over dy and z (closed form over Q = g X^T, R = xhat X^T,
+    SX), against (a) float64 torch: train-mode batch_norm backward + conv2d weight gradient through autograd on the SAME f16 dy / z
+    (reference: autograd through models.py:92-113), and (b) the emulation of the descriptor.  fp16 MFMA operands, fp32 accumulation:
+    agreement to the operand rounding (2^-11 relative per term, averaged over thousands of pixels)."""
+    lib, fake = libs
+    N, cin, H, W, c, act = case
+    g = torch.Generator().manual_seed(H * 13 + W)
+    x = torch.rand(N, cin, H, W, generator=g)
+    z = (torch.randn(N, H, W, c + 8, generator=g) * 1.3 + 0.2).half()        # channels [0, c) of wider buffers: pitches > c
+    dy = (torch.randn(N, H, W, c + 16, generator=g) * 0.05).half()
+    gamma, beta = torch.rand(c, generator=g) + 0.5, torch.randn(c, generator=g) * 0.3
+    zz = z[..., :c].float().reshape(-1, c).double()
+    mean = zz.mean(0)
+    invstd = 1.0 / torch.sqrt(zz.var(0, unbiased=False) + 1e-5)
+    # float64 reference through autograd: y = act(bn(conv)); the conv output is GIVEN (z), so differentiate bn + act w.r.t. z and
+    # push that gradient into conv2d's weight gradient
+    zt = zz.clone().requires_grad_(True)
+    xh = (zt - zt.mean(0)) / torch.sqrt(zt.var(0, unbiased=False) + 1e-5)
+    ga, be = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    u = ga * xh + be
+    y = {1: lambda t: F.leaky_relu(t, 0.1), 5: lambda t: t * torch.tanh(F.softplus(t))}[act](u)
+    dyd = dy[..., :c].float().reshape(-1, c).double()
+    dz, dga, dbe = torch.autograd.grad((y * dyd).sum(), (zt, ga, be))
+    dzn = dz.view(N, H, W, c).permute(0, 3, 1, 2)
+    wref = torch.nn.grad.conv2d_weight(x.double(), (c, cin, 3, 3), dzn, stride=1, padding=1)
+    outs = []
+    for L, dev in ((lib, GPU), (fake, 'cpu')):
+        t = lambda a: a.to(dev)
+        outs.append([o.cpu() for o in oh.stem_bwd(L, t(x), t(dy), t(z), t(gamma), t(beta), t(mean.float()), t(invstd.float()), act=act)])
+    (dw, dg, db), (dw_e, dg_e, db_e) = outs
+    for got, emu, want, tag in ((dw, dw_e, wref, 'dw'), (dg, dg_e, dga, 'dgamma'), (db, db_e, dbe, 'dbeta')):
+        scale = want.abs().max().item()
+        assert (got.double() - want).abs().max().item() <= 3e-3 * scale, (tag, (got.double() - want).abs().max().item(), scale)
+        assert (got - emu).abs().max().item() <= 1e-3 * scale, (tag, 'vs emulation')
+
+
 @pytest.mark.parametrize('code', [F32, F16], ids=['fp32', 'fp16'])
 @pytest.mark.parametrize('accumulate', [False, True], ids=['write', 'acc'])
 @pytest.mark.parametrize('case', DGRAD_CASES, ids=lambda c: 'n%d_%dx%d_c%d-%d_k%ds%d' % c)

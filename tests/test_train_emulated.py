@@ -55,6 +55,43 @@ def test_mini_fp16_storage_stays_close(mini):
         assert th.cosine(grads[k], grads_ref[k]) > 0.97, k
 
 
+@pytest.fixture(scope='module')
+def mini16():
+    """The mini cfg with 16 filters in its first conv (the one-pass first-block backward covers 16 / 32 output channels)."""
+    path = th.write_cfg(th.mini_cfg_text().replace('filters=8', 'filters=16', 1))
+    yield path
+    os.unlink(path)
+
+
+def test_first_block_backward_in_one_pass_equals_the_four_launch_form(mini16, monkeypatch):
+    """csrc/stem_bwd.hip (emulated here): BatchNorm backward + weight gradient of block 0 from ONE pass over dy and z, through the
+    closed form dW = gamma invstd (Q - S1/P SX - S2/P R).  Same fp16 step with YOLO_HIP_STEM_BWD=0 (reduce, apply, image copy,
+    weight gradient): every gradient of the first block agrees to the fp16 rounding of dz the four-launch form stores (the
+    one-pass form keeps dz in fp32), every other gradient is identical (nothing downstream of block 0 changes)."""
+    model = th.build(mini16, 52)          # 52: segments of 32 pixels with a 20-pixel tail
+    x = synth.image_batch(4, 52, seed=0)
+    _, _, _, ws = th.eager_step(model, x)
+    raws_a, grads_a, m = th.engine_step(model, x, ws, 'fp16', lib=fakelib.FakeLib())
+    plan = m.__dict__['_hip_train_engine']._current
+    assert any(what.startswith('stembwd') for what, _ in plan['bwd_ops'])
+    assert not any(what in ('dbn0', 'dbnx0', 'image0', 'wgrad0') for what, _ in plan['bwd_ops'])
+    monkeypatch.setenv('YOLO_HIP_STEM_BWD', '0')
+    raws_b, grads_b, m = th.engine_step(model, x, ws, 'fp16', lib=fakelib.FakeLib())
+    plan = m.__dict__['_hip_train_engine']._current
+    assert all(what in [w for w, _ in plan['bwd_ops']] for what in ('dbn0', 'dbnx0', 'image0', 'wgrad0'))
+    first = [k for k in grads_a if k.startswith('module_list.0.')]
+    assert len(first) == 3
+    for k in grads_a:
+        if k in first:
+            assert th.rel_l2(grads_a[k], grads_b[k]) <= 2e-3, (k, th.rel_l2(grads_a[k], grads_b[k]))
+        else:
+            assert torch.equal(grads_a[k], grads_b[k]), k
+    # and against eager fp32 autograd the one-pass form is at least as close as the four-launch form
+    _, grads_ref, _, _ = th.eager_step(model, x, ws)
+    for k in first:
+        assert th.rel_l2(grads_a[k], grads_ref[k]) <= 1.05 * th.rel_l2(grads_b[k], grads_ref[k]) + 1e-4, k
+
+
 def _gray_model():
     import models
     # linear activations: a leaky kink that flips under a different fp32 summation order moves every upstream gradient by

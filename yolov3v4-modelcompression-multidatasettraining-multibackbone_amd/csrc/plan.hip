@@ -30,6 +30,7 @@ union AnyDesc {
     yh_pack_batch_desc pack_batch;
     yh_dw_bwd_desc dw_bwd;
     yh_se_bwd_desc se_bwd;
+    yh_stem_bwd_desc stem_bwd;
 };
 
 struct Fixup {
@@ -70,6 +71,7 @@ size_t desc_size(int kind) {
         case YH_OP_PACK_BATCH: return sizeof(yh_pack_batch_desc);
         case YH_OP_DW_WGRAD: case YH_OP_DW_DGRAD: return sizeof(yh_dw_bwd_desc);
         case YH_OP_SE_BWD: return sizeof(yh_se_bwd_desc);
+        case YH_OP_STEM_BWD: return sizeof(yh_stem_bwd_desc);
         default: return 0;
     }
 }
@@ -102,6 +104,7 @@ int launch(int kind, const AnyDesc& d, void* stream) {
         case YH_OP_DW_WGRAD: return yh_dw_wgrad(&d.dw_bwd, stream);
         case YH_OP_DW_DGRAD: return yh_dw_dgrad(&d.dw_bwd, stream);
         case YH_OP_SE_BWD: return yh_se_bwd(&d.se_bwd, stream);
+        case YH_OP_STEM_BWD: return yh_stem_bwd(&d.stem_bwd, stream);
         case YH_OP_NCHW_TO_NHWC:
             return yh_nchw_to_nhwc(d.layout.x, d.layout.y, d.layout.n, d.layout.c, d.layout.h, d.layout.w_in, d.layout.c_pad,
                                    d.layout.ldy, d.layout.dtype, stream);

@@ -130,6 +130,13 @@ class StemWgradDesc(WgradDesc):
     pass
 
 
+class StemBwdDesc(C.Structure):
+    _fields_ = [('x', _vp), ('dy', _vp), ('z', _vp), ('gamma', _vp), ('beta', _vp), ('mean', _vp), ('invstd', _vp),
+                ('dgamma', _vp), ('dbeta', _vp), ('dw', _vp), ('ws', _vp), ('ws_floats', _i64),
+                ('n', _i32), ('cin', _i32), ('h', _i32), ('w_in', _i32), ('cout', _i32), ('lddy', _i32), ('ldz', _i32), ('act', _i32),
+                ('slope', _f32)]
+
+
 class ResampleDesc(C.Structure):
     _fields_ = [('x', _vp), ('y', _vp), ('n', _i32), ('h', _i32), ('w_in', _i32), ('c', _i32), ('big_h', _i32),
                 ('big_w', _i32), ('ldx', _i32), ('ldy', _i32), ('dtype', _i32)]
@@ -216,12 +223,12 @@ class CastDesc(C.Structure):
 
 OP_BN_STATS, OP_BN_FINALIZE, OP_BN_ACT_FWD, OP_BN_BWD_REDUCE, OP_BN_BWD_APPLY = 12, 13, 14, 15, 16
 OP_WGRAD, OP_STEM_WGRAD, OP_DILATE2, OP_UPSAMPLE2_BWD, OP_CAST_F32, OP_NCHW_TO_NHWC, OP_POOL_BWD, OP_PACK_BATCH = 17, 18, 19, 20, 21, 22, 23, 24
-OP_DW_WGRAD, OP_DW_DGRAD, OP_SE_BWD = 25, 26, 27
+OP_DW_WGRAD, OP_DW_DGRAD, OP_SE_BWD, OP_STEM_BWD = 25, 26, 27, 28
 
 OP_KIND = {BnStatsDesc: OP_BN_STATS, BnFinalizeDesc: OP_BN_FINALIZE, BnActFwdDesc: OP_BN_ACT_FWD,
            BnBwdReduceDesc: OP_BN_BWD_REDUCE, BnBwdApplyDesc: OP_BN_BWD_APPLY, WgradDesc: OP_WGRAD,
            StemWgradDesc: OP_STEM_WGRAD, DilateDesc: OP_DILATE2, UpsampleBwdDesc: OP_UPSAMPLE2_BWD, CastDesc: OP_CAST_F32, LayoutDesc: OP_NCHW_TO_NHWC, PoolBwdDesc: OP_POOL_BWD, PackBatchDesc: OP_PACK_BATCH, DwWgradDesc: OP_DW_WGRAD, DwDgradDesc: OP_DW_DGRAD,
-           SeBwdDesc: OP_SE_BWD,
+           SeBwdDesc: OP_SE_BWD, StemBwdDesc: OP_STEM_BWD,
            ConvDesc: OP_CONV, StemDesc: OP_STEM, PoolDesc: OP_POOL, CopyDesc: OP_COPY, AddDesc: OP_ADD,
            DecodeDesc: OP_DECODE, DwDesc: OP_DW, SeDesc: OP_SE, QCopyDesc: OP_QCOPY, QPoolDesc: OP_QPOOL, QAddDesc: OP_QADD}
 
@@ -263,6 +270,8 @@ _SIGNATURES = {
     'yh_conv2d_wgrad': (C.c_int, [C.POINTER(WgradDesc), _vp]),
     'yh_conv2d_wgrad_workspace': (_i64, [C.POINTER(WgradDesc)]),
     'yh_conv2d_wgrad_kernel': (C.c_int, [C.POINTER(WgradDesc)]),
+    'yh_stem_bwd_workspace': (_i64, [C.POINTER(StemBwdDesc)]),
+    'yh_stem_bwd': (C.c_int, [C.POINTER(StemBwdDesc), _vp]),
     'yh_bn_reduce_workspace': (_i64, [C.POINTER(BnDesc)]),
     'yh_stem_wgrad': (C.c_int, [C.POINTER(WgradDesc), _vp]),
     'yh_dilate2': (C.c_int, [C.POINTER(ResampleDesc), _vp]),

@@ -37,7 +37,7 @@ import torch.nn as nn
 
 from . import hiplib
 from .hiplib import (ConvDesc, StemDesc, CopyDesc, AddDesc, BnStatsDesc, BnFinalizeDesc, BnActFwdDesc, BnBwdReduceDesc,
-                     BnBwdApplyDesc, WgradDesc, StemWgradDesc, UpsampleBwdDesc, CastDesc, LayoutDesc, PoolDesc, PoolBwdDesc, PackItem, PackBatchDesc, DwDesc, SeDesc, DwWgradDesc,
+                     BnBwdApplyDesc, WgradDesc, StemWgradDesc, StemBwdDesc, UpsampleBwdDesc, CastDesc, LayoutDesc, PoolDesc, PoolBwdDesc, PackItem, PackBatchDesc, DwDesc, SeDesc, DwWgradDesc,
                      DwDgradDesc, SeBwdDesc)
 from .plan import DarknetEngine, ALIGN_C, _round_up
 
@@ -659,6 +659,22 @@ class TrainEngine(DarknetEngine):
                     else:                     # activation without BN: z already holds the bias
                         acc = dict(sum=grads.ptr(v.g_b if v.g_b is not None else self._junk(plan, grads, v.c_phys)),
                                    sumsq=grads.ptr(self._junk(plan, grads, v.c_phys)))
+                    if s.kind == 'input' and self._stem_bwd_fused(v, s):
+                        # first block: BatchNorm backward + weight gradient as ONE pass over dy and z (csrc/stem_bwd.hip) - its dz
+                        # has no other reader (no data gradient into the image), so it is never written
+                        sd = StemBwdDesc(x=None, dy=dyp, z=base['z'], gamma=bnp['gamma'], beta=bnp['beta'], mean=bnp['mean'],
+                                         invstd=bnp['invstd'], dgamma=grads.ptr(v.g_gamma), dbeta=grads.ptr(v.g_beta),
+                                         dw=grads.ptr(v.g_w), n=N, cin=s.C, h=s.H, w_in=s.W, cout=v.c_phys, lddy=lddy,
+                                         ldz=v.c_phys, act=v.act, slope=v.slope)
+                        need = int(lib.yh_stem_bwd_workspace(C.byref(sd)))
+                        if need <= 0:
+                            raise RuntimeError('yh_stem_bwd_workspace rejected a geometry _stem_bwd_fused accepted')
+                        sd.ws_floats = need
+                        plan['ws_floats'] = max(plan['ws_floats'], need)
+                        op = add(bwd, plan['bwd_ops'], sd, 'stembwd%d' % v.block)
+                        fixup(bwd, op, StemBwdDesc, 'ws', SLOT_WS)
+                        fixup(bwd, op, StemBwdDesc, 'x', SLOT_INPUT)
+                        continue
                     add_reduction(bwd, plan['bwd_ops'], BnBwdReduceDesc(**base, **acc, dy=dyp, lddy=lddy), 'dbn%d' % v.block)
                     op = add(bwd, plan['bwd_ops'], BnBwdApplyDesc(**base, **acc, dy=dyp, lddy=lddy, out=dzp, ldo=v.c_phys),
                              'dbnx%d' % v.block)
@@ -728,6 +744,14 @@ class TrainEngine(DarknetEngine):
             lib.yh_plan_bind_slot(handle, SLOT_WS, plan['ws'].data_ptr())
         lib.yh_plan_bind_slot(bwd, SLOT_WS2, plan['ws2'].data_ptr())
         return plan
+
+    def _stem_bwd_fused(self, v, s):
+        """The one-pass backward of the first block applies: fp16 step, 3x3 / stride 1 / pad 1 on a 1- or 3-channel image, 16 or
+        32 output channels, BatchNorm + activation, nothing fused into its store (YOLO_HIP_STEM_BWD=0: the four-launch form)."""
+        if os.environ.get('YOLO_HIP_STEM_BWD', '1') == '0':
+            return False
+        return (self.code == hiplib.YH_F16 and v.bn is not None and v.k == 3 and v.stride == 1 and v.pad == 1 and s.C in (1, 3)
+                and v.c_phys in (16, 32) and v.C == v.c_phys and v.ups == 1 and v.res is None and v.conv.bias is None)
 
     @staticmethod
     def _junk(plan, grads, n):
