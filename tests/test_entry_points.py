@@ -101,15 +101,15 @@ def test_terminaltables_shim_and_star_imports():
 @pytest.mark.gpu
 @pytest.mark.parametrize('device_augment', [False, True], ids=['host_loader', 'device_augment'])
 def test_train_and_test_on_the_gpu_path(dataset_dir, tiny_cfg, tmp_path, monkeypatch, device_augment):
-    """train.py (mixed precision) + test.test on a GPU: the HIP training and inference paths behind the entry points; with
-    --device-augment the items reach the loop as recipes and are rendered by yh_mosaic_affine_hsv."""
+    """train.py (mixed precision) + test.test on a GPU: the HIP training and inference paths behind the entry points; by default
+    (device augmentation; --host-augment switches it off) the items reach the loop as recipes and are rendered by yh_mosaic_affine_hsv."""
     if not torch.cuda.is_available():
         pytest.skip('no GPU')
     monkeypatch.chdir(tmp_path)
     import train as train_mod
     import test as test_mod
     opt = train_mod.make_parser().parse_args(['--epochs', '2', '--batch-size', '4', '--cfg', tiny_cfg, '--data', str(dataset_dir / 'synth.data'),
-                                              '--img-size', '64', '64', '64', '-mpt', '--nosave'] + (['--device-augment'] if device_augment else []))
+                                              '--img-size', '64', '64', '64', '-mpt', '--nosave'] + ([] if device_augment else ['--host-augment']))
     opt.local_rank = -1
     results = train_mod.train(opt, train_mod.hyp)
     assert len(results) == 7 and all(np.isfinite(results))

@@ -133,6 +133,15 @@ CONV_CASES = [
     (2, 29, 30, 32, 64, 3, 2, 1, True, 1, False, 72, 32, 64),       # x and y are channel slices, residual
     (5, 7, 5, 32, 64, 3, 1, 1, False, 1, False, 72, 0, 0),          # tiny images: a block spans several; fewer blocks than waves
     (1, 3, 5, 32, 32, 3, 1, 1, False, 1, False, 72, 0, 0),          # 15 pixels: less than one block
+    # persistent 1x1 kernel with the weights in LDS (tile 73): every (MT, KS, MS) form, residual, pixel tails, channel-slice operands
+    (3, 37, 41, 256, 128, 1, 1, 1, False, 1, False, 73, 0, 0),       # (8, 8, 1): 76^2 forward shape, leaky + folded BN
+    (2, 45, 43, 128, 256, 1, 1, 0, True, 1, False, 73, 0, 0),        # (8, 4, 2): 76^2 data gradient shape: wave pairs, residual, linear
+    (2, 33, 31, 64, 32, 1, 1, 5, False, 1, False, 73, 0, 0),         # (2, 2, 1) mish
+    (2, 29, 30, 32, 64, 1, 1, 0, True, 1, False, 73, 32, 64),        # (4, 1, 1) x and y are channel slices, residual
+    (5, 7, 5, 128, 64, 1, 1, 1, True, 1, False, 73, 0, 0),           # (4, 4, 1) fewer blocks than waves
+    (1, 3, 5, 64, 128, 1, 1, 1, False, 1, False, 73, 0, 0),          # (8, 2, 1) 15 pixels: less than one block
+    (2, 20, 21, 128, 128, 1, 1, 1, True, 1, False, 73, 0, 0),        # (8, 4, 1)
+    (2, 20, 21, 64, 64, 1, 1, 1, False, 1, False, 73, 0, 0),         # (4, 2, 1)
 ]
 
 
@@ -141,7 +150,7 @@ CONV_CASES = [
 def test_conv_matches_emulation(libs, code, case):
     lib, fake = libs
     N, H, W, cin, cout, k, s, act, use_res, ups, out_f32, tile, xe, ye = case
-    if code == F32 and (61 <= tile <= 69 or tile in (71, 72) or tile == 43):
+    if code == F32 and (61 <= tile <= 69 or tile in (71, 72, 73) or tile == 43):
         pytest.skip('the full-line K step kernels and the streaming 1x1 kernel are fp16 / int8 kernels')
     g = torch.Generator().manual_seed(hash(case) % (2 ** 31))
     dt = oh.tdtype(code)
@@ -178,6 +187,26 @@ def test_conv_matches_emulation(libs, code, case):
     tol = 2e-5 if (code == F32) else (2e-4 if out_f32 else 2.5e-3)
     err = (yg - yc).abs().max().item()
     assert err <= tol * scale, 'max err %g (scale %g)' % (err, scale)
+
+
+@pytest.mark.parametrize('case', [(3, 37, 41, 256, 128, False, 1), (2, 45, 43, 128, 256, True, 0), (2, 29, 30, 64, 32, True, 5)],
+                         ids=['256-128', '128-256_res', '64-32_res_mish'])
+def test_lds_weights_1x1_kernel_is_bit_identical_to_the_ring_kernel(libs, case):
+    """Tile 73 promises the ring kernels' epilogue arithmetic operation for operation (fp32 bias + activation + residual, ONE rounding):
+    on random operands its output equals the ring kernel's bit for bit (only the store path differs)."""
+    lib, _ = libs
+    N, H, W, cin, cout, use_res, act = case
+    g = torch.Generator().manual_seed(cin * 3 + cout)
+    w = _rand(g, cout, cin, 1, 1, scale=cin ** -0.5).to(GPU)
+    bn = tuple(t.to(GPU) for t in _bn(g, cout)) if act != 0 else None
+    cb = None if bn is not None else _rand(g, cout).to(GPU)
+    x = _rand(g, N, H, W, cin).half().to(GPU)
+    res = _rand(g, N, H, W, cout).half().to(GPU) if use_res else None
+    packed, bias, cin_k, m_pad = oh.pack_conv(lib, F16, w, cb, bn, cin_phys=cin)
+    ys = [oh.conv(lib, F16, x, packed, bias, cin_k, m_pad, cout, 1, 1, 0, act=act, res=res, tile=t).clone() for t in (21, 73)]
+    if GPU == 'cuda':
+        torch.cuda.synchronize()
+    assert torch.equal(ys[0], ys[1])
 
 
 @pytest.mark.parametrize('tile', [0, 43], ids=['auto', 'halo_pp'])

@@ -409,13 +409,16 @@ def test_maxpool_backward_matches_autograd(libs, code, case):
                                   (2, 26, 26, 128, 256, 3, 1, 43), (5, 9, 7, 64, 128, 3, 1, 43), (1, 76, 76, 32, 192, 3, 1, 43),
                                   # streaming 3x3 kernel: one row per wave of the launch, the tail's repeated last pixel counts once
                                   (3, 37, 41, 32, 64, 3, 1, 72), (2, 45, 43, 32, 64, 3, 2, 72), (2, 33, 31, 32, 32, 3, 1, 72),
-                                  (1, 3, 5, 32, 32, 3, 1, 72)],
+                                  (1, 3, 5, 32, 32, 3, 1, 72),
+                                  # persistent LDS-weights 1x1 kernel: one row per pixel stream (a wave, or the wave pair of a 256-channel layer)
+                                  (3, 37, 41, 256, 128, 1, 1, 73), (2, 45, 43, 64, 32, 1, 1, 73), (2, 33, 31, 128, 256, 1, 1, 73),
+                                  (1, 3, 5, 128, 64, 1, 1, 73)],
                          ids=lambda c: 'n%d_%dx%d_c%d-%d_k%ds%d_t%d' % c)
 def test_conv_epilogue_batch_statistics(libs, code, case):
     """Training forward: the conv epilogue's partial sums + yh_bn_finalize(nparts) == statistics of the stored output."""
     lib, _ = libs
     N, H, W, cin, cout, k, s, tile = case
-    if code == F32 and tile in (43, 72):
+    if code == F32 and tile in (43, 72, 73):
         pytest.skip('fp16 / int8 kernel')
     g = torch.Generator().manual_seed(hash(case) % (2 ** 31))
     dt = oh.tdtype(code)

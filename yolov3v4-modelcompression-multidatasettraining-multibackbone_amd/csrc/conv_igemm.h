@@ -446,6 +446,12 @@ int launch_k64_tile(const ConvArgs& a, int tile, int dtype, int out_f32, hipStre
 int launch_pointwise_tile(const ConvArgs& a, int dtype, int out_f32, hipStream_t stream);   // conv_pointwise.hip, tile code 71
 int launch_stream3_tile(const ConvArgs& a, int dtype, hipStream_t stream);                    // conv_stream3.hip, tile code 72
 long stream3_stats_rows(long P, int cout);                                                       // its statistics rows: one per wave
+// conv_pw_lds.hip, tile code 73: 1x1 / s1 with the whole weight matrix (<= 64 KB, Cout <= 256, Cin <= 256) resident in LDS; f16,
+// plain / residual / statistics forms
+int launch_pwl_tile(const ConvArgs& a, hipStream_t stream);
+bool pwl_supported(int dtype, int out_f32, int cin, int cin_k, int cout, long P, int ldx, int ldy, int ldr, const void* x, const void* y,
+                   const void* res, bool stats);
+long pwl_stats_rows(long P, int cout);                                                          // one row per pixel stream
 // conv_halo_pp.hip, tile code 43: 3x3 / s1 / p1, 128 channels x 512 virtual pixels; f16 and int8, output type = input type
 int launch_hpp_tile(const ConvArgs& a, int dtype, hipStream_t stream);
 bool hpp_geometry(int W, int cin_k, int bk, int* rows_hp, int* lb, int* hbufs, size_t* lds);

@@ -1011,10 +1011,24 @@ static bool pick_stream3_tile(const yh_conv_desc* d) {
     return !off && stream3_supported(d) && (long)d->n * d->ho * d->wo >= 262144;
 }
 
+// The persistent LDS-resident-weights 1x1 kernel (conv_pw_lds.hip): byte-bound 1x1 layers on large grids, forward (with BatchNorm
+// statistics) and data gradient (with the residual accumulate) alike.
+static bool pwl_desc_supported(const yh_conv_desc* d) {
+    if (d->kh != 1 || d->kw != 1 || d->stride != 1 || d->pad != 0 || d->ups != 1) return false;
+    if (d->act != YH_ACT_LINEAR && d->act != YH_ACT_LEAKY && d->act != YH_ACT_MISH) return false;
+    return yh::pwl_supported(d->dtype, d->out_f32, d->cin, d->cin_k, d->cout, (long)d->n * d->ho * d->wo, d->ldx, d->ldy, d->ldr, d->x, d->y,
+                             d->res, d->stats_ws != nullptr);
+}
+static bool pick_pwl_tile(const yh_conv_desc* d) {
+    static const bool off = getenv("YH_NO_PWL") != nullptr;
+    return !off && pwl_desc_supported(d) && (long)d->n * d->ho * d->wo >= 262144;
+}
+
 extern "C" int yh_conv2d_tile(const yh_conv_desc* d) {
     if (!d) return YH_EINVAL;
     if (d->tile != 0) return d->tile;
     if (pick_pointwise_tile(d)) return 71;
+    if (pick_pwl_tile(d)) return 73;
     if (pick_stream3_tile(d)) return 72;
     if (pick_hpp_tile(d)) return 43;
     if (pick_halo_tile(d)) return 41;
@@ -1047,6 +1061,7 @@ extern "C" int64_t yh_conv2d_stats_rows(const yh_conv_desc* d) {
     if (!q.stats_ws) q.stats_ws = reinterpret_cast<float*>(sizeof(float));
     const int tile = yh_conv2d_tile(&q);
     if (tile == 72) return (int64_t)yh::stream3_stats_rows((long)d->n * d->ho * d->wo, d->cout);       // one row per wave of the launch
+    if (tile == 73) return (int64_t)yh::pwl_stats_rows((long)d->n * d->ho * d->wo, d->cout);            // one row per pixel stream
     if (tile == 43)   // halo ping-pong kernel: 512 VIRTUAL pixels (one shared pad row / column) per tile, one row per wave
         return (int64_t)(((long)d->n * (d->h + 1) * (d->w_in + 1) + 511) / 512) * 8;
     if (!tile_geometry(tile, &bn, &wn)) return 0;
@@ -1124,6 +1139,10 @@ extern "C" int yh_conv2d_fwd(const yh_conv_desc* d, void* stream) {
     if (tile == 72) {
         if (!stream3_supported(d)) return YH_EUNSUPPORTED;
         return launch_stream3_tile(a, d->dtype, s);
+    }
+    if (tile == 73) {
+        if (!pwl_desc_supported(d)) return YH_EUNSUPPORTED;
+        return launch_pwl_tile(a, s);
     }
     if (d->dtype == YH_F16) {
         return d->out_f32 ? dispatch_tile<f16, float>(a, tile, s) : dispatch_tile<f16, f16>(a, tile, s);

@@ -1,0 +1,259 @@
+// 1x1 convolutions whose whole weight matrix fits in LDS, as a PERSISTENT streaming kernel (tile code 73; round 4).
+//
+// Why: the 1x1 layers of Darknet-53 at 304^2 / 152^2 / 76^2 (64 <-> 32, 128 <-> 64, 256 <-> 128 channels; forward AND data gradient, the
+// latter with its residual accumulate) are byte-bound - 85 .. 170 FLOP per byte - and ran at 3.1 - 3.9 TB/s on the ring kernels: a
+// 256 x 128 tile lives for 4 - 8 K steps, so ring fill, first-tile latency and the epilogue are ~40 % of a workgroup's life, and two
+// workgroups per CU only partly cover each other (profiles/r03_train_layers_final.txt: 9.8 ms of the
+// 56 ms step).  conv_pointwise.hip removed that for Cout x Cin <= 128 x 32 .. 32 x 128 (weights in registers).  Here the weights
+// (<= 64 KB) sit in LDS as ready-made MFMA A fragments, one workgroup per CU stays resident, and every wave streams over 32-pixel
+// blocks:
+//   * B fragments straight from global memory in MFMA layout (16 bytes of one pixel row per lane), refilled with the NEXT block's
+//     bytes as soon as a K step's MFMAs have consumed them - one block of distance between a load and its use, straight-line code
+//     (tails re-load the last block: a branch around a load would reset the compiler's counted waits, DESIGN.md "Toolchain facts");
+//   * A fragments by one conflict-free ds_read_b128 each (MT per K step for 2 MT MFMAs);
+//   * epilogue through a per-wave LDS tile so that loads and stores are whole pixel rows (16 bytes per lane, consecutive lanes on
+//     consecutive units): the NEXT block's residual rows are loaded before this block's stores are issued (one in-order vmcnt queue),
+//     parked in the tile, added in fp32 to the un-rounded accumulator and rounded ONCE - bit-identical to the ring kernels' epilogue
+//     (conv_igemm.h conv_epilogue_plain), bias + activation included;
+//   * training forward: BatchNorm partial sums of the values as stored, per lane over all of a wave's blocks (a lane always owns the
+//     same 8 channels in the row-major pass), one partial row per pixel stream.
+// Cout up to 256: MS = 2 waves share a pixel stream, each computing 128 of the output channels from the same B rows (the second
+// wave's loads hit L1 / L2).  fp16 only; int8 1x1 layers stay on conv_pointwise.hip / the ring kernels.
+#include "conv_igemm.h"
+
+namespace yh {
+
+// MT: 16-channel row groups per wave (<= 8); KS: K steps of 32 input channels; MS: waves per pixel stream (channel split);
+// MODE 0 plain, 1 residual, 2 statistics
+template <int MT, int KS, int MS, int ACT, int MODE>
+__global__ __launch_bounds__(512, 2) void conv1x1_lds_kernel(const ConvArgs a, const int nblocks) {
+    constexpr int NW = 8, TN = 2, BP = TN * 16;               // 8 waves; 32 pixels per block
+    constexpr int ROWB = MT * 32;                             // bytes of this wave's channels in one pixel row
+    constexpr int PITCH = ROWB + 16;                          // staging tile pitch (bank spread)
+    constexpr int UNITS = ROWB / 16;                          // 16-byte units per pixel row of the wave's channel range
+    constexpr int RPI = 64 / UNITS;                           // pixel rows per row-major pass instruction
+    constexpr int NPASS = BP / RPI;                           // row-major instructions per block
+    constexpr int W_BYTES = MS * MT * KS * 1024;              // A fragments: [MS * MT][KS][64 lanes][16 B]
+    constexpr int BIAS_BYTES = MS * MT * 16 * 4;
+    extern __shared__ __attribute__((aligned(16))) unsigned char pl_smem[];
+    unsigned char* const wl = pl_smem;
+    float* const bl = reinterpret_cast<float*>(pl_smem + W_BYTES);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    unsigned char* const tile = pl_smem + W_BYTES + BIAS_BYTES + wave * (BP * PITCH);
+    const int pc = lane & 15, kq = lane >> 4, mq = kq << 2;
+    const f16* const xg = reinterpret_cast<const f16*>(a.x);
+    const f16* const rg = reinterpret_cast<const f16*>(a.res);
+    f16* const yg = reinterpret_cast<f16*>(a.y);
+
+    // ---- weights -> LDS as A fragments (fragment f = (row group, k step): lane (pc, kq) holds W[16 rg + pc][32 k + 8 kq .. +7])
+    {
+        const f16* const wg = reinterpret_cast<const f16*>(a.w);
+        for (int f = wave; f < MS * MT * KS; f += NW) {
+            const int rgp = f / KS, k = f - rgp * KS;
+            const u32x4 v = *reinterpret_cast<const u32x4*>(wg + (long)(rgp * 16 + pc) * a.cin_k + k * 32 + kq * 8);
+            *reinterpret_cast<u32x4*>(wl + (f * 64 + lane) * 16) = v;
+        }
+        for (int m = tid; m < MS * MT * 16; m += NW * 64) bl[m] = m < a.Cout ? a.bias[m] : 0.f;
+    }
+    __syncthreads();
+
+    const int half = wave % MS;                               // which MT x 16 channels of the output this wave computes
+    const int stream = (blockIdx.x * NW + wave) / MS, nstreams = gridDim.x * NW / MS;
+    const int ch0 = half * MT * 16;
+    const unsigned char* const wl_h = wl + half * (MT * KS * 1024) + lane * 16;
+    const float* const bl_h = bl + ch0 + mq;
+
+    // row-major pass geometry: lane -> (pixel row rr + RPI * pass, 16-byte unit cu) of the wave's channel range
+    const int cu = lane % UNITS, rr = lane / UNITS;
+    float s1[8], s2[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s1[e] = s2[e] = 0.f;
+
+    f16x8 fb[TN][KS];
+    u32x4 rv[NPASS];
+    auto load_b = [&](int blk, int k) {       // K step k of block blk (clamped: a tail re-loads valid bytes that are never stored)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            long p = (long)blk * BP + j * 16 + pc;
+            p = p < a.P ? p : a.P - 1;
+            fb[j][k] = *reinterpret_cast<const f16x8*>(xg + p * a.ldx + k * 32 + kq * 8);
+        }
+    };
+    auto load_res = [&](int blk) {
+#pragma unroll
+        for (int q = 0; q < NPASS; ++q) {
+            long p = (long)blk * BP + rr + q * RPI;
+            p = p < a.P ? p : a.P - 1;
+            rv[q] = *reinterpret_cast<const u32x4*>(rg + p * a.ldr + ch0 + cu * 8);
+        }
+    };
+
+    int blk = stream;
+    if (blk < nblocks) {
+#pragma unroll
+        for (int k = 0; k < KS; ++k) load_b(blk, k);
+        if constexpr (MODE == 1) load_res(blk);
+    }
+    for (; blk < nblocks; blk += nstreams) {
+        const int nb = blk + nstreams < nblocks ? blk + nstreams : blk;     // past the end: this block again (unused)
+        if constexpr (MODE == 1) {
+            // park this block's residual rows in the staging tile (row-major 16-byte units), then fetch the next block's
+#pragma unroll
+            for (int q = 0; q < NPASS; ++q) *reinterpret_cast<u32x4*>(tile + (rr + q * RPI) * PITCH + cu * 16) = rv[q];
+        }
+        f32x4 acc[MT][TN];
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < KS; ++k) {
+            f16x8 wa[MT];
+#pragma unroll
+            for (int i = 0; i < MT; ++i) wa[i] = *reinterpret_cast<const f16x8*>(wl_h + (i * KS + k) * 1024);
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[i], fb[j][k], acc[i][j], 0, 0, 0);
+            load_b(nb, k);                     // refill: the next block's bytes for this K step
+        }
+        if constexpr (MODE == 1) load_res(nb);  // before this block's stores: loads and stores share one in-order queue
+        __builtin_amdgcn_wave_barrier();
+        // ---- phase 1: bias + activation (+ residual from the tile, fp32, one rounding) -> the tile, 4 channels of one pixel per lane
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(bl_h + i * 16);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                f16* const cell = reinterpret_cast<f16*>(tile + (j * 16 + pc) * PITCH) + i * 16 + mq;
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = activate_c<ACT>(acc[i][j][e] + bv[e], a.slope);
+                if constexpr (MODE == 1) {
+                    const f16x4 r = *reinterpret_cast<const f16x4*>(cell);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] += (float)r[e];
+                }
+                store4<f16>(cell, v[0], v[1], v[2], v[3]);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        // ---- phase 2: whole pixel rows to global memory
+        const long p0 = (long)blk * BP;
+#pragma unroll
+        for (int q = 0; q < NPASS; ++q) {
+            const int row = rr + q * RPI;
+            const u32x4 v = *reinterpret_cast<const u32x4*>(tile + row * PITCH + cu * 16);
+            const bool ok = p0 + row < a.P;
+            if (ok) *reinterpret_cast<u32x4*>(yg + (p0 + row) * a.ldy + ch0 + cu * 8) = v;
+            if constexpr (MODE == 2) {
+                const f16x8 h = __builtin_bit_cast(f16x8, v);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float f = ok ? (float)h[e] : 0.f;
+                    s1[e] += f;
+                    s2[e] = fmaf(f, f, s2[e]);
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    if constexpr (MODE == 2) {
+        // one partial row per pixel stream: [sum | sum of squares][Cout]; the RPI lanes that share a channel unit add up first
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+#pragma unroll
+            for (int m = UNITS; m < 64; m <<= 1) {
+                s1[e] += __shfl_xor(s1[e], m);
+                s2[e] += __shfl_xor(s2[e], m);
+            }
+        if (lane < UNITS) {
+            float* const row = a.stats_part + (long)stream * 2 * a.Cout + ch0 + cu * 8;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                row[e] = s1[e];
+                row[a.Cout + e] = s2[e];
+            }
+        }
+    }
+}
+
+// (MT, KS, MS) of a layer, or false: Cout = 16 MT MS exactly, Cin = 32 KS, weights <= 64 KB, MT <= 8
+static bool pwl_shape(int cin_k, int cout, int* mt, int* ks, int* ms) {
+    if (cin_k % 32 || cout % 16 || cout < 32 || cout > 256 || cin_k < 32 || cin_k > 256) return false;
+    *ms = cout > 128 ? 2 : 1;
+    if (cout % (16 * *ms)) return false;
+    *mt = cout / (16 * *ms);
+    *ks = cin_k / 32;
+    if (*mt > 8 || (*mt != 2 && *mt != 4 && *mt != 8) || (*ks != 1 && *ks != 2 && *ks != 4 && *ks != 8)) return false;
+    return (long)cout * cin_k * 2 <= 64 * 1024;
+}
+
+static int pwl_grid(long P, int ms, int* nblocks) {
+    *nblocks = (int)((P + 31) / 32);
+    long wgs = ((long)*nblocks * ms + 7) / 8;
+    if (wgs > 256) wgs = 256;                    // one resident workgroup per CU
+    return (int)(wgs < 1 ? 1 : wgs);
+}
+
+bool pwl_supported(int dtype, int out_f32, int cin, int cin_k, int cout, long P, int ldx, int ldy, int ldr, const void* x, const void* y,
+                   const void* res, bool stats) {
+    int mt, ks, ms;
+    if (dtype != YH_F16 || out_f32 || cin != cin_k || !pwl_shape(cin_k, cout, &mt, &ks, &ms)) return false;
+    if (stats && res) return false;
+    if (ldx % 8 || ldy % 8 || (res && ldr % 8) || !aligned16(x) || !aligned16(y) || (res && !aligned16(res))) return false;
+    return P > 0 && P < (1L << 31) - 64;
+}
+
+long pwl_stats_rows(long P, int cout) {
+    int nblocks;
+    const int ms = cout > 128 ? 2 : 1;
+    return (long)pwl_grid(P, ms, &nblocks) * 8 / ms;
+}
+
+template <int MT, int KS, int MS, int ACT> static int launch_pwl_mode(const ConvArgs& a, hipStream_t s) {
+    int nblocks;
+    const int grid = pwl_grid(a.P, MS, &nblocks);
+    const size_t lds = (size_t)MS * MT * KS * 1024 + (size_t)MS * MT * 16 * 4 + (size_t)8 * 32 * (MT * 32 + 16);
+#define YH_PWL_GO(MODE)                                                                                       \
+    do {                                                                                                      \
+        auto kern = conv1x1_lds_kernel<MT, KS, MS, ACT, MODE>;                                                \
+        const hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds);                    \
+        if (e != hipSuccess) return (int)e;                                                                   \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, s, a, nblocks);                                  \
+    } while (0)
+    if (a.stats_part) YH_PWL_GO(2);
+    else if (a.res) YH_PWL_GO(1);
+    else YH_PWL_GO(0);
+#undef YH_PWL_GO
+    return check_launch();
+}
+
+template <int MT, int KS, int MS> static int launch_pwl_act(const ConvArgs& a, hipStream_t s) {
+    switch (a.act) {
+        case YH_ACT_LINEAR: return launch_pwl_mode<MT, KS, MS, YH_ACT_LINEAR>(a, s);
+        case YH_ACT_LEAKY: return launch_pwl_mode<MT, KS, MS, YH_ACT_LEAKY>(a, s);
+        case YH_ACT_MISH: return launch_pwl_mode<MT, KS, MS, YH_ACT_MISH>(a, s);
+        default: return YH_EUNSUPPORTED;
+    }
+}
+
+// tile code 73 (conv_igemm.hip yh_conv2d_tile)
+int launch_pwl_tile(const ConvArgs& a, hipStream_t s) {
+    int mt, ks, ms;
+    if (!pwl_shape(a.cin_k, a.Cout, &mt, &ks, &ms)) return YH_EUNSUPPORTED;
+#define YH_PWL_CASE(M, K, S2) if (mt == M && ks == K && ms == S2) return launch_pwl_act<M, K, S2>(a, s)
+    YH_PWL_CASE(2, 2, 1);    //  64 ->  32   (304^2 forward)
+    YH_PWL_CASE(4, 1, 1);    //  32 ->  64   (304^2 data gradient)
+    YH_PWL_CASE(4, 4, 1);    // 128 ->  64   (152^2 forward)
+    YH_PWL_CASE(8, 2, 1);    //  64 -> 128   (152^2 data gradient)
+    YH_PWL_CASE(8, 8, 1);    // 256 -> 128   (76^2 forward)
+    YH_PWL_CASE(8, 4, 2);    // 128 -> 256   (76^2 data gradient)
+    YH_PWL_CASE(8, 4, 1);    // 128 -> 128   (YOLOv4 CSP stages)
+    YH_PWL_CASE(4, 2, 1);    //  64 ->  64
+#undef YH_PWL_CASE
+    return YH_EUNSUPPORTED;
+}
+
+}  // namespace yh

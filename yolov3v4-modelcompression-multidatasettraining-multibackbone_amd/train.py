@@ -186,10 +186,13 @@ def train(opt, hyp):
             model.register_comm_hook(None, default_hooks.fp16_compress_hook)
         model.yolo_layers = core.yolo_layers
 
-    # --device-augment: items arrive as recipes (cropped source frames + geometry + gains) and one HIP kernel per item does the
-    # mosaic, warp, HSV, flip, transpose and /256 on the GPU (engine/preprocess.py render_mosaic_items, csrc/augment.hip)
+    # Device augmentation (the default on a GPU; --host-augment restores the host loader): items arrive as recipes (cropped source
+    # frames + geometry + gains) and one HIP kernel per item does the mosaic, warp, HSV, flip, transpose and /256 on the GPU
+    # (engine/preprocess.py render_mosaic_items, csrc/augment.hip) - bit-identical to the host items (tests/test_augment.py), at
+    # 0.2 ms instead of 49 ms of a host core per item, which is what an 8-GPU node needs to be fed
+    device_augment = device.type == 'cuda' and not getattr(opt, 'host_augment', False)
     dataset = LoadImagesAndLabels(train_path, img_size, batch_size, augment=True, hyp=hyp, rect=opt.rect, cache_images=opt.cache_images,
-                                  rank=rank, is_gray_scale=opt.gray_scale, device_augment=opt.device_augment and device.type == 'cuda',
+                                  rank=rank, is_gray_scale=opt.gray_scale, device_augment=device_augment,
                                   arith=getattr(opt, 'image_arith', None))
     nw = min([os.cpu_count() or 1, batch_size if batch_size > 1 else 0, 8])
     sampler = torch.utils.data.distributed.DistributedSampler(dataset) if distributed else None
@@ -361,7 +364,9 @@ def make_parser():
     parser.add_argument('--notest', action='store_true', help='only test final epoch')
     parser.add_argument('--cache-images', action='store_true', help='cache images for faster training')
     parser.add_argument('--device-augment', action='store_true',
-                        help='mosaic / affine / HSV / flip of the training items on the GPU (same random streams, same pixels as the host loader)')
+                        help='(default on a GPU; kept for command lines of earlier rounds) mosaic / affine / HSV / flip of the training '
+                             'items on the GPU: same random streams, same pixels as the host loader')
+    parser.add_argument('--host-augment', action='store_true', help='augment the training items on the host cores even when training on a GPU')
     parser.add_argument('--image-arith', choices=['pillow', 'cv2'], default=None,
                         help="uint8 arithmetic of the device input pipeline: 'pillow' = this package's host loader, 'cv2' = the reference's "
                              "OpenCV calls restated (GPU only: needs --device-augment); default: $YOLO_IMAGE_ARITH or pillow")
