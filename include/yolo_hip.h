@@ -502,6 +502,14 @@ typedef struct yh_stem_bwd_desc {
     int64_t ws_floats;
     int32_t n, cin, h, w_in, cout, lddy, ldz, act;
     float slope;
+    /* Optional: the data gradient of the NEXT conv fused in (dz1 != NULL; then `dy` is not read at all).  When the first block's
+     * output has exactly one consumer and that consumer is a 3x3 / stride 2 / pad 1 conv with 64 output channels (Darknet-53's
+     * conv1, CSPDarknet53's conv1), dy = conv_transpose(dz1, w1) is computed per 32-pixel segment from the 1 or 2 rows of dz1 it
+     * depends on (12 or 24 MFMAs) instead of being written by yh_conv2d_fwd(ups = 4) and read back: 1.5 GB less to write and 1.5 GB
+     * less to read at 608 x 608 x 32 x batch 64 (reference: autograd through models.py:92-113 of blocks 0 and 1).  cout must be 32. */
+    const void* dz1;        /* gradient of the next conv's output, NHWC f16 [n][h1][w1][k1 = 64], pitch lddz1      */
+    const void* w1;         /* its weights as yh_conv_pack_weights_dgrad packs them: [m1_pad rows >= cout][9 flipped taps][k1_pad] f16 */
+    int32_t h1, w1_in, k1, k1_pad, lddz1;
 } yh_stem_bwd_desc;
 int64_t yh_stem_bwd_workspace(const yh_stem_bwd_desc* d);
 int yh_stem_bwd(const yh_stem_bwd_desc* d, void* stream);

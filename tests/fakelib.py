@@ -634,7 +634,18 @@ class FakeLib:
         ld = lambda p: torch.from_numpy(flat(p, c, np.float32).copy())
         gamma, beta, mu, istd = ld(d.gamma), ld(d.beta), ld(d.mean), ld(d.invstd)
         z = torch.from_numpy(pitched(d.z, P, c, d.ldz, np.float16).astype(np.float32))
-        dy = torch.from_numpy(pitched(d.dy, P, c, d.lddy, np.float16).astype(np.float32))
+        if _addr(d.dz1):
+            # the next conv's data gradient fused in: dy = conv_transpose(dz1, W1) (3x3 / s2 / p1), rounded to f16 as the launch
+            # of its own would have stored it; W1[k][c][r][s] = image[c][2 - r][2 - s][k] (yh_conv_pack_weights_dgrad layout)
+            assert c == 32 and d.k1 == 64 and d.h1 == (d.h - 1) // 2 + 1 and d.w1_in == (d.w_in - 1) // 2 + 1
+            img = torch.from_numpy(flat(d.w1, c * 9 * d.k1_pad, np.float16).astype(np.float32)).view(c, 3, 3, d.k1_pad)[..., :d.k1]
+            w1 = img.flip(1, 2).permute(3, 0, 1, 2).contiguous()                      # [k][c][r][s]
+            dz1 = torch.from_numpy(pitched(d.dz1, d.n * d.h1 * d.w1_in, d.k1, d.lddz1, np.float16).astype(np.float32))
+            dz1 = dz1.view(d.n, d.h1, d.w1_in, d.k1).permute(0, 3, 1, 2)
+            op = (d.h - (2 * (d.h1 - 1) + 1), d.w_in - (2 * (d.w1_in - 1) + 1))
+            dy = F.conv_transpose2d(dz1, w1, stride=2, padding=1, output_padding=op).permute(0, 2, 3, 1).reshape(P, c).half().float()
+        else:
+            dy = torch.from_numpy(pitched(d.dy, P, c, d.lddy, np.float16).astype(np.float32))
         xh = (z - mu) * istd
         g = dy * self._act_grad(gamma * xh + beta, d.act, d.slope)
         s1, s2 = g.double().sum(0), (g * xh).double().sum(0)

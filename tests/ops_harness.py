@@ -364,8 +364,9 @@ def stem_wgrad_mfma(lib, code, x, dz, cout, stride=1, pad=1):
     return dw, img
 
 
-def stem_bwd(lib, x, dy, z, gamma, beta, mean, invstd, act=1, slope=0.1):
-    """yh_stem_bwd on x (N,cin,H,W) fp32, dy / z (N,H,W,ld) f16: returns (dw [c][cin][3][3], dgamma, dbeta), all fp32."""
+def stem_bwd(lib, x, dy, z, gamma, beta, mean, invstd, act=1, slope=0.1, dz1=None, w1=None):
+    """yh_stem_bwd on x (N,cin,H,W) fp32, dy / z (N,H,W,ld) f16: returns (dw [c][cin][3][3], dgamma, dbeta), all fp32.
+    With dz1 (N,H1,W1,ld1) f16 and w1 (64,32,3,3) fp32 the next conv's data gradient is fused in and dy is ignored."""
     from engine.hiplib import StemBwdDesc
     N, cin, H, W = x.shape
     c = gamma.numel()
@@ -373,7 +374,15 @@ def stem_bwd(lib, x, dy, z, gamma, beta, mean, invstd, act=1, slope=0.1):
     dw = torch.zeros(c, cin, 3, 3, device=dev)
     dg, db = torch.zeros(c, device=dev), torch.zeros(c, device=dev)
     d = StemBwdDesc(x=P(x), dy=P(dy), z=P(z), gamma=P(gamma), beta=P(beta), mean=P(mean), invstd=P(invstd), dgamma=P(dg), dbeta=P(db),
-                    dw=P(dw), n=N, cin=cin, h=H, w_in=W, cout=c, lddy=dy.shape[3], ldz=z.shape[3], act=act, slope=slope)
+                    dw=P(dw), n=N, cin=cin, h=H, w_in=W, cout=c, lddy=0 if dy is None else dy.shape[3], ldz=z.shape[3], act=act, slope=slope)
+    keep = None
+    if dz1 is not None:
+        k1 = w1.shape[0]
+        img = torch.zeros(128 * 9 * k1, device=dev, dtype=torch.float16)
+        rc = lib.yh_conv_pack_weights_dgrad(hiplib.YH_F16, P(w1), k1, c, 3, 3, k1, 128, P(img), stream())
+        assert rc == 0, rc
+        d.dz1, d.w1, d.h1, d.w1_in, d.k1, d.k1_pad, d.lddz1 = P(dz1), P(img), dz1.shape[1], dz1.shape[2], k1, k1, dz1.shape[3]
+        keep = img
     need = int(lib.yh_stem_bwd_workspace(C.byref(d)))
     assert need > 0
     ws = torch.full((need,), float('nan'), device=dev)

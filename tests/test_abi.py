@@ -35,7 +35,8 @@ def test_struct_layout_matches_c_compiler(tmp_path):
     structs = {'yh_conv_desc': hiplib.ConvDesc, 'yh_stem_desc': hiplib.StemDesc, 'yh_pool_desc': hiplib.PoolDesc,
                'yh_copy_desc': hiplib.CopyDesc, 'yh_add_desc': hiplib.AddDesc, 'yh_decode_desc': hiplib.DecodeDesc,
                'yh_dw_desc': hiplib.DwDesc, 'yh_se_desc': hiplib.SeDesc, 'yh_qcopy_desc': hiplib.QCopyDesc,
-               'yh_qadd_desc': hiplib.QAddDesc, 'yh_letterbox_desc': hiplib.LetterboxDesc, 'yh_mosaic_desc': hiplib.MosaicDesc}
+               'yh_qadd_desc': hiplib.QAddDesc, 'yh_letterbox_desc': hiplib.LetterboxDesc, 'yh_mosaic_desc': hiplib.MosaicDesc,
+               'yh_stem_bwd_desc': hiplib.StemBwdDesc, 'yh_wgrad_desc': hiplib.WgradDesc, 'yh_bn_desc': hiplib.BnDesc}
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "yolo_hip.h"', 'int main(void){']
     for cname, cls in structs.items():
         lines.append('printf("%s %%zu\\n", sizeof(%s));' % (cname, cname))

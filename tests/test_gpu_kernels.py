@@ -133,6 +133,9 @@ CONV_CASES = [
     (2, 29, 30, 32, 64, 3, 2, 1, True, 1, False, 72, 32, 64),       # x and y are channel slices, residual
     (5, 7, 5, 32, 64, 3, 1, 1, False, 1, False, 72, 0, 0),          # tiny images: a block spans several; fewer blocks than waves
     (1, 3, 5, 32, 32, 3, 1, 1, False, 1, False, 72, 0, 0),          # 15 pixels: less than one block
+    (3, 37, 41, 64, 32, 3, 1, 0, False, 1, False, 72, 0, 0),        # two K steps per tap (64 -> 32: conv3's data gradient), linear
+    (2, 29, 30, 64, 32, 3, 1, 1, True, 1, False, 72, 64, 32),       # the same with residual, leaky, channel-slice operands
+    (2, 21, 19, 48, 32, 3, 2, 5, False, 1, False, 72, 0, 0),        # cin 48: channel tail inside the second K step, stride 2, mish
     # persistent 1x1 kernel with the weights in LDS (tile 73): every (MT, KS, MS) form, residual, pixel tails, channel-slice operands
     (3, 37, 41, 256, 128, 1, 1, 1, False, 1, False, 73, 0, 0),       # (8, 8, 1): 76^2 forward shape, leaky + folded BN
     (2, 45, 43, 128, 256, 1, 1, 0, True, 1, False, 73, 0, 0),        # (8, 4, 2): 76^2 data gradient shape: wave pairs, residual, linear

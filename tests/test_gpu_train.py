@@ -273,6 +273,46 @@ def test_first_block_backward_in_one_pass(libs, case):
         assert (got - emu).abs().max().item() <= 1e-3 * scale, (tag, 'vs emulation')
 
 
+@pytest.mark.parametrize('case', [(2, 3, 40, 64, 1), (1, 3, 21, 45, 1), (3, 1, 17, 33, 5), (1, 3, 96, 608, 1), (2, 3, 8, 31, 1)],
+                         ids=['even', 'odd_sizes_tail', 'gray_mish', 'row608', 'odd_w'])
+def test_first_block_backward_with_the_next_data_gradient_fused_in(libs, case):
+    """yh_stem_bwd with dz1 / w1: dy of block 0 is never stored - the pass computes conv_transpose(dz1, W1) (the data gradient of a
+    3x3 / s2 / p1 conv with 64 output channels) per segment.  Against (a) float64 torch: conv_transpose2d -> rounded to f16 like the
+    stored tensor -> BatchNorm / activation backward through autograd -> conv2d weight gradient, (b) the emulation."""
+    lib, fake = libs
+    N, cin, H, W, act = case
+    c, k1 = 32, 64
+    H1, W1 = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    g = torch.Generator().manual_seed(H * 7 + W)
+    x = torch.rand(N, cin, H, W, generator=g)
+    z = (torch.randn(N, H, W, c, generator=g) * 1.3 + 0.2).half()
+    dz1 = (torch.randn(N, H1, W1, k1 + 8, generator=g) * 0.05).half()
+    w1 = torch.randn(k1, c, 3, 3, generator=g) * (c * 9) ** -0.5
+    gamma, beta = torch.rand(c, generator=g) + 0.5, torch.randn(c, generator=g) * 0.3
+    zz = z.float().reshape(-1, c).double()
+    mean, invstd = zz.mean(0), 1.0 / torch.sqrt(zz.var(0, unbiased=False) + 1e-5)
+    op = (H - (2 * (H1 - 1) + 1), W - (2 * (W1 - 1) + 1))
+    dy = F.conv_transpose2d(dz1[..., :k1].float().permute(0, 3, 1, 2).double(), w1.half().double(), stride=2, padding=1, output_padding=op)
+    dyd = dy.permute(0, 2, 3, 1).reshape(-1, c).half().double()          # what the separate launch would have stored
+    zt = zz.clone().requires_grad_(True)
+    xh = (zt - zt.mean(0)) / torch.sqrt(zt.var(0, unbiased=False) + 1e-5)
+    ga, be = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    u = ga * xh + be
+    y = {1: lambda t: F.leaky_relu(t, 0.1), 5: lambda t: t * torch.tanh(F.softplus(t))}[act](u)
+    dz, dga, dbe = torch.autograd.grad((y * dyd).sum(), (zt, ga, be))
+    wref = torch.nn.grad.conv2d_weight(x.double(), (c, cin, 3, 3), dz.view(N, H, W, c).permute(0, 3, 1, 2), stride=1, padding=1)
+    outs = []
+    for L, dev in ((lib, GPU), (fake, 'cpu')):
+        t = lambda a: a.to(dev)
+        outs.append([o.cpu() for o in oh.stem_bwd(L, t(x), None, t(z), t(gamma), t(beta), t(mean.float()), t(invstd.float()), act=act,
+                                                  dz1=t(dz1), w1=t(w1))])
+    (dw, dg, db), (dw_e, dg_e, db_e) = outs
+    for got, emu, want, tag in ((dw, dw_e, wref, 'dw'), (dg, dg_e, dga, 'dgamma'), (db, db_e, dbe, 'dbeta')):
+        scale = want.abs().max().item()
+        assert (got.double() - want).abs().max().item() <= 4e-3 * scale, (tag, (got.double() - want).abs().max().item(), scale)
+        assert (got - emu).abs().max().item() <= 2e-3 * scale, (tag, 'vs emulation')
+
+
 @pytest.mark.parametrize('code', [F32, F16], ids=['fp32', 'fp16'])
 @pytest.mark.parametrize('accumulate', [False, True], ids=['write', 'acc'])
 @pytest.mark.parametrize('case', DGRAD_CASES, ids=lambda c: 'n%d_%dx%d_c%d-%d_k%ds%d' % c)

@@ -92,6 +92,36 @@ def test_first_block_backward_in_one_pass_equals_the_four_launch_form(mini16, mo
         assert th.rel_l2(grads_a[k], grads_ref[k]) <= 1.05 * th.rel_l2(grads_b[k], grads_ref[k]) + 1e-4, k
 
 
+def test_next_data_gradient_fused_into_the_first_block_backward(monkeypatch):
+    """Darknet-53's opening (3x3 32, then 3x3 / s2 64 as the stem's only consumer): the data gradient of the second conv is computed
+    inside the first block's backward pass (yh_stem_bwd dz1 / w1) - no dgrad launch, dy of block 0 never exists.  Same fp16 step with
+    YOLO_HIP_STEM_DGRAD=0 (data gradient as a launch of its own, ups = 4 form): identical plans otherwise, gradients equal to the
+    rounding of the emulated conv-transpose."""
+    c = lambda f, k, st: th._CONV % (f, k, st, 'leaky')
+    text = ('[net]\nbatch=1\nwidth=64\nheight=64\nchannels=3\n\n' + c(32, 3, 1) + c(64, 3, 2) + c(32, 1, 1) + c(64, 3, 1)
+            + '[shortcut]\nfrom=-3\nactivation=linear\n\n' + th._HEAD + th._YOLO % '3,4,5')
+    path = th.write_cfg(text)
+    try:
+        model = th.build(path, 52)
+        x = synth.image_batch(3, 52, seed=0)
+        _, grads_ref, _, ws = th.eager_step(model, x)
+        raws_a, grads_a, m = th.engine_step(model, x, ws, 'fp16', lib=fakelib.FakeLib())
+        ops = [w for w, _ in m.__dict__['_hip_train_engine']._current['bwd_ops']]
+        assert 'stembwd_dgrad0' in ops and 'dgrad1' not in ops and 'wgrad1' in ops
+        monkeypatch.setenv('YOLO_HIP_STEM_DGRAD', '0')
+        raws_b, grads_b, m = th.engine_step(model, x, ws, 'fp16', lib=fakelib.FakeLib())
+        ops = [w for w, _ in m.__dict__['_hip_train_engine']._current['bwd_ops']]
+        assert 'stembwd0' in ops and 'dgrad1' in ops
+        for k in grads_a:
+            assert th.rel_l2(grads_a[k], grads_b[k]) <= 1e-3, (k, th.rel_l2(grads_a[k], grads_b[k]))
+            if not k.startswith('module_list.0.'):
+                assert torch.equal(grads_a[k], grads_b[k]), k
+        for k in grads_ref:
+            assert th.cosine(grads_a[k], grads_ref[k]) > 0.97, k
+    finally:
+        os.unlink(path)
+
+
 def _gray_model():
     import models
     # linear activations: a leaky kink that flips under a different fp32 summation order moves every upstream gradient by

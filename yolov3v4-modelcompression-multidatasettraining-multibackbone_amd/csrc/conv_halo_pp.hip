@@ -169,8 +169,14 @@ template <int T9, int LB> struct HppAllow {
 // (two pieces each per tap in taps 0 .. 5, offsets from a table in LDS).  A wave's LDS-DMA returns are counted IN ORDER, so with
 // ROLE 0 a 16-row halo piece (16 scattered half lines, slow) in front of the weight pieces holds every counted wait for the next
 // weight tile up - the weight-gradient halo kernel gained 20 % from separating the two streams (profiles/r03_wgrad_halo.txt).
+// Division of a 31-bit index by a run-time constant as multiply-high + shift (host: hpp_magic): the ~35-instruction software divide
+// sat 2 (LB + 4) times per lane on the critical path of every workgroup - the halo offsets must exist before the first LDS-DMA
+// piece can be issued, the pixel indices before the first store - ~600 instructions of prologue before the first load.
+struct HppDiv { unsigned m_img, s_img, m_wp, s_wp; };
+__device__ __forceinline__ int hpp_div(int n, unsigned m, unsigned s) { return (int)(__umulhi((unsigned)n, m) >> s); }
+
 template <typename T, int LB, int ROLE>
-__global__ __launch_bounds__(512, 2) void conv3x3_hpp_kernel(const ConvArgs a, const int rows_hp, const int hbufs) {
+__global__ __launch_bounds__(512, 2) void conv3x3_hpp_kernel(const ConvArgs a, const int rows_hp, const int hbufs, const HppDiv dv) {
     constexpr int VEC = Prec<T>::VEC, BK = VEC * 4;       // one 64-byte chunk per row per K step: 32 f16 / 64 int8 channels
     constexpr int BM = 128, BN = 512, TM = 8, TN = 4, NW = 8, SA = 4;
     constexpr int A_CELLS = BM * 4;
@@ -217,9 +223,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_hpp_kernel(const ConvArgs a, c
         const int v = (int)q0 - Wp - 1 + j;      // the launcher keeps the whole virtual space below 2^31
         int off = -1;
         if (j < rows_hp && v >= 0) {
-            const int n = v / IMG;
+            const int n = hpp_div(v, dv.m_img, dv.s_img);
             const int rem = v - n * IMG;
-            const int yy = rem / Wp, xx = rem - yy * Wp;
+            const int yy = hpp_div(rem, dv.m_wp, dv.s_wp), xx = rem - yy * Wp;
             if (n < a.N && yy >= 1 && xx >= 1) off = ((n * a.H + yy - 1) * a.W + xx - 1) * a.ldx;
         }
         return off;
@@ -409,9 +415,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_hpp_kernel(const ConvArgs a, c
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int q = (int)q0 + wave * 64 + j * 16 + r16;
-        const int n = q / IMG;
+        const int n = hpp_div(q, dv.m_img, dv.s_img);
         const int rem = q - n * IMG;
-        const int yy = rem / Wp, xx = rem - yy * Wp;
+        const int yy = hpp_div(rem, dv.m_wp, dv.s_wp), xx = rem - yy * Wp;
         pix[j] = (n < a.N && yy >= 1 && xx >= 1) ? ((long)n * a.H + yy - 1) * a.W + xx - 1 : -1;
     }
     const long tile_row = (long)p_tile * NW + wave;
@@ -420,6 +426,16 @@ __global__ __launch_bounds__(512, 2) void conv3x3_hpp_kernel(const ConvArgs a, c
         case YH_ACT_MISH: hpp_epilogue<T, YH_ACT_MISH>(a, acc, bvs, pix, m0, tile_row, lane); break;
         default: hpp_epilogue<T, YH_ACT_LINEAR>(a, acc, bvs, pix, m0, tile_row, lane); break;
     }
+}
+
+// n / d for 0 <= n < 2^31, d >= 2: q = mulhi(n, m) >> s with L = ceil(log2 d), m = ceil(2^(31 + L) / d) < 2^32, s = L - 1
+// (n m / 2^(31 + L) = n / d + n e / (d 2^(31 + L)) with 0 <= e < d <= 2^L: the error term stays below 1 / d for n < 2^31)
+static void hpp_magic(unsigned d, unsigned* m, unsigned* s) {
+    unsigned L = 0;
+    while ((1ull << L) < d) ++L;
+    const unsigned long long num = 1ull << (31 + L);
+    *m = (unsigned)((num + d - 1) / d);
+    *s = L - 1;
 }
 
 // geometry shared by the launcher, the tile picker and the statistics-row query
@@ -458,6 +474,9 @@ template <typename T> static int launch_hpp(const ConvArgs& a0, hipStream_t stre
     a.p_tiles = (int)((Q + 511) / 512);
     const long blocks = (long)a.m_tiles * a.p_tiles;
     if (blocks <= 0 || blocks > 0x7fffffffL) return YH_EINVAL;
+    HppDiv dv;
+    hpp_magic((unsigned)((a.H + 1) * (a.W + 1)), &dv.m_img, &dv.s_img);       // both divisors >= 4 (H, W >= 1)
+    hpp_magic((unsigned)(a.W + 1), &dv.m_wp, &dv.s_wp);
     // ROLE 1 (separate weight / halo waves; needs its 48 halo pieces to cover the image) is an A/B form, measured 5 - 9 % SLOWER
     // than the shared form here (profiles/r03_hpp_role_ab.txt) - the weight tiles are L2-resident and short, unlike the dz stream
     // of the weight-gradient kernel where the same separation gained 20 %.  Its instantiations spill 3 registers at the 256 cap,
@@ -474,7 +493,7 @@ template <typename T> static int launch_hpp(const ConvArgs& a0, hipStream_t stre
         auto kern = YH_HPP_KERN(LBV);                                                                                          \
         hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds);   /* per (kernel, device) */                      \
         if (e != hipSuccess) return (int)e;                                                                                    \
-        hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(512), lds, stream, a, rows_hp, hbufs);                           \
+        hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(512), lds, stream, a, rows_hp, hbufs, dv);                       \
         break;                                                                                                                 \
     }
     switch (lb) {

@@ -999,7 +999,8 @@ static bool stream3_supported(const yh_conv_desc* d) {
     if (d->kh != 3 || d->kw != 3 || d->pad != 1 || (d->stride != 1 && d->stride != 2) || d->ups != 1 || d->out_f32) return false;
     if (d->stats_ws && (d->dtype != YH_F16 || d->res)) return false;
     if (d->act != YH_ACT_LINEAR && d->act != YH_ACT_LEAKY && d->act != YH_ACT_MISH) return false;
-    if (d->cin_k != (d->dtype == YH_I8 ? 64 : 32)) return false;
+    const bool two_steps = d->dtype == YH_F16 && d->cin_k == 64 && d->cout == 32 && !d->stats_ws;     // 64 -> 32: conv3's data gradient
+    if (d->cin_k != (d->dtype == YH_I8 ? 64 : 32) && !two_steps) return false;
     if (d->cout != 32 && d->cout != 64 && !(d->cout == 128 && d->dtype == YH_I8)) return false;
     const int esz = d->dtype == YH_I8 ? 1 : 2;
     if ((d->ldy * esz) % 16 || (reinterpret_cast<uintptr_t>(d->y) & 15u)) return false;                    // whole 16-byte units per row
@@ -1008,6 +1009,10 @@ static bool stream3_supported(const yh_conv_desc* d) {
 }
 static bool pick_stream3_tile(const yh_conv_desc* d) {
     static const bool off = getenv("YH_NO_STREAM3") != nullptr;
+    // The two-K-step form (fp16 64 -> 32, round 4) is an explicit-tile A/B form only: 0.77 ms on conv3's data gradient against 0.72 ms
+    // for the 64 x 128 ring tile - with 18 fragment loads per pixel group the nine-fold tap re-reads through L1 / TA (9 x 757 MB) bound
+    // it, not HBM (profiles/r04_stream3_two_steps.txt)
+    if (d->dtype == YH_F16 && d->cin_k != 32) return false;
     return !off && stream3_supported(d) && (long)d->n * d->ho * d->wo >= 262144;
 }
 

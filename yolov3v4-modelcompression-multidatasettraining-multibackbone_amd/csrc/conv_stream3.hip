@@ -42,7 +42,9 @@ template <> __device__ __forceinline__ i32x4 s3_mfma<int8_t>(const u32x4& a, con
 // in-order vmcnt queue exactly only through straight-line code; with `if (more)` / `if (p < P)` around the loads it fell back to the
 // conservative count at every join and the last taps of a block waited for the NEXT block's prefetches (vmcnt(0) at tap 8: 0.50 ms
 // instead of the numbers in profiles/r03_stream3_ab.txt).
-template <typename T, int MT, int ACT, bool HAS_RES, bool STATS, int S3_WAVES, int OCC>
+// KS (round 4): MFMA K steps of input channels per tap - 2 for the fp16 data gradient of Darknet-53's conv3 (64 -> 32 at 304^2, which
+// ran 0.76 ms on the register-staged 32 x 256 tile against a byte floor of 0.21): 18 B fragments per pixel group instead of 9.
+template <typename T, int MT, int ACT, bool HAS_RES, bool STATS, int S3_WAVES, int OCC, int KS = 1>
 __global__ __launch_bounds__(S3_WAVES * 64, OCC) void conv3x3_stream_kernel(const ConvArgs a, const long nblocks) {
     typedef T OutT;
     typedef typename S3Frag<T>::type frag_t;
@@ -57,14 +59,14 @@ __global__ __launch_bounds__(S3_WAVES * 64, OCC) void conv3x3_stream_kernel(cons
     const T* const rg = reinterpret_cast<const T*>(a.res);
     OutT* const yg = reinterpret_cast<OutT*>(a.y);
     extern __shared__ __attribute__((aligned(16))) char lds[];
-    frag_t* const wl = reinterpret_cast<frag_t*>(lds);                      // [MT * 9][64 lanes]
-    char* const tile = lds + MT * 9 * 64 * 16 + wv * (16 * PITCH);          // per wave: [16 pixels][PITCH]
+    frag_t* const wl = reinterpret_cast<frag_t*>(lds);                      // [MT * 9 * KS][64 lanes]
+    char* const tile = lds + MT * 9 * KS * 64 * 16 + wv * (16 * PITCH);     // per wave: [16 pixels][PITCH]
 
     {
         const T* const wg = reinterpret_cast<const T*>(a.w);
-        for (int idx = threadIdx.x; idx < MT * 9 * 64; idx += S3_WAVES * 64) {
-            const int l = idx & 63, it = idx >> 6, i = it / 9, t = it - i * 9;
-            wl[idx] = *reinterpret_cast<const frag_t*>(wg + (long)(i * 16 + (l & 15)) * a.ktot + t * a.cin_k + (l >> 4) * UNIT);
+        for (int idx = threadIdx.x; idx < MT * 9 * KS * 64; idx += S3_WAVES * 64) {
+            const int l = idx & 63, itk = idx >> 6, it = itk / KS, k = itk - it * KS, i = it / 9, t = it - i * 9;
+            wl[idx] = *reinterpret_cast<const frag_t*>(wg + (long)(i * 16 + (l & 15)) * a.ktot + t * a.cin_k + k * S3Frag<T>::K + (l >> 4) * UNIT);
         }
     }
     f32x4 bvs[MT];
@@ -72,7 +74,9 @@ __global__ __launch_bounds__(S3_WAVES * 64, OCC) void conv3x3_stream_kernel(cons
     for (int i = 0; i < MT; ++i) bvs[i] = *reinterpret_cast<const f32x4*>(a.bias + i * 16 + mq);
     __syncthreads();
 
-    const bool cok = kq * UNIT < a.Cin;              // lanes past the channel count (int8 Cin 32 in a 64-byte step) hold zeros
+    bool cok[KS];                                    // lanes past the channel count (int8 Cin 32 in a 64-byte step) hold zeros
+#pragma unroll
+    for (int k = 0; k < KS; ++k) cok[k] = k * S3Frag<T>::K + kq * UNIT < a.Cin;
     const int HoWo = a.Ho * a.Wo;
     const char* const zpage = reinterpret_cast<const char*>(g_zero_page);
     // per pixel group: byte offset of input pixel (hi0, wi0) = the top-left tap, 32 bits (the picker keeps x below 2 GB)
@@ -95,12 +99,12 @@ __global__ __launch_bounds__(S3_WAVES * 64, OCC) void conv3x3_stream_kernel(cons
         }
         return g;
     };
-    auto load_tap = [&](const Geo& g, const int t, const bool live, frag_t (&f)[TN]) {
+    auto load_tap = [&](const Geo& g, const int t, const int k, const bool live, frag_t (&f)[TN]) {
         const int r = t / 3, s = t - 3 * r;                  // compile-time after unrolling
-        const int tap = (r * a.W + s) * pix_bytes;
+        const int tap = (r * a.W + s) * pix_bytes + k * 64;
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-            const bool ok = live && cok && (unsigned)(g.hi0[j] + r) < (unsigned)a.H && (unsigned)(g.wi0[j] + s) < (unsigned)a.W;
+            const bool ok = live && cok[k] && (unsigned)(g.hi0[j] + r) < (unsigned)a.H && (unsigned)(g.wi0[j] + s) < (unsigned)a.W;
             // a padding tap (or a lane past the channel count, or a wave without a next block) reads the zero page: the select sits
             // on the ADDRESS, so the load is unconditional and nothing waits for its data before the MFMAs that use it
             // (the address goes through an opaque register move: left visible, the select of two pointers under a load is turned
@@ -126,8 +130,8 @@ __global__ __launch_bounds__(S3_WAVES * 64, OCC) void conv3x3_stream_kernel(cons
     }
     long blk = wave;
     Geo g = geometry(blk);
-    frag_t fr[9][TN];
-    static_for<9>([&](auto tc) { load_tap(g, decltype(tc)::value, blk < nblocks, fr[decltype(tc)::value]); });
+    frag_t fr[9 * KS][TN];
+    static_for<9 * KS>([&](auto tc) { load_tap(g, decltype(tc)::value / KS, decltype(tc)::value % KS, blk < nblocks, fr[decltype(tc)::value]); });
     for (; blk < nblocks; blk += nwaves) {
         const long p0 = blk * (TN * 16);
         res_t rv[TN][MT];
@@ -147,15 +151,15 @@ __global__ __launch_bounds__(S3_WAVES * 64, OCC) void conv3x3_stream_kernel(cons
         for (int i = 0; i < MT; ++i)
 #pragma unroll
             for (int j = 0; j < TN; ++j) acc[i][j] = acc_t{0, 0, 0, 0};
-        static_for<9>([&](auto tc) {
-            constexpr int t = decltype(tc)::value;
+        static_for<9 * KS>([&](auto tc) {
+            constexpr int tk = decltype(tc)::value, t = tk / KS, k = tk % KS;
 #pragma unroll
             for (int i = 0; i < MT; ++i) {
-                const frag_t wa = wl[(i * 9 + t) * 64 + lane];
+                const frag_t wa = wl[((i * 9 + t) * KS + k) * 64 + lane];
 #pragma unroll
-                for (int j = 0; j < TN; ++j) acc[i][j] = s3_mfma<T>(wa, fr[t][j], acc[i][j]);
+                for (int j = 0; j < TN; ++j) acc[i][j] = s3_mfma<T>(wa, fr[tk][j], acc[i][j]);
             }
-            load_tap(g, t, more, fr[t]);
+            load_tap(g, t, k, more, fr[tk]);
         });
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
@@ -222,15 +226,15 @@ template <int WAVES> static long s3_grid(long P) {
 }
 long stream3_stats_rows(long P, int cout) { return cout == 64 ? s3_grid<4>(P) * 4 : s3_grid<6>(P) * 6; }     // fp16 forms only
 
-template <typename T, int MT, int WAVES, int OCC> static int launch_s3_act(const ConvArgs& a, hipStream_t s) {
+template <typename T, int MT, int WAVES, int OCC, int KS = 1> static int launch_s3_act(const ConvArgs& a, hipStream_t s) {
     const long nblocks = (a.P + 31) / 32;
     const long grid = s3_grid<WAVES>(a.P);
-    const size_t shmem = (size_t)MT * 9 * 64 * 16 + (size_t)WAVES * 16 * (MT * 16 * sizeof(T) + 16);
+    const size_t shmem = (size_t)MT * 9 * KS * 64 * 16 + (size_t)WAVES * 16 * (MT * 16 * sizeof(T) + 16);
     const bool res = a.res != nullptr, stats = a.stats_part != nullptr;
-    if (stats && (res || sizeof(T) == 1)) return YH_EINVAL;
+    if (stats && (res || sizeof(T) == 1 || KS != 1)) return YH_EINVAL;      // (the two-step form is a data-gradient form: no statistics rows)
 #define YH_S3_GO(A, R, S)                                                                                                      \
     do {                                                                                                                       \
-        auto kern = conv3x3_stream_kernel<T, MT, A, R, S, WAVES, OCC>;                                                         \
+        auto kern = conv3x3_stream_kernel<T, MT, A, R, S, WAVES, OCC, KS>;                                                     \
         const hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), shmem);   /* int8 Cout 128: ~92 KB */    \
         if (e != hipSuccess) return (int)e;                                                                                    \
         hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(WAVES * 64), shmem, s, a, nblocks);                                \
@@ -238,7 +242,7 @@ template <typename T, int MT, int WAVES, int OCC> static int launch_s3_act(const
     switch (a.act) {
 #define YH_S3(A)                                                         \
     case A:                                                               \
-        if constexpr (sizeof(T) == 2) {                                   \
+        if constexpr (sizeof(T) == 2 && KS == 1) {                        \
             if (stats) { YH_S3_GO(A, false, true); break; }               \
         }                                                                 \
         if (res) YH_S3_GO(A, true, false);                                \
@@ -255,6 +259,8 @@ template <typename T, int MT, int WAVES, int OCC> static int launch_s3_act(const
 // tile code 72 (conv_igemm.hip yh_conv2d_tile): Cout 32 or 64 exactly; int8 also 128 (64 -> 128 at 304^2 / 152^2 is one K step there)
 int launch_stream3_tile(const ConvArgs& a, int dtype, hipStream_t s) {
     if (dtype == YH_F16) {
+        if (a.Cout == 32 && a.cin_k == 64) return launch_s3_act<f16, 2, 4, 2, 2>(a, s);     // two K steps per tap: 144 fragment registers
+        if (a.cin_k != 32) return YH_EUNSUPPORTED;
         if (a.Cout == 32) return launch_s3_act<f16, 2, 6, 3>(a, s);
         if (a.Cout == 64) return launch_s3_act<f16, 4, 4, 2>(a, s);
     } else if (dtype == YH_I8) {

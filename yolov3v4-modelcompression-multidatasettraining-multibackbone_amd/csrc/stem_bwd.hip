@@ -294,6 +294,300 @@ __global__ __launch_bounds__(256, 2) void stem_bwd_partial_kernel(const yh_stem_
     for (int i = tid; i < Row::SIZE; i += 256) out[i] = part[i];
 }
 
+// ---- the same pass with the NEXT conv's data gradient fused in (yh_stem_bwd_desc::dz1): dy is never read - and never written by
+// anyone.  Next conv = 3x3 / stride 2 / pad 1, K1 = 64 output channels, C = 32.  For the segment's row h and its 32 columns w:
+//     dy[h][w][c] = sum over taps (r, s) with (h + 1 - r), (w + 1 - s) even, ho = (h + 1 - r) / 2, wo = (w + 1 - s) / 2 in range
+//                   of sum_k dz1[ho][wo][k] W1[k][c][r][s]
+// h even: r = 1;  h odd: r = 0 (ho = (h + 1) / 2) and r = 2 (ho = (h - 1) / 2).  The 32 pixels split into the 16 even columns
+// w0 + 2 pc (s = 1, wo = w0 / 2 + pc) and the 16 odd ones (s = 2 with the same wo, s = 0 with wo + 1): per dz1 row two B fragments
+// per K step (columns wo and wo + 1, 16 bytes of one dz1 pixel per lane - its channels are contiguous) feed 4 + 8 MFMAs whose A
+// fragments are W1's data-gradient image (yh_conv_pack_weights_dgrad: rows = c, flipped taps) resident in LDS.  The results arrive in
+// MFMA D layout - 4 channels of one pixel per lane - so z is loaded in that layout too (8 bytes per lane), and g / xhat are written
+// into the [pixel][channel] A tile as 8-byte cells; from there on the pass is the unfused kernel's (X tile, transposed reads, MFMAs).
+template <int CIN, int ACT>
+__global__ __launch_bounds__(256, 2) void stem_bwd_dgrad_kernel(const yh_stem_bwd_desc d, const int segs_per_row, const int nseg) {
+    constexpr int C = 32, K1S = 2;              // 32 channels, K1 = 64 = two MFMA K steps
+    constexpr int AROWS = 2 * C + 16, PA = AROWS * 2, PB = 96, NI = AROWS / 16;
+    constexpr int A_BYTES = 32 * PA, B_BYTES = 32 * PB, WAVE_BYTES = A_BYTES + B_BYTES;
+    constexpr int NRC = 3 * CIN;
+    constexpr int W1_BYTES = 9 * 2 * K1S * 1024;     // [tap][row group][k step][64 lanes][16 B] = 36 KB
+    typedef SbRow<C> Row;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[4 * WAVE_BYTES + W1_BYTES];
+    // (the workgroup's partial row reuses the waves' tiles after the loop: 69.6 KB in all, two workgroups per CU with room to spare)
+    static_assert(Row::SIZE * 4 <= 4 * WAVE_BYTES, "partial row must fit the tiles");
+    float* const part = reinterpret_cast<float*>(smem);
+    typedef void __attribute__((address_space(3))) * lptr_t;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    unsigned char* const At = smem + wave * WAVE_BYTES;
+    unsigned char* const Bt = At + A_BYTES;
+    unsigned char* const W1l = smem + 4 * WAVE_BYTES;
+    const unsigned at_lds = (unsigned)(uintptr_t)(lptr_t)At;
+    const int pc = lane & 15, kq = lane >> 4;
+
+    for (int i = lane; i < WAVE_BYTES / 16; i += 64) reinterpret_cast<sb_u32x4*>(At)[i] = sb_u32x4{0u, 0u, 0u, 0u};
+    __builtin_amdgcn_wave_barrier();
+    if (lane < 32) *reinterpret_cast<f16*>(At + lane * PA + 2 * C * 2) = (f16)1.f;
+    {   // W1 fragments: tap (r, s) of the ORIGINAL kernel is tap (2 - r, 2 - s) of the flipped image; lane (pc, kq) of fragment
+        // (row group i, k step k) holds image[16 i + pc][tap][32 k + 8 kq .. + 7]
+        const f16* const wg = reinterpret_cast<const f16*>(d.w1);
+        for (int f = wave; f < 9 * 2 * K1S; f += 4) {
+            const int t = f / (2 * K1S), ik = f - t * (2 * K1S), i = ik / K1S, k = ik - i * K1S;
+            const int r = t / 3, s = t - 3 * r;
+            const int ft = (2 - r) * 3 + (2 - s);
+            const sb_u32x4 v = *reinterpret_cast<const sb_u32x4*>(wg + ((long)(i * 16 + pc) * 9 + ft) * d.k1_pad + k * 32 + kq * 8);
+            *reinterpret_cast<sb_u32x4*>(W1l + (f * 64 + lane) * 16) = v;
+        }
+    }
+    __syncthreads();
+
+    // per-lane constants in D layout: channels 16 i + 4 kq + e (i = 0, 1; e = 0 .. 3), as pairs
+    f32x2 isv[4], nmu[4], gis[4], bsh[4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int ch = 16 * i + 4 * kq + 2 * h + k;
+                const float is = d.invstd[ch], mu = d.mean[ch];
+                isv[2 * i + h][k] = is;
+                nmu[2 * i + h][k] = -mu * is;
+                gis[2 * i + h][k] = d.gamma[ch];
+                bsh[2 * i + h][k] = d.beta[ch];
+            }
+    f32x2 s1[4], s2[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) s1[e] = s2[e] = f32x2{0.f, 0.f};
+    f32x4 acc[NI][2];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) acc[i][0] = acc[i][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const f16* const zg = reinterpret_cast<const f16*>(d.z) + 4 * kq;
+    const f16* const dzg = reinterpret_cast<const f16*>(d.dz1) + kq * 8;
+    const int gw = blockIdx.x * 4 + wave, nw = gridDim.x * 4;
+    const int d_row = nw / segs_per_row, d_sg = nw - d_row * segs_per_row;
+    struct Pos { int n, h, sg; };
+    auto advance = [&](Pos& p) {
+        p.sg += d_sg;
+        p.h += d_row;
+        if (p.sg >= segs_per_row) { p.sg -= segs_per_row; ++p.h; }
+        while (p.h >= d.h) { p.h -= d.h; ++p.n; }
+    };
+
+    typedef unsigned int sb_u32x2 __attribute__((ext_vector_type(2)));
+    struct Seg { sb_u32x4 bz[2][2][K1S]; sb_u32x2 z[2][2]; float img[9]; };      // [dz1 row slot][column wo / wo + 1][k step]; z[i][even / odd]
+    const int HW = d.h * d.w_in;
+    auto load_seg = [&](const Pos& ps, Seg& g) {
+        const int w0 = ps.sg * 32;
+        // dz1 rows: slot 0 = ho (h + 1) >> 1 (r = 1 for even h, r = 0 for odd h), slot 1 = ho (h - 1) >> 1 (r = 2, odd h only);
+        // clamped addresses, masked values: no branch around a load
+        const int ho0 = (ps.h + 1) >> 1, ho1 = (ps.h - 1) >> 1;
+        const int wo = (w0 >> 1) + pc;
+#pragma unroll
+        for (int sl = 0; sl < 2; ++sl) {
+            const int ho = sl ? ho1 : ho0;
+            const int hc = min(max(ho, 0), d.h1 - 1);
+            const bool rok = sl ? (ps.h & 1) : ho0 < d.h1;
+#pragma unroll
+            for (int c2 = 0; c2 < 2; ++c2) {
+                const int wc = min(wo + c2, d.w1_in - 1);
+                const unsigned msk = (rok && wo + c2 < d.w1_in) ? 0xffffffffu : 0u;
+                const f16* const src = dzg + (((long)ps.n * d.h1 + hc) * d.w1_in + wc) * d.lddz1;
+#pragma unroll
+                for (int k = 0; k < K1S; ++k) {
+                    const sb_u32x4 v = *reinterpret_cast<const sb_u32x4*>(src + k * 32);
+                    g.bz[sl][c2][k] = sb_u32x4{v[0] & msk, v[1] & msk, v[2] & msk, v[3] & msk};
+                }
+            }
+        }
+        const long p0 = ((long)ps.n * d.h + ps.h) * d.w_in + w0;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const int px = 2 * pc + b;
+                const long p = w0 + px < d.w_in ? p0 + px : p0;
+                g.z[i][b] = *reinterpret_cast<const sb_u32x2*>(zg + p * d.ldz + 16 * i);
+            }
+        const int wi = w0 - 1 + lane;
+        const int wcl = min(max(wi, 0), d.w_in - 1);
+        const bool wok = lane < 34 && wi >= 0 && wi < d.w_in;
+        const float* const xin = d.x + (long)ps.n * CIN * HW + wcl;
+#pragma unroll
+        for (int rc = 0; rc < 9; ++rc) {
+            g.img[rc] = 0.f;
+            if (rc < NRC) {
+                const int r = rc / CIN, ci = rc - r * CIN;
+                const int hi = ps.h + r - 1;
+                const int hc = min(max(hi, 0), d.h - 1);
+                const float v = xin[ci * HW + hc * d.w_in];
+                g.img[rc] = v * ((wok && hi >= 0 && hi < d.h) ? 1.f : 0.f);
+            }
+        }
+    };
+
+    const int q16 = pc, g4 = kq;
+    const unsigned a_rd0 = at_lds + (8 * g4 + (q16 >> 2)) * PA + 4 * (q16 & 3) * 2;
+    const unsigned char* const b_rd = Bt + q16 * PB + 16 + g4 * 16;
+    unsigned char* const b_wr = Bt + 16 + lane * 2;
+    const unsigned char* const w1_rd = W1l + lane * 16;
+    auto w1frag = [&](int r, int s, int i, int k) {
+        return *reinterpret_cast<const f16x8*>(w1_rd + ((((r * 3 + s) * 2 + i) * K1S + k) * 64) * 16);
+    };
+    auto process = [&](const Pos& ps, Seg& g) {
+        const int w0 = ps.sg * 32;
+        const int valid = d.w_in - w0;
+        // ---- dy of the segment: D layout, even columns (dye) and odd columns (dyo), channels 16 i + 4 kq + e
+        f32x4 dye[2], dyo[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) dye[i] = dyo[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const bool hodd = ps.h & 1;
+#pragma unroll
+        for (int sl = 0; sl < 2; ++sl) {
+            if (sl == 0 || hodd) {                 // wave-uniform; the masked fragments of an absent row are zeros anyway
+                const int r = sl ? 2 : (hodd ? 0 : 1);
+#pragma unroll
+                for (int k = 0; k < K1S; ++k) {
+                    const f16x8 b0 = __builtin_bit_cast(f16x8, g.bz[sl][0][k]), b1 = __builtin_bit_cast(f16x8, g.bz[sl][1][k]);
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        dye[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1frag(r, 1, i, k), b0, dye[i], 0, 0, 0);
+                        dyo[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1frag(r, 2, i, k), b0, dyo[i], 0, 0, 0);
+                        dyo[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1frag(r, 0, i, k), b1, dyo[i], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        // ---- g and xhat in D layout -> the A tile (8-byte cells); pixels beyond the row end: g = 0
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const int px = 2 * pc + b;
+                const bool ok = px < valid;
+                const f16x4 zv = __builtin_bit_cast(f16x4, g.z[i][b]);
+                const f32x4 dyv = b ? dyo[i] : dye[i];
+                f16x4 gv, xv;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int e = 2 * i + h;
+                    const f32x2 zf = {(float)zv[2 * h], (float)zv[2 * h + 1]};
+                    // the data gradient the unfused path would have STORED is rounded to fp16: keep that rounding (same values reach
+                    // the sums as in the four-launch form)
+                    const f32x2 df = {ok ? (float)(f16)dyv[2 * h] : 0.f, ok ? (float)(f16)dyv[2 * h + 1] : 0.f};
+                    const f32x2 xh = __builtin_elementwise_fma(zf, isv[e], nmu[e]);
+                    const f32x2 u = __builtin_elementwise_fma(gis[e], xh, bsh[e]);
+                    const f32x2 m = {sb_dact<ACT>(u[0], d.act, d.slope), sb_dact<ACT>(u[1], d.act, d.slope)};
+                    const f32x2 gg = df * m;
+                    s1[e] += gg;
+                    s2[e] = __builtin_elementwise_fma(gg, xh, s2[e]);
+                    gv[2 * h] = (f16)gg[0];
+                    gv[2 * h + 1] = (f16)gg[1];
+                    xv[2 * h] = (f16)xh[0];
+                    xv[2 * h + 1] = (f16)xh[1];
+                }
+                unsigned char* const cell = At + px * PA + (16 * i + 4 * kq) * 2;
+                *reinterpret_cast<f16x4*>(cell) = gv;
+                *reinterpret_cast<f16x4*>(cell + C * 2) = xv;
+            }
+        // ---- X columns (as the unfused kernel)
+        const bool keep0 = lane < valid;
+        if (lane < 34) {
+#pragma unroll
+            for (int rc = 0; rc < 9; ++rc) {
+                if (rc < NRC) {
+                    const int r = rc / CIN, ci = rc - r * CIN;
+                    const f16 v = (f16)g.img[rc];
+                    const f16 v0 = keep0 ? v : (f16)0.f;
+                    *reinterpret_cast<f16*>(b_wr + ((r * 3 + 0) * CIN + ci) * PB) = v0;
+                    *reinterpret_cast<f16*>(b_wr + ((r * 3 + 1) * CIN + ci) * PB - 2) = v;
+                    *reinterpret_cast<f16*>(b_wr + ((r * 3 + 2) * CIN + ci) * PB - 4) = v;
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        sb_v2i ra[NI][2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int i = 0; i < NI; ++i) ra[i][h] = sb_read_tr16(a_rd0 + h * 4 * PA + i * 32);
+        f16x8 fb[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) fb[j] = *reinterpret_cast<const f16x8*>(b_rd + j * 16 * PB);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            asm volatile("" : "+v"(ra[i][0]), "+v"(ra[i][1]));
+            const sb_v4i t = {ra[i][0][0], ra[i][0][1], ra[i][1][0], ra[i][1][1]};
+            const f16x8 fa = __builtin_bit_cast(f16x8, t);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa, fb[j], acc[i][j], 0, 0, 0);
+        }
+        __builtin_amdgcn_wave_barrier();
+    };
+
+    Seg cur, nxt;
+    Pos pcur, pn;
+    {
+        const int row = gw / segs_per_row;
+        pcur.sg = gw - row * segs_per_row;
+        pcur.n = row / d.h;
+        pcur.h = row - pcur.n * d.h;
+    }
+    if (gw < nseg) {
+        load_seg(pcur, cur);
+        for (int s = gw; s < nseg; s += nw) {
+            pn = pcur;
+            if (s + nw < nseg) advance(pn);
+            load_seg(pn, nxt);
+            process(pcur, cur);
+            cur = nxt;
+            pcur = pn;
+        }
+    }
+
+    // ---- per-wave sums: lanes that share kq (the 16 pixel lanes) add up; lane pc == 0 of each kq holds channels 16 i + 4 kq + e
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+#pragma unroll
+            for (int m = 1; m < 16; m <<= 1) {
+                s1[e][k] += __shfl_xor(s1[e][k], m);
+                s2[e][k] += __shfl_xor(s2[e][k], m);
+            }
+        }
+    __syncthreads();          // every wave is done with its tiles
+    for (int i = tid; i < Row::SIZE; i += 256) part[i] = 0.f;
+    __syncthreads();
+    if (pc == 0) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const int ch = 16 * i + 4 * kq + 2 * h + k;
+                    atomicAdd(&part[Row::S1 + ch], s1[2 * i + h][k]);
+                    atomicAdd(&part[Row::S2 + ch], s2[2 * i + h][k]);
+                }
+    }
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int m = 16 * i + 4 * g4 + e, k = 16 * j + q16;
+                if (m < 2 * C) atomicAdd(&part[m * 32 + k], acc[i][j][e]);
+                else if (m == 2 * C) atomicAdd(&part[Row::SX + k], acc[i][j][e]);
+            }
+    __syncthreads();
+    float* const out = d.ws + (long)blockIdx.x * Row::SIZE;
+    for (int i = tid; i < Row::SIZE; i += 256) out[i] = part[i];
+}
+
 // one workgroup per output channel: column sums of the partial rows in double, then the closed form
 template <int C>
 __global__ __launch_bounds__(256) void stem_bwd_final_kernel(const yh_stem_bwd_desc d, const int nparts) {
@@ -358,9 +652,9 @@ extern "C" int64_t yh_stem_bwd_workspace(const yh_stem_bwd_desc* d) {
 
 extern "C" int yh_stem_bwd(const yh_stem_bwd_desc* d, void* stream) {
     if (!sb_supported(d)) return d ? YH_EUNSUPPORTED : YH_EINVAL;
-    if (!d->x || !d->dy || !d->z || !d->gamma || !d->beta || !d->mean || !d->invstd || !d->dgamma || !d->dbeta || !d->dw || !d->ws)
+    if (!d->x || (!d->dy && !d->dz1) || !d->z || !d->gamma || !d->beta || !d->mean || !d->invstd || !d->dgamma || !d->dbeta || !d->dw || !d->ws)
         return YH_EINVAL;
-    if (d->lddy % 8 || d->ldz % 8 || !aligned16(d->dy) || !aligned16(d->z)) return YH_EALIGN;
+    if (!d->dz1 && (d->lddy % 8 || d->ldz % 8 || !aligned16(d->dy) || !aligned16(d->z))) return YH_EALIGN;
     if ((long)d->n * d->h * d->w_in * (long)(d->lddy > d->ldz ? d->lddy : d->ldz) >= (1L << 40)) return YH_EINVAL;
     int spr;
     long nseg;
@@ -369,6 +663,22 @@ extern "C" int yh_stem_bwd(const yh_stem_bwd_desc* d, void* stream) {
     if (d->ws_floats < need) return YH_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     if (nseg + 4L * wgs >= 0x7fffffffL) return YH_EUNSUPPORTED;
+    if (d->dz1) {      // the next conv's data gradient fused in: 3x3 / s2 / p1, 64 output channels, onto the 32 channels of this block
+        if (!d->w1 || d->cout != 32 || d->k1 != 64 || d->k1_pad != 64 || d->h1 != (d->h + 2 - 3) / 2 + 1 || d->w1_in != (d->w_in + 2 - 3) / 2 + 1)
+            return YH_EUNSUPPORTED;
+        if (d->lddz1 % 8 || !aligned16(d->dz1) || !aligned16(d->w1) || d->ldz % 4 || (((uintptr_t)d->z) & 7u)) return YH_EALIGN;
+#define YH_SBD_GO(CI)                                                                                                    \
+    do {                                                                                                                \
+        if (d->act == YH_ACT_LEAKY) hipLaunchKernelGGL((stem_bwd_dgrad_kernel<CI, YH_ACT_LEAKY>), dim3(wgs), dim3(256), 0, s, *d, spr, (int)nseg); \
+        else if (d->act == YH_ACT_MISH) hipLaunchKernelGGL((stem_bwd_dgrad_kernel<CI, YH_ACT_MISH>), dim3(wgs), dim3(256), 0, s, *d, spr, (int)nseg); \
+        else hipLaunchKernelGGL((stem_bwd_dgrad_kernel<CI, -1>), dim3(wgs), dim3(256), 0, s, *d, spr, (int)nseg);        \
+        hipLaunchKernelGGL(stem_bwd_final_kernel<32>, dim3(32), dim3(256), 0, s, *d, wgs);                              \
+    } while (0)
+        if (d->cin == 3) YH_SBD_GO(3);
+        else YH_SBD_GO(1);
+#undef YH_SBD_GO
+        return check_launch();
+    }
 #define YH_SB_GO(CC, CI)                                                                                                 \
     do {                                                                                                                \
         if (d->act == YH_ACT_LEAKY) hipLaunchKernelGGL((stem_bwd_partial_kernel<CC, CI, YH_ACT_LEAKY>), dim3(wgs), dim3(256), 0, s, *d, spr, (int)nseg); \

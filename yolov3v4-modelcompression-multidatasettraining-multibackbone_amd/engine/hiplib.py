@@ -134,7 +134,7 @@ class StemBwdDesc(C.Structure):
     _fields_ = [('x', _vp), ('dy', _vp), ('z', _vp), ('gamma', _vp), ('beta', _vp), ('mean', _vp), ('invstd', _vp),
                 ('dgamma', _vp), ('dbeta', _vp), ('dw', _vp), ('ws', _vp), ('ws_floats', _i64),
                 ('n', _i32), ('cin', _i32), ('h', _i32), ('w_in', _i32), ('cout', _i32), ('lddy', _i32), ('ldz', _i32), ('act', _i32),
-                ('slope', _f32)]
+                ('slope', _f32), ('dz1', _vp), ('w1', _vp), ('h1', _i32), ('w1_in', _i32), ('k1', _i32), ('k1_pad', _i32), ('lddz1', _i32)]
 
 
 class ResampleDesc(C.Structure):

@@ -132,7 +132,10 @@ class TrainEngine(DarknetEngine):
                 continue
             items.append(PackItem(w=w, bias=cb, packed=P(pk['w']), bias_out=P(pk['b']), mode=0, k_pad=pk['cin_k'], m_pad=pk['m_pad'],
                                   **geo))
-            if v.stride == 2 and 'wt_fused' in pk:
+            if v.stride == 2 and pk.get('stem_fused'):
+                # its data gradient runs inside the first block's backward pass (csrc/stem_bwd.hip): the plain flipped-tap image
+                items.append(PackItem(w=w, packed=P(pk['wt']), mode=1, k_pad=pk['cout_k'], m_pad=pk['dm_pad'], **geo))
+            elif v.stride == 2 and 'wt_fused' in pk:
                 items.append(PackItem(w=w, packed=P(pk['wt_fused']), mode=5, k_pad=pk['cout_k'], m_pad=pk['fused_m_pad'],
                                       cout_pad=v.src.c_phys, **geo))
             elif v.stride == 2:
@@ -307,7 +310,10 @@ class TrainEngine(DarknetEngine):
                                b=torch.empty(m_pad, device=dev, dtype=torch.float32), cin_k=cin_k, m_pad=m_pad,
                                wt=None if v.stride == 2 else torch.empty(dm_pad * taps * cout_k, device=dev, dtype=self.dtype),
                                cout_k=cout_k, dm_pad=dm_pad)
-                if v.stride == 2 and 16 <= v.src.c_phys <= 32 and v.src.c_phys % 4 == 0:
+                if self._dgrad_fused_into_stem(values, v):
+                    v.tpack['stem_fused'] = True
+                    v.tpack['wt'] = torch.empty(dm_pad * taps * cout_k, device=dev, dtype=self.dtype)
+                elif v.stride == 2 and 16 <= v.src.c_phys <= 32 and v.src.c_phys % 4 == 0:
                     # few input channels: the data gradient is bound by reading dz and writing dx, so all four parity phases
                     # run as ONE 2x2-tap GEMM with 4 * cin rows (16 tap-GEMMs instead of 9, but dz is read once, not four
                     # times, and each workgroup writes whole rows of dx): yh_conv2d_fwd ups = 4
@@ -666,12 +672,14 @@ class TrainEngine(DarknetEngine):
                                          invstd=bnp['invstd'], dgamma=grads.ptr(v.g_gamma), dbeta=grads.ptr(v.g_beta),
                                          dw=grads.ptr(v.g_w), n=N, cin=s.C, h=s.H, w_in=s.W, cout=v.c_phys, lddy=lddy,
                                          ldz=v.c_phys, act=v.act, slope=v.slope)
+                        for key, val in getattr(v, 'fused_dgrad', {}).items():
+                            setattr(sd, key, val)
                         need = int(lib.yh_stem_bwd_workspace(C.byref(sd)))
                         if need <= 0:
                             raise RuntimeError('yh_stem_bwd_workspace rejected a geometry _stem_bwd_fused accepted')
                         sd.ws_floats = need
                         plan['ws_floats'] = max(plan['ws_floats'], need)
-                        op = add(bwd, plan['bwd_ops'], sd, 'stembwd%d' % v.block)
+                        op = add(bwd, plan['bwd_ops'], sd, ('stembwd%d' if not getattr(v, 'fused_dgrad', None) else 'stembwd_dgrad%d') % v.block)
                         fixup(bwd, op, StemBwdDesc, 'ws', SLOT_WS)
                         fixup(bwd, op, StemBwdDesc, 'x', SLOT_INPUT)
                         continue
@@ -711,7 +719,13 @@ class TrainEngine(DarknetEngine):
             common = dict(bias=P(zero_bias), n=N, cin=v.c_phys, cout=s.c_phys, stride=1, ldx=lddz, ldr=s.ld if mode == 'acc' else 0,
                           ldy=s.ld, cin_k=pk['cout_k'], m_pad=pk['dm_pad'], act=LINEAR, slope=0.0, out_f32=0, dtype=self.code,
                           tile=self.force_tile if self.force_tile < 40 else 0, acc_scale=0.0, out_scale=0.0)
-            if v.stride == 2 and 'wt_fused' in pk:
+            if pk.get('stem_fused'):
+                # no launch: the first block's backward computes this data gradient from dz on the fly (yh_stem_bwd dz1 / w1) and
+                # never materialises it.  dz stays valid until then: the first block writes no dz of its own.
+                if mode != 'write':
+                    raise RuntimeError('fused first-block data gradient must be the only contribution to its gradient')
+                s.fused_dgrad = dict(dz1=dzp, lddz1=lddz, w1=P(pk['wt']), h1=v.Ho, w1_in=v.Wo, k1=v.c_phys, k1_pad=pk['cout_k'])
+            elif v.stride == 2 and 'wt_fused' in pk:
                 fused = dict(common, cout=4 * s.c_phys, m_pad=pk['fused_m_pad'])
                 if zero_bias.numel() < pk['fused_m_pad']:
                     raise RuntimeError('zero bias row is shorter than the fused data-gradient image')
@@ -752,6 +766,28 @@ class TrainEngine(DarknetEngine):
             return False
         return (self.code == hiplib.YH_F16 and v.bn is not None and v.k == 3 and v.stride == 1 and v.pad == 1 and s.C in (1, 3)
                 and v.c_phys in (16, 32) and v.C == v.c_phys and v.ups == 1 and v.res is None and v.conv.bias is None)
+
+    def _dgrad_fused_into_stem(self, values, v):
+        """conv `v` is the ONLY consumer of the first block, a 3x3 / stride 2 / pad 1 conv with 64 output channels on its 32
+        channels, and the first block takes the one-pass backward: then v's data gradient is computed inside that pass
+        (YOLO_HIP_STEM_DGRAD=0 keeps it a launch of its own)."""
+        s = v.src
+        if os.environ.get('YOLO_HIP_STEM_DGRAD', '1') == '0' or os.environ.get('YOLO_HIP_WGRAD_LANE', '0') == '1':
+            return False
+        if v.kind != 'conv' or s.kind != 'conv' or s.src.kind != 'input' or not self._stem_bwd_fused(s, s.src):
+            return False
+        if not (v.k == 3 and v.stride == 2 and v.pad == 1 and v.C == 64 and v.c_phys == 64 and s.c_phys == 32 and not v.fp32):
+            return False
+        if s.parent is not None or s.c_off != 0 or s.ld != s.c_phys:
+            return False
+        users = 0
+        for u in values:
+            if u is v:
+                continue
+            refs = [getattr(u, 'src', None), getattr(u, 'res', None), getattr(u, 'a', None), getattr(u, 'b', None)]
+            refs += [part[0] for part in getattr(u, 'parts', [])] if u.kind == 'concat' else []
+            users += any(r is s for r in refs)
+        return users == 0
 
     @staticmethod
     def _junk(plan, grads, n):
