@@ -122,6 +122,43 @@ def test_next_data_gradient_fused_into_the_first_block_backward(monkeypatch):
         os.unlink(path)
 
 
+def test_loss_backward_writes_the_head_tensors_own_gradient(mini):
+    """engine/loss.py takes the NHWC head tensors the raw heads are views of as its autograd inputs (`_head_bases`): the fused loss
+    backward then writes the head tensor's own gradient and autograd's slice / view backward (zero fill + strided copy per head)
+    never runs.  Same loss, same parameter gradients as with plain view inputs."""
+    import copy
+    from engine import loss as hloss
+    from engine.padded import make_train_engine
+    from utils.utils import compute_loss
+    model = th.build(mini, 64)
+    model.nc, model.gr = 2, 1.0
+    model.hyp = {'giou': 3.54, 'cls': 37.4, 'cls_pw': 1.0, 'obj': 64.3, 'obj_pw': 1.0, 'iou_t': 0.20, 'fl_gamma': 0.0}
+    x = synth.image_batch(2, 64, seed=0)
+    targets = torch.tensor([[0, 1, 0.5, 0.5, 0.3, 0.4], [1, 0, 0.3, 0.6, 0.2, 0.2], [1, 1, 0.7, 0.2, 0.5, 0.3]])
+    outs = []
+    for use_bases in (True, False):
+        m = copy.deepcopy(model).train()
+        os.environ['YOLO_HIP_TRAIN_PRECISION'] = 'fp32'
+        try:
+            m.__dict__['_hip_train_engine'] = make_train_engine(m, 'fp32', x, lib=fakelib.FakeLib())
+            hloss._LIB_OVERRIDE = fakelib.FakeLib()
+            raws, _ = m._forward_hip_train(x)
+            bases = hloss._head_bases(raws)
+            assert bases is not None and all(b.dim() == 4 for b, _, _ in bases)
+            if not use_bases:
+                raws = [r * 1.0 for r in raws]          # fresh tensors: no longer views of the head tensors
+                assert hloss._head_bases(raws) is None
+            loss, items = compute_loss(raws, targets, m)
+            loss.backward()
+        finally:
+            hloss._LIB_OVERRIDE = None
+            del os.environ['YOLO_HIP_TRAIN_PRECISION']
+        outs.append((float(loss.detach()), {k: p.grad.clone() for k, p in m.named_parameters()}))
+    assert outs[0][0] == outs[1][0]
+    for k in outs[0][1]:
+        assert torch.equal(outs[0][1][k], outs[1][1][k]), k
+
+
 def _gray_model():
     import models
     # linear activations: a leaky kink that flips under a different fp32 summation order moves every upstream gradient by
