@@ -451,6 +451,39 @@ def test_int8_conv_matches_emulation(libs, case):
     assert diff.max().item() <= 1.0 and (diff > 0).float().mean().item() <= 1e-4, (diff.max().item(), (diff > 0).float().mean().item())
 
 
+@pytest.mark.parametrize('case', [(2, 19, 19, 128, 128, 3, 1, 1, 43), (3, 38, 38, 64, 255, 3, 1, 5, 43), (1, 76, 76, 192, 64, 3, 1, 0, 43),
+                                  (3, 37, 41, 32, 64, 3, 1, 1, 72), (2, 45, 43, 64, 128, 3, 2, 1, 72), (2, 33, 31, 64, 32, 3, 1, 5, 72)],
+                         ids=lambda c: 'q_n%d_%dx%d_c%d-%d_k%ds%d_a%d_t%d' % c)
+def test_int8_conv_matches_torch_directly(libs, case):
+    """the MFMA-i8 forms of the halo ping-pong and streaming 3x3 kernels against torch DIRECTLY, not against
+    tests/fakelib.py: the reference's eval arithmetic (quantized_ptq_cos.py:288-296, 543-567, 717) restated on float64 tensors -
+    integer convolution (exact), acc * s_w s_x + bias, activation, / s_a, round half away from zero, clamp to int8 - on random int8
+    operands.  Mish goes through float32 expf in the kernel: results on a rounding tie may differ by one grid step there."""
+    lib, _ = libs
+    import torch.nn.functional as F
+    N, H, W, cin, cout, k, s, act, tile = case
+    g = torch.Generator().manual_seed(hash(case) % (2 ** 31))
+    w_scale, x_scale, out_scale = 2.0 ** -9, 2.0 ** -5, 2.0 ** -4
+    qi = torch.randint(-127, 128, (cout, cin, k, k), generator=g).float() * (torch.rand(cout, cin, k, k, generator=g) < 0.5)
+    x = torch.randint(-128, 128, (N, H, W, cin), generator=g).to(torch.int8)
+    qb = torch.randint(-128, 128, (cout,), generator=g).float() * 2.0 ** -6
+    pad = (k - 1) // 2
+    y, _ = oh.qconv(lib, x.to(GPU), (qi * w_scale).to(GPU), w_scale, qb.to(GPU), w_scale * x_scale, out_scale, k, s, pad, act=act, tile=tile)
+    if GPU == 'cuda':
+        torch.cuda.synchronize()
+    acc = F.conv2d(x.double().permute(0, 3, 1, 2), qi.double(), None, s, pad)                  # exact integers
+    v = (acc.float() * (w_scale * x_scale) + qb.view(1, -1, 1, 1)).float()                      # the kernel's fp32 steps
+    v = {0: lambda t: t, 1: lambda t: torch.where(t > 0, t, t * 0.1), 5: lambda t: t * torch.tanh(F.softplus(t))}[act](v)
+    t = v / out_scale
+    want = torch.clamp(torch.sign(t) * torch.floor(t.abs() + 0.5), -128, 127).permute(0, 2, 3, 1)
+    got = y.float().cpu()[..., :cout]
+    diff = (got - want).abs()
+    if act == 5:
+        assert diff.max().item() <= 1.0 and (diff > 0).float().mean().item() <= 2e-3, (diff.max().item(), (diff > 0).float().mean().item())
+    else:
+        assert torch.equal(got, want), (diff.max().item(), (diff > 0).float().mean().item())
+
+
 @pytest.mark.parametrize('tile,stride,cout', [(0, 1, 64), (24, 1, 64), (72, 1, 64), (72, 2, 64), (72, 1, 32), (72, 1, 128)],
                          ids=['auto', 'ring', 'stream3', 'stream3_s2', 'stream3_c32', 'stream3_c128'])
 def test_int8_fused_shortcut_matches_emulation(libs, tile, stride, cout):

@@ -196,6 +196,28 @@ def test_wgrad_halo_form_is_exact_on_small_integers(libs, monkeypatch, case, wgs
     assert torch.equal(got.cpu(), ref)
 
 
+@pytest.mark.parametrize('case', [(2, 21, 19, 64, 256), (1, 76, 76, 128, 256), (3, 38, 38, 256, 512), (3, 33, 120, 32, 256)],
+                         ids=lambda c: 'n%d_%dx%d_c%d-%d' % c)
+def test_wgrad_halo_form_matches_autograd_on_random_operands(libs, case):
+    """`conv_wgrad_halo_kernel` against torch autograd DIRECTLY (float64 conv2d weight gradient of the same f16
+    operands), random - not small-integer - values: products exact in fp32, accumulation order the only difference (<= 1e-4 of the
+    gradient's scale, the bound of the im2col form in test_wgrad_matches_autograd)."""
+    if DRY:
+        pytest.skip('kernel-only property')
+    lib, _ = libs
+    N, H, W, cin, cout = case
+    g = torch.Generator().manual_seed(sum(case) + 1)
+    x = (torch.randn(N, H, W, cin, generator=g) * 0.7).half()
+    dz = (torch.randn(N, H, W, cout, generator=g) * 0.05).half()
+    d = oh.WgradDesc(n=N, h=H, w_in=W, cin=cin, ho=H, wo=W, cout=cout, kh=3, kw=3, stride=1, pad=1, ldx=cin, lddz=cout, dtype=F16, splits=0)
+    d.x = d.dz = d.dw = 4096
+    assert lib.yh_conv2d_wgrad_kernel(oh.C.byref(d)) == 90, 'the case must run on the halo kernel'
+    got = oh.wgrad(lib, F16, x.to(GPU), dz.to(GPU), cin, cout, 3, 1, 1, use_ws=True).cpu().double()
+    ref = torch.nn.grad.conv2d_weight(x.double().permute(0, 3, 1, 2), (cout, cin, 3, 3), dz.double().permute(0, 3, 1, 2), padding=1)
+    err = (got - ref).abs().max().item()
+    assert err <= 1e-4 * ref.abs().max().item(), (err, ref.abs().max().item())
+
+
 def test_wgrad_f16_exact_on_small_integers(libs):
     """Integer operands: every product and partial sum is exact, so MFMA + atomics must reproduce autograd bit for bit."""
     lib, _ = libs
@@ -915,6 +937,63 @@ def test_training_step_on_gpu_matches_reference_golden(libs, tag, rel, size, nc)
         den += float((rows ** 2).sum())
         assert abs(params[k].grad.abs().sum().item() - want[1]) <= 1e-2 * want[1] + 1e-6, k
     assert (num / den) ** 0.5 <= 3e-3
+
+
+def test_headline_shape_fp32_step_against_the_reference_golden(libs):
+    """the external anchor AT the shape the bench times.  tests/golden/train_step_608.npz is one training step of
+    the REFERENCE itself (YOLOv3 Darknet-53, 608 x 608, batch 2, fp32 CPU: train-mode forward, compute_loss, backward; generated by
+    tests/golden/make_golden_train608.py from /root/reference).  The fp32 HIP step on the GPU (train forward + fused compute_loss +
+    backward, every kernel of the fp32 path at 608 geometry) against it: loss items, raw-head checksums, running statistics, and the
+    parameter gradients in the l2 / cosine sense - a 75-conv random-weight net is ill-conditioned (one leaky-ReLU kink that flips
+    under a different summation order moves every upstream gradient: eager fp32 itself is ~1e-2 from an fp64 run)."""
+    if DRY:
+        pytest.skip('a 608 x 608 Darknet-53 step on the host emulation takes minutes; the emulator is covered at 64 - 128 px')
+    from models import Darknet
+    from utils.utils import compute_loss
+    import test_train_emulated as tte
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'train_step_608.npz'))
+    size, batch, stride = int(gold['size']), int(gold['batch']), int(gold['stride'])
+    torch.manual_seed(0)
+    model = Darknet(os.path.join(conftest.PKG, 'cfg', 'yolov3', 'yolov3.cfg'), (size, size))
+    state = model.state_dict()
+    synth.randomize_bn_(state, seed=1)
+    model.load_state_dict(state)
+    model.nc, model.hyp, model.gr = 80, dict(tte.GOLD_HYP), 1.0
+    targets = synth.loss_inputs(model, size, batch=batch, seed=9, labels_per_image=8)[1].to(GPU)
+    model.train().to(GPU)
+    x = synth.image_batch(batch, size, seed=0).to(GPU)
+    os.environ['YOLO_HIP_TRAIN_PRECISION'] = 'fp32'
+    try:
+        pred, _ = model(x)
+    finally:
+        del os.environ['YOLO_HIP_TRAIN_PRECISION']
+    assert model.__dict__.get('_hip_train_engine') is not None
+    loss, items = compute_loss(pred, targets, model)
+    loss.backward()
+    np.testing.assert_allclose(items.detach().cpu().numpy(), gold['items'], rtol=2e-3)
+    for i, p in enumerate(pred):
+        want = gold['raw%d_checks' % i]
+        got = p.detach().double()
+        assert abs(got.abs().sum().item() - want[1]) <= 2e-3 * want[1] and abs(got.abs().max().item() - want[2]) <= 1e-2 * want[2], i
+    params = dict(model.named_parameters())
+    names = [str(n) for n in gold['param_names']]
+    assert names == list(params)
+    rows = np.concatenate([params[k].grad.reshape(-1)[::stride].float().cpu().numpy() for k in names])
+    want = gold['grad_rows']
+    assert rows.shape == want.shape
+    rel = float(np.linalg.norm(rows - want) / np.linalg.norm(want))
+    cos = float((rows * want).sum() / (np.linalg.norm(rows) * np.linalg.norm(want)))
+    sums = np.array([params[k].grad.abs().sum().item() for k in names])
+    ratio = sums / np.maximum(gold['grad_checks'][:, 1], 1e-30)
+    big = gold['grad_checks'][:, 1] >= 1e-3 * gold['grad_checks'][:, 1].max()
+    print('608 b2 fp32 HIP step vs the reference golden: loss items %s, gradient rel l2 %.3g, cosine %.5f, |grad| sum ratio of the '
+          'dominant parameters %.3f .. %.3f' % (items.detach().cpu().numpy(), rel, cos, ratio[big].min(), ratio[big].max()))
+    assert rel <= 0.1 and cos >= 0.995, (rel, cos)
+    assert 0.8 <= ratio[big].min() and ratio[big].max() <= 1.25
+    sd = model.state_dict()
+    for k, w in zip([str(n) for n in gold['running_names']], gold['running_checks']):
+        got = sd[k].double()
+        assert abs(got.abs().sum().item() - w[1]) <= 1e-3 * w[1] + 1e-6, k
 
 
 def test_fused_loss_defers_the_label_check_without_a_host_sync(libs):
