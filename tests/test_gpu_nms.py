@@ -95,3 +95,26 @@ def test_hip_nms_bound_forgets_outliers_and_respects_the_mask_budget(monkeypatch
     got = non_max_suppression(dense, 0.05, 0.6, multi_label=True)
     for i in range(2):
         _compare(got[i], want_dense[i], 'budget path img %d' % i)
+
+
+def test_hip_nms_processes_large_batches_in_chunks(monkeypatch):
+    """test.py settings (conf 0.001, multi-label): thousands of candidates per image and an IoU bit mask quadratic in them.  With a
+    small work budget the batch is processed in image chunks; same boxes as one pass and as the oracle; a single image beyond the
+    budget raises MemoryError naming the candidate count."""
+    from engine import nms as hnms
+    from utils.utils import non_max_suppression
+    monkeypatch.setattr(hnms, '_density', {})
+    pred = synth.nms_candidates(5, 3000, 20, 71, n_clusters=40, hot=0.9).cuda()
+    want = oracle.non_max_suppression(pred.cpu().numpy(), 0.05, 0.6, multi_label=True)
+    one = non_max_suppression(pred, 0.05, 0.6, multi_label=True)
+    mmax = int(max(hnms._density[1]) * 3000)
+    assert mmax > 2000
+    monkeypatch.setattr(hnms, '_density', {})
+    monkeypatch.setattr(hnms, '_WORK_BUDGET', 2 * (mmax * 2) * ((mmax * 2 + 63) // 64) * 8)      # room for about two images
+    chunked = non_max_suppression(pred, 0.05, 0.6, multi_label=True)
+    for i in range(5):
+        _compare(one[i], want[i], 'one pass img %d' % i)
+        _compare(chunked[i], want[i], 'chunked img %d' % i)
+    monkeypatch.setattr(hnms, '_WORK_BUDGET', 1 << 16)
+    with pytest.raises(MemoryError):
+        non_max_suppression(pred, 0.05, 0.6, multi_label=True)

@@ -19,49 +19,96 @@ __device__ __forceinline__ bool finite6(float a, float b, float c, float d, floa
     return isfinite(a) && isfinite(b) && isfinite(c) && isfinite(d) && isfinite(e);
 }
 
-__device__ __forceinline__ void emit(float* cand, int32_t* count, int img, int cap, float x1, float y1, float x2,
+// Slot allocation aggregated per wave: the lanes that emit a candidate for the same image in this step share ONE atomicAdd (the
+// leader's; a wave spans at most two images) - at test.py's settings (conf 0.001, multi-label) an image emits 10^4 candidates and
+// every one of them used to be its own same-address atomic (3.4 ms for 16 images of 21 000).
+__device__ __forceinline__ void emit(float* cand, int32_t* count, int img, int cap, bool want, float x1, float y1, float x2,
                                      float y2, float score, int cls, int key) {
-    const int slot = atomicAdd(count + img, 1);
-    if (cand == nullptr || slot >= cap) return;
-    float* r = cand + ((long)img * cap + slot) * REC;
-    f32x4 lo = {x1, y1, x2, y2};
-    f32x4 hi = {score, (float)cls, __int_as_float(key), 0.f};
-    *reinterpret_cast<f32x4*>(r) = lo;
-    *reinterpret_cast<f32x4*>(r + 4) = hi;
+    unsigned long long todo = __ballot(want);
+    const int lane = threadIdx.x & 63;
+    while (todo) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const int limg = __shfl(img, leader);
+        const unsigned long long same = __ballot(want && img == limg);
+        int base = 0;
+        if (lane == leader) base = atomicAdd(count + limg, __popcll(same));
+        base = __shfl(base, leader);
+        if (want && img == limg) {
+            const int slot = base + __popcll(same & ((1ull << lane) - 1ull));
+            if (cand != nullptr && slot < cap) {
+                float* r = cand + ((long)img * cap + slot) * REC;
+                f32x4 lo = {x1, y1, x2, y2};
+                f32x4 hi = {score, (float)cls, __int_as_float(key), 0.f};
+                *reinterpret_cast<f32x4*>(r) = lo;
+                *reinterpret_cast<f32x4*>(r + 4) = hi;
+            }
+        }
+        todo &= ~same;
+    }
 }
 
-// one thread per prediction row
+// multi-label (test.py: every class score above the threshold is a candidate): one thread per (row, class), classes fastest, so a
+// wave reads consecutive class scores of ONE row (coalesced) and the row's box / objectness as broadcasts; rows below the
+// objectness threshold (99 % of them) cost one load.  Every lane of a wave runs emit() once (the ballots need the whole wave).
+__global__ __launch_bounds__(256) void nms_candidates_ml_kernel(const float* __restrict__ pred, int n, int rows, int nc, float conf,
+                                                                const uint8_t* __restrict__ class_mask, float* cand, int32_t* count,
+                                                                int cap) {
+    const long total = (long)n * rows * nc;
+    const int no = nc + 5;
+    const long span = (long)gridDim.x * blockDim.x;
+    const long iters = (total + span - 1) / span;
+    for (long it = 0; it < iters; ++it) {
+        const long i = it * span + blockIdx.x * (long)blockDim.x + threadIdx.x;
+        bool want = i < total;
+        const long rw = (want ? i : 0) / nc;
+        const int c = (int)((want ? i : 0) - rw * nc);
+        const float* x = pred + rw * no;
+        const float obj = x[4];
+        want = want && obj > conf;
+        float x1 = 0.f, y1 = 0.f, x2 = 0.f, y2 = 0.f, sc = 0.f;
+        if (want) {
+            const float w = x[2], h = x[3];
+            want = w > kMinWH && w < kMaxWH && h > kMinWH && h < kMaxWH;
+            const float cx = x[0], cy = x[1];
+            x1 = cx - w / 2; y1 = cy - h / 2; x2 = cx + w / 2; y2 = cy + h / 2;
+            sc = x[5 + c] * obj;
+            want = want && sc > conf && (!class_mask || class_mask[c]) && finite6(x1, y1, x2, y2, sc);
+        }
+        const int img = (int)(rw / rows), row = (int)(rw - (long)img * rows);
+        emit(cand, count, img, cap, want, x1, y1, x2, y2, sc, c, row * nc + c);
+    }
+}
+
+// best class only (detect.py): one thread per prediction row
 __global__ __launch_bounds__(256) void nms_candidates_kernel(const float* __restrict__ pred, int n, int rows, int nc,
-                                                             float conf, int multi_label,
-                                                             const uint8_t* __restrict__ class_mask, float* cand,
+                                                             float conf, const uint8_t* __restrict__ class_mask, float* cand,
                                                              int32_t* count, int cap) {
     const long total = (long)n * rows;
     const int no = nc + 5;
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const float* x = pred + i * no;
+    const long span = (long)gridDim.x * blockDim.x;
+    const long iters = (total + span - 1) / span;
+    for (long it = 0; it < iters; ++it) {
+        const long i = it * span + blockIdx.x * (long)blockDim.x + threadIdx.x;
+        bool live = i < total;
+        const float* x = pred + (live ? i : 0) * no;
         const float obj = x[4];
-        if (!(obj > conf)) continue;
+        live = live && obj > conf;
         const float w = x[2], h = x[3];
-        if (!(w > kMinWH && w < kMaxWH && h > kMinWH && h < kMaxWH)) continue;
-        const int img = (int)(i / rows), row = (int)(i - (long)img * rows);
+        live = live && (w > kMinWH && w < kMaxWH && h > kMinWH && h < kMaxWH);
+        const int img = (int)((live ? i : 0) / rows), row = (int)((live ? i : 0) - (long)img * rows);
         const float cx = x[0], cy = x[1];
         const float x1 = cx - w / 2, y1 = cy - h / 2, x2 = cx + w / 2, y2 = cy + h / 2;
-        if (multi_label) {
-            for (int c = 0; c < nc; ++c) {
-                const float s = x[5 + c] * obj;
-                if (s > conf && (!class_mask || class_mask[c]) && finite6(x1, y1, x2, y2, s))
-                    emit(cand, count, img, cap, x1, y1, x2, y2, s, c, row * nc + c);
-            }
-        } else {
-            float best = x[5] * obj;
-            int bc = 0;
+        float best = 0.f;
+        int bc = 0;
+        if (live) {
+            best = x[5] * obj;
             for (int c = 1; c < nc; ++c) {
                 const float s = x[5 + c] * obj;
                 if (s > best) { best = s; bc = c; }
             }
-            if ((!class_mask || class_mask[bc]) && finite6(x1, y1, x2, y2, best))
-                emit(cand, count, img, cap, x1, y1, x2, y2, best, bc, row * nc + bc);
         }
+        const bool want = live && (!class_mask || class_mask[bc]) && finite6(x1, y1, x2, y2, best);
+        emit(cand, count, img, cap, want, x1, y1, x2, y2, best, bc, row * nc + bc);
     }
 }
 
@@ -142,8 +189,13 @@ __global__ __launch_bounds__(64) void nms_mask_kernel(const float* __restrict__ 
     const f32x4 me = offset_box(base + (long)i * REC, agnostic);
     const int lim = min(64, m - cb * 64);
     unsigned long long bits = 0;
-    for (int k = (rb == cb ? threadIdx.x + 1 : 0); k < lim; ++k)
-        if (iou_off(me, cols[k]) > thr) bits |= 1ull << k;
+    for (int k = (rb == cb ? threadIdx.x + 1 : 0); k < lim; ++k) {
+        // boxes of different classes are offset by 4096 per class: almost every pair has no overlap extent at all.  Rejecting those
+        // before the divide changes nothing (inter = 0 gives IoU 0 or NaN, neither > thr) and is most of the pairs at 10^4 candidates
+        const f32x4 o = cols[k];
+        if (!(fminf(me[2], o[2]) > fmaxf(me[0], o[0]) && fminf(me[3], o[3]) > fmaxf(me[1], o[1]))) continue;
+        if (iou_off(me, o) > thr) bits |= 1ull << k;
+    }
     mask[((long)img * mmax + i) * words + cb] = bits;
 }
 
@@ -166,6 +218,8 @@ __global__ __launch_bounds__(256) void nms_reduce_kernel(const unsigned long lon
     for (int w = threadIdx.x; w < mw; w += blockDim.x) remv[w] = 0;
     if (threadIdx.x == 0) kept_total = 0;
     __syncthreads();
+    // (A/B, profiles/r04_nms_stages.txt: holding the diagonal words in wave 0's registers and resolving a step through lane reads
+    // was SLOWER - 3.2 vs 2.8 ms at 21 000 candidates: the variable-lane read became a ds_bpermute per box.)
     for (int blk = 0; blk < mw; ++blk) {
         const int lim = min(64, m - blk * 64);
         if ((int)threadIdx.x < lim) diag[threadIdx.x] = mk[((long)blk * 64 + threadIdx.x) * words + blk];
@@ -185,13 +239,20 @@ __global__ __launch_bounds__(256) void nms_reduce_kernel(const unsigned long lon
         }
         __syncthreads();
         const unsigned long long kb = keep_bits;
+        // the suppression rows of this step's kept boxes, OR-ed into the words still to come.  Eight rows per trip, their loads
+        // independent of each other (kb is uniform: no divergence) - the one-row-at-a-time form paid a memory latency per kept box
+        // (5.6 ms for 16 images of 21 000 candidates, the slowest stage of the evaluation-settings NMS)
         for (int w = blk + 1 + threadIdx.x; w < mw; w += blockDim.x) {
             unsigned long long acc = remv[w];
-            unsigned long long rest = kb;
-            while (rest) {
-                const int b = __ffsll((long long)rest) - 1;
-                rest &= rest - 1;
-                acc |= mk[((long)blk * 64 + b) * words + w];
+            const unsigned long long* col = mk + (long)blk * 64 * words + w;
+#pragma unroll 1
+            for (int b0 = 0; b0 < 64; b0 += 8) {
+                const unsigned g8 = (unsigned)(kb >> b0) & 0xffu;
+                if (!g8) continue;
+                unsigned long long v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = ((g8 >> u) & 1u) ? col[(long)(b0 + u) * words] : 0ull;
+                acc |= (v[0] | v[1]) | (v[2] | v[3]) | ((v[4] | v[5]) | (v[6] | v[7]));
             }
             remv[w] = acc;
         }
@@ -247,11 +308,15 @@ extern "C" int yh_nms_candidates(const float* pred, int n, int rows, int nc, flo
                                  const uint8_t* class_mask, float* cand, int32_t* count, int cap, void* stream) {
     if (!pred || !count || n <= 0 || rows <= 0 || nc <= 0 || cap < 0) return YH_EINVAL;
     if (cand && !aligned16(cand)) return YH_EALIGN;
-    const long total = (long)n * rows;
+    const long total = (long)n * rows * (multi_label ? nc : 1);
     long g = (total + 255) / 256;
-    if (g > 4096) g = 4096;
-    hipLaunchKernelGGL(nms_candidates_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, pred, n, rows, nc, conf_thres,
-                       multi_label, class_mask, cand, count, cap);
+    if (g > 65536) g = 65536;
+    if (multi_label)
+        hipLaunchKernelGGL(nms_candidates_ml_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, pred, n, rows, nc, conf_thres,
+                           class_mask, cand, count, cap);
+    else
+        hipLaunchKernelGGL(nms_candidates_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, pred, n, rows, nc, conf_thres,
+                           class_mask, cand, count, cap);
     return check_launch();
 }
 

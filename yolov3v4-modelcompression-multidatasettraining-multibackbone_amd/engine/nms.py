@@ -5,6 +5,11 @@ survived per image).  The candidate buffers are therefore sized by an upper boun
 counts; every kernel takes the per-image counts from device memory.  The single read returns candidate counts and survivor
 counts together; only when an image had more candidates than the bound the pass is repeated with an exact bound (a second read).
 
+Evaluation settings (test.py: conf 0.001, multi-label) produce 10^3 - 10^5 candidates per image, and the IoU bit mask is quadratic
+in the bound: when the buffers of a batch would exceed ``_WORK_BUDGET`` the images are processed in chunks (the reference's loop is
+per image anyway, utils.py:797); a single image beyond the budget raises MemoryError with the candidate count (torchvision's
+bit-mask NMS, which the reference calls, fails the same way).
+
 The bound is a power of two with 2x head-room over the candidate DENSITY (candidates per prediction row) of the last few calls:
 keyed on the label mode only, so the rectangular shapes of an evaluation run share it, and windowed, so one outlier batch (or
 a test.py call at conf 0.001 before a detect.py call at conf 0.3) stops costing memory after ``_HINT_WINDOW`` calls.  The IoU
@@ -21,6 +26,7 @@ MERGE_LO, MERGE_HI = 1, 3000  # merge-NMS applies for 1 < n < 3000 (utils.py:845
 _CAP_MIN = 256
 _HINT_WINDOW = 8              # calls a density observation is remembered for
 _MASK_BUDGET = 256 << 20      # bytes of IoU bit mask a *guessed* bound may cost; above it the counts are read first
+_WORK_BUDGET = 8 << 30        # bytes of candidate / mask buffers one pass may hold: larger batches are processed in image chunks
 _density = {}                 # multi_label -> deque of the last candidate densities (max candidates of an image / rows)
 
 
@@ -58,11 +64,29 @@ def _non_max_suppression(prediction, conf_thres, iou_thres, multi_label, classes
     cap = min(guess, _pow2_at_least(most))
     ag = 1 if agnostic else 0
     exact = False
+
+    def per_image_bytes(c):
+        return c * ((c + 63) // 64) * 8 + c * (8 + 8 + 6 + 1) * 4
+
+    def in_chunks(c):
+        """Run the images in groups whose buffers fit the budget and concatenate the results."""
+        if per_image_bytes(c) > _WORK_BUDGET:
+            raise MemoryError('non_max_suppression: %d candidates in one image need a %.1f GB IoU bit mask (conf_thres %g, %s): raise '
+                              'conf_thres' % (c, per_image_bytes(c) / 1e9, conf_thres, 'multi-label' if ml else 'best class'))
+        step = max(1, int(_WORK_BUDGET // per_image_bytes(c)))
+        out = []
+        for i in range(0, n, step):
+            out += _non_max_suppression(pred[i:i + step], conf_thres, iou_thres, multi_label, classes, agnostic)
+        return out
+
     if n * cap * ((cap + 63) // 64) * 8 > _MASK_BUDGET:
         # a guessed bound this large is not worth its mask: count first (one extra 4n-byte read), then size exactly
         count = torch.zeros(n, dtype=torch.int32, device=dev)
         hiplib.check(lib.yh_nms_candidates(P(pred), n, rows, nc, conf_thres, ml, P(cmask), None, P(count), 0, S), 'nms count')
         cap, exact = _pow2_at_least(max(int(count.max()), 1)), True
+        if n * per_image_bytes(cap) > _WORK_BUDGET and (n > 1 or per_image_bytes(cap) > _WORK_BUDGET):
+            _density.setdefault(ml, collections.deque(maxlen=_HINT_WINDOW)).append(cap / 2.0 / float(rows))
+            return in_chunks(cap)
     while True:
         words = (cap + 63) // 64
         counts = torch.zeros((2, n), dtype=torch.int32, device=dev)     # row 0: candidates per image, row 1: survivors
@@ -84,6 +108,9 @@ def _non_max_suppression(prediction, conf_thres, iou_thres, multi_label, classes
             break
         assert not exact, 'candidate count changed between the count pass and the emit pass'
         cap = _pow2_at_least(mmax)             # an image overflowed the bound: repeat with one that holds every candidate
+        if n * per_image_bytes(cap) > _WORK_BUDGET and (n > 1 or per_image_bytes(cap) > _WORK_BUDGET):
+            _density.setdefault(ml, collections.deque(maxlen=_HINT_WINDOW)).append(mmax / float(rows))
+            return in_chunks(cap)
     _density.setdefault(ml, collections.deque(maxlen=_HINT_WINDOW)).append(mmax / float(rows))
     out = [None] * n
     for i in range(n):
