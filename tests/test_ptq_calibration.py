@@ -200,6 +200,85 @@ def test_calibration_on_the_gpu_then_int8_engine(cfg_dir):
     assert (d[..., :4] > 0.05).float().mean().item() <= 0.02 and (d[..., 4:] > 2e-3).float().mean().item() <= 0.02
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize('tag', ['v3_608', 'v4_640'])
+def test_device_calibration_at_the_baseline_shapes_then_int8_engine(tag):
+    """`PTQ.py`-style calibration of the BASELINE networks on the GPU - YOLOv3-608 and YOLOv4-640, batch 2,
+    3 calibration batches, every scale search and every calibration-mode convolution through engine/calib.py (csrc/calib.hip,
+    yh_conv2d_fwd fp32) - against the scale decisions of the SAME recipe on the host (tests/golden/ptq_calib_<tag>.npz, written by
+    tests/golden/make_golden_ptq608.py with the module's host loop, i.e. the reference's loop quantized_ptq_cos.py:64-93): all but
+    the documented cosine near-ties coincide.  Then the calibrated graph in eval mode: the int8 MFMA engine's raw heads equal the
+    calibrated modules' own CPU evaluation bit for bit on dyadic frames (the stem's fp32 conv is exact there)."""
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU')
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('make_golden_ptq608', os.path.join(os.path.dirname(GOLD), 'make_golden_ptq608.py'))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    rel, size = gen.CASES[tag]
+    gold = np.load(os.path.join(os.path.dirname(GOLD), 'ptq_calib_%s.npz' % tag))
+    # every search of the run is ALSO evaluated by the reference's loop (fp32 torch reductions) on the same device tensor: a decision
+    # that differs must be a tie of that loop's own cosines
+    import utils.quantized.quantized_ptq_cos as q
+    from engine import calib
+    log = []
+    dev_search = q._search
+
+    def both(t, first_step, n, bits):
+        j_dev, cos_dev = dev_search(t, first_step, n, bits)
+        os.environ['YOLO_PTQ_HOST_SEARCH'] = '1'
+        try:
+            j_host, cos_host = dev_search(t, first_step, n, bits)
+        finally:
+            del os.environ['YOLO_PTQ_HOST_SEARCH']
+        log.append((j_dev, j_host, float(cos_host[j_dev]), float(cos_host[j_host]), float(max(cos_dev))))
+        return j_dev, cos_dev
+    q._search = both
+    try:
+        qm, scales = gen.calibrated_scales(rel, size, device='cuda')
+    finally:
+        q._search = dev_search
+    differ = [(a, b, ca, cb) for a, b, ca, cb, _ in log if a != b]
+    gap = max([abs(ca - cb) for _, _, ca, cb in differ] or [0.0])
+    print('%s: %d cosine searches on the device, %d decided differently by the fp32 loop on the same tensor; largest cosine gap between the '
+          'two choices %.2g' % (tag, len(log), len(differ), gap))
+    assert len(log) >= 400 and len(differ) <= 0.1 * len(log) and gap <= 2e-5
+    assert set(scales) == set(gold.files) and len(scales) >= 500
+    same = sum(bool(np.array_equal(scales[k], gold[k])) for k in scales)
+    worst = max(float(np.max(np.maximum(scales[k] / gold[k], gold[k] / scales[k]))) for k in scales if np.all(gold[k] > 0) and np.all(scales[k] > 0))
+    steps = np.concatenate([np.abs(np.log2(scales[k] / gold[k])).reshape(-1) for k in scales if np.all(gold[k] > 0) and np.all(scales[k] > 0)])
+    print('%s calibration on the GPU vs the host-calibrated golden: %d of %d scale tensors identical, largest ratio %.3g; per scale value: %.1f %% '
+          'equal, %.1f %% one power-of-two step apart, %.1f %% two' % (tag, same, len(scales), worst, 100 * np.mean(steps == 0),
+                                                                       100 * np.mean(steps == 1), 100 * np.mean(steps == 2)))
+    # Against the golden (written in the build container: oneDNN convolutions, fp32 cosine sums) the comparison is statistical: votes
+    # over power-of-two candidates whose cosines tie to 1e-6 flip with the last bits of the tensors, and in a 75 / 110-layer net one
+    # flipped activation scale changes every tensor behind it.  Measured: ~80 % of the tensors identical, the rest one or two steps.
+    assert same >= 0.6 * len(scales) and worst <= 4.0
+    qm.eval()
+    x = synth.dyadic_frames(synth.image_batch(1, size, seed=77))
+    with torch.no_grad():
+        io, raws, _ = qm(x.cuda())
+    eng = qm.__dict__['_hip_engine']
+    assert eng is not None and eng.precision == 'int8'
+    cpu = copy.deepcopy(qm).cpu()
+    cpu.__dict__['_hip_engine'] = None
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    with torch.no_grad():
+        _, raws_cpu, _ = cpu(x)
+    off = [((a.cpu() != b).float().mean().item(), (a.cpu() - b).abs().max().item()) for a, b in zip(raws, raws_cpu)]
+    print('%s int8 engine vs the calibrated modules on the CPU, dyadic frame: fraction of head values that differ %s, largest difference %s'
+          % (tag, ['%.2g' % f for f, _ in off], ['%.3g' % d for _, d in off]))
+    if tag == 'v3_608':      # leaky ReLU: integer arithmetic end to end -> bit for bit
+        for a, b in zip(raws, raws_cpu):
+            assert torch.equal(a.cpu(), b), (a.cpu() - b).abs().max().item()
+    else:
+        # Mish is evaluated in fp32 on both sides, by different formulas (the kernel: v n / (n + 2) with n = e^v (e^v + 2) on expf;
+        # torch on the CPU: v tanh(softplus(v))): values that land on a rounding tie of the next grid can come out one step apart,
+        # and a 110-layer quantised net carries such a flip to its heads.  Bounded, not bit-equal (the synthetic power-of-two state
+        # of tests/test_ptq_large.py happens to be bit-equal; the reference itself cannot calibrate this cfg at all, SURVEY 8c).
+        assert all(f <= 0.15 for f, _ in off), off
+
+
 # ------------------------------------------------------------------------------ device calibration services (csrc/calib.hip)
 def _calibrate(qm, way_device, monkeypatch, batches=3):
     import utils.quantized.quantized_ptq_cos as q
