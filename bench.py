@@ -154,6 +154,39 @@ def build_qmodel_synthetic(cfg, size, device, float_model=None, frames=None):
     return qm.to(device).eval()
 
 
+def build_qmodel_calibrated(cfg, size, device, float_model, frames, batches=3, batch=2):
+    """The COS-PTQ graph calibrated ON THE DEVICE as PTQ.py does it (reference PTQ.py:60-100: train-mode forwards over calibration
+    batches; every scale vote through csrc/calib.hip, every calibration convolution through yh_conv2d_fwd fp32): `batches` batches of
+    `batch` frames of the bench input.  tests/test_ptq_calibration.py::test_device_calibration_at_the_baseline_shapes_then_int8_engine
+    pins this flow (every search equals the reference's loop on the same tensor; the calibrated int8 engine equals the calibrated
+    modules' CPU evaluation)."""
+    import models
+    fm = float_model
+    torch.manual_seed(0)
+    qm = models.Darknet(cfg, (size, size), quantized=3, a_bit=8, w_bit=8, shortcut_way=1)
+    with torch.no_grad():     # load_darknet_weights(quant=True) semantics (reference models.py:610-628): BN tensors land on the conv
+        for f, q in zip(fm.module_list, qm.module_list):
+            if isinstance(f, torch.nn.Sequential) and len(f) and isinstance(f[0], torch.nn.Conv2d):
+                qc = q[0]
+                qc.weight.data.copy_(f[0].weight.data.float())
+                bn = f[1] if len(f) > 1 and isinstance(f[1], torch.nn.modules.batchnorm.BatchNorm2d) else None
+                if bn is not None:
+                    qc.gamma.data.copy_(bn.weight.data.float())
+                    qc.beta.data.copy_(bn.bias.data.float())
+                    qc.running_mean.copy_(bn.running_mean.float())
+                    qc.running_var.copy_(bn.running_var.float())
+                else:
+                    qc.bias.data.copy_(f[0].bias.data.float())
+                    qc.gamma.data.zero_()
+                    qc.beta.data.zero_()
+    qm.to(device).train()
+    with torch.no_grad():
+        for it in range(batches):
+            lo = (it * batch) % max(1, frames.shape[0] - batch + 1)
+            qm(frames[lo:lo + batch].float())
+    return qm.eval()
+
+
 def conv_flops(plan):
     """Algorithmic FLOPs (2 x MACs on logical channels) of every conv op of a built plan, by op index."""
     flops = {}
@@ -764,7 +797,18 @@ def detect_main(args, device, dist, world, rank, cpu_baseline_leg=True, eval_nms
         if not args.raw_heads:
             heads = detector_like_heads_(fm, x[:min(16, args.batch)], per_image=args.nms_candidates)
         if args.precision == 'int8':
-            model = build_qmodel_synthetic(args.cfg, args.size, device, float_model=fm, frames=None if args.raw_heads else x[:2])
+            calib = 'synthetic power-of-two state covering the float ranges (tools/synthetic_ptq.py)'
+            model = None
+            if not args.raw_heads and os.environ.get('YOLO_BENCH_PTQ', 'device') == 'device':
+                try:
+                    model = build_qmodel_calibrated(args.cfg, args.size, device, fm, x[:min(6, args.batch)])
+                    calib = 'COS-PTQ calibrated on the device, 3 batches of 2 bench frames (engine/calib.py)'
+                except Exception as e:      # noqa: BLE001 - timing leg: fall back to the synthetic state, say so
+                    calib += '; device calibration failed: %s: %s' % (type(e).__name__, str(e)[:120])
+                    model = None
+            if model is None:
+                model = build_qmodel_synthetic(args.cfg, args.size, device, float_model=fm, frames=None if args.raw_heads else x[:2])
+            heads = dict(heads or {}, int8_state=calib)
         else:
             model = fm
         del fm
