@@ -50,7 +50,7 @@ TILE_NAMES = {1: '128x128', 2: '64x256', 3: '32x256', 4: '64x128', 5: '128x64', 
               14: '64x128k8', 15: '128x64k8', 16: '256x128k8', 21: 'dma3_128x128', 22: 'dma3_64x256', 24: 'dma3_64x128',
               25: 'dma3_128x64', 26: 'dma3_256x128', 27: 'dma3_128x256', 41: 'halo_128x256', 43: 'hpp_128x512', 51: 'abl_noload', 52: 'abl_nomfma', 42: 'halo_256x256', 31: 'dma4_128x128', 32: 'dma4_64x256', 34: 'dma4_64x128',
               35: 'dma4_128x64', 61: 'k64_256x256', 62: 'k64_128x512', 63: 'k64_256x128w4', 64: 'pp_256x256', 65: 'pp_128x512',
-              66: 'pp_512x128', 67: 'pp2_256x256', 68: 'pp2_128x512', 69: 'pp2_512x128', 71: 'pw_stream', 72: 's3_stream'}
+              66: 'pp_512x128', 67: 'pp2_256x256', 68: 'pp2_128x512', 69: 'pp2_512x128', 71: 'pw_stream', 72: 's3_stream', 73: 'pwl_stream'}
 
 
 def tile_name(code):
@@ -259,6 +259,10 @@ def rocprof_kernel_name(kernel):
     import re
     m = re.match(r'conv_igemm_(fp16|int8|fp32)_(dma3|halo|pp|hpp)_(\d+x\d+)$', kernel)
     if not m:
+        m2 = re.match(r'conv_igemm_(fp16|int8)_(pwl_stream|s3_stream|pw_stream)$', kernel)
+        if m2:
+            t = {'fp16': 'f16', 'int8': 'i8'}[m2.group(1)]
+            return {'pwl_stream': 'conv1x1_lds_kernel', 's3_stream': 'conv3x3_stream<%s>' % t, 'pw_stream': 'conv_pointwise_kernel'}[m2.group(2)]
         return None
     t = {'fp16': 'f16', 'int8': 'i8', 'fp32': 'f32'}[m.group(1)]
     return {'dma3': 'conv_igemm_glds<%s,%s,%s,S3>', 'halo': 'conv3x3_halo<%s,%s,%s>', 'pp': 'conv_igemm_pp<%s,%s,%s>',

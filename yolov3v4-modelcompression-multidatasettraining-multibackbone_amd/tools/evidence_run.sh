@@ -1,15 +1,18 @@
 #!/bin/bash
-# Evidence run on a GPU box (what produced profiles/r03_*): full GPU test tier, smoke, the default bench line, rocprofv3 stats of the same
-# command, HBM traffic (FETCH_SIZE / WRITE_SIZE, one counter per pass) and SQ / TCC counters of the training step, per-layer tables.
-# Usage:  gpurun --timeout 2400 -- bash yolov3v4-modelcompression-multidatasettraining-multibackbone_amd/tools/evidence_run.sh TAG
-# Everything lands under gpurun_out/TAG_*; copy what is to be kept into profiles/.
+# Evidence run on a GPU box (what produced profiles/r04_*): full GPU test tier, smoke, the default bench line, rocprofv3 stats of the same
+# command, HBM traffic (FETCH_SIZE / WRITE_SIZE, one counter per pass, aggregated PER DISPATCH) and SQ / TCC counters of the training step,
+# per-layer tables.
+# Usage:  gpurun --timeout 3000 -- bash yolov3v4-modelcompression-multidatasettraining-multibackbone_amd/tools/evidence_run.sh TAG [notests]
+# Everything lands under gpurun_out/TAG_*; copy what is to be kept into profiles/ (hbm_traffic.json: gpurun_out/TAG_hbm_traffic.json).
 R="$GRAFT_REPO_ROOT"; cd "$R" || exit 1
 PKG=$R/yolov3v4-modelcompression-multidatasettraining-multibackbone_amd
 T=$PKG/tools
 TAG=${1:-evidence}
 mkdir -p gpurun_out
 export TMPDIR=/tmp
-( timeout 1500 python -m pytest tests -m gpu -q -s 2>&1 | grep -v "^Model Summary\|amdgpu.ids" | grep "passed\|failed\|FAILED\|Error\|int8 vs\|raw heads\|mAP\|608 b64\|drift\|pruned mobilenet\|calibration on" | tail -70 ) > gpurun_out/${TAG}_tests.log 2>&1
+if [ "$2" != "notests" ]; then
+( timeout 1800 python -m pytest tests -m gpu -q -s 2>&1 | grep -v "^Model Summary\|amdgpu.ids" | grep "passed\|failed\|FAILED\|Error\|int8 vs\|raw heads\|mAP\|608 b\|drift\|pruned mobilenet\|calibration on\|cosine searches\|int8 engine vs" | tail -80 ) > gpurun_out/${TAG}_tests.log 2>&1
+fi
 ( timeout 200 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | grep -v "^Model Summary\|amdgpu.ids" | tail -4 ) > gpurun_out/${TAG}_smoke.log 2>&1
 ( timeout 900 python bench.py 2>&1 | tail -1 ) > gpurun_out/${TAG}_bench_default.json 2>&1
 cd /tmp
@@ -26,9 +29,21 @@ python $T/rocprof_summary.py stats $(find /tmp/prof_default -name "*.db" | head 
 python $T/rocprof_summary.py traffic gpurun_out/${TAG}_traffic_train.json $(find /tmp/prof_train_FETCH_SIZE /tmp/prof_train_WRITE_SIZE -name "*.db") > gpurun_out/${TAG}_traffic.log 2>&1
 python $T/rocprof_summary.py traffic gpurun_out/${TAG}_traffic_detect.json $(find /tmp/prof_det_FETCH_SIZE /tmp/prof_det_WRITE_SIZE -name "*.db") >> gpurun_out/${TAG}_traffic.log 2>&1
 python $T/rocprof_summary.py traffic gpurun_out/${TAG}_traffic_int8.json $(find /tmp/prof_i8_FETCH_SIZE /tmp/prof_i8_WRITE_SIZE -name "*.db") >> gpurun_out/${TAG}_traffic.log 2>&1
+python - <<PY
+import json
+out = {'_note': 'HBM bytes per dispatch per kernel from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py (tools/evidence_run.sh); '
+               'per-dispatch means; fetch_kib_raw = counter as read, hbm_bytes_per_dispatch = 2 x fetch + write (see tools/rocprof_summary.py traffic and '
+               'profiles/r04_traffic_calibration.txt: exact for streaming reads, an upper bound for kernels that fetch 64-byte row pieces)'}
+for sec, f in (('train_batch64', 'train'), ('batch64', 'detect'), ('batch64_int8', 'int8')):
+    try:
+        out[sec] = json.load(open('gpurun_out/${TAG}_traffic_%s.json' % f))
+    except Exception as e:
+        out[sec] = {'_error': str(e)}
+json.dump(out, open('gpurun_out/${TAG}_hbm_traffic.json', 'w'), indent=1, sort_keys=True)
+PY
 python $T/rocprof_summary.py pmc $(find /tmp/pmc_sq /tmp/pmc_tcc -name "*.db") > gpurun_out/${TAG}_pmc_train.txt 2>&1
 timeout 300 python $T/profile_train.py --batch 64 --size 608 > gpurun_out/${TAG}_train_layers.txt 2>&1
 timeout 300 python $T/profile_layers.py --batch 64 --size 608 > gpurun_out/${TAG}_layers_fp16.txt 2>&1
 timeout 300 python $T/profile_layers.py --batch 64 --size 608 --precision int8 > gpurun_out/${TAG}_layers_int8.txt 2>&1
 timeout 600 python $T/pruned_finetune.py --bench > gpurun_out/${TAG}_pruned.txt 2>&1
-tail -12 gpurun_out/${TAG}_tests.log; cat gpurun_out/${TAG}_smoke.log; cut -c1-300 gpurun_out/${TAG}_bench_default.json; head -14 gpurun_out/${TAG}_rocprof_stats.txt; cat gpurun_out/${TAG}_traffic.log; tail -5 gpurun_out/${TAG}_pruned.txt
+tail -14 gpurun_out/${TAG}_tests.log 2>/dev/null; cat gpurun_out/${TAG}_smoke.log; cut -c1-300 gpurun_out/${TAG}_bench_default.json; head -14 gpurun_out/${TAG}_rocprof_stats.txt; cat gpurun_out/${TAG}_traffic.log; tail -5 gpurun_out/${TAG}_pruned.txt
