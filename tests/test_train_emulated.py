@@ -511,8 +511,10 @@ def test_live_running_statistics_edited_between_steps_reach_the_padded_twin():
         with torch.no_grad():
             bn.running_mean.fill_(7.0)
             bn.running_var.fill_(3.0)
+            bn.num_batches_tracked.zero_()          # a live reset of the step counter must reach the twin as well
         ref_mean = 0.9 * bn.running_mean.clone()
         model._forward_hip_train(x)
+        assert int(bn.num_batches_tracked) == 1
         # new = 0.9 * edited + 0.1 * batch statistic: with the edit reverted it would sit near 0.1 * batch, far from 6.3
         assert (bn.running_mean - ref_mean).abs().max().item() < 0.5
         assert bn.running_var.min().item() > 2.0
