@@ -428,6 +428,239 @@ __global__ __launch_bounds__(512, 2) void conv3x3_hpp_kernel(const ConvArgs a, c
     }
 }
 
+// ---- PERSISTENT form (tile code 44; round 4).  The kernel above pays ~29 000 cycles per 128 x 512 tile outside its K loop - workgroup
+// launch, index set-up, the first halo image and weight stages arriving into an idle CU, the epilogue's stores draining before the CU
+// takes its next workgroup - as much as 22 K steps; a 76 x 76 128 -> 256 layer has 18.  Here one
+// workgroup per CU walks over its tiles (the same XCD-chunked order) and the stream never stops at a tile boundary:
+//   * the weight ring keeps running: in the last three K steps of a tile the stages of the NEXT tile's steps 0 .. 2 are issued;
+//   * the next tile's first halo image is fetched during the current tile's last channel chunk, exactly like a next chunk's image;
+//   * the two wave groups re-align for the epilogue and stagger again for the next tile (one barrier interval per tile);
+//   * halo piece offsets are computed when a piece is issued (multiply-high divisions), not held in registers: the next tile's
+//     offsets need no state, and the kernel has LB registers fewer than the one above.
+// The epilogue's stores sit on the same in-order queue as the next tile's LDS-DMA: the first counted waits of a tile also wait for the
+// previous tile's last stores (~2000 cycles once per tile).  Needs >= 2 channel chunks (two halo buffers).  Same arithmetic, same
+// summation order, same statistics rows as the kernel above: bit-identical results.
+template <typename T, int LB>
+__global__ __launch_bounds__(512, 2) void conv3x3_hpp_persist_kernel(const ConvArgs a, const int rows_hp, const HppDiv dv, const int total_tiles) {
+    constexpr int VEC = Prec<T>::VEC, BK = VEC * 4;
+    constexpr int BM = 128, BN = 512, TM = 8, TN = 4, NW = 8, SA = 4;
+    constexpr int A_CELLS = BM * 4;
+    static_assert(sizeof(T) <= 2, "f16 / int8");
+    typedef typename HppMma<T>::frag_t frag_t;
+    typedef typename AccOf<T>::type acc_t;
+    typedef const void __attribute__((address_space(1))) * gptr_t;
+    typedef void __attribute__((address_space(3))) * lptr_t;
+
+    extern __shared__ __attribute__((aligned(16))) u32x4 hsm[];
+    u32x4* const Aring = hsm;                                     // [SA][128 rows x 4 cells]
+    u32x4* const Hbuf = hsm + SA * A_CELLS;                       // [2][rows_hp x 4 cells]
+    u32x4* const dummy = Hbuf + 2 * rows_hp * 4;                  // [64] sink of the pieces beyond the image
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int group = wave >> 2;
+    const int Wp = a.W + 1;
+    const int IMG = (a.H + 1) * Wp;
+    const int lrow = lane >> 2;
+    const int lu = (lane & 3) ^ (((lane >> 4) & 1) << 1);
+    const T* const xg = reinterpret_cast<const T*>(a.x);
+    const int wrow = wave * 16 + lrow;
+
+    // tile k of this workgroup = virtual block blockIdx.x + k gridDim.x of a total_tiles-block launch of the kernel above
+    auto tile_of = [&](int v, int& m_tile, int& p_tile) {
+        const int nb = total_tiles;
+        const int q = nb >> 3, rr = nb & 7, xcd = v & 7;
+        const int logical = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (v >> 3);
+        p_tile = logical / a.m_tiles;
+        m_tile = logical - p_tile * a.m_tiles;
+    };
+    // this lane's element offset into the packed weights for the tile rows at m0 (the launcher keeps the image below 2^31 elements):
+    // one register for the current tile; the next tile's is recomputed at its three issue sites
+    const T* const wbase = reinterpret_cast<const T*>(a.w);
+    auto weight_off = [&](int m0) { return min(m0 + wrow, a.m_pad - 1) * a.ktot + lu * VEC; };
+    auto halo_offset = [&](int q0, int j) {      // element offset of halo row j of the tile at q0 (channel 0), or -1
+        const int v = q0 - Wp - 1 + j;
+        int off = -1;
+        if (j < rows_hp && v >= 0) {
+            const int n = hpp_div(v, dv.m_img, dv.s_img);
+            const int rem = v - n * IMG;
+            const int yy = hpp_div(rem, dv.m_wp, dv.s_wp), xx = rem - yy * Wp;
+            if (n < a.N && yy >= 1 && xx >= 1) off = ((n * a.H + yy - 1) * a.W + xx - 1) * a.ldx;
+        }
+        return off;
+    };
+    const unsigned zlo = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)g_zero_page);
+    const unsigned zhi = __builtin_amdgcn_readfirstlane((unsigned)((uintptr_t)g_zero_page >> 32));
+    auto issue_a = [&](int woff, int stage, int tap, int kc) {
+        __builtin_amdgcn_global_load_lds((gptr_t)(wbase + (woff + tap * a.cin_k + kc)), (lptr_t)(Aring + stage * A_CELLS + wave * 64), 16, 0, 0);
+    };
+    auto issue_h = [&](int buf, int q0, int kc, int i) {      // piece i of this wave (group g = wave + 8 i) of the image of tile q0
+        const int g = wave + i * NW;
+        const int off = halo_offset(q0, g * 16 + lrow);
+        const bool ok = off >= 0 && kc + lu * VEC < a.Cin;
+        const unsigned long long u = (unsigned long long)(uintptr_t)(xg + (off + kc + lu * VEC));
+        const unsigned lo = ok ? (unsigned)u : zlo, hi = ok ? (unsigned)(u >> 32) : zhi;
+        u32x4* dst = (g * 16 < rows_hp) ? Hbuf + buf * (rows_hp * 4) + g * 64 : dummy;
+        __builtin_amdgcn_global_load_lds((gptr_t)(uintptr_t)(((unsigned long long)hi << 32) | lo), (lptr_t)dst, 16, 0, 0);
+    };
+
+    const int r16 = lane & 15, kq = lane >> 4;
+    const int a_off = r16 * 4 + (kq ^ (((r16 >> 2) & 1) << 1));
+    frag_t fa[4], fb[4];
+    acc_t acc[TM][TN];
+    auto read_a = [&](const u32x4* st, int half) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            u32x4 v = st[(half * 64 + i * 16) * 4 + a_off];
+            fa[i] = *reinterpret_cast<frag_t*>(&v);
+        }
+    };
+    auto read_b = [&](const u32x4* hb, int tapoff) {
+        const int rt = r16 + tapoff;
+        const int off = (wave * 64 + rt) * 4 + (kq ^ (((rt >> 2) & 1) << 1));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            u32x4 v = hb[off + j * 64];
+            fb[j] = *reinterpret_cast<frag_t*>(&v);
+        }
+    };
+    auto mma = [&](auto hc) {
+        constexpr int h = decltype(hc)::value;
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[h * 4 + i][j] = HppMma<T>::mma(fa[i], fb[j], acc[h * 4 + i][j]);
+        __builtin_amdgcn_s_setprio(0);
+    };
+    typedef std::integral_constant<int, 0> H0;
+    typedef std::integral_constant<int, 1> H1;
+#define YH_HPP_BARRIER()                     \
+    do {                                     \
+        __builtin_amdgcn_sched_barrier(0);   \
+        __builtin_amdgcn_s_barrier();        \
+        __builtin_amdgcn_sched_barrier(0);   \
+    } while (0)
+#define YH_HPP_PHASE(LOADS, MMA)                              \
+    do {                                                      \
+        LOADS;                                                \
+        __builtin_amdgcn_sched_barrier(0);                    \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   \
+        __builtin_amdgcn_s_barrier();                         \
+        __builtin_amdgcn_sched_barrier(0);                    \
+        MMA;                                                  \
+        YH_HPP_BARRIER();                                     \
+    } while (0)
+
+    const int nchunks = a.cin_k / BK;
+    const int nk = 9 * nchunks;
+    int vb = blockIdx.x;                         // virtual block of the current tile
+    int m_tile, p_tile;
+    tile_of(vb, m_tile, p_tile);
+    int wsrc = weight_off(m_tile * BM);
+    // ---- prologue of the FIRST tile: halo image of chunk 0, weight tiles of steps 0 .. 2; steps 1 and 2 stay in flight
+    static_for<LB>([&](auto ic) { issue_h(0, p_tile * BN, 0, decltype(ic)::value); });
+    issue_a(wsrc, 0, 0, 0);
+    issue_a(wsrc, 1, 1, 0);
+    issue_a(wsrc, 2, 2, 0);
+    wait_vmcnt<2>();
+    YH_HPP_BARRIER();
+
+    int st_r = 0, st_w = 3;      // ring stage of step s / of step s + 3 (the ring runs on across tiles)
+    int cc = 0;                  // running chunk count: chunk cc lives in halo buffer cc & 1
+    for (;;) {
+        const int m0 = m_tile * BM;
+        const int q0 = p_tile * BN;
+        const int vnext = vb + (int)gridDim.x;
+        const bool has_next = vnext < total_tiles;
+        int m_next = 0, p_next = 0;
+        if (has_next) tile_of(vnext, m_next, p_next);
+        const int q0_next = p_next * BN;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = acc_t{0, 0, 0, 0};
+        if (group == 1) YH_HPP_BARRIER();   // stagger: group 1 runs one barrier interval behind group 0
+
+        int s = 0;                   // K step being computed
+        int ptap = 3, pkc = 0;       // tap / channel offset of step s + 3
+        for (int c = 0; c < nchunks; ++c, ++cc) {
+            const bool last_chunk = c + 1 == nchunks;
+            const bool more_h = !last_chunk || has_next;       // an image is fetched during this chunk: the next chunk's, or the next tile's first
+            const u32x4* const hb = Hbuf + (cc & 1) * (rows_hp * 4);
+            const int nbuf = (cc + 1) & 1;
+            const int hq0 = last_chunk ? q0_next : q0, hkc = last_chunk ? 0 : (c + 1) * BK;
+            static_for<9>([&](auto tc) {
+                constexpr int t = decltype(tc)::value;
+                const u32x4* const st = Aring + st_r * A_CELLS;
+                const int tapoff = (t / 3) * Wp + (t % 3);
+                constexpr int allow = HppAllow<t, LB>::value;
+                // ---- phase X; weight tile of step s + 3: this tile's, or - in the last three steps - the next tile's steps 0 .. 2
+                YH_HPP_PHASE({
+                    read_a(st, 0);
+                    read_b(hb, tapoff);
+                    if (s + 3 < nk) issue_a(wsrc, st_w, ptap, pkc);
+                    else if (has_next) issue_a(weight_off(m_next * BM), st_w, s + 3 - nk, 0);
+                }, mma(H0{}));
+                // ---- phase Y; halo pieces; then this wave's share of step s + 1 (and of everything older) must have landed
+                YH_HPP_PHASE({
+                    read_a(st, 1);
+                    if constexpr (t < LB) { if (more_h) issue_h(nbuf, hq0, hkc, t); }
+                    if (more_h) wait_vmcnt<allow>();
+                    else {
+                        const int rem = nk - 2 - s;
+                        if (rem >= 2) wait_vmcnt<2>(); else if (rem == 1) wait_vmcnt<1>(); else wait_vmcnt<0>();
+                    }
+                }, mma(H1{}));
+                ++s;
+                st_r = (st_r + 1) & (SA - 1);
+                st_w = (st_w + 1) & (SA - 1);
+                if (++ptap == 9) { ptap = 0; pkc += BK; }
+            });
+        }
+        if (group == 0) YH_HPP_BARRIER();   // re-align: matches group 1's extra barrier at the start of the tile
+
+        // ---- epilogue of this tile (every load before the first store); the next tile's first stages are already in LDS / in flight.
+        // Its arguments (output / residual / statistics pointers, pitches, scales: ~30 scalars the K loop never touches) are re-read
+        // from the kernel-argument segment HERE, through a pointer the compiler cannot see through: kept live across the tile loop
+        // they overflow the scalar register file and the spills land in vector registers the K loop needs
+        unsigned long long kp = (unsigned long long)(uintptr_t)__builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+s"(kp));
+        const ConvArgs ae = *reinterpret_cast<const ConvArgs __attribute__((address_space(4)))*>((uintptr_t)kp);
+        const int mq = (lane >> 4) << 2;
+        f32x4 bvs[TM];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int m = m0 + i * 16 + mq;
+            bvs[i] = m < ae.Cout ? *reinterpret_cast<const f32x4*>(ae.bias + m) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i) asm volatile("" ::"v"(bvs[i]));
+        long pix[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int q = q0 + wave * 64 + j * 16 + r16;
+            const int n = hpp_div(q, dv.m_img, dv.s_img);
+            const int rem = q - n * IMG;
+            const int yy = hpp_div(rem, dv.m_wp, dv.s_wp), xx = rem - yy * Wp;
+            pix[j] = (n < a.N && yy >= 1 && xx >= 1) ? ((long)n * a.H + yy - 1) * a.W + xx - 1 : -1;
+        }
+        const long tile_row = (long)p_tile * NW + wave;
+        switch (ae.act) {
+            case YH_ACT_LEAKY: hpp_epilogue<T, YH_ACT_LEAKY>(ae, acc, bvs, pix, m0, tile_row, lane); break;
+            case YH_ACT_MISH: hpp_epilogue<T, YH_ACT_MISH>(ae, acc, bvs, pix, m0, tile_row, lane); break;
+            default: hpp_epilogue<T, YH_ACT_LINEAR>(ae, acc, bvs, pix, m0, tile_row, lane); break;
+        }
+        if (!has_next) break;
+        vb = vnext;
+        m_tile = m_next;
+        p_tile = p_next;
+        wsrc = weight_off(m_next * BM);
+    }
+#undef YH_HPP_PHASE
+#undef YH_HPP_BARRIER
+}
+
 // n / d for 0 <= n < 2^31, d >= 2: q = mulhi(n, m) >> s with L = ceil(log2 d), m = ceil(2^(31 + L) / d) < 2^32, s = L - 1
 // (n m / 2^(31 + L) = n / d + n e / (d 2^(31 + L)) with 0 <= e < d <= 2^L: the error term stays below 1 / d for n < 2^31)
 static void hpp_magic(unsigned d, unsigned* m, unsigned* s) {
@@ -453,6 +686,8 @@ bool hpp_geometry(int W, int cin_k, int bk, int* rows_hp, int* lb, int* hbufs, s
     *lds = ((size_t)4 * 128 * 4 + (size_t)*hbufs * *rows_hp * 4 + 64) * 16 + (size_t)*rows_hp * 4;   // + the halo offset table
     return *lds <= 160 * 1024;
 }
+
+int launch_hpp_persist_tile(const ConvArgs& a, int dtype, hipStream_t stream);
 
 template <typename T> static int launch_hpp(const ConvArgs& a0, hipStream_t stream) {
     constexpr int BK = Prec<T>::VEC * 4;
@@ -505,7 +740,62 @@ template <typename T> static int launch_hpp(const ConvArgs& a0, hipStream_t stre
     return check_launch();
 }
 
+template <typename T> static int launch_hpp_persist(const ConvArgs& a0, hipStream_t stream) {
+    constexpr int BK = Prec<T>::VEC * 4;
+    ConvArgs a = a0;
+    if (a.R != 3 || a.S != 3 || a.stride != 1 || a.pad != 1 || a.ups != 1) return YH_EUNSUPPORTED;
+    if (a.act != YH_ACT_LINEAR && a.act != YH_ACT_LEAKY && a.act != YH_ACT_MISH) return YH_EUNSUPPORTED;
+    if (a.cin_k % BK) return YH_EALIGN;
+    int rows_hp, lb, hbufs;
+    size_t lds;
+    if (!hpp_geometry(a.W, a.cin_k, BK, &rows_hp, &lb, &hbufs, &lds) || hbufs != 2) return YH_EUNSUPPORTED;      // >= 2 channel chunks
+    if ((long)a.N * a.H * a.W * a.ldx + a.cin_k >= 0x7fffffffL || (long)a.m_pad * a.ktot >= 0x7fffffffL) return YH_EUNSUPPORTED;
+    if ((long)(a.N + 1) * (a.H + 1) * (a.W + 1) + 4096 >= 0x7fffffffL) return YH_EUNSUPPORTED;
+    const unsigned amask = sizeof(T) == 2 ? 15u : 7u;
+    if (a.Cout % 8 || a.ldy % 8 || (((uintptr_t)a.y) & amask) || (a.res && (a.ldr % 8 || (((uintptr_t)a.res) & amask)))) return YH_EALIGN;
+    a.m_tiles = (a.Cout + 127) / 128;
+    const long Q = (long)a.N * (a.H + 1) * (a.W + 1);
+    a.p_tiles = (int)((Q + 511) / 512);
+    const long blocks = (long)a.m_tiles * a.p_tiles;
+    if (blocks <= 0 || blocks > 0x7fffffffL) return YH_EINVAL;
+    HppDiv dv;
+    hpp_magic((unsigned)((a.H + 1) * (a.W + 1)), &dv.m_img, &dv.s_img);
+    hpp_magic((unsigned)(a.W + 1), &dv.m_wp, &dv.s_wp);
+    const unsigned grid = (unsigned)(blocks < 256 ? blocks : 256);       // one resident workgroup per CU
+#define YH_HPPP_CASE(LBV)                                                                                                      \
+    case LBV: {                                                                                                                \
+        auto kern = conv3x3_hpp_persist_kernel<T, LBV>;                                                                        \
+        hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds);                                           \
+        if (e != hipSuccess) return (int)e;                                                                                    \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, stream, a, rows_hp, dv, (int)blocks);                             \
+        break;                                                                                                                 \
+    }
+    switch (lb) {
+        YH_HPPP_CASE(5) YH_HPPP_CASE(6) YH_HPPP_CASE(7)
+        default: return YH_EUNSUPPORTED;
+    }
+#undef YH_HPPP_CASE
+    return check_launch();
+}
+
+int launch_hpp_persist_tile(const ConvArgs& a, int dtype, hipStream_t stream) {
+    if (dtype == YH_F16) return launch_hpp_persist<f16>(a, stream);
+    if (dtype == YH_I8) return launch_hpp_persist<int8_t>(a, stream);
+    return YH_EINVAL;
+}
+
 int launch_hpp_tile(const ConvArgs& a, int dtype, hipStream_t stream) {
+    // the persistent form takes every launch it supports (>= 2 channel chunks) with more tiles than CUs; YH_HPP_PERSIST=0: the
+    // one-tile-per-workgroup kernel (A/B, profiles/r04_hpp_persist_ab.txt)
+    static const bool persist = [] { const char* e = getenv("YH_HPP_PERSIST"); return !e || atoi(e) != 0; }();
+    if (persist && a.R == 3 && a.S == 3 && a.stride == 1 && a.pad == 1 && a.ups == 1) {
+        const int bk = dtype == YH_I8 ? 64 : 32;
+        const long tiles = (long)((a.Cout + 127) / 128) * (((long)a.N * (a.H + 1) * (a.W + 1) + 511) / 512);
+        if (a.cin_k % bk == 0 && a.cin_k / bk >= 2 && tiles > 256) {
+            const int rc = launch_hpp_persist_tile(a, dtype, stream);
+            if (rc != YH_EUNSUPPORTED) return rc;
+        }
+    }
     if (dtype == YH_F16) return launch_hpp<f16>(a, stream);
     if (dtype == YH_I8) return launch_hpp<int8_t>(a, stream);
     return YH_EINVAL;
