@@ -428,6 +428,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_hpp_kernel(const ConvArgs a, c
     }
 }
 
+#ifdef YH_HPP_PERSIST_AB
 // ---- PERSISTENT form (tile code 44; round 4).  The kernel above pays ~29 000 cycles per 128 x 512 tile outside its K loop - workgroup
 // launch, index set-up, the first halo image and weight stages arriving into an idle CU, the epilogue's stores draining before the CU
 // takes its next workgroup - as much as 22 K steps; a 76 x 76 128 -> 256 layer has 18.  Here one
@@ -494,9 +495,14 @@ __global__ __launch_bounds__(512, 2) void conv3x3_hpp_persist_kernel(const ConvA
     auto issue_a = [&](int woff, int stage, int tap, int kc) {
         __builtin_amdgcn_global_load_lds((gptr_t)(wbase + (woff + tap * a.cin_k + kc)), (lptr_t)(Aring + stage * A_CELLS + wave * 64), 16, 0, 0);
     };
-    auto issue_h = [&](int buf, int q0, int kc, int i) {      // piece i of this wave (group g = wave + 8 i) of the image of tile q0
+    int boff[LB];      // this lane's row offsets of the image being fetched: the current tile's; from the last chunk on the next tile's
+    auto set_offsets = [&](int q0) {
+        static_for<LB>([&](auto ic) { boff[decltype(ic)::value] = halo_offset(q0, (wave + decltype(ic)::value * NW) * 16 + lrow); });
+    };
+    auto issue_h = [&](int buf, int kc, auto ic) {      // piece i of this wave (group g = wave + 8 i)
+        constexpr int i = decltype(ic)::value;
         const int g = wave + i * NW;
-        const int off = halo_offset(q0, g * 16 + lrow);
+        const int off = boff[i];
         const bool ok = off >= 0 && kc + lu * VEC < a.Cin;
         const unsigned long long u = (unsigned long long)(uintptr_t)(xg + (off + kc + lu * VEC));
         const unsigned lo = ok ? (unsigned)u : zlo, hi = ok ? (unsigned)(u >> 32) : zhi;
@@ -559,7 +565,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_hpp_persist_kernel(const ConvA
     tile_of(vb, m_tile, p_tile);
     int wsrc = weight_off(m_tile * BM);
     // ---- prologue of the FIRST tile: halo image of chunk 0, weight tiles of steps 0 .. 2; steps 1 and 2 stay in flight
-    static_for<LB>([&](auto ic) { issue_h(0, p_tile * BN, 0, decltype(ic)::value); });
+    set_offsets(p_tile * BN);
+    static_for<LB>([&](auto ic) { issue_h(0, 0, ic); });
     issue_a(wsrc, 0, 0, 0);
     issue_a(wsrc, 1, 1, 0);
     issue_a(wsrc, 2, 2, 0);
@@ -589,7 +596,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_hpp_persist_kernel(const ConvA
             const bool more_h = !last_chunk || has_next;       // an image is fetched during this chunk: the next chunk's, or the next tile's first
             const u32x4* const hb = Hbuf + (cc & 1) * (rows_hp * 4);
             const int nbuf = (cc + 1) & 1;
-            const int hq0 = last_chunk ? q0_next : q0, hkc = last_chunk ? 0 : (c + 1) * BK;
+            const int hkc = last_chunk ? 0 : (c + 1) * BK;
+            if (last_chunk && has_next) set_offsets(q0_next);      // the current tile's offsets were last used in the previous chunk
             static_for<9>([&](auto tc) {
                 constexpr int t = decltype(tc)::value;
                 const u32x4* const st = Aring + st_r * A_CELLS;
@@ -605,7 +613,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_hpp_persist_kernel(const ConvA
                 // ---- phase Y; halo pieces; then this wave's share of step s + 1 (and of everything older) must have landed
                 YH_HPP_PHASE({
                     read_a(st, 1);
-                    if constexpr (t < LB) { if (more_h) issue_h(nbuf, hq0, hkc, t); }
+                    if constexpr (t < LB) { if (more_h) issue_h(nbuf, hkc, tc); }
                     if (more_h) wait_vmcnt<allow>();
                     else {
                         const int rem = nk - 2 - s;
@@ -626,7 +634,13 @@ __global__ __launch_bounds__(512, 2) void conv3x3_hpp_persist_kernel(const ConvA
         // they overflow the scalar register file and the spills land in vector registers the K loop needs
         unsigned long long kp = (unsigned long long)(uintptr_t)__builtin_amdgcn_kernarg_segment_ptr();
         asm volatile("" : "+s"(kp));
-        const ConvArgs ae = *reinterpret_cast<const ConvArgs __attribute__((address_space(4)))*>((uintptr_t)kp);
+        typedef const ConvArgs __attribute__((address_space(4))) * kargs_t;     // constant address space: scalar loads
+        const kargs_t ka = reinterpret_cast<kargs_t>((uintptr_t)kp);
+        ConvArgs ae;
+        ae.bias = ka->bias; ae.res = ka->res; ae.y = ka->y; ae.Cout = ka->Cout; ae.ldr = ka->ldr; ae.ldy = ka->ldy;
+        ae.acc_scale = ka->acc_scale; ae.inv_out_scale = ka->inv_out_scale; ae.act = ka->act; ae.slope = ka->slope;
+        ae.stats_part = ka->stats_part; ae.q_rx = ka->q_rx; ae.q_ra = ka->q_ra; ae.q_scale_x = ka->q_scale_x;
+        ae.q_scale_a = ka->q_scale_a; ae.q_inv_scale_sum = ka->q_inv_scale_sum;
         const int mq = (lane >> 4) << 2;
         f32x4 bvs[TM];
 #pragma unroll
@@ -661,6 +675,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_hpp_persist_kernel(const ConvA
 #undef YH_HPP_BARRIER
 }
 
+#endif  // YH_HPP_PERSIST_AB
+
 // n / d for 0 <= n < 2^31, d >= 2: q = mulhi(n, m) >> s with L = ceil(log2 d), m = ceil(2^(31 + L) / d) < 2^32, s = L - 1
 // (n m / 2^(31 + L) = n / d + n e / (d 2^(31 + L)) with 0 <= e < d <= 2^L: the error term stays below 1 / d for n < 2^31)
 static void hpp_magic(unsigned d, unsigned* m, unsigned* s) {
@@ -686,8 +702,6 @@ bool hpp_geometry(int W, int cin_k, int bk, int* rows_hp, int* lb, int* hbufs, s
     *lds = ((size_t)4 * 128 * 4 + (size_t)*hbufs * *rows_hp * 4 + 64) * 16 + (size_t)*rows_hp * 4;   // + the halo offset table
     return *lds <= 160 * 1024;
 }
-
-int launch_hpp_persist_tile(const ConvArgs& a, int dtype, hipStream_t stream);
 
 template <typename T> static int launch_hpp(const ConvArgs& a0, hipStream_t stream) {
     constexpr int BK = Prec<T>::VEC * 4;
@@ -740,6 +754,7 @@ template <typename T> static int launch_hpp(const ConvArgs& a0, hipStream_t stre
     return check_launch();
 }
 
+#ifdef YH_HPP_PERSIST_AB
 template <typename T> static int launch_hpp_persist(const ConvArgs& a0, hipStream_t stream) {
     constexpr int BK = Prec<T>::VEC * 4;
     ConvArgs a = a0;
@@ -783,11 +798,14 @@ int launch_hpp_persist_tile(const ConvArgs& a, int dtype, hipStream_t stream) {
     if (dtype == YH_I8) return launch_hpp_persist<int8_t>(a, stream);
     return YH_EINVAL;
 }
+#endif  // YH_HPP_PERSIST_AB
 
 int launch_hpp_tile(const ConvArgs& a, int dtype, hipStream_t stream) {
-    // the persistent form takes every launch it supports (>= 2 channel chunks) with more tiles than CUs; YH_HPP_PERSIST=0: the
-    // one-tile-per-workgroup kernel (A/B, profiles/r04_hpp_persist_ab.txt)
-    static const bool persist = [] { const char* e = getenv("YH_HPP_PERSIST"); return !e || atoi(e) != 0; }();
+    // The persistent form (one workgroup per CU walking over its tiles) measured 10 - 25 % SLOWER than one tile per workgroup on every
+    // layer of the two models (profiles/r04_hpp_persist_ab.txt) and spills; it is only compiled into an A/B build
+    // (make CXXFLAGS+=-DYH_HPP_PERSIST_AB), where YH_HPP_PERSIST=1 routes the launches it supports (>= 2 channel chunks, > 256 tiles).
+#ifdef YH_HPP_PERSIST_AB
+    static const bool persist = [] { const char* e = getenv("YH_HPP_PERSIST"); return e && atoi(e) != 0; }();
     if (persist && a.R == 3 && a.S == 3 && a.stride == 1 && a.pad == 1 && a.ups == 1) {
         const int bk = dtype == YH_I8 ? 64 : 32;
         const long tiles = (long)((a.Cout + 127) / 128) * (((long)a.N * (a.H + 1) * (a.W + 1) + 511) / 512);
@@ -796,6 +814,7 @@ int launch_hpp_tile(const ConvArgs& a, int dtype, hipStream_t stream) {
             if (rc != YH_EUNSUPPORTED) return rc;
         }
     }
+#endif
     if (dtype == YH_F16) return launch_hpp<f16>(a, stream);
     if (dtype == YH_I8) return launch_hpp<int8_t>(a, stream);
     return YH_EINVAL;
