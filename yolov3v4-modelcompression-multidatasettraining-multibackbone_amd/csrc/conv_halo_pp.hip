@@ -776,7 +776,8 @@ template <typename T> static int launch_hpp_persist(const ConvArgs& a0, hipStrea
     HppDiv dv;
     hpp_magic((unsigned)((a.H + 1) * (a.W + 1)), &dv.m_img, &dv.s_img);
     hpp_magic((unsigned)(a.W + 1), &dv.m_wp, &dv.s_wp);
-    const unsigned grid = (unsigned)(blocks < 256 ? blocks : 256);       // one resident workgroup per CU
+    static const long wgs = [] { const char* e = getenv("YH_HPP_PERSIST_GRID"); return e ? atol(e) : 256L; }();      // 256: one workgroup per CU; 512: two
+    const unsigned grid = (unsigned)(blocks < wgs ? blocks : wgs);
 #define YH_HPPP_CASE(LBV)                                                                                                      \
     case LBV: {                                                                                                                \
         auto kern = conv3x3_hpp_persist_kernel<T, LBV>;                                                                        \
