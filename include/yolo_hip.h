@@ -146,12 +146,16 @@ typedef struct yh_stem_desc {
     float slope;
     int32_t dtype;
     float out_scale;   /* YH_I8 only: the output is quantised, y_q = clamp(round_half_away(y / out_scale)) stored int8 */
+    float* stats_ws;           /* training forward (as yh_conv_desc.stats_ws): yh_conv2d_stem_stats_rows(d) rows of [2][cout]   */
+    int64_t stats_ws_floats;   /* partial sums of y and y*y as stored, summed by yh_bn_finalize (nparts).  NULL = none.        */
 } yh_stem_desc;
 
 int yh_stem_pack_weights(const float* w, const float* conv_bias, const float* bn_gamma, const float* bn_beta,
                          const float* bn_mean, const float* bn_var, float bn_eps, int cout, int cin, int kh,
                          int kw, int cout_pad, float* packed, float* bias_out, void* stream);
 int yh_conv2d_stem_fwd(const yh_stem_desc* d, void* stream);
+/* rows of partial sums the kernel this descriptor selects emits (0 = it has no statistics epilogue: run yh_bn_stats) */
+int64_t yh_conv2d_stem_stats_rows(const yh_stem_desc* d);
 
 /* ---------------------------------------------------------------------------------------------------
  * Depthwise block: y = act(dwconv(x, W') + b'), one k x k filter per channel (k = 3 or 5 in the MobilenetV3 /

@@ -315,7 +315,22 @@ class FakeLib:
             y = rnd_away(y / d.out_scale).clamp(-128, 127)
         out = pitched(d.y, d.n * d.ho * d.wo, d.cout, d.ldy, npdt)
         out[:] = y.permute(0, 2, 3, 1).reshape(-1, d.cout).numpy().astype(npdt)
+        if _addr(d.stats_ws):   # the statistics epilogue of the MFMA stem: the emulator emits the sums in row 0 of its two rows
+            rows = self.yh_conv2d_stem_stats_rows(d)
+            if not rows:
+                return -3       # YH_EUNSUPPORTED
+            assert d.stats_ws_floats >= rows * 2 * d.cout
+            q = torch.from_numpy(out.astype(np.float32))
+            ws = flat(d.stats_ws, rows * 2 * d.cout, np.float32)
+            ws[:] = 0.0
+            ws[:d.cout] = q.sum(0).numpy()
+            ws[d.cout:2 * d.cout] = (q * q).sum(0).numpy()
         return 0
+
+    def yh_conv2d_stem_stats_rows(self, dref):
+        d = dref._obj if hasattr(dref, '_obj') else dref
+        ok = d.cin == 3 and d.kh == 3 and d.kw == 3 and d.pad == 1 and d.stride in (1, 2) and d.cout % 8 == 0 and d.dtype != hiplib.YH_I8
+        return 2 if ok else 0
 
     def yh_maxpool2d_fwd(self, dref, stream):
         d = dref._obj if hasattr(dref, '_obj') else dref

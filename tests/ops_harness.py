@@ -65,7 +65,7 @@ def conv(lib, code, x, packed, bias, cin_k, m_pad, cout_phys, k, stride, pad, ac
     return y
 
 
-def stem(lib, code, x, w, cb=None, bn=None, eps=1e-5, stride=1, pad=1, act=1, slope=0.1):
+def stem(lib, code, x, w, cb=None, bn=None, eps=1e-5, stride=1, pad=1, act=1, slope=0.1, stats=None):
     cout, cin, kh, kw = w.shape
     N, _, H, W = x.shape
     cout_phys = round_up(cout, 8)
@@ -80,6 +80,12 @@ def stem(lib, code, x, w, cb=None, bn=None, eps=1e-5, stride=1, pad=1, act=1, sl
     y = torch.full((N, Ho, Wo, cout_phys), 3.0, device=x.device, dtype=tdtype(code))
     d = StemDesc(x=P(x), w=P(packed), bias=P(bias), y=P(y), n=N, cin=cin, h=H, w_in=W, ho=Ho, wo=Wo, cout=cout_phys,
                  cout_pad=cout_pad, kh=kh, kw=kw, stride=stride, pad=pad, ldy=cout_phys, act=act, slope=slope, dtype=code)
+    if stats is not None:      # the statistics epilogue of the MFMA first-layer kernel: rows of [2][cout] partial sums
+        rows = int(lib.yh_conv2d_stem_stats_rows(C.byref(d)))
+        assert rows > 0, 'this stem shape has no statistics epilogue'
+        ws = torch.full((rows * 2 * cout_phys,), float('nan'), device=x.device, dtype=torch.float32)
+        d.stats_ws, d.stats_ws_floats = P(ws), ws.numel()
+        stats['rows'], stats['ws'] = rows, ws
     rc = lib.yh_conv2d_stem_fwd(C.byref(d), stream())
     assert rc == 0, rc
     return y

@@ -291,6 +291,38 @@ def test_stem_matches_emulation(libs, code, shape):
 
 
 @pytest.mark.parametrize('code', [F32, F16], ids=['fp32', 'fp16'])
+@pytest.mark.parametrize('shape', [(3, 70, 100, 32, 1), (2, 67, 45, 64, 2), (33, 64, 512, 16, 1), (1, 37, 131, 24, 2), (4, 128, 128, 16, 1), (4, 128, 128, 32, 2)])
+def test_stem_on_the_matrix_cores_with_statistics(libs, code, shape):
+    """The 3 x 3 x 3-plane first layer on v_mfma_f32_16x16x4_f32 (csrc/conv_stem_mfma.hip; reference models.py:88-113 on the NCHW
+    frames): ragged 16 x 32 tiles, more tiles than one round of workgroups, both strides, one and two channel tiles per workgroup,
+    against torch's fp32 convolution; the BatchNorm partial sums of the epilogue are the sums of the values it stored."""
+    lib, fake = libs
+    N, H, W, cout, s = shape
+    g = torch.Generator().manual_seed(31)
+    x = torch.rand(N, 3, H, W, generator=g)
+    w = _rand(g, cout, 3, 3, 3, scale=0.3)
+    cb = _rand(g, cout, scale=0.2)
+    st = {}
+    y = oh.stem(lib, code, x.to(GPU), w.to(GPU), cb.to(GPU), None, stride=s, act=0, stats=st)
+    got = y.float().cpu()
+    want = torch.nn.functional.conv2d(x, w, cb, stride=s, padding=1).permute(0, 2, 3, 1)
+    tol = 2e-6 if code == F32 else 1e-3      # fp32: summation order only; fp16: the rounding of the stored value
+    assert (got[..., :cout] - want).abs().max().item() <= tol * want.abs().max().item()
+    c_phys = y.shape[-1]
+    ws = st['ws'].cpu().view(st['rows'], 2, c_phys).double().sum(0)
+    q = got.double().reshape(-1, c_phys)
+    assert torch.isfinite(st['ws']).all()
+    np.testing.assert_allclose(ws[0].numpy(), q.sum(0).numpy(), rtol=2e-5, atol=1e-3)
+    np.testing.assert_allclose(ws[1].numpy(), (q * q).sum(0).numpy(), rtol=2e-5, atol=1e-3)
+    # and the emulation of the C ABI emits the same totals
+    st2 = {}
+    y2 = oh.stem(fake, code, x, w, cb, None, stride=s, act=0, stats=st2)
+    ws2 = st2['ws'].view(st2['rows'], 2, c_phys).double().sum(0)
+    np.testing.assert_allclose(ws.numpy(), ws2.numpy(), rtol=2e-3 if code == F16 else 2e-5, atol=0.5 if code == F16 else 1e-3)
+    assert (got - y2.float()).abs().max().item() <= (2e-3 if code == F16 else 2e-6) * want.abs().max().item()
+
+
+@pytest.mark.parametrize('code', [F32, F16], ids=['fp32', 'fp16'])
 @pytest.mark.parametrize('k,s,H', [(2, 2, 26), (2, 2, 13), (2, 1, 13), (5, 1, 19), (9, 1, 19), (13, 1, 20), (3, 2, 17)])
 def test_maxpool_matches_emulation(libs, code, k, s, H):
     lib, fake = libs

@@ -60,4 +60,8 @@ inline hipError_t ensure_dynamic_lds(const void* kern, size_t bytes) {
 
 inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15u) == 0; }
 
+// conv_stem_mfma.hip: the 3 x 3 x 3-plane first layer on the matrix cores (YH_EUNSUPPORTED: use the kernel in elementwise.hip)
+int launch_stem_mfma(const yh_stem_desc& d, hipStream_t stream);
+long stem_mfma_stats_rows(const yh_stem_desc& d);
+
 }  // namespace yh

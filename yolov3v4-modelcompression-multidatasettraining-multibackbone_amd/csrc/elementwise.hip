@@ -3,6 +3,8 @@
 // All activations are NHWC with 16-byte vector accesses along the channel axis.
 #include "common.h"
 
+#include <type_traits>
+
 namespace yh {
 
 // ---------------------------------------------------------------------------------------- packing
@@ -300,31 +302,155 @@ __global__ __launch_bounds__(256) void add_gather_kernel(const yh_add_desc d) {
 }
 
 // ------------------------------------------------------------------------------------- yolo decode
-// grid.x = n * na * ny: one workgroup per (image, anchor, grid row); threads sweep the nx * no outputs of the
-// row, which are contiguous in both io and raw; the head map is read in 4*no-byte runs (one per cell).
+// e^x to ~1 ulp on the hardware exp2: x log2(e) in two pieces (product and its rounding error + the low word of log2 e), the second
+// folded back in as a first-order correction.  ocml's expf costs ~25 VALU slots per value, this 7; v_exp_f32 saturates to 0 / inf
+// at the ends of the range like expf.
+__device__ __forceinline__ float exp_fast(float x) {
+    const float L2E_HI = 1.44269502162933349609375f, L2E_LO = 1.92596299e-8f;
+    const float t = x * L2E_HI;
+    const float r = fmaf(x, L2E_LO, fmaf(x, L2E_HI, -t));
+    const float e = __builtin_amdgcn_exp2f(t);
+    return fmaf(e, r * 0.693147180559945f, e);
+}
+// 1 / d for d >= 1 (finite or +inf): the hardware reciprocal (1 ulp) refined by one Newton step
+__device__ __forceinline__ float rcp_fast(float d) {
+    const float r = __builtin_amdgcn_rcpf(d);
+    return d < 3.0e38f ? fmaf(fmaf(-d, r, 1.f), r, r) : r;
+}
+
+// grid.x = n * ny: one workgroup per (image, grid row).  Threads sweep the nx cells of the row in memory order - a cell's
+// na * no head values are contiguous, so every wave load is one dense run - and write the na output runs of the row (each
+// nx * no floats, contiguous in io and raw).  The (cell, anchor, channel) index of a thread advances by 256 elements per trip with
+// two carries instead of a division; one exponential per element (of v for w / h, of -v for the sigmoids); 4 independent loads per
+// trip, issued one trip ahead; 32-bit offsets.  Byte-bound by design: 4 B read + 4 B written per value, ~25 VALU slots per value.
+template <bool RAW>
 __global__ __launch_bounds__(256) void yolo_decode_kernel(const yh_decode_desc d) {
-    const int row = blockIdx.x;
-    const int y = row % d.ny;
-    const int t = row / d.ny;
-    const int a = t % d.na, n = t / d.na;
-    const int span = d.nx * d.no;
-    const float* prow = d.p + ((long)n * d.ny + y) * d.nx * d.ldp + a * d.no;
-    const long obase = (((long)n * d.na + a) * d.ny + y) * span;  // raw is (n, a, y, x, o) contiguous
-    float* const io = d.io + ((long)n * d.rows_total + d.row_off + ((long)a * d.ny + y) * d.nx) * d.no;
-    const float aw = d.anchor_w[a], ah = d.anchor_h[a];
-    for (int i = threadIdx.x; i < span; i += blockDim.x) {
-        const int x = i / d.no, o = i - x * d.no;
-        const float v = prow[(long)x * d.ldp + o];
-        if (d.raw) d.raw[obase + i] = v;
-        float out;
-        if (o < 2) {
-            out = (1.f / (1.f + expf(-v)) + (float)(o == 0 ? x : y)) * d.stride;
-        } else if (o < 4) {
-            out = (expf(v) * (o == 2 ? aw : ah)) * d.stride;
-        } else {
-            out = 1.f / (1.f + expf(-v));
+    __shared__ float anchor[16];
+    if (threadIdx.x < 16) anchor[threadIdx.x] = threadIdx.x < 8 ? d.anchor_w[threadIdx.x & 7] : d.anchor_h[threadIdx.x & 7];
+    __syncthreads();
+    const int y = blockIdx.x % d.ny, n = blockIdx.x / d.ny;
+    const int no = d.no, na = d.na;
+    const float* prow = d.p + ((long)n * d.ny + y) * d.nx * d.ldp;
+    const int cell_row = d.nx * no;                                 // floats of one anchor's output run of this row
+    const int arun = d.ny * cell_row;                               // floats between the runs of consecutive anchors
+    float* const io = d.io + ((long)n * d.rows_total + d.row_off) * no + (long)y * cell_row;
+    float* const raw = RAW ? d.raw + (long)n * na * arun + (long)y * cell_row : nullptr;
+    // element e = (x * na + a) * no + o; this thread starts at e = threadIdx.x and advances by 256
+    const int so = 256 % no, st = 256 / no, sa = st % na, sx = st / na;
+    int o = threadIdx.x % no, t0 = threadIdx.x / no, a = t0 % na, x = t0 / na;
+    const float fy = (float)y;
+    auto advance = [&]() {
+        o += so;
+        const int c = o >= no;
+        o -= c ? no : 0;
+        a += sa + c;
+        const int c2 = a >= na;
+        a -= c2 ? na : 0;
+        x += sx + c2;
+    };
+    // branch-free: every lane computes the exponential, the sigmoid and the anchor product and selects
+    auto value = [&](float v, int xx, int aa, int oo) {
+        const bool wh = oo == 2 || oo == 3;
+        const float e = exp_fast(wh ? v : -v);
+        const float sg = rcp_fast(1.f + e);
+        const float box = (sg + (oo == 0 ? (float)xx : fy)) * d.stride;                  // models.py:410-413: (sigmoid + grid) * stride
+        const float size = (e * anchor[(oo == 3 ? 8 : 0) + aa]) * d.stride;             // (exp * anchor) * stride
+        return wh ? size : (oo < 2 ? box : sg);
+    };
+    // Loads and stores share one in-order completion counter: a trip that stores and then loads waits for its stores to be
+    // acknowledged before the next values arrive.  Software pipeline: the next trip's U loads are issued BEFORE this trip's stores,
+    // and the full trips carry no predicate, so that the compiler can count the wait for them past the stores.
+    constexpr int U = 4;
+    float v[U];
+    int xs[U], as[U], os[U];
+    auto load = [&]() {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            xs[u] = x; as[u] = a; os[u] = o;
+            v[u] = prow[min(x, d.nx - 1) * d.ldp + a * no + o];
+            advance();
         }
-        io[i] = out;
+    };
+    const int full_trips = d.nx * na * no / (256 * U);
+    load();
+    for (int t = 0; t < full_trips; ++t) {
+        float cv[U];
+        int at[U];
+        float out[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            cv[u] = v[u];
+            at[u] = as[u] * arun + xs[u] * no + os[u];
+            out[u] = value(v[u], xs[u], as[u], os[u]);
+        }
+        load();
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if constexpr (RAW) raw[at[u]] = cv[u];
+            io[at[u]] = out[u];
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u)          // the ragged last trip
+        if (xs[u] < d.nx) {
+            const int at = as[u] * arun + xs[u] * no + os[u];
+            if constexpr (RAW) raw[at] = v[u];
+            io[at] = value(v[u], xs[u], as[u], os[u]);
+        }
+}
+
+// The same decode for heads whose cell fits one workgroup (na * no <= 256; 255 for the COCO heads): a thread owns ONE (anchor,
+// channel) pair for the whole kernel - which of the three formulas applies, the anchor and the output run are per-thread constants -
+// and walks over the cells of the grid row, 256 / (na no) cells per pass.  Per value: one add for the source offset, one for the
+// destination, the exponential, the reciprocal, two selects.  Loads run one trip (U passes) ahead of the stores, as above.
+template <bool RAW>
+__global__ __launch_bounds__(256) void yolo_decode_cell_kernel(const yh_decode_desc d) {
+    __shared__ float anchor[16];
+    if (threadIdx.x < 16) anchor[threadIdx.x] = threadIdx.x < 8 ? d.anchor_w[threadIdx.x & 7] : d.anchor_h[threadIdx.x & 7];
+    __syncthreads();
+    const int y = blockIdx.x % d.ny, n = blockIdx.x / d.ny;
+    const int no = d.no, na = d.na, G = na * no;
+    const int cpp = 256 / G;                                        // cells per pass
+    const int xs = threadIdx.x / G, r = threadIdx.x - xs * G;
+    if (xs >= cpp) return;
+    const int a = r / no, o = r - a * no;
+    const bool wh = o == 2 || o == 3, box = o < 2;
+    const float anc = anchor[(o == 3 ? 8 : 0) + a];
+    const float fy = (float)y;
+    const float* src = d.p + ((long)n * d.ny + y) * d.nx * d.ldp + r;
+    const int cell_row = d.nx * no, arun = d.ny * cell_row;
+    float* const io = d.io + ((long)n * d.rows_total + d.row_off) * no + (long)y * cell_row + a * arun + o;
+    float* const raw = RAW ? d.raw + (long)n * na * arun + (long)y * cell_row + a * arun + o : nullptr;
+    auto value = [&](float v, int x) {
+        const float e = exp_fast(wh ? v : -v);
+        const float sg = rcp_fast(1.f + e);
+        const float b = (sg + (o == 0 ? (float)x : fy)) * d.stride;       // models.py:410-413: (sigmoid + grid) * stride
+        const float s = (e * anc) * d.stride;                            // (exp * anchor) * stride
+        return wh ? s : (box ? b : sg);
+    };
+    // What bounds this kernel is bytes in flight: loads alone run at 3.9 TB/s and stores alone at 5 TB/s, but a loop that waits for
+    // its 4 loads per trip ran both at 2.7 TB/s combined.  Each thread keeps a ring of D loads in flight: load i + D is issued when
+    // value i is taken.  Loads and stores complete through ONE in-order counter and the compiler's counted wait for load i
+    // (vmcnt(D - 1): "the D - 1 younger loads may be outstanding") does not know about the stores between them, so in hardware it
+    // also waits for the stores older than the youngest D - 1 operations - about D / 2 iterations back, never the recent ones.
+    // (Issuing the loads as untracked inline assembly with a hand-written vmcnt(2 D - 1) does not work: the compiler considers the
+    // destination register valid - and reusable - the moment the asm statement has executed.)
+    constexpr int D = 16;
+    float ring[D];
+    const int iters = (d.nx + cpp - 1) / cpp;          // uniform over the workgroup; cells beyond nx are loaded clamped and not stored
+#pragma unroll
+    for (int k = 0; k < D; ++k) ring[k] = src[min(xs + k * cpp, d.nx - 1) * d.ldp];
+    for (int base = 0; base < iters; base += D) {
+#pragma unroll
+        for (int k = 0; k < D; ++k) {
+            const int i = base + k, x = xs + i * cpp;
+            const float v = ring[k];
+            ring[k] = src[min(x + D * cpp, d.nx - 1) * d.ldp];
+            if (x < d.nx) {
+                if constexpr (RAW) raw[x * no] = v;
+                io[x * no] = value(v, x);
+            }
+        }
     }
 }
 
@@ -389,6 +515,11 @@ extern "C" int yh_stem_pack_weights(const float* w, const float* conv_bias, cons
     return check_launch();
 }
 
+extern "C" int64_t yh_conv2d_stem_stats_rows(const yh_stem_desc* d) {
+    if (!d || getenv("YH_STEM_VALU")) return 0;
+    return stem_mfma_stats_rows(*d);
+}
+
 extern "C" int yh_conv2d_stem_fwd(const yh_stem_desc* d, void* stream) {
     if (!d || !d->x || !d->w || !d->bias || !d->y) return YH_EINVAL;
     if (d->n <= 0 || d->cin <= 0 || d->cin > 4 || d->h <= 0 || d->w_in <= 0 || d->cout <= 0) return YH_EINVAL;
@@ -398,6 +529,12 @@ extern "C" int yh_conv2d_stem_fwd(const yh_stem_desc* d, void* stream) {
     if (d->ho != (d->h + 2 * d->pad - d->kh) / d->stride + 1 || d->wo != (d->w_in + 2 * d->pad - d->kw) / d->stride + 1) return YH_EINVAL;
     const long P = (long)d->n * d->ho * d->wo;
     hipStream_t s = (hipStream_t)stream;
+    static const bool valu = getenv("YH_STEM_VALU") != nullptr;         // A/B: the packed-FMA kernel below for every shape
+    if (!valu) {
+        const int rc = launch_stem_mfma(*d, s);                          // conv_stem_mfma.hip: 3 x 3 x 3 taps on the matrix cores
+        if (rc != YH_EUNSUPPORTED) return rc;
+    }
+    if (d->stats_ws) return YH_EUNSUPPORTED;                            // only the MFMA kernel has the statistics epilogue
     const bool wide = d->cout_pad % 32 == 0;
     const dim3 grid((unsigned)((P + 255) / 256), (unsigned)(d->cout_pad / (wide ? 32 : 16)));
     static const bool rolled = getenv("YH_STEM_ROLLED") != nullptr;      // A/B: the tap-by-tap loop for every shape
@@ -469,8 +606,15 @@ extern "C" int yh_add_channels(const yh_add_desc* d, void* stream) {
 extern "C" int yh_yolo_decode(const yh_decode_desc* d, void* stream) {
     if (!d || !d->p || !d->io || d->n <= 0 || d->ny <= 0 || d->nx <= 0 || d->na <= 0 || d->na > 8 || d->no < 5) return YH_EINVAL;
     if (d->ldp < d->na * d->no || d->row_off < 0 || d->row_off + d->na * d->ny * d->nx > d->rows_total) return YH_EINVAL;
-    const long rows = (long)d->n * d->na * d->ny;
-    if (rows > 0x7fffffffL) return YH_EINVAL;
-    hipLaunchKernelGGL(yolo_decode_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, *d);
+    const long rows = (long)d->n * d->ny;
+    if (rows > 0x7fffffffL || (long)d->nx * d->ldp > 0x3fffffffL || (long)d->na * d->ny * d->nx * d->no > 0x7fffffffL) return YH_EINVAL;
+    static const bool generic = getenv("YH_DECODE_GENERIC") != nullptr;      // A/B: the element-order kernel for every head
+    if (d->na * d->no <= 256 && !generic) {
+        if (d->raw) hipLaunchKernelGGL(yolo_decode_cell_kernel<true>, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, *d);
+        else hipLaunchKernelGGL(yolo_decode_cell_kernel<false>, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, *d);
+        return check_launch();
+    }
+    if (d->raw) hipLaunchKernelGGL(yolo_decode_kernel<true>, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, *d);
+    else hipLaunchKernelGGL(yolo_decode_kernel<false>, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, *d);
     return check_launch();
 }

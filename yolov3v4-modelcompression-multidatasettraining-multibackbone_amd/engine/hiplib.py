@@ -35,7 +35,8 @@ class StemDesc(C.Structure):
     _fields_ = [('x', _vp), ('w', _vp), ('bias', _vp), ('y', _vp),
                 ('n', _i32), ('cin', _i32), ('h', _i32), ('w_in', _i32), ('ho', _i32), ('wo', _i32),
                 ('cout', _i32), ('cout_pad', _i32), ('kh', _i32), ('kw', _i32), ('stride', _i32), ('pad', _i32),
-                ('ldy', _i32), ('act', _i32), ('slope', _f32), ('dtype', _i32), ('out_scale', _f32)]
+                ('ldy', _i32), ('act', _i32), ('slope', _f32), ('dtype', _i32), ('out_scale', _f32),
+                ('stats_ws', _vp), ('stats_ws_floats', _i64)]
 
 
 class PoolDesc(C.Structure):
@@ -244,6 +245,7 @@ _SIGNATURES = {
     'yh_stem_pack_weights': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _f32, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                        _vp, _vp, _vp]),
     'yh_conv2d_stem_fwd': (C.c_int, [C.POINTER(StemDesc), _vp]),
+    'yh_conv2d_stem_stats_rows': (_i64, [C.POINTER(StemDesc)]),
     'yh_dw_pack_weights': (C.c_int, [C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _f32, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp]),
     'yh_dwconv2d_fwd': (C.c_int, [C.POINTER(DwDesc), _vp]),
     'yh_se_fwd': (C.c_int, [C.POINTER(SeDesc), _vp]),

@@ -396,8 +396,16 @@ class TrainEngine(DarknetEngine):
                                  dtype=self.code, out_scale=0.0)
                     if v.c_phys > pk['cout_pad'] or v.fp32:
                         raise NotImplementedError('HIP training path: stem geometry')
+                    if v.bn is not None and not direct and os.environ.get('YOLO_HIP_STEM_STATS', '1') != '0':
+                        # the MFMA first-layer kernel also emits the BatchNorm partial sums of what it stores (no yh_bn_stats pass)
+                        fused_stats = int(lib.yh_conv2d_stem_stats_rows(C.byref(d)))
+                        if fused_stats:
+                            d.stats_ws_floats = fused_stats * 2 * v.c_phys
+                            plan['ws_floats'] = max(plan['ws_floats'], d.stats_ws_floats)
                     op = add(fwd, plan['fwd_ops'], d, 'stem%d' % v.block)
                     fixup(fwd, op, StemDesc, 'x', SLOT_INPUT)
+                    if fused_stats:
+                        fixup(fwd, op, StemDesc, 'stats_ws', SLOT_WS)
                 else:
                     d = ConvDesc(x=P(s.storage, s.c_off), w=P(pk['w']), bias=P(pk['b']), res=None,
                                  y=None if v.fp32 else (y if direct else P(zt)), n=N, h=s.H, w_in=s.W, cin=s.c_phys,
@@ -431,7 +439,7 @@ class TrainEngine(DarknetEngine):
                     for t in (bn.weight, bn.bias, bn.running_mean, bn.running_var):
                         if t.dtype != torch.float32 or not t.is_contiguous():
                             raise NotImplementedError('HIP training path: BatchNorm tensors must be contiguous fp32')
-                    fused = s.kind != 'input' and fused_stats
+                    fused = bool(fused_stats)
                     if not fused:
                         add_reduction(fwd, plan['fwd_ops'], BnStatsDesc(**base, **bnp), 'bnstat%d' % v.block)
                     fin = BnFinalizeDesc(**base, **bnp, running_mean=P(bn.running_mean), running_var=P(bn.running_var),
