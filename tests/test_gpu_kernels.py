@@ -457,6 +457,13 @@ QCONV_CASES = [
     (2, 29, 30, 48, 64, 3, 1, 0, 1, False, 72),       # cin 48, linear
     (2, 37, 41, 64, 128, 3, 1, 1, 1, False, 72),      # 128 output channels (8-wave workgroups): Darknet-53 conv7 / conv10
     (2, 45, 43, 64, 128, 3, 2, 1, 1, False, 72),      # conv5: stride 2
+    # persistent 1x1 kernel with the weights in LDS on MFMA-i8 (tile 73): every instantiated (MT, KS, MS), pixel tails
+    (3, 37, 41, 256, 128, 1, 1, 1, 1, False, 73),     # (8, 4, 1): the 76^2 layers of Darknet-53
+    (2, 33, 31, 128, 64, 1, 1, 5, 1, False, 73),      # (4, 2, 1) mish
+    (2, 29, 30, 128, 128, 1, 1, 0, 1, False, 73),     # (8, 2, 1) linear
+    (1, 3, 5, 64, 64, 1, 1, 1, 1, False, 73),         # (4, 1, 1): 15 pixels, less than one block
+    (2, 20, 21, 256, 256, 1, 1, 1, 1, False, 73),     # (8, 4, 2): wave pairs share a pixel stream
+    (5, 7, 5, 128, 256, 1, 1, 1, 1, False, 73),       # (8, 2, 2)
 ]
 
 
@@ -484,7 +491,8 @@ def test_int8_conv_matches_emulation(libs, case):
 
 
 @pytest.mark.parametrize('case', [(2, 19, 19, 128, 128, 3, 1, 1, 43), (3, 38, 38, 64, 255, 3, 1, 5, 43), (1, 76, 76, 192, 64, 3, 1, 0, 43),
-                                  (3, 37, 41, 32, 64, 3, 1, 1, 72), (2, 45, 43, 64, 128, 3, 2, 1, 72), (2, 33, 31, 64, 32, 3, 1, 5, 72)],
+                                  (3, 37, 41, 32, 64, 3, 1, 1, 72), (2, 45, 43, 64, 128, 3, 2, 1, 72), (2, 33, 31, 64, 32, 3, 1, 5, 72),
+                                  (3, 37, 41, 256, 128, 1, 1, 1, 73), (2, 20, 21, 256, 256, 1, 1, 0, 73)],
                          ids=lambda c: 'q_n%d_%dx%d_c%d-%d_k%ds%d_a%d_t%d' % c)
 def test_int8_conv_matches_torch_directly(libs, case):
     """the MFMA-i8 forms of the halo ping-pong and streaming 3x3 kernels against torch DIRECTLY, not against

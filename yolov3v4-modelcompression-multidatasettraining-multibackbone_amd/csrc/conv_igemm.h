@@ -448,7 +448,7 @@ int launch_stream3_tile(const ConvArgs& a, int dtype, hipStream_t stream);      
 long stream3_stats_rows(long P, int cout);                                                       // its statistics rows: one per wave
 // conv_pw_lds.hip, tile code 73: 1x1 / s1 with the whole weight matrix (<= 64 KB, Cout <= 256, Cin <= 256) resident in LDS; f16,
 // plain / residual / statistics forms
-int launch_pwl_tile(const ConvArgs& a, hipStream_t stream);
+int launch_pwl_tile(const ConvArgs& a, int dtype, hipStream_t stream);
 bool pwl_supported(int dtype, int out_f32, int cin, int cin_k, int cout, long P, int ldx, int ldy, int ldr, const void* x, const void* y,
                    const void* res, bool stats);
 long pwl_stats_rows(long P, int cout);                                                          // one row per pixel stream

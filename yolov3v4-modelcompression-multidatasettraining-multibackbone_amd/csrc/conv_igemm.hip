@@ -1147,7 +1147,7 @@ extern "C" int yh_conv2d_fwd(const yh_conv_desc* d, void* stream) {
     }
     if (tile == 73) {
         if (!pwl_desc_supported(d)) return YH_EUNSUPPORTED;
-        return launch_pwl_tile(a, s);
+        return launch_pwl_tile(a, d->dtype, s);
     }
     if (d->dtype == YH_F16) {
         return d->out_f32 ? dispatch_tile<f16, float>(a, tile, s) : dispatch_tile<f16, f16>(a, tile, s);

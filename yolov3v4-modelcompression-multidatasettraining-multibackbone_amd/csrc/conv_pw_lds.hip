@@ -18,17 +18,38 @@
 //   * training forward: BatchNorm partial sums of the values as stored, per lane over all of a wave's blocks (a lane always owns the
 //     same 8 channels in the row-major pass), one partial row per pixel stream.
 // Cout up to 256: MS = 2 waves share a pixel stream, each computing 128 of the output channels from the same B rows (the second
-// wave's loads hit L1 / L2).  fp16 only; int8 1x1 layers stay on conv_pointwise.hip / the ring kernels.
+// wave's loads hit L1 / L2).  fp16, and int8 (PTQ inference: v_mfma_i32_16x16x64_i8, 64 channels per K step, the requantising
+// epilogue of conv_igemm.h; plain mode only - the quantised shortcut follows the 3x3 layers, never a 1x1).
 #include "conv_igemm.h"
 
 namespace yh {
 
-// MT: 16-channel row groups per wave (<= 8); KS: K steps of 32 input channels; MS: waves per pixel stream (channel split);
-// MODE 0 plain, 1 residual, 2 statistics
-template <int MT, int KS, int MS, int ACT, int MODE>
+template <typename T> struct PwlMma;
+template <> struct PwlMma<f16> {
+    typedef f16x8 frag_t;
+    typedef f32x4 acc_t;
+    static __device__ __forceinline__ acc_t mma(const frag_t& a, const frag_t& b, const acc_t& c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+    }
+};
+template <> struct PwlMma<int8_t> {
+    typedef i32x4 frag_t;
+    typedef i32x4 acc_t;
+    static __device__ __forceinline__ acc_t mma(const frag_t& a, const frag_t& b, const acc_t& c) {
+        return __builtin_amdgcn_mfma_i32_16x16x64_i8(a, b, c, 0, 0, 0);
+    }
+};
+
+// MT: 16-channel row groups per wave (<= 8); KS: K steps of 32 (fp16) / 64 (int8) input channels; MS: waves per pixel stream
+// (channel split); MODE 0 plain, 1 residual, 2 statistics (fp16 only)
+template <typename T, int MT, int KS, int MS, int ACT, int MODE>
 __global__ __launch_bounds__(512, 2) void conv1x1_lds_kernel(const ConvArgs a, const int nblocks) {
+    typedef typename PwlMma<T>::frag_t frag_t;
+    typedef typename PwlMma<T>::acc_t acc_t;
+    static_assert(sizeof(T) == 2 || MODE == 0, "int8: plain mode only");
+    constexpr int ES = sizeof(T), VEC = 16 / ES, KB = 4 * VEC; // bytes per element, elements per 16-byte unit, channels per K step
     constexpr int NW = 8, TN = 2, BP = TN * 16;               // 8 waves; 32 pixels per block
-    constexpr int ROWB = MT * 32;                             // bytes of this wave's channels in one pixel row
+    constexpr int ROWB = MT * 16 * ES;                        // bytes of this wave's channels in one pixel row
     constexpr int PITCH = ROWB + 16;                          // staging tile pitch (bank spread)
     constexpr int UNITS = ROWB / 16;                          // 16-byte units per pixel row of the wave's channel range
     constexpr int RPI = 64 / UNITS;                           // pixel rows per row-major pass instruction
@@ -42,16 +63,16 @@ __global__ __launch_bounds__(512, 2) void conv1x1_lds_kernel(const ConvArgs a, c
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     unsigned char* const tile = pl_smem + W_BYTES + BIAS_BYTES + wave * (BP * PITCH);
     const int pc = lane & 15, kq = lane >> 4, mq = kq << 2;
-    const f16* const xg = reinterpret_cast<const f16*>(a.x);
-    const f16* const rg = reinterpret_cast<const f16*>(a.res);
-    f16* const yg = reinterpret_cast<f16*>(a.y);
+    const T* const xg = reinterpret_cast<const T*>(a.x);
+    const T* const rg = reinterpret_cast<const T*>(a.res);
+    T* const yg = reinterpret_cast<T*>(a.y);
 
-    // ---- weights -> LDS as A fragments (fragment f = (row group, k step): lane (pc, kq) holds W[16 rg + pc][32 k + 8 kq .. +7])
+    // ---- weights -> LDS as A fragments (fragment f = (row group, k step): lane (pc, kq) holds W[16 rg + pc][KB k + VEC kq .. +VEC-1])
     {
-        const f16* const wg = reinterpret_cast<const f16*>(a.w);
+        const T* const wg = reinterpret_cast<const T*>(a.w);
         for (int f = wave; f < MS * MT * KS; f += NW) {
             const int rgp = f / KS, k = f - rgp * KS;
-            const u32x4 v = *reinterpret_cast<const u32x4*>(wg + (long)(rgp * 16 + pc) * a.cin_k + k * 32 + kq * 8);
+            const u32x4 v = *reinterpret_cast<const u32x4*>(wg + (long)(rgp * 16 + pc) * a.cin_k + k * KB + kq * VEC);
             *reinterpret_cast<u32x4*>(wl + (f * 64 + lane) * 16) = v;
         }
         for (int m = tid; m < MS * MT * 16; m += NW * 64) bl[m] = m < a.Cout ? a.bias[m] : 0.f;
@@ -70,14 +91,14 @@ __global__ __launch_bounds__(512, 2) void conv1x1_lds_kernel(const ConvArgs a, c
 #pragma unroll
     for (int e = 0; e < 8; ++e) s1[e] = s2[e] = 0.f;
 
-    f16x8 fb[TN][KS];
+    frag_t fb[TN][KS];
     u32x4 rv[NPASS];
     auto load_b = [&](int blk, int k) {       // K step k of block blk (clamped: a tail re-loads valid bytes that are never stored)
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             long p = (long)blk * BP + j * 16 + pc;
             p = p < a.P ? p : a.P - 1;
-            fb[j][k] = *reinterpret_cast<const f16x8*>(xg + p * a.ldx + k * 32 + kq * 8);
+            fb[j][k] = *reinterpret_cast<const frag_t*>(xg + p * a.ldx + k * KB + kq * VEC);
         }
     };
     auto load_res = [&](int blk) {
@@ -85,7 +106,7 @@ __global__ __launch_bounds__(512, 2) void conv1x1_lds_kernel(const ConvArgs a, c
         for (int q = 0; q < NPASS; ++q) {
             long p = (long)blk * BP + rr + q * RPI;
             p = p < a.P ? p : a.P - 1;
-            rv[q] = *reinterpret_cast<const u32x4*>(rg + p * a.ldr + ch0 + cu * 8);
+            rv[q] = *reinterpret_cast<const u32x4*>(rg + p * a.ldr + ch0 + cu * VEC);
         }
     };
 
@@ -102,20 +123,20 @@ __global__ __launch_bounds__(512, 2) void conv1x1_lds_kernel(const ConvArgs a, c
 #pragma unroll
             for (int q = 0; q < NPASS; ++q) *reinterpret_cast<u32x4*>(tile + (rr + q * RPI) * PITCH + cu * 16) = rv[q];
         }
-        f32x4 acc[MT][TN];
+        acc_t acc[MT][TN];
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll
-            for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int j = 0; j < TN; ++j) acc[i][j] = acc_t{0, 0, 0, 0};
 #pragma unroll
         for (int k = 0; k < KS; ++k) {
-            f16x8 wa[MT];
+            frag_t wa[MT];
 #pragma unroll
-            for (int i = 0; i < MT; ++i) wa[i] = *reinterpret_cast<const f16x8*>(wl_h + (i * KS + k) * 1024);
+            for (int i = 0; i < MT; ++i) wa[i] = *reinterpret_cast<const frag_t*>(wl_h + (i * KS + k) * 1024);
 #pragma unroll
             for (int i = 0; i < MT; ++i)
 #pragma unroll
-                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[i], fb[j][k], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < TN; ++j) acc[i][j] = PwlMma<T>::mma(wa[i], fb[j][k], acc[i][j]);
             load_b(nb, k);                     // refill: the next block's bytes for this K step
         }
         if constexpr (MODE == 1) load_res(nb);  // before this block's stores: loads and stores share one in-order queue
@@ -126,16 +147,22 @@ __global__ __launch_bounds__(512, 2) void conv1x1_lds_kernel(const ConvArgs a, c
             const f32x4 bv = *reinterpret_cast<const f32x4*>(bl_h + i * 16);
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
-                f16* const cell = reinterpret_cast<f16*>(tile + (j * 16 + pc) * PITCH) + i * 16 + mq;
+                T* const cell = reinterpret_cast<T*>(tile + (j * 16 + pc) * PITCH) + i * 16 + mq;
                 float v[4];
+                if constexpr (sizeof(T) == 1) {      // the requantising epilogue of conv_igemm.h (conv_epilogue_plain)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = activate_c<ACT>(acc[i][j][e] + bv[e], a.slope);
+                    for (int e = 0; e < 4; ++e)
+                        v[e] = round_clamp_i8(activate_c<ACT>((float)acc[i][j][e] * a.acc_scale + bv[e], a.slope) * a.inv_out_scale);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = activate_c<ACT>(acc[i][j][e] + bv[e], a.slope);
+                }
                 if constexpr (MODE == 1) {
                     const f16x4 r = *reinterpret_cast<const f16x4*>(cell);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] += (float)r[e];
                 }
-                store4<f16>(cell, v[0], v[1], v[2], v[3]);
+                store4<T>(cell, v[0], v[1], v[2], v[3]);
             }
         }
         __builtin_amdgcn_wave_barrier();
@@ -146,7 +173,7 @@ __global__ __launch_bounds__(512, 2) void conv1x1_lds_kernel(const ConvArgs a, c
             const int row = rr + q * RPI;
             const u32x4 v = *reinterpret_cast<const u32x4*>(tile + row * PITCH + cu * 16);
             const bool ok = p0 + row < a.P;
-            if (ok) *reinterpret_cast<u32x4*>(yg + (p0 + row) * a.ldy + ch0 + cu * 8) = v;
+            if (ok) *reinterpret_cast<u32x4*>(yg + (p0 + row) * a.ldy + ch0 + cu * VEC) = v;
             if constexpr (MODE == 2) {
                 const f16x8 h = __builtin_bit_cast(f16x8, v);
 #pragma unroll
@@ -179,15 +206,15 @@ __global__ __launch_bounds__(512, 2) void conv1x1_lds_kernel(const ConvArgs a, c
     }
 }
 
-// (MT, KS, MS) of a layer, or false: Cout = 16 MT MS exactly, Cin = 32 KS, weights <= 64 KB, MT <= 8
-static bool pwl_shape(int cin_k, int cout, int* mt, int* ks, int* ms) {
-    if (cin_k % 32 || cout % 16 || cout < 32 || cout > 256 || cin_k < 32 || cin_k > 256) return false;
+// (MT, KS, MS) of a layer, or false: Cout = 16 MT MS exactly, Cin = kb KS (kb = 32 fp16 / 64 int8), weights <= 64 KB, MT <= 8
+static bool pwl_shape(int cin_k, int cout, int kb, int* mt, int* ks, int* ms) {
+    if (cin_k % kb || cout % 16 || cout < 32 || cout > 256 || cin_k < kb || cin_k > 8 * kb) return false;
     *ms = cout > 128 ? 2 : 1;
     if (cout % (16 * *ms)) return false;
     *mt = cout / (16 * *ms);
-    *ks = cin_k / 32;
+    *ks = cin_k / kb;
     if (*mt > 8 || (*mt != 2 && *mt != 4 && *mt != 8) || (*ks != 1 && *ks != 2 && *ks != 4 && *ks != 8)) return false;
-    return (long)cout * cin_k * 2 <= 64 * 1024;
+    return (long)cout * cin_k * (kb == 32 ? 2 : 1) <= 64 * 1024;
 }
 
 static int pwl_grid(long P, int ms, int* nblocks) {
@@ -197,12 +224,21 @@ static int pwl_grid(long P, int ms, int* nblocks) {
     return (int)(wgs < 1 ? 1 : wgs);
 }
 
+// int8 instantiations (launch_pwl_tile): 256 -> 128 (76^2 of Darknet-53), 128 -> 64, 128 -> 128, 64 -> 64, 256 -> 256 / 128 -> 256 (CSP stages)
+static bool pwl_i8_case(int mt, int ks, int ms) {
+    return (mt == 8 && ks == 4 && ms == 1) || (mt == 4 && ks == 2 && ms == 1) || (mt == 8 && ks == 2 && ms == 1) || (mt == 4 && ks == 1 && ms == 1) ||
+           (mt == 8 && ks == 4 && ms == 2) || (mt == 8 && ks == 2 && ms == 2);
+}
+
 bool pwl_supported(int dtype, int out_f32, int cin, int cin_k, int cout, long P, int ldx, int ldy, int ldr, const void* x, const void* y,
                    const void* res, bool stats) {
     int mt, ks, ms;
-    if (dtype != YH_F16 || out_f32 || cin != cin_k || !pwl_shape(cin_k, cout, &mt, &ks, &ms)) return false;
+    if ((dtype != YH_F16 && dtype != YH_I8) || out_f32 || cin != cin_k) return false;
+    if (!pwl_shape(cin_k, cout, dtype == YH_I8 ? 64 : 32, &mt, &ks, &ms)) return false;
     if (stats && res) return false;
-    if (ldx % 8 || ldy % 8 || (res && ldr % 8) || !aligned16(x) || !aligned16(y) || (res && !aligned16(res))) return false;
+    if (dtype == YH_I8 && (stats || res || !pwl_i8_case(mt, ks, ms))) return false;      // plain mode, the shapes instantiated below
+    const int vec = dtype == YH_I8 ? 16 : 8;
+    if (ldx % vec || ldy % vec || (res && ldr % vec) || !aligned16(x) || !aligned16(y) || (res && !aligned16(res))) return false;
     return P > 0 && P < (1L << 31) - 64;
 }
 
@@ -212,46 +248,61 @@ long pwl_stats_rows(long P, int cout) {
     return (long)pwl_grid(P, ms, &nblocks) * 8 / ms;
 }
 
-template <int MT, int KS, int MS, int ACT> static int launch_pwl_mode(const ConvArgs& a, hipStream_t s) {
+template <typename T, int MT, int KS, int MS, int ACT> static int launch_pwl_mode(const ConvArgs& a, hipStream_t s) {
     int nblocks;
     const int grid = pwl_grid(a.P, MS, &nblocks);
-    const size_t lds = (size_t)MS * MT * KS * 1024 + (size_t)MS * MT * 16 * 4 + (size_t)8 * 32 * (MT * 32 + 16);
+    const size_t lds = (size_t)MS * MT * KS * 1024 + (size_t)MS * MT * 16 * 4 + (size_t)8 * 32 * (MT * 16 * sizeof(T) + 16);
 #define YH_PWL_GO(MODE)                                                                                       \
     do {                                                                                                      \
-        auto kern = conv1x1_lds_kernel<MT, KS, MS, ACT, MODE>;                                                \
+        auto kern = conv1x1_lds_kernel<T, MT, KS, MS, ACT, MODE>;                                             \
         const hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds);                    \
         if (e != hipSuccess) return (int)e;                                                                   \
         hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, s, a, nblocks);                                  \
     } while (0)
-    if (a.stats_part) YH_PWL_GO(2);
-    else if (a.res) YH_PWL_GO(1);
-    else YH_PWL_GO(0);
+    if constexpr (sizeof(T) == 1) {
+        if (a.stats_part || a.res) return YH_EUNSUPPORTED;
+        YH_PWL_GO(0);
+    } else {
+        if (a.stats_part) YH_PWL_GO(2);
+        else if (a.res) YH_PWL_GO(1);
+        else YH_PWL_GO(0);
+    }
 #undef YH_PWL_GO
     return check_launch();
 }
 
-template <int MT, int KS, int MS> static int launch_pwl_act(const ConvArgs& a, hipStream_t s) {
+template <typename T, int MT, int KS, int MS> static int launch_pwl_act(const ConvArgs& a, hipStream_t s) {
     switch (a.act) {
-        case YH_ACT_LINEAR: return launch_pwl_mode<MT, KS, MS, YH_ACT_LINEAR>(a, s);
-        case YH_ACT_LEAKY: return launch_pwl_mode<MT, KS, MS, YH_ACT_LEAKY>(a, s);
-        case YH_ACT_MISH: return launch_pwl_mode<MT, KS, MS, YH_ACT_MISH>(a, s);
+        case YH_ACT_LINEAR: return launch_pwl_mode<T, MT, KS, MS, YH_ACT_LINEAR>(a, s);
+        case YH_ACT_LEAKY: return launch_pwl_mode<T, MT, KS, MS, YH_ACT_LEAKY>(a, s);
+        case YH_ACT_MISH: return launch_pwl_mode<T, MT, KS, MS, YH_ACT_MISH>(a, s);
         default: return YH_EUNSUPPORTED;
     }
 }
 
 // tile code 73 (conv_igemm.hip yh_conv2d_tile)
-int launch_pwl_tile(const ConvArgs& a, hipStream_t s) {
+int launch_pwl_tile(const ConvArgs& a, int dtype, hipStream_t s) {
     int mt, ks, ms;
-    if (!pwl_shape(a.cin_k, a.Cout, &mt, &ks, &ms)) return YH_EUNSUPPORTED;
-#define YH_PWL_CASE(M, K, S2) if (mt == M && ks == K && ms == S2) return launch_pwl_act<M, K, S2>(a, s)
-    YH_PWL_CASE(2, 2, 1);    //  64 ->  32   (304^2 forward)
-    YH_PWL_CASE(4, 1, 1);    //  32 ->  64   (304^2 data gradient)
-    YH_PWL_CASE(4, 4, 1);    // 128 ->  64   (152^2 forward)
-    YH_PWL_CASE(8, 2, 1);    //  64 -> 128   (152^2 data gradient)
-    YH_PWL_CASE(8, 8, 1);    // 256 -> 128   (76^2 forward)
-    YH_PWL_CASE(8, 4, 2);    // 128 -> 256   (76^2 data gradient)
-    YH_PWL_CASE(8, 4, 1);    // 128 -> 128   (YOLOv4 CSP stages)
-    YH_PWL_CASE(4, 2, 1);    //  64 ->  64
+    if (!pwl_shape(a.cin_k, a.Cout, dtype == YH_I8 ? 64 : 32, &mt, &ks, &ms)) return YH_EUNSUPPORTED;
+#define YH_PWL_CASE(T, M, K, S2) if (mt == M && ks == K && ms == S2) return launch_pwl_act<T, M, K, S2>(a, s)
+    if (dtype == YH_I8) {
+        YH_PWL_CASE(int8_t, 8, 4, 1);    // 256 -> 128   (76^2)
+        YH_PWL_CASE(int8_t, 4, 2, 1);    // 128 ->  64   (152^2)
+        YH_PWL_CASE(int8_t, 8, 2, 1);    // 128 -> 128   (YOLOv4 CSP stages)
+        YH_PWL_CASE(int8_t, 4, 1, 1);    //  64 ->  64
+        YH_PWL_CASE(int8_t, 8, 4, 2);    // 256 -> 256
+        YH_PWL_CASE(int8_t, 8, 2, 2);    // 128 -> 256
+        return YH_EUNSUPPORTED;
+    }
+    if (dtype != YH_F16) return YH_EUNSUPPORTED;
+    YH_PWL_CASE(f16, 2, 2, 1);    //  64 ->  32   (304^2 forward)
+    YH_PWL_CASE(f16, 4, 1, 1);    //  32 ->  64   (304^2 data gradient)
+    YH_PWL_CASE(f16, 4, 4, 1);    // 128 ->  64   (152^2 forward)
+    YH_PWL_CASE(f16, 8, 2, 1);    //  64 -> 128   (152^2 data gradient)
+    YH_PWL_CASE(f16, 8, 8, 1);    // 256 -> 128   (76^2 forward)
+    YH_PWL_CASE(f16, 8, 4, 2);    // 128 -> 256   (76^2 data gradient)
+    YH_PWL_CASE(f16, 8, 4, 1);    // 128 -> 128   (YOLOv4 CSP stages)
+    YH_PWL_CASE(f16, 4, 2, 1);    //  64 ->  64
 #undef YH_PWL_CASE
     return YH_EUNSUPPORTED;
 }
