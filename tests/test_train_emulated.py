@@ -92,6 +92,31 @@ def test_first_block_backward_in_one_pass_equals_the_four_launch_form(mini16, mo
         assert th.rel_l2(grads_a[k], grads_ref[k]) <= 1.05 * th.rel_l2(grads_b[k], grads_ref[k]) + 1e-4, k
 
 
+def test_first_layer_statistics_ride_in_its_epilogue(mini16, monkeypatch):
+    """csrc/conv_stem_mfma.hip (emulated here): the first-layer kernel emits the BatchNorm partial sums of what it stores
+    (yh_conv2d_stem_stats_rows rows of [2][cout], summed by yh_bn_finalize like a conv's stats_ws rows), so the plan has no
+    yh_bn_stats pass over the largest tensor of the net (reference models.py:100 computes these statistics inside BatchNorm2d).
+    YOLO_HIP_STEM_STATS=0 keeps the separate pass: on fp32 storage both plans produce the same step up to the order of the sums."""
+    model = th.build(mini16, 52)
+    x = synth.image_batch(4, 52, seed=0)
+    _, _, _, ws = th.eager_step(model, x)
+    raws_a, grads_a, m = th.engine_step(model, x, ws, 'fp32', lib=fakelib.FakeLib())
+    plan = m.__dict__['_hip_train_engine']._current
+    names = [w for w, _ in plan['fwd_ops']]
+    assert 'stem0' in names and 'bnfin0' in names and 'bnstat0' not in names
+    stem = dict(plan['fwd_ops'])['stem0']
+    fin = dict(plan['fwd_ops'])['bnfin0']
+    assert stem.stats_ws_floats == fin.nparts * 2 * stem.cout and fin.nparts == 2      # FakeLib reports two rows
+    monkeypatch.setenv('YOLO_HIP_STEM_STATS', '0')
+    raws_b, grads_b, m = th.engine_step(model, x, ws, 'fp32', lib=fakelib.FakeLib())
+    names = [w for w, _ in m.__dict__['_hip_train_engine']._current['fwd_ops']]
+    assert 'bnstat0' in names
+    for a, b in zip(raws_a, raws_b):
+        assert (a - b).abs().max().item() <= 1e-5 * b.abs().max().item()
+    for k in grads_a:
+        assert th.rel_l2(grads_a[k], grads_b[k]) <= 1e-4, (k, th.rel_l2(grads_a[k], grads_b[k]))
+
+
 def test_next_data_gradient_fused_into_the_first_block_backward(monkeypatch):
     """Darknet-53's opening (3x3 32, then 3x3 / s2 64 as the stem's only consumer): the data gradient of the second conv is computed
     inside the first block's backward pass (yh_stem_bwd dz1 / w1) - no dgrad launch, dy of block 0 never exists.  Same fp16 step with
