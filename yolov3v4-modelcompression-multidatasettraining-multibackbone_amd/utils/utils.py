@@ -294,15 +294,22 @@ def nms_greedy(boxes, scores, iou_thres):
     if n == 0:
         return torch.zeros(0, dtype=torch.long, device=boxes.device)
     order = torch.argsort(scores, descending=True, stable=True)
-    b = boxes[order]
-    iou = box_iou(b, b)
-    alive = torch.ones(n, dtype=torch.bool)
-    over = (iou > iou_thres).cpu()
+    b = boxes[order].detach().cpu().float().numpy()
+    # one IoU ROW per kept box (box_iou's arithmetic in fp32) instead of the n x n matrix: evaluation settings (test.py: conf 0.001,
+    # multi-label) give 10^4 candidates per image, 2 GB of matrix and a minute of Python per image in the quadratic form
+    area = (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1])
+    alive = np.ones(n, dtype=bool)
+    thr = np.float32(iou_thres)
     keep = []
     for i in range(n):
-        if alive[i]:
-            keep.append(i)
-            alive &= ~over[i]
+        if not alive[i]:
+            continue
+        keep.append(i)
+        w = np.minimum(b[i, 2], b[i + 1:, 2]) - np.maximum(b[i, 0], b[i + 1:, 0])
+        h = np.minimum(b[i, 3], b[i + 1:, 3]) - np.maximum(b[i, 1], b[i + 1:, 1])
+        inter = np.maximum(w, np.float32(0)) * np.maximum(h, np.float32(0))
+        with np.errstate(divide='ignore', invalid='ignore'):      # degenerate boxes: 0 / 0 = NaN compares False, as in torch
+            alive[i + 1:] &= ~(inter / (area[i] + area[i + 1:] - inter) > thr)
     return order[torch.tensor(keep, dtype=torch.long, device=boxes.device)]
 
 
