@@ -256,6 +256,11 @@ typedef struct yh_qadd_desc {
     float rx, ra, scale_x, scale_a, inv_scale_sum;
 } yh_qadd_desc;
 int yh_qadd(const yh_qadd_desc* d, void* stream);
+/* Device self-test of the Mish the int8 epilogues use (csrc/common.h mish_for_grid: a cheap form, the exact form wherever the
+ * result lies next to a rounding tie of the activation grid) over the float bit patterns [bits0, bits1), |v| <= 64:
+ * out[0] = values whose int8 grid index differs from the exact form's (must be 0), out[1] = largest relative difference of the
+ * cheap form in units of 1e-9, out[2] = values decided by the exact form.  out: 3 x uint64 in device memory, zeroed by the caller. */
+int yh_qmish_selftest(uint32_t bits0, uint32_t bits1, float inv_s, uint64_t* out, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * YOLO head decode, YOLOLayer.forward eval branch (models.py:406-418, grid :367-378, anchors :362):

@@ -524,6 +524,28 @@ def test_int8_conv_matches_torch_directly(libs, case):
         assert torch.equal(got, want), (diff.max().item(), (diff > 0).float().mean().item())
 
 
+def test_int8_mish_gives_the_exact_forms_grid_value_for_every_float(libs):
+    """The Mish of the int8 epilogues (csrc/common.h mish_for_grid: a cheap form - hardware exp2 / rcp with one correction step each -
+    and the exact form wherever the scaled result lies next to a rounding tie) against the exact form of the other kernels, over
+    EVERY normal float up to |v| = 64, for the activation scales the calibrated nets use: the rounded int8 value is the same
+    for all 2.2e9 inputs per scale, the cheap form is within 1e-6 relative everywhere (the fallback band is 4e-6), and the exact
+    form is consulted for well under 1 value in 1000.  That is what keeps the int8 heads bit-equal to the reference's on exact
+    frames (tests/test_ptq_large.py) at about half the epilogue's instructions (reference Mish: models.py, x * tanh(softplus(x)))."""
+    lib, _ = libs
+    if GPU == 'cpu':
+        pytest.skip('device self-test')
+    out = torch.zeros(3, dtype=torch.int64, device=GPU)
+    for inv_s in (2.0 ** 2, 2.0 ** 3, 2.0 ** 4, 2.0 ** 5, 2.0 ** 6, 2.0 ** 7):
+        for b0, b1 in ((0x00800000, 0x42800001), (0x80800000, 0xC2800001)):        # every normal float with |v| <= 64, both signs
+            out.zero_()
+            assert lib.yh_qmish_selftest(b0, b1, inv_s, oh.P(out), oh.stream()) == 0
+            torch.cuda.synchronize()
+            bad, worst, slow = out.tolist()
+            assert bad == 0, (inv_s, hex(b0), bad)
+            assert worst <= 1000, (inv_s, hex(b0), worst * 1e-9)
+            assert slow <= 1e-3 * (b1 - b0), (inv_s, hex(b0), slow / (b1 - b0))
+
+
 @pytest.mark.parametrize('tile,stride,cout', [(0, 1, 64), (24, 1, 64), (72, 1, 64), (72, 2, 64), (72, 1, 32), (72, 1, 128)],
                          ids=['auto', 'ring', 'stream3', 'stream3_s2', 'stream3_c32', 'stream3_c128'])
 def test_int8_fused_shortcut_matches_emulation(libs, tile, stride, cout):

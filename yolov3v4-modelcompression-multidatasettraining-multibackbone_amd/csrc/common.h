@@ -35,6 +35,59 @@ __device__ __forceinline__ float activate(float v, int act, float slope) {
     }
 }
 
+// e^x to ~1 ulp on the hardware exp2: x log2(e) in two pieces (product and its rounding error + the low word of log2 e), the second
+// folded back in as a first-order correction.  ocml's expf costs ~25 VALU slots per value, this 7; v_exp_f32 saturates to 0 / inf
+// at the ends of the range like expf.
+__device__ __forceinline__ float exp_fast(float x) {
+    const float L2E_HI = 1.44269502162933349609375f, L2E_LO = 1.92596299e-8f;
+    const float t = x * L2E_HI;
+    const float r = fmaf(x, L2E_LO, fmaf(x, L2E_HI, -t));
+    const float e = __builtin_amdgcn_exp2f(t);
+    return fmaf(e, r * 0.693147180559945f, e);
+}
+// 1 / d for d >= 1 (finite or +inf): the hardware reciprocal (1 ulp) refined by one Newton step
+__device__ __forceinline__ float rcp_fast(float d) {
+    const float r = __builtin_amdgcn_rcpf(d);
+    return d < 3.0e38f ? fmaf(fmaf(-d, r, 1.f), r, r) : r;
+}
+
+// Mish for the int8 (PTQ) epilogues, whose result is rounded onto the activation grid right away.  mish_fast costs ~20 VALU slots
+// where activate()'s form (ocml expf + IEEE divide) costs ~45, and agrees with it to < 1e-6 relative for every float (exhaustive
+// device self-test yh_qmish_selftest, tests/test_gpu_kernels.py).  mish_for_grid returns a value whose ROUNDED grid index is that
+// of activate()'s for every input: where the fast value, scaled by 1 / s_a, lies within 4e-6 relative of a rounding tie (k + 0.5)
+// - a few values in 10^5 - the exact form decides.  The int8 heads stay bit-equal to the reference on exact frames
+// (tests/test_ptq_large.py), which a plain substitution of the fast form did not (measured: a handful of values per tensor flip).
+__device__ __forceinline__ float mish_fast(float v) {
+    const float e = exp_fast(fminf(v, 20.f));
+    const float n = e * (e + 2.f);
+    return v > 20.f ? v : v * (n * rcp_fast(n + 2.f));
+}
+__device__ __forceinline__ float mish_for_grid(float v, float inv_s) {
+    float y = mish_fast(v);
+    const float t = fabsf(y * inv_s);
+    const float f = t - floorf(t);
+    if (fabsf(f - 0.5f) <= 4e-6f * t) y = activate(v, YH_ACT_MISH, 0.f);
+    return y;
+}
+// the same for the N values of a fragment with ONE branch: a per-value branch costs the fast form its advantage (measured: no gain,
+// every value a basic block of its own); if any of the N lies next to a tie, all N take the exact form (same grid values either way)
+template <int N> __device__ __forceinline__ void mish_for_grid_n(float (&v)[N], float inv_s) {
+    float y[N];
+    bool near = false;
+#pragma unroll
+    for (int e = 0; e < N; ++e) {
+        y[e] = mish_fast(v[e]);
+        const float t = fabsf(y[e] * inv_s);
+        near = near || fabsf((t - floorf(t)) - 0.5f) <= 4e-6f * t;
+    }
+    if (near) {
+#pragma unroll
+        for (int e = 0; e < N; ++e) y[e] = activate(v[e], YH_ACT_MISH, 0.f);
+    }
+#pragma unroll
+    for (int e = 0; e < N; ++e) v[e] = y[e];
+}
+
 template <typename T> __device__ __forceinline__ float to_f32(T v) { return (float)v; }
 
 inline int check_launch() {

@@ -52,7 +52,7 @@ __device__ __forceinline__ void hpp_epilogue(const ConvArgs& a, AccT (&acc)[8][4
     auto value = [&](auto ic, auto jc, int e) {
         constexpr int i = decltype(ic)::value, j = decltype(jc)::value;
         if constexpr (sizeof(T) == 1) {
-            const float y = activate_c<ACT>((float)acc[i][j][e] * a.acc_scale + bvs[i][e], a.slope);
+            const float y = activate_q<ACT>((float)acc[i][j][e] * a.acc_scale + bvs[i][e], a.slope, a.inv_out_scale);
             return round_clamp_i8(y * a.inv_out_scale);
         } else {
             return activate_c<ACT>((float)acc[i][j][e] + bvs[i][e], a.slope);
@@ -121,11 +121,21 @@ __device__ __forceinline__ void hpp_epilogue(const ConvArgs& a, AccT (&acc)[8][4
             constexpr int i2 = decltype(ic)::value;
             typedef std::integral_constant<int, 2 * i2> I0;
             typedef std::integral_constant<int, 2 * i2 + 1> I1;
-            float v[8];
+            float v[8], qa[4], qb[4];
+            if constexpr (sizeof(T) == 1) {
+                quantize4<ACT>(acc[I0::value][decltype(jc)::value], bvs[I0::value], a, qa);
+                quantize4<ACT>(acc[I1::value][decltype(jc)::value], bvs[I1::value], a, qb);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    qa[e] = value(I0{}, jc, e);
+                    qb[e] = value(I1{}, jc, e);
+                }
+            }
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const unsigned lo = __builtin_bit_cast(unsigned, (float)value(I0{}, jc, e));
-                const unsigned hi = __builtin_bit_cast(unsigned, (float)value(I1{}, jc, e));
+                const unsigned lo = __builtin_bit_cast(unsigned, qa[e]);
+                const unsigned hi = __builtin_bit_cast(unsigned, qb[e]);
                 const auto r = __builtin_amdgcn_permlane16_swap(lo, hi, false, false);
                 v[e] = __builtin_bit_cast(float, (unsigned)r[0]);
                 v[4 + e] = __builtin_bit_cast(float, (unsigned)r[1]);

@@ -151,6 +151,28 @@ template <int ACT> __device__ __forceinline__ float activate_c(float v, float sl
     else return v;
 }
 
+// the int8 epilogues' activation: activate_c, with mish through common.h's mish_for_grid (same grid value, ~half the instructions)
+template <int ACT> __device__ __forceinline__ float activate_q(float v, float slope, float inv_out_scale) {
+    if constexpr (ACT == YH_ACT_MISH) return mish_for_grid(v, inv_out_scale);
+    else return activate_c<ACT>(v, slope);
+}
+
+// int8 epilogue of one fragment: q[e] = round_clamp_i8(act(acc[e] * s_w s_x + bias[e]) / s_a), the four values of a lane together
+// (mish takes its fast / exact decision once per fragment, common.h mish_for_grid_n)
+template <int ACT, typename AccV>
+__device__ __forceinline__ void quantize4(const AccV& acc, const f32x4& bias, const ConvArgs& a, float (&q)[4]) {
+    float y[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) y[e] = (float)acc[e] * a.acc_scale + bias[e];
+    if constexpr (ACT == YH_ACT_MISH) mish_for_grid_n<4>(y, a.inv_out_scale);
+    else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) y[e] = activate_c<ACT>(y[e], a.slope);
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) q[e] = round_clamp_i8(y[e] * a.inv_out_scale);
+}
+
 // The common case of the epilogue - plain dense NHWC store (ups == 1) - with the activation fixed at compile time: the code a
 // wave executes for its 32 fragments is then ~1.5 k instructions instead of a 40 k-instruction body with every activation and
 // every store form unrolled per fragment (instruction-cache misses dominated the generic form on the 128 x 64 wave tiles).
@@ -165,7 +187,7 @@ __device__ __forceinline__ void conv_epilogue_plain(const ConvArgs& a, AccT (&ac
     auto value = [&](auto ic, auto jc, int e) {
         constexpr int i = decltype(ic)::value, j = decltype(jc)::value;
         if constexpr (sizeof(T) == 1) {
-            const float y = activate_c<ACT>((float)acc[i][j][e] * a.acc_scale + bvs[i][e], a.slope);
+            const float y = activate_q<ACT>((float)acc[i][j][e] * a.acc_scale + bvs[i][e], a.slope, a.inv_out_scale);
             const float q = round_clamp_i8(y * a.inv_out_scale);
             return sizeof(OutT) == 1 ? q : q * a.out_scale;
         } else {
@@ -242,8 +264,16 @@ __device__ __forceinline__ void conv_epilogue_plain(const ConvArgs& a, AccT (&ac
                 const int m = mbase + i * 16;
                 if (m >= a.Cout) return;
                 float v[4];
+                if constexpr (sizeof(T) == 1) {
+                    quantize4<ACT>(acc[i][J::value], bvs[i], a, v);
+                    if constexpr (sizeof(OutT) != 1) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = value(ic, J{}, e);
+                        for (int e = 0; e < 4; ++e) v[e] *= a.out_scale;
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = value(ic, J{}, e);
+                }
                 if constexpr (sizeof(T) != 1) {
                     if (have_res) {
 #pragma unroll
@@ -417,7 +447,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, AccT (&acc)[TM]
                     // activation in fp32, then round-half-away/clamp onto the activation grid
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        const float y = activate((float)acc[i][j][e] * a.acc_scale + bv[e], a.act, a.slope);
+                        const float t = (float)acc[i][j][e] * a.acc_scale + bv[e];
+                        const float y = a.act == YH_ACT_MISH ? mish_for_grid(t, a.inv_out_scale) : activate(t, a.act, a.slope);
                         const float q = round_clamp_i8(y * a.inv_out_scale);
                         v[e] = sizeof(OutT) == 1 ? q : q * a.out_scale;
                     }

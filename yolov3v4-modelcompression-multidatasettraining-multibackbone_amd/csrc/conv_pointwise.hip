@@ -83,11 +83,23 @@ __global__ __launch_bounds__(256) void conv_pointwise_kernel(const ConvArgs a, c
             }
         auto value = [&](int i, int j, int e) {
             if constexpr (sizeof(T) == 1) {
-                const float y = activate_c<ACT>((float)acc[i][j][e] * a.acc_scale + bvs[i][e], a.slope);
+                const float y = activate_q<ACT>((float)acc[i][j][e] * a.acc_scale + bvs[i][e], a.slope, a.inv_out_scale);
                 const float q = round_clamp_i8(y * a.inv_out_scale);
                 return sizeof(OutT) == 1 ? q : q * a.out_scale;
             } else {
                 return activate_c<ACT>((float)acc[i][j][e] + bvs[i][e], a.slope);
+            }
+        };
+        auto value4 = [&](int i, int j, float (&o)[4]) {
+            if constexpr (sizeof(T) == 1) {
+                quantize4<ACT>(acc[i][j], bvs[i], a, o);
+                if constexpr (sizeof(OutT) != 1) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] *= a.out_scale;
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = value(i, j, e);
             }
         };
         if (coalesced) {
@@ -99,9 +111,11 @@ __global__ __launch_bounds__(256) void conv_pointwise_kernel(const ConvArgs a, c
 #pragma unroll
             for (int j = 0; j < TN; ++j)
 #pragma unroll
-                for (int i = 0; i < MT; ++i)
-                    store4<OutT>(reinterpret_cast<OutT*>(tile + (j * 16 + pc) * PITCH) + i * 16 + mq, value(i, j, 0), value(i, j, 1),
-                                 value(i, j, 2), value(i, j, 3));
+                for (int i = 0; i < MT; ++i) {
+                    float o[4];
+                    value4(i, j, o);
+                    store4<OutT>(reinterpret_cast<OutT*>(tile + (j * 16 + pc) * PITCH) + i * 16 + mq, o[0], o[1], o[2], o[3]);
+                }
             __builtin_amdgcn_wave_barrier();
             const long p0 = blk * (TN * 16);
             const int valid_units = (a.Cout * (int)sizeof(OutT) + 15) / 16;
@@ -122,7 +136,11 @@ __global__ __launch_bounds__(256) void conv_pointwise_kernel(const ConvArgs a, c
 #pragma unroll
                     for (int i = 0; i < MT; ++i) {
                         const int m = i * 16 + mq;
-                        if (m < a.Cout) store4<OutT>(prow + m, value(i, j, 0), value(i, j, 1), value(i, j, 2), value(i, j, 3));
+                        if (m < a.Cout) {
+                            float o[4];
+                            value4(i, j, o);
+                            store4<OutT>(prow + m, o[0], o[1], o[2], o[3]);
+                        }
                     }
                 }
             }

@@ -150,9 +150,7 @@ __global__ __launch_bounds__(512, 2) void conv1x1_lds_kernel(const ConvArgs a, c
                 T* const cell = reinterpret_cast<T*>(tile + (j * 16 + pc) * PITCH) + i * 16 + mq;
                 float v[4];
                 if constexpr (sizeof(T) == 1) {      // the requantising epilogue of conv_igemm.h (conv_epilogue_plain)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        v[e] = round_clamp_i8(activate_c<ACT>((float)acc[i][j][e] * a.acc_scale + bv[e], a.slope) * a.inv_out_scale);
+                    quantize4<ACT>(acc[i][j], bv, a, v);
                 } else {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = activate_c<ACT>(acc[i][j][e] + bv[e], a.slope);

@@ -225,7 +225,8 @@ __global__ __launch_bounds__(256, 2) void conv_stem_mfma_kernel(const yh_stem_de
         }
     };
     auto finish = [&](float v) {
-        float y = ACT == YH_ACT_LINEAR ? v : ACT == YH_ACT_LEAKY ? (v > 0.f ? v : v * d.slope) : activate(v, d.act, d.slope);
+        float y = ACT == YH_ACT_LINEAR ? v : ACT == YH_ACT_LEAKY ? (v > 0.f ? v : v * d.slope)
+                  : (sizeof(T) == 1 && d.act == YH_ACT_MISH) ? mish_for_grid(v, inv_q) : activate(v, d.act, d.slope);
         if constexpr (sizeof(T) == 1) {      // PTQ: onto the activation grid (round half away, clamp)
             const float s = y * inv_q;
             y = fminf(fmaxf(copysignf(floorf(fabsf(s) + 0.5f), s), -128.f), 127.f);

@@ -166,13 +166,11 @@ __global__ __launch_bounds__(S3_WAVES * 64, OCC) void conv3x3_stream_kernel(cons
 #pragma unroll
             for (int i = 0; i < MT; ++i) {
                 float v[4];
+                if constexpr (sizeof(T) == 1) quantize4<ACT>(acc[i][j], bvs[i], a, v);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     if constexpr (sizeof(T) == 1) {
-                        const float y = activate_c<ACT>((float)acc[i][j][e] * a.acc_scale + bvs[i][e], a.slope);
-                        float q = round_clamp_i8(y * a.inv_out_scale);
-                        if constexpr (HAS_RES) q = qadd_value(q, (float)(int8_t)((rv[j][i] >> (8 * e)) & 0xff), a);
-                        v[e] = q;
+                        if constexpr (HAS_RES) v[e] = qadd_value(v[e], (float)(int8_t)((rv[j][i] >> (8 * e)) & 0xff), a);
                     } else {
                         float y = activate_c<ACT>((float)acc[i][j][e] + bvs[i][e], a.slope);
                         if constexpr (HAS_RES) y += (float)rv[j][i][e];

@@ -302,22 +302,6 @@ __global__ __launch_bounds__(256) void add_gather_kernel(const yh_add_desc d) {
 }
 
 // ------------------------------------------------------------------------------------- yolo decode
-// e^x to ~1 ulp on the hardware exp2: x log2(e) in two pieces (product and its rounding error + the low word of log2 e), the second
-// folded back in as a first-order correction.  ocml's expf costs ~25 VALU slots per value, this 7; v_exp_f32 saturates to 0 / inf
-// at the ends of the range like expf.
-__device__ __forceinline__ float exp_fast(float x) {
-    const float L2E_HI = 1.44269502162933349609375f, L2E_LO = 1.92596299e-8f;
-    const float t = x * L2E_HI;
-    const float r = fmaf(x, L2E_LO, fmaf(x, L2E_HI, -t));
-    const float e = __builtin_amdgcn_exp2f(t);
-    return fmaf(e, r * 0.693147180559945f, e);
-}
-// 1 / d for d >= 1 (finite or +inf): the hardware reciprocal (1 ulp) refined by one Newton step
-__device__ __forceinline__ float rcp_fast(float d) {
-    const float r = __builtin_amdgcn_rcpf(d);
-    return d < 3.0e38f ? fmaf(fmaf(-d, r, 1.f), r, r) : r;
-}
-
 // grid.x = n * ny: one workgroup per (image, grid row).  Threads sweep the nx cells of the row in memory order - a cell's
 // na * no head values are contiguous, so every wave load is one dense run - and write the na output runs of the row (each
 // nx * no floats, contiguous in io and raw).  The (cell, anchor, channel) index of a thread advances by 256 elements per trip with

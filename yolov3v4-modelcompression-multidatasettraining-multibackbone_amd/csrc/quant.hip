@@ -131,6 +131,38 @@ extern "C" int yh_qpool(const yh_pool_desc* d, void* stream) {
     return check_launch();
 }
 
+// Self-test of the int8 epilogues' Mish (common.h mish_for_grid) over float bit patterns [bits0, bits1): out[0] = values whose grid
+// index round_clamp(mish * inv_s) differs between the exact form and mish_for_grid, out[1] = max relative difference (as float bits,
+// in units of 1e-9) between the exact form and mish_fast, out[2] = values on which the exact form was consulted.
+__global__ __launch_bounds__(256) void qmish_selftest_kernel(unsigned bits0, unsigned bits1, float inv_s, unsigned long long* out) {
+    unsigned long long bad = 0, slow = 0;
+    unsigned worst = 0;
+    const unsigned long long n = (unsigned long long)bits1 - bits0;
+    for (unsigned long long i = blockIdx.x * (unsigned long long)blockDim.x + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * blockDim.x) {
+        const float v = __uint_as_float(bits0 + (unsigned)i);
+        if (!(fabsf(v) <= 64.f)) continue;
+        const float ye = activate(v, YH_ACT_MISH, 0.f), yf = mish_fast(v), yg = mish_for_grid(v, inv_s);
+        const float qe = fminf(fmaxf(copysignf(floorf(fabsf(ye * inv_s) + 0.5f), ye * inv_s), -128.f), 127.f);
+        const float qg = fminf(fmaxf(copysignf(floorf(fabsf(yg * inv_s) + 0.5f), yg * inv_s), -128.f), 127.f);
+        bad += qe != qg;
+        slow += __float_as_uint(yg) != __float_as_uint(yf);
+        if (fabsf(ye) > 1e-30f) {
+            const float rel = fabsf(yf - ye) / fabsf(ye) * 1e9f;
+            worst = max(worst, (unsigned)fminf(rel, 4e9f));
+        }
+    }
+    atomicAdd(out, bad);
+    atomicMax(out + 1, (unsigned long long)worst);
+    atomicAdd(out + 2, slow);
+}
+
+extern "C" int yh_qmish_selftest(uint32_t bits0, uint32_t bits1, float inv_s, uint64_t* out, void* stream) {
+    if (!out || bits1 < bits0 || !(inv_s > 0.f)) return YH_EINVAL;
+    hipLaunchKernelGGL(qmish_selftest_kernel, dim3(4096), dim3(256), 0, (hipStream_t)stream, bits0, bits1, inv_s,
+                       reinterpret_cast<unsigned long long*>(out));
+    return check_launch();
+}
+
 extern "C" int yh_qadd(const yh_qadd_desc* d, void* stream) {
     if (!d || !d->x || !d->a || !d->y || d->pixels <= 0 || d->c <= 0) return YH_EINVAL;
     if (!(d->rx > 0.f) || !(d->ra > 0.f) || !(d->scale_x > 0.f) || !(d->scale_a > 0.f) || !(d->inv_scale_sum > 0.f)) return YH_EINVAL;

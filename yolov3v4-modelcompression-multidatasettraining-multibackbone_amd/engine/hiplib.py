@@ -246,6 +246,7 @@ _SIGNATURES = {
                                        _vp, _vp, _vp]),
     'yh_conv2d_stem_fwd': (C.c_int, [C.POINTER(StemDesc), _vp]),
     'yh_conv2d_stem_stats_rows': (_i64, [C.POINTER(StemDesc)]),
+    'yh_qmish_selftest': (C.c_int, [C.c_uint32, C.c_uint32, _f32, _vp, _vp]),
     'yh_dw_pack_weights': (C.c_int, [C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _f32, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp]),
     'yh_dwconv2d_fwd': (C.c_int, [C.POINTER(DwDesc), _vp]),
     'yh_se_fwd': (C.c_int, [C.POINTER(SeDesc), _vp]),
