@@ -212,6 +212,27 @@ def test_lds_weights_1x1_kernel_is_bit_identical_to_the_ring_kernel(libs, case):
     assert torch.equal(ys[0], ys[1])
 
 
+@pytest.mark.parametrize('cin,cout,use_res', [(256, 64, False), (32, 256, False), (32, 32, True), (128, 32, True)],
+                         ids=['256-64', '32-256', '32-32_res', '128-32_res'])
+def test_auto_tile_on_large_1x1_shapes_without_an_lds_weights_form(libs, cin, cout, use_res):
+    """the picker sent every fp16 1x1 layer with >= 262 144 pixels whose (MT, KS, MS) passes pwl_shape to tile 73, but only
+    eight forms are instantiated - pruned / custom cfgs (256 -> 64, 32 -> 256, 32 -> 32 with a residual ..) got YH_EUNSUPPORTED from
+    yh_conv2d_fwd.  The auto-picked tile must run and equal the ring kernel bit for bit."""
+    if DRY:
+        pytest.skip('tile selection is a property of the library')
+    lib, _ = libs
+    g = torch.Generator().manual_seed(cin + 7 * cout)
+    N, H, W = 1, 512, 513
+    w = _rand(g, cout, cin, 1, 1, scale=cin ** -0.5).to(GPU)
+    cb = _rand(g, cout).to(GPU)
+    x = _rand(g, N, H, W, cin).half().to(GPU)
+    res = _rand(g, N, H, W, cout).half().to(GPU) if use_res else None
+    packed, bias, cin_k, m_pad = oh.pack_conv(lib, F16, w, cb, None, cin_phys=cin)
+    ys = [oh.conv(lib, F16, x, packed, bias, cin_k, m_pad, cout, 1, 1, 0, act=0, res=res, tile=t).clone() for t in (0, 21)]
+    torch.cuda.synchronize()
+    assert torch.equal(ys[0], ys[1])
+
+
 @pytest.mark.parametrize('tile', [0, 43], ids=['auto', 'halo_pp'])
 def test_conv_f16_exact_on_small_integers(libs, tile):
     """Integer-valued operands make every product and partial sum exact: the MFMA path must be bit-exact (any summation order)."""

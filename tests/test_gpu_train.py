@@ -173,17 +173,22 @@ def test_wgrad_row_tiles_agree(libs, monkeypatch, case, bm, use_ws):
     assert torch.equal(got.cpu(), ref)
 
 
+@pytest.mark.parametrize('mode', ['1', '2'], ids=['halo', 'roll'])
 @pytest.mark.parametrize('wgs', ['', '4', '64'], ids=['auto', 'few_splits', 'many_splits'])
-@pytest.mark.parametrize('case', [(2, 21, 19, 64, 256), (7, 16, 40, 32, 512), (1, 76, 76, 128, 256), (3, 33, 152, 32, 256)],
+@pytest.mark.parametrize('case', [(2, 21, 19, 64, 256), (7, 16, 40, 32, 512), (1, 76, 76, 128, 256), (3, 33, 152, 32, 256),
+                                  (2, 23, 17, 128, 128), (1, 9, 152, 64, 128), (1, 5, 190, 64, 384), (9, 4, 16, 192, 128)],
                          ids=lambda c: 'n%d_%dx%d_c%d-%d' % c)
-def test_wgrad_halo_form_is_exact_on_small_integers(libs, monkeypatch, case, wgs):
-    """The 3x3 halo weight-gradient kernel (csrc/conv_wgrad.hip: one shared pad row / column, dz in virtual pixel order, halo image
-    read as nine shifted views) on integer operands: every product and partial sum exact, so any mistake in the pad handling, the
-    tap offsets, the split ranges or the partial-tile reduction shows as a wrong integer.  Ragged last chunks, chunk counts that do
-    not divide by the splits, W = 152 (five halo pieces per wave)."""
+def test_wgrad_halo_form_is_exact_on_small_integers(libs, monkeypatch, case, wgs, mode):
+    """The 3x3 halo weight-gradient kernels on integer operands: every product and partial sum exact, so any mistake in the pad
+    handling, the tap offsets, the split ranges or the partial-tile reduction shows as a wrong integer.  mode 1: conv_wgrad_halo_kernel
+    (csrc/conv_wgrad.hip: one shared pad row / column, dz in virtual pixel order, halo image read as nine shifted views; cout % 256,
+    cin % 32); mode 2: conv_wgrad_roll_kernel (csrc/conv_wgrad_roll.hip: 128 x [9 x 64] tile, x rows rolling through a 512-row ring;
+    cout % 128, cin % 64) - a case one form does not take runs on the next form down, which must be just as exact.  Ragged last
+    chunks / steps, split counts that do not divide, W = 152 and 190 (the shortest dz rings), images smaller than one 32-position step."""
     if DRY:
         pytest.skip('kernel-only property')
     lib, _ = libs
+    monkeypatch.setenv('YH_WGRAD_HALO', mode)
     if wgs:
         monkeypatch.setenv('YH_WGRAD_HALO_WGS', wgs)
     N, H, W, cin, cout = case
@@ -196,26 +201,51 @@ def test_wgrad_halo_form_is_exact_on_small_integers(libs, monkeypatch, case, wgs
     assert torch.equal(got.cpu(), ref)
 
 
-@pytest.mark.parametrize('case', [(2, 21, 19, 64, 256), (1, 76, 76, 128, 256), (3, 38, 38, 256, 512), (3, 33, 120, 32, 256)],
+@pytest.mark.parametrize('mode,kernel', [('1', 90), ('2', 91)], ids=['halo', 'roll'])
+@pytest.mark.parametrize('case', [(2, 21, 19, 64, 256), (1, 76, 76, 128, 256), (3, 38, 38, 256, 512), (3, 33, 120, 64, 256)],
                          ids=lambda c: 'n%d_%dx%d_c%d-%d' % c)
-def test_wgrad_halo_form_matches_autograd_on_random_operands(libs, case):
-    """`conv_wgrad_halo_kernel` against torch autograd DIRECTLY (float64 conv2d weight gradient of the same f16
+def test_wgrad_halo_form_matches_autograd_on_random_operands(libs, monkeypatch, case, mode, kernel):
+    """the halo kernels against torch autograd DIRECTLY (float64 conv2d weight gradient of the same f16
     operands), random - not small-integer - values: products exact in fp32, accumulation order the only difference (<= 1e-4 of the
     gradient's scale, the bound of the im2col form in test_wgrad_matches_autograd)."""
     if DRY:
         pytest.skip('kernel-only property')
     lib, _ = libs
+    monkeypatch.setenv('YH_WGRAD_HALO', mode)
     N, H, W, cin, cout = case
     g = torch.Generator().manual_seed(sum(case) + 1)
     x = (torch.randn(N, H, W, cin, generator=g) * 0.7).half()
     dz = (torch.randn(N, H, W, cout, generator=g) * 0.05).half()
     d = oh.WgradDesc(n=N, h=H, w_in=W, cin=cin, ho=H, wo=W, cout=cout, kh=3, kw=3, stride=1, pad=1, ldx=cin, lddz=cout, dtype=F16, splits=0)
     d.x = d.dz = d.dw = 4096
-    assert lib.yh_conv2d_wgrad_kernel(oh.C.byref(d)) == 90, 'the case must run on the halo kernel'
+    assert lib.yh_conv2d_wgrad_kernel(oh.C.byref(d)) == kernel, 'the case must run on the kernel under test'
     got = oh.wgrad(lib, F16, x.to(GPU), dz.to(GPU), cin, cout, 3, 1, 1, use_ws=True).cpu().double()
     ref = torch.nn.grad.conv2d_weight(x.double().permute(0, 3, 1, 2), (cout, cin, 3, 3), dz.double().permute(0, 3, 1, 2), padding=1)
     err = (got - ref).abs().max().item()
     assert err <= 1e-4 * ref.abs().max().item(), (err, ref.abs().max().item())
+
+
+@pytest.mark.parametrize('case', [(2, 17, 23, 64, 128, 32, 16), (1, 20, 31, 128, 256, 64, 128)], ids=lambda c: 'n%d_%dx%d_c%d-%d_x%d_z%d' % c)
+def test_wgrad_roll_form_reads_pitched_channel_slices(libs, monkeypatch, case):
+    """conv_wgrad_roll_kernel on operands that are channel slices of wider buffers (route / concat outputs: ldx > cin, lddz > cout,
+    non-zero first channel), exact on integers; the surrounding channels hold large values that must not be read."""
+    if DRY:
+        pytest.skip('kernel-only property')
+    lib, _ = libs
+    monkeypatch.setenv('YH_WGRAD_HALO', '2')
+    N, H, W, cin, cout, xe, ze = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randint(-3, 4, (N, H, W, cin + 2 * xe), generator=g).half()
+    dz = torch.randint(-2, 3, (N, H, W, cout + 2 * ze), generator=g).half()
+    x[..., :xe] = 1000.0
+    x[..., xe + cin:] = 1000.0
+    dz[..., :ze] = 1000.0
+    dz[..., ze + cout:] = 1000.0
+    got = oh.wgrad(lib, F16, x.to(GPU), dz.to(GPU), cin, cout, 3, 1, 1, x_off=xe, dz_off=ze, use_ws=True)
+    _sync()
+    ref = torch.nn.grad.conv2d_weight(x[..., xe:xe + cin].float().permute(0, 3, 1, 2), (cout, cin, 3, 3),
+                                      dz[..., ze:ze + cout].float().permute(0, 3, 1, 2), padding=1)
+    assert torch.equal(got.cpu(), ref)
 
 
 def test_wgrad_f16_exact_on_small_integers(libs):
@@ -565,8 +595,9 @@ def test_pack_batch_equals_single_layer_packers(libs, code):
         assert torch.equal(a, b), 'image %d differs' % k
 
 
-@pytest.mark.parametrize('rel,size,nc', [('yolov3/yolov3.cfg', 320, 80), ('yolov3tiny/yolov3-tiny-hand.cfg', 416, 1)], ids=['coco80', 'hand1'])
-def test_fused_loss_kernels_match_torch_loss(libs, rel, size, nc):
+@pytest.mark.parametrize('rel,size,nc', [('yolov3/yolov3.cfg', 320, 80), ('yolov3tiny/yolov3-tiny-hand.cfg', 416, 1),
+                                         ('yolov3tiny/yolov3-tiny-hand.cfg', 416, 91)], ids=['coco80', 'hand1', 'wide91'])
+def test_fused_loss_kernels_match_torch_loss(libs, rel, size, nc, tmp_path):
     """csrc/loss.hip vs the torch restatement of compute_loss run on the CPU (itself pinned by the reference goldens on the CPU
     tier): loss items to 1e-5, gradient of every raw head element to 1e-4 of its scale, through strided NHWC head views.
     The CPU is the comparison point because cells matched by several targets take the LAST target's objectness there (what
@@ -576,7 +607,12 @@ def test_fused_loss_kernels_match_torch_loss(libs, rel, size, nc):
     from models import Darknet
     from utils import utils as U
     torch.manual_seed(0)
-    model = Darknet(os.path.join(conftest.PKG, 'cfg', rel), (size, size))
+    path = os.path.join(conftest.PKG, 'cfg', rel)
+    if nc == 91:      # a head wider than one workgroup row (na * no = 3 * 96 = 288 > 256), any dataset with nc > 80
+        text = open(path).read().replace('classes=1', 'classes=91').replace('filters=18', 'filters=288')
+        path = str(tmp_path / 'tiny91.cfg')
+        open(path, 'w').write(text)
+    model = Darknet(path, (size, size))
     model.nc, model.gr = nc, 0.6
     model.hyp = {'giou': 3.54, 'cls': 37.4, 'cls_pw': 1.3, 'obj': 64.3, 'obj_pw': 0.8, 'iou_t': 0.20, 'fl_gamma': 0.0}
     raws, targets = synth.loss_inputs(model, size, batch=4, seed=33, labels_per_image=12)

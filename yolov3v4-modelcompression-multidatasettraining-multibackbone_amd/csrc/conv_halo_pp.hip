@@ -267,6 +267,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_hpp_kernel(const ConvArgs a, c
     const unsigned zlo = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)g_zero_page);
     const unsigned zhi = __builtin_amdgcn_readfirstlane((unsigned)((uintptr_t)g_zero_page >> 32));
     auto issue_piece = [&](int buf, int kc, int g, int off) {     // halo piece g (wave-uniform), this lane's row offset `off`
+        // the piece's LDS destination is re-derived at every issue (four scalar instructions): with g visible as a loop invariant the
+        // compiler keeps the LB destinations and their in-image flags in scalar registers over the whole K loop, and the int8 LB = 7
+        // form ran out of them (11 SGPR spills and a scratch frame: `make check-spills`)
+        asm volatile("" : "+s"(g));
         const bool ok = off >= 0 && kc + lu * VEC < a.Cin;
         const unsigned long long u = (unsigned long long)(uintptr_t)(xg + (off + kc + lu * VEC));
         const unsigned lo = ok ? (unsigned)u : zlo, hi = ok ? (unsigned)(u >> 32) : zhi;

@@ -228,6 +228,13 @@ static bool pwl_i8_case(int mt, int ks, int ms) {
            (mt == 8 && ks == 4 && ms == 2) || (mt == 8 && ks == 2 && ms == 2);
 }
 
+// fp16 instantiations (launch_pwl_tile's YH_PWL_CASE list, kept in step with it): every other (mt, ks, ms) stays on the ring kernels -
+// pruned / custom cfgs reach shapes such as 256 -> 64 or 32 -> 256 (the auto-picked tile 73 returned YH_EUNSUPPORTED there)
+static bool pwl_f16_case(int mt, int ks, int ms) {
+    return (mt == 2 && ks == 2 && ms == 1) || (mt == 4 && ks == 1 && ms == 1) || (mt == 4 && ks == 4 && ms == 1) || (mt == 8 && ks == 2 && ms == 1) ||
+           (mt == 8 && ks == 8 && ms == 1) || (mt == 8 && ks == 4 && ms == 2) || (mt == 8 && ks == 4 && ms == 1) || (mt == 4 && ks == 2 && ms == 1);
+}
+
 bool pwl_supported(int dtype, int out_f32, int cin, int cin_k, int cout, long P, int ldx, int ldy, int ldr, const void* x, const void* y,
                    const void* res, bool stats) {
     int mt, ks, ms;
@@ -235,6 +242,7 @@ bool pwl_supported(int dtype, int out_f32, int cin, int cin_k, int cout, long P,
     if (!pwl_shape(cin_k, cout, dtype == YH_I8 ? 64 : 32, &mt, &ks, &ms)) return false;
     if (stats && res) return false;
     if (dtype == YH_I8 && (stats || res || !pwl_i8_case(mt, ks, ms))) return false;      // plain mode, the shapes instantiated below
+    if (dtype == YH_F16 && !pwl_f16_case(mt, ks, ms)) return false;
     const int vec = dtype == YH_I8 ? 16 : 8;
     if (ldx % vec || ldy % vec || (res && ldr % vec) || !aligned16(x) || !aligned16(y) || (res && !aligned16(res))) return false;
     return P > 0 && P < (1L << 31) - 64;

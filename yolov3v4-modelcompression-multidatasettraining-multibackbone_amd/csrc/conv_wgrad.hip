@@ -1216,6 +1216,13 @@ extern "C" int yh_conv_pack_weights_dgrad(int dtype, const float* w, int cout, i
     return check_launch();
 }
 
+// YH_WGRAD_HALO: 0 = im2col kernels only, 1 = conv_wgrad_halo_kernel (round 3), 2 = conv_wgrad_roll_kernel (conv_wgrad_roll.hip,
+// round 5) where it qualifies and the round-3 form elsewhere.  Read at every call (the tests switch it per case).
+static int wgrad_halo_mode() {
+    const char* e = getenv("YH_WGRAD_HALO");
+    return e ? atoi(e) : YH_WGRAD_HALO_DEFAULT;
+}
+
 static bool wgrad_xcd_mapping() {
     const char* e = getenv("YH_WGRAD_XCD");   // A/B knob: 0 = plain (tile, split) grid
     return !e || atoi(e) != 0;
@@ -1231,8 +1238,7 @@ static bool wgrad_halo_geometry(const yh_wgrad_desc* d, WgradArgs* pa, int* pspl
     WgradArgs& a = *pa;
     // On by default (YH_WGRAD_HALO=0 disables it): 807 / 916 / 856 vs 759 / 861 / 740 TFLOP/s for the im2col kernel on the
     // 76 / 38 / 19 grids at batch 64 (profiles/r03_wgrad_halo.txt); its compute side alone (LDS-DMA ablated) runs at 1550
-    const char* mode_env = getenv("YH_WGRAD_HALO");
-    const int mode = mode_env ? atoi(mode_env) : 1;
+    const int mode = wgrad_halo_mode();
     if (!mode || d->dtype != YH_F16 || d->splits == -1) return false;
     if (d->kh != 3 || d->kw != 3 || d->stride != 1 || d->pad != 1 || d->ho != d->h || d->wo != d->w_in) return false;
     if (d->cout % 256 || d->cin % 32 || d->w_in < 16) return false;
@@ -1365,10 +1371,14 @@ extern "C" int yh_conv2d_wgrad(const yh_wgrad_desc* d, void* stream) {
     if (d->ldx % vec || d->lddz % vec || !aligned16(d->x) || !aligned16(d->dz)) return YH_EALIGN;
     if (d->cin % vec || d->cin_w > d->cin) return YH_EALIGN;
     if ((long)d->n * d->h * d->w_in * d->ldx >= (1L << 31) || (long)d->n * d->ho * d->wo * d->lddz >= (1L << 31)) return YH_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    if (wgrad_halo_mode() == 2) {
+        const int rc = launch_wgrad_roll(d, st);
+        if (rc != YH_EUNSUPPORTED) return rc;      // does not qualify / no workspace: the forms below
+    }
     WgradArgs a;
     int splits;
     wgrad_geometry(d, &a, &splits);
-    hipStream_t st = (hipStream_t)stream;
     if (a.halo) {
         const int htiles = a.tiles_m * a.tiles_n;
         if (d->ws && d->ws_floats >= (int64_t)splits * htiles * a.bm * a.bn) {
@@ -1439,6 +1449,7 @@ extern "C" int yh_conv2d_wgrad(const yh_wgrad_desc* d, void* stream) {
 
 extern "C" int yh_conv2d_wgrad_kernel(const yh_wgrad_desc* d) {
     if (!d || d->n <= 0 || d->cin <= 0 || d->cout <= 0 || (d->dtype != YH_F16 && d->dtype != YH_F32)) return YH_EINVAL;
+    if (wgrad_halo_mode() == 2 && wgrad_roll_workspace(d) > 0) return 91;
     WgradArgs a;
     int splits;
     wgrad_geometry(d, &a, &splits);
@@ -1453,7 +1464,9 @@ extern "C" int64_t yh_conv2d_wgrad_workspace(const yh_wgrad_desc* d) {
     WgradArgs a;
     int splits;
     wgrad_geometry(d, &a, &splits);
-    return (int64_t)splits * a.tiles_m * a.tiles_n * a.bm * a.bn;
+    const int64_t need = (int64_t)splits * a.tiles_m * a.tiles_n * a.bm * a.bn;
+    const int64_t roll = wgrad_halo_mode() == 2 ? wgrad_roll_workspace(d) : 0;
+    return roll > need ? roll : need;
 }
 
 extern "C" int yh_stem_wgrad(const yh_wgrad_desc* d, void* stream) {

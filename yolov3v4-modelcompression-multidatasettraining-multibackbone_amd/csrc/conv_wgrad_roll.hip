@@ -1,0 +1,384 @@
+// 3x3 / stride 1 / pad 1 weight gradient, "rolling halo" form (fp16; cout % 128 == 0, cin % 64 == 0, 16 <= W <= 190; round 5).
+//
+//   dw[co][ci][r][s] = sum over output pixels p of dz[p][co] * x[p shifted by tap (r, s)][ci]        (autograd of models.py:92-98)
+//
+// conv_wgrad_halo_kernel (conv_wgrad.hip, round 3) owns a 256 (co) x [9 taps x 32 ci] tile per workgroup and moves 16 KB of dz plus
+// 1/8 of a 256-pixel halo image of x per 32-pixel K step: 18 - 19 KB for 4.7 MFLOP, and its compute side alone runs at 1550 TFLOP/s where
+// the full kernel reaches 830 - 970 - the global -> LDS stream, not the matrix pipe, sets its step time.
+// This kernel keeps the accumulator budget (73 728 outputs = 295 KB of registers, one workgroup per CU, 12 waves) and the three
+// rotating wave groups of that kernel, and changes what the stream has to deliver:
+//   * tile 128 (co) x [9 taps x 64 ci]: the squarest split of 73 728 outputs.  Per 32-pixel step 8 KB of dz + 4 KB of x = 12 KB;
+//   * x is not staged per chunk but ROLLS: the virtual pixel space of conv_halo_pp.hip (one shared pad row / column per image:
+//     v = n (H+1)(W+1) + (y+1)(W+1) + (x+1), tap (r, s) = row offset (r-1)(W+1) + (s-1)) is walked in order, row v of x lives in
+//     slot v mod 512 of a 64 KB ring of 128-byte rows, and every step fetches exactly the 32 rows that enter the window
+//     [v - (W+2), v + 31 + (W+2)] - no halo overlap is fetched twice inside a split, no second buffer, no per-split pixel table;
+//   * every DMA lane decodes its own row: (image, y, x) advance by 32 positions per step with two compare-selects (32 = q (W+1) + r),
+//     a pad position (or one beyond the batch) reads the zero page.  One LDS-DMA instruction per wave per step: waves 0 .. 7 the 4-row
+//     pieces of dz (256-byte rows), waves 8 .. 11 the 8-row pieces of x - a uniform stream, every wave's in-order counter sees only
+//     its own pieces;
+//   * the LDS that the second halo image and the table took goes into the dz ring: S = min(10, 16 - JL) stages (JL = x steps the window
+//     leads by), S - 1 steps = up to 108 KB in flight per CU where the round-3 kernel had 64 KB for 1.5 x the bytes per step.
+// Fragment reads are ds_read_b64_tr_b16 on both operands (rows = pixels, transposed on the read side).  dz rows: the unit permutation
+// of conv_wgrad_dma_kernel<4, .> (16 units, XOR ((r & 3) | ((r >> 3) & 1) << 2) << 1).  x rows (128 B = half of the 64 banks, any tap
+// offset): 32-byte column k of row r is stored at k ^ (((r >> 1) & 1) | ((r >> 3) & 1) << 1) - the 8 row pieces that share an LDS cycle
+// (rows e + {0,1,2,3,8,9,10,11}) split into two parities of four rows {e, e+2, e+8, e+10} whose XOR values are always distinct (bit 3
+// flips between r and r + 8, bit 1 between r and r + 2, a carry out of bits 1-2 flips both of one pair): conflict-free for every e.
+// Partial tiles per pixel split go to the workspace in MFMA-native order, summed by wgrad_roll_reduce_kernel in split order.
+#include "common.h"
+#include <stdlib.h>
+
+namespace yh {
+
+__device__ __attribute__((aligned(16))) const uint32_t g_zero16r[4] = {0u, 0u, 0u, 0u};  // source of every pad-position 16-byte load
+
+struct RollArgs {
+    yh_wgrad_desc d;
+    int tiles_m, tiles_n;     // cout / 128, cin / 64
+    int steps_total, sps;     // 32-position steps of the virtual pixel space, steps per split
+    int S, JL;                // dz ring stages; x stream lead in steps: ceil((2 (W+1) + 2) / 32)
+    int q32, r32;             // 32 = q32 (W+1) + r32
+    int cin_w;
+    int nostagger;            // profiling knob (YH_WGRAD_HALO_NOSTAGGER): the three wave groups in phase
+};
+
+typedef int wr_v2i __attribute__((ext_vector_type(2)));
+template <int OFF> __device__ __forceinline__ wr_v2i wr_read_tr16(unsigned lds_byte_addr) {
+    wr_v2i r;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(r) : "v"(lds_byte_addr), "n"(OFF));
+    return r;
+}
+
+__device__ __forceinline__ int wr_swz_dz(int r) { return ((r & 3) | (((r >> 3) & 1) << 2)) << 1; }   // 16-byte units of a 256-byte dz row
+__device__ __forceinline__ int wr_swz_x(int r) { return ((r >> 1) & 1) | (((r >> 3) & 1) << 1); }    // 32-byte columns of a 128-byte x row
+
+__device__ __forceinline__ void wr_wait_keep(int keep) {      // counted wait with a wave-uniform run-time count: literal operands only
+    switch (keep) {
+        case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+        case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+        case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+        case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+        case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+        case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+        case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
+}
+
+constexpr int WR_XRING = 65536;     // 512 rows x 128 B
+constexpr int WR_ABYTES = 8192;     // one dz step: 32 rows x 256 B
+
+// ABL (profiling only, results are garbage): 3 = no LDS-DMA (the compute side alone)
+template <int ABL>
+__global__ __launch_bounds__(768, 3) void conv_wgrad_roll_kernel(const RollArgs a) {
+    constexpr int NT = 768;
+    const yh_wgrad_desc& d = a.d;
+    extern __shared__ __attribute__((aligned(128))) unsigned char rsm[];   // [x ring 64 KB][S dz stages of 8 KB]: the only LDS object
+    typedef const void __attribute__((address_space(1))) * gptr_t;
+    typedef void __attribute__((address_space(3))) * lptr_t;
+
+    const int tiles = a.tiles_m * a.tiles_n;
+    int tile_id, split_id;
+    {   // consecutive (split, tile) ids share an XCD: all tiles of a split read the same dz / x rows through one L2
+        const int nb = gridDim.x, bid = blockIdx.x;
+        const int q = nb >> 3, rr = nb & 7, xcd = bid & 7;
+        const int logical = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (bid >> 3);
+        split_id = logical / tiles;
+        tile_id = logical - split_id * tiles;
+    }
+    const int tm = tile_id % a.tiles_m, tn = tile_id / a.tiles_m;
+    const int co0 = tm * 128, ci0 = tn * 64;
+    const int s0 = split_id * a.sps;
+    const int nsteps = min(a.sps, a.steps_total - s0);
+    if (nsteps <= 0) return;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / 6, wn = wave - wm * 6;      // wave tile: channels 64 wm .. +63 x the three taps of filter row wn >> 1 x 32 ci (half wn & 1)
+    const int trow = wn >> 1, hh = wn & 1;
+    const int S = a.S, D = S - 1, JL = a.JL;
+    const int Wp = d.w_in + 1, Hp = d.h + 1, IMG = Hp * Wp;
+    const unsigned lds0 = (unsigned)(uintptr_t)(lptr_t)rsm;
+
+    // the zero page's address as two SCALARS: a pointer select against it costs no vector registers (168-register cap; a spilled
+    // pointer would be reloaded by a scratch load, which sits on the LDS-DMA queue's counter)
+    const unsigned zlo = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)g_zero16r);
+    const unsigned zhi = __builtin_amdgcn_readfirstlane((unsigned)((uintptr_t)g_zero16r >> 32));
+
+    // ---- this lane's row of the stream.  dz waves (0 .. 7): instruction = 4 rows x 16 units, row 4 wave + lane / 16 of the step;
+    // x waves (8 .. 11): 8 rows x 8 units, row 8 (wave - 8) + lane / 8 of the x step, which starts W + 2 positions before the dz step
+    const bool dz_wave = wave < 8;                                      // wave-uniform
+    int n, yy, xx, cofs;
+    {
+        int rowl, p;
+        if (dz_wave) {
+            rowl = 4 * wave + (lane >> 4);
+            cofs = co0 + (((lane & 15) ^ wr_swz_dz(rowl)) << 3);
+            p = 32 * s0 + rowl;
+        } else {
+            rowl = 8 * (wave - 8) + (lane >> 3);
+            cofs = ci0 + (((lane & 7) ^ (wr_swz_x(rowl) << 1)) << 3);
+            p = 32 * s0 - Wp - 1 + rowl;
+        }
+        const int pp = p + IMG;                      // p >= -(W + 2) > -IMG
+        const int q = pp / IMG;
+        const int rem = pp - q * IMG;
+        n = q - 1;
+        yy = rem / Wp;
+        xx = rem - yy * Wp;
+    }
+    const f16* const srcbase = reinterpret_cast<const f16*>(dz_wave ? d.dz : d.x);
+    const unsigned ld = (unsigned)(dz_wave ? d.lddz : d.ldx);
+    unsigned slot;                                   // LDS byte offset (from rsm) of this wave's next piece
+    int stage_i = 0;                                 // dz: ring stage of the next piece; x: x step of the next piece (mod 16)
+    slot = dz_wave ? WR_XRING + wave * 1024 : (wave - 8) * 1024;
+    auto issue = [&]() {
+        const bool ok = (unsigned)n < (unsigned)d.n && yy >= 1 && xx >= 1;
+        const unsigned pix = (unsigned)((n * d.h + yy - 1) * d.w_in + xx - 1);
+        const unsigned long long u = (unsigned long long)(uintptr_t)(srcbase + (pix * ld + (unsigned)cofs));
+        const unsigned lo = ok ? (unsigned)u : zlo, hi = ok ? (unsigned)(u >> 32) : zhi;
+        __builtin_amdgcn_global_load_lds((gptr_t)(uintptr_t)(((unsigned long long)hi << 32) | lo), (lptr_t)(rsm + slot), 16, 0, 0);
+        // the next step's row: 32 positions on
+        xx += a.r32;
+        yy += a.q32;
+        const bool cx = xx >= Wp;
+        xx = cx ? xx - Wp : xx;
+        yy = cx ? yy + 1 : yy;
+        const bool cy = yy >= Hp;
+        yy = cy ? yy - Hp : yy;
+        n = cy ? n + 1 : n;
+        ++stage_i;
+        if (dz_wave) {
+            const bool w = stage_i == S;
+            stage_i = w ? 0 : stage_i;
+            slot = w ? WR_XRING + wave * 1024 : slot + WR_ABYTES;
+        } else {
+            slot = (slot + 4096) & (WR_XRING - 1);
+        }
+    };
+
+    f32x4 acc[4][6];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 6; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // ---- fragment addressing (ds_read_b64_tr_b16: lane (q, g) supplies 4 consecutive channels of pixel row 8g + 4h + q/4 and
+    // receives 4 consecutive pixels of channel q of the 16-channel block)
+    const int q = lane & 15, g = lane >> 4;
+    unsigned a_addr0;                  // dz fragment 0, half 0, inside a stage; fragment i: ^ (i << 5); half 1: + 4 rows = offset 1024
+    unsigned b_abs[3][2];              // x: tap column s, half h; channel block 0 (block 1 = ^ 32); absolute LDS address, rolls 4 KB per step
+    {
+        const int row = 8 * g + (q >> 2);
+        const int cha = wm * 64 + 4 * (q & 3);
+        a_addr0 = row * 256 + ((((cha >> 3) ^ wr_swz_dz(row)) << 4) | ((cha & 7) * 2));
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int s = 0; s < 3; ++s) {
+                const int xr = row + 4 * h + trow * Wp + s;      // slot row at step 0 (slot 0 = position 32 s0 - (W + 2))
+                b_abs[s][h] = lds0 + (unsigned)((xr & 511) * 128 + (((2 * hh) ^ wr_swz_x(xr)) << 5) + (q & 3) * 8);
+            }
+    }
+    const unsigned roll_add = 4096u - lds0;       // b = lds0 + ((b - lds0 + 4096) & 0xffff)
+
+    // ---- K loop.  Three groups of one wave per SIMD (waves 0-3, 4-7, 8-11) rotate through LOAD (20 transposed fragment reads), MFMA
+    // (24 MFMAs) and the stream interval (this wave's LDS-DMA piece for step s + D, the counted wait, the address roll), one barrier
+    // interval each; group g runs g intervals behind group 0.  Interval t = 3 s + phase + g:
+    //   * a piece of step s + D is issued at t >= 3 s + 2 into the stage / slot of step s - 1, whose last reader (group 2, LOAD of
+    //     step s - 1) finished at t = 3 s - 1;
+    //   * a wave's wait in step s's stream interval (t <= 3 s + 4) covers its piece of step s + 2; the first read of step s + 2 is at
+    //     t = 3 s + 6: one full barrier in between, for every group.
+    const int grp = a.nostagger ? 0 : (wave >> 2);
+#define YH_WR_BARRIER()                      \
+    do {                                     \
+        __builtin_amdgcn_sched_barrier(0);   \
+        __builtin_amdgcn_s_barrier();        \
+        __builtin_amdgcn_sched_barrier(0);   \
+    } while (0)
+    if constexpr (ABL != 3) {
+        const int n_pro = dz_wave ? min(D, nsteps) : min(JL + D, nsteps + JL);
+        for (int k = 0; k < n_pro; ++k) issue();
+        wr_wait_keep(max(0, n_pro - (dz_wave ? 2 : JL + 2)));       // steps 0 and 1 (x steps 0 .. JL + 1) have landed
+    }
+    YH_WR_BARRIER();
+    for (int k = 0; k < grp; ++k) YH_WR_BARRIER();      // stagger
+    int st_read = 0;
+    for (int s = 0; s < nsteps; ++s) {
+        // ---- LOAD
+        const unsigned stage = lds0 + WR_XRING + st_read * WR_ABYTES;
+        wr_v2i ra[4][2], rb[6][2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            ra[i][0] = wr_read_tr16<0>(stage + (a_addr0 ^ (i << 5)));
+            ra[i][1] = wr_read_tr16<1024>(stage + (a_addr0 ^ (i << 5)));
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+#pragma unroll
+            for (int sx = 0; sx < 3; ++sx) {
+                rb[2 * sx][h] = wr_read_tr16<0>(b_abs[sx][h]);
+                rb[2 * sx + 1][h] = wr_read_tr16<0>(b_abs[sx][h] ^ 32);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(ra[0][0]), "+v"(ra[0][1]), "+v"(ra[1][0]), "+v"(ra[1][1]), "+v"(ra[2][0]), "+v"(ra[2][1]),
+                       "+v"(ra[3][0]), "+v"(ra[3][1]), "+v"(rb[0][0]), "+v"(rb[0][1]), "+v"(rb[1][0]), "+v"(rb[1][1]),
+                       "+v"(rb[2][0]), "+v"(rb[2][1]), "+v"(rb[3][0]), "+v"(rb[3][1]), "+v"(rb[4][0]), "+v"(rb[4][1]),
+                       "+v"(rb[5][0]), "+v"(rb[5][1])
+                     :
+                     : "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- MFMA
+        typedef int v4i __attribute__((ext_vector_type(4)));
+        f16x8 fa[4], fb[6];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const v4i t = {ra[i][0][0], ra[i][0][1], ra[i][1][0], ra[i][1][1]};
+            fa[i] = __builtin_bit_cast(f16x8, t);
+        }
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            const v4i t = {rb[j][0][0], rb[j][0][1], rb[j][1][0], rb[j][1][1]};
+            fb[j] = __builtin_bit_cast(f16x8, t);
+        }
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 6; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        YH_WR_BARRIER();
+        // ---- stream interval (the other two groups read / multiply)
+        if constexpr (ABL != 3) {
+            if (s + D < nsteps) issue();
+            wr_wait_keep(min(D - 2, max(0, nsteps - 3 - s)));
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int sx = 0; sx < 3; ++sx) b_abs[sx][h] = lds0 + ((b_abs[sx][h] + roll_add) & (WR_XRING - 1));
+        st_read = st_read + 1 == S ? 0 : st_read + 1;
+        YH_WR_BARRIER();
+    }
+    for (int k = grp; k < 2; ++k) YH_WR_BARRIER();      // every wave has executed the same number of barriers
+#undef YH_WR_BARRIER
+
+    f32x4* part = reinterpret_cast<f32x4*>(d.ws) + ((long)split_id * tiles + tile_id) * (24 * NT);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 6; ++j) part[(i * 6 + j) * NT + tid] = acc[i][j];
+}
+
+// Partial tiles -> dw.  One thread per (tile, fragment, lane slot); the splits of a group are added in index order (four running sums
+// of every fourth split), groups meet in fp32 atomics (one group for <= 16 splits: plain accumulate, bit-reproducible).
+__global__ __launch_bounds__(768) void wgrad_roll_reduce_kernel(const RollArgs a, int splits, int per_group) {
+    constexpr int NT = 768;
+    const yh_wgrad_desc& d = a.d;
+    const int tiles = a.tiles_m * a.tiles_n;
+    const int tile = blockIdx.x / 24, ij = blockIdx.x % 24;
+    const int i = ij / 6, j = ij % 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / 6, wn = wave - wm * 6;
+    const f32x4* part = reinterpret_cast<const f32x4*>(d.ws) + ((long)tile * 24 + ij) * NT + tid;
+    const long stride = (long)tiles * 24 * NT;
+    const int sA = blockIdx.y * per_group, sB = min(sA + per_group, splits);
+    f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = v0, v2 = v0, v3 = v0;
+    int sp = sA;
+    for (; sp + 3 < sB; sp += 4) {
+        v0 += part[sp * stride];
+        v1 += part[(sp + 1) * stride];
+        v2 += part[(sp + 2) * stride];
+        v3 += part[(sp + 3) * stride];
+    }
+    for (; sp < sB; ++sp) v0 += part[sp * stride];
+    const f32x4 v = (v0 + v1) + (v2 + v3);
+    const int tm = tile % a.tiles_m, tn = tile / a.tiles_m;
+    const int tap = (wn >> 1) * 3 + (j >> 1);
+    const int ci = tn * 64 + (wn & 1) * 32 + (j & 1) * 16 + (lane & 15);
+    if (ci >= a.cin_w) return;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int co = tm * 128 + wm * 64 + i * 16 + 4 * (lane >> 4) + r;
+        if (co >= d.cout) continue;
+        float* dst = d.dw + ((long)co * a.cin_w + ci) * 9 + tap;
+        if (gridDim.y == 1) *dst += v[r];
+        else atomicAdd(dst, v[r]);
+    }
+}
+
+// geometry of the rolling form; false when the layer does not qualify (host code, no launch)
+bool wgrad_roll_geometry(const yh_wgrad_desc* d, RollArgs* pa, int* psplits, size_t* plds) {
+    RollArgs& a = *pa;
+    if (d->dtype != YH_F16 || d->splits == -1) return false;
+    if (d->kh != 3 || d->kw != 3 || d->stride != 1 || d->pad != 1 || d->ho != d->h || d->wo != d->w_in) return false;
+    if (d->cout % 128 || d->cin % 64 || d->w_in < 16 || d->h < 2) return false;
+    if (d->cin_w > 0 && d->cin_w != d->cin) return false;
+    const int Wp = d->w_in + 1;
+    const int JL = (2 * Wp + 2 + 31) / 32;
+    int S = 16 - JL;
+    if (S > 10) S = 10;
+    { const char* e = getenv("YH_WGRAD_ROLL_STAGES"); if (e && atoi(e) >= 4 && atoi(e) <= S) S = atoi(e); }   // A/B knob: fewer stages
+    if (S < 4) return false;
+    const long Q = (long)d->n * (d->h + 1) * Wp;
+    if (Q + 4096 >= 0x7fffffffL) return false;
+    a.d = *d;
+    a.cin_w = d->cin;
+    a.tiles_m = d->cout / 128;
+    a.tiles_n = d->cin / 64;
+    a.steps_total = (int)((Q + 31) / 32);
+    a.S = S;
+    a.JL = JL;
+    a.q32 = 32 / Wp;
+    a.r32 = 32 - a.q32 * Wp;
+    { const char* e = getenv("YH_WGRAD_HALO_NOSTAGGER"); a.nostagger = e && atoi(e) ? 1 : 0; }
+    const int tiles = a.tiles_m * a.tiles_n;
+    int splits = d->splits > 0 ? d->splits : 256 / tiles;          // one workgroup per CU
+    {
+        const char* e = getenv("YH_WGRAD_HALO_WGS");       // A/B and test knob: total workgroups aimed for
+        if (e && d->splits <= 0) splits = atoi(e) / tiles;
+        else if (d->splits <= 0 && splits > a.steps_total / 8) splits = a.steps_total / 8;      // library's choice: >= 8 steps per workgroup
+    }
+    if (splits < 1) splits = 1;
+    if (splits > a.steps_total) splits = a.steps_total;
+    a.sps = (a.steps_total + splits - 1) / splits;
+    *psplits = (a.steps_total + a.sps - 1) / a.sps;
+    *plds = (size_t)WR_XRING + (size_t)S * WR_ABYTES;
+    return true;
+}
+
+int64_t wgrad_roll_workspace(const yh_wgrad_desc* d) {
+    RollArgs a;
+    int splits;
+    size_t lds;
+    if (!wgrad_roll_geometry(d, &a, &splits, &lds)) return 0;
+    return (int64_t)splits * a.tiles_m * a.tiles_n * 128 * 576;
+}
+
+// YH_EUNSUPPORTED: the layer does not qualify or the workspace is too small (the caller falls back to the other forms)
+int launch_wgrad_roll(const yh_wgrad_desc* d, hipStream_t st) {
+    RollArgs a;
+    int splits;
+    size_t lds;
+    if (!wgrad_roll_geometry(d, &a, &splits, &lds)) return YH_EUNSUPPORTED;
+    const int tiles = a.tiles_m * a.tiles_n;
+    if (!d->ws || d->ws_floats < (int64_t)splits * tiles * 128 * 576) return YH_EUNSUPPORTED;
+    const char* abl_env = getenv("YH_WGRAD_ROLL_ABL");      // profiling only
+    const int abl = abl_env ? atoi(abl_env) : 0;
+    {
+        auto kern = abl == 3 ? conv_wgrad_roll_kernel<3> : conv_wgrad_roll_kernel<0>;
+        const hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds);
+        if (e != hipSuccess) return (int)e;
+        hipLaunchKernelGGL(kern, dim3((unsigned)(tiles * splits)), dim3(768), lds, st, a);
+    }
+    int groups = (splits + 15) / 16;
+    if (groups > 32) groups = 32;
+    const int per_group = (splits + groups - 1) / groups;
+    groups = (splits + per_group - 1) / per_group;
+    hipLaunchKernelGGL(wgrad_roll_reduce_kernel, dim3(tiles * 24, groups), dim3(768), 0, st, a, splits, per_group);
+    return check_launch();
+}
+
+}  // namespace yh

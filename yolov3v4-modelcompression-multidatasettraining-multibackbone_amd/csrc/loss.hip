@@ -159,21 +159,21 @@ __global__ __launch_bounds__(256) void loss_obj_fwd_kernel(const yh_loss_desc d)
 // decoded once per row with 32-bit arithmetic.  (The first form decoded every ELEMENT with five 64-bit divisions: 0.41 ms for the
 // 76 x 76 head of YOLOv3-608 batch 64 - 1 TB/s - against 0.1 ms of bytes.)
 __global__ __launch_bounds__(256) void loss_dense_bwd_kernel(const yh_loss_desc d) {
-    const int row = d.na * d.no;                              // <= 256 (checked by the launcher)
-    const int j = threadIdx.x;
-    const int a = j / d.no, o = j - a * d.no;
+    const int row = d.na * d.no;                              // any width: a thread takes elements j, j + 256, .. of the row
     const int pixels = d.bs * d.ny * d.nx, hw = d.ny * d.nx;
     const float sc = *d.scale * d.g_obj / (float)((long)d.bs * d.na * d.ny * d.nx);
-    if (j >= row) return;
-    for (int p = blockIdx.x; p < pixels; p += gridDim.x) {
-        const int b = p / hw, r = p - b * hw;
-        const int y = r / d.nx, x = r - y * d.nx;
-        float g = 0.f;
-        if (o == 4) {
-            const long cell = (((long)b * d.na + a) * d.ny + y) * d.nx + x;
-            g = sc * bce_grad(d.p[(long)b * d.sb + (long)a * d.sa + (long)y * d.sy + (long)x * d.sx + 4], d.tobj[cell], d.obj_pw);
+    for (int j = threadIdx.x; j < row; j += 256) {            // one trip for na * no <= 256 (COCO: 255), more for nc > 80
+        const int a = j / d.no, o = j - a * d.no;
+        for (int p = blockIdx.x; p < pixels; p += gridDim.x) {
+            const int b = p / hw, r = p - b * hw;
+            const int y = r / d.nx, x = r - y * d.nx;
+            float g = 0.f;
+            if (o == 4) {
+                const long cell = (((long)b * d.na + a) * d.ny + y) * d.nx + x;
+                g = sc * bce_grad(d.p[(long)b * d.sb + (long)a * d.sa + (long)y * d.sy + (long)x * d.sx + 4], d.tobj[cell], d.obj_pw);
+            }
+            d.grad[(long)b * d.gb + (long)a * d.ga + (long)y * d.gy + (long)x * d.gx + o] = g;
         }
-        d.grad[(long)b * d.gb + (long)a * d.ga + (long)y * d.gy + (long)x * d.gx + o] = g;
     }
 }
 
@@ -236,7 +236,7 @@ extern "C" int yh_yolo_loss_bwd(const yh_loss_desc* d, void* stream) {
     int rc = check_loss(d, true);
     if (rc) return rc;
     hipStream_t s = (hipStream_t)stream;
-    if (d->na * d->no > 256 || (long)d->bs * d->ny * d->nx >= 0x7fffffffL) return YH_EUNSUPPORTED;
+    if ((long)d->bs * d->ny * d->nx >= 0x7fffffffL) return YH_EUNSUPPORTED;
     const long pixels = (long)d->bs * d->ny * d->nx;
     hipLaunchKernelGGL(loss_dense_bwd_kernel, dim3((unsigned)(pixels < 16384 ? pixels : 16384)), dim3(256), 0, s, *d);
     if (d->nt > 0)
