@@ -173,7 +173,7 @@ def test_wgrad_row_tiles_agree(libs, monkeypatch, case, bm, use_ws):
     assert torch.equal(got.cpu(), ref)
 
 
-@pytest.mark.parametrize('mode', ['1', '2'], ids=['halo', 'roll'])
+@pytest.mark.parametrize('mode', ['1', '2', '3'], ids=['halo', 'auto', 'roll'])
 @pytest.mark.parametrize('wgs', ['', '4', '64'], ids=['auto', 'few_splits', 'many_splits'])
 @pytest.mark.parametrize('case', [(2, 21, 19, 64, 256), (7, 16, 40, 32, 512), (1, 76, 76, 128, 256), (3, 33, 152, 32, 256),
                                   (2, 23, 17, 128, 128), (1, 9, 152, 64, 128), (1, 5, 190, 64, 384), (9, 4, 16, 192, 128)],
@@ -182,8 +182,9 @@ def test_wgrad_halo_form_is_exact_on_small_integers(libs, monkeypatch, case, wgs
     """The 3x3 halo weight-gradient kernels on integer operands: every product and partial sum exact, so any mistake in the pad
     handling, the tap offsets, the split ranges or the partial-tile reduction shows as a wrong integer.  mode 1: conv_wgrad_halo_kernel
     (csrc/conv_wgrad.hip: one shared pad row / column, dz in virtual pixel order, halo image read as nine shifted views; cout % 256,
-    cin % 32); mode 2: conv_wgrad_roll_kernel (csrc/conv_wgrad_roll.hip: 128 x [9 x 64] tile, x rows rolling through a 512-row ring;
-    cout % 128, cin % 64) - a case one form does not take runs on the next form down, which must be just as exact.  Ragged last
+    cin % 32); mode 3: conv_wgrad_roll_kernel wherever it qualifies (csrc/conv_wgrad_roll.hip: 128 x [9 x 64] tile, x rows rolling
+    through a 512-row ring; cout % 128, cin % 64); mode 2 (the default): the library's per-layer choice between the two - a case one
+    form does not take runs on the next form down, which must be just as exact.  Ragged last
     chunks / steps, split counts that do not divide, W = 152 and 190 (the shortest dz rings), images smaller than one 32-position step."""
     if DRY:
         pytest.skip('kernel-only property')
@@ -201,7 +202,7 @@ def test_wgrad_halo_form_is_exact_on_small_integers(libs, monkeypatch, case, wgs
     assert torch.equal(got.cpu(), ref)
 
 
-@pytest.mark.parametrize('mode,kernel', [('1', 90), ('2', 91)], ids=['halo', 'roll'])
+@pytest.mark.parametrize('mode,kernel', [('1', 90), ('3', 91)], ids=['halo', 'roll'])
 @pytest.mark.parametrize('case', [(2, 21, 19, 64, 256), (1, 76, 76, 128, 256), (3, 38, 38, 256, 512), (3, 33, 120, 64, 256)],
                          ids=lambda c: 'n%d_%dx%d_c%d-%d' % c)
 def test_wgrad_halo_form_matches_autograd_on_random_operands(libs, monkeypatch, case, mode, kernel):
@@ -232,7 +233,7 @@ def test_wgrad_roll_form_reads_pitched_channel_slices(libs, monkeypatch, case):
     if DRY:
         pytest.skip('kernel-only property')
     lib, _ = libs
-    monkeypatch.setenv('YH_WGRAD_HALO', '2')
+    monkeypatch.setenv('YH_WGRAD_HALO', '3')
     N, H, W, cin, cout, xe, ze = case
     g = torch.Generator().manual_seed(sum(case))
     x = torch.randint(-3, 4, (N, H, W, cin + 2 * xe), generator=g).half()
@@ -959,6 +960,9 @@ def test_headline_shape_fp16_step_against_the_fp32_engine(libs):
     assert abs(na - nb) <= 5e-2 * nb, (na, nb)
     assert drift <= 2e-2
     assert 1.0 - cos <= 4.0 * (1.0 - cos_yard) + 0.01, (cos, cos_yard)
+    # the relative bound above would pass at cosine 0.77; measured on this ill-conditioned default-init net: 0.9176
+    # (yardstick 0.9439).  Twice the measured direction error is the absolute ceiling.
+    assert 1.0 - cos <= 2.0 * (1.0 - 0.9176), cos
 
 
 @pytest.mark.parametrize('tag,rel,size,nc', [('tinyhand', 'yolov3tiny/yolov3-tiny-hand.cfg', 128, 1), ('v4tiny', 'yolov4tiny/yolov4-tiny.cfg', 128, 80)],
@@ -985,61 +989,102 @@ def test_training_step_on_gpu_matches_reference_golden(libs, tag, rel, size, nc)
     assert (num / den) ** 0.5 <= 3e-3
 
 
-def test_headline_shape_fp32_step_against_the_reference_golden(libs):
+# fp16 engine vs the reference-generated 608 golden, measured when the case was added (profiles/r05_pytest_gpu_tail.txt, two runs): gradient
+# rel l2 0.378 / 0.436, cosine 0.927 / 0.900 - with the yardstick (fp32 engine, fp16-rounded weights + input) at rel l2 0.268, cosine 0.965:
+# absolute caps = 1.5 x the worse rel l2 and twice the worse direction error
+FP16_GOLD608_REL, FP16_GOLD608_COS = 0.65, 0.80
+
+
+@pytest.mark.parametrize('precision', ['fp32', 'fp16'])
+def test_headline_shape_fp32_step_against_the_reference_golden(libs, precision):
     """the external anchor AT the shape the bench times.  tests/golden/train_step_608.npz is one training step of
     the REFERENCE itself (YOLOv3 Darknet-53, 608 x 608, batch 2, fp32 CPU: train-mode forward, compute_loss, backward; generated by
     tests/golden/make_golden_train608.py from /root/reference).  The fp32 HIP step on the GPU (train forward + fused compute_loss +
     backward, every kernel of the fp32 path at 608 geometry) against it: loss items, raw-head checksums, running statistics, and the
     parameter gradients in the l2 / cosine sense - a 75-conv random-weight net is ill-conditioned (one leaky-ReLU kink that flips
-    under a different summation order moves every upstream gradient: eager fp32 itself is ~1e-2 from an fp64 run)."""
+    under a different summation order moves every upstream gradient: eager fp32 itself is ~1e-2 from an fp64 run).
+    precision = fp16: the engine the bench times - fp16 activations / gradients, fp32 master weights, the loss
+    scaled as train.py's GradScaler does - against the SAME reference-generated step.  Loss items, head checksums and running
+    statistics to SURVEY 8(d)'s 1e-2.  The gradient DIRECTION cannot be held to 1e-2 on this net by any fp16 engine, and the test
+    measures why: the fp32 engine, with nothing but its weights and input rounded to fp16 (activations, gradients, accumulation all
+    fp32), is run against the same golden as the yardstick (measured: rel l2 0.27, cosine 0.965 - a 5e-4 relative perturbation of the
+    weights alone turns the sampled gradient by 15 degrees); the fp16 engine may lose at most three times the yardstick's direction
+    error and twice its rel l2, and is capped at the absolute values above."""
     if DRY:
         pytest.skip('a 608 x 608 Darknet-53 step on the host emulation takes minutes; the emulator is covered at 64 - 128 px')
+    import copy
     from models import Darknet
     from utils.utils import compute_loss
     import test_train_emulated as tte
     gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'train_step_608.npz'))
     size, batch, stride = int(gold['size']), int(gold['batch']), int(gold['stride'])
     torch.manual_seed(0)
-    model = Darknet(os.path.join(conftest.PKG, 'cfg', 'yolov3', 'yolov3.cfg'), (size, size))
-    state = model.state_dict()
+    model0 = Darknet(os.path.join(conftest.PKG, 'cfg', 'yolov3', 'yolov3.cfg'), (size, size))
+    state = model0.state_dict()
     synth.randomize_bn_(state, seed=1)
-    model.load_state_dict(state)
-    model.nc, model.hyp, model.gr = 80, dict(tte.GOLD_HYP), 1.0
-    targets = synth.loss_inputs(model, size, batch=batch, seed=9, labels_per_image=8)[1].to(GPU)
-    model.train().to(GPU)
-    x = synth.image_batch(batch, size, seed=0).to(GPU)
-    os.environ['YOLO_HIP_TRAIN_PRECISION'] = 'fp32'
-    try:
-        pred, _ = model(x)
-    finally:
-        del os.environ['YOLO_HIP_TRAIN_PRECISION']
-    assert model.__dict__.get('_hip_train_engine') is not None
-    loss, items = compute_loss(pred, targets, model)
-    loss.backward()
-    np.testing.assert_allclose(items.detach().cpu().numpy(), gold['items'], rtol=2e-3)
-    for i, p in enumerate(pred):
-        want = gold['raw%d_checks' % i]
-        got = p.detach().double()
-        assert abs(got.abs().sum().item() - want[1]) <= 2e-3 * want[1] and abs(got.abs().max().item() - want[2]) <= 1e-2 * want[2], i
-    params = dict(model.named_parameters())
+    model0.load_state_dict(state)
+    model0.nc, model0.hyp, model0.gr = 80, dict(tte.GOLD_HYP), 1.0
+    targets = synth.loss_inputs(model0, size, batch=batch, seed=9, labels_per_image=8)[1].to(GPU)
+    x0 = synth.image_batch(batch, size, seed=0).to(GPU)
     names = [str(n) for n in gold['param_names']]
-    assert names == list(params)
-    rows = np.concatenate([params[k].grad.reshape(-1)[::stride].float().cpu().numpy() for k in names])
     want = gold['grad_rows']
-    assert rows.shape == want.shape
-    rel = float(np.linalg.norm(rows - want) / np.linalg.norm(want))
-    cos = float((rows * want).sum() / (np.linalg.norm(rows) * np.linalg.norm(want)))
-    sums = np.array([params[k].grad.abs().sum().item() for k in names])
-    ratio = sums / np.maximum(gold['grad_checks'][:, 1], 1e-30)
+
+    def step(prec, round_inputs=False):
+        model = copy.deepcopy(model0)
+        x = x0
+        if round_inputs:
+            with torch.no_grad():
+                for prm in model.parameters():
+                    prm.copy_(prm.half().float())
+            x = x0.half().float()
+        model.train().to(GPU)
+        os.environ['YOLO_HIP_TRAIN_PRECISION'] = prec
+        try:
+            pred, _ = model(x)
+        finally:
+            del os.environ['YOLO_HIP_TRAIN_PRECISION']
+        eng = model.__dict__.get('_hip_train_engine')
+        assert eng is not None and eng.precision == prec
+        loss, items = compute_loss(pred, targets, model)
+        gscale = 4096.0 if prec == 'fp16' else 1.0       # GradScaler: unscaled, the early layers' batch-2 gradients are fp16 subnormals
+        (loss * gscale).backward()
+        params = dict(model.named_parameters())
+        assert names == list(params)
+        for prm in params.values():
+            prm.grad.div_(gscale)
+        rows = np.concatenate([params[k].grad.reshape(-1)[::stride].float().cpu().numpy() for k in names])
+        assert rows.shape == want.shape
+        out = dict(items=items.detach().cpu().numpy(), pred=[p.detach().double().cpu() for p in pred], rows=rows,
+                   sums=np.array([params[k].grad.abs().sum().item() for k in names]), sd={k: v.double().cpu() for k, v in model.state_dict().items()},
+                   rel=float(np.linalg.norm(rows - want) / np.linalg.norm(want)),
+                   cos=float((rows * want).sum() / (np.linalg.norm(rows) * np.linalg.norm(want))), nrm=float(np.linalg.norm(rows) / np.linalg.norm(want)))
+        model.__dict__['_hip_train_engine'] = None
+        del model, eng, pred, loss
+        torch.cuda.empty_cache()
+        return out
+
+    f16 = precision == 'fp16'
+    r = step(precision)
+    np.testing.assert_allclose(r['items'], gold['items'], rtol=1e-2 if f16 else 2e-3)
+    for i, got in enumerate(r['pred']):
+        w = gold['raw%d_checks' % i]
+        assert abs(got.abs().sum().item() - w[1]) <= (1e-2 if f16 else 2e-3) * w[1] and abs(got.abs().max().item() - w[2]) <= (3e-2 if f16 else 1e-2) * w[2], i
+    ratio = r['sums'] / np.maximum(gold['grad_checks'][:, 1], 1e-30)
     big = gold['grad_checks'][:, 1] >= 1e-3 * gold['grad_checks'][:, 1].max()
-    print('608 b2 fp32 HIP step vs the reference golden: loss items %s, gradient rel l2 %.3g, cosine %.5f, |grad| sum ratio of the '
-          'dominant parameters %.3f .. %.3f' % (items.detach().cpu().numpy(), rel, cos, ratio[big].min(), ratio[big].max()))
-    assert rel <= 0.1 and cos >= 0.995, (rel, cos)
-    assert 0.8 <= ratio[big].min() and ratio[big].max() <= 1.25
-    sd = model.state_dict()
+    print('608 b2 %s HIP step vs the reference golden: loss items %s, gradient rel l2 %.3g, cosine %.5f, norm ratio %.4f, |grad| sum ratio '
+          'of the dominant parameters %.3f .. %.3f' % (precision, r['items'], r['rel'], r['cos'], r['nrm'], ratio[big].min(), ratio[big].max()))
+    if f16:
+        y = step('fp32', round_inputs=True)
+        print('608 b2 yardstick (fp32 engine, weights + input rounded to fp16) vs the reference golden: gradient rel l2 %.3g, cosine %.5f, '
+              'norm ratio %.4f' % (y['rel'], y['cos'], y['nrm']))
+        assert 1.0 - r['cos'] <= 3.0 * (1.0 - y['cos']) + 0.01 and r['rel'] <= 2.0 * y['rel'] + 0.02, (r['rel'], r['cos'], y['rel'], y['cos'])
+        assert r['rel'] <= FP16_GOLD608_REL and r['cos'] >= FP16_GOLD608_COS, (r['rel'], r['cos'])
+        assert 0.8 <= ratio[big].min() and ratio[big].max() <= 1.25
+    else:
+        assert r['rel'] <= 0.1 and r['cos'] >= 0.995, (r['rel'], r['cos'])
+        assert 0.8 <= ratio[big].min() and ratio[big].max() <= 1.25
     for k, w in zip([str(n) for n in gold['running_names']], gold['running_checks']):
-        got = sd[k].double()
-        assert abs(got.abs().sum().item() - w[1]) <= 1e-3 * w[1] + 1e-6, k
+        assert abs(r['sd'][k].abs().sum().item() - w[1]) <= (3e-3 if f16 else 1e-3) * w[1] + 1e-6, k
 
 
 def test_fused_loss_defers_the_label_check_without_a_host_sync(libs):

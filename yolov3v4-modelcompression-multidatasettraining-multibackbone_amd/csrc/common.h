@@ -119,7 +119,7 @@ long stem_mfma_stats_rows(const yh_stem_desc& d);
 
 // conv_wgrad_roll.hip: the rolling-halo 3x3 weight gradient (YH_EUNSUPPORTED: layer does not qualify / workspace too small)
 #ifndef YH_WGRAD_HALO_DEFAULT
-#define YH_WGRAD_HALO_DEFAULT 1
+#define YH_WGRAD_HALO_DEFAULT 2
 #endif
 int launch_wgrad_roll(const yh_wgrad_desc* d, hipStream_t stream);
 int64_t wgrad_roll_workspace(const yh_wgrad_desc* d);

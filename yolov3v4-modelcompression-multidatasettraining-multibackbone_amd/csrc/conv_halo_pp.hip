@@ -55,7 +55,7 @@ __device__ __forceinline__ void hpp_epilogue(const ConvArgs& a, AccT (&acc)[8][4
             const float y = activate_q<ACT>((float)acc[i][j][e] * a.acc_scale + bvs[i][e], a.slope, a.inv_out_scale);
             return round_clamp_i8(y * a.inv_out_scale);
         } else {
-            return activate_c<ACT>((float)acc[i][j][e] + bvs[i][e], a.slope);
+            return activate_t<ACT, T>((float)acc[i][j][e] + bvs[i][e], a.slope);
         }
     };
     if constexpr (sizeof(T) != 1) {
@@ -185,8 +185,15 @@ template <int T9, int LB> struct HppAllow {
 struct HppDiv { unsigned m_img, s_img, m_wp, s_wp; };
 __device__ __forceinline__ int hpp_div(int n, unsigned m, unsigned s) { return (int)(__umulhi((unsigned)n, m) >> s); }
 
-template <typename T, int LB, int ROLE>
+template <typename T, int LB, int ROLE, bool ONEBAR>
 __global__ __launch_bounds__(512, 2) void conv3x3_hpp_kernel(const ConvArgs a, const int rows_hp, const int hbufs, const HppDiv dv) {
+    // ONEBAR: ONE barrier per K step instead of four (round 5).  The instruction stream stays what it is - X loads, X MFMAs, Y loads, Y
+    // MFMAs - and so does the stagger of the two wave groups, but it is no longer enforced segment by segment: group 1's barrier of a
+    // step falls after its Y loads, group 0's after its Y MFMAs, so between two barriers group 0 runs XL XM YL YM of step s while group
+    // 1 runs YM of step s - 1 and XL XM YL of step s.  Every barrier is a round trip of 8 waves during which a SIMD's matrix pipe
+    // drains; the same change on the weight-gradient kernel (conv_wgrad_roll.hip) gained 3 - 5 %.  Hazards: the weight piece of step
+    // s + 3 is issued in XL(s), after barrier s - 1, into the stage last read in YL(s - 1), before that barrier, by either group; the
+    // counted wait of YL(s) covers step s + 1 and precedes barrier s for both groups, the first read of step s + 1 follows it.
     constexpr int VEC = Prec<T>::VEC, BK = VEC * 4;       // one 64-byte chunk per row per K step: 32 f16 / 64 int8 channels
     constexpr int BM = 128, BN = 512, TM = 8, TN = 4, NW = 8, SA = 4;
     constexpr int A_CELLS = BM * 4;
@@ -337,15 +344,17 @@ __global__ __launch_bounds__(512, 2) void conv3x3_hpp_kernel(const ConvArgs a, c
         __builtin_amdgcn_sched_barrier(0);   \
     } while (0)
     // one phase = LOAD segment (ends with: all of this wave's LDS reads returned), barrier, 16 MFMAs, barrier
-#define YH_HPP_PHASE(LOADS, MMA)                              \
+#define YH_HPP_PHASE(LOADS, MMA, BAR_L, BAR_M)                \
     do {                                                      \
         LOADS;                                                \
         __builtin_amdgcn_sched_barrier(0);                    \
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   \
-        __builtin_amdgcn_s_barrier();                         \
+        if (BAR_L) __builtin_amdgcn_s_barrier();              \
         __builtin_amdgcn_sched_barrier(0);                    \
         MMA;                                                  \
-        YH_HPP_BARRIER();                                     \
+        __builtin_amdgcn_sched_barrier(0);                    \
+        if (BAR_M) __builtin_amdgcn_s_barrier();              \
+        __builtin_amdgcn_sched_barrier(0);                    \
     } while (0)
 
     const int nchunks = a.cin_k / BK;
@@ -367,8 +376,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_hpp_kernel(const ConvArgs a, c
         wait_vmcnt<0>();
     }
     YH_HPP_BARRIER();
-    if (group == 1) YH_HPP_BARRIER();   // stagger: group 1 runs one barrier interval behind group 0
-
+    if (!ONEBAR && group == 1) YH_HPP_BARRIER();   // stagger: group 1 runs one barrier interval behind group 0
     int s = 0;                   // K step being computed
     int st_r = 0, st_w = 3;      // ring stage of step s / of step s + 3
     int ptap = 3, pkc = 0;       // tap / channel offset of step s + 3
@@ -385,7 +393,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_hpp_kernel(const ConvArgs a, c
             constexpr int allow = HppAllow<t, LB>::value;   // (a comma inside <> would split the macro argument)
             // ---- phase X: channels 0 .. 63 of the tile x this wave's 64 pixels; weight tile of step s + 3 into the stage that
             // step s - 1 was read from (both groups are past its last read: the barrier that ended the previous interval)
-            YH_HPP_PHASE({ read_a(st, 0); read_b(hb, tapoff); if ((ROLE == 0 || group == 0) && s + 3 < nk) issue_a(st_w, ptap, pkc); }, mma(H0{}));
+            YH_HPP_PHASE({ read_a(st, 0); read_b(hb, tapoff); if ((ROLE == 0 || group == 0) && s + 3 < nk) issue_a(st_w, ptap, pkc); }, mma(H0{}), !ONEBAR, !ONEBAR);
             // ---- phase Y: channels 64 .. 127; halo pieces of the next chunk; then this wave's share of step s + 1 (and of
             // everything older) must have landed: the barrier after this segment, and for the other group the next one, publish it
             YH_HPP_PHASE({
@@ -404,14 +412,14 @@ __global__ __launch_bounds__(512, 2) void conv3x3_hpp_kernel(const ConvArgs a, c
                     if constexpr (t < 6) issue_h2(nbuf, nkc, t);
                     if constexpr (t == 7) wait_vmcnt<0>();
                 }
-            }, mma(H1{}));
+            }, mma(H1{}), !ONEBAR || group == 1, !ONEBAR || group == 0);
             ++s;
             st_r = (st_r + 1) & (SA - 1);
             st_w = (st_w + 1) & (SA - 1);
             if (++ptap == 9) { ptap = 0; pkc += BK; }
         });
     }
-    if (group == 0) YH_HPP_BARRIER();   // matches group 1's extra barrier at the start
+    if (!ONEBAR && group == 0) YH_HPP_BARRIER();   // matches group 1's extra barrier at the start
 #undef YH_HPP_PHASE
 #undef YH_HPP_BARRIER
 
@@ -717,6 +725,24 @@ bool hpp_geometry(int W, int cin_k, int bk, int* rows_hp, int* lb, int* hbufs, s
     return *lds <= 160 * 1024;
 }
 
+// ONEBAR (one barrier per K step) measured 3 - 10 % SLOWER than the four-barrier form on every 3x3 layer of both models, bit-identical
+// outputs (profiles/r05_hpp_one_barrier_ab.txt: sum over 13 layer shapes 2.96 against 2.78 ms) - unlike the weight-gradient kernel, whose
+// three wave groups gained 3 - 5 % from it: here the enforced alternation of the two groups IS the overlap.  Its instantiations are only
+// compiled into an A/B build (make CXXFLAGS+=-DYH_HPP_ONEBAR_AB; then YH_HPP_BARRIERS=1 selects them); the int8 LB = 7 form runs out of
+// scalar registers with it (8 SGPR spills, tools/check_spills.py) and always keeps four barriers.
+template <typename T, int LBV> static auto hpp_kern(int one_bar) -> void (*)(const ConvArgs, const int, const int, const HppDiv) {
+#ifdef YH_HPP_ONEBAR_AB
+    if constexpr (!(sizeof(T) == 1 && LBV == 7)) {
+        if (one_bar) return conv3x3_hpp_kernel<T, LBV, 0, true>;
+    }
+#endif
+    (void)one_bar;
+    return conv3x3_hpp_kernel<T, LBV, 0, false>;
+}
+
+#ifndef YH_HPP_ONE_BARRIER_DEFAULT
+#define YH_HPP_ONE_BARRIER_DEFAULT 0
+#endif
 template <typename T> static int launch_hpp(const ConvArgs& a0, hipStream_t stream) {
     constexpr int BK = Prec<T>::VEC * 4;
     ConvArgs a = a0;
@@ -740,6 +766,8 @@ template <typename T> static int launch_hpp(const ConvArgs& a0, hipStream_t stre
     HppDiv dv;
     hpp_magic((unsigned)((a.H + 1) * (a.W + 1)), &dv.m_img, &dv.s_img);       // both divisors >= 4 (H, W >= 1)
     hpp_magic((unsigned)(a.W + 1), &dv.m_wp, &dv.s_wp);
+    const char* bar_env = getenv("YH_HPP_BARRIERS");      // A/B knob: 4 = a barrier after every segment (rounds 3 - 4), 1 = one per K step
+    const int one_bar = bar_env ? (atoi(bar_env) == 1 ? 1 : 0) : YH_HPP_ONE_BARRIER_DEFAULT;
     // ROLE 1 (separate weight / halo waves; needs its 48 halo pieces to cover the image) is an A/B form, measured 5 - 9 % SLOWER
     // than the shared form here (profiles/r03_hpp_role_ab.txt) - the weight tiles are L2-resident and short, unlike the dz stream
     // of the weight-gradient kernel where the same separation gained 20 %.  Its instantiations spill 3 registers at the 256 cap,
@@ -747,9 +775,9 @@ template <typename T> static int launch_hpp(const ConvArgs& a0, hipStream_t stre
 #ifdef YH_HPP_ROLE_AB
     static const int role_env = [] { const char* e = getenv("YH_HPP_ROLE"); return e ? atoi(e) : 0; }();
     const int role = (role_env && rows_hp <= 768) ? 1 : 0;
-#define YH_HPP_KERN(LBV) (role ? conv3x3_hpp_kernel<T, LBV, 1> : conv3x3_hpp_kernel<T, LBV, 0>)
+#define YH_HPP_KERN(LBV) (role ? conv3x3_hpp_kernel<T, LBV, 1, false> : hpp_kern<T, LBV>(one_bar))
 #else
-#define YH_HPP_KERN(LBV) conv3x3_hpp_kernel<T, LBV, 0>
+#define YH_HPP_KERN(LBV) hpp_kern<T, LBV>(one_bar)
 #endif
 #define YH_HPP_CASE(LBV)                                                                                                       \
     case LBV: {                                                                                                                \

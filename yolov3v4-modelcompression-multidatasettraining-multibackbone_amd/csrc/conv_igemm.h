@@ -151,6 +151,15 @@ template <int ACT> __device__ __forceinline__ float activate_c(float v, float sl
     else return v;
 }
 
+// the fp16 epilogues' activation (round 5; DESIGN.md 3, round 4 item c''): Mish through the hardware exp2 / rcp form of common.h (~20
+// VALU slots per value instead of the ~45 of ocml expf + an IEEE divide; within 1e-6 relative of it for every float: the rounded
+// fp16 value differs by at most one ulp on ~0.1 % of the values) - YOLOv4's 1x1 layers were VALU-bound on this, not byte-bound.  The
+// fp32 kernels keep the exact form (they are the side of the fp32 box / conf comparisons against the oracle).
+template <int ACT, typename T> __device__ __forceinline__ float activate_t(float v, float slope) {
+    if constexpr (ACT == YH_ACT_MISH && sizeof(T) == 2) return mish_fast(v);
+    else return activate_c<ACT>(v, slope);
+}
+
 // the int8 epilogues' activation: activate_c, with mish through common.h's mish_for_grid (same grid value, ~half the instructions)
 template <int ACT> __device__ __forceinline__ float activate_q(float v, float slope, float inv_out_scale) {
     if constexpr (ACT == YH_ACT_MISH) return mish_for_grid(v, inv_out_scale);
@@ -191,7 +200,7 @@ __device__ __forceinline__ void conv_epilogue_plain(const ConvArgs& a, AccT (&ac
             const float q = round_clamp_i8(y * a.inv_out_scale);
             return sizeof(OutT) == 1 ? q : q * a.out_scale;
         } else {
-            return activate_c<ACT>((float)acc[i][j][e] + bvs[i][e], a.slope);
+            return activate_t<ACT, T>((float)acc[i][j][e] + bvs[i][e], a.slope);
         }
     };
     if constexpr (sizeof(T) != 1) {

@@ -87,7 +87,7 @@ __global__ __launch_bounds__(256) void conv_pointwise_kernel(const ConvArgs a, c
                 const float q = round_clamp_i8(y * a.inv_out_scale);
                 return sizeof(OutT) == 1 ? q : q * a.out_scale;
             } else {
-                return activate_c<ACT>((float)acc[i][j][e] + bvs[i][e], a.slope);
+                return activate_t<ACT, T>((float)acc[i][j][e] + bvs[i][e], a.slope);
             }
         };
         auto value4 = [&](int i, int j, float (&o)[4]) {

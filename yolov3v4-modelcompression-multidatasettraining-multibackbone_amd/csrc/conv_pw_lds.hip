@@ -153,7 +153,7 @@ __global__ __launch_bounds__(512, 2) void conv1x1_lds_kernel(const ConvArgs a, c
                     quantize4<ACT>(acc[i][j], bv, a, v);
                 } else {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = activate_c<ACT>(acc[i][j][e] + bv[e], a.slope);
+                    for (int e = 0; e < 4; ++e) v[e] = activate_t<ACT, T>(acc[i][j][e] + bv[e], a.slope);
                 }
                 if constexpr (MODE == 1) {
                     const f16x4 r = *reinterpret_cast<const f16x4*>(cell);

@@ -172,7 +172,7 @@ __global__ __launch_bounds__(S3_WAVES * 64, OCC) void conv3x3_stream_kernel(cons
                     if constexpr (sizeof(T) == 1) {
                         if constexpr (HAS_RES) v[e] = qadd_value(v[e], (float)(int8_t)((rv[j][i] >> (8 * e)) & 0xff), a);
                     } else {
-                        float y = activate_c<ACT>((float)acc[i][j][e] + bvs[i][e], a.slope);
+                        float y = activate_t<ACT, T>((float)acc[i][j][e] + bvs[i][e], a.slope);
                         if constexpr (HAS_RES) y += (float)rv[j][i][e];
                         v[e] = y;
                     }

@@ -1216,8 +1216,9 @@ extern "C" int yh_conv_pack_weights_dgrad(int dtype, const float* w, int cout, i
     return check_launch();
 }
 
-// YH_WGRAD_HALO: 0 = im2col kernels only, 1 = conv_wgrad_halo_kernel (round 3), 2 = conv_wgrad_roll_kernel (conv_wgrad_roll.hip,
-// round 5) where it qualifies and the round-3 form elsewhere.  Read at every call (the tests switch it per case).
+// YH_WGRAD_HALO: 0 = im2col kernels only, 1 = conv_wgrad_halo_kernel (round 3), 2 (default) = conv_wgrad_roll_kernel (conv_wgrad_roll.hip,
+// round 5) on the layers it measured faster on and the round-3 form elsewhere, 3 = the round-5 form wherever it qualifies.  Read at
+// every call (the tests switch it per case).
 static int wgrad_halo_mode() {
     const char* e = getenv("YH_WGRAD_HALO");
     return e ? atoi(e) : YH_WGRAD_HALO_DEFAULT;
@@ -1372,7 +1373,7 @@ extern "C" int yh_conv2d_wgrad(const yh_wgrad_desc* d, void* stream) {
     if (d->cin % vec || d->cin_w > d->cin) return YH_EALIGN;
     if ((long)d->n * d->h * d->w_in * d->ldx >= (1L << 31) || (long)d->n * d->ho * d->wo * d->lddz >= (1L << 31)) return YH_EINVAL;
     hipStream_t st = (hipStream_t)stream;
-    if (wgrad_halo_mode() == 2) {
+    if (wgrad_halo_mode() >= 2) {
         const int rc = launch_wgrad_roll(d, st);
         if (rc != YH_EUNSUPPORTED) return rc;      // does not qualify / no workspace: the forms below
     }
@@ -1449,7 +1450,7 @@ extern "C" int yh_conv2d_wgrad(const yh_wgrad_desc* d, void* stream) {
 
 extern "C" int yh_conv2d_wgrad_kernel(const yh_wgrad_desc* d) {
     if (!d || d->n <= 0 || d->cin <= 0 || d->cout <= 0 || (d->dtype != YH_F16 && d->dtype != YH_F32)) return YH_EINVAL;
-    if (wgrad_halo_mode() == 2 && wgrad_roll_workspace(d) > 0) return 91;
+    if (wgrad_halo_mode() >= 2 && wgrad_roll_workspace(d) > 0) return 91;
     WgradArgs a;
     int splits;
     wgrad_geometry(d, &a, &splits);
@@ -1465,7 +1466,7 @@ extern "C" int64_t yh_conv2d_wgrad_workspace(const yh_wgrad_desc* d) {
     int splits;
     wgrad_geometry(d, &a, &splits);
     const int64_t need = (int64_t)splits * a.tiles_m * a.tiles_n * a.bm * a.bn;
-    const int64_t roll = wgrad_halo_mode() == 2 ? wgrad_roll_workspace(d) : 0;
+    const int64_t roll = wgrad_halo_mode() >= 2 ? wgrad_roll_workspace(d) : 0;
     return roll > need ? roll : need;
 }
 

@@ -39,6 +39,8 @@ struct RollArgs {
     int q32, r32;             // 32 = q32 (W+1) + r32
     int cin_w;
     int nostagger;            // profiling knob (YH_WGRAD_HALO_NOSTAGGER): the three wave groups in phase
+    int prio;                 // 1: s_setprio 1 around the MFMA segments
+    unsigned long long* timing;   // TIMING builds only: [3 groups][8] cycle sums of workgroup 0 (tools/wgrad_ab.py --timing)
 };
 
 typedef int wr_v2i __attribute__((ext_vector_type(2)));
@@ -68,9 +70,27 @@ __device__ __forceinline__ void wr_wait_keep(int keep) {      // counted wait wi
 constexpr int WR_XRING = 65536;     // 512 rows x 128 B
 constexpr int WR_ABYTES = 8192;     // one dz step: 32 rows x 256 B
 
-// ABL (profiling only, results are garbage): 3 = no LDS-DMA (the compute side alone)
-template <int ABL>
+// ABL (profiling only, bit flags; results are garbage unless ABL & 7 == 0): 1 = no LDS-DMA (the compute side alone), 2 = no fragment
+// reads and no MFMAs (the stream alone), 4 = every piece reads the zero page (the DMA path without memory traffic), 8 = s_memtime
+// stamps around every segment of the K loop, summed per wave group of one workgroup into a.timing
+#define YH_WR_STAMP(k)                                                                   \
+    do {                                                                                 \
+        if constexpr (TIMING) {                                                          \
+            __builtin_amdgcn_sched_barrier(0);                                           \
+            const unsigned long long now_ = __builtin_amdgcn_s_memtime();                \
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                           \
+            tsum[k] += now_ - tlast;                                                     \
+            tlast = now_;                                                                \
+            __builtin_amdgcn_sched_barrier(0);                                           \
+        }                                                                                \
+    } while (0)
+// ORDER: 0 = every fragment read of a step in one barrier interval (LOAD / MFMA / stream), 1 = SPLIT (R1 / R2 / MFMA), 2 = FREE (one
+// barrier per step, see the K loop)
+template <int ABL, int ORDER>
 __global__ __launch_bounds__(768, 3) void conv_wgrad_roll_kernel(const RollArgs a) {
+    constexpr bool SPLIT = ORDER == 1, FREE = ORDER == 2;
+    constexpr bool TIMING = (ABL & 8) != 0, NODMA = (ABL & 1) != 0, NOCOMPUTE = (ABL & 2) != 0, ZEROSRC = (ABL & 4) != 0;
+    unsigned long long tsum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = 0;
     constexpr int NT = 768;
     const yh_wgrad_desc& d = a.d;
     extern __shared__ __attribute__((aligned(128))) unsigned char rsm[];   // [x ring 64 KB][S dz stages of 8 KB]: the only LDS object
@@ -95,7 +115,7 @@ __global__ __launch_bounds__(768, 3) void conv_wgrad_roll_kernel(const RollArgs 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / 6, wn = wave - wm * 6;      // wave tile: channels 64 wm .. +63 x the three taps of filter row wn >> 1 x 32 ci (half wn & 1)
     const int trow = wn >> 1, hh = wn & 1;
-    const int S = a.S, D = S - 1, JL = a.JL;
+    const int S = a.S, D = FREE ? S - 2 : S - 1, JL = a.JL;
     const int Wp = d.w_in + 1, Hp = d.h + 1, IMG = Hp * Wp;
     const unsigned lds0 = (unsigned)(uintptr_t)(lptr_t)rsm;
 
@@ -132,7 +152,7 @@ __global__ __launch_bounds__(768, 3) void conv_wgrad_roll_kernel(const RollArgs 
     int stage_i = 0;                                 // dz: ring stage of the next piece; x: x step of the next piece (mod 16)
     slot = dz_wave ? WR_XRING + wave * 1024 : (wave - 8) * 1024;
     auto issue = [&]() {
-        const bool ok = (unsigned)n < (unsigned)d.n && yy >= 1 && xx >= 1;
+        const bool ok = !ZEROSRC && (unsigned)n < (unsigned)d.n && yy >= 1 && xx >= 1;
         const unsigned pix = (unsigned)((n * d.h + yy - 1) * d.w_in + xx - 1);
         const unsigned long long u = (unsigned long long)(uintptr_t)(srcbase + (pix * ld + (unsigned)cofs));
         const unsigned lo = ok ? (unsigned)u : zlo, hi = ok ? (unsigned)(u >> 32) : zhi;
@@ -195,29 +215,214 @@ __global__ __launch_bounds__(768, 3) void conv_wgrad_roll_kernel(const RollArgs 
         __builtin_amdgcn_s_barrier();        \
         __builtin_amdgcn_sched_barrier(0);   \
     } while (0)
-    if constexpr (ABL != 3) {
+    if constexpr (!NODMA) {
         const int n_pro = dz_wave ? min(D, nsteps) : min(JL + D, nsteps + JL);
         for (int k = 0; k < n_pro; ++k) issue();
         wr_wait_keep(max(0, n_pro - (dz_wave ? 2 : JL + 2)));       // steps 0 and 1 (x steps 0 .. JL + 1) have landed
     }
     YH_WR_BARRIER();
-    for (int k = 0; k < grp; ++k) YH_WR_BARRIER();      // stagger
+    if constexpr (!FREE) for (int k = 0; k < grp; ++k) YH_WR_BARRIER();      // stagger
     int st_read = 0;
+    if constexpr (TIMING) tlast = __builtin_amdgcn_s_memtime();
+    // SPLIT form.  Measured on the form below (profiles/r05_wgrad_roll_segments.txt): with the LDS-DMA ablated its LOAD segment - 20
+    // ds_read_b64_tr_b16 from ONE wave per SIMD - takes ~500 cycles where the 24 MFMAs of the group next to it take ~410: 8-byte LDS
+    // reads reach their rate only with several waves per SIMD issuing them (MI355X_MICROARCH.md, LDS), so the interval is set by the
+    // reads.  Here a step's reads are spread over BOTH intervals in which a wave does not multiply - R1: the 12 x fragments, R2: the
+    // LDS-DMA piece, the 8 dz fragments, the counted wait and the address roll - so two waves per SIMD read in every interval.
+    // Interval t = 3 s + phase + g (phase 0 = R1, 1 = R2, 2 = MFMA):
+    //   * the piece of step s + D is issued in R2(s) (t >= 3 s + 1) into the stage of step s - 1, last read in R2(s - 1) (t <= 3 s),
+    //     and into the x slot of x step s - 1, last read in R1(s - 1) (t <= 3 s - 1);
+    //   * the wait in R2(s) (t <= 3 s + 3) covers the piece of step s + 2, first read in R1(s + 2) at t >= 3 s + 6.
+    // FREE form (ORDER 2).  Measured on the two forms below (profiles/r05_wgrad_roll_segments.txt): a segment of 8, 12 or 20 fragment
+    // reads takes 450 - 600 cycles whatever its length, the 24 MFMAs ~430, and every one of the three barriers of a step adds the
+    // round trip of 12 waves plus the restart of the next segment to an interval in which the matrix pipe of each SIMD then idles: ~600
+    // cycles per interval for ~410 of MFMA work.  Here the rotation is kept but no longer enforced segment by segment: ONE barrier per
+    // step; between two barriers every wave runs its three segments back to back, the groups in rotated order
+    //   group 0: MFMA(T)  R1(T+1)  R2(T+1)      group 1: R1(T)  R2(T)  MFMA(T)      group 2: R2(T)  MFMA(T)  R1(T+1)
+    // so that, with equal segment lengths, one wave per SIMD multiplies at any time and nothing but the matrix pipe itself serialises
+    // two waves that overlap.  Hazards (barrier T opens interval T):
+    //   * the piece of step s + D (D = S - 2) is issued in R2(s) - group 0: interval s - 1 - into the stage of step s - 2 and the x slot
+    //     of x step s - 2, whose last readers (groups 1, 2: R2(s - 2) / R1(s - 2)) ran in interval s - 2;
+    //   * the wait in R2(s) - groups 1, 2: interval s - covers the piece of step s + 2 and is published by barrier s + 1; the first
+    //     read of step s + 2 is group 0's R1(s + 2) in interval s + 1.
+    if constexpr (FREE) {
+        wr_v2i ra[4][2], rb[6][2];
+        auto seg_r1 = [&]() {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+#pragma unroll
+                for (int sx = 0; sx < 3; ++sx) {
+                    rb[2 * sx][h] = NOCOMPUTE ? wr_v2i{(int)b_abs[sx][h], h} : wr_read_tr16<0>(b_abs[sx][h]);
+                    rb[2 * sx + 1][h] = NOCOMPUTE ? wr_v2i{(int)b_abs[sx][h], sx} : wr_read_tr16<0>(b_abs[sx][h] ^ 32);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+v"(rb[0][0]), "+v"(rb[0][1]), "+v"(rb[1][0]), "+v"(rb[1][1]), "+v"(rb[2][0]), "+v"(rb[2][1]),
+                           "+v"(rb[3][0]), "+v"(rb[3][1]), "+v"(rb[4][0]), "+v"(rb[4][1]), "+v"(rb[5][0]), "+v"(rb[5][1])
+                         :
+                         : "memory");
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        auto seg_r2 = [&](int s) {
+            if constexpr (!NODMA) {
+                if (s + D < nsteps) issue();
+            }
+            const unsigned stage = lds0 + WR_XRING + st_read * WR_ABYTES;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                ra[i][0] = NOCOMPUTE ? wr_v2i{(int)stage, i} : wr_read_tr16<0>(stage + (a_addr0 ^ (i << 5)));
+                ra[i][1] = NOCOMPUTE ? wr_v2i{(int)stage, i} : wr_read_tr16<1024>(stage + (a_addr0 ^ (i << 5)));
+            }
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int sx = 0; sx < 3; ++sx) b_abs[sx][h] = lds0 + ((b_abs[sx][h] + roll_add) & (WR_XRING - 1));
+            st_read = st_read + 1 == S ? 0 : st_read + 1;
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (!NODMA) wr_wait_keep(min(D - 2, max(0, nsteps - 3 - s)));
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+v"(ra[0][0]), "+v"(ra[0][1]), "+v"(ra[1][0]), "+v"(ra[1][1]), "+v"(ra[2][0]), "+v"(ra[2][1]),
+                           "+v"(ra[3][0]), "+v"(ra[3][1])
+                         :
+                         : "memory");
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        auto seg_mm = [&]() {
+            typedef int v4i __attribute__((ext_vector_type(4)));
+            f16x8 fa[4], fb[6];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const v4i t = {ra[i][0][0], ra[i][0][1], ra[i][1][0], ra[i][1][1]};
+                fa[i] = __builtin_bit_cast(f16x8, t);
+            }
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                const v4i t = {rb[j][0][0], rb[j][0][1], rb[j][1][0], rb[j][1][1]};
+                fb[j] = __builtin_bit_cast(f16x8, t);
+            }
+            if constexpr (NOCOMPUTE) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) asm volatile("" ::"v"(fa[i]));
+#pragma unroll
+                for (int j = 0; j < 6; ++j) asm volatile("" ::"v"(fb[j]));
+            } else {
+                if (a.prio) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 6; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+                if (a.prio) __builtin_amdgcn_s_setprio(0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        // one instruction stream for every wave (R1, R2, MFMA, R1, ..): a group differs only in WHERE its one barrier per step falls -
+        // group 2 after R1, group 0 after R2, group 1 after the MFMAs (and once before its first segment instead of after its last)
+        const int g3 = wave >> 2;
+        if (g3 == 1) YH_WR_BARRIER();
+        for (int s = 0; s < nsteps; ++s) {
+            seg_r1();
+            if (g3 == 2) YH_WR_BARRIER();
+            seg_r2(s);
+            if (g3 == 0) YH_WR_BARRIER();
+            seg_mm();
+            if (g3 == 1 && s + 1 < nsteps) YH_WR_BARRIER();
+        }
+    } else if constexpr (SPLIT) {
+        for (int s = 0; s < nsteps; ++s) {
+            wr_v2i ra[4][2], rb[6][2];
+            // ---- R1: x fragments
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+#pragma unroll
+                for (int sx = 0; sx < 3; ++sx) {
+                    rb[2 * sx][h] = NOCOMPUTE ? wr_v2i{(int)b_abs[sx][h], h} : wr_read_tr16<0>(b_abs[sx][h]);
+                    rb[2 * sx + 1][h] = NOCOMPUTE ? wr_v2i{(int)b_abs[sx][h], sx} : wr_read_tr16<0>(b_abs[sx][h] ^ 32);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+v"(rb[0][0]), "+v"(rb[0][1]), "+v"(rb[1][0]), "+v"(rb[1][1]), "+v"(rb[2][0]), "+v"(rb[2][1]),
+                           "+v"(rb[3][0]), "+v"(rb[3][1]), "+v"(rb[4][0]), "+v"(rb[4][1]), "+v"(rb[5][0]), "+v"(rb[5][1])
+                         :
+                         : "memory");
+            YH_WR_STAMP(0);      // x fragments returned
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            YH_WR_STAMP(1);      // barrier 1
+            // ---- R2: this wave's LDS-DMA piece, dz fragments, address roll, counted wait
+            if constexpr (!NODMA) {
+                if (s + D < nsteps) issue();
+                YH_WR_STAMP(6);      // piece issued
+            }
+            const unsigned stage = lds0 + WR_XRING + st_read * WR_ABYTES;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                ra[i][0] = NOCOMPUTE ? wr_v2i{(int)stage, i} : wr_read_tr16<0>(stage + (a_addr0 ^ (i << 5)));
+                ra[i][1] = NOCOMPUTE ? wr_v2i{(int)stage, i} : wr_read_tr16<1024>(stage + (a_addr0 ^ (i << 5)));
+            }
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int sx = 0; sx < 3; ++sx) b_abs[sx][h] = lds0 + ((b_abs[sx][h] + roll_add) & (WR_XRING - 1));
+            st_read = st_read + 1 == S ? 0 : st_read + 1;
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (!NODMA) wr_wait_keep(min(D - 2, max(0, nsteps - 3 - s)));
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+v"(ra[0][0]), "+v"(ra[0][1]), "+v"(ra[1][0]), "+v"(ra[1][1]), "+v"(ra[2][0]), "+v"(ra[2][1]),
+                           "+v"(ra[3][0]), "+v"(ra[3][1])
+                         :
+                         : "memory");
+            YH_WR_STAMP(4);      // R2's work
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            YH_WR_STAMP(5);      // barrier 2
+            // ---- MFMA
+            typedef int v4i __attribute__((ext_vector_type(4)));
+            f16x8 fa[4], fb[6];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const v4i t = {ra[i][0][0], ra[i][0][1], ra[i][1][0], ra[i][1][1]};
+                fa[i] = __builtin_bit_cast(f16x8, t);
+            }
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                const v4i t = {rb[j][0][0], rb[j][0][1], rb[j][1][0], rb[j][1][1]};
+                fb[j] = __builtin_bit_cast(f16x8, t);
+            }
+            if constexpr (NOCOMPUTE) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) asm volatile("" ::"v"(fa[i]));
+#pragma unroll
+                for (int j = 0; j < 6; ++j) asm volatile("" ::"v"(fb[j]));
+            } else {
+                if (a.prio) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 6; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+                if (a.prio) __builtin_amdgcn_s_setprio(0);
+            }
+            YH_WR_STAMP(2);      // 24 MFMAs issued
+            YH_WR_BARRIER();
+            YH_WR_STAMP(3);      // barrier 3
+        }
+    } else
     for (int s = 0; s < nsteps; ++s) {
         // ---- LOAD
         const unsigned stage = lds0 + WR_XRING + st_read * WR_ABYTES;
         wr_v2i ra[4][2], rb[6][2];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            ra[i][0] = wr_read_tr16<0>(stage + (a_addr0 ^ (i << 5)));
-            ra[i][1] = wr_read_tr16<1024>(stage + (a_addr0 ^ (i << 5)));
+            ra[i][0] = NOCOMPUTE ? wr_v2i{(int)stage, i} : wr_read_tr16<0>(stage + (a_addr0 ^ (i << 5)));
+            ra[i][1] = NOCOMPUTE ? wr_v2i{(int)stage, i} : wr_read_tr16<1024>(stage + (a_addr0 ^ (i << 5)));
         }
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
 #pragma unroll
             for (int sx = 0; sx < 3; ++sx) {
-                rb[2 * sx][h] = wr_read_tr16<0>(b_abs[sx][h]);
-                rb[2 * sx + 1][h] = wr_read_tr16<0>(b_abs[sx][h] ^ 32);
+                rb[2 * sx][h] = NOCOMPUTE ? wr_v2i{(int)b_abs[sx][h], h} : wr_read_tr16<0>(b_abs[sx][h]);
+                rb[2 * sx + 1][h] = NOCOMPUTE ? wr_v2i{(int)b_abs[sx][h], sx} : wr_read_tr16<0>(b_abs[sx][h] ^ 32);
             }
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -228,8 +433,10 @@ __global__ __launch_bounds__(768, 3) void conv_wgrad_roll_kernel(const RollArgs 
                        "+v"(rb[5][0]), "+v"(rb[5][1])
                      :
                      : "memory");
+        YH_WR_STAMP(0);      // fragment reads issued and returned
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
+        YH_WR_STAMP(1);      // barrier 1
         // ---- MFMA
         typedef int v4i __attribute__((ext_vector_type(4)));
         f16x8 fa[4], fb[6];
@@ -243,16 +450,26 @@ __global__ __launch_bounds__(768, 3) void conv_wgrad_roll_kernel(const RollArgs 
             const v4i t = {rb[j][0][0], rb[j][0][1], rb[j][1][0], rb[j][1][1]};
             fb[j] = __builtin_bit_cast(f16x8, t);
         }
-        __builtin_amdgcn_s_setprio(1);
+        if constexpr (NOCOMPUTE) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < 4; ++i) asm volatile("" ::"v"(fa[i]));
 #pragma unroll
-            for (int j = 0; j < 6; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[i], fb[j], acc[i][j], 0, 0, 0);
-        __builtin_amdgcn_s_setprio(0);
+            for (int j = 0; j < 6; ++j) asm volatile("" ::"v"(fb[j]));
+        } else {
+            if (a.prio) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 6; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+            if (a.prio) __builtin_amdgcn_s_setprio(0);
+        }
+        YH_WR_STAMP(2);      // 24 MFMAs issued
         YH_WR_BARRIER();
+        YH_WR_STAMP(3);      // barrier 2
         // ---- stream interval (the other two groups read / multiply)
-        if constexpr (ABL != 3) {
+        if constexpr (!NODMA) {
             if (s + D < nsteps) issue();
+            YH_WR_STAMP(6);      // piece issued
             wr_wait_keep(min(D - 2, max(0, nsteps - 3 - s)));
         }
 #pragma unroll
@@ -260,11 +477,20 @@ __global__ __launch_bounds__(768, 3) void conv_wgrad_roll_kernel(const RollArgs 
 #pragma unroll
             for (int sx = 0; sx < 3; ++sx) b_abs[sx][h] = lds0 + ((b_abs[sx][h] + roll_add) & (WR_XRING - 1));
         st_read = st_read + 1 == S ? 0 : st_read + 1;
+        YH_WR_STAMP(4);      // stream interval's work (issue, counted wait, address roll)
         YH_WR_BARRIER();
+        YH_WR_STAMP(5);      // barrier 3
     }
-    for (int k = grp; k < 2; ++k) YH_WR_BARRIER();      // every wave has executed the same number of barriers
+    if constexpr (!FREE) for (int k = grp; k < 2; ++k) YH_WR_BARRIER();      // every wave has executed the same number of barriers
 #undef YH_WR_BARRIER
 
+    if constexpr (TIMING) {
+        if (blockIdx.x == 8 && (wave & 3) == 0 && lane == 0 && a.timing) {
+#pragma unroll
+            for (int k = 0; k < 7; ++k) a.timing[(wave >> 2) * 8 + k] = tsum[k];
+            a.timing[(wave >> 2) * 8 + 7] = (unsigned long long)nsteps;
+        }
+    }
     f32x4* part = reinterpret_cast<f32x4*>(d.ws) + ((long)split_id * tiles + tile_id) * (24 * NT);
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -309,18 +535,80 @@ __global__ __launch_bounds__(768) void wgrad_roll_reduce_kernel(const RollArgs a
     }
 }
 
+// Partial tiles -> dw, second form (the default).  The first form above scatters: a lane's four values are four output channels of one
+// (ci, tap), 36 bytes from its neighbour's - 1.2 M four-byte read-modify-writes (or atomics) per 76 x 76 layer - and measured 41 us per
+// launch for 75 MB (1.9 TB/s), a sixth of the whole weight gradient.  Here one workgroup owns a [16 co][16 ci][9 taps] block of dw:
+// wave t (of 9) sums the fragment that holds tap t of the block over the splits (eight independent 16-byte loads in flight per lane,
+// fixed order), the block is transposed through LDS and leaves as 16 rows of 576 contiguous bytes.  Workgroups = tiles x 32 x G; G > 1
+// (few tiles: the 76 x 76 and 152 x 152 layers) splits the pixel splits over G workgroups that meet in row-contiguous atomics.
+template <bool VEC>
+__global__ __launch_bounds__(576) void wgrad_roll_reduce2_kernel(const RollArgs a, int splits, int per_group) {
+    constexpr int NT = 768;
+    const yh_wgrad_desc& d = a.d;
+    __shared__ __attribute__((aligned(16))) float blk[16][148];
+    const int tiles = a.tiles_m * a.tiles_n;
+    int bid = blockIdx.x;
+    const int b = bid & 1, hh = (bid >> 1) & 1, i = (bid >> 2) & 3, wm = (bid >> 4) & 1, tile = bid >> 5;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int tap = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int trow = tap / 3, tcol = tap - trow * 3;
+    const int w_src = wm * 6 + trow * 2 + hh, ij = i * 6 + tcol * 2 + b;
+    const f32x4* part = reinterpret_cast<const f32x4*>(d.ws) + ((long)tile * 24 + ij) * NT + w_src * 64 + lane;
+    const long stride = (long)tiles * 24 * NT;
+    const int sA = blockIdx.y * per_group, sB = min(sA + per_group, splits);
+    f32x4 v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+    int sp = sA;
+    for (; sp + 7 < sB; sp += 8) {
+        f32x4 t[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t[k] = part[(sp + k) * stride];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] += t[k];
+    }
+    for (int k = 0; sp < sB; ++sp, ++k) v[k & 7] += part[sp * stride];
+    const f32x4 sum = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+#pragma unroll
+    for (int r = 0; r < 4; ++r) blk[4 * (lane >> 4) + r][(lane & 15) * 9 + tap] = sum[r];
+    __syncthreads();
+    const int row = tid / 36, c4 = tid - row * 36;
+    const int tm = tile % a.tiles_m, tn = tile / a.tiles_m;
+    const int co = tm * 128 + wm * 64 + i * 16 + row, ci0 = tn * 64 + hh * 32 + b * 16;
+    float* dst = d.dw + ((long)co * a.cin_w + ci0) * 9 + c4 * 4;
+    const f32x4 o = *reinterpret_cast<const f32x4*>(&blk[row][c4 * 4]);
+    if (gridDim.y == 1) {       // this workgroup owns the rows: plain accumulate (dw is accumulated into; the caller zeroes it)
+        if constexpr (VEC) {
+            f32x4 cur = *reinterpret_cast<f32x4*>(dst);
+            cur += o;
+            *reinterpret_cast<f32x4*>(dst) = cur;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) dst[e] += o[e];
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) atomicAdd(dst + e, o[e]);
+    }
+}
+
 // geometry of the rolling form; false when the layer does not qualify (host code, no launch)
 bool wgrad_roll_geometry(const yh_wgrad_desc* d, RollArgs* pa, int* psplits, size_t* plds) {
     RollArgs& a = *pa;
+    const char* mode_env = getenv("YH_WGRAD_HALO");
+    const int force = mode_env ? atoi(mode_env) : YH_WGRAD_HALO_DEFAULT;
     if (d->dtype != YH_F16 || d->splits == -1) return false;
     if (d->kh != 3 || d->kw != 3 || d->stride != 1 || d->pad != 1 || d->ho != d->h || d->wo != d->w_in) return false;
     if (d->cout % 128 || d->cin % 64 || d->w_in < 16 || d->h < 2) return false;
     if (d->cin_w > 0 && d->cin_w != d->cin) return false;
     const int Wp = d->w_in + 1;
     const int JL = (2 * Wp + 2 + 31) / 32;
-    int S = 16 - JL;
-    if (S > 10) S = 10;
-    { const char* e = getenv("YH_WGRAD_ROLL_STAGES"); if (e && atoi(e) >= 4 && atoi(e) <= S) S = atoi(e); }   // A/B knob: fewer stages
+    // dz ring stages.  The x ring bounds them at 16 - JL, the LDS at 10; measured (profiles/r05_wgrad_roll_ab.txt): 6 stages = four
+    // steps (48 KB) in flight are the fastest on every layer of YOLOv3-608 - 8 and 10 lose 1 - 5 %: a CU is served ~11 B / clk of LDS-DMA
+    // however deep its queue is (tools/probe/run_probe.py), more pieces in flight only lengthen the in-order queue each wave waits on
+    const int s_max = 16 - JL < 10 ? 16 - JL : 10;
+    int S = s_max < 6 ? s_max : 6;
+    { const char* e = getenv("YH_WGRAD_ROLL_STAGES"); if (e && atoi(e) >= 4 && atoi(e) <= s_max) S = atoi(e); }   // A/B knob
     if (S < 4) return false;
     const long Q = (long)d->n * (d->h + 1) * Wp;
     if (Q + 4096 >= 0x7fffffffL) return false;
@@ -335,6 +623,11 @@ bool wgrad_roll_geometry(const yh_wgrad_desc* d, RollArgs* pa, int* psplits, siz
     a.r32 = 32 - a.q32 * Wp;
     { const char* e = getenv("YH_WGRAD_HALO_NOSTAGGER"); a.nostagger = e && atoi(e) ? 1 : 0; }
     const int tiles = a.tiles_m * a.tiles_n;
+    // Which layers take this form (library's choice; YH_WGRAD_HALO=3 forces it wherever it qualifies).  In the training step of
+    // YOLOv3-608 batch 64 (profiles/r05_train_wgrad_mode_ab.txt, r05_wgrad_roll_ab.txt) it beats conv_wgrad_halo_kernel on the layers
+    // with FEW tiles and many pixel splits - 76 x 76 128 -> 256 (4 tiles): 0.245 against 0.263 ms, 152 x 152 64 -> 128 (1 tile; the
+    // round-3 form does not take cout 128): 0.241 against 0.320 - and loses 2 - 3 % on the 38 x 38 / 19 x 19 layers (16 / 64 tiles).
+    if (force < 3 && tiles > 8 && d->cout % 256 == 0) return false;
     int splits = d->splits > 0 ? d->splits : 256 / tiles;          // one workgroup per CU
     {
         const char* e = getenv("YH_WGRAD_HALO_WGS");       // A/B and test knob: total workgroups aimed for
@@ -368,16 +661,40 @@ int launch_wgrad_roll(const yh_wgrad_desc* d, hipStream_t st) {
     const char* abl_env = getenv("YH_WGRAD_ROLL_ABL");      // profiling only
     const int abl = abl_env ? atoi(abl_env) : 0;
     {
-        auto kern = abl == 3 ? conv_wgrad_roll_kernel<3> : conv_wgrad_roll_kernel<0>;
+        const char* order_env = getenv("YH_WGRAD_ROLL_ORDER");     // A/B knob: 0 = one read interval, 1 = split reads, 2 = one barrier per step
+        const int order = order_env ? atoi(order_env) : 2;
+        { const char* e = getenv("YH_WGRAD_ROLL_PRIO"); a.prio = e ? atoi(e) : 0; }   // s_setprio 1 around the MFMAs measured 1 - 3 % slower
+        auto kern = order == 2 ? conv_wgrad_roll_kernel<0, 2> : order == 1 ? conv_wgrad_roll_kernel<0, 1> : conv_wgrad_roll_kernel<0, 0>;
+        if (abl == 1) kern = order == 2 ? conv_wgrad_roll_kernel<1, 2> : order == 1 ? conv_wgrad_roll_kernel<1, 1> : conv_wgrad_roll_kernel<1, 0>;
+        if (abl == 2) kern = order == 2 ? conv_wgrad_roll_kernel<2, 2> : conv_wgrad_roll_kernel<2, 0>;
+#define YH_WR_PICK(A) if (abl == A) kern = order == 1 ? conv_wgrad_roll_kernel<A, 1> : conv_wgrad_roll_kernel<A, 0>
+        YH_WR_PICK(8); YH_WR_PICK(9); YH_WR_PICK(10); YH_WR_PICK(12);
+#undef YH_WR_PICK
+        a.timing = nullptr;
+        if (abl & 8) {      // the stamps land behind the partial tiles (the caller's workspace holds 64 more floats: tools/wgrad_ab.py)
+            if (d->ws_floats < (int64_t)splits * tiles * 128 * 576 + 64) return YH_EINVAL;
+            a.timing = reinterpret_cast<unsigned long long*>(d->ws + (int64_t)splits * tiles * 128 * 576);
+        }
         const hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds);
         if (e != hipSuccess) return (int)e;
         hipLaunchKernelGGL(kern, dim3((unsigned)(tiles * splits)), dim3(768), lds, st, a);
     }
-    int groups = (splits + 15) / 16;
-    if (groups > 32) groups = 32;
-    const int per_group = (splits + groups - 1) / groups;
-    groups = (splits + per_group - 1) / per_group;
-    hipLaunchKernelGGL(wgrad_roll_reduce_kernel, dim3(tiles * 24, groups), dim3(768), 0, st, a, splits, per_group);
+    const char* red_env = getenv("YH_WGRAD_ROLL_REDUCE");      // A/B knob: 1 = the scattering first form
+    if (red_env && atoi(red_env) == 1) {
+        int groups = (splits + 15) / 16;
+        if (groups > 32) groups = 32;
+        const int per_group = (splits + groups - 1) / groups;
+        groups = (splits + per_group - 1) / per_group;
+        hipLaunchKernelGGL(wgrad_roll_reduce_kernel, dim3(tiles * 24, groups), dim3(768), 0, st, a, splits, per_group);
+    } else {
+        int groups = (256 + tiles * 32 - 1) / (tiles * 32);       // >= one workgroup per CU where the splits allow it
+        if (groups > splits / 4) groups = splits / 4;
+        if (groups < 1) groups = 1;
+        const int per_group = (splits + groups - 1) / groups;
+        groups = (splits + per_group - 1) / per_group;
+        if (aligned16(d->dw)) hipLaunchKernelGGL(wgrad_roll_reduce2_kernel<true>, dim3(tiles * 32, groups), dim3(576), 0, st, a, splits, per_group);
+        else hipLaunchKernelGGL(wgrad_roll_reduce2_kernel<false>, dim3(tiles * 32, groups), dim3(576), 0, st, a, splits, per_group);
+    }
     return check_launch();
 }
 

@@ -1,0 +1,121 @@
+// Micro-benchmark (not part of libyolo_hip.so): feasibility of a ONE-wave-per-SIMD weight-gradient K loop - a wave owns 128 x 144
+// outputs (8 x 9 MFMA 16x16x32 tiles, 288 accumulator registers), 34 transposed LDS reads per 72 MFMAs, every fragment re-read right
+// after its last MFMA of the step (single-buffered fragments, rolling refresh).  No LDS-DMA, no barriers unless asked: the compute
+// side alone, cycles per 32-pixel step.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef int v2i __attribute__((ext_vector_type(2)));
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct W1Args { unsigned long long* out; float* sink; int iters; int barrier; };
+
+__device__ __forceinline__ v2i rd_tr(unsigned addr) {
+    v2i r;
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(r) : "v"(addr));
+    return r;
+}
+template <int OFF> __device__ __forceinline__ v2i rd_tr_o(unsigned addr) {
+    v2i r;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF));
+    return r;
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256, 1) void wave1_probe_kernel(const W1Args a) {
+    extern __shared__ __attribute__((aligned(128))) unsigned char lds[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int q = lane & 15, g = lane >> 4;
+    // A (dz): 256-byte rows, row 8g + q/4, 16-byte unit (2 i + (q & 3) / 2) ^ swz(row); B (x): 128-byte rows with a tap offset
+    const int row = 8 * g + (q >> 2);
+    unsigned a_addr0 = 65536 + row * 256 + ((((4 * (q & 3)) >> 3) ^ ((((row & 3) | (((row >> 3) & 1) << 2)) << 1))) << 4) + (((4 * (q & 3)) & 7) * 2);
+    unsigned b_addr[9][2];
+    for (int t = 0; t < 9; ++t)
+        for (int h = 0; h < 2; ++h) {
+            const int xr = row + 4 * h + (t / 3) * 77 + (t % 3);
+            const int f = ((xr >> 1) & 1) | (((xr >> 3) & 1) << 1);
+            b_addr[t][h] = (unsigned)((xr & 511) * 128 + (((wave & 3) ^ f) << 5) + (q & 3) * 8);
+        }
+    f32x4 acc[8][9];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 9; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    v2i ra[8][2], rb[9][2];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { ra[i][0] = rd_tr_o<0>(a_addr0 ^ (i << 5)); ra[i][1] = rd_tr_o<1024>(a_addr0 ^ (i << 5)); }
+#pragma unroll
+    for (int j = 0; j < 9; ++j) { rb[j][0] = rd_tr(b_addr[j][0]); rb[j][1] = rd_tr(b_addr[j][1]); }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    unsigned stage = 0;
+    for (int it = 0; it < a.iters; ++it) {
+        if (a.barrier) __builtin_amdgcn_s_barrier();
+        stage = (stage + 8192) & 0x7fff;                // next step's dz stage (4 stages)
+        const unsigned abase = a_addr0 + stage;
+#pragma unroll
+        for (int j = 0; j < 9; ++j) {
+            // all of step s's MFMAs on B fragment j; fragment j is dead afterwards: refresh it from the next step's rows
+            const v4i tb = {rb[j][0][0], rb[j][0][1], rb[j][1][0], rb[j][1][1]};
+            const f16x8 fb = __builtin_bit_cast(f16x8, tb);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const v4i ta = {ra[i][0][0], ra[i][0][1], ra[i][1][0], ra[i][1][1]};
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, ta), fb, acc[i][j], 0, 0, 0);
+                if (MODE >= 1 && j == 8) {      // A fragment i is dead after its last MFMA of the step
+                    __builtin_amdgcn_sched_barrier(0);
+                    ra[i][0] = rd_tr_o<0>(abase ^ (i << 5));
+                    ra[i][1] = rd_tr_o<1024>(abase ^ (i << 5));
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            if (MODE >= 1) {
+                __builtin_amdgcn_sched_barrier(0);
+                b_addr[j][0] = (b_addr[j][0] + 4096) & 0xffff;
+                b_addr[j][1] = (b_addr[j][1] + 4096) & 0xffff;
+                rb[j][0] = rd_tr(b_addr[j][0]);
+                rb[j][1] = rd_tr(b_addr[j][1]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if (MODE >= 1) {
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+v"(ra[0][0]), "+v"(ra[0][1]), "+v"(ra[1][0]), "+v"(ra[1][1]), "+v"(ra[2][0]), "+v"(ra[2][1]), "+v"(ra[3][0]), "+v"(ra[3][1]),
+                           "+v"(ra[4][0]), "+v"(ra[4][1]), "+v"(ra[5][0]), "+v"(ra[5][1]), "+v"(ra[6][0]), "+v"(ra[6][1]), "+v"(ra[7][0]), "+v"(ra[7][1])
+                         :: "memory");
+            asm volatile(""
+                         : "+v"(rb[0][0]), "+v"(rb[0][1]), "+v"(rb[1][0]), "+v"(rb[1][1]), "+v"(rb[2][0]), "+v"(rb[2][1]), "+v"(rb[3][0]), "+v"(rb[3][1]),
+                           "+v"(rb[4][0]), "+v"(rb[4][1]), "+v"(rb[5][0]), "+v"(rb[5][1]), "+v"(rb[6][0]), "+v"(rb[6][1]), "+v"(rb[7][0]), "+v"(rb[7][1]),
+                           "+v"(rb[8][0]), "+v"(rb[8][1])
+                         :: "memory");
+        }
+    }
+    __syncthreads();
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    if (threadIdx.x == 0) a.out[blockIdx.x] = t1 - t0;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 9; ++j) s += acc[i][j];
+    if (a.sink) *reinterpret_cast<f32x4*>(a.sink + ((long)blockIdx.x * 256 + threadIdx.x) * 4) = s;
+}
+
+extern "C" int wave1_probe(const W1Args* a, int mode, int grid, void* stream) {
+    const size_t ldsb = 128 * 1024;
+    auto k0 = wave1_probe_kernel<0>;
+    auto k1 = wave1_probe_kernel<1>;
+    static bool raised = false;
+    if (!raised) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k0), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k1), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        raised = true;
+    }
+    if (mode == 0) hipLaunchKernelGGL(k0, dim3(grid), dim3(256), ldsb, (hipStream_t)stream, *a);
+    else hipLaunchKernelGGL(k1, dim3(grid), dim3(256), ldsb, (hipStream_t)stream, *a);
+    return (int)hipGetLastError();
+}
