@@ -253,7 +253,8 @@ def test_device_calibration_at_the_baseline_shapes_then_int8_engine(tag):
     # Against the golden (written in the build container: oneDNN convolutions, fp32 cosine sums) the comparison is statistical: votes
     # over power-of-two candidates whose cosines tie to 1e-6 flip with the last bits of the tensors, and in a 75 / 110-layer net one
     # flipped activation scale changes every tensor behind it.  Measured: ~80 % of the tensors identical, the rest one or two steps.
-    assert same >= 0.6 * len(scales) and worst <= 4.0
+    # thresholds at 1.5 x the measured share of differing tensors (v3_608: 78.0 % identical, v4_640: 86.1 %)
+    assert same >= {'v3_608': 0.67, 'v4_640': 0.79}.get(tag, 0.6) * len(scales) and worst <= 4.0
     qm.eval()
     x = synth.dyadic_frames(synth.image_batch(1, size, seed=77))
     with torch.no_grad():
@@ -272,11 +273,15 @@ def test_device_calibration_at_the_baseline_shapes_then_int8_engine(tag):
         for a, b in zip(raws, raws_cpu):
             assert torch.equal(a.cpu(), b), (a.cpu() - b).abs().max().item()
     else:
-        # Mish is evaluated in fp32 on both sides, by different formulas (the kernel: v n / (n + 2) with n = e^v (e^v + 2) on expf;
-        # torch on the CPU: v tanh(softplus(v))): values that land on a rounding tie of the next grid can come out one step apart,
-        # and a 110-layer quantised net carries such a flip to its heads.  Bounded, not bit-equal (the synthetic power-of-two state
-        # of tests/test_ptq_large.py happens to be bit-equal; the reference itself cannot calibrate this cfg at all).
-        assert all(f <= 0.15 for f, _ in off), off
+        # Mish: the kernel decides a value next to a rounding tie of the activation grid by the ONE-ROUNDING form (common.h mish_f64:
+        # v n / (n + 2), n = e^v (e^v + 2) in double, rounded once); torch on the CPU evaluates v tanh(softplus(v)) in fp32 (~3 ulp
+        # from the true value through log1pf / expf / tanhf), so a value whose true Mish lies within torch's own error of a tie comes
+        # out one grid step apart, and a 110-layer quantised net carries such a flip to its heads.  Round 5 measured that the kernel
+        # side is not the lever: with the float form v n / (n + 2) on expf (rounds 1 - 4) and with the exactly rounded form the share
+        # of differing head values is the same 0.6 % / 1.4 % / 1.2 %, one grid step at most - bit-equality with torch's CPU libm is
+        # not reachable by any formula on the GPU.  Bounded at 1.5 - 2 x the measured share (the synthetic power-of-two state of
+        # tests/test_ptq_large.py is bit-equal; the reference itself cannot calibrate this cfg at all).
+        assert all(f <= 0.025 and d <= 0.0625 for f, d in off), off
 
 
 # ------------------------------------------------------------------------------ device calibration services (csrc/calib.hip)

@@ -132,7 +132,7 @@ extern "C" int yh_qpool(const yh_pool_desc* d, void* stream) {
 }
 
 // Self-test of the int8 epilogues' Mish (common.h mish_for_grid) over float bit patterns [bits0, bits1): out[0] = values whose grid
-// index round_clamp(mish * inv_s) differs between the exact form and mish_for_grid, out[1] = max relative difference (as float bits,
+// index round_clamp(mish * inv_s) differs between the one-rounding form (mish_f64) and mish_for_grid, out[1] = max relative difference (as float bits,
 // in units of 1e-9) between the exact form and mish_fast, out[2] = values on which the exact form was consulted.
 __global__ __launch_bounds__(256) void qmish_selftest_kernel(unsigned bits0, unsigned bits1, float inv_s, unsigned long long* out) {
     unsigned long long bad = 0, slow = 0;
@@ -141,7 +141,7 @@ __global__ __launch_bounds__(256) void qmish_selftest_kernel(unsigned bits0, uns
     for (unsigned long long i = blockIdx.x * (unsigned long long)blockDim.x + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * blockDim.x) {
         const float v = __uint_as_float(bits0 + (unsigned)i);
         if (!(fabsf(v) <= 64.f)) continue;
-        const float ye = activate(v, YH_ACT_MISH, 0.f), yf = mish_fast(v), yg = mish_for_grid(v, inv_s);
+        const float ye = mish_f64(v), yf = mish_fast(v), yg = mish_for_grid(v, inv_s);
         const float qe = fminf(fmaxf(copysignf(floorf(fabsf(ye * inv_s) + 0.5f), ye * inv_s), -128.f), 127.f);
         const float qg = fminf(fmaxf(copysignf(floorf(fabsf(yg * inv_s) + 0.5f), yg * inv_s), -128.f), 127.f);
         bad += qe != qg;

@@ -64,16 +64,29 @@ def _non_max_suppression(prediction, conf_thres, iou_thres, multi_label, classes
     cap = min(guess, _pow2_at_least(most))
     ag = 1 if agnostic else 0
     exact = False
+    work_budget = {}      # resolved at most once per call, and only when a pass is large enough to ask (budget())
 
     def per_image_bytes(c):
         return c * ((c + 63) // 64) * 8 + c * (8 + 8 + 6 + 1) * 4
 
+    def budget():
+        """Bytes the buffers of one pass may take: the fixed ceiling, and never more than half of what the device has free right now (an
+        evaluation inside a training run shares the GPU with ~40 GB of step buffers; smaller parts have less than the ceiling in all)."""
+        b = work_budget.get('v')
+        if b is None:
+            try:
+                free = torch.cuda.mem_get_info(dev)[0] if dev.type == 'cuda' else _WORK_BUDGET
+            except Exception:
+                free = _WORK_BUDGET
+            b = work_budget['v'] = int(min(_WORK_BUDGET, max(free // 2, 64 << 20)))
+        return b
+
     def in_chunks(c):
         """Run the images in groups whose buffers fit the budget and concatenate the results."""
-        if per_image_bytes(c) > _WORK_BUDGET:
+        if per_image_bytes(c) > budget():
             raise MemoryError('non_max_suppression: %d candidates in one image need a %.1f GB IoU bit mask (conf_thres %g, %s): raise '
                               'conf_thres' % (c, per_image_bytes(c) / 1e9, conf_thres, 'multi-label' if ml else 'best class'))
-        step = max(1, int(_WORK_BUDGET // per_image_bytes(c)))
+        step = max(1, int(budget() // per_image_bytes(c)))
         out = []
         for i in range(0, n, step):
             out += _non_max_suppression(pred[i:i + step], conf_thres, iou_thres, multi_label, classes, agnostic)
@@ -83,9 +96,10 @@ def _non_max_suppression(prediction, conf_thres, iou_thres, multi_label, classes
         # a guessed bound this large is not worth its mask: count first (one extra 4n-byte read), then size exactly
         count = torch.zeros(n, dtype=torch.int32, device=dev)
         hiplib.check(lib.yh_nms_candidates(P(pred), n, rows, nc, conf_thres, ml, P(cmask), None, P(count), 0, S), 'nms count')
-        cap, exact = _pow2_at_least(max(int(count.max()), 1)), True
-        if n * per_image_bytes(cap) > _WORK_BUDGET and (n > 1 or per_image_bytes(cap) > _WORK_BUDGET):
-            _density.setdefault(ml, collections.deque(maxlen=_HINT_WINDOW)).append(cap / 2.0 / float(rows))
+        cmax = max(int(count.max()), 1)
+        cap, exact = _pow2_at_least(cmax), True
+        if n * per_image_bytes(cap) > budget() and (n > 1 or per_image_bytes(cap) > budget()):
+            _density.setdefault(ml, collections.deque(maxlen=_HINT_WINDOW)).append(cmax / float(rows))     # the TRUE count
             return in_chunks(cap)
     while True:
         words = (cap + 63) // 64
@@ -108,7 +122,7 @@ def _non_max_suppression(prediction, conf_thres, iou_thres, multi_label, classes
             break
         assert not exact, 'candidate count changed between the count pass and the emit pass'
         cap = _pow2_at_least(mmax)             # an image overflowed the bound: repeat with one that holds every candidate
-        if n * per_image_bytes(cap) > _WORK_BUDGET and (n > 1 or per_image_bytes(cap) > _WORK_BUDGET):
+        if n * per_image_bytes(cap) > budget() and (n > 1 or per_image_bytes(cap) > budget()):
             _density.setdefault(ml, collections.deque(maxlen=_HINT_WINDOW)).append(mmax / float(rows))
             return in_chunks(cap)
     _density.setdefault(ml, collections.deque(maxlen=_HINT_WINDOW)).append(mmax / float(rows))

@@ -264,9 +264,14 @@ class PaddedTwin:
         if self.real_bufs:
             # only when somebody wrote to a live buffer since the last pull_stats (tensor version counters: ~150 integer reads instead
             # of a cat + scatter per step)
+            # Writes through `.data` views (`bn.running_mean.data.zero_()`) do not move a version counter: rebinding shows
+            # in the data pointers tracked with the versions, and every 64th step syncs unconditionally - after a pull_stats the live
+            # buffers equal the twin's, so the forced sync changes nothing in a normal run and bounds how long such an edit can stay
+            # unseen (Darknet.hip_refresh() is the immediate way).
             seen = self.__dict__.get('_buf_versions')
             now = self._live_versions()
-            if seen != now:
+            self._push_count = self.__dict__.get('_push_count', 0) + 1
+            if seen != now or self._push_count % 64 == 0:
                 self.buf_flat.index_copy_(0, self.pull_index, torch.cat([b.reshape(-1) for b in self.real_bufs]))
                 pairs = [(rk.num_batches_tracked, tk.num_batches_tracked) for rk, tk in self._bn_pairs if rk.num_batches_tracked is not None]
                 if pairs:      # a live reset of the step counter reaches the twin too
@@ -284,8 +289,8 @@ class PaddedTwin:
         self._buf_versions = self._live_versions()      # what the live buffers look like when WE wrote them last
 
     def _live_versions(self):
-        return [b._version for b in self.real_bufs] + [rk.num_batches_tracked._version for rk, _ in self._bn_pairs
-                                                        if rk.num_batches_tracked is not None]
+        return [(b._version, b.data_ptr()) for b in self.real_bufs] + [rk.num_batches_tracked._version for rk, _ in self._bn_pairs
+                                                                        if rk.num_batches_tracked is not None]
 
     def map_grads(self, real_subset, twin_grads):
         """Gradients of the twin parameters of one backward range -> gradients of the matching live parameters."""

@@ -553,7 +553,9 @@ class Darknet(nn.Module):
         """Drop the HIP engine; the next CUDA eval forward re-packs from the live parameters.
 
         The engine already notices optimizer steps and ``param.data = ...`` rebinding (tensor version /
-        address); call this after editing weights through ``param.data`` views in place."""
+        address); call this after editing weights OR BatchNorm buffers through ``.data`` views in place
+        (``bn.running_mean.data.zero_()`` moves no version counter: the training engine would pick it up
+        only at its next unconditional buffer sync, engine/padded.py push)."""
         self.__dict__['_hip_engine'] = self.__dict__['_hip_train_engine'] = None
 
     def _apply(self, fn, *args, **kwargs):

@@ -190,7 +190,11 @@ def train(opt, hyp):
     # frames + geometry + gains) and one HIP kernel per item does the mosaic, warp, HSV, flip, transpose and /256 on the GPU
     # (engine/preprocess.py render_mosaic_items, csrc/augment.hip) - bit-identical to the host items (tests/test_augment.py), at
     # 0.2 ms instead of 49 ms of a host core per item, which is what an 8-GPU node needs to be fed
-    device_augment = device.type == 'cuda' and not getattr(opt, 'host_augment', False)
+    # --rect batches are letterboxed per batch rectangle; the device recipe covers only rectangles that need no second resize
+    # (utils/datasets.py rect_train_item), so rect training keeps the host loader unless --device-augment asks for the device path
+    # explicitly (the default must not turn a working --rect run into a NotImplementedError)
+    device_augment = device.type == 'cuda' and not getattr(opt, 'host_augment', False) and \
+        (not opt.rect or getattr(opt, 'device_augment', False))
     dataset = LoadImagesAndLabels(train_path, img_size, batch_size, augment=True, hyp=hyp, rect=opt.rect, cache_images=opt.cache_images,
                                   rank=rank, is_gray_scale=opt.gray_scale, device_augment=device_augment,
                                   arith=getattr(opt, 'image_arith', None))

@@ -495,7 +495,8 @@ def rect_train_item(self, index):
     r, unpad, (dw, dh), (top, bottom, left, right) = _letterbox_plan(h, w, shape, scaleup=True)    # letterbox(..., auto=False, scaleup=True)
     if unpad != (w, h):
         raise NotImplementedError('%s: letterbox would resize the %dx%d image a second time for the rectangle %s; not built for '
-                                  'device_augment' % (self.img_files[index], w, h, tuple(shape)))
+                                  'device_augment - train with --host-augment (or without --device-augment) for this data set'
+                                  % (self.img_files[index], w, h, tuple(shape)))
     canvas = (h + top + bottom, w + left + right)
     x = self.labels[index]
     labels = np.zeros((0, 5), dtype=np.float32)
