@@ -403,7 +403,7 @@ def train_main(args, device, dist, world, rank, local_rank):
     return out
 
 
-WGRAD_KERNELS = {90: 'conv_wgrad_halo', 22: 'conv_wgrad_dma<2,2>', 42: 'conv_wgrad_dma<4,2>', 44: 'conv_wgrad_dma<4,4>',
+WGRAD_KERNELS = {90: 'conv_wgrad_halo', 91: 'conv_wgrad_roll', 22: 'conv_wgrad_dma<2,2>', 42: 'conv_wgrad_dma<4,2>', 44: 'conv_wgrad_dma<4,4>',
                  82: 'conv_wgrad_dma<8,2>', 84: 'conv_wgrad_dma<8,4>', 1: 'conv_wgrad'}   # yh_conv2d_wgrad_kernel codes
 
 
@@ -512,8 +512,8 @@ def train_roofline(eng, x, precision):
     peak = PEAK_TFLOPS[precision]
     dg = groups[dom]
     traffic = traffic_of(rocprof_name(dom), section, dg['bytes']) if precision == 'fp16' else None
-    if traffic is not None and dom == 'conv_wgrad_halo':
-        companion = traffic_of('wgrad_halo_reduce', section)
+    if traffic is not None and dom in ('conv_wgrad_halo', 'conv_wgrad_roll'):
+        companion = traffic_of('wgrad_halo_reduce' if dom == 'conv_wgrad_halo' else 'wgrad_roll_reduce', section)
         if companion:
             traffic['second_launch'] = {k: companion[k] for k in ('kernel', 'hbm_bytes_per_launch', 'write_bytes', 'fetch_bytes_raw')}
     members = {k: dict(ms=round(groups[k]['ms'], 3), n=groups[k]['n'], tflops=round(groups[k]['flops'] / groups[k]['ms'] / 1e9, 1),

@@ -396,11 +396,11 @@ def test_dgrad_matches_autograd(libs, code, accumulate, case):
 
 @pytest.mark.parametrize('code', [F32, F16], ids=['fp32', 'fp16'])
 @pytest.mark.parametrize('accumulate', [False, True], ids=['write', 'acc'])
-@pytest.mark.parametrize('case', [(2, 32, 32, 32, 64), (1, 25, 27, 32, 64), (3, 19, 22, 16, 40), (1, 9, 9, 24, 64)],
+@pytest.mark.parametrize('case', [(2, 32, 32, 32, 64), (1, 25, 27, 32, 64), (3, 19, 22, 16, 40), (1, 9, 9, 24, 64), (2, 21, 24, 64, 128)],
                          ids=lambda c: 'n%d_%dx%d_c%d-%d' % c)
 def test_fused_stride2_dgrad_matches_autograd_and_the_phase_form(libs, code, accumulate, case):
     """ups = 4: the four parity phases of a 3x3 / stride-2 data gradient as one 2x2-tap pass with 4 * cin rows (the form the
-    engine uses for layers with <= 32 input channels), against autograd and against the four-launch phase form, odd sizes
+    engine uses for layers with <= 64 input channels), against autograd and against the four-launch phase form, odd sizes
     included; also through the host emulation."""
     lib, fake = libs
     N, H, W, cin, cout = case

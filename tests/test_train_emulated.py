@@ -304,9 +304,10 @@ def test_yolov3_train_plan_against_fp64(mini):
     assert plan['zero_list'] == []  # every gradient buffer's first writer covers it: no memsets in the step
     kinds = [w.rstrip('0123456789') for w, _ in plan['bwd_ops']]
     # 69 stride-1 data gradients + 5 stride-2 layers x 4 parity phases
-    # five stride-2 layers: the first (32 input channels, memory bound) runs its four parity phases as one pass (ups = 4)
-    assert kinds.count('wgrad') == 75 and kinds.count('dgrad') == 69 + 4 * 4 + 1
-    assert sum(1 for what, d in plan['bwd_ops'] if what.startswith('dgrad') and d.ups == 4) == 1
+    # five stride-2 layers: the first two (32 and 64 input channels, memory bound) run their four parity phases as one pass (ups = 4;
+    # round 5: 64 channels measured 0.642 against 0.704 ms, profiles/r05_fused_dgrad_ab.txt)
+    assert kinds.count('wgrad') == 75 and kinds.count('dgrad') == 69 + 3 * 4 + 2
+    assert sum(1 for what, d in plan['bwd_ops'] if what.startswith('dgrad') and d.ups == 4) == 2
 
 
 def test_backward_ranges_hand_gradients_over_early(mini, monkeypatch):

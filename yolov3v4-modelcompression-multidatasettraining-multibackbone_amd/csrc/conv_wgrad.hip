@@ -1113,9 +1113,79 @@ __device__ __forceinline__ void pack_item_elems(const yh_pack_item& it) {
     }
 }
 
-__global__ __launch_bounds__(256) void pack_batch_kernel(const yh_pack_item* items) {
+// Tiled form of the dense images (modes 0, 1, 2; 1x1 and 3x3 filters; round 5).  The gather form above reads the fp32 parameter with
+// the stride of the DESTINATION order: consecutive threads of a data-gradient image are consecutive output channels, 4 bytes from
+// 64 different lines (cin * taps floats apart) per wave instruction - 0.97 - 1.9 GB fetched to repack 248 MB of weights
+// (profiles/r04_rocprof_pmc_train.txt), 0.445 ms per step.  Here a workgroup moves a tile [64 rows of the SOURCE's slow axis][E = CI x
+// taps contiguous floats] through LDS: rows are read as they lie (288- / 256-byte runs), the image is written in 128-byte runs.
+//   mode 0: source row = output channel m, run = 8 (1x1: 64) input channels x taps; image row (m, tap) gets 8 / 64 consecutive c
+//           -> tile [8 m][64 c x taps] instead: for the forward image the contiguous axis of BOTH sides is c, so rows = m, E = 64 taps
+//   mode 1 / 2: source row = output channel co, run = CI input channels x taps; image row (ci, tap') gets 64 consecutive co
+constexpr int PK_PITCH = 73;      // floats per LDS row of the [64][72] tile (odd: the transposed reads walk rows conflict-free)
+template <typename T>
+__device__ __forceinline__ void pack_item_tiled(const yh_pack_item& it, float* lds) {
+    T* out = reinterpret_cast<T*>(it.packed);
+    const int taps = it.kh * it.kw, tid = threadIdx.x;
+    if (it.mode == 0) {
+        // tile: 8 output channels x 64 input channels (x taps): lds[m_l][c_l * taps + tap], pitch 64 * taps + 1
+        const int pitch = 64 * taps + 1;
+        const int ct = (it.k_pad + 63) / 64, mt = (it.m_pad + 7) / 8;
+        for (int tile = blockIdx.x; tile < ct * mt; tile += gridDim.x) {
+            const int m0 = (tile / ct) * 8, c0 = (tile % ct) * 64;
+            const int run = min(64, it.cin - c0) * taps;         // contiguous floats of a source row inside the tile (<= 0: padding only)
+            __syncthreads();
+            for (int idx = tid; idx < 8 * 64 * taps; idx += 256) {
+                const int m_l = idx / (64 * taps), e = idx - m_l * (64 * taps);
+                const int m = m0 + m_l;
+                lds[m_l * pitch + e] = (m < it.cout && e < run) ? it.w[((long)m * it.cin + c0) * taps + e] : 0.f;
+            }
+            __syncthreads();
+            for (int idx = tid; idx < 8 * taps * 64; idx += 256) {
+                const int c_l = idx & 63, r = idx >> 6;          // r = m_l * taps + tap
+                const int m_l = r / taps, tap = r - m_l * taps;
+                const int m = m0 + m_l, c = c0 + c_l;
+                if (m < it.m_pad && c < it.k_pad) out[((long)m * taps + tap) * it.k_pad + c] = (T)lds[m_l * pitch + c_l * taps + tap];
+            }
+        }
+    } else {
+        // modes 1 / 2: tile 64 output channels (image columns) x CI input channels (image rows) x source taps
+        const int CI = taps == 1 ? 64 : 8, E = CI * taps;
+        const int khp = it.mode == 2 ? (it.pa + it.pad) / 2 + 1 : it.kh, kwp = it.mode == 2 ? (it.pb + it.pad) / 2 + 1 : it.kw;
+        const int tp = khp * kwp;                                 // taps of the image
+        const int cot = (it.k_pad + 63) / 64, cit = (it.m_pad + CI - 1) / CI;
+        for (int tile = blockIdx.x; tile < cot * cit; tile += gridDim.x) {
+            const int ci0 = (tile / cot) * CI, co0 = (tile % cot) * 64;
+            const int run = min(CI, it.cin - ci0) * taps;
+            __syncthreads();
+            for (int idx = tid; idx < 64 * E; idx += 256) {
+                const int co_l = idx / E, e = idx - co_l * E;
+                const int co = co0 + co_l;
+                lds[co_l * PK_PITCH + e] = (co < it.cout && e < run) ? it.w[((long)co * it.cin + ci0) * taps + e] : 0.f;
+            }
+            __syncthreads();
+            for (int idx = tid; idx < CI * tp * 64; idx += 256) {
+                const int co_l = idx & 63, r = idx >> 6;         // r = ci_l * tp + tap'
+                const int ci_l = r / tp, t2 = r - ci_l * tp;
+                int fr, fs;
+                if (it.mode == 2) { fr = it.pa + it.pad - 2 * (t2 / kwp); fs = it.pb + it.pad - 2 * (t2 % kwp); }
+                else { fr = it.kh - 1 - t2 / it.kw; fs = it.kw - 1 - t2 % it.kw; }
+                const int ci = ci0 + ci_l, co = co0 + co_l;
+                float v = 0.f;
+                if (fr >= 0 && fr < it.kh && fs >= 0 && fs < it.kw) v = lds[co_l * PK_PITCH + ci_l * taps + fr * it.kw + fs];
+                if (ci < it.m_pad && co < it.k_pad) out[((long)ci * tp + t2) * it.k_pad + co] = (T)v;
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void pack_batch_kernel(const yh_pack_item* items, const int pack_tiled_enabled) {
+    __shared__ float pk_lds[8 * (64 * 9 + 1) > 64 * PK_PITCH ? 8 * (64 * 9 + 1) : 64 * PK_PITCH];
     const yh_pack_item it = items[blockIdx.y];
     const int taps = it.kh * it.kw;
+    if ((it.mode == 0 || it.mode == 1 || it.mode == 2) && it.dtype == YH_F16 && (taps == 1 || (it.kh == 3 && it.kw == 3)) &&
+        pack_tiled_enabled) {
+        pack_item_tiled<f16>(it, pk_lds);
+    } else
     if (it.mode == 4) {   // depthwise: packed[tap][c] = w[c][tap], zero for padded channels
         const long total = (long)taps * it.k_pad;
         for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -1361,7 +1431,8 @@ extern "C" int yh_conv_pack_weights_dgrad_phase(int dtype, const float* w, int c
 
 extern "C" int yh_pack_batch(const yh_pack_item* items, int n_items, void* stream) {
     if (!items || n_items <= 0 || n_items > 65535) return YH_EINVAL;
-    hipLaunchKernelGGL(pack_batch_kernel, dim3(512, n_items), dim3(256), 0, (hipStream_t)stream, items);
+    const char* e = getenv("YH_PACK_GATHER");        // A/B knob: 1 = the gather form for every image
+    hipLaunchKernelGGL(pack_batch_kernel, dim3(512, n_items), dim3(256), 0, (hipStream_t)stream, items, (e && atoi(e)) ? 0 : 1);
     return check_launch();
 }
 

@@ -88,7 +88,7 @@ constexpr int WR_ABYTES = 8192;     // one dz step: 32 rows x 256 B
 // barrier per step, see the K loop)
 template <int ABL, int ORDER>
 __global__ __launch_bounds__(768, 3) void conv_wgrad_roll_kernel(const RollArgs a) {
-    constexpr bool SPLIT = ORDER == 1, FREE = ORDER == 2;
+    constexpr bool SPLIT = ORDER == 1, FREE = ORDER == 2, REFRESH = ORDER == 3;
     constexpr bool TIMING = (ABL & 8) != 0, NODMA = (ABL & 1) != 0, NOCOMPUTE = (ABL & 2) != 0, ZEROSRC = (ABL & 4) != 0;
     unsigned long long tsum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = 0;
     constexpr int NT = 768;
@@ -116,6 +116,7 @@ __global__ __launch_bounds__(768, 3) void conv_wgrad_roll_kernel(const RollArgs 
     const int wm = wave / 6, wn = wave - wm * 6;      // wave tile: channels 64 wm .. +63 x the three taps of filter row wn >> 1 x 32 ci (half wn & 1)
     const int trow = wn >> 1, hh = wn & 1;
     const int S = a.S, D = FREE ? S - 2 : S - 1, JL = a.JL;
+    constexpr int KW = REFRESH ? 3 : 2;        // the counted wait of a step covers the piece of KW steps on
     const int Wp = d.w_in + 1, Hp = d.h + 1, IMG = Hp * Wp;
     const unsigned lds0 = (unsigned)(uintptr_t)(lptr_t)rsm;
 
@@ -218,10 +219,10 @@ __global__ __launch_bounds__(768, 3) void conv_wgrad_roll_kernel(const RollArgs 
     if constexpr (!NODMA) {
         const int n_pro = dz_wave ? min(D, nsteps) : min(JL + D, nsteps + JL);
         for (int k = 0; k < n_pro; ++k) issue();
-        wr_wait_keep(max(0, n_pro - (dz_wave ? 2 : JL + 2)));       // steps 0 and 1 (x steps 0 .. JL + 1) have landed
+        wr_wait_keep(max(0, n_pro - (dz_wave ? KW : JL + KW)));       // steps 0 .. KW - 1 (x steps 0 .. JL + KW - 1) have landed
     }
     YH_WR_BARRIER();
-    if constexpr (!FREE) for (int k = 0; k < grp; ++k) YH_WR_BARRIER();      // stagger
+    if constexpr (!FREE && !REFRESH) for (int k = 0; k < grp; ++k) YH_WR_BARRIER();      // stagger (ORDER 0 / 1: whole barrier intervals)
     int st_read = 0;
     if constexpr (TIMING) tlast = __builtin_amdgcn_s_memtime();
     // SPLIT form.  Measured on the form below (profiles/r05_wgrad_roll_segments.txt): with the LDS-DMA ablated its LOAD segment - 20
@@ -245,7 +246,96 @@ __global__ __launch_bounds__(768, 3) void conv_wgrad_roll_kernel(const RollArgs 
     //     of x step s - 2, whose last readers (groups 1, 2: R2(s - 2) / R1(s - 2)) ran in interval s - 2;
     //   * the wait in R2(s) - groups 1, 2: interval s - covers the piece of step s + 2 and is published by barrier s + 1; the first
     //     read of step s + 2 is group 0's R1(s + 2) in interval s + 1.
-    if constexpr (FREE) {
+    // REFRESH form (ORDER 3).  tools/probe/run_lds_probe.py: twelve waves that each do 20 fragment reads THEN 24 MFMAs per trip need
+    // 1530 cycles per trip, the same waves with every fragment re-read right after its last MFMA of the trip 1382 - a segment of 8-byte
+    // LDS reads is issue-bound per wave (one per ~24 cycles) and its latency is dead time for that wave, spread between the MFMAs it
+    // is not.  So a wave holds ONE set of fragments and refreshes it in place: x fragment pair j (tap column j) is dead after the four
+    // MFMAs of column j and is re-read for step s + 1 at once, dz fragment i after MFMA (i, last column).  No LOAD segment is left:
+    // a step is C_0 .. C_5 (4 MFMAs + refresh reads each) and ST (this wave's LDS-DMA piece, the counted wait).  One barrier per step, at
+    // a group-dependent point of the stream (after C_1 / C_3 / C_5) so that the three waves of a SIMD stay a third of a step apart.
+    // Hazards (b_s = barrier of step s; interval I_s ends with it): step s + 1's data is read in C(s), i.e. in I_s or I_(s+1), and
+    // every such read has RETURNED at the lgkmcnt(0) that opens step s + 1, before b_(s+1); the wait in ST(s') (in I_(s'+1)) covers the
+    // piece of step s' + 3, published by b_(s'+1), first read in C_0(s' + 2) in I_(s'+2); the piece of step s' + D (D = S - 1) issued in
+    // ST(s') overwrites the stage of step s' - 1, whose reads returned before b_(s'-1).
+    if constexpr (REFRESH) {
+        wr_v2i ra[4][2], rb[6][2];
+        const int g3 = wave >> 2;
+        // fragments of step 0 (landed and published by the prologue), addresses rolled to step 1
+        {
+            const unsigned stage = lds0 + WR_XRING;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                ra[i][0] = wr_read_tr16<0>(stage + (a_addr0 ^ (i << 5)));
+                ra[i][1] = wr_read_tr16<1024>(stage + (a_addr0 ^ (i << 5)));
+            }
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int sx = 0; sx < 3; ++sx) {
+                    rb[2 * sx][h] = wr_read_tr16<0>(b_abs[sx][h]);
+                    rb[2 * sx + 1][h] = wr_read_tr16<0>(b_abs[sx][h] ^ 32);
+                }
+        }
+        st_read = 1 == S ? 0 : 1;
+        for (int s = 0; s < nsteps; ++s) {
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+v"(ra[0][0]), "+v"(ra[0][1]), "+v"(ra[1][0]), "+v"(ra[1][1]), "+v"(ra[2][0]), "+v"(ra[2][1]),
+                           "+v"(ra[3][0]), "+v"(ra[3][1]), "+v"(rb[0][0]), "+v"(rb[0][1]), "+v"(rb[1][0]), "+v"(rb[1][1]),
+                           "+v"(rb[2][0]), "+v"(rb[2][1]), "+v"(rb[3][0]), "+v"(rb[3][1]), "+v"(rb[4][0]), "+v"(rb[4][1]),
+                           "+v"(rb[5][0]), "+v"(rb[5][1])
+                         :
+                         : "memory");
+            const unsigned stage = lds0 + WR_XRING + st_read * WR_ABYTES;      // dz of step s + 1
+            typedef int v4i __attribute__((ext_vector_type(4)));
+            f16x8 fa[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const v4i t = {ra[i][0][0], ra[i][0][1], ra[i][1][0], ra[i][1][1]};
+                fa[i] = __builtin_bit_cast(f16x8, t);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int sx = 0; sx < 3; ++sx) {
+#pragma unroll
+                for (int bq = 0; bq < 2; ++bq) {
+                    const int j = 2 * sx + bq;
+                    const v4i tb = {rb[j][0][0], rb[j][0][1], rb[j][1][0], rb[j][1][1]};
+                    const f16x8 fb = __builtin_bit_cast(f16x8, tb);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        if constexpr (!NOCOMPUTE) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[i], fb, acc[i][j], 0, 0, 0);
+                        if (j == 5) {           // dz fragment i is dead: refresh it from the stage of step s + 1
+                            __builtin_amdgcn_sched_barrier(0);
+                            ra[i][0] = wr_read_tr16<0>(stage + (a_addr0 ^ (i << 5)));
+                            ra[i][1] = wr_read_tr16<1024>(stage + (a_addr0 ^ (i << 5)));
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    // x fragment j is dead: refresh it (step s + 1's rows; block bq of tap column sx; the pair's addresses roll
+                    // here, between the MFMAs, not in a block of their own)
+                    if (bq == 0) {
+                        b_abs[sx][0] = lds0 + ((b_abs[sx][0] + roll_add) & (WR_XRING - 1));
+                        b_abs[sx][1] = lds0 + ((b_abs[sx][1] + roll_add) & (WR_XRING - 1));
+                    }
+                    rb[j][0] = wr_read_tr16<0>(b_abs[sx][0] ^ (32 * bq));
+                    rb[j][1] = wr_read_tr16<0>(b_abs[sx][1] ^ (32 * bq));
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (bq == 1 && g3 == sx) YH_WR_BARRIER();       // this group's one barrier of the step: after C_1 / C_3 / C_5
+                    if constexpr (!NODMA) {
+                        // this wave's LDS-DMA piece of step s + D, behind column 2 (after group 0's barrier point, so that every
+                        // group issues it after ITS barrier of the step ... no: groups 1, 2 issue it before theirs - the stage it
+                        // overwrites was last read two steps ago either way, see the hazard note above)
+                        if (j == 2 && s + D < nsteps) issue();
+                    }
+                }
+            }
+            st_read = st_read + 1 == S ? 0 : st_read + 1;
+            // ---- this wave's piece of step s + 3 must have landed (its piece of step s + D was issued behind column 2)
+            if constexpr (!NODMA) wr_wait_keep(min(D - 3, max(0, nsteps - 4 - s)));
+        }
+    } else if constexpr (FREE) {
         wr_v2i ra[4][2], rb[6][2];
         auto seg_r1 = [&]() {
 #pragma unroll
@@ -481,7 +571,7 @@ __global__ __launch_bounds__(768, 3) void conv_wgrad_roll_kernel(const RollArgs 
         YH_WR_BARRIER();
         YH_WR_STAMP(5);      // barrier 3
     }
-    if constexpr (!FREE) for (int k = grp; k < 2; ++k) YH_WR_BARRIER();      // every wave has executed the same number of barriers
+    if constexpr (!FREE && !REFRESH) for (int k = grp; k < 2; ++k) YH_WR_BARRIER();      // every wave has executed the same number of barriers
 #undef YH_WR_BARRIER
 
     if constexpr (TIMING) {
@@ -607,7 +697,7 @@ bool wgrad_roll_geometry(const yh_wgrad_desc* d, RollArgs* pa, int* psplits, siz
     // steps (48 KB) in flight are the fastest on every layer of YOLOv3-608 - 8 and 10 lose 1 - 5 %: a CU is served ~11 B / clk of LDS-DMA
     // however deep its queue is (tools/probe/run_probe.py), more pieces in flight only lengthen the in-order queue each wave waits on
     const int s_max = 16 - JL < 10 ? 16 - JL : 10;
-    int S = s_max < 6 ? s_max : 6;
+    int S = s_max < 8 ? s_max : 8;
     { const char* e = getenv("YH_WGRAD_ROLL_STAGES"); if (e && atoi(e) >= 4 && atoi(e) <= s_max) S = atoi(e); }   // A/B knob
     if (S < 4) return false;
     const long Q = (long)d->n * (d->h + 1) * Wp;
@@ -627,7 +717,7 @@ bool wgrad_roll_geometry(const yh_wgrad_desc* d, RollArgs* pa, int* psplits, siz
     // YOLOv3-608 batch 64 (profiles/r05_train_wgrad_mode_ab.txt, r05_wgrad_roll_ab.txt) it beats conv_wgrad_halo_kernel on the layers
     // with FEW tiles and many pixel splits - 76 x 76 128 -> 256 (4 tiles): 0.245 against 0.263 ms, 152 x 152 64 -> 128 (1 tile; the
     // round-3 form does not take cout 128): 0.241 against 0.320 - and loses 2 - 3 % on the 38 x 38 / 19 x 19 layers (16 / 64 tiles).
-    if (force < 3 && tiles > 8 && d->cout % 256 == 0) return false;
+    (void)force;      // (round 5, ORDER 2: layers with > 8 tiles stayed on the round-3 kernel; ORDER 3 is faster on every shape)
     int splits = d->splits > 0 ? d->splits : 256 / tiles;          // one workgroup per CU
     {
         const char* e = getenv("YH_WGRAD_HALO_WGS");       // A/B and test knob: total workgroups aimed for
@@ -662,10 +752,10 @@ int launch_wgrad_roll(const yh_wgrad_desc* d, hipStream_t st) {
     const int abl = abl_env ? atoi(abl_env) : 0;
     {
         const char* order_env = getenv("YH_WGRAD_ROLL_ORDER");     // A/B knob: 0 = one read interval, 1 = split reads, 2 = one barrier per step
-        const int order = order_env ? atoi(order_env) : 2;
+        const int order = order_env ? atoi(order_env) : 3;      // 3 = fragments refreshed between the MFMAs (no LOAD segment)
         { const char* e = getenv("YH_WGRAD_ROLL_PRIO"); a.prio = e ? atoi(e) : 0; }   // s_setprio 1 around the MFMAs measured 1 - 3 % slower
-        auto kern = order == 2 ? conv_wgrad_roll_kernel<0, 2> : order == 1 ? conv_wgrad_roll_kernel<0, 1> : conv_wgrad_roll_kernel<0, 0>;
-        if (abl == 1) kern = order == 2 ? conv_wgrad_roll_kernel<1, 2> : order == 1 ? conv_wgrad_roll_kernel<1, 1> : conv_wgrad_roll_kernel<1, 0>;
+        auto kern = order == 3 ? conv_wgrad_roll_kernel<0, 3> : order == 2 ? conv_wgrad_roll_kernel<0, 2> : order == 1 ? conv_wgrad_roll_kernel<0, 1> : conv_wgrad_roll_kernel<0, 0>;
+        if (abl == 1) kern = order == 3 ? conv_wgrad_roll_kernel<1, 3> : order == 2 ? conv_wgrad_roll_kernel<1, 2> : order == 1 ? conv_wgrad_roll_kernel<1, 1> : conv_wgrad_roll_kernel<1, 0>;
         if (abl == 2) kern = order == 2 ? conv_wgrad_roll_kernel<2, 2> : conv_wgrad_roll_kernel<2, 0>;
 #define YH_WR_PICK(A) if (abl == A) kern = order == 1 ? conv_wgrad_roll_kernel<A, 1> : conv_wgrad_roll_kernel<A, 0>
         YH_WR_PICK(8); YH_WR_PICK(9); YH_WR_PICK(10); YH_WR_PICK(12);

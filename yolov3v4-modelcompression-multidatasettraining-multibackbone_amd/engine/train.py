@@ -41,6 +41,12 @@ from .hiplib import (ConvDesc, StemDesc, CopyDesc, AddDesc, BnStatsDesc, BnFinal
                      DwDgradDesc, SeBwdDesc)
 from .plan import DarknetEngine, ALIGN_C, _round_up
 
+# stride-2 data gradients with at most this many input channels run as ONE four-phase pass (ups = 4: 16 tap-GEMMs instead of 9, dz read
+# once); above it the four parity-phase launches.  Measured (profiles/r05_fused_dgrad_ab.txt): 64 input channels (152^2, 128 -> 64) 0.642 ms
+# fused against 0.704 in four launches; 128 channels (76^2) 0.480 against 0.441 - the 78 % of extra tap work outweighs the dz re-reads from
+# there on.  A/B knob: YOLO_HIP_FUSED_DGRAD_MAX
+_FUSED_DGRAD_MAX_CIN = int(os.environ.get('YOLO_HIP_FUSED_DGRAD_MAX', '64'))
+
 SLOT_INPUT = 0
 SLOT_WS = 1          # shared fp32 workspace of the two-stage reductions
 SLOT_WS2 = 63        # the same for the ops of the side lane (weight gradients): the two lanes run concurrently
@@ -313,7 +319,7 @@ class TrainEngine(DarknetEngine):
                 if self._dgrad_fused_into_stem(values, v):
                     v.tpack['stem_fused'] = True
                     v.tpack['wt'] = torch.empty(dm_pad * taps * cout_k, device=dev, dtype=self.dtype)
-                elif v.stride == 2 and 16 <= v.src.c_phys <= 32 and v.src.c_phys % 4 == 0:
+                elif v.stride == 2 and 16 <= v.src.c_phys <= _FUSED_DGRAD_MAX_CIN and v.src.c_phys % 4 == 0:
                     # few input channels: the data gradient is bound by reading dz and writing dx, so all four parity phases
                     # run as ONE 2x2-tap GEMM with 4 * cin rows (16 tap-GEMMs instead of 9, but dz is read once, not four
                     # times, and each workgroup writes whole rows of dx): yh_conv2d_fwd ups = 4

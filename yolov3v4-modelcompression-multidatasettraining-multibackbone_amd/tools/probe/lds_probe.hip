@@ -36,7 +36,7 @@ __global__ __launch_bounds__(768) void lds_probe_kernel(const LdsArgs a) {
     for (int k = 0; k < 20; ++k) r[k] = v2i{lane, k};
     __syncthreads();
     const unsigned long long t0 = __builtin_amdgcn_s_memtime();
-    for (int it = 0; it < a.iters; ++it) {
+    for (int it = 0; it < (a.mfma == 2 ? 0 : a.iters); ++it) {
         if constexpr (KIND == 2) {
 #pragma unroll
             for (int k = 0; k < 10; ++k) {
@@ -67,6 +67,48 @@ __global__ __launch_bounds__(768) void lds_probe_kernel(const LdsArgs a) {
             }
         }
         for (int k = 0; k < 10; ++k) addr[k] = (addr[k] + 4096) & 0xffff;
+    }
+    if (a.mfma == 2) {
+        // "rolling refresh": the wave tile of conv_wgrad_roll (4 A x 6 B fragments, 24 MFMAs) with every fragment re-read right after
+        // its last MFMA of the step - B fragment j after the four MFMAs of column j, A fragment i after MFMA (i, 5) - so that the 20
+        // reads are spread between the MFMAs instead of forming a segment of their own; r[0..7] = A (2 reads each), r[8..19] = B
+        f32x4 c[4][6];
+        for (int i = 0; i < 4; ++i) for (int j = 0; j < 6; ++j) c[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const unsigned long long u0 = __builtin_amdgcn_s_memtime();
+        for (int it = 0; it < a.iters; ++it) {
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7]), "+v"(r[8]), "+v"(r[9]),
+                           "+v"(r[10]), "+v"(r[11]), "+v"(r[12]), "+v"(r[13]), "+v"(r[14]), "+v"(r[15]), "+v"(r[16]), "+v"(r[17]), "+v"(r[18]), "+v"(r[19])
+                         :: "memory");
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                const v4i tb = {r[8 + 2 * j][0], r[8 + 2 * j][1], r[9 + 2 * j][0], r[9 + 2 * j][1]};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const v4i ta = {r[2 * i][0], r[2 * i][1], r[2 * i + 1][0], r[2 * i + 1][1]};
+                    c[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, ta), __builtin_bit_cast(f16x8, tb), c[i][j], 0, 0, 0);
+                    if (j == 5) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        rd<KIND == 2 ? 1 : KIND>(addr[i], r[2 * i]);
+                        rd<KIND == 2 ? 1 : KIND>(addr[i] ^ 32, r[2 * i + 1]);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                addr[4 + j] = (addr[4 + j] + 4096) & 0xffff;
+                rd<KIND == 2 ? 1 : KIND>(addr[4 + j], r[8 + 2 * j]);
+                rd<KIND == 2 ? 1 : KIND>(addr[4 + j] ^ 32, r[9 + 2 * j]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            for (int k = 0; k < 4; ++k) addr[k] = (addr[k] + 4096) & 0xffff;
+        }
+        __syncthreads();
+        const unsigned long long u1 = __builtin_amdgcn_s_memtime();
+        if (threadIdx.x == 0) a.out[blockIdx.x] = u1 - u0;
+        float s2 = 0;
+        for (int i = 0; i < 4; ++i) for (int j = 0; j < 6; ++j) s2 += c[i][j][0] + c[i][j][1] + c[i][j][2] + c[i][j][3];
+        if (s2 == 1.2345f) a.out[gridDim.x + threadIdx.x] = 2;
+        return;
     }
     __syncthreads();
     const unsigned long long t1 = __builtin_amdgcn_s_memtime();

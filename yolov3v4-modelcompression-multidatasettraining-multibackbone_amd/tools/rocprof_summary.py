@@ -46,6 +46,10 @@ def short(name):
     m = re.match(r'(?:void yh::conv3x3_stream_kernel<(signed char|_Float16),|_ZN2yh21conv3x3_stream_kernelI(DF16_|a))', name)
     if m:
         return 'conv3x3_stream<%s>' % ('i8' if (m.group(1) == 'signed char' or m.group(2) == 'a') else 'f16')
+    if 'conv_wgrad_roll_kernel' in name:
+        return 'conv_wgrad_roll'
+    if 'wgrad_roll_reduce' in name:
+        return 'wgrad_roll_reduce'
     if 'conv_wgrad_halo_kernel' in name:
         return 'conv_wgrad_halo'
     if 'wgrad_halo_reduce_kernel' in name:
