@@ -174,6 +174,16 @@ template <int T9, int LB> struct HppAllow {
     static constexpr int value = T9 == 8 ? 2 : 2 + in(T9 - 2) + in(T9 - 1) + in(T9);
 };
 
+// The same for the REFRESH form of the K loop (KFORM 2), whose waits cover the weight tile of step s + 2: group 0 waits at the end of
+// tap t (behind it in the queue: the halo piece of tap t - 1, the weight tile of step s + 3, the halo piece of tap t), group 1 before
+// its mid-step barrier (behind it: the halo piece of tap t - 1 and the tile of step s + 3).  From tap 7 on every halo piece must have
+// landed (the next chunk's image is first read in tap 8's second phase).
+template <int T9, int LB> struct HppAllow2 {
+    static constexpr int in(int t) { return (t >= 0 && t < LB) ? 1 : 0; }
+    static constexpr int end = T9 >= 7 ? 1 : 1 + in(T9 - 1) + in(T9);
+    static constexpr int mid = T9 >= 7 ? 1 : 1 + in(T9 - 1);
+};
+
 // ROLE = how the LDS-DMA issue is shared out.  0: every wave issues one 16-row weight piece per K step and one halo piece per tap
 // (taps 0 .. LB-1).  1: the waves of group 0 issue the weight tiles (two pieces each per step), the waves of group 1 the halo images
 // (two pieces each per tap in taps 0 .. 5, offsets from a table in LDS).  A wave's LDS-DMA returns are counted IN ORDER, so with
@@ -185,9 +195,10 @@ template <int T9, int LB> struct HppAllow {
 struct HppDiv { unsigned m_img, s_img, m_wp, s_wp; };
 __device__ __forceinline__ int hpp_div(int n, unsigned m, unsigned s) { return (int)(__umulhi((unsigned)n, m) >> s); }
 
-template <typename T, int LB, int ROLE, bool ONEBAR>
+template <typename T, int LB, int ROLE, int KFORM>
 __global__ __launch_bounds__(512, 2) void conv3x3_hpp_kernel(const ConvArgs a, const int rows_hp, const int hbufs, const HppDiv dv) {
-    // ONEBAR: ONE barrier per K step instead of four (round 5).  The instruction stream stays what it is - X loads, X MFMAs, Y loads, Y
+    constexpr bool ONEBAR = KFORM == 1, REFRESH = KFORM == 2;
+    // KFORM 1 (ONEBAR): ONE barrier per K step instead of four (round 5).  The instruction stream stays what it is - X loads, X MFMAs, Y loads, Y
     // MFMAs - and so does the stagger of the two wave groups, but it is no longer enforced segment by segment: group 1's barrier of a
     // step falls after its Y loads, group 0's after its Y MFMAs, so between two barriers group 0 runs XL XM YL YM of step s while group
     // 1 runs YM of step s - 1 and XL XM YL of step s.  Every barrier is a round trip of 8 waves during which a SIMD's matrix pipe
@@ -375,6 +386,87 @@ __global__ __launch_bounds__(512, 2) void conv3x3_hpp_kernel(const ConvArgs a, c
         for (int i = 0; i < 6; ++i) issue_h2(0, 0, i);
         wait_vmcnt<0>();
     }
+    if constexpr (REFRESH) {
+        // ---- REFRESH form (round 5).  The weight-gradient kernel gained 8 - 16 % when its fragment reads stopped being a segment of
+        // their own (conv_wgrad_roll.hip ORDER 3; tools/probe/run_lds_probe.py): a wave holds ONE set of fragments and re-reads each
+        // right after its last MFMA.  Here: fa = the four weight fragments of a 64-channel half, fb = the four pixel fragments of the tap.
+        //   X (channels 0 .. 63), row-major: fa[i] is dead after its four MFMAs -> refreshed with the SAME step's second half;
+        //   Y (channels 64 .. 127), column-major: fb[j] is dead after column j -> refreshed with the next tap's (at tap 8: the next chunk's
+        //   image) rows; fa[i] after MFMA (i, 3) -> the next step's first half.
+        // 12 reads between 32 MFMAs, no LOAD segment, ONE barrier per step: group 0's at the end of the step, group 1's after X, each
+        // preceded by that group's counted wait for the weight tile of step s + 2 (HppAllow2).  Hazards: the tile of step s + 3 is issued at
+        // the start of step s into the stage last read in X(s - 1), which precedes barrier s - 1 for both groups; stage s + 1 is read from
+        // Y(s) on, after barrier s - 1, which every wave reaches with its share of tile s + 1 landed.
+        static_assert(!REFRESH || ROLE == 0, "the refresh form shares the LDS-DMA issue among all waves");
+        wait_vmcnt<1>();       // (the shared prologue above left the tiles of steps 1 and 2 in flight) step 1's is read from Y(0) on
+        YH_HPP_BARRIER();
+        read_a(Aring, 0);
+        read_b(Hbuf, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        int s = 0, st_r = 0, st_w = 3, ptap = 3, pkc = 0;
+        for (int c = 0; c < nchunks; ++c) {
+            const bool more_h = LB <= 7 ? c + 1 < nchunks : false;
+            const u32x4* const hb = Hbuf + (c & (hbufs - 1)) * (rows_hp * 4);
+            const u32x4* const hb_next = Hbuf + ((c + 1) & (hbufs - 1)) * (rows_hp * 4);
+            const int nbuf = (c + 1) & 1, nkc = (c + 1) * BK;
+            static_for<9>([&](auto tc) {
+                constexpr int t = decltype(tc)::value;
+                const u32x4* const st = Aring + st_r * A_CELLS;
+                const u32x4* const stn = Aring + ((st_r + 1) & (SA - 1)) * A_CELLS;
+                const u32x4* const hbn = t < 8 ? hb : hb_next;
+                const int rt_next = r16 + (t < 8 ? ((t + 1) / 3) * Wp + ((t + 1) % 3) : 0);
+                const int b_next = (wave * 64 + rt_next) * 4 + (kq ^ (((rt_next >> 2) & 1) << 1));
+                if (s + 3 < nk) issue_a(st_w, ptap, pkc);
+                __builtin_amdgcn_sched_barrier(0);
+                // ---- X
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[i][j] = HppMma<T>::mma(fa[i], fb[j], acc[i][j]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    u32x4 v = st[(64 + i * 16) * 4 + a_off];
+                    fa[i] = *reinterpret_cast<frag_t*>(&v);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (group == 1) {
+                    if (more_h) wait_vmcnt<HppAllow2<t, LB>::mid>();
+                    else if (s + 3 < nk) wait_vmcnt<1>();
+                    else wait_vmcnt<0>();
+                    YH_HPP_BARRIER();
+                }
+                if constexpr (t < LB) { if (more_h) issue_h(nbuf, nkc, tc); }
+                __builtin_amdgcn_sched_barrier(0);
+                // ---- Y
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        acc[4 + i][j] = HppMma<T>::mma(fa[i], fb[j], acc[4 + i][j]);
+                        if (j == 3) {
+                            __builtin_amdgcn_sched_barrier(0);
+                            u32x4 v = stn[(i * 16) * 4 + a_off];
+                            fa[i] = *reinterpret_cast<frag_t*>(&v);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    u32x4 v = hbn[b_next + j * 64];
+                    fb[j] = *reinterpret_cast<frag_t*>(&v);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (group == 0) {
+                    if (more_h) wait_vmcnt<HppAllow2<t, LB>::end>();
+                    else if (s + 3 < nk) wait_vmcnt<1>();
+                    else wait_vmcnt<0>();
+                    YH_HPP_BARRIER();
+                }
+                ++s;
+                st_r = (st_r + 1) & (SA - 1);
+                st_w = (st_w + 1) & (SA - 1);
+                if (++ptap == 9) { ptap = 0; pkc += BK; }
+            });
+        }
+    } else {
     YH_HPP_BARRIER();
     if (!ONEBAR && group == 1) YH_HPP_BARRIER();   // stagger: group 1 runs one barrier interval behind group 0
     int s = 0;                   // K step being computed
@@ -420,6 +512,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_hpp_kernel(const ConvArgs a, c
         });
     }
     if (!ONEBAR && group == 0) YH_HPP_BARRIER();   // matches group 1's extra barrier at the start
+    }
 #undef YH_HPP_PHASE
 #undef YH_HPP_BARRIER
 
@@ -725,23 +818,36 @@ bool hpp_geometry(int W, int cin_k, int bk, int* rows_hp, int* lb, int* hbufs, s
     return *lds <= 160 * 1024;
 }
 
+// KFORM 2 (fragments refreshed between the MFMAs, no LOAD segment - the form that gained the weight-gradient kernel 8 - 16 %) measured
+// 0 - 8 % SLOWER here, bit-identical outputs (profiles/r05_hpp_refresh_ab.txt: sum over 13 layer shapes 2.76 against 2.64 ms): with a
+// 4-stage weight ring the counted wait may leave ONE tile in flight instead of two, and the 16-byte fragment reads of this kernel were
+// never the issue-bound 8-byte reads of the weight gradient.  Compiled only with -DYH_HPP_REFRESH_AB (YH_HPP_KFORM=2 selects it; its
+// int8 instantiations spill 2 - 4 SGPRs).
 // ONEBAR (one barrier per K step) measured 3 - 10 % SLOWER than the four-barrier form on every 3x3 layer of both models, bit-identical
 // outputs (profiles/r05_hpp_one_barrier_ab.txt: sum over 13 layer shapes 2.96 against 2.78 ms) - unlike the weight-gradient kernel, whose
 // three wave groups gained 3 - 5 % from it: here the enforced alternation of the two groups IS the overlap.  Its instantiations are only
 // compiled into an A/B build (make CXXFLAGS+=-DYH_HPP_ONEBAR_AB; then YH_HPP_BARRIERS=1 selects them); the int8 LB = 7 form runs out of
 // scalar registers with it (8 SGPR spills, tools/check_spills.py) and always keeps four barriers.
-template <typename T, int LBV> static auto hpp_kern(int one_bar) -> void (*)(const ConvArgs, const int, const int, const HppDiv) {
+template <typename T, int LBV> static auto hpp_kern(int kform) -> void (*)(const ConvArgs, const int, const int, const HppDiv) {
 #ifdef YH_HPP_ONEBAR_AB
     if constexpr (!(sizeof(T) == 1 && LBV == 7)) {
-        if (one_bar) return conv3x3_hpp_kernel<T, LBV, 0, true>;
+        if (kform == 1) return conv3x3_hpp_kernel<T, LBV, 0, 1>;
     }
 #endif
-    (void)one_bar;
-    return conv3x3_hpp_kernel<T, LBV, 0, false>;
+#ifdef YH_HPP_REFRESH_AB
+    if constexpr (LBV <= 7) {
+        if (kform == 2) return conv3x3_hpp_kernel<T, LBV, 0, 2>;
+    }
+#endif
+    (void)kform;
+    return conv3x3_hpp_kernel<T, LBV, 0, 0>;
 }
 
 #ifndef YH_HPP_ONE_BARRIER_DEFAULT
 #define YH_HPP_ONE_BARRIER_DEFAULT 0
+#endif
+#ifndef YH_HPP_KFORM_DEFAULT
+#define YH_HPP_KFORM_DEFAULT 0
 #endif
 template <typename T> static int launch_hpp(const ConvArgs& a0, hipStream_t stream) {
     constexpr int BK = Prec<T>::VEC * 4;
@@ -768,6 +874,8 @@ template <typename T> static int launch_hpp(const ConvArgs& a0, hipStream_t stre
     hpp_magic((unsigned)(a.W + 1), &dv.m_wp, &dv.s_wp);
     const char* bar_env = getenv("YH_HPP_BARRIERS");      // A/B knob: 4 = a barrier after every segment (rounds 3 - 4), 1 = one per K step
     const int one_bar = bar_env ? (atoi(bar_env) == 1 ? 1 : 0) : YH_HPP_ONE_BARRIER_DEFAULT;
+    const char* form_env = getenv("YH_HPP_KFORM");        // A/B knob: 0 = LOAD / MFMA segments (rounds 3 - 4), 2 = fragments refreshed between the MFMAs
+    const int kform = one_bar ? 1 : (form_env ? atoi(form_env) : YH_HPP_KFORM_DEFAULT);
     // ROLE 1 (separate weight / halo waves; needs its 48 halo pieces to cover the image) is an A/B form, measured 5 - 9 % SLOWER
     // than the shared form here (profiles/r03_hpp_role_ab.txt) - the weight tiles are L2-resident and short, unlike the dz stream
     // of the weight-gradient kernel where the same separation gained 20 %.  Its instantiations spill 3 registers at the 256 cap,
@@ -775,9 +883,9 @@ template <typename T> static int launch_hpp(const ConvArgs& a0, hipStream_t stre
 #ifdef YH_HPP_ROLE_AB
     static const int role_env = [] { const char* e = getenv("YH_HPP_ROLE"); return e ? atoi(e) : 0; }();
     const int role = (role_env && rows_hp <= 768) ? 1 : 0;
-#define YH_HPP_KERN(LBV) (role ? conv3x3_hpp_kernel<T, LBV, 1, false> : hpp_kern<T, LBV>(one_bar))
+#define YH_HPP_KERN(LBV) (role ? conv3x3_hpp_kernel<T, LBV, 1, 0> : hpp_kern<T, LBV>(kform))
 #else
-#define YH_HPP_KERN(LBV) hpp_kern<T, LBV>(one_bar)
+#define YH_HPP_KERN(LBV) hpp_kern<T, LBV>(kform)
 #endif
 #define YH_HPP_CASE(LBV)                                                                                                       \
     case LBV: {                                                                                                                \
