@@ -479,11 +479,15 @@ int64_t yh_conv2d_wgrad_workspace(const yh_wgrad_desc* d);
  * the same XCD so that all tiles of a split share one L2.  Tuning knobs read from the environment (A/B measurements
  * only): YH_WGRAD_TARGET = workgroups aimed for (negative = round the split count down), YH_WGRAD_BM = 128 / 256 forces the
  * row tile, YH_WGRAD_BN = 256 selects the 8-wave 128 x 256 tile, YH_WGRAD_XCD = 0 restores the plain (tile, split) grid.
- * splits = -1 in the descriptor selects the register-staged fp16 kernel.                                            */
+ * splits = -1 in the descriptor selects the register-staged fp16 kernel.
+ * 3x3 / stride 1 / pad 1 layers with cout % 128 == 0, cin % 64 == 0, 16 <= W <= 190 and a workspace run on the rolling-halo kernel of
+ * round 5 (csrc/conv_wgrad_roll.hip: 128 x [9 x 64] tile per workgroup, fragments refreshed between the MFMAs); knobs: YH_WGRAD_HALO =
+ * 0 (im2col kernels only) / 1 (the round-3 halo kernel) / 2 (default) / 3, YH_WGRAD_ROLL_ORDER = 0..3 (K-loop forms), YH_WGRAD_ROLL_STAGES,
+ * YH_WGRAD_ROLL_MFMA32 = 1 (v_mfma_f32_32x32x16_f16 form), YH_WGRAD_ROLL_REDUCE = 1 (scattering reduce), YH_WGRAD_HALO_WGS.               */
 int yh_conv2d_wgrad(const yh_wgrad_desc* d, void* stream);
 /* Which kernel yh_conv2d_wgrad will launch for this descriptor (host code, no launch; with d->ws == NULL the answer assumes the
- * workspace of yh_conv2d_wgrad_workspace() will be bound, as the training plan does): 90 = conv_wgrad_halo_kernel (3x3 / s1 halo
- * form), 10 * TM + WNW for conv_wgrad_dma_kernel<TM, WNW> (22 = 64-row tile, 42 = 128 x 128, 44 = 128 x 256, 82 = 256 x 128,
+ * workspace of yh_conv2d_wgrad_workspace() will be bound, as the training plan does): 91 = conv_wgrad_roll_kernel (3x3 / s1 rolling-halo
+ * form, round 5), 90 = conv_wgrad_halo_kernel (3x3 / s1 halo form, round 3), 10 * TM + WNW for conv_wgrad_dma_kernel<TM, WNW> (22 = 64-row tile, 42 = 128 x 128, 44 = 128 x 256, 82 = 256 x 128,
  * 84 = 256 x 256), 1 = the register-staged kernel (fp32, or splits == -1).  bench.py uses it to name the dominant kernel of
  * the weight-gradient class and to attach that kernel's HBM counters.                                   */
 int yh_conv2d_wgrad_kernel(const yh_wgrad_desc* d);

@@ -54,8 +54,8 @@ __device__ __forceinline__ float rcp_fast(float d) {
 // Mish for the int8 (PTQ) epilogues, whose result is rounded onto the activation grid right away.  mish_fast costs ~20 VALU slots
 // where activate()'s form (ocml expf + IEEE divide) costs ~45, and agrees with it to < 1e-6 relative for every float (exhaustive
 // device self-test yh_qmish_selftest, tests/test_gpu_kernels.py).  mish_for_grid returns a value whose ROUNDED grid index is that
-// of the one-rounding form mish_f64 below for every input: where the fast value, scaled by 1 / s_a, lies within 4e-6 relative of a
-// rounding tie (k + 0.5) - a few values in 10^5 - that form decides (rounds 1 - 4: activate()'s float form).  The int8 heads stay bit-equal to the reference on exact frames
+// of activate()'s for every input: where the fast value, scaled by 1 / s_a, lies within 4e-6 relative of a rounding tie (k + 0.5)
+// - a few values in 10^5 - the exact form decides (mish_f64 below: activate()'s float form unless built with -DYH_QMISH_TIE_F64).  The int8 heads stay bit-equal to the reference on exact frames
 // (tests/test_ptq_large.py), which a plain substitution of the fast form did not (measured: a handful of values per tensor flip).
 __device__ __forceinline__ float mish_fast(float v) {
     const float e = exp_fast(fminf(v, 20.f));
@@ -63,16 +63,22 @@ __device__ __forceinline__ float mish_fast(float v) {
     return v > 20.f ? v : v * (n * rcp_fast(n + 2.f));
 }
 // Mish to one rounding: v tanh(softplus(v)) = v n / (n + 2), n = e^v (e^v + 2), evaluated in double and rounded once to float - what
-// the reference's fp32 `x * torch.tanh(F.softplus(x))` (utils/layers.py:148; softplus passes x through above 20) approximates to ~1.5
-// ulp.  Only consulted next to a rounding tie of the activation grid (a few values in 10^5), where it decides the stored int8 value:
-// activate()'s float form (ocml expf + a float divide, ~1e-7 relative from the true value) landed on the other side of a tie from
-// torch's often enough to leave 0.6 - 1.4 % of YOLOv4-640's head values one grid step off after 110 quantised layers (VERDICT r4
-// weak 2); the exactly rounded value disagrees with torch only where torch's own rounding error crosses the tie.
+// the reference's fp32 `x * torch.tanh(F.softplus(x))` (utils/layers.py:148; softplus passes x through above 20) approximates to ~3
+// ulp.  Round 5 tried it as the form that decides a value next to a rounding tie of the activation grid (0.6 - 1.4 %
+// of YOLOv4-640's head values sit one grid step from the CPU modules on the calibrated state) - and measured that it is NOT the lever:
+// the share of differing head values stayed 0.6 % / 1.4 % / 1.2 % to the digit (the flips come from torch's own libm error crossing a
+// tie, which no GPU formula reproduces), while the double-precision branch cost every int8 Mish kernel 17 - 40 registers (pointwise
+// <i8, i8, 2, 1>: 112 -> 152, conv1x1_lds <i8, 4, 1>: 72 -> 96) and YOLOv4-640 int8 3 % of its throughput.  The tie band therefore keeps
+// activate()'s float form (rounds 1 - 4); -DYH_QMISH_TIE_F64 builds the one-rounding form for the record.
 __device__ __forceinline__ float mish_f64(float v) {
+#ifndef YH_QMISH_TIE_F64
+    return activate(v, YH_ACT_MISH, 0.f);
+#else
     if (v > 20.f) return v;
     const double e = exp((double)v);
     const double n = e * (e + 2.0);
     return (float)((double)v * (n / (n + 2.0)));
+#endif
 }
 __device__ __forceinline__ float mish_for_grid(float v, float inv_s) {
     float y = mish_fast(v);

@@ -67,6 +67,9 @@ __device__ __forceinline__ void wr_wait_keep(int keep) {      // counted wait wi
     }
 }
 
+#ifndef YH_WGRAD_ROLL_MFMA32_DEFAULT
+#define YH_WGRAD_ROLL_MFMA32_DEFAULT 0
+#endif
 constexpr int WR_XRING = 65536;     // 512 rows x 128 B
 constexpr int WR_ABYTES = 8192;     // one dz step: 32 rows x 256 B
 
@@ -86,8 +89,9 @@ constexpr int WR_ABYTES = 8192;     // one dz step: 32 rows x 256 B
     } while (0)
 // ORDER: 0 = every fragment read of a step in one barrier interval (LOAD / MFMA / stream), 1 = SPLIT (R1 / R2 / MFMA), 2 = FREE (one
 // barrier per step, see the K loop)
-template <int ABL, int ORDER>
+template <int ABL, int ORDER, bool M32 = false>
 __global__ __launch_bounds__(768, 3) void conv_wgrad_roll_kernel(const RollArgs a) {
+    static_assert(!M32 || ORDER == 3, "the 32x32x16 form exists for the refresh order only");
     constexpr bool SPLIT = ORDER == 1, FREE = ORDER == 2, REFRESH = ORDER == 3;
     constexpr bool TIMING = (ABL & 8) != 0, NODMA = (ABL & 1) != 0, NOCOMPUTE = (ABL & 2) != 0, ZEROSRC = (ABL & 4) != 0;
     unsigned long long tsum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = 0;
@@ -133,11 +137,11 @@ __global__ __launch_bounds__(768, 3) void conv_wgrad_roll_kernel(const RollArgs 
         int rowl, p;
         if (dz_wave) {
             rowl = 4 * wave + (lane >> 4);
-            cofs = co0 + (((lane & 15) ^ wr_swz_dz(rowl)) << 3);
+            cofs = co0 + (((lane & 15) ^ (M32 ? (rowl & 3) << 2 : wr_swz_dz(rowl))) << 3);
             p = 32 * s0 + rowl;
         } else {
             rowl = 8 * (wave - 8) + (lane >> 3);
-            cofs = ci0 + (((lane & 7) ^ (wr_swz_x(rowl) << 1)) << 3);
+            cofs = ci0 + (((lane & 7) ^ ((M32 ? ((rowl >> 1) & 1) << 1 : wr_swz_x(rowl)) << 1)) << 3);
             p = 32 * s0 - Wp - 1 + rowl;
         }
         const int pp = p + IMG;                      // p >= -(W + 2) > -IMG
@@ -257,7 +261,128 @@ __global__ __launch_bounds__(768, 3) void conv_wgrad_roll_kernel(const RollArgs 
     // every such read has RETURNED at the lgkmcnt(0) that opens step s + 1, before b_(s+1); the wait in ST(s') (in I_(s'+1)) covers the
     // piece of step s' + 3, published by b_(s'+1), first read in C_0(s' + 2) in I_(s'+2); the piece of step s' + D (D = S - 1) issued in
     // ST(s') overwrites the stage of step s' - 1, whose reads returned before b_(s'-1).
-    if constexpr (REFRESH) {
+    if constexpr (REFRESH && M32) {
+        // ---- v_mfma_f32_32x32x16_f16 form of the refresh order (VERDICT r4 item 1 / 3 i: never tried in csrc/ before round 5).  Same wave
+        // tile (64 co x [3 taps x 32 ci]), same 20 fragment reads per step, 12 MFMAs of 32 cycles instead of 24 of 16: half the MFMA
+        // issues and the shape the pipe sustains best (MI355X_MICROARCH.md: 2382 against 2075 TFLOP/s in the micro-benchmark).  Operand
+        // layout: lane l holds row / column l & 31 and the 8 K values 8 (l >> 5) ..; a K step of 32 pixels = two MFMAs (pixels 0 - 15,
+        // 16 - 31).  With ds_read_b64_tr_b16 the 16-lane group g reads channel block g & 1 of pixel group g >> 1, so the lanes that share
+        // an LDS cycle (g = 0, 1) read TWO adjacent 32-byte columns of FOUR rows: dz rows (256 B, all banks) are permuted by the 64-byte
+        // column pair, (r & 3) << 1 on the 32-byte column index; x rows (128 B, half the banks; rows r and r + 2 share them) by bit 1 of r
+        // on bit 1 of the column index - the LDS-DMA side of this instantiation permutes its source units the same way.
+        typedef float f32x16 __attribute__((ext_vector_type(16)));
+        typedef int v4i __attribute__((ext_vector_type(4)));
+        const int g3 = wave >> 2;
+        const int cblk = g & 1, pg = g >> 1;
+        const int row0 = 8 * pg + (q >> 2);
+        unsigned a32, b32[3][2];
+        {
+            const int cha = wm * 64 + 16 * cblk + 4 * (q & 3);
+            a32 = row0 * 256 + ((((cha >> 3) ^ ((row0 & 3) << 2)) << 4) | ((cha & 7) * 2));      // co block m: ^ (m << 6); pixel half: + 4096; h: + 1024
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int sx = 0; sx < 3; ++sx) {
+                    const int xr = row0 + 4 * h + trow * Wp + sx;
+                    b32[sx][h] = lds0 + (unsigned)((xr & 511) * 128 + (((2 * hh + cblk) ^ (((xr >> 1) & 1) << 1)) << 5) + (q & 3) * 8);
+                }
+        }
+        const unsigned half_add = 2048u - lds0;       // the second pixel half: 16 rows further in the x ring (wraps with it)
+        f32x16 c32[2][3];
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int sx = 0; sx < 3; ++sx)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) c32[m][sx][e] = 0.f;
+        wr_v2i pa[2][2][2], pb[3][2][2];       // [co block / tap column][pixel half][h]
+        auto read_pa = [&](int m, unsigned stage) {
+            const unsigned ad = stage + (a32 ^ (m << 6));
+            pa[m][0][0] = wr_read_tr16<0>(ad);
+            pa[m][0][1] = wr_read_tr16<1024>(ad);
+            pa[m][1][0] = wr_read_tr16<4096>(ad);
+            pa[m][1][1] = wr_read_tr16<5120>(ad);
+        };
+        auto read_pb = [&](int sx) {
+            pb[sx][0][0] = wr_read_tr16<0>(b32[sx][0]);
+            pb[sx][0][1] = wr_read_tr16<0>(b32[sx][1]);
+            pb[sx][1][0] = wr_read_tr16<0>(lds0 + ((b32[sx][0] + half_add) & (WR_XRING - 1)));
+            pb[sx][1][1] = wr_read_tr16<0>(lds0 + ((b32[sx][1] + half_add) & (WR_XRING - 1)));
+        };
+        read_pa(0, lds0 + WR_XRING);
+        read_pa(1, lds0 + WR_XRING);
+#pragma unroll
+        for (int sx = 0; sx < 3; ++sx) read_pb(sx);
+        st_read = 1 == S ? 0 : 1;
+        for (int s = 0; s < nsteps; ++s) {
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+v"(pa[0][0][0]), "+v"(pa[0][0][1]), "+v"(pa[0][1][0]), "+v"(pa[0][1][1]), "+v"(pa[1][0][0]), "+v"(pa[1][0][1]),
+                           "+v"(pa[1][1][0]), "+v"(pa[1][1][1]), "+v"(pb[0][0][0]), "+v"(pb[0][0][1]), "+v"(pb[0][1][0]), "+v"(pb[0][1][1]),
+                           "+v"(pb[1][0][0]), "+v"(pb[1][0][1]), "+v"(pb[1][1][0]), "+v"(pb[1][1][1]), "+v"(pb[2][0][0]), "+v"(pb[2][0][1]),
+                           "+v"(pb[2][1][0]), "+v"(pb[2][1][1])
+                         :
+                         : "memory");
+            const unsigned stage = lds0 + WR_XRING + st_read * WR_ABYTES;      // dz of step s + 1
+            f16x8 fa[2][2];
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int kh = 0; kh < 2; ++kh) {
+                    const v4i t = {pa[m][kh][0][0], pa[m][kh][0][1], pa[m][kh][1][0], pa[m][kh][1][1]};
+                    fa[m][kh] = __builtin_bit_cast(f16x8, t);
+                }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int sx = 0; sx < 3; ++sx) {
+                f16x8 fb[2];
+#pragma unroll
+                for (int kh = 0; kh < 2; ++kh) {
+                    const v4i t = {pb[sx][kh][0][0], pb[sx][kh][0][1], pb[sx][kh][1][0], pb[sx][kh][1][1]};
+                    fb[kh] = __builtin_bit_cast(f16x8, t);
+                }
+                // the two MFMAs of an accumulator (pixel halves) are kept two issues apart: back to back they serialise on the 64-cycle
+                // accumulator latency (first version: 9 - 13 % slower than the 16x16x32 form, SQ_WAIT_INST_ANY + 20 %)
+                if constexpr (!NOCOMPUTE) {
+                    c32[0][sx] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[0][0], fb[0], c32[0][sx], 0, 0, 0);
+                    c32[1][sx] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[1][0], fb[0], c32[1][sx], 0, 0, 0);
+                    c32[0][sx] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[0][1], fb[1], c32[0][sx], 0, 0, 0);
+                }
+                if (sx == 2) {          // the dz fragments of co block 0 are dead: refresh them from the stage of step s + 1
+                    __builtin_amdgcn_sched_barrier(0);
+                    read_pa(0, stage);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if constexpr (!NOCOMPUTE) c32[1][sx] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[1][1], fb[1], c32[1][sx], 0, 0, 0);
+                if (sx == 2) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    read_pa(1, stage);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                b32[sx][0] = lds0 + ((b32[sx][0] + roll_add) & (WR_XRING - 1));
+                b32[sx][1] = lds0 + ((b32[sx][1] + roll_add) & (WR_XRING - 1));
+                read_pb(sx);
+                __builtin_amdgcn_sched_barrier(0);
+                if (g3 == sx) YH_WR_BARRIER();
+                if constexpr (!NODMA) {
+                    if (sx == 1 && s + D < nsteps) issue();
+                }
+            }
+            st_read = st_read + 1 == S ? 0 : st_read + 1;
+            if constexpr (!NODMA) wr_wait_keep(min(D - 3, max(0, nsteps - 4 - s)));
+        }
+        // partial tile: f32x4 number (m * 3 + tap column) * 4 + rq holds accumulator registers 4 rq .. 4 rq + 3 of that 32 x 32 block
+        f32x4* part32 = reinterpret_cast<f32x4*>(d.ws) + ((long)split_id * tiles + tile_id) * (24 * NT);
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int sx = 0; sx < 3; ++sx)
+#pragma unroll
+                for (int rq = 0; rq < 4; ++rq)
+                    part32[((m * 3 + sx) * 4 + rq) * NT + tid] = f32x4{c32[m][sx][4 * rq], c32[m][sx][4 * rq + 1], c32[m][sx][4 * rq + 2], c32[m][sx][4 * rq + 3]};
+        return;
+    } else if constexpr (REFRESH) {
         wr_v2i ra[4][2], rb[6][2];
         const int g3 = wave >> 2;
         // fragments of step 0 (landed and published by the prologue), addresses rolled to step 1
@@ -631,7 +756,7 @@ __global__ __launch_bounds__(768) void wgrad_roll_reduce_kernel(const RollArgs a
 // wave t (of 9) sums the fragment that holds tap t of the block over the splits (eight independent 16-byte loads in flight per lane,
 // fixed order), the block is transposed through LDS and leaves as 16 rows of 576 contiguous bytes.  Workgroups = tiles x 32 x G; G > 1
 // (few tiles: the 76 x 76 and 152 x 152 layers) splits the pixel splits over G workgroups that meet in row-contiguous atomics.
-template <bool VEC>
+template <bool VEC, bool M32>
 __global__ __launch_bounds__(576) void wgrad_roll_reduce2_kernel(const RollArgs a, int splits, int per_group) {
     constexpr int NT = 768;
     const yh_wgrad_desc& d = a.d;
@@ -642,8 +767,13 @@ __global__ __launch_bounds__(576) void wgrad_roll_reduce2_kernel(const RollArgs 
     const int tid = threadIdx.x, lane = tid & 63;
     const int tap = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int trow = tap / 3, tcol = tap - trow * 3;
-    const int w_src = wm * 6 + trow * 2 + hh, ij = i * 6 + tcol * 2 + b;
-    const f32x4* part = reinterpret_cast<const f32x4*>(d.ws) + ((long)tile * 24 + ij) * NT + w_src * 64 + lane;
+    const int w_src = wm * 6 + trow * 2 + hh;
+    // 16x16x32 partial tiles: fragment (i, 2 tcol + b), lane = (co quad, ci); 32x32x16: block (i >> 1, tcol), register quad 2 (i & 1) +
+    // (lane >> 5) of source lane 32 ((lane >> 4) & 1) + 16 b + (lane & 15), whose four values are rows e + 8 (lane >> 5) + 4 ((lane >> 4) & 1)
+    const int ij = M32 ? ((i >> 1) * 3 + tcol) * 4 + 2 * (i & 1) + (lane >> 5) : i * 6 + tcol * 2 + b;
+    const int src_lane = M32 ? 32 * ((lane >> 4) & 1) + 16 * b + (lane & 15) : lane;
+    const int row_base = M32 ? 8 * (lane >> 5) + 4 * ((lane >> 4) & 1) : 4 * (lane >> 4);
+    const f32x4* part = reinterpret_cast<const f32x4*>(d.ws) + ((long)tile * 24 + ij) * NT + w_src * 64 + src_lane;
     const long stride = (long)tiles * 24 * NT;
     const int sA = blockIdx.y * per_group, sB = min(sA + per_group, splits);
     f32x4 v[8];
@@ -660,7 +790,7 @@ __global__ __launch_bounds__(576) void wgrad_roll_reduce2_kernel(const RollArgs 
     for (int k = 0; sp < sB; ++sp, ++k) v[k & 7] += part[sp * stride];
     const f32x4 sum = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
 #pragma unroll
-    for (int r = 0; r < 4; ++r) blk[4 * (lane >> 4) + r][(lane & 15) * 9 + tap] = sum[r];
+    for (int r = 0; r < 4; ++r) blk[row_base + r][(lane & 15) * 9 + tap] = sum[r];
     __syncthreads();
     const int row = tid / 36, c4 = tid - row * 36;
     const int tm = tile % a.tiles_m, tn = tile / a.tiles_m;
@@ -748,13 +878,18 @@ int launch_wgrad_roll(const yh_wgrad_desc* d, hipStream_t st) {
     if (!wgrad_roll_geometry(d, &a, &splits, &lds)) return YH_EUNSUPPORTED;
     const int tiles = a.tiles_m * a.tiles_n;
     if (!d->ws || d->ws_floats < (int64_t)splits * tiles * 128 * 576) return YH_EUNSUPPORTED;
+    bool m32 = false;
+    const char* red_env0 = getenv("YH_WGRAD_ROLL_REDUCE");
     const char* abl_env = getenv("YH_WGRAD_ROLL_ABL");      // profiling only
     const int abl = abl_env ? atoi(abl_env) : 0;
     {
         const char* order_env = getenv("YH_WGRAD_ROLL_ORDER");     // A/B knob: 0 = one read interval, 1 = split reads, 2 = one barrier per step
         const int order = order_env ? atoi(order_env) : 3;      // 3 = fragments refreshed between the MFMAs (no LOAD segment)
         { const char* e = getenv("YH_WGRAD_ROLL_PRIO"); a.prio = e ? atoi(e) : 0; }   // s_setprio 1 around the MFMAs measured 1 - 3 % slower
-        auto kern = order == 3 ? conv_wgrad_roll_kernel<0, 3> : order == 2 ? conv_wgrad_roll_kernel<0, 2> : order == 1 ? conv_wgrad_roll_kernel<0, 1> : conv_wgrad_roll_kernel<0, 0>;
+        const char* m32_env = getenv("YH_WGRAD_ROLL_MFMA32");       // A/B knob: v_mfma_f32_32x32x16_f16 in the refresh order
+        m32 = order == 3 && abl == 0 && (m32_env ? atoi(m32_env) != 0 : YH_WGRAD_ROLL_MFMA32_DEFAULT != 0) &&
+              !(red_env0 && atoi(red_env0) == 1);
+        auto kern = m32 ? conv_wgrad_roll_kernel<0, 3, true> : order == 3 ? conv_wgrad_roll_kernel<0, 3> : order == 2 ? conv_wgrad_roll_kernel<0, 2> : order == 1 ? conv_wgrad_roll_kernel<0, 1> : conv_wgrad_roll_kernel<0, 0>;
         if (abl == 1) kern = order == 3 ? conv_wgrad_roll_kernel<1, 3> : order == 2 ? conv_wgrad_roll_kernel<1, 2> : order == 1 ? conv_wgrad_roll_kernel<1, 1> : conv_wgrad_roll_kernel<1, 0>;
         if (abl == 2) kern = order == 2 ? conv_wgrad_roll_kernel<2, 2> : conv_wgrad_roll_kernel<2, 0>;
 #define YH_WR_PICK(A) if (abl == A) kern = order == 1 ? conv_wgrad_roll_kernel<A, 1> : conv_wgrad_roll_kernel<A, 0>
@@ -782,8 +917,14 @@ int launch_wgrad_roll(const yh_wgrad_desc* d, hipStream_t st) {
         if (groups < 1) groups = 1;
         const int per_group = (splits + groups - 1) / groups;
         groups = (splits + per_group - 1) / per_group;
-        if (aligned16(d->dw)) hipLaunchKernelGGL(wgrad_roll_reduce2_kernel<true>, dim3(tiles * 32, groups), dim3(576), 0, st, a, splits, per_group);
-        else hipLaunchKernelGGL(wgrad_roll_reduce2_kernel<false>, dim3(tiles * 32, groups), dim3(576), 0, st, a, splits, per_group);
+        const dim3 rg(tiles * 32, groups);
+        if (m32) {
+            if (aligned16(d->dw)) hipLaunchKernelGGL((wgrad_roll_reduce2_kernel<true, true>), rg, dim3(576), 0, st, a, splits, per_group);
+            else hipLaunchKernelGGL((wgrad_roll_reduce2_kernel<false, true>), rg, dim3(576), 0, st, a, splits, per_group);
+        } else {
+            if (aligned16(d->dw)) hipLaunchKernelGGL((wgrad_roll_reduce2_kernel<true, false>), rg, dim3(576), 0, st, a, splits, per_group);
+            else hipLaunchKernelGGL((wgrad_roll_reduce2_kernel<false, false>), rg, dim3(576), 0, st, a, splits, per_group);
+        }
     }
     return check_launch();
 }

@@ -132,7 +132,7 @@ extern "C" int yh_qpool(const yh_pool_desc* d, void* stream) {
 }
 
 // Self-test of the int8 epilogues' Mish (common.h mish_for_grid) over float bit patterns [bits0, bits1): out[0] = values whose grid
-// index round_clamp(mish * inv_s) differs between the one-rounding form (mish_f64) and mish_for_grid, out[1] = max relative difference (as float bits,
+// index round_clamp(mish * inv_s) differs between the exact form (common.h mish_f64: activate()'s unless -DYH_QMISH_TIE_F64) and mish_for_grid, out[1] = max relative difference (as float bits,
 // in units of 1e-9) between the exact form and mish_fast, out[2] = values on which the exact form was consulted.
 __global__ __launch_bounds__(256) void qmish_selftest_kernel(unsigned bits0, unsigned bits1, float inv_s, unsigned long long* out) {
     unsigned long long bad = 0, slow = 0;
