@@ -311,6 +311,45 @@ def test_stem_matches_emulation(libs, code, shape):
     assert (ys[0] - ys[1]).abs().max().item() <= tol * (ys[1].abs().max().item() + 1e-6)
 
 
+@pytest.mark.parametrize('shape', [(3, 70, 100, 32), (2, 64, 96, 16), (1, 608, 608, 32)], ids=str)
+def test_split_fp16_first_layer_against_the_fp32_mfma_form(libs, monkeypatch, shape):
+    """Round 5: the first layer of the fp16 / int8 engines contracts fp16 hi + lo halves of its fp32 operands on
+    v_mfma_f32_16x16x32_f16 (csrc/conv_stem_mfma.hip SPLIT; 0.53 -> 0.41 ms at 608 x 608 batch 64) instead of the fp32 MFMA, which
+    stays selectable (YH_STEM_F32=1) and is the form of the fp32 engine.  (a) Frames on the k / 256 grid and weights that are fp16
+    numbers - what the int8 parity tests feed it - give BIT-IDENTICAL stored values; (b) random fp32 frames and weights agree with
+    torch's fp32 convolution as closely as the fp32 form does after the fp16 store (the dropped lo x lo term is 2^-22 relative), and
+    the two forms differ from each other by at most one fp16 ulp on a handful of values."""
+    if DRY:
+        pytest.skip('kernel-only property')
+    lib, _ = libs
+    N, H, W, cout = shape
+    g = torch.Generator().manual_seed(cout + H)
+    cb = torch.randint(-128, 129, (cout,), generator=g).float() / 256.0      # dyadic too: no partial sum of (a) rounds
+
+    def both(x, w):
+        ys = []
+        for f32 in ('1', '0'):
+            monkeypatch.setenv('YH_STEM_F32', f32)
+            ys.append(oh.stem(lib, F16, x.to(GPU), w.to(GPU), cb.to(GPU), None, stride=1, act=1).float().cpu())
+        torch.cuda.synchronize()
+        return ys
+    # (a) dyadic frames, fp16-representable weights: every product and (here) every partial sum exact in both forms
+    x = torch.randint(0, 256, (N, 3, H, W), generator=g).float() / 256.0
+    w = (torch.randint(-64, 65, (cout, 3, 3, 3), generator=g).float() / 256.0)
+    a, b = both(x, w)
+    assert torch.equal(a, b)
+    # (b) arbitrary fp32 operands
+    x = torch.rand(N, 3, H, W, generator=g)
+    w = _rand(g, cout, 3, 3, 3, scale=0.3)
+    a, b = both(x, w)
+    want = torch.nn.functional.leaky_relu(torch.nn.functional.conv2d(x, w, cb, padding=1), 0.1).permute(0, 2, 3, 1)
+    scale = want.abs().max().item()
+    ea, eb = (a[..., :cout] - want).abs().max().item(), (b[..., :cout] - want).abs().max().item()
+    assert eb <= 1e-3 * scale and eb <= 1.05 * ea + 1e-6 * scale, (ea, eb)
+    diff = (a != b).float().mean().item()
+    assert (a - b).abs().max().item() <= 2.0 ** -10 * scale and diff <= 2e-3, ((a - b).abs().max().item(), diff)
+
+
 @pytest.mark.parametrize('code', [F32, F16], ids=['fp32', 'fp16'])
 @pytest.mark.parametrize('shape', [(3, 70, 100, 32, 1), (2, 67, 45, 64, 2), (33, 64, 512, 16, 1), (1, 37, 131, 24, 2), (4, 128, 128, 16, 1), (4, 128, 128, 32, 2)])
 def test_stem_on_the_matrix_cores_with_statistics(libs, code, shape):

@@ -11,7 +11,7 @@ import sys
 
 import conftest
 
-SOURCES = ['conv_halo_pp.hip', 'conv_wgrad.hip', 'conv_wgrad_roll.hip'] + (['conv_igemm_k64.hip'] if os.environ.get('YOLO_TEST_SPILLS_ALL') else [])
+SOURCES = ['conv_halo_pp.hip', 'conv_wgrad.hip', 'conv_wgrad_roll.hip', 'conv_stem_mfma.hip'] + (['conv_igemm_k64.hip'] if os.environ.get('YOLO_TEST_SPILLS_ALL') else [])
 
 
 def test_no_kernel_of_the_dma_ring_sources_uses_scratch():

@@ -93,7 +93,16 @@ template <> struct StemPack<int8_t, 4> {
 // one VALU instruction per 4 cycles): every per-element index is computed ONCE per thread (sample offsets in global memory and in
 // LDS, the lane's store offset), tiles that lie inside the frame take a path without bounds arithmetic, and per-group offsets are
 // compile-time constants that fold into the instructions' immediate fields.
-template <typename T, int NT, int S, int ACT, bool STATS>
+// SPLIT (round 5; fp16 / int8 outputs): the contraction on v_mfma_f32_16x16x32_f16 instead of the fp32 MFMA, which runs at the
+// vector rate (0.52 ms where the bytes need 0.30).  K = 27 padded to 32 = ONE MFMA of 16 cycles where the
+// fp32 form needs seven of 32.  fp32 operands are split into two fp16 halves, v = hi + lo / 2048 with hi = fp16(v) and lo = fp16((v -
+// hi) * 2048) (the scale keeps the residual out of fp16's subnormal range; 2048 is exact): w x = w_hi x_hi + (w_lo x_hi + w_hi x_lo) /
+// 2048 to 2^-21 relative (the lo x lo term is dropped), three MFMAs with fp32 accumulation, the two cross terms in an accumulator of
+// their own that is folded in with one fma.  Every partial product is exact in fp32; where BOTH operands are fp16 numbers - the dyadic
+// frames and power-of-two weight grids of the int8 parity tests - lo is zero and the result equals the fp32 form bit for bit
+// (whenever every partial sum is representable, the same condition as before).  The fp32 engine keeps the fp32 MFMA (YH_STEM_F32=1
+// selects it for every precision).
+template <typename T, int NT, int S, int ACT, bool STATS, bool SPLIT = false>
 __global__ __launch_bounds__(256, 2) void conv_stem_mfma_kernel(const yh_stem_desc d, const int tiles_x, const int tiles_y, const int total_tiles) {
     typedef StemTile<S> G;
     constexpr int CO = 16 * NT, CPL = 4 * NT;          // channels per workgroup pass / per lane
@@ -106,13 +115,24 @@ __global__ __launch_bounds__(256, 2) void conv_stem_mfma_kernel(const yh_stem_de
 
     // resident weight fragments and the lane's bias / first channel
     float a[NT][7];
+    f16x8 ah[NT], al[NT];            // SPLIT: k = 8 g + e, hi and scaled lo halves
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         const int ch = co0 + (NT == 2 ? 8 * (px >> 2) + 4 * t + (px & 3) : px);
 #pragma unroll
         for (int j = 0; j < 7; ++j) {
             const int k = g + 4 * j;
-            a[t][j] = k < 27 ? d.w[k * d.cout_pad + ch] : 0.f;
+            a[t][j] = (!SPLIT && k < 27) ? d.w[k * d.cout_pad + ch] : 0.f;
+        }
+        if constexpr (SPLIT) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int k = 8 * g + e;
+                const float w = k < 27 ? d.w[k * d.cout_pad + ch] : 0.f;
+                const f16 hi = (f16)w;
+                ah[t][e] = hi;
+                al[t][e] = (f16)((w - (float)hi) * 2048.f);
+            }
         }
     }
     const int ch_lane = co0 + CPL * g;                 // the lane's CPL consecutive channels (tile t: ch_lane + 4 t + r)
@@ -129,6 +149,18 @@ __global__ __launch_bounds__(256, 2) void conv_stem_mfma_kernel(const yh_stem_de
         const int tap = k / 3, ci = k - tap * 3;
         laneoff[j] = (k < 27 ? ci * G::PLANE + (tap / 3) * G::PCP + tap % 3 : 0) + wave * 4 * S * G::PCP + px * S;
     }
+    // SPLIT: the lane's eight samples k = 8 g + e (k >= 27: any valid word, its weight is zero); two 16-bit offsets per register in the
+    // form with statistics, which is two registers short otherwise (tools/check_spills.py)
+    constexpr bool PACK8 = SPLIT && STATS;
+    int laneoff8[PACK8 ? 4 : 8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int k = 8 * g + e;
+        const int tap = k / 3, ci = k - tap * 3;
+        const int off = (k < 27 ? ci * G::PLANE + (tap / 3) * G::PCP + tap % 3 : 0) + wave * 4 * S * G::PCP + px * S;
+        if constexpr (PACK8) laneoff8[e >> 1] = (e & 1) ? (laneoff8[e >> 1] | (off << 16)) : off;
+        else laneoff8[e] = off;
+    }
     const float inv_q = sizeof(T) == 1 ? 1.f / d.out_scale : 1.f;
     const bool lane_ch_ok = ch_lane < d.cout;          // cout % 8 == 0: whole lanes
     const int store_lane = (wave * 4 * d.wo + px) * d.ldy + ch_lane;      // element offset of the lane's group 0 inside a tile
@@ -140,7 +172,7 @@ __global__ __launch_bounds__(256, 2) void conv_stem_mfma_kernel(const yh_stem_de
 
     // this thread's staged samples: offsets in LDS and relative to the tile's first sample in global memory.  Held in registers for
     // stride 1 (8 samples per thread); recomputed per tile for stride 2 (26 per thread: the registers are worth more than the VALU)
-    constexpr bool KEEP = S == 1;
+    constexpr bool KEEP = S == 1 && !(SPLIT && STATS);      // (the split form with statistics spilled 17 registers with the 16 offsets resident)
     constexpr int NK = KEEP ? NU : 1;
     int loff[NK], goff[NK];
     auto sample = [&](int u, int& lo, int& go, int tid) {
@@ -202,6 +234,19 @@ __global__ __launch_bounds__(256, 2) void conv_stem_mfma_kernel(const yh_stem_de
             emask = m;
         }
     };
+    // SPLIT: a sample is converted ONCE, when it is written to LDS, into the word fp16(v) | fp16((v - fp16(v)) * 2048) << 16 - a tile's
+    // 1836 samples are read ~18 times each by the fragment gathers, which then only shuffle halves (first version: 40 conversion
+    // instructions per 16-pixel group, 0.49 -> 0.42 ms; the byte floor is 0.30)
+    auto split_word = [&](float v) {
+        if constexpr (SPLIT) {
+            const f16 hi = (f16)v;
+            const f16 lo = (f16)((v - (float)hi) * 2048.f);
+            const unsigned u = (unsigned)__builtin_bit_cast(unsigned short, hi) | ((unsigned)__builtin_bit_cast(unsigned short, lo) << 16);
+            return __uint_as_float(u);
+        } else {
+            return v;
+        }
+    };
     auto commit = [&](int buf, bool inside) {
         float* pw = patch[buf];
         int tl = tid;
@@ -212,7 +257,7 @@ __global__ __launch_bounds__(256, 2) void conv_stem_mfma_kernel(const yh_stem_de
                 int lo, go;
                 if constexpr (KEEP) lo = loff[u];
                 else sample(u, lo, go, tl);
-                if (u < NU - 1 || last_ok) pw[lo] = stage[u];
+                if (u < NU - 1 || last_ok) pw[lo] = split_word(stage[u]);
             }
         } else {
 #pragma unroll
@@ -220,7 +265,7 @@ __global__ __launch_bounds__(256, 2) void conv_stem_mfma_kernel(const yh_stem_de
                 int lo, go;
                 if constexpr (KEEP) lo = loff[u];
                 else sample(u, lo, go, tl);
-                if (u < NU - 1 || last_ok) pw[lo] = (emask >> u) & 1u ? stage[u] : 0.f;
+                if (u < NU - 1 || last_ok) pw[lo] = (emask >> u) & 1u ? split_word(stage[u]) : 0.f;
             }
         }
     };
@@ -244,16 +289,42 @@ __global__ __launch_bounds__(256, 2) void conv_stem_mfma_kernel(const yh_stem_de
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
             const int qlds = (q >> 1) * S * G::PCP + (q & 1) * 16 * S;      // compile-time after unrolling
-            float b[7];
-#pragma unroll
-            for (int j = 0; j < 7; ++j) b[j] = pb[laneoff[j] + qlds];
             f32x4 acc[NT];
+            if constexpr (SPLIT) {
+                unsigned wd[8];
 #pragma unroll
-            for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t][0], b[0], bias[t], 0, 0, 0);
+                for (int e = 0; e < 8; ++e) {
+                    const int lo8 = PACK8 ? ((e & 1) ? (int)((unsigned)laneoff8[e >> 1] >> 16) : (laneoff8[e >> 1] & 0xffff)) : laneoff8[PACK8 ? 0 : e];
+                    wd[e] = __float_as_uint(pb[lo8 + qlds]);
+                }
+                typedef unsigned u32x4s __attribute__((ext_vector_type(4)));
+                u32x4s uh, ul;
 #pragma unroll
-            for (int j = 1; j < 7; ++j)
+                for (int e = 0; e < 4; ++e) {
+                    uh[e] = __builtin_amdgcn_perm(wd[2 * e + 1], wd[2 * e], 0x05040100u);      // the two hi halves
+                    ul[e] = __builtin_amdgcn_perm(wd[2 * e + 1], wd[2 * e], 0x07060302u);      // the two lo halves
+                }
+                const f16x8 bh = __builtin_bit_cast(f16x8, uh), bl = __builtin_bit_cast(f16x8, ul);
+                const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t][j], b[j], acc[t], 0, 0, 0);
+                for (int t = 0; t < NT; ++t) {
+                    const f32x4 hh = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[t], bh, bias[t], 0, 0, 0);
+                    f32x4 cr = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[t], bh, zero, 0, 0, 0);
+                    cr = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[t], bl, cr, 0, 0, 0);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[t][r] = fmaf(cr[r], 1.f / 2048.f, hh[r]);
+                }
+            } else {
+                float b[7];
+#pragma unroll
+                for (int j = 0; j < 7; ++j) b[j] = pb[laneoff[j] + qlds];
+#pragma unroll
+                for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t][0], b[0], bias[t], 0, 0, 0);
+#pragma unroll
+                for (int j = 1; j < 7; ++j)
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t][j], b[j], acc[t], 0, 0, 0);
+            }
             float v[CPL];
 #pragma unroll
             for (int t = 0; t < NT; ++t)
@@ -271,7 +342,7 @@ __global__ __launch_bounds__(256, 2) void conv_stem_mfma_kernel(const yh_stem_de
                         ssq[t][r] = fmaf(s, s, ssq[t][r]);
                     }
             }
-            if (STATS || (q & 1)) __builtin_amdgcn_sched_barrier(0);      // interleave pairs of groups at most (registers)
+            if (STATS || SPLIT || (q & 1)) __builtin_amdgcn_sched_barrier(0);      // interleave pairs of groups at most (registers)
         }
     };
     auto stores = [&](T* ytile, bool whole, int oy0, int ox0) {
@@ -293,6 +364,10 @@ __global__ __launch_bounds__(256, 2) void conv_stem_mfma_kernel(const yh_stem_de
     for (int t = 0; t < NT; ++t) {
 #pragma unroll
         for (int j = 0; j < 7; ++j) asm volatile("" ::"v"(a[t][j]));
+        if constexpr (SPLIT) {
+            asm volatile("" ::"v"(ah[t]));
+            asm volatile("" ::"v"(al[t]));
+        }
         asm volatile("" ::"v"(bias[t]));
     }
     const bool all_channels = co0 + CO <= d.cout;
@@ -365,9 +440,16 @@ typedef void (*stem_kern_t)(const yh_stem_desc, const int, const int, const int)
 // the instantiation a descriptor runs on (nullptr: none)
 static stem_kern_t stem_pick(const yh_stem_desc& d) {
     const bool wide = d.cout_pad % 32 == 0, s1 = d.stride == 1;
-#define YH_STEMK(T, ACT, STATS)                                                                                            \
-    (wide ? (s1 ? (stem_kern_t)conv_stem_mfma_kernel<T, 2, 1, ACT, STATS> : (stem_kern_t)conv_stem_mfma_kernel<T, 2, 2, ACT, STATS>) \
-          : (s1 ? (stem_kern_t)conv_stem_mfma_kernel<T, 1, 1, ACT, STATS> : (stem_kern_t)conv_stem_mfma_kernel<T, 1, 2, ACT, STATS>))
+    const char* f32_env = getenv("YH_STEM_F32");      // A/B knob: the fp32 MFMA form for every precision
+    const bool split = d.dtype != YH_F32 && !(f32_env && atoi(f32_env));
+#define YH_STEMK1(T, ACT, STATS, SP)                                                                                       \
+    (wide ? (s1 ? (stem_kern_t)conv_stem_mfma_kernel<T, 2, 1, ACT, STATS, SP> : (stem_kern_t)conv_stem_mfma_kernel<T, 2, 2, ACT, STATS, SP>) \
+          : (s1 ? (stem_kern_t)conv_stem_mfma_kernel<T, 1, 1, ACT, STATS, SP> : (stem_kern_t)conv_stem_mfma_kernel<T, 1, 2, ACT, STATS, SP>))
+    // (stride 2 keeps the fp32 form: its 26 staged samples per thread leave no room for the split operands - 14 .. 53 spilled registers)
+#define YH_STEMK2(T, ACT, STATS, SP)                                                                                       \
+    (wide ? (s1 ? (stem_kern_t)conv_stem_mfma_kernel<T, 2, 1, ACT, STATS, SP> : (stem_kern_t)conv_stem_mfma_kernel<T, 2, 2, ACT, STATS, false>) \
+          : (s1 ? (stem_kern_t)conv_stem_mfma_kernel<T, 1, 1, ACT, STATS, SP> : (stem_kern_t)conv_stem_mfma_kernel<T, 1, 2, ACT, STATS, false>))
+#define YH_STEMK(T, ACT, STATS) (split ? YH_STEMK2(T, ACT, STATS, !(std::is_same<T, float>::value)) : YH_STEMK1(T, ACT, STATS, false))
 #define YH_STEMM(T)                                                                                                       \
     do {                                                                                                                   \
         if (d.stats_ws_floats > 0) return d.act == YH_ACT_LINEAR ? YH_STEMK(T, YH_ACT_LINEAR, true) : nullptr;             \
@@ -384,6 +466,8 @@ static stem_kern_t stem_pick(const yh_stem_desc& d) {
     }
 #undef YH_STEMM
 #undef YH_STEMK
+#undef YH_STEMK1
+#undef YH_STEMK2
     return nullptr;
 }
 
