@@ -300,10 +300,31 @@ int yh_yolo_decode(const yh_decode_desc* d, void* stream);
  *                      (reference: 1 < n < 3000, :844-852) the box is sum_j w_j box_j / sum_j w_j with
  *                      w_j = (IoU(kept_k, j) > thr) * score_j over all m records; otherwise the kept box.
  *                      out fp32 [n][cap][6]; kmax >= max kept count (grid sizing).
- * mmax >= max count over the batch (grid and mask sizing), mmax <= cap.                                  */
+ * mmax >= max count over the batch (grid and mask sizing), mmax <= cap.
+ *
+ * Class-segmented form of steps 3 + 4 (round 5; not agnostic, nc <= 255): the class offset of :840 exists so that one
+ * torchvision.nms call never suppresses across classes, so one workgroup per (image, class) runs the SAME greedy scan
+ * on that class's boxes alone - no IoU bit mask in memory, n x nc scans side by side.
+ * 2' yh_nms_sort_cls   = yh_nms_sort, and cls8[img][rank] = class of every sorted position (uint8 [n][cap]).
+ * 2" yh_nms_sort_tiles = 2' in O(m log m): tiles of 2048 records sorted in LDS (bitonic, same 64-bit keys), global rank = rank in the
+ *                      own tile + one binary search per other tile; cap must be a power of two >= 256; cls8 may be NULL;
+ *                      ws: 12 bytes per record slot (n * cap * 12), 16-byte aligned.
+ * 3' yh_nms_class_scan keep8 uint8 [n][cap] (1 = kept, per sorted position), then keep_idx / n_keep as step 4 writes
+ *                      them.  state uint32 [n][8], initialised by the caller to {0, ~0, ~0, 0, 0, 0, 0, 0}: [0] bit 0 =
+ *                      a class held more than 2048 candidates; [1..4] = order-preserving encodings of min x1, min y1,
+ *                      max x2, max y2 of the image's candidates; [5] = 1 when the image needs the general steps 3 + 4
+ *                      instead: a class overflowed, or the candidates span more than 4096 in x AND in y, in which case
+ *                      boxes of different classes could overlap after the offset (below that they provably cannot
+ *                      and the result is the general form's bit for bit).  n_keep[img] = 0 for such an image.      */
 int yh_nms_candidates(const float* pred, int n, int rows, int nc, float conf_thres, int multi_label,
                       const uint8_t* class_mask, float* cand, int32_t* count, int cap, void* stream);
 int yh_nms_sort(const float* cand, const int32_t* count, int n, int cap, int mmax, float* sorted, void* stream);
+int yh_nms_sort_cls(const float* cand, const int32_t* count, int n, int cap, int mmax, float* sorted, uint8_t* cls8,
+                    void* stream);
+int yh_nms_sort_tiles(const float* cand, const int32_t* count, int n, int cap, int mmax, float* sorted, uint8_t* cls8,
+                      void* ws, size_t ws_bytes, void* stream);
+int yh_nms_class_scan(const float* sorted, const uint8_t* cls8, const int32_t* count, int n, int cap, int nc,
+                      float iou_thres, uint8_t* keep8, uint32_t* state, int32_t* keep_idx, int32_t* n_keep, void* stream);
 int yh_nms_mask(const float* sorted, const int32_t* count, int n, int cap, int mmax, float iou_thres, int agnostic,
                 uint64_t* mask, void* stream);
 int yh_nms_reduce(const uint64_t* mask, const int32_t* count, int n, int cap, int mmax, int32_t* keep_idx,

@@ -31,9 +31,14 @@ def _compare(got, want, tag):
     np.testing.assert_array_equal(g[:, 5], want[:, 5], err_msg=tag)
 
 
+SEG = pytest.mark.parametrize('seg', ['', '1', '0'], ids=['auto', 'by-class', 'bit-mask'])
+
+
+@SEG
 @pytest.mark.parametrize('path', NMS_FIXTURES, ids=[os.path.basename(p)[4:-4] for p in NMS_FIXTURES])
-def test_hip_nms_matches_reference_golden(path):
+def test_hip_nms_matches_reference_golden(path, seg, monkeypatch):
     from utils.utils import non_max_suppression
+    monkeypatch.setenv('YOLO_HIP_NMS_SEGMENTED', seg)      # '': class by class for multi-label calls; 1: whenever not agnostic; 0: never
     fx = np.load(path, allow_pickle=False)
     pred = synth.nms_candidates(int(fx['n_img']), int(fx['rows']), int(fx['nc']), int(fx['seed']))
     got = non_max_suppression(pred.cuda(), conf_thres=float(fx['conf']), iou_thres=float(fx['iou']),
@@ -44,9 +49,11 @@ def test_hip_nms_matches_reference_golden(path):
 
 @pytest.mark.parametrize('rows,nc,conf,ml,seed', [(3000, 80, 0.3, False, 51), (1500, 20, 0.05, True, 52),
                                                   (9000, 80, 0.2, False, 53), (700, 2, 0.4, True, 54)])
-def test_hip_nms_matches_oracle(rows, nc, conf, ml, seed):
+@SEG
+def test_hip_nms_matches_oracle(rows, nc, conf, ml, seed, seg, monkeypatch):
     """Larger seeded sets, including n >= 3000 candidates where the reference skips the merge step."""
     from utils.utils import non_max_suppression
+    monkeypatch.setenv('YOLO_HIP_NMS_SEGMENTED', seg)
     pred = synth.nms_candidates(2, rows, nc, seed, n_clusters=40, hot=0.9 if rows >= 9000 else 0.35)
     want = oracle.non_max_suppression(pred.numpy(), conf, 0.6, multi_label=ml)
     got = non_max_suppression(pred.cuda(), conf, 0.6, multi_label=ml)
@@ -71,6 +78,7 @@ def test_hip_nms_bound_forgets_outliers_and_respects_the_mask_budget(monkeypatch
     (b) a guessed bound whose mask exceeds the budget takes the count-first path - and every path returns the same boxes."""
     from engine import nms as hnms
     from utils.utils import non_max_suppression
+    monkeypatch.setenv('YOLO_HIP_NMS_SEGMENTED', '0')      # the mask budget is the bit-mask form's (the class-by-class form has no mask)
     monkeypatch.setattr(hnms, '_density', {})
     dense = synth.nms_candidates(2, 4000, 20, 61, n_clusters=40, hot=0.9).cuda()
     sparse = synth.nms_candidates(2, 4000, 20, 62, n_clusters=10, hot=0.02).cuda()
@@ -97,12 +105,14 @@ def test_hip_nms_bound_forgets_outliers_and_respects_the_mask_budget(monkeypatch
         _compare(got[i], want_dense[i], 'budget path img %d' % i)
 
 
-def test_hip_nms_processes_large_batches_in_chunks(monkeypatch):
+@pytest.mark.parametrize('seg', ['0'], ids=['bit-mask'])
+def test_hip_nms_processes_large_batches_in_chunks(monkeypatch, seg):
     """test.py settings (conf 0.001, multi-label): thousands of candidates per image and an IoU bit mask quadratic in them.  With a
     small work budget the batch is processed in image chunks; same boxes as one pass and as the oracle; a single image beyond the
     budget raises MemoryError naming the candidate count."""
     from engine import nms as hnms
     from utils.utils import non_max_suppression
+    monkeypatch.setenv('YOLO_HIP_NMS_SEGMENTED', seg)      # the budget arithmetic of this test is the bit-mask form's
     monkeypatch.setattr(hnms, '_density', {})
     pred = synth.nms_candidates(5, 3000, 20, 71, n_clusters=40, hot=0.9).cuda()
     want = oracle.non_max_suppression(pred.cpu().numpy(), 0.05, 0.6, multi_label=True)
@@ -118,3 +128,79 @@ def test_hip_nms_processes_large_batches_in_chunks(monkeypatch):
     monkeypatch.setattr(hnms, '_WORK_BUDGET', 1 << 16)
     with pytest.raises(MemoryError):
         non_max_suppression(pred, 0.05, 0.6, multi_label=True)
+
+
+def _same(a, b, tag):
+    assert len(a) == len(b)
+    for i, (x, y) in enumerate(zip(a, b)):
+        assert (x is None) == (y is None), '%s img %d' % (tag, i)
+        if x is not None:
+            assert torch.equal(x, y), '%s img %d: %d vs %d boxes' % (tag, i, x.shape[0], y.shape[0])
+
+
+def test_hip_nms_class_by_class_equals_the_bit_mask_form_at_evaluation_settings(monkeypatch):
+    """Round 5.  test.py's settings (conf 0.001, multi-label) on clustered predictions: 10^4 candidates per image in
+    80 classes, most of them suppressed.  One workgroup per (image, class) runs the greedy scan on that class's boxes alone
+    (yh_nms_class_scan) - BIT-identical output to the bit-mask form over all candidates, and to the oracle on the smaller images;
+    the single host read reports that no image needed the general form."""
+    from engine import nms as hnms
+    from utils.utils import non_max_suppression
+    monkeypatch.setattr(hnms, '_density', {})
+    pred = synth.nms_candidates(4, 2500, 80, 81, n_clusters=30, hot=0.5)
+    pred[0, 260:, 4] = 0                                     # ~ 260 rows with objectness, nearly all of their 80 class scores pass
+    pred[1, 120:, 4] = 0
+    pred[2, 30:, 4] = 0                                      # an image with few candidates (merge applies: < 3000)
+    pred[3, :, 4] = 0                                        # and one with none
+    want = oracle.non_max_suppression(pred[1:].numpy(), 0.001, 0.6, multi_label=True)
+    dev = pred.cuda()
+    monkeypatch.setenv('YOLO_HIP_NMS_SEGMENTED', '0')
+    general = non_max_suppression(dev, 0.001, 0.6, multi_label=True)
+    monkeypatch.setenv('YOLO_HIP_NMS_SEGMENTED', '')
+    reads = []
+    orig = torch.Tensor.cpu
+    monkeypatch.setattr(torch.Tensor, 'cpu', lambda t, *a, **k: (reads.append(tuple(t.shape)), orig(t, *a, **k))[1])
+    by_class = non_max_suppression(dev, 0.001, 0.6, multi_label=True)
+    by_class = non_max_suppression(dev, 0.001, 0.6, multi_label=True)      # second call: the bound is known
+    cands = hnms._density[1][-1] * 2500
+    monkeypatch.undo()
+    assert reads[-1] == (10, 4) and len([r for r in reads if r == (10, 4)]) <= 3, reads      # ONE read in the steady state
+    _same(by_class, general, 'class by class vs bit mask')
+    m = [0 if d is None else d.shape[0] for d in by_class]
+    assert cands > 15000 and 1000 < m[0] < 0.5 * cands and m[3] == 0, (cands, m)      # most candidates are suppressed
+    _compare(by_class[1], want[0], '~ 9000 candidates')
+    _compare(by_class[2], want[1], 'few candidates, merged')
+    assert by_class[3] is None and want[2] is None
+
+
+def test_hip_nms_class_by_class_hands_over_what_it_does_not_cover(monkeypatch):
+    """(a) A class with more than 2048 candidates, (b) candidates spread over more than 4096 pixels in x and y - where the reference's
+    offset boxes of DIFFERENT classes can overlap: a class-0 box at (5000, 5000) and a class-1 box at (904, 904) are the same box after
+    `+ cls * 4096` (utils.py:840) and the reference keeps only the better one.  Both are detected on the device, the batch takes the
+    bit-mask form, and the result is the oracle's."""
+    from engine import nms as hnms
+    from utils.utils import non_max_suppression
+    monkeypatch.setattr(hnms, '_density', {})
+    monkeypatch.setenv('YOLO_HIP_NMS_SEGMENTED', '')
+    big = synth.nms_candidates(2, 4000, 2, 91, n_clusters=25, hot=0.9)      # two classes, ~3500 candidates each
+    want = oracle.non_max_suppression(big.numpy(), 0.02, 0.6, multi_label=True)
+    got = non_max_suppression(big.cuda(), 0.02, 0.6, multi_label=True)
+    for i in range(2):
+        _compare(got[i], want[i], 'class overflow img %d' % i)
+    far = torch.zeros(2, 64, 5 + 3)
+    far[:, :, 4] = 0.0
+    far[0, 0] = torch.tensor([5000., 5000., 1500., 1500., 0.9, 0.95, 0.01, 0.01])
+    far[0, 1] = torch.tensor([904., 904., 1500., 1500., 0.8, 0.01, 0.95, 0.01])
+    far[0, 2] = torch.tensor([100., 100., 50., 60., 0.7, 0.01, 0.01, 0.95])
+    far[1, 0] = torch.tensor([300., 300., 80., 80., 0.9, 0.95, 0.9, 0.01])
+    far[1, 1] = torch.tensor([302., 301., 80., 80., 0.8, 0.95, 0.01, 0.01])
+    want = oracle.non_max_suppression(far.numpy(), 0.3, 0.6, multi_label=True)
+    assert len(want[0]) == 2 and len(want[1]) == 2           # the cross-class suppression happened; image 1: 3 candidates -> 2
+    got = non_max_suppression(far.cuda(), 0.3, 0.6, multi_label=True)
+    for i in range(2):
+        _compare(got[i], want[i], 'far-out img %d' % i)
+    # without the far-out boxes the same call stays class by class (and still agrees)
+    far[0, 0, 4] = 0.0
+    want = oracle.non_max_suppression(far.numpy(), 0.3, 0.6, multi_label=True)
+    got = non_max_suppression(far.cuda(), 0.3, 0.6, multi_label=True)
+    for i in range(2):
+        _compare(got[i], want[i], 'near img %d' % i)

@@ -120,7 +120,7 @@ __device__ __forceinline__ unsigned long long sort_key(float score, int key) {
 
 // rank by counting: position of i = number of records that order before it.  grid (ceil(mmax/256), n)
 __global__ __launch_bounds__(256) void nms_sort_kernel(const float* __restrict__ cand, const int32_t* __restrict__ count,
-                                                       int cap, float* __restrict__ sorted) {
+                                                       int cap, float* __restrict__ sorted, uint8_t* __restrict__ cls8) {
     __shared__ unsigned long long keys[256];
     const int img = blockIdx.y;
     int m = count[img];
@@ -151,7 +151,108 @@ __global__ __launch_bounds__(256) void nms_sort_kernel(const float* __restrict__
         float* dst = sorted + ((long)img * cap + rank) * REC;
         *reinterpret_cast<f32x4*>(dst) = lo;
         *reinterpret_cast<f32x4*>(dst + 4) = hi;
+        if (cls8) cls8[(long)img * cap + rank] = (uint8_t)(int)hi[1];      // the class of every sorted position, one byte each (nms_class_kernel)
     }
+}
+
+// ---- tile sort + rank by binary search (round 5) --------------------------------------------------------------------------------------
+// The counting sort above compares every pair: 4.4 x 10^8 comparisons per image at 21 000 candidates (0.68 ms for 16 images, the largest
+// stage left once the suppression runs class by class).  Here tiles of SORT_TILE records are sorted in LDS (bitonic network on the same
+// 64-bit keys, the record's slot as payload), and a record's global rank is its rank in its own tile plus, for every other tile, the
+// number of keys below it - a binary search, keys being unique.  Same total order, so the sorted list is the counting sort's.
+constexpr int SORT_TILE = 2048;
+
+// grid (ceil(mmax / tile), n), 256 threads; tile = min(cap, SORT_TILE), a power of two >= 256
+__global__ __launch_bounds__(256) void nms_tile_sort_kernel(const float* __restrict__ cand, const int32_t* __restrict__ count, int cap,
+                                                            int tile, unsigned long long* __restrict__ tkey, int32_t* __restrict__ tslot) {
+    __shared__ unsigned long long k[SORT_TILE];
+    __shared__ int v[SORT_TILE];
+    const int img = blockIdx.y, t0 = blockIdx.x * tile;
+    int m = count[img];
+    if (m > cap) m = cap;
+    if (t0 >= m) return;
+    const float* base = cand + (long)img * cap * REC;
+    for (int e = threadIdx.x; e < tile; e += 256) {
+        const int slot = t0 + e;
+        unsigned long long key = ~0ull;      // padding sorts behind every record
+        if (slot < m) {
+            const f32x4 h = *reinterpret_cast<const f32x4*>(base + (long)slot * REC + 4);
+            key = sort_key(h[0], __float_as_int(h[2]));
+        }
+        k[e] = key;
+        v[e] = slot;
+    }
+    __syncthreads();
+    for (int kk = 2; kk <= tile; kk <<= 1) {
+        for (int j = kk >> 1; j > 0; j >>= 1) {
+            for (int i = threadIdx.x; i < (tile >> 1); i += 256) {
+                const int l = 2 * i - (i & (j - 1)), p = l + j;
+                const unsigned long long a = k[l], b = k[p];
+                if ((a > b) == ((l & kk) == 0)) {
+                    k[l] = b; k[p] = a;
+                    const int va = v[l];
+                    v[l] = v[p]; v[p] = va;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    unsigned long long* dk = tkey + (long)img * cap + t0;
+    int32_t* dv = tslot + (long)img * cap + t0;
+    for (int e = threadIdx.x; e < tile; e += 256) {
+        dk[e] = k[e];
+        dv[e] = v[e];
+    }
+}
+
+// grid (ceil(mmax / 256), n), 256 threads: one thread per record of the tile-sorted list
+__global__ __launch_bounds__(256) void nms_tile_rank_kernel(const float* __restrict__ cand, const int32_t* __restrict__ count, int cap,
+                                                            int tile, const unsigned long long* __restrict__ tkey,
+                                                            const int32_t* __restrict__ tslot, float* __restrict__ sorted,
+                                                            uint8_t* __restrict__ cls8) {
+    const int img = blockIdx.y;
+    int m = count[img];
+    if (m > cap) m = cap;
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= ((m + tile - 1) / tile) * tile) return;
+    const int mine_t = e / tile, r = e - mine_t * tile;
+    if (r >= min(tile, m - mine_t * tile)) return;      // padding
+    const unsigned long long* tk = tkey + (long)img * cap;
+    const unsigned long long mine = tk[e];
+    const int ntiles = (m + tile - 1) / tile;
+    int rank = r;
+    for (int g0 = 0; g0 < ntiles; g0 += 8) {
+        int lo[8], hi[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int t = g0 + u;
+            lo[u] = 0;
+            hi[u] = (t < ntiles && t != mine_t) ? min(tile, m - t * tile) : 0;
+        }
+        for (int step = 0; step < 12; ++step) {      // 2^11 = SORT_TILE: the interval is empty after 12 halvings; 8 independent loads per round
+            unsigned long long q[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int mid = (lo[u] + hi[u]) >> 1;
+                q[u] = lo[u] < hi[u] ? tk[(long)(g0 + u) * tile + mid] : 0ull;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int mid = (lo[u] + hi[u]) >> 1;
+                if (lo[u] < hi[u]) {
+                    if (q[u] < mine) lo[u] = mid + 1; else hi[u] = mid;
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) rank += lo[u];
+    }
+    const float* src = cand + ((long)img * cap + tslot[(long)img * cap + e]) * REC;
+    const f32x4 a = *reinterpret_cast<const f32x4*>(src), b = *reinterpret_cast<const f32x4*>(src + 4);
+    float* dst = sorted + ((long)img * cap + rank) * REC;
+    *reinterpret_cast<f32x4*>(dst) = a;
+    *reinterpret_cast<f32x4*>(dst + 4) = b;
+    if (cls8) cls8[(long)img * cap + rank] = (uint8_t)(int)b[1];
 }
 
 __device__ __forceinline__ float iou_off(const f32x4& a, const f32x4& b) {
@@ -261,6 +362,208 @@ __global__ __launch_bounds__(256) void nms_reduce_kernel(const unsigned long lon
     if (threadIdx.x == 0) n_keep[img] = (int)kept_total;
 }
 
+// ---- class-segmented suppression (round 5) -------------------------------------------------------------------------------------------
+// The reference offsets every box by cls * 4096 (utils.py:840) so that ONE torchvision.nms call never suppresses across classes.  At
+// test.py's settings (conf 0.001, multi-label) an image has 10^4 candidates in 80 classes: the IoU bit mask of the general path is 80 x
+// larger than the pairs that can interact, and its greedy scan is ONE serial chain of m / 64 steps with two dependent global-memory
+// latencies each (profiles/r04_nms_stages.txt: 1.3 + 2.8 ms of 4.9 for 16 images of 21 000).  Here one workgroup owns one (image, class):
+// it collects the class's positions of the score-sorted list (in order), keeps their offset boxes in LDS and runs the same greedy scan
+// on them - 64 boxes per step, the step's 64 x 64 IoU bits resolved by wave 0 in scalar registers, the kept boxes of the step tested
+// against the later ones straight from LDS.  No mask in memory; 80 x n scans run concurrently.
+//
+// When is that EXACTLY the reference's result?  Boxes of classes c < c' are offset by >= 4096 against each other in x AND y.  With
+// xmin / xmax the extreme raw coordinates of an image's candidates and xmax - xmin <= 4096 (or the same in y), rounding being monotonic,
+// fl(a.x2 + 4096 c) <= fl(b.x1 + 4096 c'): the overlap extent is <= 0, the intersection 0, IoU 0 (or NaN) - never > thr, in the scan
+// and in the merge weights alike.  nms_compact_kernel checks it per image (extremes collected here through atomics) and reports images
+// that fail it, or whose class holds more than SEG_MAX candidates, in state[img][5]: the host then runs the general path on the batch.
+// The IoU arithmetic is iou_off() on offset_box() values: the same fp32 operations in the same order as the general path's.
+constexpr int SEG_MAX = 2048;
+
+__device__ __forceinline__ unsigned ord_enc(float f) {      // unsigned order == float order (finite values)
+    const unsigned b = __float_as_uint(f);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float ord_dec(unsigned u) {
+    return __uint_as_float((u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u);
+}
+
+__device__ __forceinline__ bool seg_overlap(const f32x4& a, const f32x4& b) {
+    return fminf(a[2], b[2]) > fmaxf(a[0], b[0]) && fminf(a[3], b[3]) > fmaxf(a[1], b[1]);
+}
+
+// grid (nc, n), 256 threads.  state[img][8] (host-initialised: [0] = 0, [1], [2] = 0xFFFFFFFF, [3], [4] = 0):
+// [0] |= 1 when a class overflows SEG_MAX; [1..4] = ordered encodings of min x1, min y1, max x2, max y2
+__global__ __launch_bounds__(256) void nms_class_kernel(const float* __restrict__ sorted, const uint8_t* __restrict__ cls8,
+                                                        const int32_t* __restrict__ count, int cap, float thr,
+                                                        uint8_t* __restrict__ keep8, unsigned* __restrict__ state) {
+    __shared__ f32x4 box[SEG_MAX];
+    __shared__ int pos[SEG_MAX];
+    __shared__ uint8_t dead[SEG_MAX];
+    __shared__ unsigned long long part[4][64];
+    __shared__ unsigned long long kb_sh;
+    __shared__ int wcnt[4];
+    const int img = blockIdx.y, c = blockIdx.x;
+    int m = count[img];
+    if (m > cap) m = cap;
+    if (m <= 0) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    const uint8_t* cl = cls8 + (long)img * cap;
+    // ---- the class's positions, in score order: wave w scans a quarter of the list (count, then write)
+    const int quarter = (((m + 3) >> 2) + 63) & ~63;
+    const int lo = wave * quarter, hi = min(m, lo + quarter);
+    int cnt = 0;
+    for (int p0 = lo; p0 < hi; p0 += 512) {
+        unsigned v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int p = p0 + u * 64 + lane;
+            v[u] = p < hi ? cl[p] : 0xFFu;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) cnt += __popcll(__ballot(v[u] == (unsigned)c));
+    }
+    if (lane == 0) wcnt[wave] = cnt;
+    __syncthreads();
+    const int total = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+    if (total == 0) return;
+    if (total > SEG_MAX) {
+        if (tid == 0) atomicOr(state + (long)img * 8, 1u);
+        return;
+    }
+    int run = 0;
+    for (int w = 0; w < wave; ++w) run += wcnt[w];
+    for (int p0 = lo; p0 < hi; p0 += 512) {
+        unsigned v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int p = p0 + u * 64 + lane;
+            v[u] = p < hi ? cl[p] : 0xFFu;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const bool hit = v[u] == (unsigned)c;
+            const unsigned long long b = __ballot(hit);
+            if (hit) pos[run + __popcll(b & below)] = p0 + u * 64 + lane;
+            run += __popcll(b);
+        }
+    }
+    __syncthreads();
+    // ---- offset boxes into LDS; extremes of the raw coordinates
+    const float* base = sorted + (long)img * cap * REC;
+    float x1 = INFINITY, y1 = INFINITY, x2 = -INFINITY, y2 = -INFINITY;
+    for (int r = tid; r < total; r += 256) {
+        const float* rec = base + (long)pos[r] * REC;
+        const f32x4 b = *reinterpret_cast<const f32x4*>(rec);
+        box[r] = offset_box(rec, 0);
+        dead[r] = 0;
+        x1 = fminf(x1, b[0]); y1 = fminf(y1, b[1]); x2 = fmaxf(x2, b[2]); y2 = fmaxf(y2, b[3]);
+    }
+    for (int d = 32; d > 0; d >>= 1) {
+        x1 = fminf(x1, __shfl_xor(x1, d)); y1 = fminf(y1, __shfl_xor(y1, d));
+        x2 = fmaxf(x2, __shfl_xor(x2, d)); y2 = fmaxf(y2, __shfl_xor(y2, d));
+    }
+    if (lane == 0 && wave * 64 < total) {      // a wave without a box holds +-inf: nothing to report
+        unsigned* st = state + (long)img * 8;
+        atomicMin(st + 1, ord_enc(x1)); atomicMin(st + 2, ord_enc(y1));
+        atomicMax(st + 3, ord_enc(x2)); atomicMax(st + 4, ord_enc(y2));
+    }
+    __syncthreads();
+    // ---- greedy scan, 64 boxes per step
+    uint8_t* kp = keep8 + (long)img * cap;
+    const int nblk = (total + 63) >> 6;
+    for (int blk = 0; blk < nblk; ++blk) {
+        const int b0 = blk * 64, lim = min(64, total - b0);
+        {   // the step's own 64 x 64 bits: thread = (row lane, column quarter wave)
+            unsigned long long bits = 0;
+            if (lane < lim) {
+                const f32x4 me = box[b0 + lane];
+                const int k1 = min(lim, wave * 16 + 16);
+                for (int k = max(wave * 16, lane + 1); k < k1; ++k) {
+                    const f32x4 o = box[b0 + k];
+                    if (seg_overlap(me, o) && iou_off(me, o) > thr) bits |= 1ull << k;
+                }
+            }
+            part[wave][lane] = bits;
+        }
+        __syncthreads();
+        if (wave == 0) {
+            const unsigned long long d = part[0][lane] | part[1][lane] | part[2][lane] | part[3][lane];
+            const int dlo = (int)(unsigned)d, dhi = (int)(unsigned)(d >> 32);
+            unsigned long long dm = __ballot(lane >= lim || dead[b0 + min(lane, lim - 1)] != 0);
+            unsigned long long kb = 0;
+#pragma unroll
+            for (int b = 0; b < 64; ++b) {      // uniform: scalar registers, lane reads with a constant lane
+                if (!((dm >> b) & 1ull)) {
+                    kb |= 1ull << b;
+                    dm |= ((unsigned long long)(unsigned)__builtin_amdgcn_readlane(dhi, b) << 32) |
+                          (unsigned)__builtin_amdgcn_readlane(dlo, b);
+                }
+            }
+            if (lane < lim) kp[pos[b0 + lane]] = (uint8_t)((kb >> lane) & 1ull);
+            if (lane == 0) kb_sh = kb;
+        }
+        __syncthreads();
+        const unsigned long long kb = kb_sh;
+        if (kb != 0 && blk + 1 < nblk) {
+            for (int j = b0 + 64 + tid; j < total; j += 256) {
+                if (dead[j]) continue;
+                const f32x4 me = box[j];
+                unsigned long long todo = kb;
+                while (todo) {
+                    const int b = __ffsll((long long)todo) - 1;
+                    todo &= todo - 1;
+                    const f32x4 o = box[b0 + b];
+                    if (seg_overlap(o, me) && iou_off(o, me) > thr) {
+                        dead[j] = 1;
+                        break;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// grid (n), 1024 threads: the verdict of the segmented path per image and, where it stands, the kept positions in score order
+__global__ __launch_bounds__(1024) void nms_compact_kernel(const uint8_t* __restrict__ keep8, const int32_t* __restrict__ count,
+                                                           int cap, unsigned* __restrict__ state, int32_t* __restrict__ keep_idx,
+                                                           int32_t* __restrict__ n_keep) {
+    __shared__ int wsum[16];
+    const int img = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int m = count[img];
+    if (m > cap) m = cap;
+    unsigned* st = state + (long)img * 8;
+    if (m <= 0) {
+        if (tid == 0) { n_keep[img] = 0; st[5] = 0; }
+        return;
+    }
+    const double ex = (double)ord_dec(st[3]) - (double)ord_dec(st[1]), ey = (double)ord_dec(st[4]) - (double)ord_dec(st[2]);
+    const bool general = st[0] != 0 || !(ex <= (double)kMaxWH || ey <= (double)kMaxWH);
+    if (general) {
+        if (tid == 0) { n_keep[img] = 0; st[5] = 1; }
+        return;
+    }
+    const uint8_t* kp = keep8 + (long)img * cap;
+    const int per = (m + 1023) >> 10;
+    const int lo = min(m, tid * per), hi = min(m, lo + per);
+    int mine = 0;
+    for (int p = lo; p < hi; ++p) mine += kp[p];
+    int incl = mine;
+    for (int d = 1; d < 64; d <<= 1) {
+        const int t = __shfl_up(incl, d);
+        if (lane >= d) incl += t;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    int off = incl - mine;
+    for (int w = 0; w < wave; ++w) off += wsum[w];
+    int32_t* dst = keep_idx + (long)img * cap;
+    for (int p = lo; p < hi; ++p)
+        if (kp[p]) dst[off++] = p;
+    if (tid == 1023) { n_keep[img] = off; st[5] = 0; }
+}
+
 // one wave per kept box: weighted mean of every box it overlaps (IoU > thr), weights = scores
 __global__ __launch_bounds__(256) void nms_merge_kernel(const float* __restrict__ sorted, const int32_t* __restrict__ count,
                                                         const int32_t* __restrict__ keep_idx,
@@ -323,7 +626,45 @@ extern "C" int yh_nms_candidates(const float* pred, int n, int rows, int nc, flo
 extern "C" int yh_nms_sort(const float* cand, const int32_t* count, int n, int cap, int mmax, float* sorted, void* stream) {
     if (!cand || !count || !sorted || n <= 0 || cap <= 0 || mmax <= 0 || mmax > cap) return YH_EINVAL;
     if (!aligned16(cand) || !aligned16(sorted)) return YH_EALIGN;
-    hipLaunchKernelGGL(nms_sort_kernel, dim3((mmax + 255) / 256, n), dim3(256), 0, (hipStream_t)stream, cand, count, cap, sorted);
+    hipLaunchKernelGGL(nms_sort_kernel, dim3((mmax + 255) / 256, n), dim3(256), 0, (hipStream_t)stream, cand, count, cap, sorted,
+                       (uint8_t*)nullptr);
+    return check_launch();
+}
+
+extern "C" int yh_nms_sort_cls(const float* cand, const int32_t* count, int n, int cap, int mmax, float* sorted, uint8_t* cls8,
+                               void* stream) {
+    if (!cand || !count || !sorted || !cls8 || n <= 0 || cap <= 0 || mmax <= 0 || mmax > cap) return YH_EINVAL;
+    if (!aligned16(cand) || !aligned16(sorted)) return YH_EALIGN;
+    hipLaunchKernelGGL(nms_sort_kernel, dim3((mmax + 255) / 256, n), dim3(256), 0, (hipStream_t)stream, cand, count, cap, sorted, cls8);
+    return check_launch();
+}
+
+extern "C" int yh_nms_sort_tiles(const float* cand, const int32_t* count, int n, int cap, int mmax, float* sorted, uint8_t* cls8,
+                                 void* ws, size_t ws_bytes, void* stream) {
+    if (!cand || !count || !sorted || !ws || n <= 0 || cap <= 0 || mmax <= 0 || mmax > cap) return YH_EINVAL;
+    if (!aligned16(cand) || !aligned16(sorted) || !aligned16(ws)) return YH_EALIGN;
+    if ((cap & (cap - 1)) != 0 || cap < 256) return YH_EUNSUPPORTED;      // tiles are powers of two that divide the bound
+    if (ws_bytes < (size_t)n * cap * 12) return YH_EINVAL;
+    const int tile = cap < SORT_TILE ? cap : SORT_TILE;
+    unsigned long long* tkey = (unsigned long long*)ws;
+    int32_t* tslot = (int32_t*)(tkey + (size_t)n * cap);
+    hipLaunchKernelGGL(nms_tile_sort_kernel, dim3((mmax + tile - 1) / tile, n), dim3(256), 0, (hipStream_t)stream, cand, count, cap, tile,
+                       tkey, tslot);
+    const int padded = ((mmax + tile - 1) / tile) * tile;
+    hipLaunchKernelGGL(nms_tile_rank_kernel, dim3((padded + 255) / 256, n), dim3(256), 0, (hipStream_t)stream, cand, count, cap, tile, tkey,
+                       tslot, sorted, cls8);
+    return check_launch();
+}
+
+extern "C" int yh_nms_class_scan(const float* sorted, const uint8_t* cls8, const int32_t* count, int n, int cap, int nc,
+                                 float iou_thres, uint8_t* keep8, uint32_t* state, int32_t* keep_idx, int32_t* n_keep, void* stream) {
+    if (!sorted || !cls8 || !count || !keep8 || !state || !keep_idx || !n_keep || n <= 0 || cap <= 0 || nc <= 0) return YH_EINVAL;
+    if (!aligned16(sorted)) return YH_EALIGN;
+    if (nc > 255 || n > 65535) return YH_EUNSUPPORTED;      // one byte per class id, 0xFF = no candidate
+    hipLaunchKernelGGL(nms_class_kernel, dim3(nc, n), dim3(256), 0, (hipStream_t)stream, sorted, cls8, count, cap, iou_thres, keep8,
+                       (unsigned*)state);
+    hipLaunchKernelGGL(nms_compact_kernel, dim3(n), dim3(1024), 0, (hipStream_t)stream, keep8, count, cap, (unsigned*)state, keep_idx,
+                       n_keep);
     return check_launch();
 }
 

@@ -259,6 +259,9 @@ _SIGNATURES = {
     'yh_yolo_decode': (C.c_int, [C.POINTER(DecodeDesc), _vp]),
     'yh_nms_candidates': (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _f32, C.c_int, _vp, _vp, _vp, C.c_int, _vp]),
     'yh_nms_sort': (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp]),
+    'yh_nms_sort_cls': (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp]),
+    'yh_nms_sort_tiles': (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, C.c_size_t, _vp]),
+    'yh_nms_class_scan': (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _f32, _vp, _vp, _vp, _vp, _vp]),
     'yh_nms_mask': (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, _f32, C.c_int, _vp, _vp]),
     'yh_nms_reduce': (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp]),
     'yh_nms_merge': (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _f32, C.c_int, C.c_int, C.c_int, _vp, _vp]),

@@ -15,8 +15,17 @@ keyed on the label mode only, so the rectangular shapes of an evaluation run sha
 a test.py call at conf 0.001 before a detect.py call at conf 0.3) stops costing memory after ``_HINT_WINDOW`` calls.  The IoU
 bit mask is quadratic in the bound (n * cap * cap / 8 bytes); above ``_MASK_BUDGET`` the bound is not trusted and the call takes
 the exact path: a count-only pass, one extra read, buffers sized by the true maximum.
+
+Round 5: with per-class offsets (not agnostic) and multi-label candidates the suppression runs class by class
+(``yh_nms_class_scan``: one workgroup per (image, class), boxes in LDS, no bit mask - csrc/nms.hip says when that is the
+reference's result bit for bit and checks it on the device).  Its buffers are linear in the bound, so the mask budget does not
+apply; the single read also returns the per-image verdict, and only a batch with an image that needs the general form (a class
+above 2048 candidates, or candidates spread over more than 4096 pixels in x and y) takes the mask path afterwards.
+``YOLO_HIP_NMS_SEGMENTED`` = 0 (never) / 1 (whenever not agnostic) / unset (multi-label only) selects it; its sort is the tile
+sort of ``yh_nms_sort_tiles`` (``YOLO_HIP_NMS_SORT=count``: the counting sort of the bit-mask form).
 """
 import collections
+import os
 
 import torch
 
@@ -63,11 +72,13 @@ def _non_max_suppression(prediction, conf_thres, iou_thres, multi_label, classes
     guess = _CAP_MIN if not seen else _pow2_at_least(int(2 * max(seen) * rows) + 1)
     cap = min(guess, _pow2_at_least(most))
     ag = 1 if agnostic else 0
+    how = os.environ.get('YOLO_HIP_NMS_SEGMENTED', '')
+    seg = (not ag) and nc <= 255 and how != '0' and (ml == 1 or how == '1')
     exact = False
     work_budget = {}      # resolved at most once per call, and only when a pass is large enough to ask (budget())
 
-    def per_image_bytes(c):
-        return c * ((c + 63) // 64) * 8 + c * (8 + 8 + 6 + 1) * 4
+    def per_image_bytes(c, general=True):
+        return (c * ((c + 63) // 64) * 8 if general else 14 * c) + c * (8 + 8 + 6 + 1) * 4
 
     def budget():
         """Bytes the buffers of one pass may take: the fixed ceiling, and never more than half of what the device has free right now (an
@@ -81,50 +92,82 @@ def _non_max_suppression(prediction, conf_thres, iou_thres, multi_label, classes
             b = work_budget['v'] = int(min(_WORK_BUDGET, max(free // 2, 64 << 20)))
         return b
 
-    def in_chunks(c):
+    def too_big(c, general):
+        """Do the buffers of one pass over the whole batch exceed the budget?  (Asks the device only when they are large at all.)"""
+        need = n * per_image_bytes(c, general)
+        return need > min(64 << 20, _WORK_BUDGET) and need > budget()
+
+    def in_chunks(c, general):
         """Run the images in groups whose buffers fit the budget and concatenate the results."""
-        if per_image_bytes(c) > budget():
-            raise MemoryError('non_max_suppression: %d candidates in one image need a %.1f GB IoU bit mask (conf_thres %g, %s): raise '
-                              'conf_thres' % (c, per_image_bytes(c) / 1e9, conf_thres, 'multi-label' if ml else 'best class'))
-        step = max(1, int(budget() // per_image_bytes(c)))
+        _density.setdefault(ml, collections.deque(maxlen=_HINT_WINDOW)).append(c / float(rows))     # a TRUE count (ADVICE r4)
+        each = per_image_bytes(_pow2_at_least(c), general)
+        if each > budget():
+            raise MemoryError('non_max_suppression: %d candidates in one image need %.1f GB of buffers%s (conf_thres %g, %s): raise '
+                              'conf_thres' % (c, each / 1e9, ', most of it the IoU bit mask' if general else '', conf_thres,
+                                              'multi-label' if ml else 'best class'))
+        step = max(1, int(budget() // each))
         out = []
         for i in range(0, n, step):
             out += _non_max_suppression(pred[i:i + step], conf_thres, iou_thres, multi_label, classes, agnostic)
         return out
 
-    if n * cap * ((cap + 63) // 64) * 8 > _MASK_BUDGET:
+    if (not seg and n * cap * ((cap + 63) // 64) * 8 > _MASK_BUDGET) or too_big(cap, not seg):
         # a guessed bound this large is not worth its mask: count first (one extra 4n-byte read), then size exactly
         count = torch.zeros(n, dtype=torch.int32, device=dev)
         hiplib.check(lib.yh_nms_candidates(P(pred), n, rows, nc, conf_thres, ml, P(cmask), None, P(count), 0, S), 'nms count')
         cmax = max(int(count.max()), 1)
         cap, exact = _pow2_at_least(cmax), True
-        if n * per_image_bytes(cap) > budget() and (n > 1 or per_image_bytes(cap) > budget()):
-            _density.setdefault(ml, collections.deque(maxlen=_HINT_WINDOW)).append(cmax / float(rows))     # the TRUE count (ADVICE r4)
-            return in_chunks(cap)
+        if too_big(cap, not seg):
+            return in_chunks(cmax, not seg)
     while True:
         words = (cap + 63) // 64
-        counts = torch.zeros((2, n), dtype=torch.int32, device=dev)     # row 0: candidates per image, row 1: survivors
-        count, n_keep = counts[0], counts[1]
+        ctl = torch.zeros((10, n), dtype=torch.int32, device=dev)     # row 0: candidates per image, row 1: survivors, rest: state [n][8]
+        count, n_keep, state = ctl[0], ctl[1], ctl[2:].view(n, 8)
         cand = torch.empty((n, cap, 8), dtype=torch.float32, device=dev)
         hiplib.check(lib.yh_nms_candidates(P(pred), n, rows, nc, conf_thres, ml, P(cmask), P(cand), P(count), cap, S), 'nms cand')
         srt = torch.empty_like(cand)
-        hiplib.check(lib.yh_nms_sort(P(cand), P(count), n, cap, cap, P(srt), S), 'nms sort')
-        mask = torch.empty((n, cap, words), dtype=torch.int64, device=dev)
-        hiplib.check(lib.yh_nms_mask(P(srt), P(count), n, cap, cap, iou_thres, ag, P(mask), S), 'nms mask')
         keep_idx = torch.empty((n, cap), dtype=torch.int32, device=dev)
-        hiplib.check(lib.yh_nms_reduce(P(mask), P(count), n, cap, cap, P(keep_idx), P(n_keep), S), 'nms reduce')
         res = torch.empty((n, cap, 6), dtype=torch.float32, device=dev)
-        hiplib.check(lib.yh_nms_merge(P(srt), P(count), P(keep_idx), P(n_keep), n, cap, cap, iou_thres, ag,
-                                      MERGE_LO, MERGE_HI, P(res), S), 'nms merge')
-        host = counts.cpu()                    # the one device-to-host read of the call
+
+        def general_steps():
+            mask = torch.empty((n, cap, words), dtype=torch.int64, device=dev)
+            hiplib.check(lib.yh_nms_mask(P(srt), P(count), n, cap, cap, iou_thres, ag, P(mask), S), 'nms mask')
+            hiplib.check(lib.yh_nms_reduce(P(mask), P(count), n, cap, cap, P(keep_idx), P(n_keep), S), 'nms reduce')
+
+        def merge_step():
+            hiplib.check(lib.yh_nms_merge(P(srt), P(count), P(keep_idx), P(n_keep), n, cap, cap, iou_thres, ag,
+                                          MERGE_LO, MERGE_HI, P(res), S), 'nms merge')
+        if seg:
+            state[:, 1:3] = -1       # minima start at the largest encoding
+            cls8 = torch.empty((n, cap), dtype=torch.uint8, device=dev)
+            keep8 = torch.empty((n, cap), dtype=torch.uint8, device=dev)
+            if os.environ.get('YOLO_HIP_NMS_SORT', 'tiles') == 'tiles':      # O(m log m): tile sort in LDS + rank by binary search
+                ws = torch.empty(n * cap * 12, dtype=torch.uint8, device=dev)
+                hiplib.check(lib.yh_nms_sort_tiles(P(cand), P(count), n, cap, cap, P(srt), P(cls8), P(ws), ws.numel(), S), 'nms sort')
+            else:                                                               # 'count': the O(m^2) counting sort (A/B)
+                hiplib.check(lib.yh_nms_sort_cls(P(cand), P(count), n, cap, cap, P(srt), P(cls8), S), 'nms sort')
+            hiplib.check(lib.yh_nms_class_scan(P(srt), P(cls8), P(count), n, cap, nc, iou_thres, P(keep8), P(state), P(keep_idx),
+                                               P(n_keep), S), 'nms class scan')
+        else:
+            hiplib.check(lib.yh_nms_sort(P(cand), P(count), n, cap, cap, P(srt), S), 'nms sort')
+            general_steps()
+        merge_step()
+        host = ctl.cpu()                       # the one device-to-host read of the call
         mmax = int(host[0].max())
         if mmax <= cap:
+            if seg and bool(host[2:].view(n, 8)[:, 5].any()):
+                # an image the class-by-class form does not cover: the bit-mask form on the sorted records that are already there
+                # (a second read; its mask is quadratic in the bound, so the budget decides between one pass and image chunks)
+                if too_big(cap, True):
+                    return in_chunks(mmax, True)
+                general_steps()
+                merge_step()
+                host = ctl.cpu()
             break
         assert not exact, 'candidate count changed between the count pass and the emit pass'
         cap = _pow2_at_least(mmax)             # an image overflowed the bound: repeat with one that holds every candidate
-        if n * per_image_bytes(cap) > budget() and (n > 1 or per_image_bytes(cap) > budget()):
-            _density.setdefault(ml, collections.deque(maxlen=_HINT_WINDOW)).append(mmax / float(rows))
-            return in_chunks(cap)
+        if too_big(cap, not seg):
+            return in_chunks(mmax, not seg)
     _density.setdefault(ml, collections.deque(maxlen=_HINT_WINDOW)).append(mmax / float(rows))
     out = [None] * n
     for i in range(n):
