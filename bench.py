@@ -613,6 +613,7 @@ def main():
                     help='train: forward + loss + backward + SGD step (BASELINE metric "train fp16", configs[2] at N GPUs); '
                          'detect: forward + NMS (configs[1]); both (default): train is the headline value, detect rides along')
     ap.add_argument('--no-nms', action='store_true')
+    ap.add_argument('--two-pass-nms', action='store_true', help='detect leg: model(x) then non_max_suppression(inf) (rounds 1 - 4) instead of model.hip_detect')
     ap.add_argument('--raw-heads', action='store_true', help='keep the random head weights (no NMS candidates at conf 0.3): forward-only timing')
     ap.add_argument('--nms-candidates', type=int, default=100, help='objectness candidates per image the synthetic heads are calibrated to')
     ap.add_argument('--no-v4', action='store_true', help='skip the YOLOv4-640 fp16 / int8 rider legs of the default run')
@@ -839,11 +840,15 @@ def detect_main(args, device, dist, world, rank, cpu_baseline_leg=True, eval_nms
     if not all_ranks_ok(err is None, dist, device):
         raise err if err is not None else RuntimeError('detect leg failed on another rank')
 
-    def step():
+    def step():      # detect.py's loop body (this package's detect.py: model.hip_detect = forward + NMS as one engine call)
         with torch.no_grad():
-            inf, _, _ = model(x)
-        if not args.no_nms:
-            non_max_suppression(inf, conf_thres=0.3, iou_thres=0.6, multi_label=False)
+            if args.no_nms:
+                model(x)
+            elif args.two_pass_nms:
+                inf, _, _ = model(x)
+                non_max_suppression(inf, conf_thres=0.3, iou_thres=0.6, multi_label=False)
+            else:
+                model.hip_detect(x, conf_thres=0.3, iou_thres=0.6, multi_label=False)
 
     from engine import distutil
     for _ in range(args.warmup):

@@ -278,6 +278,12 @@ typedef struct yh_decode_desc {
     float anchor_w[8], anchor_h[8];  /* cfg anchors[mask] / stride in fp32 (models.py:362), na <= 8 */
 } yh_decode_desc;
 int yh_yolo_decode(const yh_decode_desc* d, void* stream);
+/* Decode + step 1 of the NMS below in one pass (round 5): the candidate records yh_yolo_decode followed by yh_nms_candidates would
+ * produce for this head - same values, same keys (row = row_off + (a*ny + y)*nx + x of the concatenated tensor) - without writing the
+ * (n, rows_total, no) tensor: only rows whose objectness passes conf_thres are decoded (models.py:406-418 feeding utils.py:799-827).
+ * d->io and d->raw are ignored; call once per head with the same cand / count buffers; cand == NULL counts only.            */
+int yh_yolo_decode_candidates(const yh_decode_desc* d, float conf_thres, int multi_label, const uint8_t* class_mask,
+                              float* cand, int32_t* count, int cap, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * Non-maximum suppression, utils/utils.py:782-860, batched over the n images of one forward.

@@ -8,7 +8,7 @@ import torch
 
 import synth
 from oracle import darknet_oracle as oracle
-from test_oracle_golden import GOLD
+from test_oracle_golden import GOLD, build_mirror
 
 pytestmark = pytest.mark.gpu
 NMS_FIXTURES = sorted(glob.glob(os.path.join(GOLD, 'nms_*.npz')))
@@ -204,3 +204,65 @@ def test_hip_nms_class_by_class_hands_over_what_it_does_not_cover(monkeypatch):
     got = non_max_suppression(far.cuda(), 0.3, 0.6, multi_label=True)
     for i in range(2):
         _compare(got[i], want[i], 'near img %d' % i)
+
+
+@pytest.mark.parametrize('rel,size,precision', [('yolov3/yolov3.cfg', 320, 'fp16'), ('yolov3tiny/yolov3-tiny-hand.cfg', 416, 'fp32'),
+                                                ('yolov4tiny/yolov4-tiny.cfg', 416, 'fp16')], ids=['yolov3-320-fp16', 'tiny-hand-416-fp32', 'v4tiny-416-fp16'])
+@pytest.mark.parametrize('ml', [False, True], ids=['best-class', 'multi-label'])
+def test_decode_fused_into_the_candidate_pass_gives_the_two_pass_detections(rel, size, precision, ml, cfg_dir, monkeypatch):
+    """Round 5: models.Darknet.hip_detect = forward + NMS as one engine call.  The plan stops at the head
+    convolutions; yh_yolo_decode_candidates decodes only the rows whose objectness passes the threshold, straight into the candidate
+    records - the (N, rows, 5 + nc) tensor of models.py:418 / :554 is never written.  Same list of (n_i, 6) tensors as
+    non_max_suppression(model(x)[0], ...), BIT for bit; also with a class filter, and when the batch is split into image chunks."""
+    from engine import nms as hnms
+    from utils.utils import non_max_suppression
+    if not os.path.exists(os.path.join(cfg_dir, rel)):
+        pytest.skip('cfg not in this checkout')
+    model = build_mirror(cfg_dir, rel, size).cuda()
+    model.hip_precision = precision
+    x = synth.image_batch(5, size, seed=33).cuda()
+    with torch.no_grad():
+        inf = model(x)[0].clone()
+    if ml and inf.shape[2] > 6:      # random heads: every score sits near 0.25 - put the threshold under the 1500 best (row, class) scores
+        conf = float((inf[..., 5:] * inf[..., 4:5]).flatten().topk(1500).values[-1])
+    else:
+        conf = float(inf[..., 4].flatten().float().quantile(0.97))      # ~ 3 % of the rows carry objectness
+    monkeypatch.setattr(hnms, '_density', {})
+    two = non_max_suppression(inf, conf, 0.6, multi_label=ml)
+    with torch.no_grad():
+        one = model.hip_detect(x, conf, 0.6, multi_label=ml)
+        _same(one, two, 'fused vs two-pass')
+        assert sum(0 if d is None else d.shape[0] for d in one) >= 20
+        nc = inf.shape[2] - 5
+        if nc > 1:
+            pick = [0, nc - 1]
+            _same(model.hip_detect(x, conf, 0.6, multi_label=ml, classes=pick), non_max_suppression(inf, conf, 0.6, multi_label=ml, classes=pick),
+                  'class filter')
+        monkeypatch.setattr(hnms, '_density', {})
+        mmax = max(int((inf[i, :, 4] > conf).sum()) for i in range(5)) * (nc if ml else 1)
+        cap = hnms._pow2_at_least(max(mmax, 1))
+        monkeypatch.setattr(hnms, '_WORK_BUDGET', 2 * (cap * ((cap + 63) // 64) * 8 + cap * 23 * 4 + 14 * cap) + 4096)      # two images per pass
+        _same(model.hip_detect(x, conf, 0.6, multi_label=ml), two, 'image chunks')
+        monkeypatch.undo()
+        monkeypatch.setenv('YOLO_HIP_FUSED_DETECT', '0')
+        _same(model.hip_detect(x, conf, 0.6, multi_label=ml), two, 'switched off')
+
+
+def test_fused_detection_on_the_int8_engine_and_on_the_eager_path():
+    """The int8 engine's heads are fp32 too (the head convolution dequantises): hip_detect equals the two calls there as well; on a CPU
+    model (eager modules) hip_detect IS the two calls."""
+    from utils.utils import non_max_suppression
+    from test_ptq import build_qmodel
+    from ptq_minicfg import SIZE
+    m, _ = build_qmodel()
+    x = synth.image_batch(3, SIZE, seed=7)
+    with torch.no_grad():
+        cpu_inf = m(x)[0]
+        conf = float(cpu_inf[..., 4].flatten().quantile(0.95)) * 0.999
+        _same(m.hip_detect(x, conf, 0.6), non_max_suppression(cpu_inf, conf, 0.6, multi_label=False), 'eager')
+        m.cuda()
+        inf = m(x.cuda())[0].clone()
+        assert m.__dict__['_hip_engine'].precision == 'int8'
+        two = non_max_suppression(inf, conf, 0.6, multi_label=False)
+        assert sum(0 if d is None else d.shape[0] for d in two) >= 5
+        _same(m.hip_detect(x.cuda(), conf, 0.6), two, 'int8 fused vs two-pass')

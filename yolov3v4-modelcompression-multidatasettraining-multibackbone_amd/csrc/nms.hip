@@ -112,6 +112,71 @@ __global__ __launch_bounds__(256) void nms_candidates_kernel(const float* __rest
     }
 }
 
+// ---- decode + candidates in one pass over the head convolutions' outputs (round 5) -------------------
+// YOLOLayer.forward's eval branch (models.py:406-418) followed by the candidate filter above (utils.py:799-827), without the (n, rows,
+// 5 + nc) tensor in between: at 608 x 608, batch 64 the decode writes 495 MB of which the filter keeps ~100 rows per image.  One thread
+// per prediction row reads the row's objectness logit; only rows above the threshold (0.4 % at detect.py's settings) are decoded at all.
+// Every decoded value is the decode kernels' (csrc/elementwise.hip: rcp_fast(1 + exp_fast(-v)), (sigmoid + cell) * stride, (exp_fast(v) *
+// anchor) * stride), every candidate test is the kernels' above on those values, the key is the row's position in the concatenated tensor:
+// the records equal the two-pass path's as a set, and the sort makes the rest identical.
+__device__ __forceinline__ float dec_sigmoid(float v) { return rcp_fast(1.f + exp_fast(-v)); }
+
+template <bool ML>
+__global__ __launch_bounds__(256) void yolo_decode_candidates_kernel(const yh_decode_desc d, const float conf,
+                                                                     const uint8_t* __restrict__ class_mask, float* cand,
+                                                                     int32_t* count, const int cap) {
+    __shared__ float anchor[16];
+    if (threadIdx.x < 16) anchor[threadIdx.x] = threadIdx.x < 8 ? d.anchor_w[threadIdx.x & 7] : d.anchor_h[threadIdx.x & 7];
+    __syncthreads();
+    const int nc = d.no - 5, cells = d.ny * d.nx;
+    const long per_img = (long)d.na * cells, total = per_img * d.n;
+    const long span = (long)gridDim.x * blockDim.x;
+    const long iters = (total + span - 1) / span;
+    for (long it = 0; it < iters; ++it) {
+        const long i = it * span + blockIdx.x * (long)blockDim.x + threadIdx.x;
+        bool live = i < total;
+        const long ii = live ? i : 0;
+        const int img = (int)(ii / per_img);
+        const int r = (int)(ii - (long)img * per_img);      // row inside this head: (a ny + y) nx + x (models.py:416 view order)
+        const int a = r / cells, yx = r - a * cells, y = yx / d.nx, x = yx - y * d.nx;
+        const float* src = d.p + (((long)img * d.ny + y) * d.nx + x) * d.ldp + a * d.no;
+        const float obj = dec_sigmoid(src[4]);
+        live = live && obj > conf;
+        if (__ballot(live) == 0ull) continue;                // wave-uniform: emit() needs every lane of a wave
+        float x1 = 0.f, y1 = 0.f, x2 = 0.f, y2 = 0.f;
+        if (live) {
+            const float cx = (dec_sigmoid(src[0]) + (float)x) * d.stride, cy = (dec_sigmoid(src[1]) + (float)y) * d.stride;
+            const float w = (exp_fast(src[2]) * anchor[a]) * d.stride, h = (exp_fast(src[3]) * anchor[8 + a]) * d.stride;
+            live = w > kMinWH && w < kMaxWH && h > kMinWH && h < kMaxWH;
+            x1 = cx - w / 2; y1 = cy - h / 2; x2 = cx + w / 2; y2 = cy + h / 2;
+        }
+        const int row = d.row_off + r;
+        if constexpr (ML) {
+            for (int c = 0; c < nc; ++c) {
+                bool want = live;
+                float sc = 0.f;
+                if (live) {
+                    sc = dec_sigmoid(src[5 + c]) * obj;
+                    want = sc > conf && (!class_mask || class_mask[c]) && finite6(x1, y1, x2, y2, sc);
+                }
+                emit(cand, count, img, cap, want, x1, y1, x2, y2, sc, c, row * nc + c);
+            }
+        } else {
+            float best = 0.f;
+            int bc = 0;
+            if (live) {
+                best = dec_sigmoid(src[5]) * obj;
+                for (int c = 1; c < nc; ++c) {
+                    const float sv = dec_sigmoid(src[5 + c]) * obj;
+                    if (sv > best) { best = sv; bc = c; }
+                }
+            }
+            const bool want = live && (!class_mask || class_mask[bc]) && finite6(x1, y1, x2, y2, best);
+            emit(cand, count, img, cap, want, x1, y1, x2, y2, best, bc, row * nc + bc);
+        }
+    }
+}
+
 __device__ __forceinline__ unsigned long long sort_key(float score, int key) {
     // scores are finite and > 0 here: their bit patterns order like the values
     const unsigned sb = 0xFFFFFFFFu - __float_as_uint(score);
@@ -619,6 +684,23 @@ extern "C" int yh_nms_candidates(const float* pred, int n, int rows, int nc, flo
                            class_mask, cand, count, cap);
     else
         hipLaunchKernelGGL(nms_candidates_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, pred, n, rows, nc, conf_thres,
+                           class_mask, cand, count, cap);
+    return check_launch();
+}
+
+extern "C" int yh_yolo_decode_candidates(const yh_decode_desc* d, float conf_thres, int multi_label, const uint8_t* class_mask,
+                                         float* cand, int32_t* count, int cap, void* stream) {
+    if (!d || !d->p || !count || d->n <= 0 || d->ny <= 0 || d->nx <= 0 || d->na <= 0 || d->na > 8 || d->no <= 5 || cap < 0) return YH_EINVAL;
+    if (cand && !aligned16(cand)) return YH_EALIGN;
+    if ((long)d->rows_total * (d->no - 5) > 0x7fffffffL) return YH_EUNSUPPORTED;      // the key is a 32-bit row * nc + cls
+    const long total = (long)d->n * d->na * d->ny * d->nx;
+    long g = (total + 255) / 256;
+    if (g > 65536) g = 65536;
+    if (multi_label)
+        hipLaunchKernelGGL(yolo_decode_candidates_kernel<true>, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, *d, conf_thres,
+                           class_mask, cand, count, cap);
+    else
+        hipLaunchKernelGGL(yolo_decode_candidates_kernel<false>, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, *d, conf_thres,
                            class_mask, cand, count, cap);
     return check_launch();
 }

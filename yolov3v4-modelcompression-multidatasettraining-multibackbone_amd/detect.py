@@ -68,10 +68,15 @@ def detect(opt, save_img=True):
             x = x.unsqueeze(0)
         t1 = torch_utils.time_synchronized()
         with torch.no_grad():
-            pred = model(x, augment=opt.augment)[0]
-        t2 = torch_utils.time_synchronized()
-        pred = non_max_suppression(pred.float(), opt.conf_thres, opt.iou_thres, multi_label=False, classes=opt.classes,
-                                   agnostic=opt.agnostic_nms)
+            if opt.augment or not hasattr(model, 'hip_detect'):
+                pred = model(x, augment=opt.augment)[0]
+                t2 = torch_utils.time_synchronized()
+                pred = non_max_suppression(pred.float(), opt.conf_thres, opt.iou_thres, multi_label=False, classes=opt.classes,
+                                           agnostic=opt.agnostic_nms)
+            else:      # forward + NMS as one engine call (models.Darknet.hip_detect: same boxes, no decoded tensor in between)
+                pred = model.hip_detect(x, opt.conf_thres, opt.iou_thres, multi_label=False, classes=opt.classes,
+                                        agnostic=opt.agnostic_nms)
+                t2 = torch_utils.time_synchronized()
         for det in pred:
             save_path = str(Path(out) / Path(path).name)
             s = '%gx%g ' % tuple(x.shape[2:])

@@ -257,6 +257,7 @@ _SIGNATURES = {
     'yh_copy_channels': (C.c_int, [C.POINTER(CopyDesc), _vp]),
     'yh_add_channels': (C.c_int, [C.POINTER(AddDesc), _vp]),
     'yh_yolo_decode': (C.c_int, [C.POINTER(DecodeDesc), _vp]),
+    'yh_yolo_decode_candidates': (C.c_int, [C.POINTER(DecodeDesc), _f32, C.c_int, _vp, _vp, _vp, C.c_int, _vp]),
     'yh_nms_candidates': (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _f32, C.c_int, _vp, _vp, _vp, C.c_int, _vp]),
     'yh_nms_sort': (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp]),
     'yh_nms_sort_cls': (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp]),

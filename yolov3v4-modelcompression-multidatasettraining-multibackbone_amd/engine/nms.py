@@ -25,6 +25,7 @@ above 2048 candidates, or candidates spread over more than 4096 pixels in x and 
 sort of ``yh_nms_sort_tiles`` (``YOLO_HIP_NMS_SORT=count``: the counting sort of the bit-mask form).
 """
 import collections
+import ctypes as C
 import os
 
 import torch
@@ -39,9 +40,54 @@ _WORK_BUDGET = 8 << 30        # bytes of candidate / mask buffers one pass may h
 _density = {}                 # multi_label -> deque of the last candidate densities (max candidates of an image / rows)
 
 
+class _Rows:
+    """Where the candidates come from: the decoded (N, rows, 5 + nc) tensor (yh_nms_candidates) ..."""
+
+    def __init__(self, pred):
+        if pred.dim() != 3:
+            raise ValueError('expected (N, rows, 5 + nc)')
+        pred = pred.contiguous()
+        self.pred = pred if pred.dtype == torch.float32 else pred.float()
+        self.n, self.rows, no = self.pred.shape
+        self.nc, self.device = no - 5, self.pred.device
+
+    def candidates(self, lib, conf, ml, cmask, cand, count, cap, stream):
+        hiplib.check(lib.yh_nms_candidates(hiplib.ptr(self.pred), self.n, self.rows, self.nc, conf, ml, hiplib.ptr(cmask), hiplib.ptr(cand),
+                                           hiplib.ptr(count), cap, stream), 'nms candidates')
+
+    def images(self, i0, i1):
+        return _Rows(self.pred[i0:i1])
+
+
+class _Heads:
+    """... or the head convolutions' outputs themselves (yh_yolo_decode_candidates: decode and filter in one pass, DarknetEngine.detect)."""
+
+    def __init__(self, descs, n, rows, nc, device):
+        self.descs, self.n, self.rows, self.nc, self.device = descs, n, rows, nc, device
+
+    def candidates(self, lib, conf, ml, cmask, cand, count, cap, stream):
+        for d in self.descs:
+            hiplib.check(lib.yh_yolo_decode_candidates(C.byref(d), conf, ml, hiplib.ptr(cmask), hiplib.ptr(cand), hiplib.ptr(count), cap,
+                                                       stream), 'decode + candidates')
+
+    def images(self, i0, i1):
+        part = []
+        for d in self.descs:
+            e = hiplib.DecodeDesc.from_buffer_copy(d)
+            e.p = d.p + i0 * d.ny * d.nx * d.ldp * 4          # fp32 NHWC with pitch ldp, image-major
+            e.n = i1 - i0
+            part.append(e)
+        return _Heads(part, i1 - i0, self.rows, self.nc, self.device)
+
+
 def non_max_suppression(prediction, conf_thres=0.1, iou_thres=0.6, multi_label=True, classes=None, agnostic=False):
     with hiplib.on_device(prediction):
-        return _non_max_suppression(prediction, conf_thres, iou_thres, multi_label, classes, agnostic)
+        return _non_max_suppression(_Rows(prediction), conf_thres, iou_thres, multi_label, classes, agnostic)
+
+
+def non_max_suppression_heads(descs, n, rows, nc, device, conf_thres=0.1, iou_thres=0.6, multi_label=True, classes=None, agnostic=False):
+    """The same call on the yolo heads' raw outputs (``descs``: one yh_decode_desc per head, as the plan holds them)."""
+    return _non_max_suppression(_Heads(descs, n, rows, nc, device), conf_thres, iou_thres, multi_label, classes, agnostic)
 
 
 def _pow2_at_least(v):
@@ -51,16 +97,9 @@ def _pow2_at_least(v):
     return c
 
 
-def _non_max_suppression(prediction, conf_thres, iou_thres, multi_label, classes, agnostic):
+def _non_max_suppression(src, conf_thres, iou_thres, multi_label, classes, agnostic):
     lib = hiplib.load()
-    if prediction.dim() != 3:
-        raise ValueError('expected (N, rows, 5 + nc)')
-    pred = prediction.contiguous()
-    if pred.dtype != torch.float32:
-        pred = pred.float()
-    n, rows, no = pred.shape
-    nc = no - 5
-    dev = pred.device
+    n, rows, nc, dev = src.n, src.rows, src.nc, src.device
     P, S = hiplib.ptr, hiplib.stream_ptr()
     cmask = None
     if classes:
@@ -108,13 +147,13 @@ def _non_max_suppression(prediction, conf_thres, iou_thres, multi_label, classes
         step = max(1, int(budget() // each))
         out = []
         for i in range(0, n, step):
-            out += _non_max_suppression(pred[i:i + step], conf_thres, iou_thres, multi_label, classes, agnostic)
+            out += _non_max_suppression(src.images(i, min(n, i + step)), conf_thres, iou_thres, multi_label, classes, agnostic)
         return out
 
     if (not seg and n * cap * ((cap + 63) // 64) * 8 > _MASK_BUDGET) or too_big(cap, not seg):
         # a guessed bound this large is not worth its mask: count first (one extra 4n-byte read), then size exactly
         count = torch.zeros(n, dtype=torch.int32, device=dev)
-        hiplib.check(lib.yh_nms_candidates(P(pred), n, rows, nc, conf_thres, ml, P(cmask), None, P(count), 0, S), 'nms count')
+        src.candidates(lib, conf_thres, ml, cmask, None, count, 0, S)
         cmax = max(int(count.max()), 1)
         cap, exact = _pow2_at_least(cmax), True
         if too_big(cap, not seg):
@@ -124,7 +163,7 @@ def _non_max_suppression(prediction, conf_thres, iou_thres, multi_label, classes
         ctl = torch.zeros((10, n), dtype=torch.int32, device=dev)     # row 0: candidates per image, row 1: survivors, rest: state [n][8]
         count, n_keep, state = ctl[0], ctl[1], ctl[2:].view(n, 8)
         cand = torch.empty((n, cap, 8), dtype=torch.float32, device=dev)
-        hiplib.check(lib.yh_nms_candidates(P(pred), n, rows, nc, conf_thres, ml, P(cmask), P(cand), P(count), cap, S), 'nms cand')
+        src.candidates(lib, conf_thres, ml, cmask, cand, count, cap, S)
         srt = torch.empty_like(cand)
         keep_idx = torch.empty((n, cap), dtype=torch.int32, device=dev)
         res = torch.empty((n, cap, 6), dtype=torch.float32, device=dev)

@@ -661,6 +661,8 @@ class DarknetEngine:
         no = heads[0].no
         off = 0
         plan['raw_shapes'] = []
+        plan['decode_descs'] = []                       # the heads as yh_yolo_decode_candidates takes them (detect())
+        plan['first_decode_op'] = len(plan['ops'])      # the decode ops are the last ops of the plan
         for k, h in enumerate(heads):
             if h.no != no:
                 raise ValueError('yolo heads disagree on the class count')
@@ -674,6 +676,7 @@ class DarknetEngine:
             fixup(op, DecodeDesc, 'io', SLOT_IO)
             fixup(op, DecodeDesc, 'raw', SLOT_RAW0 + k)      # bound to NULL per call when the caller does not want the copies
             plan['raw_shapes'].append((N, h.na, s.H, s.W, h.no))
+            plan['decode_descs'].append(DecodeDesc.from_buffer_copy(d))
             off += h.na * s.H * s.W
         plan['rows'], plan['no'] = rows, no
         return plan
@@ -693,6 +696,48 @@ class DarknetEngine:
         self._signature = self._current_signature()
 
     def __call__(self, x):
+        x, plan = self._plan_for(x)
+        N = x.shape[0]
+        lib, handle = self.lib, plan['handle']
+        if 0 < N <= self.graph_max_batch and x.is_cuda and hasattr(lib, 'yh_plan_graph_launch'):
+            io, raws = self._run_graph(plan, x)
+        else:
+            io = torch.empty((N, plan['rows'], plan['no']), device=x.device, dtype=torch.float32)
+            raws = [torch.empty(shape, device=x.device, dtype=torch.float32) for shape in plan['raw_shapes']] \
+                if self.want_raw else []
+            lib.yh_plan_bind_slot(handle, SLOT_INPUT, x.data_ptr())
+            lib.yh_plan_bind_slot(handle, SLOT_IO, io.data_ptr())
+            for k in range(len(plan['raw_shapes'])):
+                lib.yh_plan_bind_slot(handle, SLOT_RAW0 + k, raws[k].data_ptr() if raws else hiplib.SLOT_NULL)
+            hiplib.check(lib.yh_plan_run(handle, hiplib.stream_ptr()), 'yh_plan_run')
+        feats = self._features(plan) if self.return_features else []
+        return io, tuple(raws), feats
+
+    def detect(self, x, conf_thres=0.3, iou_thres=0.6, multi_label=False, classes=None, agnostic=False):
+        """``non_max_suppression(model(x)[0], ...)`` (reference detect.py:104-109) without the decoded (N, rows, 5 + nc) tensor: the plan
+        runs up to the head convolutions, ``yh_yolo_decode_candidates`` decodes only the rows whose objectness passes ``conf_thres``
+        straight into the NMS candidate records, the remaining NMS steps are ``engine/nms.py``'s.  Same list of (n_i, 6) tensors,
+        bit for bit (tests/test_gpu_nms.py).  Small batches keep the hipGraph replay of ``__call__`` (launch-bound there)."""
+        from . import nms as hnms
+        x, plan = self._plan_for(x)
+        N = x.shape[0]
+        lib, handle = self.lib, plan['handle']
+        if (0 < N <= self.graph_max_batch and x.is_cuda and hasattr(lib, 'yh_plan_graph_launch')) or self.return_features \
+                or os.environ.get('YOLO_HIP_FUSED_DETECT', '1') == '0':
+            keep = self.want_raw
+            self.want_raw = False
+            try:
+                io = self(x)[0]
+            finally:
+                self.want_raw = keep
+            return hnms.non_max_suppression(io, conf_thres, iou_thres, multi_label, classes, agnostic)
+        lib.yh_plan_bind_slot(handle, SLOT_INPUT, x.data_ptr())
+        hiplib.check(lib.yh_plan_run_range(handle, 0, plan['first_decode_op'], hiplib.stream_ptr()), 'yh_plan_run_range')
+        return hnms.non_max_suppression_heads(plan['decode_descs'], N, plan['rows'], plan['no'] - 5, x.device, conf_thres, iou_thres,
+                                              multi_label, classes, agnostic)
+
+    def _plan_for(self, x):
+        """The checks of a call and the plan of this input shape (built on first use)."""
         if x.dim() != 4:
             raise ValueError('expected an (N, C, H, W) batch')
         x = x.contiguous()
@@ -740,21 +785,7 @@ class DarknetEngine:
             plan = self._plans[key] = self._build_plan(N, Cin, H, W)
         else:
             self._plans[key] = self._plans.pop(key)   # most recently used last
-
-        lib, handle = self.lib, plan['handle']
-        if 0 < N <= self.graph_max_batch and x.is_cuda and hasattr(lib, 'yh_plan_graph_launch'):
-            io, raws = self._run_graph(plan, x)
-        else:
-            io = torch.empty((N, plan['rows'], plan['no']), device=x.device, dtype=torch.float32)
-            raws = [torch.empty(shape, device=x.device, dtype=torch.float32) for shape in plan['raw_shapes']] \
-                if self.want_raw else []
-            lib.yh_plan_bind_slot(handle, SLOT_INPUT, x.data_ptr())
-            lib.yh_plan_bind_slot(handle, SLOT_IO, io.data_ptr())
-            for k in range(len(plan['raw_shapes'])):
-                lib.yh_plan_bind_slot(handle, SLOT_RAW0 + k, raws[k].data_ptr() if raws else hiplib.SLOT_NULL)
-            hiplib.check(lib.yh_plan_run(handle, hiplib.stream_ptr()), 'yh_plan_run')
-        feats = self._features(plan) if self.return_features else []
-        return io, tuple(raws), feats
+        return x, plan
 
     def _run_graph(self, plan, x):
         """Small-batch path: static I/O buffers + one hipGraph launch; results are copied out (fresh tensors).

@@ -489,6 +489,24 @@ class Darknet(nn.Module):
         with _on_device(x.device):   # kernels launch on the current device / stream: make it the input's
             return eng(x)
 
+    def hip_detect(self, x, conf_thres=0.3, iou_thres=0.6, multi_label=False, classes=None, agnostic=False):
+        """``non_max_suppression(self(x)[0], conf_thres, iou_thres, ...)`` - what detect.py does with a batch (reference
+        detect.py:104-109) - as ONE engine call: on the HIP path the decoded (N, rows, 5 + nc) tensor is never written, the yolo
+        heads' outputs are decoded and filtered in one pass straight into the NMS candidate records (engine/plan.py ``detect``).
+        Same result, bit for bit; on the eager path (CPU, training mode) it is literally the two calls."""
+        from utils.utils import non_max_suppression
+        if not self._use_hip(x):
+            return non_max_suppression(self(x)[0], conf_thres, iou_thres, multi_label=multi_label, classes=classes, agnostic=agnostic)
+        from engine.plan import DarknetEngine
+        eng = self.__dict__.get('_hip_engine')
+        precision = 'int8' if self.quantized == 3 else self.hip_precision
+        if eng is None or eng.precision != precision:
+            eng = DarknetEngine(self, precision=precision)
+            self.__dict__['_hip_engine'] = eng
+        eng.return_features = False
+        with _on_device(x.device):
+            return eng.detect(x, conf_thres, iou_thres, multi_label, classes, agnostic)
+
     def _forward_eager(self, x, augment=False, verbose=False):
         img_size = x.shape[-2:]
         yolo_out, out, feature_out = [], [], []
