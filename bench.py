@@ -11,8 +11,10 @@ autocast with fp32 master weights) and the detection leg (configs[1]: forward + 
   + nesterov SGD (reference train.py:371-433), all convolution / BatchNorm / activation work on libyolo_hip.so.
   N > 1: one process per GPU, DistributedDataParallel over RCCL, per-GPU batch fixed (weak scaling), gradients
   all-reduced by DDP's hooks.
-* detect step = Darknet eval forward (BN folded, fused epilogues, 3-scale YOLO decode) + NMS at detect.py's settings
-  (conf 0.3, iou 0.6, best class) on a batch already resident in HBM.  N > 1: replicas only (no exchange).
+* detect step = detect.py's loop body on a batch already resident in HBM: Darknet eval forward (BN folded, fused epilogues),
+  3-scale YOLO decode and NMS at detect.py's settings (conf 0.3, iou 0.6, best class) - since round 5 as model.hip_detect (decode
+  fused into the NMS candidate filter, same detections bit for bit; --two-pass-nms: model(x) then non_max_suppression, rounds 1 - 4).
+  N > 1: replicas only (no exchange).
 
 Synthetic data and random-init weights (no network access).  Timing: W warm-up steps, then exactly K steps bracketed
 by barrier + synchronize on both sides, MAX over ranks (engine/distutil.py).  Rank 0 prints ONE JSON line; besides the
