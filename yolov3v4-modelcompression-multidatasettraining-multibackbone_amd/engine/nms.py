@@ -112,7 +112,7 @@ def _non_max_suppression(src, conf_thres, iou_thres, multi_label, classes, agnos
     cap = min(guess, _pow2_at_least(most))
     ag = 1 if agnostic else 0
     how = os.environ.get('YOLO_HIP_NMS_SEGMENTED', '')
-    seg = (not ag) and nc <= 255 and how != '0' and (ml == 1 or how == '1')
+    seg = (not ag) and nc <= 255 and n <= 65535 and how != '0' and (ml == 1 or how == '1')
     exact = False
     work_budget = {}      # resolved at most once per call, and only when a pass is large enough to ask (budget())
 
