@@ -397,6 +397,203 @@ class FakeLib:
             flat(d.raw, raw.numel(), np.float32)[:] = raw.reshape(-1).numpy()
         return 0
 
+    # ---- non-maximum suppression (csrc/nms.hip): records of 8 floats, int32 counts, fp32 arithmetic in the kernels' operation order
+    _MIN_WH, _MAX_WH, _SEG_MAX = np.float32(2.0), np.float32(4096.0), 2048
+
+    def _emit(self, cand, count, cap, img, recs):
+        """Append records (list of 8-float rows) of image `img` at the cursor; counts run on past the bound like the kernels'."""
+        cnt = flat(count, img + 1, np.int32)
+        if _addr(cand):
+            room = max(0, min(len(recs), cap - int(cnt[img])))
+            if room:
+                dst = flat(cand, (img + 1) * cap * 8, np.float32).reshape(img + 1, cap, 8)
+                dst[img, int(cnt[img]):int(cnt[img]) + room] = np.asarray(recs[:room], np.float32)
+        cnt[img] += len(recs)
+
+    def _rows_to_records(self, x, row0, nc, conf, ml, mask):
+        """x: (rows, 5 + nc) decoded rows of one image -> records in the kernels' filter order (utils.py:799-827)."""
+        f = np.float32
+        conf = f(conf)
+        recs = []
+        live = np.nonzero(x[:, 4] > conf)[0]
+        for r in live:
+            cx, cy, w, h, obj = x[r, :5]
+            if not (w > self._MIN_WH and w < self._MAX_WH and h > self._MIN_WH and h < self._MAX_WH):
+                continue
+            box = [f(cx - w / f(2)), f(cy - h / f(2)), f(cx + w / f(2)), f(cy + h / f(2))]
+            sc = (x[r, 5:] * obj).astype(np.float32)
+            if ml:
+                pick = [c for c in range(nc) if sc[c] > conf]
+            else:
+                pick = [int(np.argmax(sc))]      # first maximum, like the kernel's strict '>' scan
+            for c in pick:
+                if mask is not None and not mask[c]:
+                    continue
+                if not np.isfinite(box + [sc[c]]).all():
+                    continue
+                key = np.array([(row0 + r) * nc + c], np.int32).view(np.float32)[0]
+                recs.append(box + [sc[c], f(c), key, f(0)])
+        return recs
+
+    def yh_nms_candidates(self, pred, n, rows, nc, conf, ml, class_mask, cand, count, cap, stream):
+        x = flat(pred, n * rows * (5 + nc), np.float32).reshape(n, rows, 5 + nc)
+        mask = flat(class_mask, nc, np.uint8) if _addr(class_mask) else None
+        for i in range(n):
+            self._emit(cand, count, cap, i, self._rows_to_records(x[i], 0, nc, conf, ml, mask))
+        self.calls.append('nms_candidates')
+        return 0
+
+    def yh_yolo_decode_candidates(self, dref, conf, ml, class_mask, cand, count, cap, stream):
+        d = dref._obj if hasattr(dref, '_obj') else dref
+        rows, nc = d.na * d.ny * d.nx, d.no - 5
+        io = np.zeros((d.n, d.rows_total, d.no), np.float32)      # the decode emulation's values for this head, then the same filter
+        e = DecodeDesc.from_buffer_copy(d)
+        e.io, e.raw = io.ctypes.data, None
+        self.yh_yolo_decode(e, stream)
+        mask = flat(class_mask, nc, np.uint8) if _addr(class_mask) else None
+        for i in range(d.n):
+            self._emit(cand, count, cap, i, self._rows_to_records(io[i, d.row_off:d.row_off + rows], d.row_off, nc, conf, ml, mask))
+        self.calls.append('decode_candidates')
+        return 0
+
+    def _order(self, rec):
+        key = rec[:, 6].copy().view(np.int32)
+        return np.lexsort((key, -rec[:, 4].astype(np.float64)))      # score descending, ties by ascending key
+
+    def yh_nms_sort(self, cand, count, n, cap, mmax, sorted_, stream, cls8=None):
+        src = flat(cand, n * cap * 8, np.float32).reshape(n, cap, 8)
+        dst = flat(sorted_, n * cap * 8, np.float32).reshape(n, cap, 8)
+        cnt = flat(count, n, np.int32)
+        for i in range(n):
+            m = min(int(cnt[i]), cap)
+            dst[i, :m] = src[i, :m][self._order(src[i, :m])]
+            if _addr(cls8):
+                flat(cls8, n * cap, np.uint8).reshape(n, cap)[i, :m] = dst[i, :m, 5].astype(np.uint8)
+        return 0
+
+    def yh_nms_sort_cls(self, cand, count, n, cap, mmax, sorted_, cls8, stream):
+        return self.yh_nms_sort(cand, count, n, cap, mmax, sorted_, stream, cls8=cls8)
+
+    def yh_nms_sort_tiles(self, cand, count, n, cap, mmax, sorted_, cls8, ws, ws_bytes, stream):
+        assert cap >= 256 and cap & (cap - 1) == 0 and ws_bytes >= n * cap * 12 and _addr(ws)
+        return self.yh_nms_sort(cand, count, n, cap, mmax, sorted_, stream, cls8=cls8)
+
+    @staticmethod
+    def _iou_matrix(a, b):
+        """IoU of every box of a against every box of b, fp32, the kernels' operation order (iou_off)."""
+        f = np.float32
+        iw = np.maximum(np.minimum(a[:, None, 2], b[None, :, 2]) - np.maximum(a[:, None, 0], b[None, :, 0]), f(0))
+        ih = np.maximum(np.minimum(a[:, None, 3], b[None, :, 3]) - np.maximum(a[:, None, 1], b[None, :, 1]), f(0))
+        inter = (iw * ih).astype(f)
+        aa = ((a[:, 2] - a[:, 0]) * (a[:, 3] - a[:, 1])).astype(f)
+        ab = ((b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1])).astype(f)
+        with np.errstate(all='ignore'):
+            return (inter / ((aa[:, None] + ab[None, :]).astype(f) - inter)).astype(f)
+
+    def _offset(self, rec, agnostic):
+        off = (rec[:, 5] * (np.float32(0) if agnostic else self._MAX_WH)).astype(np.float32)
+        return (rec[:, :4] + off[:, None]).astype(np.float32)
+
+    @staticmethod
+    def _greedy(over):
+        """over[i, j] (j > i): i suppresses j.  Kept indices in order."""
+        m = over.shape[0]
+        dead = np.zeros(m, bool)
+        keep = []
+        for i in range(m):
+            if dead[i]:
+                continue
+            keep.append(i)
+            dead[i + 1:] |= over[i, i + 1:]
+        return keep
+
+    def yh_nms_mask(self, sorted_, count, n, cap, mmax, thr, agnostic, mask, stream):
+        rec = flat(sorted_, n * cap * 8, np.float32).reshape(n, cap, 8)
+        cnt = flat(count, n, np.int32)
+        words = (mmax + 63) // 64
+        bits = flat(mask, n * mmax * words, np.uint64).reshape(n, mmax, words)
+        for i in range(n):
+            m = min(int(cnt[i]), cap)
+            box = self._offset(rec[i, :m], agnostic)
+            over = np.triu(self._iou_matrix(box, box) > np.float32(thr), 1)
+            pad = np.zeros((m, words * 64), bool)
+            pad[:, :m] = over
+            bits[i, :m] = np.packbits(pad.reshape(m, words, 64), axis=2, bitorder='little').view(np.uint64).reshape(m, words)
+        self.calls.append('nms_mask')
+        return 0
+
+    def yh_nms_reduce(self, mask, count, n, cap, mmax, keep_idx, n_keep, stream):
+        cnt = flat(count, n, np.int32)
+        words = (mmax + 63) // 64
+        bits = flat(mask, n * mmax * words, np.uint64).reshape(n, mmax, words)
+        kidx = flat(keep_idx, n * cap, np.int32).reshape(n, cap)
+        nk = flat(n_keep, n, np.int32)
+        for i in range(n):
+            m = min(int(cnt[i]), cap)
+            over = np.unpackbits(bits[i, :m].view(np.uint8).reshape(m, words * 8), axis=1, bitorder='little')[:, :m].astype(bool)
+            keep = self._greedy(over)
+            kidx[i, :len(keep)] = keep
+            nk[i] = len(keep)
+        return 0
+
+    def yh_nms_class_scan(self, sorted_, cls8, count, n, cap, nc, thr, keep8, state, keep_idx, n_keep, stream):
+        if nc > 255 or n > 65535:
+            return hiplib.YH_EUNSUPPORTED if hasattr(hiplib, 'YH_EUNSUPPORTED') else -6
+        rec = flat(sorted_, n * cap * 8, np.float32).reshape(n, cap, 8)
+        cl = flat(cls8, n * cap, np.uint8).reshape(n, cap)
+        cnt = flat(count, n, np.int32)
+        st = flat(state, n * 8, np.uint32).reshape(n, 8)
+        kidx = flat(keep_idx, n * cap, np.int32).reshape(n, cap)
+        nk = flat(n_keep, n, np.int32)
+        for i in range(n):
+            assert st[i, 0] == 0 and st[i, 1] == 0xFFFFFFFF and st[i, 2] == 0xFFFFFFFF and st[i, 3] == 0 and st[i, 4] == 0, 'state not initialised'
+            m = min(int(cnt[i]), cap)
+            nk[i], st[i, 5] = 0, 0
+            if m == 0:
+                continue
+            r = rec[i, :m]
+            general = bool(np.bincount(cl[i, :m], minlength=nc).max() > self._SEG_MAX)
+            ex = float(r[:, 2].max()) - float(r[:, 0].min())
+            ey = float(r[:, 3].max()) - float(r[:, 1].min())
+            general = general or not (ex <= 4096.0 or ey <= 4096.0)
+            if general:
+                st[i, 5] = 1
+                continue
+            box = self._offset(r, 0)
+            keep = np.zeros(m, bool)
+            for c in range(nc):
+                pos = np.nonzero(cl[i, :m] == c)[0]
+                if len(pos):
+                    over = np.triu(self._iou_matrix(box[pos], box[pos]) > np.float32(thr), 1)
+                    keep[pos[self._greedy(over)]] = True
+            k = np.nonzero(keep)[0]
+            kidx[i, :len(k)] = k
+            nk[i] = len(k)
+        self.calls.append('nms_class_scan')
+        return 0
+
+    def yh_nms_merge(self, sorted_, count, keep_idx, n_keep, n, cap, kmax, thr, agnostic, merge_lo, merge_hi, out, stream):
+        rec = flat(sorted_, n * cap * 8, np.float32).reshape(n, cap, 8)
+        cnt = flat(count, n, np.int32)
+        kidx = flat(keep_idx, n * cap, np.int32).reshape(n, cap)
+        nk = flat(n_keep, n, np.int32)
+        res = flat(out, n * cap * 6, np.float32).reshape(n, cap, 6)
+        for i in range(n):
+            m, k = min(int(cnt[i]), cap), int(nk[i])
+            if k == 0:
+                continue
+            r = rec[i, :m]
+            keep = kidx[i, :k]
+            boxes = r[keep, :4].copy()
+            if merge_lo < m < merge_hi:
+                off = self._offset(r, agnostic)
+                w = (self._iou_matrix(off[keep], off) > np.float32(thr)).astype(np.float32) * r[None, :, 4]
+                boxes = ((w @ r[:, :4]) / w.sum(1, keepdims=True)).astype(np.float32)
+            res[i, :k, :4] = boxes
+            res[i, :k, 4] = r[keep, 4]
+            res[i, :k, 5] = r[keep, 5]
+        return 0
+
     # ---- training path
     @staticmethod
     def _act_grad(u, act, slope):
