@@ -115,13 +115,19 @@ def test(cfg, data, weights=None, batch_size=16, imgsz=416, conf_thres=0.001, io
         whwh = torch.tensor([width, height, width, height], dtype=torch.float32, device=device)
         with torch.no_grad():
             t = torch_utils.time_synchronized()
-            inf_out, train_out = model(imgs, augment=augment)[:2]
-            t_inf += torch_utils.time_synchronized() - t
-            if hasattr(model, 'hyp') and train_out is not None:
-                loss += compute_loss([x.float() for x in train_out], targets, model)[1][:3].to(device)
-            t = torch_utils.time_synchronized()
-            output = non_max_suppression(inf_out, conf_thres=conf_thres, iou_thres=iou_thres, multi_label=multi_label)
-            t_nms += torch_utils.time_synchronized() - t
+            if not augment and not hasattr(model, 'hyp') and hasattr(model, 'hip_detect'):
+                # stand-alone evaluation (no validation loss wanted): forward + NMS as one engine call - on the HIP path the decoded
+                # (N, rows, 5 + nc) tensor is never written (models.Darknet.hip_detect; same detections bit for bit)
+                output = model.hip_detect(imgs, conf_thres, iou_thres, multi_label=multi_label)
+                t_inf += torch_utils.time_synchronized() - t
+            else:
+                inf_out, train_out = model(imgs, augment=augment)[:2]
+                t_inf += torch_utils.time_synchronized() - t
+                if hasattr(model, 'hyp') and train_out is not None:
+                    loss += compute_loss([x.float() for x in train_out], targets, model)[1][:3].to(device)
+                t = torch_utils.time_synchronized()
+                output = non_max_suppression(inf_out, conf_thres=conf_thres, iou_thres=iou_thres, multi_label=multi_label)
+                t_nms += torch_utils.time_synchronized() - t
 
         for si, pred in enumerate(output):
             labels = targets[targets[:, 0] == si, 1:]
