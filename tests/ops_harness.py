@@ -207,6 +207,7 @@ def qconv(lib, x, qw, w_scale, qbias, acc_scale, out_scale, k, stride, pad, act=
         d.q_rx, d.q_ra, d.q_scale_x, d.q_scale_a, d.q_inv_scale_sum = (float(v) for v in qadd)
     rc = lib.yh_conv2d_fwd(C.byref(d), stream())
     assert rc == 0, 'yh_conv2d_fwd(i8) rc=%d' % rc
+    qconv.last_tile = int(lib.yh_conv2d_tile(C.byref(d))) if hasattr(lib, 'yh_conv2d_tile') else -1      # which kernel the call took
     return y, packed
 
 

@@ -606,11 +606,15 @@ def test_int8_mish_gives_the_exact_forms_grid_value_for_every_float(libs):
             assert slow <= 1e-3 * (b1 - b0), (inv_s, hex(b0), slow / (b1 - b0))
 
 
+@pytest.mark.parametrize('qadd', [(0.5, 2.0, 2.0 ** -4, 2.0 ** -6, 2.0 ** 3), (4.0, 1.0, 2.0 ** -6, 2.0 ** -6, 2.0 ** 5),
+                                  (1.0, 1.5, 2.0 ** -5, 2.0 ** -5, 2.0 ** 4)], ids=['general', 'pow2-exact', 'general-ra'])
 @pytest.mark.parametrize('tile,stride,cout', [(0, 1, 64), (24, 1, 64), (72, 1, 64), (72, 2, 64), (72, 1, 32), (72, 1, 128)],
                          ids=['auto', 'ring', 'stream3', 'stream3_s2', 'stream3_c32', 'stream3_c128'])
-def test_int8_fused_shortcut_matches_emulation(libs, tile, stride, cout):
+def test_int8_fused_shortcut_matches_emulation(libs, tile, stride, cout, qadd, monkeypatch):
     """The quantised shortcut that follows a conv (COSPTQuantizedShortcut, quantized_ptq_cos.py:877-912) in the conv's epilogue: the
-    same integers from every kernel that carries it (ring, streaming 3x3) and from the emulation."""
+    same integers from every kernel that carries it (ring, streaming 3x3) and from the emulation.  'pow2-exact': integer power-of-two
+    ratios as every calibrated `_min` shortcut has them - the kernels then take the exact short form (conv_igemm.h qadd_n: q A + r B,
+    every intermediate of the general arithmetic being exact), and YH_QADD_POW2=0 (general arithmetic) must give the same bytes."""
     lib, fake = libs
     g = torch.Generator().manual_seed(100 + tile + stride + cout)
     N, H, W, cin, k = 3, 37, 41, (64 if cout == 128 else 32), 3
@@ -620,15 +624,48 @@ def test_int8_fused_shortcut_matches_emulation(libs, tile, stride, cout):
     qb = torch.randint(-128, 128, (cout,), generator=g).float() * 2.0 ** -6
     Ho, Wo = (H + 2 - k) // stride + 1, (W + 2 - k) // stride + 1
     res = torch.randint(-128, 128, (N, Ho, Wo, cout), generator=g).to(torch.int8)
-    qadd = (0.5, 2.0, 2.0 ** -4, 2.0 ** -6, 2.0 ** 3)
     ys = []
     for L, dev in ((lib, GPU), (fake, 'cpu')):
         y, _ = oh.qconv(L, x.to(dev), qw.to(dev), w_scale, qb.to(dev), w_scale * x_scale, out_scale, k, stride, 1, act=1, tile=tile,
                         res=res.to(dev), qadd=qadd)
         ys.append(y.float().cpu())
+    if not DRY:
+        monkeypatch.setenv('YH_QADD_POW2', '0')
+        y, _ = oh.qconv(lib, x.to(GPU), qw.to(GPU), w_scale, qb.to(GPU), w_scale * x_scale, out_scale, k, stride, 1, act=1, tile=tile,
+                        res=res.to(GPU), qadd=qadd)
+        assert torch.equal(y.float().cpu(), ys[0]), 'short form differs from the general arithmetic'
     diff = (ys[0] - ys[1]).abs()
     assert diff.max().item() <= 1.0 and (diff > 0).float().mean().item() <= 1e-4, (diff.max().item(), (diff > 0).float().mean().item())
     assert ys[1].abs().max().item() > 20 and (ys[1].abs() == 127).float().mean().item() < 0.5       # a meaningful range, not saturated
+
+
+@pytest.mark.parametrize('qadd', [(4.0, 1.0, 2.0 ** -6, 2.0 ** -6, 2.0 ** 5), (0.5, 2.0, 2.0 ** -4, 2.0 ** -6, 2.0 ** 3)], ids=['pow2-exact', 'general'])
+def test_int8_fused_shortcut_on_the_halo_ping_pong_kernel(libs, qadd, monkeypatch):
+    """The same on conv3x3_hpp (tile 43: the kernel of the 76^2 / 38^2 / 19^2 shortcut layers of both bench nets), at a shape the
+    automatic choice sends there: kernels == emulation, and the exact short form == the general arithmetic byte for byte."""
+    lib, fake = libs
+    g = torch.Generator().manual_seed(431)
+    N, H, W, cin, cout, k = 8, 112, 112, 128, 128, 3
+    w_scale, x_scale, out_scale = 2.0 ** -10, 2.0 ** -5, 2.0 ** -4
+    qw = torch.randint(-127, 128, (cout, cin, k, k), generator=g).float() * (torch.rand(cout, cin, k, k, generator=g) < 0.3) * w_scale
+    x = torch.randint(-128, 128, (N, H, W, cin), generator=g).to(torch.int8)
+    qb = torch.randint(-128, 128, (cout,), generator=g).float() * 2.0 ** -6
+    res = torch.randint(-128, 128, (N, H, W, cout), generator=g).to(torch.int8)
+    ys = []
+    for L, dev in ((lib, GPU), (fake, 'cpu')):
+        y, _ = oh.qconv(L, x.to(dev), qw.to(dev), w_scale, qb.to(dev), w_scale * x_scale, out_scale, k, 1, 1, act=1, tile=0,
+                        res=res.to(dev), qadd=qadd)
+        if L is lib and not DRY:
+            assert oh.qconv.last_tile == 43, oh.qconv.last_tile
+        ys.append(y.float().cpu())
+    diff = (ys[0] - ys[1]).abs()
+    assert diff.max().item() <= 1.0 and (diff > 0).float().mean().item() <= 1e-4, (diff.max().item(), (diff > 0).float().mean().item())
+    assert ys[1].abs().max().item() > 20 and (ys[1].abs() == 127).float().mean().item() < 0.5
+    if not DRY:
+        monkeypatch.setenv('YH_QADD_POW2', '0')
+        y, _ = oh.qconv(lib, x.to(GPU), qw.to(GPU), w_scale, qb.to(GPU), w_scale * x_scale, out_scale, k, 1, 1, act=1, tile=0,
+                        res=res.to(GPU), qadd=qadd)
+        assert torch.equal(y.float().cpu(), ys[0]), 'short form differs from the general arithmetic'
 
 
 def test_int8_movement_ops_match_emulation(libs):

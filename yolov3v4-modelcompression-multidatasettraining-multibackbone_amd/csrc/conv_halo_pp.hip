@@ -152,8 +152,10 @@ __device__ __forceinline__ void hpp_epilogue(const ConvArgs& a, AccT (&acc)[8][4
                 *reinterpret_cast<f16x8*>(prow + m) = o;
             } else {
                 if (have_res) {   // fused quantised shortcut: v holds the grid values the conv would have stored
+                    float r8[8];
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] = qadd_value(v[e], (float)(int8_t)((rv[i2][e >> 2] >> (8 * (e & 3))) & 0xff), a);
+                    for (int e = 0; e < 8; ++e) r8[e] = (float)(int8_t)((rv[i2][e >> 2] >> (8 * (e & 3))) & 0xff);
+                    qadd_n<8>(v, r8, a);
                 }
                 u32x2 o;
 #pragma unroll

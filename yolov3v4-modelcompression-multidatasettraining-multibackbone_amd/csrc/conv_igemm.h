@@ -133,6 +133,23 @@ __device__ __forceinline__ float qadd_value(float q, float r, const ConvArgs& a)
     return round_clamp_i8(__fmul_rn(__fadd_rn(xq, aq), a.q_inv_scale_sum));
 }
 
+// Round 5: the same shortcut when every factor is a power of two - which is every calibrated COS-PTQ graph: float ranges are 2^step
+// (quantized_ptq_cos.py:84, :109, :292), so rx, ra are 2^k, and the fused `_min` form has k >= 0.  Then q rx and r ra are integers (the
+// two roundings are the identity), their scaled sum spans <= 24 bits and the final factor is a power of two: every intermediate of
+// qadd_value() is EXACT, and so is q A + r B with A = rx scale_x / scale_sum, B = ra scale_a / scale_sum - the same real number rounded
+// once by round_clamp_i8: bit-identical by construction, 7 instead of 16 VALU slots per value.  The launch code (conv_igemm.hip,
+// qadd_pow2_args) checks the conditions on the five floats and passes A, B in q_rx, q_ra with q_scale_x = 0 as the marker.
+template <int N>
+__device__ __forceinline__ void qadd_n(float (&v)[N], const float (&r)[N], const ConvArgs& a) {
+    if (a.q_scale_x == 0.f) {      // uniform
+#pragma unroll
+        for (int e = 0; e < N; ++e) v[e] = round_clamp_i8(__fmaf_rn(v[e], a.q_rx, __fmul_rn(r[e], a.q_ra)));
+    } else {
+#pragma unroll
+        for (int e = 0; e < N; ++e) v[e] = qadd_value(v[e], r[e], a);
+    }
+}
+
 template <typename T> struct ResVec { typedef f16x4 type; };
 template <> struct ResVec<float> { typedef f32x4 type; };
 template <> struct ResVec<int8_t> { typedef unsigned type; };
@@ -290,8 +307,10 @@ __device__ __forceinline__ void conv_epilogue_plain(const ConvArgs& a, AccT (&ac
                     }
                 } else if constexpr (sizeof(OutT) == 1) {
                     if (have_res) {   // fused quantised shortcut: v holds the grid values the conv would have stored
+                        float r4[4];
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = qadd_value(v[e], (float)(int8_t)((rv[jj][i] >> (8 * e)) & 0xff), a);
+                        for (int e = 0; e < 4; ++e) r4[e] = (float)(int8_t)((rv[jj][i] >> (8 * e)) & 0xff);
+                        qadd_n<4>(v, r4, a);
                     }
                 }
                 store4<OutT>(prow + m, v[0], v[1], v[2], v[3]);

@@ -1074,6 +1074,28 @@ extern "C" int64_t yh_conv2d_stats_rows(const yh_conv_desc* d) {
     return (int64_t)((P + bn - 1) / bn) * wn;
 }
 
+// The fused quantised shortcut with power-of-two factors (conv_igemm.h qadd_n): exactness conditions on the five floats.  rx, ra must be
+// integers (2^k, 0 <= k <= 15: |q rx| < 2^23, so |t| + 0.5 and its floor are exact), the two scaled terms may differ by at most 15 binary
+// places (8-bit integers: their sum fits 24 bits), and no product leaves the normal range.  YH_QADD_POW2=0 keeps the general arithmetic (A/B).
+static void qadd_pow2_args(yh::ConvArgs& a) {
+    const char* env = getenv("YH_QADD_POW2");
+    if (env && env[0] == '0') return;
+    int e[5];
+    const float f[5] = {a.q_rx, a.q_ra, a.q_scale_x, a.q_scale_a, a.q_inv_scale_sum};
+    for (int i = 0; i < 5; ++i) {
+        int ex;
+        if (!(f[i] > 0.f) || frexpf(f[i], &ex) != 0.5f) return;
+        e[i] = ex - 1;
+        if (e[i] < -40 || e[i] > 40) return;
+    }
+    if (e[0] < 0 || e[0] > 15 || e[1] < 0 || e[1] > 15) return;
+    const int ex = e[0] + e[2], ea = e[1] + e[3];
+    if (ex - ea > 15 || ea - ex > 15) return;
+    a.q_rx = ldexpf(1.f, ex + e[4]);
+    a.q_ra = ldexpf(1.f, ea + e[4]);
+    a.q_scale_x = 0.f;      // the marker qadd_n tests
+}
+
 extern "C" int yh_conv2d_fwd(const yh_conv_desc* d, void* stream) {
     using namespace yh;
     if (!d || !d->x || !d->w || !d->bias || !d->y) return YH_EINVAL;
@@ -1120,6 +1142,7 @@ extern "C" int yh_conv2d_fwd(const yh_conv_desc* d, void* stream) {
     a.act = d->act; a.slope = d->slope; a.ups = d->ups;
     a.y_h = d->y_h; a.y_w = d->y_w; a.y_off_h = d->y_off_h; a.y_off_w = d->y_off_w;
     a.q_rx = d->q_rx; a.q_ra = d->q_ra; a.q_scale_x = d->q_scale_x; a.q_scale_a = d->q_scale_a; a.q_inv_scale_sum = d->q_inv_scale_sum;
+    if (d->dtype == YH_I8 && d->res) qadd_pow2_args(a);
     a.no_lds_store = getenv("YH_PW_DIRECT") != nullptr;
     a.stats_part = nullptr;
     if (d->stats_ws) {

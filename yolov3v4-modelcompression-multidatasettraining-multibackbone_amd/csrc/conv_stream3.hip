@@ -166,11 +166,18 @@ __global__ __launch_bounds__(S3_WAVES * 64, OCC) void conv3x3_stream_kernel(cons
 #pragma unroll
             for (int i = 0; i < MT; ++i) {
                 float v[4];
-                if constexpr (sizeof(T) == 1) quantize4<ACT>(acc[i][j], bvs[i], a, v);
+                if constexpr (sizeof(T) == 1) {
+                    quantize4<ACT>(acc[i][j], bvs[i], a, v);
+                    if constexpr (HAS_RES) {
+                        float r4[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) r4[e] = (float)(int8_t)((rv[j][i] >> (8 * e)) & 0xff);
+                        qadd_n<4>(v, r4, a);
+                    }
+                }
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     if constexpr (sizeof(T) == 1) {
-                        if constexpr (HAS_RES) v[e] = qadd_value(v[e], (float)(int8_t)((rv[j][i] >> (8 * e)) & 0xff), a);
                     } else {
                         float y = activate_t<ACT, T>((float)acc[i][j][e] + bvs[i][e], a.slope);
                         if constexpr (HAS_RES) y += (float)rv[j][i][e];
