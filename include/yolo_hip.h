@@ -113,7 +113,10 @@ typedef struct yh_conv_desc {
     /* int8 only, with res != NULL: the quantised shortcut that follows the conv (COSPTQuantizedShortcut_min / _max eval,
      * quantized_ptq_cos.py:877-912) in the same epilogue, exactly yh_qadd's arithmetic on the value q the conv would have stored:
      *   y = clamp(round((round(q * q_rx) * q_scale_x + round(res * q_ra) * q_scale_a) * q_inv_scale_sum))
-     * q_rx = conv activation scale / scale_x, q_ra = scale of the routed tensor / scale_a; res is int8 NHWC (pitch ldr).  */
+     * q_rx = conv activation scale / scale_x, q_ra = scale of the routed tensor / scale_a; res is int8 NHWC (pitch ldr).
+     * When all five are powers of two with integer q_rx, q_ra <= 2^15 (every calibrated COS-PTQ graph with the `_min` shortcut), every
+     * intermediate above is exact and the kernels evaluate clamp(round(q A + res B)), A = q_rx q_scale_x q_inv_scale_sum, B likewise:
+     * the same bytes in 7 instead of 16 VALU slots per value (round 5; YH_QADD_POW2=0 keeps the general arithmetic).  */
     float q_rx, q_ra, q_scale_x, q_scale_a, q_inv_scale_sum;
 } yh_conv_desc;
 int64_t yh_conv2d_stats_rows(const yh_conv_desc* d);
