@@ -125,6 +125,32 @@ def test_batches_beyond_the_budget_go_in_image_chunks(seg, fake, monkeypatch):
         hnms.non_max_suppression(pred, 0.05, 0.6, multi_label=True)
 
 
+def test_hand_over_under_a_tight_budget_terminates(fake, monkeypatch):
+    """ADVICE r5 (engine/nms.py:201): the class-by-class form hands a batch over to the bit-mask form; with a density history the bound
+    in use is inflated (>= 2 x pow2(mmax)), and when the budget lies between n x per_image(pow2(mmax)) and n x per_image(inflated bound)
+    the whole batch used to come back as ONE chunk whose sub-call picked the same inflated bound - RecursionError.  The advisor's case:
+    two images, 3000 rows, six classes, one class above 2048 candidates, budget = 2 x per_image(8192) + 1024."""
+    from engine import nms as hnms
+    pred = synth.nms_candidates(2, 3000, 6, 93, n_clusters=25, hot=0.9)
+    want = oracle.non_max_suppression(pred.numpy(), 0.02, 0.6, multi_label=True)
+    monkeypatch.setattr(hnms, '_density', {})
+    hnms.non_max_suppression(pred, 0.02, 0.6, multi_label=True)          # fills the density history: the next call starts inflated
+    mmax = int(max(hnms._density[1]) * 3000)
+    cap = hnms._pow2_at_least(mmax)
+    assert mmax > 2048 * 2 and hnms._pow2_at_least(int(2 * max(hnms._density[1]) * 3000) + 1) > cap
+    each = cap * ((cap + 63) // 64) * 8 + cap * 23 * 4
+    monkeypatch.setattr(hnms, '_WORK_BUDGET', 2 * each + 1024)
+    del fake.calls[:]
+    got = hnms.non_max_suppression(pred, 0.02, 0.6, multi_label=True)
+    assert 'nms_mask' in fake.calls and fake.calls.count('nms_class_scan') <= 4, fake.calls
+    for i in range(2):
+        _compare(got[i], want[i], 'tight budget img %d' % i)
+    # a single image whose bit mask does not fit: MemoryError, not recursion
+    monkeypatch.setattr(hnms, '_WORK_BUDGET', each // 2)
+    with pytest.raises(MemoryError):
+        hnms.non_max_suppression(pred, 0.02, 0.6, multi_label=True)
+
+
 @pytest.mark.parametrize('rel,size', [('yolov3tiny/yolov3-tiny-hand.cfg', 416), ('yolov4tiny/yolov4-tiny.cfg', 416)], ids=['tiny-hand', 'v4tiny'])
 @pytest.mark.parametrize('ml', [False, True], ids=['best-class', 'multi-label'])
 def test_detect_from_the_head_outputs_equals_decode_then_nms(rel, size, ml, cfg_dir, fake, monkeypatch):

@@ -284,6 +284,59 @@ def test_device_calibration_at_the_baseline_shapes_then_int8_engine(tag):
         assert all(f <= 0.025 and d <= 0.0625 for f, d in off), off
 
 
+@pytest.mark.gpu
+def test_map_protocol_on_the_device_calibrated_yolov4_640_state(cfg_dir):
+    """north_star's "mAP@0.5 within +-0.2 pt" for BASELINE config 4 (YOLOv4-640 int8) on a CALIBRATED state.  The
+    float graph is conditioned like a trained detector's (layer gains equalised, one favourite class per anchor: synth.py) so that the
+    protocol measures box / score fidelity rather than tie-breaking; PTQ.py-style calibration then runs ON THE DEVICE (3 batches of 2,
+    engine/calib.py); in eval mode the int8 MFMA engine's detections on two frames are scored by tests/map_protocol.py against the
+    detections of the SAME calibrated modules evaluated on the CPU - the reference's arithmetic (quantized_ptq_cos.py:288-296,717;
+    this package's modules are bit-equal to it wherever the reference runs, tests/test_ptq_large.py).  Frames on the k / 256 grid:
+    the stem convolution is then exact in any order, so what is left is the fp32 Mish by two formulas (0.6 - 1.4 % of the head values
+    one grid step apart, test above).  Asserted: |mAP - mAP(reference vs itself)| <= 0.002."""
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU')
+    import models
+    from map_protocol import map50
+    from utils.utils import non_max_suppression
+    size = 640
+    cfg = os.path.join(cfg_dir, 'yolov4/yolov4.cfg')
+    torch.manual_seed(0)
+    fm = models.Darknet(cfg, (size, size))
+    fm.load_state_dict(synth.randomize_bn_(fm.state_dict(), seed=1))
+    x = synth.dyadic_frames(synth.image_batch(2, size, seed=0))
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    synth.equalize_bn_gain_(fm.eval(), x)
+    fm.load_state_dict(synth.trained_like_heads_(fm.state_dict(), fm.module_defs))
+    qm = models.Darknet(cfg, (size, size), quantized=3, a_bit=8, w_bit=8, shortcut_way=1)
+    _copy_float_weights(fm, qm)
+    del fm
+    qm.cuda().train()
+    with torch.no_grad():
+        for it in range(3):
+            qm(synth.dyadic_frames(synth.image_batch(2, size, seed=10 + it)).cuda())
+    qm.eval()
+    with torch.no_grad():
+        io, raws, _ = qm(x.cuda())
+    eng = qm.__dict__['_hip_engine']
+    assert eng is not None and eng.precision == 'int8'
+    cpu = copy.deepcopy(qm).cpu()
+    cpu.__dict__['_hip_engine'] = None
+    with torch.no_grad():
+        ref_full, raws_cpu, _ = cpu(x)
+    off = [(a.cpu() != b).float().mean().item() for a, b in zip(raws, raws_cpu)]
+    conf = float(torch.quantile(ref_full[..., 4].flatten(), 0.985)) * 0.999
+    gt = non_max_suppression(ref_full.clone(), conf, 0.6, multi_label=False)
+    n_gt = sum(0 if g is None else len(g) for g in gt)
+    det = non_max_suppression(io, conf * 0.9, 0.6, multi_label=False)
+    det_self = non_max_suppression(ref_full.cuda(), conf * 0.9, 0.6, multi_label=False)
+    score, perfect = map50(gt, det), map50(gt, det_self)
+    print('synthetic mAP@0.5 on the device-calibrated YOLOv4-640 int8 state: engine %.4f, calibrated modules on the CPU against themselves %.4f '
+          '(%d ground-truth boxes on %d frames; fraction of head values that differ %s)' % (score, perfect, n_gt, len(gt), ['%.2g' % f for f in off]))
+    assert n_gt >= 10
+    assert abs(score - perfect) <= 0.002, (score, perfect)
+
+
 # ------------------------------------------------------------------------------ device calibration services (csrc/calib.hip)
 def _calibrate(qm, way_device, monkeypatch, batches=3):
     import utils.quantized.quantized_ptq_cos as q

@@ -209,6 +209,29 @@ def test_single_channel_input_trains_on_the_hip_path():
     assert_grads_close(grads, grads_ref, 2e-5)
 
 
+def test_narrow_net_with_a_64_channel_stride2_conv_builds_and_trains():
+    """ADVICE r5 (engine/train.py:322): the one-pass stride-2 data gradient for <= 64 input channels has 4 * cin = 256 rows, but the
+    shared zero bias row was sized by the widest conv INPUT rounded to 128 - a narrow (pruned) net whose widest input is <= 128 and
+    that has a stride-2 conv with 33 .. 64 inputs failed at plan build.  Such a net: 16 -> 64 -> (s2) 64 -> 32 -> head."""
+    c = lambda f, k, s: th._CONV % (f, k, s, 'leaky')
+    text = ('[net]\nbatch=1\nwidth=64\nheight=64\nchannels=3\n\n' + c(16, 3, 1) + c(64, 3, 2) + c(64, 3, 2) + c(32, 1, 1) + c(64, 3, 2)
+            + th._HEAD + th._YOLO % '3,4,5')
+    path = th.write_cfg(text)
+    try:
+        model = th.build(path, 64)
+        x = synth.image_batch(2, 64, seed=0)
+        raws_ref, grads_ref, _, ws = th.eager_step(model, x)
+        raws, grads, m = th.engine_step(model, x, ws, 'fp32', lib=fakelib.FakeLib())
+        eng = m.__dict__['_hip_train_engine']
+        fused = [v.tpack['fused_m_pad'] for v in eng._current['values'] if v.kind == 'conv' and 'fused_m_pad' in getattr(v, 'tpack', {})]
+        assert 256 in fused, fused            # the case the row was too short for
+        for a, b in zip(raws, raws_ref):
+            assert (a - b).abs().max().item() <= 2e-5 * b.abs().max().item()
+        assert_grads_close(grads, grads_ref, 2e-5)
+    finally:
+        os.unlink(path)
+
+
 def assert_grads_close(grads, grads_ref, tol):
     """rel-l2 per parameter; gradients that are analytically zero (a BatchNorm bias feeding another BatchNorm through linear
     layers) are compared against the scale of the largest gradient instead of their own round-off."""

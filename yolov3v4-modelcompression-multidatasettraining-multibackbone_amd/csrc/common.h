@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include <mutex>
 #include <set>
@@ -130,6 +131,16 @@ inline hipError_t ensure_dynamic_lds(const void* kern, size_t bytes) {
 }
 
 inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15u) == 0; }
+
+// Run-to-run deterministic reductions (round 6; the reference's CPU training step is bit-reproducible).  Every sum over workgroups of
+// the training path - BatchNorm statistics, BatchNorm backward sums, weight-gradient pixel splits, the first block's backward - is
+// taken in a FIXED order: partial results in a workspace, summed by one owner per output element, never by fp32 atomics whose
+// arrival order varies.  YH_DETERMINISTIC=0 brings back the round-5 forms (split groups meeting in atomics) for A/B runs.
+// What stays order-dependent is listed in DESIGN.md section 8 (max-pool / depthwise / SE backward scatter, >= 3 labels in one cell).
+inline bool deterministic() {
+    static const int v = [] { const char* e = getenv("YH_DETERMINISTIC"); return e ? (atoi(e) != 0 ? 1 : 0) : 1; }();
+    return v != 0;
+}
 
 // conv_stem_mfma.hip: the 3 x 3 x 3-plane first layer on the matrix cores (YH_EUNSUPPORTED: use the kernel in elementwise.hip)
 int launch_stem_mfma(const yh_stem_desc& d, hipStream_t stream);

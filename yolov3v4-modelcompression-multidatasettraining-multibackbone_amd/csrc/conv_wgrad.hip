@@ -617,7 +617,7 @@ __global__ __launch_bounds__(128 * WNW) void conv_wgrad_dma_kernel(const WgradAr
 // Second stage: one thread per (tile, i, j, lane slot) and split group: sum the group's splits, add into dw[co][ci][tap]
 // (a handful of groups per element, so these atomics are uncontended).
 template <int TM, int WNW>
-__global__ __launch_bounds__(128 * WNW) void wgrad_reduce_kernel(const WgradArgs a, int splits, int per_group) {
+__global__ __launch_bounds__(128 * WNW) void wgrad_reduce_kernel(const WgradArgs a, int splits, int per_group, int sstep, int native) {
     constexpr int NT = 128 * WNW, BN = 64 * WNW;
     const yh_wgrad_desc& d = a.d;
     const int tiles = a.tiles_m * a.tiles_n;
@@ -625,8 +625,8 @@ __global__ __launch_bounds__(128 * WNW) void wgrad_reduce_kernel(const WgradArgs
     const int i = ij / 4, j = ij % 4;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WNW, wn = wave % WNW;
-    const f32x4* part = reinterpret_cast<const f32x4*>(d.ws) + ((long)tile * (TM * 4) + ij) * NT + tid;
-    const long stride = (long)tiles * (TM * 4) * NT;
+    f32x4* part = reinterpret_cast<f32x4*>(d.ws) + ((long)tile * (TM * 4) + ij) * NT + tid;
+    const long stride = (long)tiles * (TM * 4) * NT * sstep;      // sstep > 1: the second pass, over the groups' in-place sums
     const int s0 = blockIdx.y * per_group, s1 = min(s0 + per_group, splits);
     f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = v0, v2 = v0, v3 = v0;
     int sp = s0;
@@ -638,6 +638,10 @@ __global__ __launch_bounds__(128 * WNW) void wgrad_reduce_kernel(const WgradArgs
     }
     for (; sp < s1; ++sp) v0 += part[sp * stride];
     const f32x4 v = (v0 + v1) + (v2 + v3);
+    if (native) {      // deterministic form, first pass: the group's sum replaces its first partial tile (same element order)
+        part[s0 * stride] = v;
+        return;
+    }
     const int tm = tile % a.tiles_m, tn = tile / a.tiles_m;
     const int n = tn * BN + wn * 64 + j * 16 + (lane & 15);
     if (n >= a.ncols) return;
@@ -939,7 +943,7 @@ __global__ __launch_bounds__(768, 3) void conv_wgrad_halo_kernel(const WgradArgs
 }
 
 // one thread per (tile, fragment, lane slot) and split group, as wgrad_reduce_kernel
-__global__ __launch_bounds__(768) void wgrad_halo_reduce_kernel(const WgradArgs a, int splits, int per_group) {
+__global__ __launch_bounds__(768) void wgrad_halo_reduce_kernel(const WgradArgs a, int splits, int per_group, int sstep, int native) {
     constexpr int NT = 768;
     const yh_wgrad_desc& d = a.d;
     const int tiles = a.tiles_m * a.tiles_n;
@@ -947,8 +951,8 @@ __global__ __launch_bounds__(768) void wgrad_halo_reduce_kernel(const WgradArgs 
     const int i = ij / 6, j = ij % 6;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / 3, wn = wave - wm * 3;
-    const f32x4* part = reinterpret_cast<const f32x4*>(d.ws) + ((long)tile * 24 + ij) * NT + tid;
-    const long stride = (long)tiles * 24 * NT;
+    f32x4* part = reinterpret_cast<f32x4*>(d.ws) + ((long)tile * 24 + ij) * NT + tid;
+    const long stride = (long)tiles * 24 * NT * sstep;
     const int s0 = blockIdx.y * per_group, s1 = min(s0 + per_group, splits);
     f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = v0, v2 = v0, v3 = v0;
     int sp = s0;
@@ -960,6 +964,10 @@ __global__ __launch_bounds__(768) void wgrad_halo_reduce_kernel(const WgradArgs 
     }
     for (; sp < s1; ++sp) v0 += part[sp * stride];
     const f32x4 v = (v0 + v1) + (v2 + v3);
+    if (native) {      // deterministic form, first pass: the group's sum replaces its first partial tile (same element order)
+        part[s0 * stride] = v;
+        return;
+    }
     const int tm = tile % a.tiles_m, tn = tile / a.tiles_m;
     const int tap = wn * 3 + (j >> 1);
     const int ci = tn * 32 + (j & 1) * 16 + (lane & 15);
@@ -1477,7 +1485,12 @@ extern "C" int yh_conv2d_wgrad(const yh_wgrad_desc* d, void* stream) {
             if (groups > 32) groups = 32;
             const int per_group = (splits + groups - 1) / groups;
             groups = (splits + per_group - 1) / per_group;
-            hipLaunchKernelGGL(wgrad_halo_reduce_kernel, dim3(htiles * 24, groups), dim3(768), 0, st, a, splits, per_group);
+            if (deterministic() && groups > 1) {      // groups in place, then one owner per element adds them in order (no atomics)
+                hipLaunchKernelGGL(wgrad_halo_reduce_kernel, dim3(htiles * 24, groups), dim3(768), 0, st, a, splits, per_group, 1, 1);
+                hipLaunchKernelGGL(wgrad_halo_reduce_kernel, dim3(htiles * 24, 1), dim3(768), 0, st, a, groups, groups, per_group, 0);
+            } else {
+                hipLaunchKernelGGL(wgrad_halo_reduce_kernel, dim3(htiles * 24, groups), dim3(768), 0, st, a, splits, per_group, 1, 0);
+            }
             return check_launch();
         }
         wgrad_geometry(d, &a, &splits, false);   // no workspace for the partial tiles: the im2col form
@@ -1510,11 +1523,19 @@ extern "C" int yh_conv2d_wgrad(const yh_wgrad_desc* d, void* stream) {
         if (groups > 32) groups = 32;                       // groups are the expensive part (4x more groups measured 30 % slower)
         const int per_group = (splits + groups - 1) / groups;
         groups = (splits + per_group - 1) / per_group;
-        if (narrow) hipLaunchKernelGGL((wgrad_reduce_kernel<2, 2>), dim3(tiles * 8, groups), dim3(256), 0, st, a, splits, per_group);
-        else if (a.bm == 256 && a.bn == 256) hipLaunchKernelGGL((wgrad_reduce_kernel<8, 4>), dim3(tiles * 32, groups), dim3(512), 0, st, a, splits, per_group);
-        else if (a.bm == 256) hipLaunchKernelGGL((wgrad_reduce_kernel<8, 2>), dim3(tiles * 32, groups), dim3(256), 0, st, a, splits, per_group);
-        else if (a.bn == 256) hipLaunchKernelGGL((wgrad_reduce_kernel<4, 4>), dim3(tiles * 16, groups), dim3(512), 0, st, a, splits, per_group);
-        else hipLaunchKernelGGL((wgrad_reduce_kernel<4, 2>), dim3(tiles * 16, groups), dim3(256), 0, st, a, splits, per_group);
+        auto reduce = [&](int ngroups, int nsplits, int per, int sstep, int native) {
+            if (narrow) hipLaunchKernelGGL((wgrad_reduce_kernel<2, 2>), dim3(tiles * 8, ngroups), dim3(256), 0, st, a, nsplits, per, sstep, native);
+            else if (a.bm == 256 && a.bn == 256) hipLaunchKernelGGL((wgrad_reduce_kernel<8, 4>), dim3(tiles * 32, ngroups), dim3(512), 0, st, a, nsplits, per, sstep, native);
+            else if (a.bm == 256) hipLaunchKernelGGL((wgrad_reduce_kernel<8, 2>), dim3(tiles * 32, ngroups), dim3(256), 0, st, a, nsplits, per, sstep, native);
+            else if (a.bn == 256) hipLaunchKernelGGL((wgrad_reduce_kernel<4, 4>), dim3(tiles * 16, ngroups), dim3(512), 0, st, a, nsplits, per, sstep, native);
+            else hipLaunchKernelGGL((wgrad_reduce_kernel<4, 2>), dim3(tiles * 16, ngroups), dim3(256), 0, st, a, nsplits, per, sstep, native);
+        };
+        if (deterministic() && groups > 1) {      // the groups' sums in place, then one owner per element adds them in order (no atomics)
+            reduce(groups, splits, per_group, 1, 1);
+            reduce(1, groups, groups, per_group, 0);
+        } else {
+            reduce(groups, splits, per_group, 1, 0);
+        }
     }
     return check_launch();
 }

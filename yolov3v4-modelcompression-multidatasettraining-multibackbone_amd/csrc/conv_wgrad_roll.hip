@@ -757,7 +757,7 @@ __global__ __launch_bounds__(768) void wgrad_roll_reduce_kernel(const RollArgs a
 // fixed order), the block is transposed through LDS and leaves as 16 rows of 576 contiguous bytes.  Workgroups = tiles x 32 x G; G > 1
 // (few tiles: the 76 x 76 and 152 x 152 layers) splits the pixel splits over G workgroups that meet in row-contiguous atomics.
 template <bool VEC, bool M32>
-__global__ __launch_bounds__(576) void wgrad_roll_reduce2_kernel(const RollArgs a, int splits, int per_group) {
+__global__ __launch_bounds__(576) void wgrad_roll_reduce2_kernel(const RollArgs a, int splits, int per_group, int sstep, int native) {
     constexpr int NT = 768;
     const yh_wgrad_desc& d = a.d;
     __shared__ __attribute__((aligned(16))) float blk[16][148];
@@ -773,8 +773,8 @@ __global__ __launch_bounds__(576) void wgrad_roll_reduce2_kernel(const RollArgs 
     const int ij = M32 ? ((i >> 1) * 3 + tcol) * 4 + 2 * (i & 1) + (lane >> 5) : i * 6 + tcol * 2 + b;
     const int src_lane = M32 ? 32 * ((lane >> 4) & 1) + 16 * b + (lane & 15) : lane;
     const int row_base = M32 ? 8 * (lane >> 5) + 4 * ((lane >> 4) & 1) : 4 * (lane >> 4);
-    const f32x4* part = reinterpret_cast<const f32x4*>(d.ws) + ((long)tile * 24 + ij) * NT + w_src * 64 + src_lane;
-    const long stride = (long)tiles * 24 * NT;
+    f32x4* part = reinterpret_cast<f32x4*>(d.ws) + ((long)tile * 24 + ij) * NT + w_src * 64 + src_lane;
+    const long stride = (long)tiles * 24 * NT * sstep;      // sstep > 1: the second pass, over the groups' in-place sums
     const int sA = blockIdx.y * per_group, sB = min(sA + per_group, splits);
     f32x4 v[8];
 #pragma unroll
@@ -789,6 +789,10 @@ __global__ __launch_bounds__(576) void wgrad_roll_reduce2_kernel(const RollArgs 
     }
     for (int k = 0; sp < sB; ++sp, ++k) v[k & 7] += part[sp * stride];
     const f32x4 sum = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+    if (native) {      // deterministic form (common.h), first pass: the group's sum replaces its first partial tile - every thread reads and
+        part[sA * stride] = sum;      // writes its own element only - and a second launch with ONE group adds the groups in order
+        return;
+    }
 #pragma unroll
     for (int r = 0; r < 4; ++r) blk[row_base + r][(lane & 15) * 9 + tap] = sum[r];
     __syncthreads();
@@ -917,13 +921,21 @@ int launch_wgrad_roll(const yh_wgrad_desc* d, hipStream_t st) {
         if (groups < 1) groups = 1;
         const int per_group = (splits + groups - 1) / groups;
         groups = (splits + per_group - 1) / per_group;
-        const dim3 rg(tiles * 32, groups);
-        if (m32) {
-            if (aligned16(d->dw)) hipLaunchKernelGGL((wgrad_roll_reduce2_kernel<true, true>), rg, dim3(576), 0, st, a, splits, per_group);
-            else hipLaunchKernelGGL((wgrad_roll_reduce2_kernel<false, true>), rg, dim3(576), 0, st, a, splits, per_group);
+        auto reduce = [&](int ngroups, int nsplits, int per, int sstep, int native) {
+            const dim3 rg(tiles * 32, ngroups);
+            if (m32) {
+                if (aligned16(d->dw)) hipLaunchKernelGGL((wgrad_roll_reduce2_kernel<true, true>), rg, dim3(576), 0, st, a, nsplits, per, sstep, native);
+                else hipLaunchKernelGGL((wgrad_roll_reduce2_kernel<false, true>), rg, dim3(576), 0, st, a, nsplits, per, sstep, native);
+            } else {
+                if (aligned16(d->dw)) hipLaunchKernelGGL((wgrad_roll_reduce2_kernel<true, false>), rg, dim3(576), 0, st, a, nsplits, per, sstep, native);
+                else hipLaunchKernelGGL((wgrad_roll_reduce2_kernel<false, false>), rg, dim3(576), 0, st, a, nsplits, per, sstep, native);
+            }
+        };
+        if (deterministic() && groups > 1) {      // few-tile layers (76 x 76, 152 x 152): the split groups no longer meet in fp32 atomics
+            reduce(groups, splits, per_group, 1, 1);
+            reduce(1, groups, groups, per_group, 0);
         } else {
-            if (aligned16(d->dw)) hipLaunchKernelGGL((wgrad_roll_reduce2_kernel<true, false>), rg, dim3(576), 0, st, a, splits, per_group);
-            else hipLaunchKernelGGL((wgrad_roll_reduce2_kernel<false, false>), rg, dim3(576), 0, st, a, splits, per_group);
+            reduce(groups, splits, per_group, 1, 0);
         }
     }
     return check_launch();

@@ -268,28 +268,32 @@ __global__ __launch_bounds__(256, 2) void stem_bwd_partial_kernel(const yh_stem_
             }
         }
     __syncthreads();          // part[] is zeroed
-    if (lane < UPP) {
+    // the four waves add their sums to the workgroup row ONE AFTER THE OTHER (round 6: LDS float atomics made the order - and the last
+    // bits of dW, dgamma, dbeta - vary from run to run; within a wave every lane owns its own entries)
+    for (int turn = 0; turn < 4; ++turn) {
+        if (wave == turn) {
+            if (lane < UPP) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
+                for (int e = 0; e < 4; ++e)
 #pragma unroll
-            for (int k = 0; k < 2; ++k) {
-                atomicAdd(&part[Row::S1 + cu * 8 + 2 * e + k], s1[e][k]);
-                atomicAdd(&part[Row::S2 + cu * 8 + 2 * e + k], s2[e][k]);
+                    for (int k = 0; k < 2; ++k) {
+                        part[Row::S1 + cu * 8 + 2 * e + k] += s1[e][k];
+                        part[Row::S2 + cu * 8 + 2 * e + k] += s2[e][k];
+                    }
             }
+#pragma unroll
+            for (int i = 0; i < NI; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int m = 16 * i + 4 * g4 + e, k = 16 * j + q16;
+                        if (m < 2 * C) part[m * 32 + k] += acc[i][j][e];
+                        else if (m == 2 * C) part[Row::SX + k] += acc[i][j][e];
+                    }
+        }
+        __syncthreads();
     }
-    {
-#pragma unroll
-        for (int i = 0; i < NI; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int m = 16 * i + 4 * g4 + e, k = 16 * j + q16;
-                    if (m < 2 * C) atomicAdd(&part[m * 32 + k], acc[i][j][e]);
-                    else if (m == 2 * C) atomicAdd(&part[Row::SX + k], acc[i][j][e]);
-                }
-    }
-    __syncthreads();
     float* const out = d.ws + (long)blockIdx.x * Row::SIZE;
     for (int i = tid; i < Row::SIZE; i += 256) out[i] = part[i];
 }
@@ -561,29 +565,33 @@ __global__ __launch_bounds__(256, 2) void stem_bwd_dgrad_kernel(const yh_stem_bw
     __syncthreads();          // every wave is done with its tiles
     for (int i = tid; i < Row::SIZE; i += 256) part[i] = 0.f;
     __syncthreads();
-    if (pc == 0) {
+    for (int turn = 0; turn < 4; ++turn) {      // one wave at a time, in order: deterministic sums (see stem_bwd_partial_kernel)
+        if (wave == turn) {
+            if (pc == 0) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+                for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int h = 0; h < 2; ++h)
+                    for (int h = 0; h < 2; ++h)
 #pragma unroll
-                for (int k = 0; k < 2; ++k) {
-                    const int ch = 16 * i + 4 * kq + 2 * h + k;
-                    atomicAdd(&part[Row::S1 + ch], s1[2 * i + h][k]);
-                    atomicAdd(&part[Row::S2 + ch], s2[2 * i + h][k]);
-                }
-    }
-#pragma unroll
-    for (int i = 0; i < NI; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int m = 16 * i + 4 * g4 + e, k = 16 * j + q16;
-                if (m < 2 * C) atomicAdd(&part[m * 32 + k], acc[i][j][e]);
-                else if (m == 2 * C) atomicAdd(&part[Row::SX + k], acc[i][j][e]);
+                        for (int k = 0; k < 2; ++k) {
+                            const int ch = 16 * i + 4 * kq + 2 * h + k;
+                            part[Row::S1 + ch] += s1[2 * i + h][k];
+                            part[Row::S2 + ch] += s2[2 * i + h][k];
+                        }
             }
-    __syncthreads();
+#pragma unroll
+            for (int i = 0; i < NI; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int m = 16 * i + 4 * g4 + e, k = 16 * j + q16;
+                        if (m < 2 * C) part[m * 32 + k] += acc[i][j][e];
+                        else if (m == 2 * C) part[Row::SX + k] += acc[i][j][e];
+                    }
+        }
+        __syncthreads();
+    }
     float* const out = d.ws + (long)blockIdx.x * Row::SIZE;
     for (int i = tid; i < Row::SIZE; i += 256) out[i] = part[i];
 }

@@ -97,30 +97,56 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const yh_bn_desc d, const
 // second stage of the reductions: sum[c] += sum over workgroups of part[wg][0][c], sumsq likewise.
 // 16 columns x 16 partial-lanes per workgroup (a wave reads 64-byte row pieces of 4 partial rows at a time), row groups
 // in grid.y meeting in a few atomics per channel.
-__global__ __launch_bounds__(256) void bn_partials_kernel(const float* part, int nparts, int per_group, int c, float* s0, float* s1) {
-    __shared__ float red[256];
+__global__ __launch_bounds__(1024) void bn_partials_kernel(const float* part, int nparts, int per_group, int c, float* s0, float* s1) {
+    // blockDim.x = 16 columns x L row lanes (L = 16: several row groups that meet in atomics; L = 64 and ONE group: the deterministic
+    // form - every channel's sum is taken by one thread in a fixed order, common.h deterministic())
+    __shared__ float red[1024];
+    const int L = blockDim.x >> 4;
     const int col = blockIdx.x * 16 + (threadIdx.x & 15), lane = threadIdx.x >> 4;
     const int r0 = blockIdx.y * per_group, r1 = min(r0 + per_group, nparts);
-    float v = 0.f;
-    if (col < 2 * c)
-        for (int k = r0 + lane; k < r1; k += 16) {
-            const int q = col / c, ch = col - q * c;
-            v += part[((long)k * 2 + q) * c + ch];
+    float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
+    if (col < 2 * c) {
+        const int q = col / c, ch = col - q * c;
+        const float* src = part + (long)q * c + ch;
+        const long pitch = 2L * c;
+        int k = r0 + lane;
+        for (; k + 3 * L < r1; k += 4 * L) {      // four independent chains: the loads pipeline
+            v0 += src[k * pitch];
+            v1 += src[(k + L) * pitch];
+            v2 += src[(k + 2 * L) * pitch];
+            v3 += src[(k + 3 * L) * pitch];
         }
-    red[threadIdx.x] = v;
+        for (; k < r1; k += L) v0 += src[k * pitch];
+    }
+    red[threadIdx.x] = (v0 + v1) + (v2 + v3);
     __syncthreads();
     if (threadIdx.x < 16 && col < 2 * c) {
         float t = 0.f;
-        for (int r = 0; r < 16; ++r) t += red[r * 16 + threadIdx.x];
+        for (int r = 0; r < L; ++r) t += red[r * 16 + threadIdx.x];
         const int q = col / c, ch = col - q * c;
-        atomicAdd((q ? s1 : s0) + ch, t);
+        float* dst = (q ? s1 : s0) + ch;
+        if (gridDim.y == 1) *dst += t;            // the only writer of this channel: plain accumulate
+        else atomicAdd(dst, t);
     }
 }
 
-__global__ void bn_finalize_kernel(const yh_bn_desc d) {
+// groups > 0 (deterministic form): bn_conv_partials_kernel left row group g's column sums in row g * per_group of the workspace; they
+// are added here in group order - no atomics, and no launch more than the round-5 form had
+__global__ void bn_finalize_kernel(const yh_bn_desc d, const int groups, const int per_group) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= d.c) return;
     const float P = (float)d.pixels;
+    if (groups > 0) {
+        float s0 = d.sum[c], s1 = d.sumsq[c];
+        const float* row = d.ws + c;
+        const long pitch = (long)per_group * 2 * d.c;
+        for (int g = 0; g < groups; ++g) {
+            s0 += row[g * pitch];
+            s1 += row[g * pitch + d.c];
+        }
+        d.sum[c] = s0;
+        d.sumsq[c] = s1;
+    }
     const float mean = d.sum[c] / P;
     const float var = fmaxf(d.sumsq[c] / P - mean * mean, 0.f);
     d.mean[c] = mean;
@@ -278,6 +304,11 @@ static BnGeom bn_geom(const yh_bn_desc* d, int vn, dim3* grid, int target = 4096
 
 static void sum_partials(const yh_bn_desc* d, const dim3& grid, void* stream) {
     const int nparts = (int)grid.y;
+    if (deterministic()) {      // one owner per channel: 64 row lanes x four load chains each, summed in a fixed order
+        hipLaunchKernelGGL(bn_partials_kernel, dim3((2 * d->c + 15) / 16, 1), dim3(1024), 0, (hipStream_t)stream, d->ws, nparts, nparts,
+                           d->c, d->sum, d->sumsq);
+        return;
+    }
     int groups = (nparts + 63) / 64;                        // >= 64 rows per group
     const int per_group = (nparts + groups - 1) / groups;
     groups = (nparts + per_group - 1) / per_group;
@@ -663,8 +694,8 @@ extern "C" int yh_bn_stats(const yh_bn_desc* d, void* stream) {
 }
 
 // rows of [2][c] partials (conv epilogue) -> sum / sumsq: 16 columns x 16 row lanes per workgroup, row groups in grid.y
-__global__ __launch_bounds__(256) void bn_conv_partials_kernel(const float* part, int nparts, int per_group, int c, float* s0,
-                                                               float* s1) {
+__global__ __launch_bounds__(256) void bn_conv_partials_kernel(float* part, int nparts, int per_group, int c, float* s0,
+                                                               float* s1, int inplace) {
     __shared__ float red[256];
     const int col = blockIdx.x * 16 + (threadIdx.x & 15), lane = threadIdx.x >> 4;
     const int r0 = blockIdx.y * per_group, r1 = min(r0 + per_group, nparts);
@@ -676,7 +707,10 @@ __global__ __launch_bounds__(256) void bn_conv_partials_kernel(const float* part
     if (threadIdx.x < 16 && col < 2 * c) {
         float t = 0.f;
         for (int r = 0; r < 16; ++r) t += red[r * 16 + threadIdx.x];
-        atomicAdd((col < c ? s0 : s1) + (col < c ? col : col - c), t);
+        // inplace (deterministic form): the group's sums replace its first row (this workgroup alone reads and writes these 16 columns
+        // of rows r0 .. r1 - 1, and every read is behind the barrier above); bn_finalize_kernel adds the groups in order
+        if (inplace) part[(long)r0 * 2 * c + col] = t;
+        else atomicAdd((col < c ? s0 : s1) + (col < c ? col : col - c), t);
     }
 }
 
@@ -688,10 +722,15 @@ extern "C" int yh_bn_finalize(const yh_bn_desc* d, void* stream) {
         if (groups > 64) groups = 64;
         const int per_group = (d->nparts + groups - 1) / groups;
         groups = (d->nparts + per_group - 1) / per_group;
+        const int det = deterministic() ? 1 : 0;
         hipLaunchKernelGGL(bn_conv_partials_kernel, dim3((2 * d->c + 15) / 16, groups), dim3(256), 0, (hipStream_t)stream, d->ws,
-                           d->nparts, per_group, d->c, d->sum, d->sumsq);
+                           d->nparts, per_group, d->c, d->sum, d->sumsq, det);
+        if (det) {
+            hipLaunchKernelGGL(bn_finalize_kernel, dim3((d->c + 255) / 256), dim3(256), 0, (hipStream_t)stream, *d, groups, per_group);
+            return check_launch();
+        }
     }
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((d->c + 255) / 256), dim3(256), 0, (hipStream_t)stream, *d);
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((d->c + 255) / 256), dim3(256), 0, (hipStream_t)stream, *d, 0, 0);
     return check_launch();
 }
 

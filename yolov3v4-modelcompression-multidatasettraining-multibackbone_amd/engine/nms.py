@@ -97,7 +97,10 @@ def _pow2_at_least(v):
     return c
 
 
-def _non_max_suppression(src, conf_thres, iou_thres, multi_label, classes, agnostic):
+def _non_max_suppression(src, conf_thres, iou_thres, multi_label, classes, agnostic, cap_exact=None):
+    """cap_exact: a bound that is KNOWN to hold every image's candidates (set by `in_chunks` for its sub-calls: the chunks were sized
+    with it, so the sub-call must not pick a larger one from the density history - ADVICE r5: with the inflated guess a hand-over
+    re-chunked the whole batch as one 'chunk' for ever)."""
     lib = hiplib.load()
     n, rows, nc, dev = src.n, src.rows, src.nc, src.device
     P, S = hiplib.ptr, hiplib.stream_ptr()
@@ -138,19 +141,31 @@ def _non_max_suppression(src, conf_thres, iou_thres, multi_label, classes, agnos
 
     def in_chunks(c, general):
         """Run the images in groups whose buffers fit the budget and concatenate the results."""
-        _density.setdefault(ml, collections.deque(maxlen=_HINT_WINDOW)).append(c / float(rows))     # a TRUE count (ADVICE r4)
-        each = per_image_bytes(_pow2_at_least(c), general)
+        if cap_exact is None or c < cap_exact:
+            _density.setdefault(ml, collections.deque(maxlen=_HINT_WINDOW)).append(c / float(rows))     # a TRUE count (ADVICE r4)
+        capc = _pow2_at_least(c)
+        each = per_image_bytes(capc, general)
         if each > budget():
             raise MemoryError('non_max_suppression: %d candidates in one image need %.1f GB of buffers%s (conf_thres %g, %s): raise '
                               'conf_thres' % (c, each / 1e9, ', most of it the IoU bit mask' if general else '', conf_thres,
                                               'multi-label' if ml else 'best class'))
         step = max(1, int(budget() // each))
+        if step >= n and cap_exact == capc:
+            # this call WAS sized with capc and still does not fit (the device has less free memory than when the caller measured it):
+            # halve rather than hand the same batch down again
+            step = max(1, n // 2)
+            if n == 1:
+                raise MemoryError('non_max_suppression: the buffers of one image (%.1f GB) do not fit the free device memory' % (each / 1e9))
         out = []
         for i in range(0, n, step):
-            out += _non_max_suppression(src.images(i, min(n, i + step)), conf_thres, iou_thres, multi_label, classes, agnostic)
+            out += _non_max_suppression(src.images(i, min(n, i + step)), conf_thres, iou_thres, multi_label, classes, agnostic, cap_exact=capc)
         return out
 
-    if (not seg and n * cap * ((cap + 63) // 64) * 8 > _MASK_BUDGET) or too_big(cap, not seg):
+    if cap_exact is not None:
+        cap, exact = cap_exact, True          # the caller's chunks were sized with this bound
+        if too_big(cap, not seg):
+            return in_chunks(cap, not seg)
+    elif (not seg and n * cap * ((cap + 63) // 64) * 8 > _MASK_BUDGET) or too_big(cap, not seg):
         # a guessed bound this large is not worth its mask: count first (one extra 4n-byte read), then size exactly
         count = torch.zeros(n, dtype=torch.int32, device=dev)
         src.candidates(lib, conf_thres, ml, cmask, None, count, 0, S)

@@ -345,8 +345,11 @@ class TrainEngine(DarknetEngine):
         stats.allocate(dev)
         saved.allocate(dev)
         grads.allocate(dev)
-        zero_bias = alloc((max([_round_up(v.src.c_phys, 128) for v in values if v.kind == 'conv' and v.src.kind != 'input']
-                               + [128]),), fp32=True, zero=True)
+        # one zero row serves every data gradient as its bias: as long as the longest m_pad among them, incl. the one-pass stride-2 form's
+        # 4 * cin rows (a narrow / pruned net whose widest conv input is <= 128 but that has a stride-2 conv with 33 .. 64
+        # inputs needs 256 there and failed at plan build)
+        zero_bias = alloc((max([max(_round_up(v.src.c_phys, 128), v.tpack.get('fused_m_pad', 0))
+                                for v in values if v.kind == 'conv' and v.src.kind != 'input'] + [128]),), fp32=True, zero=True)
         dz_elems = max(N * v.Ho * v.Wo * v.c_phys for v in values if v.kind in ('conv', 'dw'))
         # Two lanes in the backward plan (include/yolo_hip.h yh_plan_set_lane), OFF by default: the weight gradient of a layer only
         # feeds the optimizer, so it can run on the plan's side stream, issued after the layer's data gradient, while the main chain

@@ -503,7 +503,9 @@ class Darknet(nn.Module):
         if eng is None or eng.precision != precision:
             eng = DarknetEngine(self, precision=precision)
             self.__dict__['_hip_engine'] = eng
-        eng.return_features = False
+        # a caller that also reads the feature list through model(x) keeps its plans: flipping the flag would make _plan_for drop every
+        # plan, buffer and hipGraph on each alternation; plan.detect takes its two-pass branch when features are on
+        eng.return_features = bool(getattr(self, 'hip_return_features', False))
         with _on_device(x.device):
             return eng.detect(x, conf_thres, iou_thres, multi_label, classes, agnostic)
 
