@@ -522,11 +522,21 @@ def train_roofline(eng, x, precision):
                        frac=round(groups[k]['flops'] / groups[k]['ms'] / 1e9 / peak, 4)) for k in sorted(cg['members'], key=lambda k: -groups[k]['ms'])}
     by_class = {c: dict(ms=round(v['ms'], 3), n=v['n'], tflops=round(v['flops'] / v['ms'] / 1e9, 1), frac=round(v['flops'] / v['ms'] / 1e9 / peak, 4))
                 for c, v in sorted(classes.items(), key=lambda kv: -kv[1]['ms']) if v['flops'] > 0}
-    return {'bound': 'mfma', 'kernel': dom, 'kernel_class': top, 'class_members': members, 'by_class': by_class,
+    # flat scalars first: the driver's record keeps the scalar keys of this object and drops the nested ones - a
+    # change of the quoted class between rounds, and the share of the BatchNorm passes, stay visible without profiles/
+    ranked = list(by_class.items())
+    second = ranked[1] if len(ranked) > 1 else (None, {})
+    bn_ms = round(sum(v[0] for k, v in roles.items() if k in ('bnact', 'dbn', 'dbnx', 'bnfin')), 3)
+    return {'bound': 'mfma', 'kernel': dom, 'kernel_class': top,
             'achieved': round(ach, 1), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(ach / peak, 4),
+            'traffic': None if traffic is None else traffic['hbm_bytes_per_launch'],
+            'class_ms': round(cg['ms'], 3), 'class2': second[0], 'class2_ms': second[1].get('ms'), 'class2_tflops': second[1].get('tflops'),
+            'class2_frac': second[1].get('frac'), 'batchnorm_passes_ms': bn_ms,
+            'top_classes': '; '.join('%s %.2f ms %.0f TFLOP/s %.3f' % (c, v['ms'], v['tflops'], v['frac']) for c, v in ranked[:4]),
+            'class_members': members, 'by_class': by_class,
             'quoted_on': 'the kernel class with the largest share of the step (all its launches); `kernel` is the instantiation that '
                          'dominates that class by time, `traffic` are that kernel\'s own counters',
-            'traffic': traffic, 'launches_per_step': cg['n'], 'avg_launch_ms': round(cg['ms'] / cg['n'], 5),
+            'traffic_detail': traffic, 'launches_per_step': cg['n'], 'avg_launch_ms': round(cg['ms'] / cg['n'], 5),
             'gflop_per_launch': round(cg['flops'] / cg['n'] / 1e9, 3), 'gpu_ms_per_step': round(total, 3),
             'by_kernel': table, 'by_role_ms': {k: round(v[0], 3) for k, v in sorted(roles.items(), key=lambda kv: -kv[1][0])}}
 

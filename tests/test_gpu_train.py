@@ -989,7 +989,17 @@ def test_training_step_on_gpu_matches_reference_golden(libs, tag, rel, size, nc)
     assert (num / den) ** 0.5 <= 3e-3
 
 
-def _reference_golden_step(gold_file, cfg_rel):
+def _worst_parameters(rows, want, lens, names, top=6):
+    """Which parameters carry the difference: (name, share of the squared error, own rel l2) of the `top` largest contributors."""
+    out, at, tot = [], 0, float(((rows - want) ** 2).sum()) + 1e-300
+    for k, n in zip(names, lens):
+        d, w = rows[at:at + n] - want[at:at + n], want[at:at + n]
+        out.append((k, float((d ** 2).sum()) / tot, float(np.linalg.norm(d) / (np.linalg.norm(w) + 1e-30))))
+        at += int(n)
+    return sorted(out, key=lambda t: -t[1])[:top]
+
+
+def _reference_golden_step(gold_file, cfg_rel, calm=False):
     """(gold, step): `step(precision, round_inputs)` runs ONE training step of this package's Darknet(cfg_rel) on the GPU in the state
     and on the inputs the golden generator gave the reference (tests/golden/make_golden_train608.py / make_golden_train_v4.py) and
     returns loss items, raw heads, sampled gradient rows with their rel l2 / cosine / norm ratio against the golden's, per-parameter
@@ -1005,6 +1015,8 @@ def _reference_golden_step(gold_file, cfg_rel):
     model0 = Darknet(os.path.join(conftest.PKG, 'cfg', *cfg_rel.split('/')), (size, size))
     state = model0.state_dict()
     synth.randomize_bn_(state, seed=1)
+    if calm:
+        synth.calm_bn_(state)
     model0.load_state_dict(state)
     model0.nc, model0.hyp, model0.gr = 80, dict(tte.GOLD_HYP), 1.0
     targets = synth.loss_inputs(model0, size, batch=batch, seed=9, labels_per_image=8)[1].to(GPU)
@@ -1040,7 +1052,7 @@ def _reference_golden_step(gold_file, cfg_rel):
         out = dict(items=items.detach().cpu().numpy(), pred=[p.detach().double().cpu() for p in pred], rows=rows,
                    sums=np.array([params[k].grad.abs().sum().item() for k in names]),
                    gnorm=float(sum(params[k].grad.double().pow(2).sum().item() for k in names) ** 0.5), sd={k: v.double().cpu() for k, v in model.state_dict().items()},
-                   rel=float(np.linalg.norm(rows - want) / np.linalg.norm(want)),
+                   rel=float(np.linalg.norm(rows - want) / np.linalg.norm(want)), worst=_worst_parameters(rows, want, gold['grad_rows_len'], names),
                    cos=float((rows * want).sum() / (np.linalg.norm(rows) * np.linalg.norm(want))), nrm=float(np.linalg.norm(rows) / np.linalg.norm(want)))
         model.__dict__['_hip_train_engine'] = None
         del model, eng, pred, loss
@@ -1099,50 +1111,63 @@ def test_headline_shape_fp32_step_against_the_reference_golden(libs, precision):
 
 
 @pytest.mark.parametrize('precision', ['fp32', 'fp16'])
-def test_yolov4_step_against_the_reference_golden(libs, precision):
-    """a WELL-CONDITIONED external anchor for the training step.  tests/golden/train_step_v4_608.npz is one training
-    step of the REFERENCE itself on YOLOv4 (cfg/yolov4/yolov4.cfg: CSPDarknet53 with Mish, SPP, PAN) at 608 x 608, batch 2, fp32 CPU
-    (tests/golden/make_golden_train_v4.py imports /root/reference).  The Darknet-53 fixture above cannot hold an fp16 engine to
-    anything (its own yardstick sits at rel l2 0.27); Mish is smooth, so here SURVEY 8(d)'s numbers are asserted AS WRITTEN for both
-    engines: loss items 1e-2, l2 norm of the whole gradient 1e-2; and the gradient itself: rel l2 of the sampled rows <= 5e-2
-    absolute and, for the fp16 engine, <= 2 x the yardstick (the fp32 engine with nothing but its weights and frames rounded to
-    fp16) + 1e-3.  The measured values are printed (profiles/r06_pytest_gpu_tail_final.txt) and quoted in DESIGN.md section 4."""
+@pytest.mark.parametrize('net', ['v3', 'v4'])
+def test_well_conditioned_step_against_the_reference_golden(libs, net, precision):
+    """a WELL-CONDITIONED external anchor for the training step at the bench shape.  tests/golden/train_step_<net>_608_calm.npz
+    is one training step of the REFERENCE itself - YOLOv3 (the network the bench times) and YOLOv4 (cfg/yolov4/yolov4.cfg: CSPDarknet53 with
+    Mish, SPP, PAN) at 608 x 608, batch 2, fp32 CPU, tests/golden/make_golden_train_calm.py imports /root/reference - in the state of
+    synth.calm_bn_: small BatchNorm gains, so that perturbations are not amplified through the depth of the net.  (In the plain random
+    state rounding the weights to fp16 alone moves Darknet-53's gradient by rel l2 0.34 and YOLOv4's by 1.5 - the verdict's hope that a
+    Mish net would be smooth did not hold, the amplification belongs to deep random batch-norm nets, not to the kinks - and the test
+    above can only cap the fp16 engine loosely.)  Here SURVEY 8(d)'s numbers are asserted AS WRITTEN for both engines: loss items 1e-2
+    (fp32: 1e-4), l2 norm of the whole gradient 1e-2 (fp32: 1e-3); and the gradient itself: rel l2 of the sampled rows <= 2e-3 for the
+    fp32 engine; for the fp16 engine <= 5e-2 absolute and <= 2 x the REFERENCE'S OWN mixed-precision step - the golden also holds the
+    reference run under torch.autocast(float16) (its --mpt recipe, train.py:371-374, on the CPU) against its fp32 step: rel l2 0.024 on
+    Darknet-53.  fp16 storage of activations and gradients costs more than fp16 weights (printed as the second yardstick: 5e-3): the
+    per-channel BatchNorm gradients are sums with heavy cancellation, and they carry most of the difference on both sides.
+    Measured values: DESIGN.md section 4 / profiles/r06_pytest_gpu_tail_final.txt."""
     if DRY:
-        pytest.skip('a 608 x 608 YOLOv4 step on the host emulation takes minutes; the emulator is covered at 64 - 128 px')
-    gold, step = _reference_golden_step('train_step_v4_608.npz', 'yolov4/yolov4.cfg')
+        pytest.skip('a 608 x 608 step on the host emulation takes minutes; the emulator is covered at 64 - 128 px')
+    gold, step = _reference_golden_step('train_step_%s_608_calm.npz' % net, {'v3': 'yolov3/yolov3.cfg', 'v4': 'yolov4/yolov4.cfg'}[net], calm=True)
     f16 = precision == 'fp16'
     r = step(precision)
     ratio = r['sums'] / np.maximum(gold['grad_checks'][:, 1], 1e-30)
     big = gold['grad_checks'][:, 1] >= 1e-3 * gold['grad_checks'][:, 1].max()
     gn = r['gnorm'] / float(gold['grad_norm'])
-    print('yolov4 608 b2 %s HIP step vs the reference golden: loss items %s (reference %s), gradient norm ratio %.5f, sampled rows rel l2 %.3g, '
-          'cosine %.6f, |grad| sum ratio of the dominant parameters %.4f .. %.4f' % (precision, r['items'], gold['items'], gn, r['rel'], r['cos'],
+    print('calm %s 608 b2 %s HIP step vs the reference golden: loss items %s (reference %s), gradient norm ratio %.5f, sampled rows rel l2 %.3g, '
+          'cosine %.6f, |grad| sum ratio of the dominant parameters %.4f .. %.4f' % (net, precision, r['items'], gold['items'], gn, r['rel'], r['cos'],
                                                                                     ratio[big].min(), ratio[big].max()))
+    print('   largest contributors to the difference (parameter, share of the squared error, own rel l2): %s' % ', '.join('%s %.2f %.2g' % w for w in r['worst']))
     y = None
     if f16:
         y = step('fp32', round_inputs=True)
-        print('yolov4 608 b2 yardstick (fp32 engine, weights + input rounded to fp16) vs the reference golden: gradient norm ratio %.5f, rel l2 %.3g, '
-              'cosine %.6f' % (y['gnorm'] / float(gold['grad_norm']), y['rel'], y['cos']))
-    np.testing.assert_allclose(r['items'], gold['items'], rtol=1e-2 if f16 else 1e-3)
+        print('calm %s 608 b2 yardstick (fp32 engine, weights + input rounded to fp16) vs the reference golden: gradient norm ratio %.5f, rel l2 %.3g, '
+              'cosine %.6f' % (net, y['gnorm'] / float(gold['grad_norm']), y['rel'], y['cos']))
+    np.testing.assert_allclose(r['items'], gold['items'], rtol=1e-2 if f16 else 1e-4)
     for i, got in enumerate(r['pred']):
         w = gold['raw%d_checks' % i]
-        assert abs(got.abs().sum().item() - w[1]) <= (1e-2 if f16 else 1e-3) * w[1], i
-    assert abs(gn - 1.0) <= 1e-2, gn                                   # SURVEY 8(d): gradient norm 1e-2
+        assert abs(got.abs().sum().item() - w[1]) <= (1e-2 if f16 else 1e-4) * w[1], i
+    assert abs(gn - 1.0) <= (1e-2 if f16 else 1e-3), gn                 # SURVEY 8(d): gradient norm 1e-2
     assert r['rel'] <= 5e-2, r['rel']
     if f16:
-        assert r['rel'] <= 2.0 * y['rel'] + 1e-3, (r['rel'], y['rel'])
+        mpt = float(gold['mpt_rel'])
+        print('calm %s 608 b2: the reference under torch.autocast(float16) against its own fp32 step: sampled rows rel l2 %.3g, gradient norm ratio %.5f'
+              % (net, mpt, float(gold['mpt_grad_norm']) / float(gold['grad_norm'])))
+        assert r['rel'] <= 2.0 * mpt, (r['rel'], mpt)
     else:
-        assert r['rel'] <= 1e-2 and r['cos'] >= 0.9999, (r['rel'], r['cos'])
-    assert 0.95 <= ratio[big].min() and ratio[big].max() <= 1.05
+        assert r['rel'] <= 2e-3 and r['cos'] >= 0.99999, (r['rel'], r['cos'])
+    # per-parameter |grad| sums of the dominant parameters (measured: fp32 0.9990 .. 1.0005, fp16 0.963 .. 1.012)
+    assert (0.95 if f16 else 0.995) <= ratio[big].min() and ratio[big].max() <= (1.05 if f16 else 1.005)
     for k, w in zip([str(n) for n in gold['running_names']], gold['running_checks']):
-        assert abs(r['sd'][k].abs().sum().item() - w[1]) <= (3e-3 if f16 else 1e-3) * w[1] + 1e-6, k
+        assert abs(r['sd'][k].abs().sum().item() - w[1]) <= (3e-3 if f16 else 1e-4) * w[1] + 1e-6, k
 
 
 @pytest.mark.parametrize('precision', ['fp32', 'fp16'])
 def test_sgd_trajectory_against_the_reference_golden(libs, precision):
     """what "training parity" means to a user - the first ten optimisation steps of the REFERENCE's loop at the
     headline shape (YOLOv3-608, batch 2; train.py:344-455 with its burn-in schedule and three-group nesterov SGD, stated once in
-    tests/sgd_protocol.py; tests/golden/sgd_608.npz generated from /root/reference's own Darknet + compute_loss on the CPU) against
+    tests/sgd_protocol.py; tests/golden/sgd_608.npz generated from /root/reference's own Darknet + compute_loss on the CPU, in the
+    well-conditioned state of synth.calm_bn_ - in the plain random state the fp32 engine itself is 11 % off by step ten) against
     the same loop on this package's Darknet on the GPU: the fp32 engine, and the fp16 engine as train.py --mpt drives it (autocast +
     GradScaler).  Per step: the four loss items within 1e-2 (fp32: 1e-3), the parameter norm within 1e-5, the displacement from the
     initial point within 1e-2 (fp32: 2e-3); at the end the parameters and running statistics by checksum."""
@@ -1156,7 +1181,7 @@ def test_sgd_trajectory_against_the_reference_golden(libs, precision):
     torch.manual_seed(0)
     model = Darknet(os.path.join(conftest.PKG, 'cfg', 'yolov3', 'yolov3.cfg'), (size, size))
     state = model.state_dict()
-    synth.randomize_bn_(state, seed=1)
+    synth.calm_bn_(synth.randomize_bn_(state, seed=1))
     model.load_state_dict(state)
     model.to(GPU)
     f16 = precision == 'fp16'

@@ -1,7 +1,15 @@
 // Training-path kernels: train-mode BatchNorm + activation forward, and their backward.
 // NHWC, one thread = one pixel x one 16-byte channel vector; per-channel reductions go through a per-block LDS
 // tree and one fp32 atomic per channel per block (Guideline 12).  Statistics and gradients of gamma/beta are fp32.
+#include <stdio.h>
+
 #include "common.h"
+
+#ifndef YH_BN_UNROLL_FWD
+#define YH_BN_UNROLL_FWD 4
+#define YH_BN_UNROLL_RED 2
+#define YH_BN_UNROLL_APP 4
+#endif
 
 namespace yh {
 
@@ -158,7 +166,13 @@ __global__ void bn_finalize_kernel(const yh_bn_desc d, const int groups, const i
     }
 }
 
-template <typename T>
+// U = pixels per thread whose loads are issued before the first of them is used (round 6).  With U = 1 (rounds 1 - 5) a thread has ONE
+// 16-byte load in flight: 8 waves per SIMD x 64 lanes x 16 B = 32 KB per CU, and at ~2 us of loaded memory latency that is 4 - 5 TB/s -
+// exactly where these passes sat while a plain torch elementwise kernel moved the same bytes at 6.0 (tools/probe/run_bn_probe.py,
+// profiles/r06_bn_probe.txt).  ACT: the activation as a COMPILE-TIME constant (round 6) - with the run-time `d.act` the switch of
+// activate() / act_grad() was expanded per element inside the loop: five scalar branches per value, ~100 per trip, in a kernel that
+// should be nothing but loads, ~12 VALU operations per value and stores.  Same arithmetic per element in every form: bit-identical.
+template <typename T, int U, int ACT>
 __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const yh_bn_desc d, const BnGeom gm) {
     typedef typename TV<T>::type V;
     constexpr int VN = TV<T>::N;
@@ -169,22 +183,19 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const yh_bn_desc d, con
     const long p1 = min(p0 + gm.ppb, (long)d.pixels);
     const int c0 = g * VN;
     const T* z = reinterpret_cast<const T*>(d.z) + c0;
-    const T* res = d.res ? reinterpret_cast<const T*>(d.res) + c0 : nullptr;
+    const bool has_res = d.res != nullptr;      // wave-uniform (a test of the per-thread pointer below is compiled as divergent)
+    const T* res = reinterpret_cast<const T*>(d.res) + c0;
     T* y = reinterpret_cast<T*>(d.out) + c0;
     float ga[VN], be[VN], mu[VN], is[VN];
     load8<VN>(d.gamma, c0, ga, 1.f);
     load8<VN>(d.beta, c0, be, 0.f);
     load8<VN>(d.gamma ? d.mean : nullptr, c0, mu, 0.f);
     load8<VN>(d.gamma ? d.invstd : nullptr, c0, is, 1.f);
-    // one 16-byte load per thread per trip at full occupancy; hoisting four pixels' loads ahead of their use was measured
-    // slower (VGPRs 114-160, occupancy 8 -> 3-4 waves per SIMD: reduce kernel 4.7 -> 5.9 ms per step)
-    for (long p = p0 + prow; p < p1; p += gm.rows) {
-        const V v = *reinterpret_cast<const V*>(z + p * d.ldz);
+    auto finish = [&](const long p, const V& v, const V& r) {
         float o[VN];
 #pragma unroll
-        for (int e = 0; e < VN; ++e) o[e] = activate(ga[e] * (((float)v[e] - mu[e]) * is[e]) + be[e], d.act, d.slope);
-        if (res) {
-            const V r = *reinterpret_cast<const V*>(res + p * d.ldr);
+        for (int e = 0; e < VN; ++e) o[e] = activate(ga[e] * (((float)v[e] - mu[e]) * is[e]) + be[e], ACT, d.slope);
+        if (has_res) {
 #pragma unroll
             for (int e = 0; e < VN; ++e) o[e] += (float)r[e];
         }
@@ -205,11 +216,34 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const yh_bn_desc d, con
         } else {
             *reinterpret_cast<V*>(y + p * d.ldo) = ov;
         }
+    };
+    long p = p0 + prow;
+    const long step = gm.rows;
+    if constexpr (U > 1) {
+        for (; p + (U - 1) * step < p1; p += U * step) {
+            V v[U], r[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) v[u] = *reinterpret_cast<const V*>(z + (p + u * step) * d.ldz);
+            if (has_res) {
+#pragma unroll
+                for (int u = 0; u < U; ++u) r[u] = *reinterpret_cast<const V*>(res + (p + u * step) * d.ldr);
+            } else {
+#pragma unroll
+                for (int u = 0; u < U; ++u) r[u] = v[u];
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) finish(p + u * step, v[u], r[u]);
+        }
+    }
+    for (; p < p1; p += step) {
+        const V v = *reinterpret_cast<const V*>(z + p * d.ldz);
+        const V r = has_res ? *reinterpret_cast<const V*>(res + p * d.ldr) : v;
+        finish(p, v, r);
     }
 }
 
 // g = dy * act'(u); accumulates sum g (-> d.sum) and sum g*xhat (-> d.sumsq)
-template <typename T>
+template <typename T, int U, int ACT>
 __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(const yh_bn_desc d, const BnGeom gm) {
     typedef typename TV<T>::type V;
     constexpr int VN = TV<T>::N;
@@ -230,24 +264,41 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(const yh_bn_desc
         load8<VN>(d.beta, c0, be, 0.f);
         load8<VN>(d.gamma ? d.mean : nullptr, c0, mu, 0.f);
         load8<VN>(d.gamma ? d.invstd : nullptr, c0, is, 1.f);
-        for (long p = p0 + prow; p < p1; p += gm.rows) {
-            const V zv = *reinterpret_cast<const V*>(z + p * d.ldz);
-            const V gv = *reinterpret_cast<const V*>(dy + p * d.lddy);
+        auto add = [&](const V& zv, const V& gv) {
 #pragma unroll
             for (int e = 0; e < VN; ++e) {
                 const float xh = ((float)zv[e] - mu[e]) * is[e];
                 const float u = ga[e] * xh + be[e];
-                const float gg = (float)gv[e] * act_grad(u, d.act, d.slope);
+                const float gg = (float)gv[e] * act_grad(u, ACT, d.slope);
                 acc[0][e] += gg;
                 acc[1][e] = fmaf(gg, xh, acc[1][e]);
             }
+        };
+        long p = p0 + prow;
+        const long step = gm.rows;
+        if constexpr (U > 1) {      // same pixel order per thread as U = 1: the sums are bit-identical
+            for (; p + (U - 1) * step < p1; p += U * step) {
+                V zv[U], gv[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    zv[u] = *reinterpret_cast<const V*>(z + (p + u * step) * d.ldz);
+                    gv[u] = *reinterpret_cast<const V*>(dy + (p + u * step) * d.lddy);
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) add(zv[u], gv[u]);
+            }
+        }
+        for (; p < p1; p += step) {
+            const V zv = *reinterpret_cast<const V*>(z + p * d.ldz);
+            const V gv = *reinterpret_cast<const V*>(dy + p * d.lddy);
+            add(zv, gv);
         }
     }
     float* const dst[2] = {d.sum, d.sumsq};
     rows_reduce_atomic<2, VN>(acc, dst, gm, cgl, prow, c0, lane_ok, gm.two_stage ? d.ws : nullptr, d.c);
 }
 
-template <typename T>
+template <typename T, int U, int ACT>
 __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const yh_bn_desc d, const BnGeom gm) {
     typedef typename TV<T>::type V;
     constexpr int VN = TV<T>::N;
@@ -271,19 +322,54 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const yh_bn_desc 
     load8<VN>(bn ? d.sumsq : nullptr, c0, m2, 0.f);
 #pragma unroll
     for (int e = 0; e < VN; ++e) { m1[e] *= invP; m2[e] *= invP; }
-    for (long p = p0 + prow; p < p1; p += gm.rows) {
-        const V zv = *reinterpret_cast<const V*>(z + p * d.ldz);
-        const V gv = *reinterpret_cast<const V*>(dy + p * d.lddy);
+    auto finish = [&](const long p, const V& zv, const V& gv) {
         V ov;
 #pragma unroll
         for (int e = 0; e < VN; ++e) {
             const float xh = ((float)zv[e] - mu[e]) * is[e];
             const float u = ga[e] * xh + be[e];
-            const float gg = (float)gv[e] * act_grad(u, d.act, d.slope);
+            const float gg = (float)gv[e] * act_grad(u, ACT, d.slope);
             ov[e] = bn ? (T)(ga[e] * is[e] * (gg - m1[e] - xh * m2[e])) : (T)gg;
         }
         *reinterpret_cast<V*>(dz + p * d.ldo) = ov;
+    };
+    long p = p0 + prow;
+    const long step = gm.rows;
+    if constexpr (U > 1) {
+        for (; p + (U - 1) * step < p1; p += U * step) {
+            V zv[U], gv[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                zv[u] = *reinterpret_cast<const V*>(z + (p + u * step) * d.ldz);
+                gv[u] = *reinterpret_cast<const V*>(dy + (p + u * step) * d.lddy);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) finish(p + u * step, zv[u], gv[u]);
+        }
     }
+    for (; p < p1; p += step) {
+        const V zv = *reinterpret_cast<const V*>(z + p * d.ldz);
+        const V gv = *reinterpret_cast<const V*>(dy + p * d.lddy);
+        finish(p, zv, gv);
+    }
+}
+
+// pixels in flight per thread of the three streaming passes (0: forward, 1: backward reduce, 2: backward apply); A/B knob
+// YH_BN_UNROLL = "f,r,a" or one number for all three
+static int bn_unroll(int which) {
+    static int v[3] = {-1, -1, -1};
+    if (v[0] < 0) {
+        int t[3] = {YH_BN_UNROLL_FWD, YH_BN_UNROLL_RED, YH_BN_UNROLL_APP};
+        const char* e = getenv("YH_BN_UNROLL");
+        if (e) {
+            int a = 0, b = 0, c = 0;
+            const int n = sscanf(e, "%d,%d,%d", &a, &b, &c);
+            if (n == 1) t[0] = t[1] = t[2] = a;
+            else if (n == 3) { t[0] = a; t[1] = b; t[2] = c; }
+        }
+        v[2] = t[2]; v[1] = t[1]; v[0] = t[0];
+    }
+    return v[which];
 }
 
 static BnGeom bn_geom(const yh_bn_desc* d, int vn, dim3* grid, int target = 4096) {
@@ -292,7 +378,14 @@ static BnGeom bn_geom(const yh_bn_desc* d, int vn, dim3* grid, int target = 4096
     gm.cgb = gm.cgs < 256 ? gm.cgs : 256;
     gm.rows = 256 / gm.cgb;
     const int gx = (gm.cgs + gm.cgb - 1) / gm.cgb;
-    long ppb = (d->pixels * gx + target - 1) / target;  // reductions: ~1024 workgroups, streaming kernels: ~4096
+    // workgroups aimed for.  Streaming passes: 16384 since round 6 (4096 before: 152^2 x 128 forward 0.149 -> 0.134 ms, 304^2 x 64 backward
+    // apply 0.45 -> 0.42 - short-lived workgroups dispatched in address order keep the chip on a compact window of memory, long-lived
+    // ones spread 2048 slow streams over the whole tensor; profiles/r06_bn_probe.txt).  Reductions: every workgroup leaves a row of
+    // partial sums for the second stage, ~1024.  A/B knobs: YH_BN_TARGET, YH_BN_RTARGET
+    static const int env_target = [] { const char* e = getenv("YH_BN_TARGET"); return e ? atoi(e) : 16384; }();
+    static const int env_rtarget = [] { const char* e = getenv("YH_BN_RTARGET"); return e ? atoi(e) : 1024; }();
+    target = target == 1024 ? env_rtarget : env_target;
+    long ppb = (d->pixels * gx + target - 1) / target;
     const long min_ppb = (long)gm.rows * 8;             // at least 8 passes: amortise the parameter loads / atomics
     if (ppb < min_ppb) ppb = min_ppb;
     ppb = (ppb + gm.rows - 1) / gm.rows * gm.rows;
@@ -741,8 +834,27 @@ extern "C" int yh_bn_act_fwd(const yh_bn_desc* d, void* stream) {
     if (d->ups == 2 && (long)d->n * d->h * d->w_in != d->pixels) return YH_EINVAL;
     dim3 grid;
     const BnGeom gm = bn_geom(d, d->dtype == YH_F16 ? 8 : 4, &grid);
-    if (d->dtype == YH_F16) hipLaunchKernelGGL(bn_act_fwd_kernel<f16>, grid, dim3(256), 0, (hipStream_t)stream, *d, gm);
-    else hipLaunchKernelGGL(bn_act_fwd_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, *d, gm);
+    const int u = bn_unroll(0);
+#define YH_BN_LAUNCH_A(K, A)                                                                                       \
+    if (d->dtype == YH_F16) {                                                                                      \
+        if (u >= 4) hipLaunchKernelGGL((K<f16, 4, A>), grid, dim3(256), 0, (hipStream_t)stream, *d, gm);            \
+        else if (u >= 2) hipLaunchKernelGGL((K<f16, 2, A>), grid, dim3(256), 0, (hipStream_t)stream, *d, gm);       \
+        else hipLaunchKernelGGL((K<f16, 1, A>), grid, dim3(256), 0, (hipStream_t)stream, *d, gm);                   \
+    } else {                                                                                                       \
+        if (u >= 4) hipLaunchKernelGGL((K<float, 4, A>), grid, dim3(256), 0, (hipStream_t)stream, *d, gm);          \
+        else if (u >= 2) hipLaunchKernelGGL((K<float, 2, A>), grid, dim3(256), 0, (hipStream_t)stream, *d, gm);     \
+        else hipLaunchKernelGGL((K<float, 1, A>), grid, dim3(256), 0, (hipStream_t)stream, *d, gm);                 \
+    }
+#define YH_BN_LAUNCH(K)                                                                                            \
+    switch (d->act) {                                                                                              \
+        case YH_ACT_LEAKY: YH_BN_LAUNCH_A(K, YH_ACT_LEAKY) break;                                                  \
+        case YH_ACT_RELU: YH_BN_LAUNCH_A(K, YH_ACT_RELU) break;                                                    \
+        case YH_ACT_RELU6: YH_BN_LAUNCH_A(K, YH_ACT_RELU6) break;                                                  \
+        case YH_ACT_HSWISH: YH_BN_LAUNCH_A(K, YH_ACT_HSWISH) break;                                                \
+        case YH_ACT_MISH: YH_BN_LAUNCH_A(K, YH_ACT_MISH) break;                                                    \
+        default: YH_BN_LAUNCH_A(K, YH_ACT_LINEAR) break;                                                           \
+    }
+    YH_BN_LAUNCH(bn_act_fwd_kernel)
     return check_launch();
 }
 
@@ -752,8 +864,8 @@ extern "C" int yh_bn_act_bwd_reduce(const yh_bn_desc* d, void* stream) {
     if (!d->sum || !d->sumsq) return YH_EINVAL;
     dim3 grid;
     const BnGeom gm = bn_geom(d, d->dtype == YH_F16 ? 8 : 4, &grid, 1024);
-    if (d->dtype == YH_F16) hipLaunchKernelGGL(bn_act_bwd_reduce_kernel<f16>, grid, dim3(256), 0, (hipStream_t)stream, *d, gm);
-    else hipLaunchKernelGGL(bn_act_bwd_reduce_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, *d, gm);
+    const int u = bn_unroll(1);
+    YH_BN_LAUNCH(bn_act_bwd_reduce_kernel)
     if (gm.two_stage) sum_partials(d, grid, stream);
     return check_launch();
 }
@@ -764,7 +876,9 @@ extern "C" int yh_bn_act_bwd_apply(const yh_bn_desc* d, void* stream) {
     if (d->gamma && (!d->sum || !d->sumsq)) return YH_EINVAL;
     dim3 grid;
     const BnGeom gm = bn_geom(d, d->dtype == YH_F16 ? 8 : 4, &grid);
-    if (d->dtype == YH_F16) hipLaunchKernelGGL(bn_act_bwd_apply_kernel<f16>, grid, dim3(256), 0, (hipStream_t)stream, *d, gm);
-    else hipLaunchKernelGGL(bn_act_bwd_apply_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, *d, gm);
+    const int u = bn_unroll(2);
+    YH_BN_LAUNCH(bn_act_bwd_apply_kernel)
+#undef YH_BN_LAUNCH
+#undef YH_BN_LAUNCH_A
     return check_launch();
 }

@@ -5,9 +5,9 @@ R="$GRAFT_REPO_ROOT"; cd "$R" || exit 1
 T=$R/yolov3v4-modelcompression-multidatasettraining-multibackbone_amd/tools
 O=gpurun_out/r6a; mkdir -p $O
 export TMPDIR=/tmp
-( timeout 900 python -m pytest tests/test_gpu_train.py -m gpu -q -s -x -k "yolov4_step or sgd_trajectory or deterministic or headline_shape_fp32_step or narrow" 2>&1 | grep -v "^Model Summary\|amdgpu.ids" | tail -40 ) > $O/tests_train.txt 2>&1
-( timeout 900 python -m pytest tests/test_ptq_calibration.py -m gpu -q -s -k "map_protocol" 2>&1 | grep -v "^Model Summary\|amdgpu.ids" | tail -12 ) > $O/tests_ptq.txt 2>&1
-for round in 1 2; do
+( timeout 900 python -m pytest tests/test_gpu_train.py -m gpu -q -s -k "well_conditioned or sgd_trajectory" 2>&1 | grep -v "^Model Summary\|amdgpu.ids" | grep "calm v\|608 b2\|sgd traj\|yolov3 320\|largest contrib\|passed\|failed\|^E  \|FAILED" | cut -c1-900 ) > $O/tests_train.txt 2>&1
+( true || timeout 900 python -m pytest tests/test_ptq_calibration.py -m gpu -q -s -k "map_protocol" 2>&1 | grep -v "^Model Summary\|amdgpu.ids" | tail -12 ) > $O/tests_ptq.txt 2>&1
+for round in ; do
   for det in 1 0; do
     echo "== YH_DETERMINISTIC=$det" >> $O/det_ab.txt
     YH_DETERMINISTIC=$det timeout 300 python bench.py --mode train --no-cpu-baseline 2>&1 | tail -1 | python -c "
@@ -17,5 +17,4 @@ k=r.get('kernels') or {}
 print(d['value'], d['ms_per_step'], {n: v['ms'] for n, v in list(k.items())[:0]}, r.get('by_class', {}).get('conv_wgrad'), {n: round(v['ms'],3) for n, v in k.items() if 'bn' in n or 'wgrad' in n or 'stem' in n})" >> $O/det_ab.txt 2>&1
   done
 done
-( timeout 300 python $T/probe/run_mall_probe.py 2>&1 | tail -14 ) > $O/mall_probe.txt 2>&1
-cat $O/tests_train.txt | tail -25; cat $O/tests_ptq.txt | tail -6; cat $O/det_ab.txt; cat $O/mall_probe.txt
+cat $O/tests_train.txt | tail -25; cat $O/tests_ptq.txt | tail -6; 
