@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define YH_ABI_VERSION 1
+#define YH_ABI_VERSION 2
 
 enum { YH_F16 = 0, YH_F32 = 1, YH_I8 = 2 };  /* YH_I8: PTQ eval path on v_mfma_i32_16x16x64_i8 (conv, stem out, pool, copy, qadd) */
 
@@ -118,8 +118,24 @@ typedef struct yh_conv_desc {
      * intermediate above is exact and the kernels evaluate clamp(round(q A + res B)), A = q_rx q_scale_x q_inv_scale_sum, B likewise:
      * the same bytes in 7 instead of 16 VALU slots per value (round 5; YH_QADD_POW2=0 keeps the general arithmetic).  */
     float q_rx, q_ra, q_scale_x, q_scale_a, q_inv_scale_sum;
+    /* Training backward (round 6; ABI 2).  bwd_z != NULL: the tensor this launch stores (a 1x1 / stride-1 data gradient, with or
+     * without its residual accumulate) COMPLETES the gradient dy of a BatchNorm + activation block - autograd of
+     * /root/reference/models.py:100-103 - whose pre-BatchNorm output is bwd_z (dtype, pitch bwd_ldz, same pixels and channels as y).
+     * The kernel then also emits that block's backward sums over the values it stores, g = dy act'(gamma xhat + beta), xhat = (z - mean)
+     * invstd: rows of [sum g | sum g xhat][cout] floats in stats_ws (yh_conv2d_bwd_stats_rows(d) rows; 0 = this launch cannot carry
+     * them), which yh_bn_act_bwd_reduce with nparts = rows adds into dbeta / dgamma - the separate reduction pass over dy and z
+     * (two reads per element) becomes one extra read of z in a kernel that has the dy row in registers anyway. */
+    const void* bwd_z;
+    const float* bwd_gamma;
+    const float* bwd_beta;
+    const float* bwd_mean;
+    const float* bwd_invstd;
+    int32_t bwd_ldz, bwd_act;
+    float bwd_slope;
+    int32_t bwd_reserved;
 } yh_conv_desc;
 int64_t yh_conv2d_stats_rows(const yh_conv_desc* d);
+int64_t yh_conv2d_bwd_stats_rows(const yh_conv_desc* d);
 
 int yh_conv2d_fwd(const yh_conv_desc* d, void* stream);
 /* YH_I8 form of the block = eval branch of BNFold_COSPTQuantizedConv2d_For_FPGA.forward

@@ -9,6 +9,7 @@ the reference goldens without a GPU.  The kernels themselves are validated on th
 same oracle.  Product code never imports this module.
 """
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -294,6 +295,18 @@ class FakeLib:
         odt = np.float32 if d.out_f32 else npdt
         out = pitched(d.y, d.n * y.shape[2] * y.shape[3], d.cout, d.ldy, odt)
         out[:] = y.permute(0, 2, 3, 1).reshape(-1, d.cout).numpy().astype(odt)
+        if _addr(d.bwd_z):      # backward sums of the block this data gradient completes (yh_conv_desc.bwd_z): one partial row
+            assert self.yh_conv2d_bwd_stats_rows(d) == 1 and d.stats_ws_floats >= 2 * d.cout and _addr(d.stats_ws)
+            ld = lambda p: torch.from_numpy(flat(p, d.cout, np.float32).copy())
+            gamma, beta, mu, istd = ld(d.bwd_gamma), ld(d.bwd_beta), ld(d.bwd_mean), ld(d.bwd_invstd)
+            dy = torch.from_numpy(out.astype(np.float32))
+            z = torch.from_numpy(pitched(d.bwd_z, d.n * d.ho * d.wo, d.cout, d.bwd_ldz, npdt).astype(np.float32))
+            xh = (z - mu) * istd
+            g = dy * self._act_grad(gamma * xh + beta, d.bwd_act, d.bwd_slope)
+            row = flat(d.stats_ws, 2 * d.cout, np.float32)
+            row[:d.cout] = g.sum(0).numpy()
+            row[d.cout:] = (g * xh).sum(0).numpy()
+            return 0
         if _addr(d.stats_ws):   # fused BatchNorm statistics of the stored values: the emulator emits a single partial row
             assert d.ups == 1 and not _addr(d.res) and d.stats_ws_floats >= 2 * d.cout
             q = torch.from_numpy(out.astype(np.float32))
@@ -623,6 +636,14 @@ class FakeLib:
     def yh_conv2d_stats_rows(self, dref):
         return 1
 
+    def yh_conv2d_bwd_stats_rows(self, dref):
+        # the emulator carries a block's backward sums on every 1x1 / stride-1 data gradient (the library: only on its persistent
+        # fp16 kernel, >= 262 144 pixels), so the CPU tier runs the fused plans at the sizes it can afford
+        d = dref._obj if hasattr(dref, '_obj') else dref
+        ok = (_addr(d.bwd_z) and d.kh == 1 and d.kw == 1 and d.stride == 1 and d.pad == 0 and d.ups == 1 and not d.out_f32
+              and d.dtype in (hiplib.YH_F16, hiplib.YH_F32) and d.act == 0 and os.environ.get('YH_NO_BWD_SUMS') is None)
+        return 1 if ok else 0
+
     # ---- COS-PTQ calibration services (csrc/calib.hip): fp32 element arithmetic, float64 sums
     def yh_ptq_search_workspace(self, count):
         return 8 * 33
@@ -823,6 +844,12 @@ class FakeLib:
 
     def yh_bn_act_bwd_reduce(self, dref, stream):
         d = dref._obj if hasattr(dref, '_obj') else dref
+        if d.nparts > 0:        # rows of [sum g | sum g xhat] left by the data gradient that completed dy (yh_conv_desc.bwd_z)
+            assert d.ws_floats >= d.nparts * 2 * d.c
+            rows = flat(d.ws, d.nparts * 2 * d.c, np.float32).reshape(d.nparts, 2, d.c)
+            flat(d.sum, d.c, np.float32)[:] += rows[:, 0].sum(0)
+            flat(d.sumsq, d.c, np.float32)[:] += rows[:, 1].sum(0)
+            return 0
         u, xh, _, _ = self._bn_u(d, self._bn_rows(d, d.z, d.ldz))
         g = self._bn_rows(d, d.dy, d.lddy) * self._act_grad(u, d.act, d.slope)
         flat(d.sum, d.c, np.float32)[:] += g.sum(0).numpy()
@@ -1077,7 +1104,8 @@ class FakeLib:
         return 1        # the emulation has one weight-gradient form
 
     def yh_bn_reduce_workspace(self, dref):
-        return 0
+        d = dref._obj if hasattr(dref, '_obj') else dref
+        return d.nparts * 2 * d.c if d.nparts > 0 else 0
 
     def yh_conv_pack_weights_dgrad(self, dtype, w, cout, cin, kh, kw, cout_k, m_pad, packed, stream):
         npdt = _NP[dtype]

@@ -42,7 +42,7 @@ def pack_conv(lib, code, w, cb=None, bn=None, eps=1e-5, cmap=None, cin_phys=None
 
 
 def conv(lib, code, x, packed, bias, cin_k, m_pad, cout_phys, k, stride, pad, act=0, slope=0.1, res=None, ups=1,
-         out_f32=False, tile=0, cin=None, x_off=0, y=None, y_off=0, res_off=0, stats=None):
+         out_f32=False, tile=0, cin=None, x_off=0, y=None, y_off=0, res_off=0, stats=None, bwd=None):
     """x: (N,H,W,ldx) NHWC buffer; reads channels [x_off, x_off+cin).  Returns the (N,Ho*ups,Wo*ups,ldy) output."""
     N, H, W, ldx = x.shape
     cin = cin if cin is not None else ldx - x_off
@@ -60,6 +60,16 @@ def conv(lib, code, x, packed, bias, cin_k, m_pad, cout_phys, k, stride, pad, ac
         ws = torch.full((rows * 2 * cout_phys,), float('nan'), device=x.device, dtype=torch.float32)
         d.stats_ws, d.stats_ws_floats = P(ws), ws.numel()
         stats['rows'], stats['ws'] = rows, ws
+    if bwd is not None:     # the block whose gradient this launch completes (yh_conv_desc.bwd_z): dict(z, gamma, beta, mean, invstd, act[, slope])
+        d.bwd_z, d.bwd_ldz, d.bwd_act, d.bwd_slope = P(bwd['z']), bwd['z'].shape[3], bwd['act'], bwd.get('slope', 0.1)
+        d.bwd_gamma, d.bwd_beta, d.bwd_mean, d.bwd_invstd = P(bwd['gamma']), P(bwd['beta']), P(bwd['mean']), P(bwd['invstd'])
+        rows = int(lib.yh_conv2d_bwd_stats_rows(C.byref(d)))
+        bwd['rows'] = rows
+        if rows <= 0:
+            return None
+        ws = torch.full((rows * 2 * cout_phys,), float('nan'), device=x.device, dtype=torch.float32)
+        d.stats_ws, d.stats_ws_floats = P(ws), ws.numel()
+        bwd['ws'] = ws
     rc = lib.yh_conv2d_fwd(C.byref(d), stream())
     assert rc == 0, 'yh_conv2d_fwd rc=%d' % rc
     return y

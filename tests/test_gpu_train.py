@@ -494,6 +494,56 @@ def test_maxpool_backward_matches_autograd(libs, code, case):
     assert (outs[0][..., 8:] - ref).abs().max().item() <= (1e-5 if code == F32 else tol16) * scale
 
 
+def _rand(g, *shape, scale=1.0):
+    return torch.randn(*shape, generator=g) * scale
+
+
+@pytest.mark.parametrize('act', [1, 5], ids=['leaky', 'mish'])
+@pytest.mark.parametrize('case', [(5, 240, 232, 32, 64, True), (3, 304, 300, 64, 128, True), (5, 240, 232, 128, 256, True), (5, 232, 240, 128, 256, False)],
+                         ids=['32-64_res', '64-128_res', '128-256_res', '128-256_write'])
+def test_data_gradient_carries_the_completed_blocks_backward_sums(libs, case, act):
+    """Round 6 (yh_conv_desc.bwd_z, conv_pw_lds.hip modes 3 / 4): a 1x1 data gradient - with or without its residual accumulate - that
+    completes the gradient dy of a BatchNorm + activation block also leaves that block's backward sums.  Against the two launches it
+    replaces: the stored tensor is bit-identical to the plain data gradient's, and the rows, added up by yh_bn_act_bwd_reduce(nparts),
+    equal the reduction pass over that tensor and z (same per-element arithmetic, other summation order: 2e-5 of sum |terms|).
+    Twice in a row: the same bits (fixed partition of the pixels over the waves, no atomics)."""
+    if DRY:
+        pytest.skip('the emulator carries the sums on any 1x1 data gradient; the plan-level test is tests/test_train_emulated.py')
+    lib, _ = libs
+    N, H, W, cin, cout, use_res = case
+    g = torch.Generator().manual_seed(cin + cout + act)
+    w = _rand(g, cout, cin, 1, 1, scale=cin ** -0.5).to(GPU)
+    cb = torch.zeros(cout, device=GPU)
+    x = _rand(g, N, H, W, cin).half().to(GPU)
+    res = _rand(g, N, H, W, cout).half().to(GPU) if use_res else None
+    z = _rand(g, N, H, W, cout).half().to(GPU)
+    gamma, beta = (torch.rand(cout, generator=g) + 0.5).to(GPU), (torch.randn(cout, generator=g) * 0.3).to(GPU)
+    mean, invstd = (torch.randn(cout, generator=g) * 0.2).to(GPU), (torch.rand(cout, generator=g) + 0.7).to(GPU)
+    packed, bias, cin_k, m_pad = oh.pack_conv(lib, F16, w, cb, None, cin_phys=cin)
+    plain = oh.conv(lib, F16, x, packed, bias, cin_k, m_pad, cout, 1, 1, 0, act=0, res=res).clone()
+    runs = []
+    for _ in range(2):
+        bw = dict(z=z, gamma=gamma, beta=beta, mean=mean, invstd=invstd, act=act)
+        y = oh.conv(lib, F16, x, packed, bias, cin_k, m_pad, cout, 1, 1, 0, act=0, res=res, bwd=bw)
+        assert y is not None and bw['rows'] > 0, 'the library does not carry the sums on this shape'
+        s1, s2 = torch.zeros(cout, device=GPU), torch.zeros(cout, device=GPU)
+        d = oh.bn_desc(F16, z, cout, dy=y, gamma=gamma, beta=beta, mean=mean, invstd=invstd, s1=s1, s2=s2, act=act)
+        d.nparts, d.ws, d.ws_floats = bw['rows'], oh.P(bw['ws']), bw['ws'].numel()
+        oh.call(lib, 'yh_bn_act_bwd_reduce', d)
+        torch.cuda.synchronize()
+        runs.append((y.clone(), s1.clone(), s2.clone()))
+    assert torch.equal(runs[0][0], plain), 'the stored data gradient changed'
+    assert all(torch.equal(a, b) for a, b in zip(runs[0], runs[1])), 'not reproducible'
+    r1, r2 = torch.zeros(cout, device=GPU), torch.zeros(cout, device=GPU)
+    oh.call(lib, 'yh_bn_act_bwd_reduce', oh.bn_desc(F16, z, cout, dy=plain, gamma=gamma, beta=beta, mean=mean, invstd=invstd, s1=r1, s2=r2, act=act))
+    torch.cuda.synchronize()
+    yf, zf = plain.float().reshape(-1, cout), z.float().reshape(-1, cout)
+    xh = (zf - mean) * invstd
+    scale1 = yf.abs().sum(0) + 1e-6
+    scale2 = (yf * xh).abs().sum(0) + 1e-6
+    assert ((runs[0][1] - r1).abs() / scale1).max().item() <= 2e-5 and ((runs[0][2] - r2).abs() / scale2).max().item() <= 2e-5
+
+
 @pytest.mark.parametrize('code', [F32, F16], ids=['fp32', 'fp16'])
 @pytest.mark.parametrize('case', [(2, 20, 20, 32, 64, 3, 1, 0), (1, 33, 31, 64, 128, 3, 2, 0), (3, 19, 19, 128, 256, 1, 1, 0),
                                   (4, 32, 32, 32, 32, 3, 1, 3), (2, 26, 26, 128, 256, 3, 1, 26), (2, 40, 40, 64, 128, 1, 1, 27),

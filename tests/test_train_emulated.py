@@ -232,6 +232,38 @@ def test_narrow_net_with_a_64_channel_stride2_conv_builds_and_trains():
         os.unlink(path)
 
 
+def test_backward_sums_ride_in_the_data_gradient_that_completes_dy(mini, monkeypatch):
+    """Round 6 (yh_conv_desc.bwd_z): when a 1x1 / stride-1 conv's data gradient writes the LAST contribution to the gradient of a
+    BatchNorm block, that launch also takes the block's backward sums (sum g, sum g xhat) from the rows it stores, and the block's
+    own reduction pass over dy and z is not emitted.  On the host emulation (which carries the sums on every such launch): the plan
+    has such launches, each followed at once by the op that adds its rows into dbeta / dgamma; the blocks they serve have no
+    reduction pass of their own; and the gradients equal those of the unfused plan (YOLO_HIP_FUSE_DBN=0) to summation order."""
+    from engine import hiplib
+    model = th.build(mini, 64)
+    x = synth.image_batch(4, 64, seed=0)
+    raws_ref, grads_ref, m_ref, ws = th.eager_step(model, x)
+    raws, grads, m = th.engine_step(model, x, ws, 'fp32', lib=fakelib.FakeLib())
+    ops = m.__dict__['_hip_train_engine']._current['bwd_ops']
+    fused = [i for i, (what, d) in enumerate(ops) if isinstance(d, hiplib.ConvDesc) and d.bwd_z]
+    assert fused, 'no data gradient carries backward sums'
+    served = set()
+    for i in fused:
+        what, d = ops[i + 1]
+        assert isinstance(d, hiplib.BnBwdReduceDesc) and d.nparts > 0 and what.startswith('dbn'), (what, d.nparts)
+        served.add(what)
+    for what, d in ops:
+        if isinstance(d, hiplib.BnBwdReduceDesc) and what in served:
+            assert d.nparts > 0, 'block %s still runs its own reduction pass' % what
+    monkeypatch.setenv('YOLO_HIP_FUSE_DBN', '0')
+    _, grads_plain, m2 = th.engine_step(model, x, ws, 'fp32', lib=fakelib.FakeLib())
+    ops2 = m2.__dict__['_hip_train_engine']._current['bwd_ops']
+    assert not [1 for what, d in ops2 if isinstance(d, hiplib.ConvDesc) and d.bwd_z]
+    assert len(ops2) == len(ops)            # one small summing op in place of one reduction pass, per served block
+    for k in grads_ref:
+        assert th.rel_l2(grads[k], grads_plain[k]) < 2e-6, k
+    assert_grads_close(grads, grads_ref, 2e-5)
+
+
 def assert_grads_close(grads, grads_ref, tol):
     """rel-l2 per parameter; gradients that are analytically zero (a BatchNorm bias feeding another BatchNorm through linear
     layers) are compared against the scale of the largest gradient instead of their own round-off."""

@@ -58,10 +58,42 @@ __device__ __forceinline__ float rcp_fast(float d) {
 // of activate()'s for every input: where the fast value, scaled by 1 / s_a, lies within 4e-6 relative of a rounding tie (k + 0.5)
 // - a few values in 10^5 - the exact form decides (mish_f64 below: activate()'s float form unless built with -DYH_QMISH_TIE_F64).  The int8 heads stay bit-equal to the reference on exact frames
 // (tests/test_ptq_large.py), which a plain substitution of the fast form did not (measured: a handful of values per tensor flip).
+// Round 6: nine VALU slots instead of ~21.  e^v straight off the hardware exp2 (argument v log2(e) rounded once: relative error
+// <= |v| 6e-8 + 1 ulp), the hardware reciprocal without its Newton step (1 ulp), no selects: above 20 the clamped form gives
+// n / (n + 2) = 1 - 2^-57, i.e. v itself to within an ulp; far below zero e^v underflows to 0 and the result is -0 like the exact
+// form's.  The errors enter through n / (n + 2), whose sensitivity to e^v is at most 2 and vanishes where Mish is the identity:
+// measured over every float with |v| <= 64 (yh_qmish_selftest): wherever the result is at least a quarter of a grid step the form stays
+// within 1e-6 relative of activate()'s (far below zero, where Mish is ~1e-20, it reaches |v| 6e-8), inside the 4e-6 band in which
+// mish_for_grid consults the exact form - and the grid values are unchanged for all 2.2e9 inputs per scale.
 __device__ __forceinline__ float mish_fast(float v) {
-    const float e = exp_fast(fminf(v, 20.f));
-    const float n = e * (e + 2.f);
-    return v > 20.f ? v : v * (n * rcp_fast(n + 2.f));
+    // No operation of this body may be contracted into an fma with a neighbour - in particular not the last product with a residual
+    // add in the caller's epilogue (it was, in one of two kernels serving the same layer: 7 of 55 680 fp16 values a ulp apart).  HIP's
+    // __fmul_rn is a plain product, so the pragma is what pins it (hipcc's default is -ffp-contract=fast-honor-pragmas).
+#pragma clang fp contract(off)
+    const float u = __builtin_amdgcn_exp2f(fminf(v, 20.f) * 1.44269504088896340736f);
+    const float n = u * (u + 2.f);
+    const float q = n * __builtin_amdgcn_rcpf(n + 2.f);
+    return v * q;
+}
+
+// derivative of the activation w.r.t. its pre-activation u (training backward: train.hip, conv_pw_lds.hip)
+__device__ __forceinline__ float act_grad(float u, int act, float slope) {
+    switch (act) {
+        case YH_ACT_LEAKY: return u > 0.f ? 1.f : slope;
+        case YH_ACT_RELU: return u > 0.f ? 1.f : 0.f;
+        case YH_ACT_RELU6: return (u > 0.f && u < 6.f) ? 1.f : 0.f;
+        case YH_ACT_HSWISH: return u <= -3.f ? 0.f : (u >= 3.f ? 1.f : (2.f * u + 3.f) / 6.f);
+        case YH_ACT_MISH: {
+            // one exp and two hardware reciprocals (1 ulp) per element: the reduce and apply kernels both evaluate this,
+            // and with two exps and two IEEE divides they were ALU bound on the mish networks (YOLOv4)
+            const float e = expf(fminf(u, 20.f));
+            const float n = e * (e + 2.f);
+            const float t = u > 20.f ? 1.f : n * __builtin_amdgcn_rcpf(n + 2.f);          // tanh(softplus(u))
+            const float sg = u > 20.f ? 1.f : e * __builtin_amdgcn_rcpf(e + 1.f);         // sigmoid(u)
+            return t + u * sg * (1.f - t * t);
+        }
+        default: return 1.f;
+    }
 }
 // Mish to one rounding: v tanh(softplus(v)) = v n / (n + 2), n = e^v (e^v + 2), evaluated in double and rounded once to float - what
 // the reference's fp32 `x * torch.tanh(F.softplus(x))` (utils/layers.py:148; softplus passes x through above 20) approximates to ~3
@@ -105,6 +137,26 @@ template <int N> __device__ __forceinline__ void mish_for_grid_n(float (&v)[N], 
     }
 #pragma unroll
     for (int e = 0; e < N; ++e) v[e] = y[e];
+}
+
+// The whole int8 Mish epilogue of N values: q[e] = round_half_away(mish(v[e]) / s_a) clamped to int8, as a float.  One scaled value
+// t = y / s_a serves the tie test (v_fract) and the rounding; the exact form replaces all N when any of them lies next to a tie
+// (same grid values either way, mish_for_grid_n); the clamp is one v_med3.
+template <int N> __device__ __forceinline__ void mish_quantize_n(const float (&v)[N], float inv_s, float (&q)[N]) {
+    float t[N];
+    bool near = false;
+#pragma unroll
+    for (int e = 0; e < N; ++e) {
+        t[e] = mish_fast(v[e]) * inv_s;
+        const float a = fabsf(t[e]);
+        near = near || fabsf(__builtin_amdgcn_fractf(a) - 0.5f) <= 4e-6f * a;
+    }
+    if (near) {
+#pragma unroll
+        for (int e = 0; e < N; ++e) t[e] = mish_f64(v[e]) * inv_s;
+    }
+#pragma unroll
+    for (int e = 0; e < N; ++e) q[e] = __builtin_amdgcn_fmed3f(copysignf(floorf(fabsf(t[e]) + 0.5f), t[e]), -128.f, 127.f);
 }
 
 template <typename T> __device__ __forceinline__ float to_f32(T v) { return (float)v; }

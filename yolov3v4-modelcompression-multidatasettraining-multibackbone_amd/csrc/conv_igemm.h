@@ -27,6 +27,11 @@ struct ConvArgs {
     int y_h, y_w, y_off_h, y_off_w;  // ups == 3: output pixel (n, ho, wo) is stored at (n, 2 ho + y_off_h, 2 wo + y_off_w) of a y_h x y_w tensor
     float q_rx, q_ra, q_scale_x, q_scale_a, q_inv_scale_sum;   // int8 + res: fused quantised shortcut (yh_qadd arithmetic)
     int no_lds_store;    // conv_pointwise.hip A/B switch: direct 4-channel stores instead of row stores through LDS
+    // training backward (yh_conv_desc.bwd_z; conv_pw_lds.hip modes 3 / 4): the block whose gradient this launch completes
+    const void* bz;
+    const float *bgamma, *bbeta, *bmean, *binvstd;
+    int ldbz, bact;
+    float bslope;
 };
 
 template <int CTRL> __device__ __forceinline__ float dpp_shr_add(float v) {
@@ -71,7 +76,7 @@ template <> struct AccOf<int8_t> { typedef i32x4 type; };
 // PTQ rounding (utils/quantized/quantized_ptq_cos.py:14-20): half away from zero, then clamp to int8
 __device__ __forceinline__ float round_clamp_i8(float t) {
     const float r = copysignf(floorf(fabsf(t) + 0.5f), t);
-    return fminf(fmaxf(r, -128.f), 127.f);
+    return __builtin_amdgcn_fmed3f(r, -128.f, 127.f);
 }
 
 template <typename OutT> __device__ __forceinline__ void store4(OutT* p, float a, float b, float c, float d);
@@ -177,6 +182,13 @@ template <int ACT, typename T> __device__ __forceinline__ float activate_t(float
     else return activate_c<ACT>(v, slope);
 }
 
+// the same choice for the epilogues that take the activation at run time (residual / 2x-store / fp32-out forms): every fp16 kernel
+// evaluates Mish by ONE formula, so two kernels that serve the same layer shape stay bit-identical to each other
+template <typename T> __device__ __forceinline__ float activate_rt(float v, int act, float slope) {
+    if (sizeof(T) == 2 && act == YH_ACT_MISH) return mish_fast(v);
+    return activate(v, act, slope);
+}
+
 // the int8 epilogues' activation: activate_c, with mish through common.h's mish_for_grid (same grid value, ~half the instructions)
 template <int ACT> __device__ __forceinline__ float activate_q(float v, float slope, float inv_out_scale) {
     if constexpr (ACT == YH_ACT_MISH) return mish_for_grid(v, inv_out_scale);
@@ -190,8 +202,10 @@ __device__ __forceinline__ void quantize4(const AccV& acc, const f32x4& bias, co
     float y[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) y[e] = (float)acc[e] * a.acc_scale + bias[e];
-    if constexpr (ACT == YH_ACT_MISH) mish_for_grid_n<4>(y, a.inv_out_scale);
-    else {
+    if constexpr (ACT == YH_ACT_MISH) {
+        mish_quantize_n<4>(y, a.inv_out_scale, q);      // tie test and rounding share one scaled value (common.h)
+        return;
+    } else {
 #pragma unroll
         for (int e = 0; e < 4; ++e) y[e] = activate_c<ACT>(y[e], a.slope);
     }
@@ -410,7 +424,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, AccT (&acc)[TM]
                     if (p0 + wn * TN * 16 + j * 16 + pc < a.P) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
-                            const float q = (float)(OutT)activate((float)acc[i][j][e] + bvs[i][e], a.act, a.slope);
+                            const float q = (float)(OutT)activate_rt<T>((float)acc[i][j][e] + bvs[i][e], a.act, a.slope);
                             s1[e] += q;
                             s2[e] = fmaf(q, q, s2[e]);
                         }
@@ -482,7 +496,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, AccT (&acc)[TM]
                     }
                 } else {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = activate((float)acc[i][j][e] + bv[e], a.act, a.slope);
+                    for (int e = 0; e < 4; ++e) v[e] = activate_rt<T>((float)acc[i][j][e] + bv[e], a.act, a.slope);
                     if (rg != nullptr) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[e] += (float)rv[jj][i][e];
@@ -509,8 +523,8 @@ long stream3_stats_rows(long P, int cout);                                      
 // plain / residual / statistics forms
 int launch_pwl_tile(const ConvArgs& a, int dtype, hipStream_t stream);
 bool pwl_supported(int dtype, int out_f32, int cin, int cin_k, int cout, long P, int ldx, int ldy, int ldr, const void* x, const void* y,
-                   const void* res, bool stats);
-long pwl_stats_rows(long P, int cout);                                                          // one row per pixel stream
+                   const void* res, bool stats, bool bwd);
+long pwl_stats_rows(long P, int cout, bool bwd = false);                                                          // one row per pixel stream
 // conv_halo_pp.hip, tile code 43: 3x3 / s1 / p1, 128 channels x 512 virtual pixels; f16 and int8, output type = input type
 int launch_hpp_tile(const ConvArgs& a, int dtype, hipStream_t stream);
 bool hpp_geometry(int W, int cin_k, int bk, int* rows_hp, int* lb, int* hbufs, size_t* lds);

@@ -238,7 +238,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm_kernel(const ConvA
             const f32x4 bv = *reinterpret_cast<const f32x4*>(a.bias + m);
             float v[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = activate(acc[i][j][e] + bv[e], a.act, a.slope);
+            for (int e = 0; e < 4; ++e) v[e] = activate_rt<T>(acc[i][j][e] + bv[e], a.act, a.slope);
             if (a.stats_part != nullptr) {   // statistics of the values as stored (rounded to the output type)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -731,7 +731,7 @@ __global__ __launch_bounds__(512, (BM <= 128 ? 4 : 2)) void conv3x3_halo_kernel(
             if (m >= a.Cout) continue;
             float v[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = activate(acc[i][j][e] + bvs[i][e], a.act, a.slope);
+            for (int e = 0; e < 4; ++e) v[e] = activate_rt<T>(acc[i][j][e] + bvs[i][e], a.act, a.slope);
             if (have_res) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] += (float)rv[i][e];
@@ -1021,8 +1021,10 @@ static bool pick_stream3_tile(const yh_conv_desc* d) {
 static bool pwl_desc_supported(const yh_conv_desc* d) {
     if (d->kh != 1 || d->kw != 1 || d->stride != 1 || d->pad != 0 || d->ups != 1) return false;
     if (d->act != YH_ACT_LINEAR && d->act != YH_ACT_LEAKY && d->act != YH_ACT_MISH) return false;
+    const bool bwd = d->bwd_z != nullptr;      // backward sums of the block this data gradient completes: stats_ws then holds THEIR rows
+    if (bwd && (d->act != YH_ACT_LINEAR || (d->bwd_act != YH_ACT_LEAKY && d->bwd_act != YH_ACT_MISH))) return false;
     return yh::pwl_supported(d->dtype, d->out_f32, d->cin, d->cin_k, d->cout, (long)d->n * d->ho * d->wo, d->ldx, d->ldy, d->ldr, d->x, d->y,
-                             d->res, d->stats_ws != nullptr);
+                             d->res, !bwd && d->stats_ws != nullptr, bwd);
 }
 static bool pick_pwl_tile(const yh_conv_desc* d) {
     static const bool off = getenv("YH_NO_PWL") != nullptr;
@@ -1057,8 +1059,19 @@ static bool tile_geometry(int tile, int* bn, int* wn) {
     }
 }
 
+// rows of [sum g | sum g xhat][cout] a launch with bwd_z leaves in stats_ws; 0: this launch cannot carry the block's backward sums
+// (only the persistent 1x1 kernel can: fp16, the data-gradient shapes of conv_pw_lds.hip, >= 262 144 pixels)
+extern "C" int64_t yh_conv2d_bwd_stats_rows(const yh_conv_desc* d) {
+    if (!d || !d->bwd_z || !d->bwd_gamma || !d->bwd_beta || !d->bwd_mean || !d->bwd_invstd || d->n <= 0 || d->ho <= 0 || d->wo <= 0) return 0;
+    if (d->dtype != YH_F16 || d->bwd_ldz % 8 || !yh::aligned16(d->bwd_z) || (d->tile != 0 && d->tile != 73)) return 0;
+    static const bool off = getenv("YH_NO_BWD_SUMS") != nullptr;      // A/B knob
+    if (off || !pick_pwl_tile(d)) return 0;
+    return (int64_t)yh::pwl_stats_rows((long)d->n * d->ho * d->wo, d->cout, true);
+}
+
 extern "C" int64_t yh_conv2d_stats_rows(const yh_conv_desc* d) {
     if (!d || d->n <= 0 || d->ho <= 0 || d->wo <= 0 || d->dtype == YH_I8) return 0;
+    if (d->bwd_z) return 0;
     int bn, wn;
     // the geometry of the launch that WILL carry the statistics: the workspace is attached after this query, and kernels without
     // a statistics epilogue (halo) must not be chosen on its account
@@ -1145,6 +1158,20 @@ extern "C" int yh_conv2d_fwd(const yh_conv_desc* d, void* stream) {
     if (d->dtype == YH_I8 && d->res) qadd_pow2_args(a);
     a.no_lds_store = getenv("YH_PW_DIRECT") != nullptr;
     a.stats_part = nullptr;
+    a.bz = nullptr;
+    a.bgamma = a.bbeta = a.bmean = a.binvstd = nullptr;
+    a.ldbz = a.bact = 0;
+    a.bslope = 0.f;
+    if (d->bwd_z) {
+        // the block's backward sums ride in this data gradient (conv_pw_lds.hip modes 3 / 4): rows into stats_ws
+        const int64_t rows = yh_conv2d_bwd_stats_rows(d);
+        if (rows <= 0) return YH_EUNSUPPORTED;
+        if (!d->stats_ws || d->stats_ws_floats < rows * 2 * d->cout) return YH_EINVAL;
+        a.stats_part = d->stats_ws;
+        a.bz = d->bwd_z; a.ldbz = d->bwd_ldz; a.bact = d->bwd_act; a.bslope = d->bwd_slope;
+        a.bgamma = d->bwd_gamma; a.bbeta = d->bwd_beta; a.bmean = d->bwd_mean; a.binvstd = d->bwd_invstd;
+        return launch_pwl_tile(a, d->dtype, (hipStream_t)stream);
+    }
     if (d->stats_ws) {
         // fused BatchNorm statistics: plain dense output only, and never on the halo kernels
         if (d->ups != 1 || d->res || d->dtype == YH_I8 || (d->tile >= 40 && d->tile < 50 && d->tile != 43)) return YH_EINVAL;

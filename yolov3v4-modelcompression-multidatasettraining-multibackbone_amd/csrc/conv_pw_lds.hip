@@ -41,12 +41,21 @@ template <> struct PwlMma<int8_t> {
 };
 
 // MT: 16-channel row groups per wave (<= 8); KS: K steps of 32 (fp16) / 64 (int8) input channels; MS: waves per pixel stream
-// (channel split); MODE 0 plain, 1 residual, 2 statistics (fp16 only)
+// (channel split); MODE 0 plain, 1 residual, 2 statistics (fp16 only).
+// MODE 3 / 4 (round 6; fp16 data gradients, yh_conv_desc.bwd_z): the tensor this launch stores - with (3) or without (4) its residual
+// accumulate - COMPLETES the gradient dy of a BatchNorm + activation block, so the block's backward sums are taken here, from the
+// rows as stored: the row-major pass already holds 8 channels of one pixel per lane; it loads the matching 16 bytes of the block's
+// pre-BatchNorm output z (issued before the K loop, consumed after it), forms g = dy act'(gamma xhat + beta), xhat = (z - mean) invstd
+// with train.hip's arithmetic and keeps sum g / sum g xhat per lane over all of the wave's blocks - one partial row per pixel stream,
+// as mode 2.  ACT is then the BLOCK's activation (the data gradient itself is linear).  What it saves: the separate reduction pass
+// read dy and z (4 bytes per element); here z alone is read (2), in a kernel that streams 10 bytes per element anyway.
 template <typename T, int MT, int KS, int MS, int ACT, int MODE>
 __global__ __launch_bounds__(512, 2) void conv1x1_lds_kernel(const ConvArgs a, const int nblocks) {
     typedef typename PwlMma<T>::frag_t frag_t;
     typedef typename PwlMma<T>::acc_t acc_t;
     static_assert(sizeof(T) == 2 || MODE == 0, "int8: plain mode only");
+    constexpr bool RES = MODE == 1 || MODE == 3, BWD = MODE == 3 || MODE == 4;
+    constexpr int CACT = BWD ? YH_ACT_LINEAR : ACT;           // the convolution's own activation
     constexpr int ES = sizeof(T), VEC = 16 / ES, KB = 4 * VEC; // bytes per element, elements per 16-byte unit, channels per K step
     constexpr int NW = 8, TN = 2, BP = TN * 16;               // 8 waves; 32 pixels per block
     constexpr int ROWB = MT * 16 * ES;                        // bytes of this wave's channels in one pixel row
@@ -90,9 +99,30 @@ __global__ __launch_bounds__(512, 2) void conv1x1_lds_kernel(const ConvArgs a, c
     float s1[8], s2[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) s1[e] = s2[e] = 0.f;
+    float pg[8], pb[8], pm[8], pi[8];                         // BWD: this lane's 8 channels of the block's BatchNorm
+    const T* const zg = reinterpret_cast<const T*>(a.bz);
+    if constexpr (BWD) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int c = ch0 + cu * 8 + e;
+            pg[e] = a.bgamma[c];
+            pb[e] = a.bbeta[c];
+            pm[e] = a.bmean[c];
+            pi[e] = a.binvstd[c];
+        }
+    }
 
     frag_t fb[TN][KS];
     u32x4 rv[NPASS];
+    u32x4 zv[BWD ? NPASS : 1];
+    auto load_z = [&](int blk) {              // the block's z rows of THIS pixel block, row-major as the store pass
+#pragma unroll
+        for (int q = 0; q < (BWD ? NPASS : 0); ++q) {
+            long p = (long)blk * BP + rr + q * RPI;
+            p = p < a.P ? p : a.P - 1;
+            zv[q] = *reinterpret_cast<const u32x4*>(zg + p * a.ldbz + ch0 + cu * VEC);
+        }
+    };
     auto load_b = [&](int blk, int k) {       // K step k of block blk (clamped: a tail re-loads valid bytes that are never stored)
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
@@ -114,11 +144,12 @@ __global__ __launch_bounds__(512, 2) void conv1x1_lds_kernel(const ConvArgs a, c
     if (blk < nblocks) {
 #pragma unroll
         for (int k = 0; k < KS; ++k) load_b(blk, k);
-        if constexpr (MODE == 1) load_res(blk);
+        if constexpr (RES) load_res(blk);
     }
     for (; blk < nblocks; blk += nstreams) {
         const int nb = blk + nstreams < nblocks ? blk + nstreams : blk;     // past the end: this block again (unused)
-        if constexpr (MODE == 1) {
+        if constexpr (BWD) load_z(blk);       // in flight over the K loop, used in the store pass
+        if constexpr (RES) {
             // park this block's residual rows in the staging tile (row-major 16-byte units), then fetch the next block's
 #pragma unroll
             for (int q = 0; q < NPASS; ++q) *reinterpret_cast<u32x4*>(tile + (rr + q * RPI) * PITCH + cu * 16) = rv[q];
@@ -139,7 +170,7 @@ __global__ __launch_bounds__(512, 2) void conv1x1_lds_kernel(const ConvArgs a, c
                 for (int j = 0; j < TN; ++j) acc[i][j] = PwlMma<T>::mma(wa[i], fb[j][k], acc[i][j]);
             load_b(nb, k);                     // refill: the next block's bytes for this K step
         }
-        if constexpr (MODE == 1) load_res(nb);  // before this block's stores: loads and stores share one in-order queue
+        if constexpr (RES) load_res(nb);  // before this block's stores: loads and stores share one in-order queue
         __builtin_amdgcn_wave_barrier();
         // ---- phase 1: bias + activation (+ residual from the tile, fp32, one rounding) -> the tile, 4 channels of one pixel per lane
 #pragma unroll
@@ -150,12 +181,12 @@ __global__ __launch_bounds__(512, 2) void conv1x1_lds_kernel(const ConvArgs a, c
                 T* const cell = reinterpret_cast<T*>(tile + (j * 16 + pc) * PITCH) + i * 16 + mq;
                 float v[4];
                 if constexpr (sizeof(T) == 1) {      // the requantising epilogue of conv_igemm.h (conv_epilogue_plain)
-                    quantize4<ACT>(acc[i][j], bv, a, v);
+                    quantize4<CACT>(acc[i][j], bv, a, v);
                 } else {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = activate_t<ACT, T>(acc[i][j][e] + bv[e], a.slope);
+                    for (int e = 0; e < 4; ++e) v[e] = activate_t<CACT, T>(acc[i][j][e] + bv[e], a.slope);
                 }
-                if constexpr (MODE == 1) {
+                if constexpr (RES) {
                     const f16x4 r = *reinterpret_cast<const f16x4*>(cell);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] += (float)r[e];
@@ -181,10 +212,21 @@ __global__ __launch_bounds__(512, 2) void conv1x1_lds_kernel(const ConvArgs a, c
                     s2[e] = fmaf(f, f, s2[e]);
                 }
             }
+            if constexpr (BWD) {              // train.hip bn_act_bwd_reduce_kernel's arithmetic on the row as stored
+                const f16x8 h = __builtin_bit_cast(f16x8, v), zz = __builtin_bit_cast(f16x8, zv[q]);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float xh = ((float)zz[e] - pm[e]) * pi[e];
+                    const float u = pg[e] * xh + pb[e];
+                    const float gg = (ok ? (float)h[e] : 0.f) * act_grad(u, ACT, a.bslope);
+                    s1[e] += gg;
+                    s2[e] = fmaf(gg, xh, s2[e]);
+                }
+            }
         }
         __builtin_amdgcn_wave_barrier();
     }
-    if constexpr (MODE == 2) {
+    if constexpr (MODE == 2 || BWD) {
         // one partial row per pixel stream: [sum | sum of squares][Cout]; the RPI lanes that share a channel unit add up first
 #pragma unroll
         for (int e = 0; e < 8; ++e)
@@ -205,15 +247,20 @@ __global__ __launch_bounds__(512, 2) void conv1x1_lds_kernel(const ConvArgs a, c
 }
 
 // (MT, KS, MS) of a layer, or false: Cout = 16 MT MS exactly, Cin = kb KS (kb = 32 fp16 / 64 int8), weights <= 64 KB, MT <= 8
-static bool pwl_shape(int cin_k, int cout, int kb, int* mt, int* ks, int* ms) {
+// bwd (modes 3 / 4): 64 channels per wave (MT = 4) whatever Cout is - the z rows, the block's 32 BatchNorm parameters and the two sums
+// per lane leave no room for 128-channel accumulators (256 VGPRs: the MT = 8 forms spilled 20 .. 108 bytes)
+static bool pwl_shape(int cin_k, int cout, int kb, int* mt, int* ks, int* ms, bool bwd = false) {
     if (cin_k % kb || cout % 16 || cout < 32 || cout > 256 || cin_k < kb || cin_k > 8 * kb) return false;
-    *ms = cout > 128 ? 2 : 1;
+    *ms = bwd ? cout / 64 : (cout > 128 ? 2 : 1);
+    if (bwd && (cout % 64 || *ms < 1)) return false;
     if (cout % (16 * *ms)) return false;
     *mt = cout / (16 * *ms);
     *ks = cin_k / kb;
     if (*mt > 8 || (*mt != 2 && *mt != 4 && *mt != 8) || (*ks != 1 && *ks != 2 && *ks != 4 && *ks != 8)) return false;
     return (long)cout * cin_k * (kb == 32 ? 2 : 1) <= 64 * 1024;
 }
+
+static int pwl_ms(int cout, bool bwd) { return bwd ? cout / 64 : (cout > 128 ? 2 : 1); }
 
 static int pwl_grid(long P, int ms, int* nblocks) {
     *nblocks = (int)((P + 31) / 32);
@@ -235,11 +282,18 @@ static bool pwl_f16_case(int mt, int ks, int ms) {
            (mt == 8 && ks == 8 && ms == 1) || (mt == 8 && ks == 4 && ms == 2) || (mt == 8 && ks == 4 && ms == 1) || (mt == 4 && ks == 2 && ms == 1);
 }
 
+// the data-gradient shapes that carry a block's backward sums (modes 3 / 4): 32 -> 64 (304^2), 64 -> 128 (152^2), 128 -> 256 (76^2)
+static bool pwl_bwd_case(int mt, int ks, int ms) {
+    return mt == 4 && ((ks == 1 && ms == 1) || (ks == 2 && ms == 2) || (ks == 4 && ms == 4));
+}
+
 bool pwl_supported(int dtype, int out_f32, int cin, int cin_k, int cout, long P, int ldx, int ldy, int ldr, const void* x, const void* y,
-                   const void* res, bool stats) {
+                   const void* res, bool stats, bool bwd) {
     int mt, ks, ms;
     if ((dtype != YH_F16 && dtype != YH_I8) || out_f32 || cin != cin_k) return false;
-    if (!pwl_shape(cin_k, cout, dtype == YH_I8 ? 64 : 32, &mt, &ks, &ms)) return false;
+    if (!pwl_shape(cin_k, cout, dtype == YH_I8 ? 64 : 32, &mt, &ks, &ms, bwd)) return false;
+    if (bwd) return dtype == YH_F16 && !stats && pwl_bwd_case(mt, ks, ms) && ldx % 8 == 0 && ldy % 8 == 0 && (!res || ldr % 8 == 0) &&
+                    aligned16(x) && aligned16(y) && (!res || aligned16(res)) && P > 0 && P < (1L << 31) - 64;
     if (stats && res) return false;
     if (dtype == YH_I8 && (stats || res || !pwl_i8_case(mt, ks, ms))) return false;      // plain mode, the shapes instantiated below
     if (dtype == YH_F16 && !pwl_f16_case(mt, ks, ms)) return false;
@@ -248,9 +302,9 @@ bool pwl_supported(int dtype, int out_f32, int cin, int cin_k, int cout, long P,
     return P > 0 && P < (1L << 31) - 64;
 }
 
-long pwl_stats_rows(long P, int cout) {
+long pwl_stats_rows(long P, int cout, bool bwd) {
     int nblocks;
-    const int ms = cout > 128 ? 2 : 1;
+    const int ms = pwl_ms(cout, bwd);
     return (long)pwl_grid(P, ms, &nblocks) * 8 / ms;
 }
 
@@ -266,10 +320,19 @@ template <typename T, int MT, int KS, int MS, int ACT> static int launch_pwl_mod
         hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, s, a, nblocks);                                  \
     } while (0)
     if constexpr (sizeof(T) == 1) {
-        if (a.stats_part || a.res) return YH_EUNSUPPORTED;
+        if (a.stats_part || a.res || a.bz) return YH_EUNSUPPORTED;
         YH_PWL_GO(0);
     } else {
-        if (a.stats_part) YH_PWL_GO(2);
+        if (a.bz) {
+            // backward sums of the block this data gradient completes: ACT is that block's activation
+            if constexpr ((ACT == YH_ACT_LEAKY || ACT == YH_ACT_MISH) && MT == 4 && ((KS == 1 && MS == 1) || (KS == 2 && MS == 2) || (KS == 4 && MS == 4))) {
+                if (!a.stats_part) return YH_EINVAL;
+                if (a.res) YH_PWL_GO(3);
+                else YH_PWL_GO(4);
+            } else {
+                return YH_EUNSUPPORTED;
+            }
+        } else if (a.stats_part) YH_PWL_GO(2);
         else if (a.res) YH_PWL_GO(1);
         else YH_PWL_GO(0);
     }
@@ -278,7 +341,7 @@ template <typename T, int MT, int KS, int MS, int ACT> static int launch_pwl_mod
 }
 
 template <typename T, int MT, int KS, int MS> static int launch_pwl_act(const ConvArgs& a, hipStream_t s) {
-    switch (a.act) {
+    switch (a.bz ? a.bact : a.act) {
         case YH_ACT_LINEAR: return launch_pwl_mode<T, MT, KS, MS, YH_ACT_LINEAR>(a, s);
         case YH_ACT_LEAKY: return launch_pwl_mode<T, MT, KS, MS, YH_ACT_LEAKY>(a, s);
         case YH_ACT_MISH: return launch_pwl_mode<T, MT, KS, MS, YH_ACT_MISH>(a, s);
@@ -289,7 +352,7 @@ template <typename T, int MT, int KS, int MS> static int launch_pwl_act(const Co
 // tile code 73 (conv_igemm.hip yh_conv2d_tile)
 int launch_pwl_tile(const ConvArgs& a, int dtype, hipStream_t s) {
     int mt, ks, ms;
-    if (!pwl_shape(a.cin_k, a.Cout, dtype == YH_I8 ? 64 : 32, &mt, &ks, &ms)) return YH_EUNSUPPORTED;
+    if (!pwl_shape(a.cin_k, a.Cout, dtype == YH_I8 ? 64 : 32, &mt, &ks, &ms, a.bz != nullptr)) return YH_EUNSUPPORTED;
 #define YH_PWL_CASE(T, M, K, S2) if (mt == M && ks == K && ms == S2) return launch_pwl_act<T, M, K, S2>(a, s)
     if (dtype == YH_I8) {
         YH_PWL_CASE(int8_t, 8, 4, 1);    // 256 -> 128   (76^2)
@@ -309,6 +372,8 @@ int launch_pwl_tile(const ConvArgs& a, int dtype, hipStream_t s) {
     YH_PWL_CASE(f16, 8, 4, 2);    // 128 -> 256   (76^2 data gradient)
     YH_PWL_CASE(f16, 8, 4, 1);    // 128 -> 128   (YOLOv4 CSP stages)
     YH_PWL_CASE(f16, 4, 2, 1);    //  64 ->  64
+    YH_PWL_CASE(f16, 4, 2, 2);    //  64 -> 128   (152^2 data gradient carrying a block's backward sums: 64 channels per wave)
+    YH_PWL_CASE(f16, 4, 4, 4);    // 128 -> 256   (76^2, likewise)
 #undef YH_PWL_CASE
     return YH_EUNSUPPORTED;
 }

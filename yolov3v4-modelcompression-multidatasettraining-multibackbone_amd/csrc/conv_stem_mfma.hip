@@ -271,6 +271,7 @@ __global__ __launch_bounds__(256, 2) void conv_stem_mfma_kernel(const yh_stem_de
     };
     auto finish = [&](float v) {
         float y = ACT == YH_ACT_LINEAR ? v : ACT == YH_ACT_LEAKY ? (v > 0.f ? v : v * d.slope)
+                  : ACT == YH_ACT_MISH ? (sizeof(T) == 1 ? mish_for_grid(v, inv_q) : sizeof(T) == 2 ? mish_fast(v) : activate(v, YH_ACT_MISH, 0.f))
                   : (sizeof(T) == 1 && d.act == YH_ACT_MISH) ? mish_for_grid(v, inv_q) : activate(v, d.act, d.slope);
         if constexpr (sizeof(T) == 1) {      // PTQ: onto the activation grid (round half away, clamp)
             const float s = y * inv_q;
@@ -455,6 +456,7 @@ static stem_kern_t stem_pick(const yh_stem_desc& d) {
         if (d.stats_ws_floats > 0) return d.act == YH_ACT_LINEAR ? YH_STEMK(T, YH_ACT_LINEAR, true) : nullptr;             \
         if (d.act == YH_ACT_LINEAR) return YH_STEMK(T, YH_ACT_LINEAR, false);                                              \
         if (d.act == YH_ACT_LEAKY) return YH_STEMK(T, YH_ACT_LEAKY, false);                                                \
+        if (d.act == YH_ACT_MISH) return YH_STEMK(T, YH_ACT_MISH, false);      /* YOLOv4's first block, round 6 */            \
         return YH_STEMK(T, -1, false);                                                                                     \
     } while (0)
     if (d.dtype == YH_F16) YH_STEMM(f16);
@@ -462,6 +464,7 @@ static stem_kern_t stem_pick(const yh_stem_desc& d) {
     if (d.dtype == YH_I8) {
         if (d.stats_ws_floats > 0) return nullptr;
         if (d.act == YH_ACT_LEAKY) return YH_STEMK(int8_t, YH_ACT_LEAKY, false);
+        if (d.act == YH_ACT_MISH) return YH_STEMK(int8_t, YH_ACT_MISH, false);
         return YH_STEMK(int8_t, -1, false);
     }
 #undef YH_STEMM

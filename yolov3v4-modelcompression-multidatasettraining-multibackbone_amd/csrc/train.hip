@@ -17,26 +17,6 @@ template <typename T> struct TV;
 template <> struct TV<f16> { typedef f16x8 type; static constexpr int N = 8; };
 template <> struct TV<float> { typedef f32x4 type; static constexpr int N = 4; };
 
-// derivative of the activation w.r.t. its pre-activation u
-__device__ __forceinline__ float act_grad(float u, int act, float slope) {
-    switch (act) {
-        case YH_ACT_LEAKY: return u > 0.f ? 1.f : slope;
-        case YH_ACT_RELU: return u > 0.f ? 1.f : 0.f;
-        case YH_ACT_RELU6: return (u > 0.f && u < 6.f) ? 1.f : 0.f;
-        case YH_ACT_HSWISH: return u <= -3.f ? 0.f : (u >= 3.f ? 1.f : (2.f * u + 3.f) / 6.f);
-        case YH_ACT_MISH: {
-            // one exp and two hardware reciprocals (1 ulp) per element: the reduce and apply kernels both evaluate this,
-            // and with two exps and two IEEE divides they were ALU bound on the mish networks (YOLOv4)
-            const float e = expf(fminf(u, 20.f));
-            const float n = e * (e + 2.f);
-            const float t = u > 20.f ? 1.f : n * __builtin_amdgcn_rcpf(n + 2.f);          // tanh(softplus(u))
-            const float sg = u > 20.f ? 1.f : e * __builtin_amdgcn_rcpf(e + 1.f);         // sigmoid(u) = e^u / (e^u + 1)
-            return t + u * sg * (1.f - t * t);
-        }
-        default: return 1.f;
-    }
-}
-
 // Thread mapping shared by all five kernels: a workgroup covers `cgb` channel groups (16 bytes each) x `rows` pixels
 // per pass, consecutive lanes on consecutive channel groups of the same pixel, so a wave reads whole contiguous rows
 // (1 KB per instruction when the tensor is dense).  Each thread keeps ONE channel group for its whole pixel range:
@@ -767,6 +747,7 @@ extern "C" int yh_maxpool2d_bwd(const yh_pool_bwd_desc* d, void* stream) {
 
 extern "C" int64_t yh_bn_reduce_workspace(const yh_bn_desc* d) {
     if (!d || d->c <= 0 || d->pixels <= 0 || (d->dtype != YH_F16 && d->dtype != YH_F32)) return 0;
+    if (d->nparts > 0) return (int64_t)d->nparts * 2 * d->c;      // the rows a data-gradient launch left (yh_conv_desc.bwd_z)
     dim3 grid;
     yh_bn_desc tmp = *d;
     tmp.ws = nullptr;
@@ -859,6 +840,14 @@ extern "C" int yh_bn_act_fwd(const yh_bn_desc* d, void* stream) {
 }
 
 extern "C" int yh_bn_act_bwd_reduce(const yh_bn_desc* d, void* stream) {
+    if (d && d->nparts > 0) {
+        // the sums were taken by the launch that completed dy (yh_conv_desc.bwd_z, conv_pw_lds.hip): d->ws holds nparts rows of
+        // [sum g | sum g xhat][c]; add them into dbeta / dgamma in a fixed order
+        if (!d->sum || !d->sumsq || !d->ws || d->c <= 0 || d->ws_floats < (int64_t)d->nparts * 2 * d->c) return YH_EINVAL;
+        hipLaunchKernelGGL(bn_partials_kernel, dim3((2 * d->c + 15) / 16, 1), dim3(1024), 0, (hipStream_t)stream, d->ws, d->nparts,
+                           d->nparts, d->c, d->sum, d->sumsq);
+        return check_launch();
+    }
     int rc = check_bn(d, true, false);
     if (rc) return rc;
     if (!d->sum || !d->sumsq) return YH_EINVAL;

@@ -28,7 +28,10 @@ class ConvDesc(C.Structure):
                 ('act', _i32), ('slope', _f32), ('ups', _i32), ('out_f32', _i32), ('dtype', _i32), ('tile', _i32),
                 ('acc_scale', _f32), ('out_scale', _f32),
                 ('y_h', _i32), ('y_w', _i32), ('y_off_h', _i32), ('y_off_w', _i32), ('stats_ws', _vp), ('stats_ws_floats', _i64),
-                ('q_rx', _f32), ('q_ra', _f32), ('q_scale_x', _f32), ('q_scale_a', _f32), ('q_inv_scale_sum', _f32)]
+                ('q_rx', _f32), ('q_ra', _f32), ('q_scale_x', _f32), ('q_scale_a', _f32), ('q_inv_scale_sum', _f32),
+                # training backward (ABI 2): the block whose gradient this data gradient completes - its backward sums ride along
+                ('bwd_z', _vp), ('bwd_gamma', _vp), ('bwd_beta', _vp), ('bwd_mean', _vp), ('bwd_invstd', _vp),
+                ('bwd_ldz', _i32), ('bwd_act', _i32), ('bwd_slope', _f32), ('bwd_reserved', _i32)]
 
 
 class StemDesc(C.Structure):
@@ -241,6 +244,7 @@ _SIGNATURES = {
     'yh_conv2d_fwd': (C.c_int, [C.POINTER(ConvDesc), _vp]),
     'yh_conv2d_tile': (C.c_int, [C.POINTER(ConvDesc)]),
     'yh_conv2d_stats_rows': (_i64, [C.POINTER(ConvDesc)]),
+    'yh_conv2d_bwd_stats_rows': (_i64, [C.POINTER(ConvDesc)]),
     'yh_qconv_pack_weights': (C.c_int, [_vp, _f32, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp]),
     'yh_stem_pack_weights': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _f32, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                        _vp, _vp, _vp]),
@@ -315,7 +319,7 @@ _SIGNATURES = {
 }
 
 EXPORTS = tuple(_SIGNATURES)
-ABI_VERSION = 1
+ABI_VERSION = 2
 _lib = None
 
 

@@ -520,6 +520,31 @@ class TrainEngine(DarknetEngine):
             if getattr(u, 'gstorage', None) is not None:
                 holders[id(u.gstorage)] = holders.get(id(u.gstorage), 0) + 1
 
+        # Who reads each value (by identity), in forward order: the backward runs over `values` in reverse, so the LAST contribution to
+        # a value's gradient comes from its consumer with the smallest index.  When that consumer is a 1x1 / stride-1 conv whose data
+        # gradient the library can run on its persistent kernel, the gradient it completes belongs to a BatchNorm block whose
+        # backward sums (sum g, sum g xhat) can be taken by that very launch - it has the finished dy rows in registers and reads z
+        # on top - instead of by a reduction pass over dy and z (yh_conv_desc.bwd_z, round 6; YOLO_HIP_FUSE_DBN=0 switches it off).
+        index = {id(u): i for i, u in enumerate(values)}
+        consumers = {}
+        for u in values:
+            ins = [getattr(u, 'src', None), getattr(u, 'res', None), getattr(u, 'a', None), getattr(u, 'b', None)]
+            ins += [part[0] for part in getattr(u, 'parts', None) or []]
+            for t in ins:
+                if t is not None and id(t) in index:
+                    consumers.setdefault(id(t), []).append(u)
+        fuse_dbn = os.environ.get('YOLO_HIP_FUSE_DBN', '1') != '0'
+
+        def completes_bn_block(v, s):
+            """conv `v` (1x1 / stride 1) writes the last contribution to grad(s), s a conv with BatchNorm whose gradient buffer is its own."""
+            if not fuse_dbn or v.k != 1 or v.stride != 1 or v.pad != 0 or s.kind != 'conv' or s.bn is None or s.plain or s.fp32 or s.ups != 1:
+                return False
+            if s.src.kind == 'input' or getattr(s, 'parent', None) is not None or s.c_off != 0 or s.ld != s.c_phys:
+                return False
+            if getattr(s, 'z', None) is None or not hasattr(s, 'bn_args'):
+                return False
+            return min(index[id(u)] for u in consumers.get(id(s), [v])) == index[id(v)]
+
         def contribution_mode(t, full_width):
             key = id(t.gstorage)
             if key in initialised:
@@ -700,7 +725,8 @@ class TrainEngine(DarknetEngine):
                         fixup(bwd, op, StemBwdDesc, 'ws', SLOT_WS)
                         fixup(bwd, op, StemBwdDesc, 'x', SLOT_INPUT)
                         continue
-                    add_reduction(bwd, plan['bwd_ops'], BnBwdReduceDesc(**base, **acc, dy=dyp, lddy=lddy), 'dbn%d' % v.block)
+                    if not getattr(v, 'dbn_done', False):     # else: the launch that completed dy took the sums (see dgrad below)
+                        add_reduction(bwd, plan['bwd_ops'], BnBwdReduceDesc(**base, **acc, dy=dyp, lddy=lddy), 'dbn%d' % v.block)
                     op = add(bwd, plan['bwd_ops'], BnBwdApplyDesc(**base, **acc, dy=dyp, lddy=lddy, out=dzp, ldo=v.c_phys),
                              'dbnx%d' % v.block)
                     dz_written_by(op, kz)
@@ -762,9 +788,30 @@ class TrainEngine(DarknetEngine):
                                  kh=th, kw=tw, pad=0, ups=3, y_h=s.H, y_w=s.W, y_off_h=a, y_off_w=b, **common),
                         'dgrad%d' % v.block)
             else:
-                add(bwd, plan['bwd_ops'],
-                    ConvDesc(x=dzp, w=P(pk['wt']), res=gptr(s) if mode == 'acc' else None, y=gptr(s), h=v.Ho, w_in=v.Wo, ho=s.H,
-                             wo=s.W, kh=v.k, kw=v.k, pad=v.k - 1 - v.pad, ups=1, **common), 'dgrad%d' % v.block)
+                dg = ConvDesc(x=dzp, w=P(pk['wt']), res=gptr(s) if mode == 'acc' else None, y=gptr(s), h=v.Ho, w_in=v.Wo, ho=s.H,
+                              wo=s.W, kh=v.k, kw=v.k, pad=v.k - 1 - v.pad, ups=1, **common)
+                rows = 0
+                if completes_bn_block(v, s):
+                    sbase, sbnp = s.bn_args
+                    for key, val in dict(bwd_z=sbase['z'], bwd_ldz=s.c_phys, bwd_act=s.act, bwd_slope=s.slope, bwd_gamma=sbnp['gamma'],
+                                         bwd_beta=sbnp['beta'], bwd_mean=sbnp['mean'], bwd_invstd=sbnp['invstd']).items():
+                        setattr(dg, key, val)
+                    rows = int(lib.yh_conv2d_bwd_stats_rows(C.byref(dg)))
+                    if rows <= 0:
+                        for key in ('bwd_z', 'bwd_gamma', 'bwd_beta', 'bwd_mean', 'bwd_invstd'):
+                            setattr(dg, key, None)
+                if rows > 0:
+                    dg.stats_ws_floats = rows * 2 * s.c_phys
+                    plan['ws_floats'] = max(plan['ws_floats'], dg.stats_ws_floats)
+                op = add(bwd, plan['bwd_ops'], dg, 'dgrad%d' % v.block)
+                if rows > 0:
+                    # the rows it leaves in the shared workspace are added into dbeta / dgamma of `s` right away (the workspace is
+                    # free game for the next op); s's own backward then starts at its apply pass
+                    fixup(bwd, op, ConvDesc, 'stats_ws', SLOT_WS)
+                    sacc = dict(sbnp, sum=grads.ptr(s.g_beta), sumsq=grads.ptr(s.g_gamma))
+                    add_reduction(bwd, plan['bwd_ops'],
+                                  BnBwdReduceDesc(**dict(sbase, ups=1), **sacc, dy=gptr(s), lddy=s.ld, nparts=rows), 'dbn%d' % s.block)
+                    s.dbn_done = True
             if side:
                 emit_wgrad()
         plan['head_shapes'] = [(N, h.src.H, h.src.W, h.src.c_phys) for h in heads]

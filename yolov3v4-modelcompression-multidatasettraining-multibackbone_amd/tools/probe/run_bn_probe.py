@@ -42,7 +42,9 @@ for hw, c in ((19, 512), (19, 1024), (38, 256), (38, 512), (76, 128), (76, 256),
     px = 64 * hw * hw
     z = torch.randn(px, c, dtype=torch.float16, device=dev)
     src = torch.randn(px, c, dtype=torch.float16, device=dev)
-    dy = torch.randn(px, c, dtype=torch.float16, device=dev)
+    skew = int(os.environ.get('YH_PROBE_SKEW', '0')) // 2       # elements: dy starts this many bytes into its allocation (HBM channel / bank alignment against z)
+    dy_store = torch.randn(px * c + skew, dtype=torch.float16, device=dev)
+    dy = dy_store[skew:].view(px, c)
     y = torch.empty_like(z)
     par = [torch.rand(c, dtype=torch.float32, device=dev) + 0.5 for _ in range(4)]
     sums = [torch.zeros(c, dtype=torch.float32, device=dev) for _ in range(2)]
@@ -67,4 +69,4 @@ for hw, c in ((19, 512), (19, 1024), (38, 256), (38, 512), (76, 128), (76, 256),
         gb = nbytes * px * c * 2 / 1e9
         res.append('%7.4f %5.2f / %7.4f %5.2f' % (w, gb / w, cc, gb / cc))
     print('%-22s %8.1f | %s' % ('%dx%d x %d' % (hw, hw, c), px * c * 2 / 1e6, ' | '.join(res)), flush=True)
-    del z, src, dy, y
+    del z, src, dy, dy_store, y
