@@ -1305,6 +1305,55 @@ def test_training_step_is_run_to_run_deterministic(libs, precision):
           % (precision, len(first[0]), len(first[2])))
 
 
+def test_step_with_backward_sums_in_the_data_gradient_equals_the_plain_step(libs, monkeypatch):
+    """Round 6 (yh_conv_desc.bwd_z) inside a whole step on the GPU: YOLOv3 at 608 x 608, batch 3 (304^2 x 3 >= 262 144 pixels: the first
+    residual stage's 1x1 data gradient runs on the persistent kernel and carries the backward sums of the block it completes), fp16, in
+    the well-conditioned state (synth.calm_bn_: summation-order differences are not amplified).  Against the same step with
+    YOLO_HIP_FUSE_DBN=0: the plan differs (a fused launch + a row-summing op in place of a reduction pass), every parameter gradient
+    agrees to summation order - and twice in a row the fused step gives the same bits."""
+    if DRY:
+        pytest.skip('plan-level equivalence on the emulator: tests/test_train_emulated.py')
+    import copy
+    from models import Darknet
+    from utils.utils import compute_loss
+    import test_train_emulated as tte
+    size, batch = 608, 3
+    torch.manual_seed(0)
+    model0 = Darknet(os.path.join(conftest.PKG, 'cfg', 'yolov3', 'yolov3.cfg'), (size, size))
+    state = model0.state_dict()
+    synth.calm_bn_(synth.randomize_bn_(state, seed=1))
+    model0.load_state_dict(state)
+    model0.nc, model0.hyp, model0.gr = 80, dict(tte.GOLD_HYP), 1.0
+    targets = synth.loss_inputs(model0, size, batch=batch, seed=9, labels_per_image=8)[1].to(GPU)
+    x = synth.image_batch(batch, size, seed=0).to(GPU)
+
+    def step():
+        model = copy.deepcopy(model0).train().to(GPU)
+        monkeypatch.setenv('YOLO_HIP_TRAIN_PRECISION', 'fp16')
+        pred, _ = model(x)
+        monkeypatch.delenv('YOLO_HIP_TRAIN_PRECISION')
+        eng = model.__dict__.get('_hip_train_engine')
+        fused = [what for what, d in eng._current['bwd_ops'] if isinstance(d, hiplib.ConvDesc) and d.bwd_z]
+        loss, _ = compute_loss(pred, targets, model)
+        (loss * 1024.0).backward()
+        torch.cuda.synchronize()
+        grads = {k: p.grad.detach().clone() / 1024.0 for k, p in model.named_parameters()}
+        model.__dict__['_hip_train_engine'] = None
+        return fused, grads
+    fused, g1 = step()
+    assert fused, 'no data gradient of this step carries backward sums'
+    _, g1b = step()
+    assert all(torch.equal(g1[k], g1b[k]) for k in g1), 'the fused step is not reproducible'
+    monkeypatch.setenv('YOLO_HIP_FUSE_DBN', '0')
+    plain, g0 = step()
+    assert not plain
+    num = sum(float((g1[k].double() - g0[k].double()).pow(2).sum()) for k in g1)
+    den = sum(float(g0[k].double().pow(2).sum()) for k in g1)
+    rel = (num / den) ** 0.5
+    print('yolov3 608 b3 fp16: %d fused launches (%s); gradient of the fused step against the plain one: rel l2 %.2e' % (len(fused), ', '.join(fused), rel))
+    assert rel <= 1e-3, rel
+
+
 def test_fused_loss_defers_the_label_check_without_a_host_sync(libs):
     """The kernels record labels outside the class range on the device; the reference's AssertionError surfaces at the next
     compute_loss call / flush_label_check() instead of stalling the step on a device-to-host read."""
