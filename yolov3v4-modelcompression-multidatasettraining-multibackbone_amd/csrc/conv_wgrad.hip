@@ -1294,9 +1294,9 @@ extern "C" int yh_conv_pack_weights_dgrad(int dtype, const float* w, int cout, i
     return check_launch();
 }
 
-// YH_WGRAD_HALO: 0 = im2col kernels only, 1 = conv_wgrad_halo_kernel (round 3), 2 (default) = conv_wgrad_roll_kernel (conv_wgrad_roll.hip,
-// round 5) on the layers it measured faster on and the round-3 form elsewhere, 3 = the round-5 form wherever it qualifies.  Read at
-// every call (the tests switch it per case).
+// YH_WGRAD_HALO: 0 = im2col kernels only, 1 = conv_wgrad_halo_kernel (round 3), 2 (default) and 3 = conv_wgrad_roll_kernel (conv_wgrad_roll.hip,
+// round 5) on every layer it qualifies for (with the fragment-refresh order it is the faster form on every shape, profiles/r05_wgrad_roll_order3_ab.txt,
+// so the per-layer choice mode 2 once made is gone and the two values are synonyms - ADVICE r5).  Read at every call (the tests switch it per case).
 static int wgrad_halo_mode() {
     const char* e = getenv("YH_WGRAD_HALO");
     return e ? atoi(e) : YH_WGRAD_HALO_DEFAULT;

@@ -847,11 +847,12 @@ bool wgrad_roll_geometry(const yh_wgrad_desc* d, RollArgs* pa, int* psplits, siz
     a.r32 = 32 - a.q32 * Wp;
     { const char* e = getenv("YH_WGRAD_HALO_NOSTAGGER"); a.nostagger = e && atoi(e) ? 1 : 0; }
     const int tiles = a.tiles_m * a.tiles_n;
-    // Which layers take this form (library's choice; YH_WGRAD_HALO=3 forces it wherever it qualifies).  In the training step of
-    // YOLOv3-608 batch 64 (profiles/r05_train_wgrad_mode_ab.txt, r05_wgrad_roll_ab.txt) it beats conv_wgrad_halo_kernel on the layers
-    // with FEW tiles and many pixel splits - 76 x 76 128 -> 256 (4 tiles): 0.245 against 0.263 ms, 152 x 152 64 -> 128 (1 tile; the
-    // round-3 form does not take cout 128): 0.241 against 0.320 - and loses 2 - 3 % on the 38 x 38 / 19 x 19 layers (16 / 64 tiles).
-    (void)force;      // (round 5, ORDER 2: layers with > 8 tiles stayed on the round-3 kernel; ORDER 3 is faster on every shape)
+    // Every layer that qualifies takes this form (YH_WGRAD_HALO = 2 and 3 alike): with the fragment-refresh order (ORDER 3) it beats the
+    // round-3 kernel on all four stage shapes of YOLOv3-608 batch 64 - 76^2 0.201 / 0.241 ms, 38^2 0.198 / 0.216, 19^2 0.211 / 0.241, 152^2
+    // 0.221 / 0.316 (profiles/r05_wgrad_roll_order3_ab.txt); the per-layer choice of the ORDER-2 days (few-tile layers only) is gone.
+    // Split groups of the reduce launch: summed in place and added by a one-group launch (deterministic, common.h), or - YH_DETERMINISTIC=0 -
+    // meeting in fp32 atomics on the few-tile layers.
+    (void)force;
     int splits = d->splits > 0 ? d->splits : 256 / tiles;          // one workgroup per CU
     {
         const char* e = getenv("YH_WGRAD_HALO_WGS");       // A/B and test knob: total workgroups aimed for

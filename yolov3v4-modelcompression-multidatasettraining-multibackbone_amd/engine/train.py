@@ -359,7 +359,10 @@ class TrainEngine(DarknetEngine):
         # these dependencies allow, tests/test_train_emulated.py).  Measured on the MI355X (YOLOv3-608 b64 fp16): 63.3 vs 63.8 ms
         # per step - the two kernels do not co-reside (a weight-gradient workgroup pair holds the whole vector register file of its
         # CU), they time-slice: every kernel takes about twice as long while the other lane is busy.  YOLO_HIP_WGRAD_LANE=1 enables.
-        two_lanes = os.environ.get('YOLO_HIP_WGRAD_LANE', '0') == '1'
+        # (round 6: 2 = only the weight gradients of the <= 38 x 38 stages, 3 = only their 1x1 ones - small grids that leave CUs idle)
+        lane_mode = int(os.environ.get('YOLO_HIP_WGRAD_LANE', '0') or 0)
+        two_lanes = lane_mode > 0
+        lane_ok = lambda u: lane_mode == 1 or (lane_mode == 2 and u.Ho <= 38) or (lane_mode == 3 and u.Ho <= 38 and u.k == 1)
         dz_bufs = [alloc((dz_elems,)) for _ in range(2 if two_lanes else 1)]
         dz_state = dict(k=0, reader=[None] * len(dz_bufs))
 
@@ -737,7 +740,7 @@ class TrainEngine(DarknetEngine):
                 op = add(bwd, plan['bwd_ops'], LayoutDesc(x=None, y=P(img), n=N, c=s.C, h=s.H, w_in=s.W, c_pad=ALIGN_C, ldy=ALIGN_C,
                                                           dtype=self.code), 'image%d' % v.block)
                 fixup(bwd, op, LayoutDesc, 'x', SLOT_INPUT)
-                side = two_lanes and dz_private
+                side = two_lanes and dz_private and lane_ok(v)
                 op = add_reduction(bwd, plan['bwd_ops'],
                                    WgradDesc(x=P(img), dz=dzp, dw=grads.ptr(v.g_w), n=N, h=s.H, w_in=s.W, cin=ALIGN_C, ho=v.Ho, wo=v.Wo,
                                              cout=v.C, kh=v.k, kw=v.k, stride=v.stride, pad=v.pad, ldx=ALIGN_C, lddz=lddz,
@@ -745,7 +748,7 @@ class TrainEngine(DarknetEngine):
                 if side:
                     on_side_lane(op, kz)
                 continue
-            side = two_lanes and dz_private
+            side = two_lanes and dz_private and lane_ok(v)
 
             def emit_wgrad(v=v, s=s, dzp=dzp, lddz=lddz, kz=kz, side=side):
                 op = add_reduction(bwd, plan['bwd_ops'],

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Evidence run on a GPU box (what produced profiles/r04_*): full GPU test tier, smoke, the default bench line, rocprofv3 stats of the same
+# Evidence run on a GPU box (what produced profiles/r04_* .. r06_*): full GPU test tier, smoke, the default bench line, rocprofv3 stats of the same
 # command, HBM traffic (FETCH_SIZE / WRITE_SIZE, one counter per pass, aggregated PER DISPATCH) and SQ / TCC counters of the training step,
 # per-layer tables.
 # Usage:  gpurun --timeout 3000 -- bash yolov3v4-modelcompression-multidatasettraining-multibackbone_amd/tools/evidence_run.sh TAG [notests]
@@ -11,7 +11,7 @@ TAG=${1:-evidence}
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 if [ "$2" != "notests" ]; then
-( timeout 1800 python -m pytest tests -m gpu -q -s 2>&1 | grep -v "^Model Summary\|amdgpu.ids" | grep "passed\|failed\|FAILED\|Error\|int8 vs\|raw heads\|mAP\|608 b\|drift\|pruned mobilenet\|calibration on\|cosine searches\|int8 engine vs" | tail -80 ) > gpurun_out/${TAG}_tests.log 2>&1
+( timeout 1800 python -m pytest tests -m gpu -q -s 2>&1 | grep -v "^Model Summary\|amdgpu.ids" | grep "passed\|failed\|FAILED\|Error\|int8 vs\|raw heads\|mAP\|608 b\|calm v\|sgd traj\|yolov3 320\|largest contrib\|drift\|pruned mobilenet\|calibration on\|cosine searches\|int8 engine vs" | grep -v "print(" | cut -c1-1200 | tail -120 ) > gpurun_out/${TAG}_tests.log 2>&1
 fi
 ( timeout 200 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | grep -v "^Model Summary\|amdgpu.ids" | tail -4 ) > gpurun_out/${TAG}_smoke.log 2>&1
 ( timeout 900 python bench.py 2>&1 | tail -1 ) > gpurun_out/${TAG}_bench_default.json 2>&1
@@ -45,5 +45,7 @@ python $T/rocprof_summary.py pmc $(find /tmp/pmc_sq /tmp/pmc_tcc -name "*.db") >
 timeout 300 python $T/profile_train.py --batch 64 --size 608 > gpurun_out/${TAG}_train_layers.txt 2>&1
 timeout 300 python $T/profile_layers.py --batch 64 --size 608 > gpurun_out/${TAG}_layers_fp16.txt 2>&1
 timeout 300 python $T/profile_layers.py --batch 64 --size 608 --precision int8 > gpurun_out/${TAG}_layers_int8.txt 2>&1
+timeout 300 python $T/profile_layers.py --batch 32 --size 640 --precision int8 --cfg $PKG/cfg/yolov4/yolov4.cfg > gpurun_out/${TAG}_layers_v4_int8.txt 2>&1
+timeout 300 python $T/profile_layers.py --batch 32 --size 640 --cfg $PKG/cfg/yolov4/yolov4.cfg > gpurun_out/${TAG}_layers_v4_fp16.txt 2>&1
 timeout 600 python $T/pruned_finetune.py --bench > gpurun_out/${TAG}_pruned.txt 2>&1
 tail -14 gpurun_out/${TAG}_tests.log 2>/dev/null; cat gpurun_out/${TAG}_smoke.log; cut -c1-300 gpurun_out/${TAG}_bench_default.json; head -14 gpurun_out/${TAG}_rocprof_stats.txt; cat gpurun_out/${TAG}_traffic.log; tail -5 gpurun_out/${TAG}_pruned.txt
