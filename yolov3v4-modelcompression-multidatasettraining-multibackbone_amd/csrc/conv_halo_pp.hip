@@ -227,12 +227,12 @@ __global__ __launch_bounds__(512, 2) void conv3x3_hpp_kernel(const ConvArgs a, c
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int group = wave >> 2;
 
-    // STAGGER (round 6 experiment, YH_HPP_STAGGER = cycles; 0 = off): one workgroup per CU and tiles of equal length keep all 256 CUs in
+    // STAGGER (round 6 experiment, YH_HPP_STAGGER = cycles; 0 = off; measured +0.3 % over 13 layer shapes, profiles/r06_hpp_stagger_ab.txt: not the lever): one workgroup per CU and tiles of equal length keep all 256 CUs in
     // phase - they all compute, then all store 128 KB each (33 MB in one burst, at the HBM write rate: the 12 600 cycles an epilogue
     // takes are exactly 128 KB x 256 CUs at 6.3 TB/s), then all compute again.  Delaying the workgroups of the FIRST round by
     // different fractions of that burst time puts the CUs out of phase for the whole launch.
-    if (a.no_lds_store > 0 && blockIdx.x < 256) {
-        const long long t_end = clock64() + (long long)((blockIdx.x * 37u) & 255u) * a.no_lds_store / 256;
+    if (a.hpp_stagger > 0 && blockIdx.x < 256) {
+        const long long t_end = clock64() + (long long)((blockIdx.x * 37u) & 255u) * a.hpp_stagger / 256;
         while (clock64() < t_end) __builtin_amdgcn_s_sleep(16);
     }
 
@@ -880,7 +880,7 @@ template <typename T> static int launch_hpp(const ConvArgs& a0, hipStream_t stre
     a.p_tiles = (int)((Q + 511) / 512);
     const long blocks = (long)a.m_tiles * a.p_tiles;
     if (blocks <= 0 || blocks > 0x7fffffffL) return YH_EINVAL;
-    { const char* e = getenv("YH_HPP_STAGGER"); a.no_lds_store = (e && blocks > 512) ? atoi(e) : 0; }   // first-round phase stagger in cycles (A/B)
+    { const char* e = getenv("YH_HPP_STAGGER"); a.hpp_stagger = (e && blocks > 512) ? atoi(e) : 0; }   // first-round phase stagger in cycles (A/B)
     HppDiv dv;
     hpp_magic((unsigned)((a.H + 1) * (a.W + 1)), &dv.m_img, &dv.s_img);       // both divisors >= 4 (H, W >= 1)
     hpp_magic((unsigned)(a.W + 1), &dv.m_wp, &dv.s_wp);

@@ -27,6 +27,7 @@ struct ConvArgs {
     int y_h, y_w, y_off_h, y_off_w;  // ups == 3: output pixel (n, ho, wo) is stored at (n, 2 ho + y_off_h, 2 wo + y_off_w) of a y_h x y_w tensor
     float q_rx, q_ra, q_scale_x, q_scale_a, q_inv_scale_sum;   // int8 + res: fused quantised shortcut (yh_qadd arithmetic)
     int no_lds_store;    // conv_pointwise.hip A/B switch: direct 4-channel stores instead of row stores through LDS
+    int hpp_stagger;     // conv_halo_pp.hip A/B switch (YH_HPP_STAGGER): cycles over which the first round's workgroups are delayed; 0 = off
     // training backward (yh_conv_desc.bwd_z; conv_pw_lds.hip modes 3 / 4): the block whose gradient this launch completes
     const void* bz;
     const float *bgamma, *bbeta, *bmean, *binvstd;

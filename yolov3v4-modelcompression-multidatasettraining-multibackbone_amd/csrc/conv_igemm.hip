@@ -1028,7 +1028,8 @@ static bool pwl_desc_supported(const yh_conv_desc* d) {
 }
 static bool pick_pwl_tile(const yh_conv_desc* d) {
     static const bool off = getenv("YH_NO_PWL") != nullptr;
-    return !off && pwl_desc_supported(d) && (long)d->n * d->ho * d->wo >= 262144;
+    static const long min_px = [] { const char* e = getenv("YH_PWL_MIN_PIXELS"); return e ? atol(e) : 262144L; }();      // A/B knob
+    return !off && pwl_desc_supported(d) && (long)d->n * d->ho * d->wo >= min_px;
 }
 
 extern "C" int yh_conv2d_tile(const yh_conv_desc* d) {
@@ -1157,6 +1158,7 @@ extern "C" int yh_conv2d_fwd(const yh_conv_desc* d, void* stream) {
     a.q_rx = d->q_rx; a.q_ra = d->q_ra; a.q_scale_x = d->q_scale_x; a.q_scale_a = d->q_scale_a; a.q_inv_scale_sum = d->q_inv_scale_sum;
     if (d->dtype == YH_I8 && d->res) qadd_pow2_args(a);
     a.no_lds_store = getenv("YH_PW_DIRECT") != nullptr;
+    a.hpp_stagger = 0;
     a.stats_part = nullptr;
     a.bz = nullptr;
     a.bgamma = a.bbeta = a.bmean = a.binvstd = nullptr;

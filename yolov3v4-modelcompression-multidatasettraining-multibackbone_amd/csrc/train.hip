@@ -10,6 +10,9 @@
 #define YH_BN_UNROLL_RED 2
 #define YH_BN_UNROLL_APP 4
 #endif
+#ifndef YH_BN_REVERSE_DEFAULT
+#define YH_BN_REVERSE_DEFAULT 4
+#endif
 
 namespace yh {
 
@@ -27,6 +30,8 @@ struct BnGeom {
     int rows;     // pixels per pass = 256 / cgb
     int ppb;      // pixels per workgroup
     int two_stage;  // reductions: partial sums to the workspace + a summing launch (no atomics)
+    int reverse;    // walk the pixel chunks from the END of the tensor (workgroup y -> chunk gridDim.y - 1 - y): the producer wrote / read the
+                    // tensor front to back, so its tail is what the 256 MiB Infinity Cache still holds when this pass starts (YH_BN_REVERSE)
 };
 
 template <int VN>
@@ -62,7 +67,7 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const yh_bn_desc d, const
     const int cgl = threadIdx.x % gm.cgb, prow = threadIdx.x / gm.cgb;
     const int g = blockIdx.x * gm.cgb + cgl;
     const bool lane_ok = prow < gm.rows && g < gm.cgs;
-    const long p0 = (long)blockIdx.y * gm.ppb;
+    const long p0 = (long)(gm.reverse ? gridDim.y - 1 - blockIdx.y : blockIdx.y) * gm.ppb;
     const long p1 = min(p0 + gm.ppb, (long)d.pixels);
     const T* z = reinterpret_cast<const T*>(d.z) + g * VN;
     float acc[2][VN];
@@ -159,7 +164,7 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const yh_bn_desc d, con
     const int cgl = threadIdx.x % gm.cgb, prow = threadIdx.x / gm.cgb;
     const int g = blockIdx.x * gm.cgb + cgl;
     if (prow >= gm.rows || g >= gm.cgs) return;
-    const long p0 = (long)blockIdx.y * gm.ppb;
+    const long p0 = (long)(gm.reverse ? gridDim.y - 1 - blockIdx.y : blockIdx.y) * gm.ppb;
     const long p1 = min(p0 + gm.ppb, (long)d.pixels);
     const int c0 = g * VN;
     const T* z = reinterpret_cast<const T*>(d.z) + c0;
@@ -230,7 +235,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(const yh_bn_desc
     const int cgl = threadIdx.x % gm.cgb, prow = threadIdx.x / gm.cgb;
     const int g = blockIdx.x * gm.cgb + cgl;
     const bool lane_ok = prow < gm.rows && g < gm.cgs;
-    const long p0 = (long)blockIdx.y * gm.ppb;
+    const long p0 = (long)(gm.reverse ? gridDim.y - 1 - blockIdx.y : blockIdx.y) * gm.ppb;
     const long p1 = min(p0 + gm.ppb, (long)d.pixels);
     const int c0 = g * VN;
     const T* z = reinterpret_cast<const T*>(d.z) + c0;
@@ -285,7 +290,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const yh_bn_desc 
     const int cgl = threadIdx.x % gm.cgb, prow = threadIdx.x / gm.cgb;
     const int g = blockIdx.x * gm.cgb + cgl;
     if (prow >= gm.rows || g >= gm.cgs) return;
-    const long p0 = (long)blockIdx.y * gm.ppb;
+    const long p0 = (long)(gm.reverse ? gridDim.y - 1 - blockIdx.y : blockIdx.y) * gm.ppb;
     const long p1 = min(p0 + gm.ppb, (long)d.pixels);
     const int c0 = g * VN;
     const T* z = reinterpret_cast<const T*>(d.z) + c0;
@@ -352,6 +357,12 @@ static int bn_unroll(int which) {
     return v[which];
 }
 
+// bit 0: forward pass, bit 1: backward reduce, bit 2: backward apply walk their tensor back to front (A/B knob YH_BN_REVERSE)
+static int bn_reverse() {
+    static const int v = [] { const char* e = getenv("YH_BN_REVERSE"); return e ? atoi(e) : YH_BN_REVERSE_DEFAULT; }();
+    return v;
+}
+
 static BnGeom bn_geom(const yh_bn_desc* d, int vn, dim3* grid, int target = 4096) {
     BnGeom gm;
     gm.cgs = d->c / vn;
@@ -372,6 +383,7 @@ static BnGeom bn_geom(const yh_bn_desc* d, int vn, dim3* grid, int target = 4096
     gm.ppb = (int)ppb;
     *grid = dim3(gx, (unsigned)((d->pixels + ppb - 1) / ppb));
     gm.two_stage = d->ws && d->ws_floats >= (int64_t)grid->y * 2 * d->c;
+    gm.reverse = 0;
     return gm;
 }
 
@@ -814,7 +826,8 @@ extern "C" int yh_bn_act_fwd(const yh_bn_desc* d, void* stream) {
     if (d->ups != 1 && d->ups != 2) return YH_EINVAL;
     if (d->ups == 2 && (long)d->n * d->h * d->w_in != d->pixels) return YH_EINVAL;
     dim3 grid;
-    const BnGeom gm = bn_geom(d, d->dtype == YH_F16 ? 8 : 4, &grid);
+    BnGeom gm = bn_geom(d, d->dtype == YH_F16 ? 8 : 4, &grid);
+    gm.reverse = bn_reverse() & 1;
     const int u = bn_unroll(0);
 #define YH_BN_LAUNCH_A(K, A)                                                                                       \
     if (d->dtype == YH_F16) {                                                                                      \
@@ -852,7 +865,8 @@ extern "C" int yh_bn_act_bwd_reduce(const yh_bn_desc* d, void* stream) {
     if (rc) return rc;
     if (!d->sum || !d->sumsq) return YH_EINVAL;
     dim3 grid;
-    const BnGeom gm = bn_geom(d, d->dtype == YH_F16 ? 8 : 4, &grid, 1024);
+    BnGeom gm = bn_geom(d, d->dtype == YH_F16 ? 8 : 4, &grid, 1024);
+    gm.reverse = (bn_reverse() >> 1) & 1;
     const int u = bn_unroll(1);
     YH_BN_LAUNCH(bn_act_bwd_reduce_kernel)
     if (gm.two_stage) sum_partials(d, grid, stream);
@@ -864,7 +878,8 @@ extern "C" int yh_bn_act_bwd_apply(const yh_bn_desc* d, void* stream) {
     if (rc) return rc;
     if (d->gamma && (!d->sum || !d->sumsq)) return YH_EINVAL;
     dim3 grid;
-    const BnGeom gm = bn_geom(d, d->dtype == YH_F16 ? 8 : 4, &grid);
+    BnGeom gm = bn_geom(d, d->dtype == YH_F16 ? 8 : 4, &grid);
+    gm.reverse = (bn_reverse() >> 2) & 1;
     const int u = bn_unroll(2);
     YH_BN_LAUNCH(bn_act_bwd_apply_kernel)
 #undef YH_BN_LAUNCH
