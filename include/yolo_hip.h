@@ -722,6 +722,10 @@ int yh_plan_add_dep(yh_plan* p, int op_index, int dep_index);
  * events; after the caller has synchronised the stream, yh_plan_get_timings writes the last replay's
  * per-op durations in milliseconds to the HOST array ms_out[n], n == yh_plan_num_ops.                    */
 int yh_plan_set_timing(yh_plan* p, int enable);
+/* round 6: the reduce launches of the plan's weight gradients (yh_conv2d_wgrad: partial tiles -> dW) run on a stream of their own, in the
+ * shadow of the following ops; every yh_plan_run / _run_range joins before it returns.  Only for plans whose weight-gradient ops have a
+ * workspace no other op uses.  Off under yh_plan_set_timing (per-op times stay additive). */
+int yh_plan_set_async_reduce(yh_plan* p, int enable);
 int yh_plan_get_timings(yh_plan* p, float* ms_out, int n);
 /* hipGraph replay for launch-bound (small batch) forwards: capture records one replay with the currently bound
  * slot pointers on a non-null stream; launch replays it with a single graph launch; reset drops the graph (needed

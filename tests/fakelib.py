@@ -1228,6 +1228,11 @@ class FakeLib:
     # lanes: the emulation replays the LATEST schedule the declared dependencies allow - a side-lane op runs only when a
     # main-lane op that waits for it comes up, or at the join at the end of the range - so a missing write-after-read dependency
     # (a main-lane op overwriting what a side-lane op still has to read) shows up as wrong numbers on the CPU tier
+    def yh_plan_set_async_reduce(self, h, enable):
+        # the emulator runs every op to completion in program order: the reduce launches have nowhere to overlap
+        self.plans[_addr(h)]['async_reduce'] = bool(enable)
+        return 0
+
     def yh_plan_set_lane(self, h, op, lane):
         self.plans[_addr(h)].setdefault('lane', {})[op] = lane
         return 0

@@ -184,6 +184,37 @@ inline hipError_t ensure_dynamic_lds(const void* kern, size_t bytes) {
 
 inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15u) == 0; }
 
+// Weight-gradient reduce launches off the critical path (round 6, yh_plan_set_async_reduce).  A weight gradient is a split-K GEMM: the main
+// kernel leaves per-split partial tiles in the workspace and small HBM-bound launches add them into dW - which nothing reads before the
+// optimizer.  Inside a plan whose weight gradients own their workspace, those launches go to the plan's reduce stream: they run in the idle
+// CUs of the next kernels' last rounds instead of in front of them.  The executor sets the context around a weight-gradient op; the next
+// weight gradient's main kernel waits for the previous reduce (same workspace), every plan range joins before it returns.
+struct AsyncReduce {
+    hipStream_t side = nullptr;
+    hipEvent_t main_done = nullptr, red_done = nullptr;
+    bool pending = false;      // a reduce is in flight on `side`
+};
+extern thread_local AsyncReduce* g_async_reduce;      // plan.hip; nullptr outside an op that may use it
+// before the main kernel overwrites the workspace: the previous reduce must have read it
+inline void reduce_guard_workspace(hipStream_t st) {
+    AsyncReduce* c = g_async_reduce;
+    if (c && c->pending) {
+        (void)hipStreamWaitEvent(st, c->red_done, 0);
+        c->pending = false;
+    }
+}
+// the stream the reduce launches of this weight gradient go to (after the main kernel on `st`)
+inline hipStream_t reduce_begin(hipStream_t st) {
+    AsyncReduce* c = g_async_reduce;
+    if (!c) return st;
+    if (hipEventRecord(c->main_done, st) != hipSuccess || hipStreamWaitEvent(c->side, c->main_done, 0) != hipSuccess) return st;
+    return c->side;
+}
+inline void reduce_end(hipStream_t st, hipStream_t rs) {
+    AsyncReduce* c = g_async_reduce;
+    if (c && rs != st && hipEventRecord(c->red_done, rs) == hipSuccess) c->pending = true;
+}
+
 // Run-to-run deterministic reductions (round 6; the reference's CPU training step is bit-reproducible).  Every sum over workgroups of
 // the training path - BatchNorm statistics, BatchNorm backward sums, weight-gradient pixel splits, the first block's backward - is
 // taken in a FIXED order: partial results in a workspace, summed by one owner per output element, never by fp32 atomics whose

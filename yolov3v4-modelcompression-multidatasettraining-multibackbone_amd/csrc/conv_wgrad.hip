@@ -1473,6 +1473,7 @@ extern "C" int yh_conv2d_wgrad(const yh_wgrad_desc* d, void* stream) {
                     hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds);                                   \
                     if (e != hipSuccess) return (int)e;                                                                        \
                 }                                                                                                              \
+                reduce_guard_workspace(st);                                                                                    \
                 hipLaunchKernelGGL(kern, dim3((unsigned)(htiles * splits)), dim3(768), lds, st, a);                            \
                 break;                                                                                                         \
             }
@@ -1485,12 +1486,14 @@ extern "C" int yh_conv2d_wgrad(const yh_wgrad_desc* d, void* stream) {
             if (groups > 32) groups = 32;
             const int per_group = (splits + groups - 1) / groups;
             groups = (splits + per_group - 1) / per_group;
+            const hipStream_t rs = reduce_begin(st);
             if (deterministic() && groups > 1) {      // groups in place, then one owner per element adds them in order (no atomics)
-                hipLaunchKernelGGL(wgrad_halo_reduce_kernel, dim3(htiles * 24, groups), dim3(768), 0, st, a, splits, per_group, 1, 1);
-                hipLaunchKernelGGL(wgrad_halo_reduce_kernel, dim3(htiles * 24, 1), dim3(768), 0, st, a, groups, groups, per_group, 0);
+                hipLaunchKernelGGL(wgrad_halo_reduce_kernel, dim3(htiles * 24, groups), dim3(768), 0, rs, a, splits, per_group, 1, 1);
+                hipLaunchKernelGGL(wgrad_halo_reduce_kernel, dim3(htiles * 24, 1), dim3(768), 0, rs, a, groups, groups, per_group, 0);
             } else {
-                hipLaunchKernelGGL(wgrad_halo_reduce_kernel, dim3(htiles * 24, groups), dim3(768), 0, st, a, splits, per_group, 1, 0);
+                hipLaunchKernelGGL(wgrad_halo_reduce_kernel, dim3(htiles * 24, groups), dim3(768), 0, rs, a, splits, per_group, 1, 0);
             }
+            reduce_end(st, rs);
             return check_launch();
         }
         wgrad_geometry(d, &a, &splits, false);   // no workspace for the partial tiles: the im2col form
@@ -1504,6 +1507,7 @@ extern "C" int yh_conv2d_wgrad(const yh_wgrad_desc* d, void* stream) {
         a.xcd_splits = splits;
         grid = dim3((unsigned)(tiles * splits), 1);
     }
+    if (a.two_stage) reduce_guard_workspace(st);      // a previous weight gradient's reduce may still be reading the workspace
     if (a.dma) {
         if (narrow) hipLaunchKernelGGL((conv_wgrad_dma_kernel<2, 2>), grid, dim3(256), 0, st, a);
         else if (a.bm == 256 && a.bn == 256 && a.pp) hipLaunchKernelGGL((conv_wgrad_dma_kernel<8, 4, true>), grid, dim3(512), 0, st, a);
@@ -1523,6 +1527,8 @@ extern "C" int yh_conv2d_wgrad(const yh_wgrad_desc* d, void* stream) {
         if (groups > 32) groups = 32;                       // groups are the expensive part (4x more groups measured 30 % slower)
         const int per_group = (splits + groups - 1) / groups;
         groups = (splits + per_group - 1) / per_group;
+        const hipStream_t ms = st;
+        st = reduce_begin(ms);
         auto reduce = [&](int ngroups, int nsplits, int per, int sstep, int native) {
             if (narrow) hipLaunchKernelGGL((wgrad_reduce_kernel<2, 2>), dim3(tiles * 8, ngroups), dim3(256), 0, st, a, nsplits, per, sstep, native);
             else if (a.bm == 256 && a.bn == 256) hipLaunchKernelGGL((wgrad_reduce_kernel<8, 4>), dim3(tiles * 32, ngroups), dim3(512), 0, st, a, nsplits, per, sstep, native);
@@ -1536,6 +1542,7 @@ extern "C" int yh_conv2d_wgrad(const yh_wgrad_desc* d, void* stream) {
         } else {
             reduce(groups, splits, per_group, 1, 0);
         }
+        reduce_end(ms, st);
     }
     return check_launch();
 }

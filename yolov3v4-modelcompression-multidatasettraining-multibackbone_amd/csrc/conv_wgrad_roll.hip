@@ -907,8 +907,11 @@ int launch_wgrad_roll(const yh_wgrad_desc* d, hipStream_t st) {
         }
         const hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds);
         if (e != hipSuccess) return (int)e;
+        reduce_guard_workspace(st);       // a previous weight gradient's reduce may still be reading the workspace (common.h AsyncReduce)
         hipLaunchKernelGGL(kern, dim3((unsigned)(tiles * splits)), dim3(768), lds, st, a);
     }
+    const hipStream_t ms = st;
+    st = reduce_begin(ms);                // the reduce launches below: on the plan's reduce stream when it has one
     const char* red_env = getenv("YH_WGRAD_ROLL_REDUCE");      // A/B knob: 1 = the scattering first form
     if (red_env && atoi(red_env) == 1) {
         int groups = (splits + 15) / 16;
@@ -916,6 +919,7 @@ int launch_wgrad_roll(const yh_wgrad_desc* d, hipStream_t st) {
         const int per_group = (splits + groups - 1) / groups;
         groups = (splits + per_group - 1) / per_group;
         hipLaunchKernelGGL(wgrad_roll_reduce_kernel, dim3(tiles * 24, groups), dim3(768), 0, st, a, splits, per_group);
+        reduce_end(ms, st);
     } else {
         int groups = (256 + tiles * 32 - 1) / (tiles * 32);       // >= one workgroup per CU where the splits allow it
         if (groups > splits / 4) groups = splits / 4;
@@ -938,6 +942,7 @@ int launch_wgrad_roll(const yh_wgrad_desc* d, hipStream_t st) {
         } else {
             reduce(groups, splits, per_group, 1, 0);
         }
+        reduce_end(ms, st);
     }
     return check_launch();
 }

@@ -8,6 +8,10 @@
 
 #include "common.h"
 
+namespace yh {
+thread_local AsyncReduce* g_async_reduce = nullptr;
+}
+
 namespace {
 
 union AnyDesc {
@@ -128,6 +132,9 @@ struct yh_plan {
     hipStream_t side = nullptr;
     std::vector<hipEvent_t> done;   // done[i]: recorded after op i when has_dependents (created lazily, timing disabled)
     hipEvent_t join = nullptr;
+    // weight-gradient reduce launches on their own stream (yh_plan_set_async_reduce; common.h AsyncReduce)
+    bool async_reduce = false;
+    yh::AsyncReduce ar;
     void drop_graph() {
         if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
         if (graph) (void)hipGraphDestroy(graph);
@@ -139,6 +146,9 @@ struct yh_plan {
         for (hipEvent_t e : done) if (e) (void)hipEventDestroy(e);
         if (join) (void)hipEventDestroy(join);
         if (side) (void)hipStreamDestroy(side);
+        if (ar.main_done) (void)hipEventDestroy(ar.main_done);
+        if (ar.red_done) (void)hipEventDestroy(ar.red_done);
+        if (ar.side) (void)hipStreamDestroy(ar.side);
         drop_graph();
     }
 };
@@ -254,7 +264,11 @@ extern "C" int yh_plan_run_range(yh_plan* p, int first, int last, void* stream) 
             if (e != hipSuccess) return (int)e;
         }
         if (p->timing) (void)hipEventRecord(p->events[2 * i], s);
+        // (per-op timing keeps the reduce launches inside the op's bracket: the numbers of the bench line stay additive)
+        const bool ar_on = p->async_reduce && !p->timing && op.kind == YH_OP_WGRAD && op.lane == 0;
+        if (ar_on) yh::g_async_reduce = &p->ar;
         const int rc = launch(op.kind, d, s);
+        yh::g_async_reduce = nullptr;
         if (p->timing) (void)hipEventRecord(p->events[2 * i + 1], s);
         if (rc != YH_OK) return rc;
         if (op.has_dependents) {
@@ -273,6 +287,11 @@ extern "C" int yh_plan_run_range(yh_plan* p, int first, int last, void* stream) 
             if (e != hipSuccess) return (int)e;
         }
     }
+    if (p->ar.pending) {      // join: dW is complete for whatever follows on the caller's stream
+        const hipError_t e = hipStreamWaitEvent(main_s, p->ar.red_done, 0);
+        if (e != hipSuccess) return (int)e;
+        p->ar.pending = false;
+    }
     if (side_used) {   // join: whatever follows on the caller's stream sees the side lane's results
         if (!p->join) {
             const hipError_t e = hipEventCreateWithFlags(&p->join, hipEventDisableTiming);
@@ -282,6 +301,20 @@ extern "C" int yh_plan_run_range(yh_plan* p, int first, int last, void* stream) 
         if (e == hipSuccess) e = hipStreamWaitEvent(main_s, p->join, 0);
         if (e != hipSuccess) return (int)e;
     }
+    return YH_OK;
+}
+
+// Weight-gradient reduce launches of this plan on their own stream.  The CALLER guarantees that the plan's weight-gradient ops do not
+// share their workspace with any other op (engine/train.py gives them SLOT_WS2).
+extern "C" int yh_plan_set_async_reduce(yh_plan* p, int enable) {
+    if (!p) return YH_EINVAL;
+    if (enable && !p->ar.side) {
+        hipError_t e = hipStreamCreateWithFlags(&p->ar.side, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&p->ar.main_done, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&p->ar.red_done, hipEventDisableTiming);
+        if (e != hipSuccess) return (int)e;
+    }
+    p->async_reduce = enable != 0;
     return YH_OK;
 }
 

@@ -245,6 +245,7 @@ _SIGNATURES = {
     'yh_conv2d_tile': (C.c_int, [C.POINTER(ConvDesc)]),
     'yh_conv2d_stats_rows': (_i64, [C.POINTER(ConvDesc)]),
     'yh_conv2d_bwd_stats_rows': (_i64, [C.POINTER(ConvDesc)]),
+    'yh_plan_set_async_reduce': (C.c_int, [_vp, C.c_int]),
     'yh_qconv_pack_weights': (C.c_int, [_vp, _f32, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp]),
     'yh_stem_pack_weights': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _f32, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                        _vp, _vp, _vp]),

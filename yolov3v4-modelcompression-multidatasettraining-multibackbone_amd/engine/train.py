@@ -363,6 +363,12 @@ class TrainEngine(DarknetEngine):
         lane_mode = int(os.environ.get('YOLO_HIP_WGRAD_LANE', '0') or 0)
         two_lanes = lane_mode > 0
         lane_ok = lambda u: lane_mode == 1 or (lane_mode == 2 and u.Ho <= 38) or (lane_mode == 3 and u.Ho <= 38 and u.k == 1)
+        # Round 6: the reduce launches of the weight gradients (partial tiles -> dW) on the plan's reduce stream, in the shadow of the ops that
+        # follow (yh_plan_set_async_reduce).  For that the weight gradients get the second workspace to themselves: the shared one is
+        # rewritten by the very next BatchNorm reduction.  Measured (profiles/r06_async_reduce_ab.txt, three alternating rounds): 52.18 against
+        # 52.01 ms per step - the 1.3 ms of reduce launches do not hide in the following kernels' idle CUs, the events cost what little
+        # overlap there is.  OFF by default; YOLO_HIP_ASYNC_REDUCE=1 enables (same bits either way).
+        async_reduce = (not two_lanes and os.environ.get('YOLO_HIP_ASYNC_REDUCE', '0') == '1' and hasattr(lib, 'yh_plan_set_async_reduce'))
         dz_bufs = [alloc((dz_elems,)) for _ in range(2 if two_lanes else 1)]
         dz_state = dict(k=0, reader=[None] * len(dz_bufs))
 
@@ -754,7 +760,7 @@ class TrainEngine(DarknetEngine):
                 op = add_reduction(bwd, plan['bwd_ops'],
                                    WgradDesc(x=P(s.storage, s.c_off), dz=dzp, dw=grads.ptr(v.g_w), n=N, h=s.H, w_in=s.W, cin=s.C, ho=v.Ho,
                                              wo=v.Wo, cout=v.C, kh=v.k, kw=v.k, stride=v.stride, pad=v.pad, ldx=s.ld, lddz=lddz,
-                                             dtype=self.code, splits=0), 'wgrad%d' % v.block, side=side)
+                                             dtype=self.code, splits=0), 'wgrad%d' % v.block, side=side or async_reduce)
                 if side:
                     on_side_lane(op, kz)
             if not side:
@@ -821,6 +827,8 @@ class TrainEngine(DarknetEngine):
         plan['segments'] = self._make_segments(plan, values, heads, bwd_pos)
         plan['ws'] = alloc((max(plan['ws_floats'], 4),), fp32=True)
         plan['ws2'] = alloc((max(plan['ws2_floats'], 4),), fp32=True)
+        if async_reduce:
+            hiplib.check(lib.yh_plan_set_async_reduce(bwd, 1), 'yh_plan_set_async_reduce')
         for handle in (fwd, bwd):
             lib.yh_plan_bind_slot(handle, SLOT_WS, plan['ws'].data_ptr())
         lib.yh_plan_bind_slot(bwd, SLOT_WS2, plan['ws2'].data_ptr())
