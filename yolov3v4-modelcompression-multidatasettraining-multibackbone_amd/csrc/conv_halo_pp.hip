@@ -43,7 +43,7 @@ template <> struct HppMma<int8_t> {
 // a padding position.  Same arithmetic and the same load-before-store ordering as conv_epilogue_plain (conv_igemm.h).
 template <typename T, int ACT, typename AccT>
 __device__ __forceinline__ void hpp_epilogue(const ConvArgs& a, AccT (&acc)[8][4], const f32x4 (&bvs)[8], const long (&pix)[4],
-                                             const int m0, const long tile_row, const int lane) {
+                                             const int m0, const long tile_row, const int lane, float* const stage) {
     constexpr int TM = 8, TN = 4;
     const int mq = (lane >> 4) << 2, pc = lane & 15;
     T* const yg = reinterpret_cast<T*>(a.y);
@@ -78,13 +78,26 @@ __device__ __forceinline__ void hpp_epilogue(const ConvArgs& a, AccT (&acc)[8][4
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const float t1 = row16_sum(s1[e]), t2 = row16_sum(s2[e]);
+                    // round 6: the wave's 2 x 128 sums are collected in its LDS row and leave as ONE 1 KB store - written straight from
+                    // the four lanes that hold them they were 64 four-lane store instructions per wave, four times the 16 of the output
+                    // itself, in front of it in the same queue (a layer with statistics ran 9 - 15 % slower than without)
+                    // (no staging row - the largest geometries fill the LDS, the persistent A/B form has none - : the direct stores)
                     const int m = mbase + i * 16 + e;
-                    if (pc == 15 && m < a.Cout) {
+                    if (pc == 15 && stage != nullptr) {
+                        stage[i * 16 + mq + e] = t1;
+                        stage[128 + i * 16 + mq + e] = t2;
+                    } else if (pc == 15 && m < a.Cout) {
                         row[m] = t1;
                         row[a.Cout + m] = t2;
                     }
                 }
             });
+            __builtin_amdgcn_wave_barrier();
+            if (stage != nullptr) {
+                const int half = lane >> 5, c4 = (lane & 31) * 4;
+                const f32x4 sv = *reinterpret_cast<const f32x4*>(stage + half * 128 + c4);
+                if (m0 + c4 < a.Cout) *reinterpret_cast<f32x4*>(row + half * a.Cout + m0 + c4) = sv;
+            }
         }
     }
     // ---- stores, 8 consecutive channels per lane.  A 16 x 16 fragment leaves a lane (k = lane >> 4, pixel lane & 15) with channels
@@ -198,7 +211,8 @@ struct HppDiv { unsigned m_img, s_img, m_wp, s_wp; };
 __device__ __forceinline__ int hpp_div(int n, unsigned m, unsigned s) { return (int)(__umulhi((unsigned)n, m) >> s); }
 
 template <typename T, int LB, int ROLE, int KFORM>
-__global__ __launch_bounds__(512, 2) void conv3x3_hpp_kernel(const ConvArgs a, const int rows_hp, const int hbufs, const HppDiv dv) {
+__global__ __launch_bounds__(512, 2) void conv3x3_hpp_kernel(const ConvArgs a, const int rows_hp, const int hbufs_arg, const HppDiv dv) {
+    const int hbufs = hbufs_arg & 0xff;                  // bit 8: the launch reserved the statistics staging rows behind the halo table
     constexpr bool ONEBAR = KFORM == 1, REFRESH = KFORM == 2;
     // KFORM 1 (ONEBAR): ONE barrier per K step instead of four (round 5).  The instruction stream stays what it is - X loads, X MFMAs, Y loads, Y
     // MFMAs - and so does the stagger of the two wave groups, but it is no longer enforced segment by segment: group 1's barrier of a
@@ -547,10 +561,12 @@ __global__ __launch_bounds__(512, 2) void conv3x3_hpp_kernel(const ConvArgs a, c
         pix[j] = (n < a.N && yy >= 1 && xx >= 1) ? ((long)n * a.H + yy - 1) * a.W + xx - 1 : -1;
     }
     const long tile_row = (long)p_tile * NW + wave;
+    // statistics staging row of this wave (1 KB) behind the halo offset table: launch_hpp adds the 8 KB when statistics are asked for
+    float* const stage = (hbufs_arg >> 8) ? reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(htab) + ((rows_hp * 4 + 15) & ~15)) + wave * 256 : nullptr;
     switch (a.act) {
-        case YH_ACT_LEAKY: hpp_epilogue<T, YH_ACT_LEAKY>(a, acc, bvs, pix, m0, tile_row, lane); break;
-        case YH_ACT_MISH: hpp_epilogue<T, YH_ACT_MISH>(a, acc, bvs, pix, m0, tile_row, lane); break;
-        default: hpp_epilogue<T, YH_ACT_LINEAR>(a, acc, bvs, pix, m0, tile_row, lane); break;
+        case YH_ACT_LEAKY: hpp_epilogue<T, YH_ACT_LEAKY>(a, acc, bvs, pix, m0, tile_row, lane, stage); break;
+        case YH_ACT_MISH: hpp_epilogue<T, YH_ACT_MISH>(a, acc, bvs, pix, m0, tile_row, lane, stage); break;
+        default: hpp_epilogue<T, YH_ACT_LINEAR>(a, acc, bvs, pix, m0, tile_row, lane, stage); break;
     }
 }
 
@@ -787,9 +803,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_hpp_persist_kernel(const ConvA
         }
         const long tile_row = (long)p_tile * NW + wave;
         switch (ae.act) {
-            case YH_ACT_LEAKY: hpp_epilogue<T, YH_ACT_LEAKY>(ae, acc, bvs, pix, m0, tile_row, lane); break;
-            case YH_ACT_MISH: hpp_epilogue<T, YH_ACT_MISH>(ae, acc, bvs, pix, m0, tile_row, lane); break;
-            default: hpp_epilogue<T, YH_ACT_LINEAR>(ae, acc, bvs, pix, m0, tile_row, lane); break;
+            case YH_ACT_LEAKY: hpp_epilogue<T, YH_ACT_LEAKY>(ae, acc, bvs, pix, m0, tile_row, lane, nullptr); break;
+            case YH_ACT_MISH: hpp_epilogue<T, YH_ACT_MISH>(ae, acc, bvs, pix, m0, tile_row, lane, nullptr); break;
+            default: hpp_epilogue<T, YH_ACT_LINEAR>(ae, acc, bvs, pix, m0, tile_row, lane, nullptr); break;
         }
         if (!has_next) break;
         vb = vnext;
@@ -880,6 +896,16 @@ template <typename T> static int launch_hpp(const ConvArgs& a0, hipStream_t stre
     a.p_tiles = (int)((Q + 511) / 512);
     const long blocks = (long)a.m_tiles * a.p_tiles;
     if (blocks <= 0 || blocks > 0x7fffffffL) return YH_EINVAL;
+    // statistics: one 1 KB staging row per wave behind the halo table, if the LDS has room for the 8 KB (YH_HPP_STATS_STAGE=0: the direct stores)
+    int stage_ok = 0;
+    if (a.stats_part != nullptr && sizeof(T) == 2) {
+        const char* e = getenv("YH_HPP_STATS_STAGE");
+        const size_t base = (lds + 15) & ~(size_t)15;
+        if (!(e && atoi(e) == 0) && base + 8192 <= 160 * 1024) {
+            lds = base + 8192;
+            stage_ok = 1;
+        }
+    }
     { const char* e = getenv("YH_HPP_STAGGER"); a.hpp_stagger = (e && blocks > 512) ? atoi(e) : 0; }   // first-round phase stagger in cycles (A/B)
     HppDiv dv;
     hpp_magic((unsigned)((a.H + 1) * (a.W + 1)), &dv.m_img, &dv.s_img);       // both divisors >= 4 (H, W >= 1)
@@ -904,7 +930,7 @@ template <typename T> static int launch_hpp(const ConvArgs& a0, hipStream_t stre
         auto kern = YH_HPP_KERN(LBV);                                                                                          \
         hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds);   /* per (kernel, device) */                      \
         if (e != hipSuccess) return (int)e;                                                                                    \
-        hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(512), lds, stream, a, rows_hp, hbufs, dv);                       \
+        hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(512), lds, stream, a, rows_hp, hbufs | (stage_ok << 8), dv);     \
         break;                                                                                                                 \
     }
     switch (lb) {
