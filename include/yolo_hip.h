@@ -479,7 +479,10 @@ typedef struct yh_dw_bwd_desc {
     void* dx;               /* dgrad output                                                                          */
     float* dw;              /* wgrad output                                                                          */
     int32_t n, h, w_in, c, ho, wo, k, stride, pad, ldx, lddz, lddx, accumulate, dtype;
+    float* ws;              /* wgrad, optional (ABI 2): yh_dw_wgrad_workspace(d) floats - per-workgroup partial rows summed by a second */
+    int64_t ws_floats;      /* launch in a fixed order; without it the workgroups meet in fp32 atomics (contended: 8 x slower)         */
 } yh_dw_bwd_desc;
+int64_t yh_dw_wgrad_workspace(const yh_dw_bwd_desc* d);
 int yh_dw_wgrad(const yh_dw_bwd_desc* d, void* stream);
 int yh_dw_dgrad(const yh_dw_bwd_desc* d, void* stream);
 typedef struct yh_se_bwd_desc {
@@ -487,6 +490,8 @@ typedef struct yh_se_bwd_desc {
     const float* w1; const float* w2; const float* pooled; const float* gate;
     float* dw1; float* dw2; float* scratch;
     int32_t n, h, w_in, c, cr, ldx, lddy, lddx, accumulate, dtype;
+    float* scratch2;        /* optional (ABI 2): fp32 [n][c + 2 cr] - the per-image factors of the two weight gradients, which a second  */
+    int64_t scratch2_floats;/* launch sums over the images in order; without it every image adds its outer products by fp32 atomics    */
 } yh_se_bwd_desc;
 int yh_se_bwd(const yh_se_bwd_desc* d, void* stream);
 

@@ -929,6 +929,9 @@ class FakeLib:
         return 0
 
     # ---- depthwise / squeeze-excite backward
+    def yh_dw_wgrad_workspace(self, dref):
+        return 0
+
     def yh_dw_wgrad(self, dref, stream):
         d = dref._obj if hasattr(dref, '_obj') else dref
         npdt = _NP[d.dtype]

@@ -710,6 +710,19 @@ def test_depthwise_backward_matches_autograd(libs, code, case):
     dw = torch.zeros(c, 1, k, k, device=GPU)
     geo = dict(n=N, h=H, w_in=W, c=c, ho=Ho, wo=Wo, k=k, stride=s, pad=pad, ldx=c, lddz=c, dtype=code)
     oh.call(lib, 'yh_dw_wgrad', DwBwdDesc(x=P(xd), dz=P(dzd), dw=P(dw), lddx=0, accumulate=0, **geo))
+    # round 6: with a workspace the workgroups' partial rows are summed by a second launch in a fixed order (no atomics): same result,
+    # accumulated INTO dw, and the same bits twice in a row
+    dws = []
+    for _ in range(2):
+        d2 = DwBwdDesc(x=P(xd), dz=P(dzd), dw=None, lddx=0, accumulate=0, **geo)
+        need = int(lib.yh_dw_wgrad_workspace(C.byref(d2)))
+        assert DRY or need > 0
+        ws = torch.full((max(need, 1),), float('nan'), device=GPU)
+        dw2 = torch.ones(c, 1, k, k, device=GPU)
+        d2.dw, d2.ws, d2.ws_floats = P(dw2), P(ws), need
+        oh.call(lib, 'yh_dw_wgrad', d2)
+        _sync()
+        dws.append(dw2.clone())
     dx = torch.full((N, H, W, c), 3.0, device=GPU, dtype=dt)
     oh.call(lib, 'yh_dw_dgrad', DwBwdDesc(dz=P(dzd), w=P(packed), dx=P(dx), lddx=c, accumulate=0, **geo))
     dxa = acc0.to(GPU).clone()
@@ -720,6 +733,8 @@ def test_depthwise_backward_matches_autograd(libs, code, case):
     ref_w = torch.nn.grad.conv2d_weight(xr, (c, 1, k, k), dzr, stride=s, padding=pad, groups=c)
     ref_x = torch.nn.grad.conv2d_input((N, c, H, W), wq, dzr, stride=s, padding=pad, groups=c).permute(0, 2, 3, 1)
     assert (dw.cpu() - ref_w).abs().max().item() <= (2e-5 if code == F32 else 1e-4) * ref_w.abs().max().item()
+    assert torch.equal(dws[0], dws[1])
+    assert (dws[0].cpu() - 1.0 - ref_w).abs().max().item() <= (2e-5 if code == F32 else 1e-4) * ref_w.abs().max().item() + 1e-6
     tol = 2e-5 if code == F32 else 2.5e-3
     assert (dx.float().cpu() - ref_x).abs().max().item() <= tol * ref_x.abs().max().item()
     ref_a = ref_x + acc0.float()

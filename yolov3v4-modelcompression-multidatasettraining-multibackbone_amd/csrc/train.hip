@@ -461,41 +461,67 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const yh_pool_bwd_desc
 // ------------------------------------------------------------------------------------------ depthwise backward
 // Up to 9 taps per pass (grid.z = tap groups): a thread owns one 16-byte channel vector and 9 x VN accumulators, so dz is
 // read once per group (once for 3x3, three times for 5x5) instead of once per tap, with full-width loads.
-template <typename T>
+// Round 6: the pixel walk is incremental 32-bit arithmetic and the taps' offsets are per-thread constants - the round-1 form decoded every
+// pixel with two 64-bit divisions and every tap with two more by the run-time kernel size (~500 instructions of index arithmetic per pixel
+// around 72 multiply-adds: YOLOv3-Mobilenetv3's 15 depthwise weight gradients took 8.4 ms of its 30.7 ms training step).  Padding taps read a
+// zero page instead of branching (a branch around a load makes the compiler wait for every load at once).  K: 3 / 5 compile-time, 0 run-time.
+__device__ __attribute__((aligned(16))) unsigned int dw_zero_page[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+
+template <typename T, int K>
 __global__ __launch_bounds__(256) void dw_wgrad_taps_kernel(const yh_dw_bwd_desc d, const BnGeom gm) {
     typedef typename TV<T>::type V;
     constexpr int VN = TV<T>::N, TG = 9;
     const int cgl = threadIdx.x % gm.cgb, prow = threadIdx.x / gm.cgb;
     const int g = blockIdx.x * gm.cgb + cgl;
     const bool ok = prow < gm.rows && g < gm.cgs;
-    const int t0 = blockIdx.z * TG, taps = d.k * d.k;
-    const long pixels = (long)d.n * d.ho * d.wo;
-    const long p0 = (long)blockIdx.y * gm.ppb, p1 = min(p0 + gm.ppb, pixels);
-    const T* x = reinterpret_cast<const T*>(d.x) + g * VN;
-    const T* dz = reinterpret_cast<const T*>(d.dz) + g * VN;
+    const int k = K ? K : d.k;
+    const int t0 = blockIdx.z * TG, taps = k * k;
+    const int pixels = d.n * d.ho * d.wo;
+    const int p0 = blockIdx.y * gm.ppb, p1 = min(p0 + gm.ppb, pixels);
+    const T* const x = reinterpret_cast<const T*>(d.x) + g * VN;
+    const T* const dz = reinterpret_cast<const T*>(d.dz) + g * VN;
+    const T* const zero = reinterpret_cast<const T*>(dw_zero_page);
     float acc[TG][VN];
+    int tky[TG], tkx[TG], toff[TG];
 #pragma unroll
-    for (int t = 0; t < TG; ++t)
+    for (int t = 0; t < TG; ++t) {
+        const int tap = t0 + t;
+        const int ky = tap / k, kx = tap - ky * k;
+        tky[t] = tap < taps ? ky : -(1 << 20);               // a tap beyond the kernel is out of bounds for every pixel
+        tkx[t] = kx;
+        toff[t] = (ky * d.w_in + kx) * d.ldx;
 #pragma unroll
         for (int e = 0; e < VN; ++e) acc[t][e] = 0.f;
-    if (ok)
-        for (long p = p0 + prow; p < p1; p += gm.rows) {
-            const int wo = (int)(p % d.wo);
-            const long r = p / d.wo;
-            const int ho = (int)(r % d.ho);
-            const long n = r / d.ho;
-            const V gv = *reinterpret_cast<const V*>(dz + p * d.lddz);
+    }
+    if (ok && p0 + prow < p1) {
+        int p = p0 + prow;
+        const int howo = d.ho * d.wo;
+        int n = p / howo;
+        const int rem = p - n * howo;
+        int ho = rem / d.wo, wo = rem - ho * d.wo;
+        for (; p < p1; p += gm.rows) {
+            const V gv = *reinterpret_cast<const V*>(dz + (long)p * d.lddz);
+            const int hi0 = ho * d.stride - d.pad, wi0 = wo * d.stride - d.pad;
+            const T* const xb = x + ((long)(n * d.h + hi0) * d.w_in + wi0) * d.ldx;      // only dereferenced at in-bounds taps
 #pragma unroll
             for (int t = 0; t < TG; ++t) {
-                const int tap = t0 + t;
-                const int hi = ho * d.stride + tap / d.k - d.pad, wi = wo * d.stride + tap % d.k - d.pad;
-                if (tap < taps && (unsigned)hi < (unsigned)d.h && (unsigned)wi < (unsigned)d.w_in) {
-                    const V xv = *reinterpret_cast<const V*>(x + ((n * d.h + hi) * d.w_in + wi) * d.ldx);
+                const bool in = (unsigned)(hi0 + tky[t]) < (unsigned)d.h && (unsigned)(wi0 + tkx[t]) < (unsigned)d.w_in;
+                const T* ad = in ? xb + toff[t] : zero;
+                asm volatile("" : "+v"(ad));                  // keep the select (the optimiser would turn it back into a branch around the load)
+                const V xv = *reinterpret_cast<const V*>(ad);
 #pragma unroll
-                    for (int e = 0; e < VN; ++e) acc[t][e] = fmaf((float)gv[e], (float)xv[e], acc[t][e]);
+                for (int e = 0; e < VN; ++e) acc[t][e] = fmaf((float)gv[e], (float)xv[e], acc[t][e]);
+            }
+            wo += gm.rows;
+            while (wo >= d.wo) {
+                wo -= d.wo;
+                if (++ho == d.ho) {
+                    ho = 0;
+                    ++n;
                 }
             }
         }
+    }
     __shared__ float red[256 * VN];
 #pragma unroll
     for (int t = 0; t < TG; ++t) {
@@ -507,10 +533,29 @@ __global__ __launch_bounds__(256) void dw_wgrad_taps_kernel(const yh_dw_bwd_desc
             for (int it = prow; it < VN; it += gm.rows) {
                 float v = 0.f;
                 for (int r = 0; r < gm.rows; ++r) v += red[it * 256 + r * gm.cgb + cgl];
-                atomicAdd(d.dw + (long)(g * VN + it) * taps + t0 + t, v);
+                // with a workspace: this workgroup's row [taps][c] of partial sums, added up by dw_partials_kernel (the contended
+                // same-address atomics of ~1500 workgroups were 90 % of this kernel's time)
+                if (d.ws) d.ws[((long)blockIdx.y * taps + t0 + t) * d.c + g * VN + it] = v;
+                else atomicAdd(d.dw + (long)(g * VN + it) * taps + t0 + t, v);
             }
         __syncthreads();
     }
+}
+
+// dw[ch][tap] += sum over the pixel chunks' rows, in row order (deterministic): one thread per (tap, channel), eight load chains
+__global__ __launch_bounds__(256) void dw_partials_kernel(const float* ws, int rows, int taps, int c, float* dw) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;      // i = tap * c + ch: consecutive threads on consecutive channels
+    if (i >= taps * c) return;
+    const long pitch = (long)taps * c;
+    float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    int r = 0;
+    for (; r + 7 < rows; r += 8) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] += ws[(r + u) * pitch + i];
+    }
+    for (int u = 0; r < rows; ++r, ++u) v[u] += ws[r * pitch + i];
+    const int tap = i / c, ch = i - tap * c;
+    dw[(long)ch * taps + tap] += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
 }
 
 template <typename T>
@@ -599,7 +644,11 @@ __global__ __launch_bounds__(256) void se_bwd_reduce_kernel(const yh_se_bwd_desc
         }
 }
 
-// B: the two Linear layers backward for one image; scratch[n] turns from d(gate) into d(pooled)
+// B: the two Linear layers backward for one image; scratch[n] turns from d(gate) into d(pooled).
+// Round 6: the weight gradients are no longer 2 x c x cr fp32 atomics per image (YOLOv3-Mobilenetv3, c 672: 7.2 M contended atomics per
+// layer): with scratch2 each image leaves its factors dA2 | relu(a1) | dA1 and se_bwd_wgrad_kernel sums the outer products over the images in
+// order.  (One output per WAVE for the two products whose rows are strided across threads was measured slower, see depthwise.hip se_fc_kernel.)
+
 __global__ __launch_bounds__(256) void se_bwd_fc_kernel(const yh_se_bwd_desc d) {
     extern __shared__ float sh[];            // a1[cr] | dA1[cr] | dA2[c]
     float* a1 = sh;
@@ -632,6 +681,15 @@ __global__ __launch_bounds__(256) void se_bwd_fc_kernel(const yh_se_bwd_desc d) 
         for (int j = 0; j < d.cr; ++j) v = fmaf(d.w1[(long)j * d.c + c], dA1[j], v);
         sc[c] = v;                           // d(pooled)
     }
+    if (d.scratch2) {
+        float* f = d.scratch2 + (long)n * (d.c + 2 * d.cr);
+        for (int c = threadIdx.x; c < d.c; c += blockDim.x) f[c] = dA2[c];
+        for (int j = threadIdx.x; j < d.cr; j += blockDim.x) {
+            f[d.c + j] = fmaxf(a1[j], 0.f);
+            f[d.c + d.cr + j] = dA1[j];
+        }
+        return;
+    }
     // weight gradients: outer products, summed over the images by atomics
     for (int i = threadIdx.x; i < d.c * d.cr; i += blockDim.x) {
         const int c = i / d.cr, j = i - c * d.cr;
@@ -639,6 +697,23 @@ __global__ __launch_bounds__(256) void se_bwd_fc_kernel(const yh_se_bwd_desc d) 
         const int j1 = i / d.c, c1 = i - j1 * d.c;
         atomicAdd(d.dw1 + i, dA1[j1] * pooled[c1]);                  // dw1[j][c]
     }
+}
+
+// B2: dw2[c][j] += sum_n dA2[n][c] relu(a1)[n][j], dw1[j][c] += sum_n dA1[n][j] pooled[n][c] - one thread per weight, images in order
+__global__ __launch_bounds__(256) void se_bwd_wgrad_kernel(const yh_se_bwd_desc d) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= d.c * d.cr) return;
+    const int c = i / d.cr, j = i - c * d.cr;
+    const int j1 = i / d.c, c1 = i - j1 * d.c;
+    const int fp = d.c + 2 * d.cr;
+    float s2 = 0.f, s1 = 0.f;
+    for (int n = 0; n < d.n; ++n) {
+        const float* f = d.scratch2 + (long)n * fp;
+        s2 = fmaf(f[c], f[d.c + j], s2);
+        s1 = fmaf(f[d.c + d.cr + j1], d.pooled[(long)n * d.c + c1], s1);
+    }
+    d.dw2[i] += s2;
+    d.dw1[i] += s1;
 }
 
 // C: dx (+)= dy * gate + d(pooled) / HW
@@ -693,21 +768,49 @@ static int check_dw(const yh_dw_bwd_desc* d) {
     return YH_OK;
 }
 
-extern "C" int yh_dw_wgrad(const yh_dw_bwd_desc* d, void* stream) {
-    int rc = check_dw(d);
-    if (rc) return rc;
-    if (!d->x || !d->dw) return YH_EINVAL;
-    const int v = d->dtype == YH_F16 ? 8 : 4;
-    if (d->ldx % v || !aligned16(d->x)) return YH_EALIGN;
+static BnGeom dw_wgrad_geom(const yh_dw_bwd_desc* d, dim3* grid) {
     yh_bn_desc geo = {};
     geo.c = d->c;
     geo.pixels = (long)d->n * d->ho * d->wo;
     geo.dtype = d->dtype;
+    const BnGeom gm = bn_geom(&geo, d->dtype == YH_F16 ? 8 : 4, grid, 512);
+    grid->z = (d->k * d->k + 8) / 9;                    // tap groups of 9
+    return gm;
+}
+
+extern "C" int64_t yh_dw_wgrad_workspace(const yh_dw_bwd_desc* d) {
+    if (check_dw(d)) return 0;
     dim3 grid;
-    const BnGeom gm = bn_geom(&geo, v, &grid, 512);
-    grid.z = (d->k * d->k + 8) / 9;                     // tap groups of 9
-    if (d->dtype == YH_F16) hipLaunchKernelGGL(dw_wgrad_taps_kernel<f16>, grid, dim3(256), 0, (hipStream_t)stream, *d, gm);
-    else hipLaunchKernelGGL(dw_wgrad_taps_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, *d, gm);
+    dw_wgrad_geom(d, &grid);
+    return (int64_t)grid.y * d->k * d->k * d->c;
+}
+
+extern "C" int yh_dw_wgrad(const yh_dw_bwd_desc* d0, void* stream) {
+    int rc = check_dw(d0);
+    if (rc) return rc;
+    if (!d0->x || !d0->dw) return YH_EINVAL;
+    const int v = d0->dtype == YH_F16 ? 8 : 4;
+    if (d0->ldx % v || !aligned16(d0->x)) return YH_EALIGN;
+    dim3 grid;
+    const BnGeom gm = dw_wgrad_geom(d0, &grid);
+    yh_dw_bwd_desc dd = *d0;
+    if (dd.ws && dd.ws_floats < (int64_t)grid.y * dd.k * dd.k * dd.c) dd.ws = nullptr;       // too small: the atomics
+    const yh_dw_bwd_desc* const d = &dd;
+    if ((long)d->n * d->ho * d->wo >= (1L << 31) - 65536 || (long)d->n * d->h * d->w_in * d->ldx >= (1L << 40)) return YH_EINVAL;
+#define YH_DWW(K)                                                                                                          \
+    do {                                                                                                                    \
+        if (d->dtype == YH_F16) hipLaunchKernelGGL((dw_wgrad_taps_kernel<f16, K>), grid, dim3(256), 0, (hipStream_t)stream, *d, gm);   \
+        else hipLaunchKernelGGL((dw_wgrad_taps_kernel<float, K>), grid, dim3(256), 0, (hipStream_t)stream, *d, gm);          \
+    } while (0)
+    if (d->k == 3) YH_DWW(3);
+    else if (d->k == 5) YH_DWW(5);
+    else YH_DWW(0);
+#undef YH_DWW
+    if (d->ws) {
+        const int total = d->k * d->k * d->c;
+        hipLaunchKernelGGL(dw_partials_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, d->ws, (int)grid.y, d->k * d->k,
+                           d->c, d->dw);
+    }
     return check_launch();
 }
 
@@ -735,7 +838,10 @@ extern "C" int yh_se_bwd(const yh_se_bwd_desc* d, void* stream) {
     const dim3 rgrid((cgs + cgb - 1) / cgb, d->n);
     if (d->dtype == YH_F16) hipLaunchKernelGGL(se_bwd_reduce_kernel<f16>, rgrid, dim3(256), 0, s, *d);
     else hipLaunchKernelGGL(se_bwd_reduce_kernel<float>, rgrid, dim3(256), 0, s, *d);
-    hipLaunchKernelGGL(se_bwd_fc_kernel, dim3(d->n), dim3(256), (size_t)(2 * d->cr + d->c) * sizeof(float), s, *d);
+    yh_se_bwd_desc dd = *d;
+    if (dd.scratch2 && dd.scratch2_floats < (int64_t)dd.n * (dd.c + 2 * dd.cr)) dd.scratch2 = nullptr;
+    hipLaunchKernelGGL(se_bwd_fc_kernel, dim3(d->n), dim3(256), (size_t)(2 * d->cr + d->c) * sizeof(float), s, dd);
+    if (dd.scratch2) hipLaunchKernelGGL(se_bwd_wgrad_kernel, dim3((d->c * d->cr + 255) / 256), dim3(256), 0, s, dd);
     const long total = (long)d->n * d->h * d->w_in * cgs;
     long gsz = (total + 255) / 256;
     const dim3 agrid((unsigned)(gsz < 1 ? 1 : (gsz > 16384 ? 16384 : gsz)));

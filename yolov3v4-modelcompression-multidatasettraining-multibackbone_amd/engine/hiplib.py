@@ -194,7 +194,8 @@ class PackBatchDesc(C.Structure):
 class DwBwdDesc(C.Structure):
     _fields_ = [('x', _vp), ('dz', _vp), ('w', _vp), ('dx', _vp), ('dw', _vp),
                 ('n', _i32), ('h', _i32), ('w_in', _i32), ('c', _i32), ('ho', _i32), ('wo', _i32), ('k', _i32), ('stride', _i32),
-                ('pad', _i32), ('ldx', _i32), ('lddz', _i32), ('lddx', _i32), ('accumulate', _i32), ('dtype', _i32)]
+                ('pad', _i32), ('ldx', _i32), ('lddz', _i32), ('lddx', _i32), ('accumulate', _i32), ('dtype', _i32),
+                ('ws', _vp), ('ws_floats', _i64)]
 
 
 class DwWgradDesc(DwBwdDesc):
@@ -209,7 +210,7 @@ class SeBwdDesc(C.Structure):
     _fields_ = [('x', _vp), ('dy', _vp), ('dx', _vp), ('w1', _vp), ('w2', _vp), ('pooled', _vp), ('gate', _vp), ('dw1', _vp),
                 ('dw2', _vp), ('scratch', _vp),
                 ('n', _i32), ('h', _i32), ('w_in', _i32), ('c', _i32), ('cr', _i32), ('ldx', _i32), ('lddy', _i32), ('lddx', _i32),
-                ('accumulate', _i32), ('dtype', _i32)]
+                ('accumulate', _i32), ('dtype', _i32), ('scratch2', _vp), ('scratch2_floats', _i64)]
 
 
 class LossDesc(C.Structure):
@@ -292,6 +293,7 @@ _SIGNATURES = {
     'yh_maxpool2d_bwd': (C.c_int, [C.POINTER(PoolBwdDesc), _vp]),
     'yh_pack_batch': (C.c_int, [_vp, C.c_int, _vp]),
     'yh_dw_wgrad': (C.c_int, [C.POINTER(DwBwdDesc), _vp]),
+    'yh_dw_wgrad_workspace': (_i64, [C.POINTER(DwBwdDesc)]),
     'yh_dw_dgrad': (C.c_int, [C.POINTER(DwBwdDesc), _vp]),
     'yh_se_bwd': (C.c_int, [C.POINTER(SeBwdDesc), _vp]),
     'yh_yolo_loss_fwd': (C.c_int, [C.POINTER(LossDesc), _vp]),

@@ -213,7 +213,7 @@ class TrainEngine(DarknetEngine):
             """Reductions get the shared workspace (bound to SLOT_WS at run time) sized by the library's own query; ops of the
             side lane have their own (SLOT_WS2)."""
             query = lib.yh_conv2d_wgrad_workspace if isinstance(desc, WgradDesc) and not isinstance(desc, StemWgradDesc) \
-                else lib.yh_bn_reduce_workspace
+                else lib.yh_dw_wgrad_workspace if isinstance(desc, DwWgradDesc) else lib.yh_bn_reduce_workspace
             need = int(query(C.byref(desc)))
             desc.ws_floats = need
             key = 'ws2_floats' if side else 'ws_floats'
@@ -285,6 +285,7 @@ class TrainEngine(DarknetEngine):
                 v.pooled = alloc((N, v.c_phys), fp32=True)
                 v.gate = alloc((N, v.c_phys), fp32=True)
                 v.scratch = alloc((N, v.c_phys), fp32=True)
+                v.scratch2 = alloc((N, v.c_phys + 2 * v.fc1.weight.shape[0]), fp32=True)      # factors of the two weight gradients per image
                 continue
             if v.kind != 'conv':
                 continue
@@ -607,6 +608,7 @@ class TrainEngine(DarknetEngine):
                     add(bwd, plan['bwd_ops'],
                         SeBwdDesc(x=P(s.storage, s.c_off), dy=gptr(v), dx=gptr(s), w1=P(v.fc1.weight), w2=P(v.fc2.weight),
                                   pooled=P(v.pooled), gate=P(v.gate), dw1=grads.ptr(v.g_w1), dw2=grads.ptr(v.g_w2), scratch=P(v.scratch),
+                                  scratch2=P(v.scratch2), scratch2_floats=v.scratch2.numel(),
                                   n=N, h=s.H, w_in=s.W, c=v.c_phys, cr=v.fc1.weight.shape[0], ldx=s.ld, lddy=v.ld, lddx=s.ld,
                                   accumulate=1 if mode == 'acc' else 0, dtype=self.code), 'dse%d' % v.block)
                 continue
@@ -632,8 +634,8 @@ class TrainEngine(DarknetEngine):
                     dz_written_by(op, kz)
                 geo = dict(n=N, h=s.H, w_in=s.W, c=v.c_phys, ho=v.H, wo=v.W, k=v.k, stride=v.stride, pad=v.pad, ldx=s.ld, lddz=lddz,
                            dtype=self.code)
-                add(bwd, plan['bwd_ops'], DwWgradDesc(x=P(s.storage, s.c_off), dz=dzp, dw=grads.ptr(v.g_w), lddx=0, accumulate=0, **geo),
-                    'dwwgrad%d' % v.block)
+                add_reduction(bwd, plan['bwd_ops'], DwWgradDesc(x=P(s.storage, s.c_off), dz=dzp, dw=grads.ptr(v.g_w), lddx=0, accumulate=0, **geo),
+                              'dwwgrad%d' % v.block)
                 if s.kind != 'input':
                     mode = contribution_mode(s, True)
                     add(bwd, plan['bwd_ops'], DwDgradDesc(dz=dzp, w=P(pk['w']), dx=gptr(s), lddx=s.ld,
