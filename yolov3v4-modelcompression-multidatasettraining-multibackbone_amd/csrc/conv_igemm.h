@@ -198,9 +198,22 @@ template <int ACT> __device__ __forceinline__ float activate_q(float v, float sl
 
 // int8 epilogue of one fragment: q[e] = round_clamp_i8(act(acc[e] * s_w s_x + bias[e]) / s_a), the four values of a lane together
 // (mish takes its fast / exact decision once per fragment, common.h mish_for_grid_n)
-template <int ACT, typename AccV>
+// (CHUNK 2: the decision per pair - same grid values, fewer live registers; conv_stream3.hip's 128-channel residual form needs it)
+template <int ACT, typename AccV, int CHUNK = 4>
 __device__ __forceinline__ void quantize4(const AccV& acc, const f32x4& bias, const ConvArgs& a, float (&q)[4]) {
     float y[4];
+    if constexpr (ACT == YH_ACT_MISH && CHUNK == 2) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            float y2[2], q2[2];
+            y2[0] = (float)acc[2 * h] * a.acc_scale + bias[2 * h];
+            y2[1] = (float)acc[2 * h + 1] * a.acc_scale + bias[2 * h + 1];
+            mish_quantize_n<2>(y2, a.inv_out_scale, q2);
+            q[2 * h] = q2[0];
+            q[2 * h + 1] = q2[1];
+        }
+        return;
+    }
 #pragma unroll
     for (int e = 0; e < 4; ++e) y[e] = (float)acc[e] * a.acc_scale + bias[e];
     if constexpr (ACT == YH_ACT_MISH) {

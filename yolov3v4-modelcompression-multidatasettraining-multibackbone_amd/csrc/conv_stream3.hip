@@ -167,7 +167,7 @@ __global__ __launch_bounds__(S3_WAVES * 64, OCC) void conv3x3_stream_kernel(cons
             for (int i = 0; i < MT; ++i) {
                 float v[4];
                 if constexpr (sizeof(T) == 1) {
-                    quantize4<ACT>(acc[i][j], bvs[i], a, v);
+                    quantize4<ACT, acc_t, (MT == 8 && HAS_RES) ? 2 : 4>(acc[i][j], bvs[i], a, v);     // (256 registers: no room for four)
                     if constexpr (HAS_RES) {
                         float r4[4];
 #pragma unroll

@@ -71,6 +71,89 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const yh_dw_desc d) {
     }
 }
 
+// Round 6: the same convolution with a FIXED channel group per thread and an incremental walk over the pixels (the form of the BatchNorm
+// passes): no division per output (the kernel above decodes every output vector with three 64-bit divisions), the kernel size and the
+// activation as template parameters (the run-time switch of activate() is expanded per element), the 3x3 weights of the thread's channel
+// group in registers, padding taps through a zero page instead of a branch around the load.  Same multiply-add order per output (taps in
+// row-major order onto the bias; a padding tap adds x = 0): bit-identical results.  K: 3 / 5, or 0 = run-time size (weights re-read per tap).
+__device__ __attribute__((aligned(16))) unsigned int dwf_zero_page[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+
+template <typename T, int K, int ACT>
+__global__ __launch_bounds__(256) void dwconv_walk_kernel(const yh_dw_desc d, const int cgb, const int rows, const int ppb) {
+    typedef typename V16<T>::type V;
+    constexpr bool WREG = K == 3;                       // 3x3: the nine weight vectors of the channel group stay in registers (5x5 would take 100)
+    constexpr int VN = V16<T>::N, KK = WREG ? K * K : 1;
+    const int cgs = d.c / VN;
+    const int cgl = threadIdx.x % cgb, prow = threadIdx.x / cgb;
+    const int g = blockIdx.x * cgb + cgl;
+    const int pixels = d.n * d.ho * d.wo;
+    const int p0 = blockIdx.y * ppb, p1 = min(p0 + ppb, pixels);
+    int p = p0 + prow;
+    if (prow >= rows || g >= cgs || p >= p1) return;
+    const int k = K ? K : d.k;
+    const T* const x = reinterpret_cast<const T*>(d.x) + g * VN;
+    const T* const w = reinterpret_cast<const T*>(d.w) + g * VN;
+    T* const y = reinterpret_cast<T*>(d.y) + g * VN;
+    const T* const zero = reinterpret_cast<const T*>(dwf_zero_page);
+    V wv[KK];
+    if constexpr (WREG) {
+#pragma unroll
+        for (int t = 0; t < KK; ++t) wv[t] = *reinterpret_cast<const V*>(w + (long)t * d.c);
+    }
+    float bias[VN];
+#pragma unroll
+    for (int e = 0; e < VN; ++e) bias[e] = d.bias[g * VN + e];
+    const int howo = d.ho * d.wo;
+    int n = p / howo;
+    const int rem = p - n * howo;
+    int ho = rem / d.wo, wo = rem - ho * d.wo;
+    const int rowpitch = d.w_in * d.ldx;
+    for (; p < p1; p += rows) {
+        float acc[VN];
+#pragma unroll
+        for (int e = 0; e < VN; ++e) acc[e] = bias[e];
+        const int hi0 = ho * d.stride - d.pad, wi0 = wo * d.stride - d.pad;
+        const T* const xb = x + ((long)(n * d.h + hi0) * d.w_in + wi0) * d.ldx;      // only dereferenced at in-bounds taps
+        if constexpr (K != 0) {
+#pragma unroll
+            for (int ky = 0; ky < K; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < K; ++kx) {
+                    const bool in = (unsigned)(hi0 + ky) < (unsigned)d.h && (unsigned)(wi0 + kx) < (unsigned)d.w_in;
+                    const T* ad = in ? xb + ky * rowpitch + kx * d.ldx : zero;
+                    asm volatile("" : "+v"(ad));              // keep the select: no branch around the load
+                    const V xv = *reinterpret_cast<const V*>(ad);
+                    const V w1 = WREG ? wv[WREG ? ky * K + kx : 0] : *reinterpret_cast<const V*>(w + (long)(ky * K + kx) * d.c);
+#pragma unroll
+                    for (int e = 0; e < VN; ++e) acc[e] = fmaf((float)xv[e], (float)w1[e], acc[e]);
+                }
+        } else {
+            for (int ky = 0; ky < k; ++ky) {
+                if ((unsigned)(hi0 + ky) >= (unsigned)d.h) continue;
+                for (int kx = 0; kx < k; ++kx) {
+                    if ((unsigned)(wi0 + kx) >= (unsigned)d.w_in) continue;
+                    const V xv = *reinterpret_cast<const V*>(xb + ky * rowpitch + kx * d.ldx);
+                    const V w1 = *reinterpret_cast<const V*>(w + (long)(ky * k + kx) * d.c);
+#pragma unroll
+                    for (int e = 0; e < VN; ++e) acc[e] = fmaf((float)xv[e], (float)w1[e], acc[e]);
+                }
+            }
+        }
+        V o;
+#pragma unroll
+        for (int e = 0; e < VN; ++e) o[e] = (T)activate(acc[e], ACT, d.slope);
+        *reinterpret_cast<V*>(y + (long)p * d.ldy) = o;
+        wo += rows;
+        while (wo >= d.wo) {
+            wo -= d.wo;
+            if (++ho == d.ho) {
+                ho = 0;
+                ++n;
+            }
+        }
+    }
+}
+
 // ---- squeeze-excite ---------------------------------------------------------------------------------
 // grid (c_phys / VN, n): per-channel mean over the H*W pixels of one image
 template <typename T>
@@ -192,6 +275,33 @@ extern "C" int yh_dwconv2d_fwd(const yh_dw_desc* d, void* stream) {
     if (d->ho != (d->h + 2 * d->pad - d->k) / d->stride + 1 || d->wo != (d->w_in + 2 * d->pad - d->k) / d->stride + 1) return YH_EINVAL;
     const long total = (long)d->n * d->ho * d->wo * (d->c / v);
     hipStream_t s = (hipStream_t)stream;
+    const long pixels = (long)d->n * d->ho * d->wo;
+    static const bool old_form = getenv("YH_DW_WALK") && atoi(getenv("YH_DW_WALK")) == 0;      // A/B knob: 0 = the round-1 kernel
+    if (!old_form && pixels < (1L << 31) - 65536 && (long)d->n * d->h * d->w_in * d->ldx < (1L << 40)) {
+        // channel groups x pixel lanes per workgroup as the BatchNorm passes; >= 4 pixels per thread (the weights are loaded once), ~8192 workgroups
+        const int cgs = d->c / v, cgb = cgs < 256 ? cgs : 256, rows = 256 / cgb, gx = (cgs + cgb - 1) / cgb;
+        long ppb = (pixels * gx + 8191) / 8192;
+        if (ppb < 4L * rows) ppb = 4L * rows;
+        ppb = (ppb + rows - 1) / rows * rows;
+        const dim3 grid(gx, (unsigned)((pixels + ppb - 1) / ppb));
+#define YH_DWF_A(T, K, A) hipLaunchKernelGGL((dwconv_walk_kernel<T, K, A>), grid, dim3(256), 0, s, *d, cgb, rows, (int)ppb)
+#define YH_DWF_K(T, K)                                                                   \
+        switch (d->act) {                                                                    \
+            case YH_ACT_LEAKY: YH_DWF_A(T, K, YH_ACT_LEAKY); break;                          \
+            case YH_ACT_RELU: YH_DWF_A(T, K, YH_ACT_RELU); break;                            \
+            case YH_ACT_RELU6: YH_DWF_A(T, K, YH_ACT_RELU6); break;                          \
+            case YH_ACT_HSWISH: YH_DWF_A(T, K, YH_ACT_HSWISH); break;                        \
+            case YH_ACT_MISH: YH_DWF_A(T, K, YH_ACT_MISH); break;                            \
+            default: YH_DWF_A(T, K, YH_ACT_LINEAR); break;                                   \
+        }
+#define YH_DWF_T(T)                                                                      \
+        if (d->k == 3) { YH_DWF_K(T, 3) } else if (d->k == 5) { YH_DWF_K(T, 5) } else { YH_DWF_K(T, 0) }
+        if (d->dtype == YH_F16) { YH_DWF_T(f16) } else { YH_DWF_T(float) }
+#undef YH_DWF_T
+#undef YH_DWF_K
+#undef YH_DWF_A
+        return check_launch();
+    }
     if (d->dtype == YH_F16) hipLaunchKernelGGL(dwconv_kernel<f16>, dim3(grid_cap(total)), dim3(256), 0, s, *d);
     else hipLaunchKernelGGL(dwconv_kernel<float>, dim3(grid_cap(total)), dim3(256), 0, s, *d);
     return check_launch();

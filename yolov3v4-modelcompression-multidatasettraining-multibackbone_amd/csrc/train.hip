@@ -607,6 +607,86 @@ __global__ __launch_bounds__(256) void dw_dgrad_kernel(const yh_dw_bwd_desc d) {
     }
 }
 
+// Round 6: the depthwise data gradient with a fixed channel group per thread and an incremental walk over the INPUT pixels (no division per
+// element, kernel size and stride as template parameters, absent taps through the zero page instead of branches); same multiply-add
+// order per element as dw_dgrad_kernel: bit-identical.  K: 3 / 5 / 0 = run time, S: 1 / 2 / 0 = run time.
+template <typename T, int K, int S>
+__global__ __launch_bounds__(256) void dw_dgrad_walk_kernel(const yh_dw_bwd_desc d, const int cgb, const int rows, const int ppb) {
+    typedef typename TV<T>::type V;
+    constexpr int VN = TV<T>::N;
+    const int cgs = d.c / VN;
+    const int cgl = threadIdx.x % cgb, prow = threadIdx.x / cgb;
+    const int g = blockIdx.x * cgb + cgl;
+    const int pixels = d.n * d.h * d.w_in;
+    const int p0 = blockIdx.y * ppb, p1 = min(p0 + ppb, pixels);
+    int p = p0 + prow;
+    if (prow >= rows || g >= cgs || p >= p1) return;
+    const int k = K ? K : d.k, stride = S ? S : d.stride;
+    const T* const dz = reinterpret_cast<const T*>(d.dz) + g * VN;
+    const T* const w = reinterpret_cast<const T*>(d.w) + g * VN;
+    T* const dx = reinterpret_cast<T*>(d.dx) + g * VN;
+    const T* const zero = reinterpret_cast<const T*>(dw_zero_page);
+    const int hw = d.h * d.w_in;
+    int n = p / hw;
+    const int rem = p - n * hw;
+    int hi = rem / d.w_in, wi = rem - hi * d.w_in;
+    for (; p < p1; p += rows) {
+        float acc[VN];
+#pragma unroll
+        for (int e = 0; e < VN; ++e) acc[e] = 0.f;
+        const T* const zb = dz + (long)n * d.ho * d.wo * d.lddz;
+        auto tap = [&](int kr, int ks, bool present) {
+            const int th = hi + d.pad - kr, tw = wi + d.pad - ks;
+            bool in = present && th >= 0 && tw >= 0;
+            int ho, wo;
+            if (stride == 1) { ho = th; wo = tw; }
+            else if (stride == 2) { in = in && !((th | tw) & 1); ho = th >> 1; wo = tw >> 1; }
+            else { in = in && th % stride == 0 && tw % stride == 0; ho = th / stride; wo = tw / stride; }
+            in = in && ho < d.ho && wo < d.wo;
+            const T* ad = in ? zb + ((long)ho * d.wo + wo) * d.lddz : zero;
+            asm volatile("" : "+v"(ad));
+            const V gv = *reinterpret_cast<const V*>(ad);
+            const V wv = *reinterpret_cast<const V*>(w + (long)(present ? kr * k + ks : 0) * d.c);
+#pragma unroll
+            for (int e = 0; e < VN; ++e) acc[e] = fmaf((float)gv[e], (float)wv[e], acc[e]);
+        };
+        if constexpr (K != 0 && S == 2) {      // only the taps of this pixel's parity class reach an output: (K + 1) / 2 per axis, not K
+            const int ph = (hi + d.pad) & 1, pw = (wi + d.pad) & 1;
+#pragma unroll
+            for (int a = 0; a < (K + 1) / 2; ++a)
+#pragma unroll
+                for (int b = 0; b < (K + 1) / 2; ++b) tap(ph + 2 * a, pw + 2 * b, ph + 2 * a < K && pw + 2 * b < K);
+        } else if constexpr (K != 0) {
+#pragma unroll
+            for (int kr = 0; kr < K; ++kr)
+#pragma unroll
+                for (int ks = 0; ks < K; ++ks) tap(kr, ks, true);
+        } else {
+            for (int kr = 0; kr < k; ++kr)
+                for (int ks = 0; ks < k; ++ks) tap(kr, ks, true);
+        }
+        T* const dst = dx + (long)p * d.lddx;
+        V o;
+        if (d.accumulate) {
+            const V old = *reinterpret_cast<const V*>(dst);
+#pragma unroll
+            for (int e = 0; e < VN; ++e) o[e] = (T)((float)old[e] + acc[e]);
+        } else {
+#pragma unroll
+            for (int e = 0; e < VN; ++e) o[e] = (T)acc[e];
+        }
+        *reinterpret_cast<V*>(dst) = o;
+        wi += rows;
+        while (wi >= d.w_in) {
+            wi -= d.w_in;
+            if (++hi == d.h) {
+                hi = 0;
+                ++n;
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------ squeeze-excite backward
 // A: scratch[n][c] = sum over the image's pixels of dy * x   (grid: channel groups x images)
 template <typename T>
@@ -821,6 +901,26 @@ extern "C" int yh_dw_dgrad(const yh_dw_bwd_desc* d, void* stream) {
     const int v = d->dtype == YH_F16 ? 8 : 4;
     if (d->lddx % v || !aligned16(d->dx) || !aligned16(d->w)) return YH_EALIGN;
     const long total = (long)d->n * d->h * d->w_in * (d->c / v);
+    const long pixels = (long)d->n * d->h * d->w_in;
+    static const bool old_form = getenv("YH_DW_WALK") && atoi(getenv("YH_DW_WALK")) == 0;      // A/B knob: 0 = the round-1 kernels
+    if (!old_form && pixels < (1L << 31) - 65536 && (long)d->n * d->ho * d->wo * d->lddz < (1L << 40)) {
+        const int cgs = d->c / v, cgb = cgs < 256 ? cgs : 256, rows = 256 / cgb, gx = (cgs + cgb - 1) / cgb;
+        long ppb = (pixels * gx + 8191) / 8192;
+        if (ppb < 2L * rows) ppb = 2L * rows;
+        ppb = (ppb + rows - 1) / rows * rows;
+        const dim3 wgrid(gx, (unsigned)((pixels + ppb - 1) / ppb));
+#define YH_DWD(T, K, S) hipLaunchKernelGGL((dw_dgrad_walk_kernel<T, K, S>), wgrid, dim3(256), 0, (hipStream_t)stream, *d, cgb, rows, (int)ppb)
+#define YH_DWD_T(T)                                                                          \
+        if (d->k == 3 && d->stride == 1) YH_DWD(T, 3, 1);                                        \
+        else if (d->k == 3 && d->stride == 2) YH_DWD(T, 3, 2);                                   \
+        else if (d->k == 5 && d->stride == 1) YH_DWD(T, 5, 1);                                   \
+        else if (d->k == 5 && d->stride == 2) YH_DWD(T, 5, 2);                                   \
+        else YH_DWD(T, 0, 0)
+        if (d->dtype == YH_F16) { YH_DWD_T(f16); } else { YH_DWD_T(float); }
+#undef YH_DWD_T
+#undef YH_DWD
+        return check_launch();
+    }
     long gsz = (total + 255) / 256;
     const dim3 grid((unsigned)(gsz < 1 ? 1 : (gsz > 16384 ? 16384 : gsz)));
     if (d->dtype == YH_F16) hipLaunchKernelGGL(dw_dgrad_kernel<f16>, grid, dim3(256), 0, (hipStream_t)stream, *d);
