@@ -159,6 +159,100 @@ template <int N> __device__ __forceinline__ void mish_quantize_n(const float (&v
     for (int e = 0; e < N; ++e) q[e] = __builtin_amdgcn_fmed3f(copysignf(floorf(fabsf(t[e]) + 0.5f), t[e]), -128.f, 127.f);
 }
 
+// out(r) = sum_k W[r * len + k] * v[k] for r < rows - the squeeze-excite matrix-vector products whose rows are contiguous.  Sixteen
+// lanes per row (a wave load touches four 64-byte runs, not 64 lines - thread-per-row is bound by the texture addresser at ~64 cycles per
+// load), eight rows of a wave in flight at once (one row per wave at a time was measured 2.7 x slower than thread-per-row: a memory latency
+// per row); v in LDS.  Fixed order: deterministic.
+template <typename F>
+__device__ __forceinline__ void rows_dot16(const float* __restrict__ W, const int rows, const int len, const float* v, F&& emit) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const int q = lane >> 4, l = lane & 15;
+    for (int r0 = wave * 8; r0 < rows; r0 += nw * 8) {
+        const int ra = r0 + q, rb = r0 + 4 + q;
+        const float* const wa = W + (long)(ra < rows ? ra : rows - 1) * len;
+        const float* const wb = W + (long)(rb < rows ? rb : rows - 1) * len;
+        float sa = 0.f, sb = 0.f;
+        for (int k = l; k < len; k += 16) {
+            const float x = v[k];
+            sa = fmaf(wa[k], x, sa);
+            sb = fmaf(wb[k], x, sb);
+        }
+#pragma unroll
+        for (int m = 8; m; m >>= 1) {
+            sa += __shfl_xor(sa, m, 16);
+            sb += __shfl_xor(sb, m, 16);
+        }
+        if (l == 0) {
+            if (ra < rows) emit(ra, sa);
+            if (rb < rows) emit(rb, sb);
+        }
+    }
+}
+
+// Per image and channel: the sum over the image's pixels of x (MUL false: squeeze-excite pooling) or of dy * x (MUL true: its backward),
+// divided by `div`.  Grid (ceil(channel groups / 8), n), 1024 threads = 8 channel groups (16 bytes each: a wave load covers 128-byte runs of
+// 8 pixels) x 128 pixel rows, two load chains per thread, rows added up in LDS in a fixed order.  Round 6: replaces one 256-thread workgroup
+// per image (64 workgroups on 256 CUs, ~90 dependent iterations) and a 256-thread tree per 8 channels of an image.
+template <typename T, typename V, int VN, bool MUL>
+__global__ __launch_bounds__(1024) void image_channel_sums_kernel(const T* __restrict__ x, const long ldx, const T* __restrict__ dy, const long lddy,
+                                                                   const int c, const int hw, const float div, float* __restrict__ out,
+                                                                   const long ldo) {
+    __shared__ float red[1024 * VN];
+    const int cgs = c / VN;
+    const int cgl = threadIdx.x & 7, prow = threadIdx.x >> 3;
+    const int g = blockIdx.x * 8 + cgl, n = blockIdx.y;
+    float a0[VN], a1[VN];
+#pragma unroll
+    for (int e = 0; e < VN; ++e) a0[e] = a1[e] = 0.f;
+    if (g < cgs) {
+        const T* const xp = x + (long)n * hw * ldx + g * VN;
+        const T* const gp = MUL ? dy + (long)n * hw * lddy + g * VN : nullptr;
+        int p = prow;
+        for (; p + 128 < hw; p += 256) {
+            const V x0 = *reinterpret_cast<const V*>(xp + (long)p * ldx), x1 = *reinterpret_cast<const V*>(xp + (long)(p + 128) * ldx);
+            if constexpr (MUL) {
+                const V g0 = *reinterpret_cast<const V*>(gp + (long)p * lddy), g1 = *reinterpret_cast<const V*>(gp + (long)(p + 128) * lddy);
+#pragma unroll
+                for (int e = 0; e < VN; ++e) {
+                    a0[e] = fmaf((float)x0[e], (float)g0[e], a0[e]);
+                    a1[e] = fmaf((float)x1[e], (float)g1[e], a1[e]);
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < VN; ++e) {
+                    a0[e] += (float)x0[e];
+                    a1[e] += (float)x1[e];
+                }
+            }
+        }
+        if (p < hw) {
+            const V x0 = *reinterpret_cast<const V*>(xp + (long)p * ldx);
+            if constexpr (MUL) {
+                const V g0 = *reinterpret_cast<const V*>(gp + (long)p * lddy);
+#pragma unroll
+                for (int e = 0; e < VN; ++e) a0[e] = fmaf((float)x0[e], (float)g0[e], a0[e]);
+            } else {
+#pragma unroll
+                for (int e = 0; e < VN; ++e) a0[e] += (float)x0[e];
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < VN; ++e) red[e * 1024 + threadIdx.x] = a0[e] + a1[e];       // [e][pixel row][channel group]
+    __syncthreads();
+    const int o = threadIdx.x >> 4, part = threadIdx.x & 15;      // output (e, channel group) x 16 parts of 8 pixel rows
+    if (o < 8 * VN) {      // (whole 16-lane groups: the shuffle below stays inside them)
+        const int ocg = o & 7, oe = o >> 3;
+        float v = 0.f;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v += red[oe * 1024 + (part * 8 + r) * 8 + ocg];
+#pragma unroll
+        for (int m = 8; m; m >>= 1) v += __shfl_xor(v, m, 16);
+        const int og = blockIdx.x * 8 + ocg;
+        if (part == 0 && og < cgs) out[(long)n * ldo + og * VN + oe] = v / div;
+    }
+}
+
 template <typename T> __device__ __forceinline__ float to_f32(T v) { return (float)v; }
 
 inline int check_launch() {

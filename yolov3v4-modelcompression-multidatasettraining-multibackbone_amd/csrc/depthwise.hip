@@ -155,59 +155,24 @@ __global__ __launch_bounds__(256) void dwconv_walk_kernel(const yh_dw_desc d, co
 }
 
 // ---- squeeze-excite ---------------------------------------------------------------------------------
-// grid (c_phys / VN, n): per-channel mean over the H*W pixels of one image
-template <typename T>
-__global__ __launch_bounds__(256) void se_pool_kernel(const yh_se_desc d) {
-    typedef typename V16<T>::type V;
-    constexpr int VN = V16<T>::N;
-    __shared__ float red[256 * VN];
-    const int g = blockIdx.x, n = blockIdx.y;
-    const long hw = (long)d.h * d.w_in;
-    const T* x = reinterpret_cast<const T*>(d.x) + (long)n * hw * d.ldx + g * VN;
-    float acc[VN];
-#pragma unroll
-    for (int e = 0; e < VN; ++e) acc[e] = 0.f;
-    for (long p = threadIdx.x; p < hw; p += blockDim.x) {
-        const V v = *reinterpret_cast<const V*>(x + p * d.ldx);
-#pragma unroll
-        for (int e = 0; e < VN; ++e) acc[e] += (float)v[e];
-    }
-#pragma unroll
-    for (int e = 0; e < VN; ++e) red[e * 256 + threadIdx.x] = acc[e];
-    __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
-        if ((int)threadIdx.x < s) {
-#pragma unroll
-            for (int e = 0; e < VN; ++e) red[e * 256 + threadIdx.x] += red[e * 256 + threadIdx.x + s];
-        }
-        __syncthreads();
-    }
-    if (threadIdx.x < VN) d.pooled[(long)n * d.c_phys + g * VN + threadIdx.x] = red[threadIdx.x * 256] / (float)hw;
-}
+// per-channel mean over the H*W pixels of one image: common.h image_channel_sums_kernel
 
-// grid n: hidden = relu(W1 pooled), gate = hsigmoid(W2 hidden); pad channels get gate 0
-__global__ __launch_bounds__(256) void se_fc_kernel(const yh_se_desc d) {
+// grid n: hidden = relu(W1 pooled), gate = hsigmoid(W2 hidden); pad channels get gate 0.  LDS: hidden[cr] | pooled in logical order [c].
+// Round 6: both products through common.h rows_dot16 with sixteen waves (thread-per-output read its row at one cache line per lane and
+// load: ~0.2 ms per 960-channel layer, texture-addresser bound; one output per wave was slower still, see rows_dot16).
+__global__ __launch_bounds__(1024) void se_fc_kernel(const yh_se_desc d) {
     extern __shared__ float hidden[];
+    float* const pl = hidden + d.cr;
     const int n = blockIdx.x;
     const float* pooled = d.pooled + (long)n * d.c_phys;
     float* gate = d.gate + (long)n * d.c_phys;
     for (int c = threadIdx.x; c < d.c_phys; c += blockDim.x) gate[c] = 0.f;
-    // (round 6: one output per WAVE with lanes striding over the row - coalesced loads, a wave reduction - measured 2.7 x SLOWER, se 1.12 ->
-    // 3.02 ms on YOLOv3-Mobilenetv3: a wave then walks its outputs one after the other, a memory latency each, where 256 threads keep
-    // 256 independent chains in flight on weights that sit in L2 anyway)
-    for (int j = threadIdx.x; j < d.cr; j += blockDim.x) {
-        const float* wr = d.w1 + (long)j * d.c;
-        float s = 0.f;
-        for (int i = 0; i < d.c; ++i) s = fmaf(wr[i], pooled[d.ch_map ? d.ch_map[i] : i], s);
-        hidden[j] = fmaxf(s, 0.f);
-    }
+    for (int c = threadIdx.x; c < d.c; c += blockDim.x) pl[c] = pooled[d.ch_map ? d.ch_map[c] : c];
     __syncthreads();
-    for (int co = threadIdx.x; co < d.c; co += blockDim.x) {
-        const float* wr = d.w2 + (long)co * d.cr;
-        float s = 0.f;
-        for (int j = 0; j < d.cr; ++j) s = fmaf(wr[j], hidden[j], s);
-        gate[d.ch_map ? d.ch_map[co] : co] = fminf(fmaxf(s + 3.f, 0.f), 6.f) / 6.f;
-    }
+    rows_dot16(d.w1, d.cr, d.c, pl, [&](int j, float s) { hidden[j] = fmaxf(s, 0.f); });
+    __syncthreads();
+    rows_dot16(d.w2, d.c, d.cr, hidden,
+               [&](int co, float s) { gate[d.ch_map ? d.ch_map[co] : co] = fminf(fmaxf(s + 3.f, 0.f), 6.f) / 6.f; });
 }
 
 template <typename T>
@@ -314,10 +279,15 @@ extern "C" int yh_se_fwd(const yh_se_desc* d, void* stream) {
     const int v = d->dtype == YH_F16 ? 8 : 4;
     if (d->c_phys % 8 || d->ldx % v || d->ldy % v || !aligned16(d->x) || !aligned16(d->y)) return YH_EALIGN;
     hipStream_t s = (hipStream_t)stream;
-    const dim3 pg(d->c_phys / v, d->n);
-    if (d->dtype == YH_F16) hipLaunchKernelGGL(se_pool_kernel<f16>, pg, dim3(256), 0, s, *d);
-    else hipLaunchKernelGGL(se_pool_kernel<float>, pg, dim3(256), 0, s, *d);
-    hipLaunchKernelGGL(se_fc_kernel, dim3(d->n), dim3(256), (size_t)d->cr * sizeof(float), s, *d);
+    const dim3 pg((d->c_phys / v + 7) / 8, d->n);
+    const int hw = d->h * d->w_in;
+    if (d->dtype == YH_F16)
+        hipLaunchKernelGGL((image_channel_sums_kernel<f16, f16x8, 8, false>), pg, dim3(1024), 0, s, (const f16*)d->x, (long)d->ldx, nullptr, 0L,
+                           d->c_phys, hw, (float)hw, d->pooled, (long)d->c_phys);
+    else
+        hipLaunchKernelGGL((image_channel_sums_kernel<float, f32x4, 4, false>), pg, dim3(1024), 0, s, (const float*)d->x, (long)d->ldx, nullptr,
+                           0L, d->c_phys, hw, (float)hw, d->pooled, (long)d->c_phys);
+    hipLaunchKernelGGL(se_fc_kernel, dim3(d->n), dim3(1024), (size_t)(d->cr + d->c) * sizeof(float), s, *d);
     const long total = (long)d->n * d->h * d->w_in * (d->c_phys / v);
     if (d->dtype == YH_F16) hipLaunchKernelGGL(se_scale_kernel<f16>, dim3(grid_cap(total)), dim3(256), 0, s, *d);
     else hipLaunchKernelGGL(se_scale_kernel<float>, dim3(grid_cap(total)), dim3(256), 0, s, *d);

@@ -542,20 +542,33 @@ __global__ __launch_bounds__(256) void dw_wgrad_taps_kernel(const yh_dw_bwd_desc
     }
 }
 
-// dw[ch][tap] += sum over the pixel chunks' rows, in row order (deterministic): one thread per (tap, channel), eight load chains
-__global__ __launch_bounds__(256) void dw_partials_kernel(const float* ws, int rows, int taps, int c, float* dw) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;      // i = tap * c + ch: consecutive threads on consecutive channels
-    if (i >= taps * c) return;
-    const long pitch = (long)taps * c;
-    float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    int r = 0;
-    for (; r + 7 < rows; r += 8) {
+// dw[ch][tap] += sum over the pixel chunks' rows in a fixed order (deterministic).  256 threads = 16 columns (i = tap * c + channel: a wave
+// load covers four 64-byte runs) x 16 row segments, four load chains per thread, segments added up in LDS (round 6, second form: one thread
+// per column with all ~512 rows behind it left ~24 workgroups walking 64 dependent iterations - as long as the taps kernel itself)
+__global__ __launch_bounds__(256) void dw_partials_kernel(const float* __restrict__ ws, int rows, int taps, int c, float* dw) {
+    __shared__ float red[256];
+    const int col = threadIdx.x & 15, seg = threadIdx.x >> 4;
+    const int i = blockIdx.x * 16 + col, total = taps * c;
+    const long pitch = total;
+    const int per = (rows + 15) / 16, r0 = seg * per, r1 = min(rows, r0 + per);
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    if (i < total) {
+        int r = r0;
+        for (; r + 3 < r1; r += 4) {
 #pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] += ws[(r + u) * pitch + i];
+            for (int u = 0; u < 4; ++u) v[u] += ws[(r + u) * pitch + i];
+        }
+        for (int u = 0; r < r1; ++r, ++u) v[u] += ws[r * pitch + i];
     }
-    for (int u = 0; r < rows; ++r, ++u) v[u] += ws[r * pitch + i];
-    const int tap = i / c, ch = i - tap * c;
-    dw[(long)ch * taps + tap] += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+    red[seg * 16 + col] = (v[0] + v[1]) + (v[2] + v[3]);
+    __syncthreads();
+    if (seg == 0 && i < total) {
+        float t = 0.f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) t += red[q * 16 + col];
+        const int tap = i / c, ch = i - tap * c;
+        dw[(long)ch * taps + tap] += t;
+    }
 }
 
 template <typename T>
@@ -688,67 +701,35 @@ __global__ __launch_bounds__(256) void dw_dgrad_walk_kernel(const yh_dw_bwd_desc
 }
 
 // ------------------------------------------------------------------------------------------ squeeze-excite backward
-// A: scratch[n][c] = sum over the image's pixels of dy * x   (grid: channel groups x images)
-template <typename T>
-__global__ __launch_bounds__(256) void se_bwd_reduce_kernel(const yh_se_bwd_desc d) {
-    typedef typename TV<T>::type V;
-    constexpr int VN = TV<T>::N;
-    __shared__ float red[256 * VN];
-    const int cgs = d.c / VN;
-    const int cgb = cgs < 256 ? cgs : 256, rows = 256 / cgb;
-    const int cgl = threadIdx.x % cgb, prow = threadIdx.x / cgb;
-    const int g = blockIdx.x * cgb + cgl, n = blockIdx.y;
-    const bool ok = prow < rows && g < cgs;
-    const int hw = d.h * d.w_in;
-    float acc[VN];
-#pragma unroll
-    for (int e = 0; e < VN; ++e) acc[e] = 0.f;
-    if (ok) {
-        const T* x = reinterpret_cast<const T*>(d.x) + (long)n * hw * d.ldx + g * VN;
-        const T* dy = reinterpret_cast<const T*>(d.dy) + (long)n * hw * d.lddy + g * VN;
-        for (int p = prow; p < hw; p += rows) {
-            const V xv = *reinterpret_cast<const V*>(x + (long)p * d.ldx);
-            const V gv = *reinterpret_cast<const V*>(dy + (long)p * d.lddy);
-#pragma unroll
-            for (int e = 0; e < VN; ++e) acc[e] = fmaf((float)xv[e], (float)gv[e], acc[e]);
-        }
-    }
-#pragma unroll
-    for (int e = 0; e < VN; ++e) red[e * 256 + threadIdx.x] = ok ? acc[e] : 0.f;
-    __syncthreads();
-    if (ok)
-        for (int it = prow; it < VN; it += rows) {
-            float v = 0.f;
-            for (int r = 0; r < rows; ++r) v += red[it * 256 + r * cgb + cgl];
-            d.scratch[(long)n * d.c + g * VN + it] = v;
-        }
-}
+// A: scratch[n][c] = sum over the image's pixels of dy * x: common.h image_channel_sums_kernel
 
 // B: the two Linear layers backward for one image; scratch[n] turns from d(gate) into d(pooled).
 // Round 6: the weight gradients are no longer 2 x c x cr fp32 atomics per image (YOLOv3-Mobilenetv3, c 672: 7.2 M contended atomics per
 // layer): with scratch2 each image leaves its factors dA2 | relu(a1) | dA1 and se_bwd_wgrad_kernel sums the outer products over the images in
 // order.  (One output per WAVE for the two products whose rows are strided across threads was measured slower, see depthwise.hip se_fc_kernel.)
 
-__global__ __launch_bounds__(256) void se_bwd_fc_kernel(const yh_se_bwd_desc d) {
-    extern __shared__ float sh[];            // a1[cr] | dA1[cr] | dA2[c]
+__global__ __launch_bounds__(1024) void se_bwd_fc_kernel(const yh_se_bwd_desc d) {
+    extern __shared__ float sh[];            // a1[cr] | dA1[cr] | dA2[c] | pooled[c] | relu(a1)[cr]
     float* a1 = sh;
     float* dA1 = sh + d.cr;
     float* dA2 = sh + 2 * d.cr;
+    float* pl = dA2 + d.c;
+    float* h1 = pl + d.c;
     const int n = blockIdx.x;
     const float* pooled = d.pooled + (long)n * d.c;
     float* sc = d.scratch + (long)n * d.c;
-    for (int j = threadIdx.x; j < d.cr; j += blockDim.x) {
-        float v = 0.f;
-        for (int c = 0; c < d.c; ++c) v = fmaf(d.w1[(long)j * d.c + c], pooled[c], v);
-        a1[j] = v;                           // pre-ReLU
-    }
+    // the forward again, the two row-contiguous products through rows_dot16 (as depthwise.hip se_fc_kernel)
+    for (int c = threadIdx.x; c < d.c; c += blockDim.x) pl[c] = pooled[c];
     __syncthreads();
-    for (int c = threadIdx.x; c < d.c; c += blockDim.x) {
-        float a2 = 0.f;
-        for (int j = 0; j < d.cr; ++j) a2 = fmaf(d.w2[(long)c * d.cr + j], fmaxf(a1[j], 0.f), a2);
+    rows_dot16(d.w1, d.cr, d.c, pl, [&](int j, float v) {
+        a1[j] = v;                           // pre-ReLU
+        h1[j] = fmaxf(v, 0.f);
+    });
+    __syncthreads();
+    rows_dot16(d.w2, d.c, d.cr, h1, [&](int c, float a2) {
         const float dsig = (a2 > -3.f && a2 < 3.f) ? (1.f / 6.f) : 0.f;   // hsigmoid(x) = relu6(x + 3) / 6
         dA2[c] = sc[c] * dsig;
-    }
+    });
     __syncthreads();
     for (int j = threadIdx.x; j < d.cr; j += blockDim.x) {
         float v = 0.f;
@@ -796,29 +777,37 @@ __global__ __launch_bounds__(256) void se_bwd_wgrad_kernel(const yh_se_bwd_desc 
     d.dw1[i] += s1;
 }
 
-// C: dx (+)= dy * gate + d(pooled) / HW
+// C: dx (+)= dy * gate + d(pooled) / HW.  Grid (channel-group blocks, pixel chunks, n): a thread keeps one channel group of one image - its
+// gate and d(pooled) values in registers - and walks the chunk's pixels (round 6; before: two 64-bit divisions and 16 scalar loads per element)
 template <typename T>
-__global__ __launch_bounds__(256) void se_bwd_apply_kernel(const yh_se_bwd_desc d) {
+__global__ __launch_bounds__(256) void se_bwd_apply_kernel(const yh_se_bwd_desc d, const int cgb, const int rows, const int ppb) {
     typedef typename TV<T>::type V;
     constexpr int VN = TV<T>::N;
-    const int cg = d.c / VN, hw = d.h * d.w_in;
-    const long total = (long)d.n * hw * cg;
+    const int cgs = d.c / VN, hw = d.h * d.w_in;
+    const int cgl = threadIdx.x % cgb, prow = threadIdx.x / cgb;
+    const int g = blockIdx.x * cgb + cgl, n = blockIdx.z;
+    const int p0 = blockIdx.y * ppb, p1 = min(p0 + ppb, hw);
+    if (prow >= rows || g >= cgs) return;
     const float inv = 1.f / (float)hw;
-    const T* dy = reinterpret_cast<const T*>(d.dy);
-    T* dx = reinterpret_cast<T*>(d.dx);
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int g = (int)(i % cg);
-        const long pix = i / cg;
-        const long n = pix / hw;
-        const V gv = *reinterpret_cast<const V*>(dy + pix * d.lddy + g * VN);
-        T* dst = dx + pix * d.lddx + g * VN;
-        V o;
+    float gt[VN], ad[VN];
 #pragma unroll
-        for (int e = 0; e < VN; ++e) {
-            const int c = g * VN + e;
-            float v = (float)gv[e] * d.gate[n * d.c + c] + d.scratch[n * d.c + c] * inv;
-            if (d.accumulate) v += (float)dst[e];
-            o[e] = (T)v;
+    for (int e = 0; e < VN; ++e) {
+        gt[e] = d.gate[(long)n * d.c + g * VN + e];
+        ad[e] = d.scratch[(long)n * d.c + g * VN + e] * inv;
+    }
+    const T* const dy = reinterpret_cast<const T*>(d.dy) + (long)n * hw * d.lddy + g * VN;
+    T* const dx = reinterpret_cast<T*>(d.dx) + (long)n * hw * d.lddx + g * VN;
+    for (int p = p0 + prow; p < p1; p += rows) {
+        const V gv = *reinterpret_cast<const V*>(dy + (long)p * d.lddy);
+        T* const dst = dx + (long)p * d.lddx;
+        V o;
+        if (d.accumulate) {
+            const V old = *reinterpret_cast<const V*>(dst);
+#pragma unroll
+            for (int e = 0; e < VN; ++e) o[e] = (T)(fmaf((float)gv[e], gt[e], ad[e]) + (float)old[e]);
+        } else {
+#pragma unroll
+            for (int e = 0; e < VN; ++e) o[e] = (T)fmaf((float)gv[e], gt[e], ad[e]);
         }
         *reinterpret_cast<V*>(dst) = o;
     }
@@ -888,7 +877,7 @@ extern "C" int yh_dw_wgrad(const yh_dw_bwd_desc* d0, void* stream) {
 #undef YH_DWW
     if (d->ws) {
         const int total = d->k * d->k * d->c;
-        hipLaunchKernelGGL(dw_partials_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, d->ws, (int)grid.y, d->k * d->k,
+        hipLaunchKernelGGL(dw_partials_kernel, dim3((total + 15) / 16), dim3(256), 0, (hipStream_t)stream, d->ws, (int)grid.y, d->k * d->k,
                            d->c, d->dw);
     }
     return check_launch();
@@ -934,19 +923,26 @@ extern "C" int yh_se_bwd(const yh_se_bwd_desc* d, void* stream) {
     const int v = d->dtype == YH_F16 ? 8 : 4;
     if (d->c % v || d->ldx % v || d->lddy % v || d->lddx % v || !aligned16(d->x) || !aligned16(d->dy) || !aligned16(d->dx)) return YH_EALIGN;
     hipStream_t s = (hipStream_t)stream;
-    const int cgs = d->c / v, cgb = cgs < 256 ? cgs : 256;
-    const dim3 rgrid((cgs + cgb - 1) / cgb, d->n);
-    if (d->dtype == YH_F16) hipLaunchKernelGGL(se_bwd_reduce_kernel<f16>, rgrid, dim3(256), 0, s, *d);
-    else hipLaunchKernelGGL(se_bwd_reduce_kernel<float>, rgrid, dim3(256), 0, s, *d);
+    const int cgs = d->c / v, cgb = cgs < 256 ? cgs : 256, hw = d->h * d->w_in;
+    if (d->n > 65535) return YH_EINVAL;
+    const dim3 rgrid((cgs + 7) / 8, d->n);
+    if (d->dtype == YH_F16)
+        hipLaunchKernelGGL((image_channel_sums_kernel<f16, f16x8, 8, true>), rgrid, dim3(1024), 0, s, (const f16*)d->x, (long)d->ldx,
+                           (const f16*)d->dy, (long)d->lddy, d->c, hw, 1.f, d->scratch, (long)d->c);
+    else
+        hipLaunchKernelGGL((image_channel_sums_kernel<float, f32x4, 4, true>), rgrid, dim3(1024), 0, s, (const float*)d->x, (long)d->ldx,
+                           (const float*)d->dy, (long)d->lddy, d->c, hw, 1.f, d->scratch, (long)d->c);
     yh_se_bwd_desc dd = *d;
     if (dd.scratch2 && dd.scratch2_floats < (int64_t)dd.n * (dd.c + 2 * dd.cr)) dd.scratch2 = nullptr;
-    hipLaunchKernelGGL(se_bwd_fc_kernel, dim3(d->n), dim3(256), (size_t)(2 * d->cr + d->c) * sizeof(float), s, dd);
+    hipLaunchKernelGGL(se_bwd_fc_kernel, dim3(d->n), dim3(1024), (size_t)(3 * d->cr + 2 * d->c) * sizeof(float), s, dd);
     if (dd.scratch2) hipLaunchKernelGGL(se_bwd_wgrad_kernel, dim3((d->c * d->cr + 255) / 256), dim3(256), 0, s, dd);
-    const long total = (long)d->n * d->h * d->w_in * cgs;
-    long gsz = (total + 255) / 256;
-    const dim3 agrid((unsigned)(gsz < 1 ? 1 : (gsz > 16384 ? 16384 : gsz)));
-    if (d->dtype == YH_F16) hipLaunchKernelGGL(se_bwd_apply_kernel<f16>, agrid, dim3(256), 0, s, *d);
-    else hipLaunchKernelGGL(se_bwd_apply_kernel<float>, agrid, dim3(256), 0, s, *d);
+    const int rows = 256 / cgb, gx = (cgs + cgb - 1) / cgb;
+    long ppb = ((long)hw * gx * d->n + 8191) / 8192;      // ~8192 workgroups, at least four pixels per thread
+    if (ppb < 4L * rows) ppb = 4L * rows;
+    ppb = (ppb + rows - 1) / rows * rows;
+    const dim3 agrid(gx, (unsigned)((hw + ppb - 1) / ppb), d->n);
+    if (d->dtype == YH_F16) hipLaunchKernelGGL(se_bwd_apply_kernel<f16>, agrid, dim3(256), 0, s, *d, cgb, rows, (int)ppb);
+    else hipLaunchKernelGGL(se_bwd_apply_kernel<float>, agrid, dim3(256), 0, s, *d, cgb, rows, (int)ppb);
     return check_launch();
 }
 
