@@ -95,6 +95,32 @@ __device__ __forceinline__ float act_grad(float u, int act, float slope) {
         default: return 1.f;
     }
 }
+// d mish / du on the hardware exp2 and ONE reciprocal (round 6; the fp16 training kernels).  With e = e^u, n = e (e + 2), t = tanh(softplus(u)) =
+// n / (n + 2): 1 - t^2 = 4 (n + 1) / (n + 2)^2 and n + 1 = (e + 1)^2, so t + u sigmoid(u) (1 - t^2) = [n (n + 2) + 4 u e (e + 1)] / (n + 2)^2.
+// ~16 VALU slots against the ~45 of act_grad's ocml expf + two reciprocals (YOLOv4's BatchNorm backward passes were VALU-bound on it, not
+// byte-bound); within ~1e-6 of it relative to the derivative's scale.  u is clamped to [-60, 20]: 1 above, u e^u (< 1e-24) below, no overflow
+// (n (n + 2) <= 5.5e34).  No contraction across the body, so that every kernel evaluates the same bits (see mish_fast).
+__device__ __forceinline__ float mish_grad_fast(float u) {
+#pragma clang fp contract(off)
+    const float c = __builtin_amdgcn_fmed3f(u, -60.f, 20.f);
+    const float e = __builtin_amdgcn_exp2f(c * 1.44269504088896340736f);
+    const float n = e * (e + 2.f);
+    const float d = n + 2.f;
+    const float r = __builtin_amdgcn_rcpf(d);
+    const float num = fmaf((4.f * c) * e, e + 1.f, n * d);
+    return (num * r) * r;
+}
+// the training kernels' choice by storage type: fp16 tensors take the fast forms (their results are rounded to 11 bits anyway), fp32 keeps
+// the exact ones - it is the side of the fp32 comparisons against the reference
+template <typename T> __device__ __forceinline__ float act_grad_t(float u, int act, float slope) {
+    if (sizeof(T) == 2 && act == YH_ACT_MISH) return mish_grad_fast(u);
+    return act_grad(u, act, slope);
+}
+template <typename T> __device__ __forceinline__ float activate_train_t(float v, int act, float slope) {
+    if (sizeof(T) == 2 && act == YH_ACT_MISH) return mish_fast(v);
+    return activate(v, act, slope);
+}
+
 // Mish to one rounding: v tanh(softplus(v)) = v n / (n + 2), n = e^v (e^v + 2), evaluated in double and rounded once to float - what
 // the reference's fp32 `x * torch.tanh(F.softplus(x))` (utils/layers.py:148; softplus passes x through above 20) approximates to ~3
 // ulp.  Round 5 tried it as the form that decides a value next to a rounding tie of the activation grid (0.6 - 1.4 %

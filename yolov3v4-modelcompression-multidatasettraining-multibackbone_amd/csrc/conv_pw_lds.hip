@@ -218,7 +218,7 @@ __global__ __launch_bounds__(512, 2) void conv1x1_lds_kernel(const ConvArgs a, c
                 for (int e = 0; e < 8; ++e) {
                     const float xh = ((float)zz[e] - pm[e]) * pi[e];
                     const float u = pg[e] * xh + pb[e];
-                    const float gg = (ok ? (float)h[e] : 0.f) * act_grad(u, ACT, a.bslope);
+                    const float gg = (ok ? (float)h[e] : 0.f) * act_grad_t<f16>(u, ACT, a.bslope);
                     s1[e] += gg;
                     s2[e] = fmaf(gg, xh, s2[e]);
                 }

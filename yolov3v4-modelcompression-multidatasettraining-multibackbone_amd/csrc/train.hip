@@ -179,7 +179,7 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const yh_bn_desc d, con
     auto finish = [&](const long p, const V& v, const V& r) {
         float o[VN];
 #pragma unroll
-        for (int e = 0; e < VN; ++e) o[e] = activate(ga[e] * (((float)v[e] - mu[e]) * is[e]) + be[e], ACT, d.slope);
+        for (int e = 0; e < VN; ++e) o[e] = activate_train_t<T>(ga[e] * (((float)v[e] - mu[e]) * is[e]) + be[e], ACT, d.slope);
         if (has_res) {
 #pragma unroll
             for (int e = 0; e < VN; ++e) o[e] += (float)r[e];
@@ -254,7 +254,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(const yh_bn_desc
             for (int e = 0; e < VN; ++e) {
                 const float xh = ((float)zv[e] - mu[e]) * is[e];
                 const float u = ga[e] * xh + be[e];
-                const float gg = (float)gv[e] * act_grad(u, ACT, d.slope);
+                const float gg = (float)gv[e] * act_grad_t<T>(u, ACT, d.slope);
                 acc[0][e] += gg;
                 acc[1][e] = fmaf(gg, xh, acc[1][e]);
             }
@@ -313,7 +313,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const yh_bn_desc 
         for (int e = 0; e < VN; ++e) {
             const float xh = ((float)zv[e] - mu[e]) * is[e];
             const float u = ga[e] * xh + be[e];
-            const float gg = (float)gv[e] * act_grad(u, ACT, d.slope);
+            const float gg = (float)gv[e] * act_grad_t<T>(u, ACT, d.slope);
             ov[e] = bn ? (T)(ga[e] * is[e] * (gg - m1[e] - xh * m2[e])) : (T)gg;
         }
         *reinterpret_cast<V*>(dz + p * d.ldo) = ov;
