@@ -484,8 +484,9 @@ def test_maxpool_backward_matches_autograd(libs, code, case):
         outs.append(dx.float().cpu())
     assert torch.equal(outs[0][..., :8], acc0[..., :8].float()), 'wrote outside the channel slice'
     scale = outs[1].abs().max().item()
-    # fp16: packed-half atomics round after every add, in arrival order (up to k*k adds meet in one element)
-    tol16 = 4e-3 if k <= 5 else 2e-2
+    # fp16: overlapping windows are gathered in fp32 and rounded once (round 6; the packed-half atomics of rounds 1 - 5 rounded after every one
+    # of up to k*k adds and needed 2e-2 at k 9 / 13); the non-overlapping k2 s2 case adds one value per element
+    tol16 = 2e-3
     assert (outs[0] - outs[1]).abs().max().item() <= (1e-5 if code == F32 else tol16) * scale
     xr = x[..., 8:].float().permute(0, 3, 1, 2).requires_grad_()
     y = F.max_pool2d(F.pad(xr, (0, 1, 0, 1)), k, s) if edge_zero else F.max_pool2d(xr, k, s, pad_lo)
@@ -1271,13 +1272,16 @@ def test_sgd_trajectory_against_the_reference_golden(libs, precision):
     print('sgd trajectory 608 b2 %s: largest relative |.|-sum error over %d final tensors (parameters + running statistics) %.2e' % (precision, len(gold['state_names']), worst))
 
 
-@pytest.mark.parametrize('precision', ['fp16', 'fp32'])
-def test_training_step_is_run_to_run_deterministic(libs, precision):
+@pytest.mark.parametrize('net,precision', [('yolov3/yolov3.cfg', 'fp16'), ('yolov3/yolov3.cfg', 'fp32'), ('yolov4/yolov4.cfg', 'fp16'),
+                                           ('yolov3-mobilenet/yolov3-mobilenet-coco.cfg', 'fp16')],
+                         ids=['yolov3-fp16', 'yolov3-fp32', 'yolov4-fp16', 'mobilenet-fp16'])
+def test_training_step_is_run_to_run_deterministic(libs, net, precision):
     """the reference's CPU training step is bit-reproducible; so is this one.  YOLOv3 at 320 x 320, batch 4: the same
     step (train-mode forward, fused compute_loss, backward) three times from the same state - `torch.equal` on every parameter gradient,
     on the raw heads and on the running statistics.  Every sum over workgroups on this path is taken in a fixed order (common.h
-    deterministic(): BatchNorm statistics and backward sums, weight-gradient pixel splits, the first block's backward); what is NOT
-    covered is listed in DESIGN.md section 8 (max-pool / depthwise / squeeze-excite backward scatter, three or more labels in one cell)."""
+    deterministic(): BatchNorm statistics and backward sums, weight-gradient pixel splits, the first block's backward).  Later in round 6
+    also YOLOv4 (SPP max-pool backward as a gather instead of fp16 atomics) and YOLOv3-Mobilenetv3 (depthwise and squeeze-excite weight
+    gradients as ordered partial rows).  Not covered: three or more labels in one (cell, anchor), the loss items' sums."""
     if DRY:
         pytest.skip('the host emulation is sequential: nothing to show')
     import copy
@@ -1286,7 +1290,7 @@ def test_training_step_is_run_to_run_deterministic(libs, precision):
     import test_train_emulated as tte
     size, batch = 320, 4
     torch.manual_seed(0)
-    model0 = Darknet(os.path.join(conftest.PKG, 'cfg', 'yolov3', 'yolov3.cfg'), (size, size))
+    model0 = Darknet(os.path.join(conftest.PKG, 'cfg', *net.split('/')), (size, size))
     state = model0.state_dict()
     synth.randomize_bn_(state, seed=1)
     model0.load_state_dict(state)
@@ -1316,8 +1320,8 @@ def test_training_step_is_run_to_run_deterministic(libs, precision):
         assert not diff, 'run %d: %d of %d parameter gradients differ from run 0, e.g. %s' % (run, len(diff), len(first[0]), diff[:3])
         assert all(torch.equal(a, b) for a, b in zip(first[1], again[1])), 'raw heads differ'
         assert all(torch.equal(first[2][k], again[2][k]) for k in first[2]), 'running statistics differ'
-    print('yolov3 320 b4 %s: three runs of the training step, %d parameter gradients + 3 raw heads + %d running statistics bit-identical'
-          % (precision, len(first[0]), len(first[2])))
+    print('%s 320 b4 %s: three runs of the training step, %d parameter gradients + 3 raw heads + %d running statistics bit-identical'
+          % (net.split('/')[0], precision, len(first[0]), len(first[2])))
 
 
 def test_step_with_backward_sums_in_the_data_gradient_equals_the_plain_step(libs, monkeypatch):

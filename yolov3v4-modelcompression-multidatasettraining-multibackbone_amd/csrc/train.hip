@@ -458,6 +458,106 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const yh_pool_bwd_desc
     }
 }
 
+// Round 6: overlapping windows (SPP: 5 / 9 / 13 at stride 1; the tiny nets' 2 at stride 1) on planes that fit in LDS, WITHOUT atomics.
+// One workgroup = one image x one channel group.  The window maximum is found separably - per row the first maximum of the k columns, then
+// over the k rows the first row that holds the maximum: the same "first maximum in row-major order" as the scan above, in 2 k instead of k^2
+// steps - and every input pixel then GATHERS the dy of the windows that chose it, in window order, in fp32, rounded once.  The scatter form
+// met in packed-fp16 atomics (a rounding per contribution, order-dependent: the one non-reproducible kernel of YOLOv4's step) and spent
+// 1.0 ms per YOLOv4-608 step on three 19 x 19 planes.
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_bwd_plane_kernel(const yh_pool_bwd_desc d) {
+    typedef typename TV<T>::type V;
+    constexpr int VN = TV<T>::N;
+    typedef short SV __attribute__((ext_vector_type(VN)));
+    extern __shared__ __attribute__((aligned(16))) char pool_sm[];
+    const int hw = d.h * d.w_in, hwo = d.h * d.wo, howo = d.ho * d.wo;
+    V* const xs = reinterpret_cast<V*>(pool_sm);               // [h][w]
+    V* const rmax = xs + hw;                                    // [h][wo]   first maximum of the row's k columns
+    V* const dys = rmax + hwo;                                  // [ho][wo]
+    SV* const rarg = reinterpret_cast<SV*>(dys + howo);         // [h][wo]   its column (-1: the implicit zero padding, -2: nothing)
+    SV* const arg = rarg + hwo;                                 // [ho][wo]  the window's pixel h * w + w (-1: none)
+    const int cg = d.c / VN;
+    const int g = blockIdx.x % cg, n = blockIdx.x / cg;
+    const T* const x = reinterpret_cast<const T*>(d.x) + (long)n * hw * d.ldx + g * VN;
+    const T* const dy = reinterpret_cast<const T*>(d.dy) + (long)n * howo * d.lddy + g * VN;
+    T* const dx = reinterpret_cast<T*>(d.dx) + (long)n * hw * d.lddx + g * VN;
+    for (int p = threadIdx.x; p < hw; p += blockDim.x) xs[p] = *reinterpret_cast<const V*>(x + (long)p * d.ldx);
+    for (int p = threadIdx.x; p < howo; p += blockDim.x) dys[p] = *reinterpret_cast<const V*>(dy + (long)p * d.lddy);
+    __syncthreads();
+    for (int i = threadIdx.x; i < hwo; i += blockDim.x) {
+        const int hi = i / d.wo, wo = i - hi * d.wo;
+        float m[VN];
+        SV a;
+#pragma unroll
+        for (int e = 0; e < VN; ++e) { m[e] = -INFINITY; a[e] = -2; }
+        for (int kx = 0; kx < d.k; ++kx) {
+            const int wi = wo * d.stride - d.pad_lo + kx;
+            if ((unsigned)wi < (unsigned)d.w_in) {
+                const V v = xs[hi * d.w_in + wi];
+#pragma unroll
+                for (int e = 0; e < VN; ++e)
+                    if ((float)v[e] > m[e]) { m[e] = (float)v[e]; a[e] = (short)wi; }
+            } else if (d.edge_zero && wi >= 0) {
+#pragma unroll
+                for (int e = 0; e < VN; ++e)
+                    if (0.f > m[e]) { m[e] = 0.f; a[e] = -1; }
+            }
+        }
+        V mv;
+#pragma unroll
+        for (int e = 0; e < VN; ++e) mv[e] = (T)m[e];      // exact: a value of the tensor, 0 or -inf
+        rmax[i] = mv;
+        rarg[i] = a;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < howo; i += blockDim.x) {
+        const int ho = i / d.wo, wo = i - ho * d.wo;
+        float m[VN];
+        SV a;
+#pragma unroll
+        for (int e = 0; e < VN; ++e) { m[e] = -INFINITY; a[e] = -1; }
+        for (int ky = 0; ky < d.k; ++ky) {
+            const int hi = ho * d.stride - d.pad_lo + ky;
+            if ((unsigned)hi < (unsigned)d.h) {
+                const V v = rmax[hi * d.wo + wo];
+                const SV c = rarg[hi * d.wo + wo];
+#pragma unroll
+                for (int e = 0; e < VN; ++e)
+                    if ((float)v[e] > m[e]) { m[e] = (float)v[e]; a[e] = c[e] < 0 ? (short)-1 : (short)(hi * d.w_in + c[e]); }
+            } else if (d.edge_zero && hi >= 0) {      // a row of the implicit zero padding (its columns wi >= 0: every window has one)
+#pragma unroll
+                for (int e = 0; e < VN; ++e)
+                    if (0.f > m[e]) { m[e] = 0.f; a[e] = -1; }
+            }
+        }
+        arg[i] = a;
+    }
+    __syncthreads();
+    for (int p = threadIdx.x; p < hw; p += blockDim.x) {
+        const int hi = p / d.w_in, wi = p - hi * d.w_in;
+        // windows that contain the pixel: ho * stride - pad_lo <= hi <= ho * stride - pad_lo + k - 1
+        const int th = hi + d.pad_lo, tw = wi + d.pad_lo;
+        const int ho0 = max(0, (th - d.k + d.stride) / d.stride), ho1 = min(d.ho - 1, th / d.stride);
+        const int wo0 = max(0, (tw - d.k + d.stride) / d.stride), wo1 = min(d.wo - 1, tw / d.stride);
+        float acc[VN];
+#pragma unroll
+        for (int e = 0; e < VN; ++e) acc[e] = 0.f;
+        for (int ho = ho0; ho <= ho1; ++ho)
+            for (int wo = wo0; wo <= wo1; ++wo) {
+                const SV a = arg[ho * d.wo + wo];
+                const V gv = dys[ho * d.wo + wo];
+#pragma unroll
+                for (int e = 0; e < VN; ++e) acc[e] += a[e] == (short)p ? (float)gv[e] : 0.f;
+            }
+        T* const dst = dx + (long)p * d.lddx;
+        const V old = *reinterpret_cast<const V*>(dst);
+        V o;
+#pragma unroll
+        for (int e = 0; e < VN; ++e) o[e] = (T)((float)old[e] + acc[e]);
+        *reinterpret_cast<V*>(dst) = o;
+    }
+}
+
 // ------------------------------------------------------------------------------------------ depthwise backward
 // Up to 9 taps per pass (grid.z = tap groups): a thread owns one 16-byte channel vector and 9 x VN accumulators, so dz is
 // read once per group (once for 3x3, three times for 5x5) instead of once per tap, with full-width loads.
@@ -952,6 +1052,26 @@ extern "C" int yh_maxpool2d_bwd(const yh_pool_bwd_desc* d, void* stream) {
     const int v = d->dtype == YH_F16 ? 8 : 4;
     if (d->c % v || d->ldx % v || d->lddy % v || d->lddx % 2 || !aligned16(d->x) || !aligned16(d->dy) || (((uintptr_t)d->dx) & 3u)) return YH_EALIGN;
     const long total = (long)d->n * d->ho * d->wo * (d->c / v);
+    {   // overlapping windows on a plane that fits in LDS: the gather form (no atomics, deterministic)
+        const long hw = (long)d->h * d->w_in, hwo = (long)d->h * d->wo, howo = (long)d->ho * d->wo;
+        const size_t shmem = (size_t)(hw + hwo + howo) * 16 + (size_t)(hwo + howo) * v * 2;
+        static const bool scatter = getenv("YH_POOL_BWD_SCATTER") && atoi(getenv("YH_POOL_BWD_SCATTER")) != 0;      // A/B: the atomics
+        if (!scatter && d->stride < d->k && hw < 32768 && shmem <= 96 * 1024 && (long)d->n * (d->c / v) < (1L << 31) && d->lddx % v == 0 &&
+            aligned16(d->dx)) {
+            const dim3 pgrid((unsigned)((long)d->n * (d->c / v)));
+            hipError_t e;
+            if (d->dtype == YH_F16) {
+                e = ensure_dynamic_lds(reinterpret_cast<const void*>(maxpool_bwd_plane_kernel<f16>), shmem);
+                if (e != hipSuccess) return (int)e;
+                hipLaunchKernelGGL(maxpool_bwd_plane_kernel<f16>, pgrid, dim3(256), shmem, (hipStream_t)stream, *d);
+            } else {
+                e = ensure_dynamic_lds(reinterpret_cast<const void*>(maxpool_bwd_plane_kernel<float>), shmem);
+                if (e != hipSuccess) return (int)e;
+                hipLaunchKernelGGL(maxpool_bwd_plane_kernel<float>, pgrid, dim3(256), shmem, (hipStream_t)stream, *d);
+            }
+            return check_launch();
+        }
+    }
     long gsz = (total + 255) / 256;
     const dim3 grid((unsigned)(gsz < 1 ? 1 : (gsz > 16384 ? 16384 : gsz)));
     if (d->dtype == YH_F16) hipLaunchKernelGGL(maxpool_bwd_kernel<f16>, grid, dim3(256), 0, (hipStream_t)stream, *d);
