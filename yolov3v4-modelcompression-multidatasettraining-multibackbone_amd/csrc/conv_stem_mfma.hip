@@ -327,10 +327,21 @@ __global__ __launch_bounds__(256, 2) void conv_stem_mfma_kernel(const yh_stem_de
                     for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t][j], b[j], acc[t], 0, 0, 0);
             }
             float v[CPL];
+            if constexpr (sizeof(T) == 1 && ACT == YH_ACT_MISH) {      // four values per tie decision, one scaled value for test and rounding
 #pragma unroll
-            for (int t = 0; t < NT; ++t)
+                for (int t = 0; t < NT; ++t) {
+                    const float in4[4] = {acc[t][0], acc[t][1], acc[t][2], acc[t][3]};
+                    float q4[4];
+                    mish_quantize_n<4>(in4, inv_q, q4);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[t * 4 + r] = finish(acc[t][r]);
+                    for (int r = 0; r < 4; ++r) v[t * 4 + r] = q4[r];
+                }
+            } else {
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[t * 4 + r] = finish(acc[t][r]);
+            }
             outv[q] = PK::pack(v);
             if constexpr (STATS) {
                 const bool ok = whole || (lane_ch_ok && oy0 + wave * 4 + (q >> 1) < d.ho && ox0 + (q & 1) * 16 + px < d.wo);
