@@ -628,6 +628,9 @@ def main():
     ap.add_argument('--two-pass-nms', action='store_true', help='detect leg: model(x) then non_max_suppression(inf) (rounds 1 - 4) instead of model.hip_detect')
     ap.add_argument('--raw-heads', action='store_true', help='keep the random head weights (no NMS candidates at conf 0.3): forward-only timing')
     ap.add_argument('--nms-candidates', type=int, default=100, help='objectness candidates per image the synthetic heads are calibrated to')
+    ap.add_argument('--families', action='store_true',
+                    help='add the YOLOv3-Mobilenetv3-416 (BASELINE configs[4]) and YOLOv4-608 training steps as rider legs (off by default: the '
+                         'default line and its rocprofv3 companion stay those of the YOLOv3-608 legs)')
     ap.add_argument('--no-v4', action='store_true', help='skip the YOLOv4-640 fp16 / int8 rider legs of the default run')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=12.0)
@@ -724,6 +727,24 @@ def main():
                     vargs.cfg = os.path.join(PKG, 'cfg', 'yolov4', 'yolov4.cfg')
                     vargs.size, vargs.batch, vargs.precision = 640, min(args.batch, 32), prec
                     rider(name, vargs)
+    if args.mode == 'both' and args.precision == 'fp16' and world == 1 and args.families \
+            and os.path.basename(args.cfg) == 'yolov3.cfg' and out is not None:
+        # the other training configurations the reference is used for, on the same step (riders; the headline stays YOLOv3-608):
+        # BASELINE.json configs[4] - YOLOv3-Mobilenetv3 (depthwise + squeeze-excite backbone) at 416, batch 64 - and YOLOv4-608, batch 32
+        import copy
+        for rel, size, batch, name in (('yolov3-mobilenet/yolov3-mobilenet-coco.cfg', 416, 64, 'train_mobilenet_416'),
+                                       ('yolov4/yolov4.cfg', 608, 32, 'train_v4_608')):
+            targs = copy.copy(args)
+            targs.cfg, targs.size, targs.batch = os.path.join(PKG, 'cfg', *rel.split('/')), size, min(args.batch, batch)
+            targs.steps, targs.warmup, targs.no_cpu_baseline = min(args.steps, 10), min(args.warmup, 3), True
+            try:
+                t = train_main(targs, device, dist, world, rank, local_rank)
+                r = t.get('roofline') or {}
+                out[name] = {k: t[k] for k in ('metric', 'value', 'unit', 'ms_per_step', 'dtype', 'config') if k in t}
+                out[name]['roofline'] = {k: r[k] for k in ('gpu_ms_per_step', 'batchnorm_passes_ms', 'by_role_ms', 'top_classes') if k in r}
+            except Exception as e:   # noqa: BLE001 - a rider must not take the headline line down with it
+                out[name + '_error'] = '%s: %s' % (type(e).__name__, str(e)[:300])
+                torch.cuda.empty_cache()
     if rank == 0:
         print(json.dumps(out))
     if dist is not None:

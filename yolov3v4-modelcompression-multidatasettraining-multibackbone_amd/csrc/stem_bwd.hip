@@ -60,8 +60,8 @@ template <int C> struct SbRow { static constexpr int PROD = 2 * C * 32, SX = PRO
 // ACT: YH_ACT_LEAKY / YH_ACT_MISH fixed at compile time (the YOLOv3 / v4 first blocks); -1 = the run-time switch (other activations)
 template <int ACT> __device__ __forceinline__ float sb_dact(float u, int act, float slope) {
     if constexpr (ACT == YH_ACT_LEAKY) return u > 0.f ? 1.f : slope;
-    else if constexpr (ACT == YH_ACT_MISH) return sb_act_grad(u, YH_ACT_MISH, slope);
-    else return sb_act_grad(u, act, slope);
+    else if constexpr (ACT == YH_ACT_MISH) return mish_grad_fast(u);      // fp16 tensors: as train.hip act_grad_t<f16> (common.h)
+    else return act == YH_ACT_MISH ? mish_grad_fast(u) : sb_act_grad(u, act, slope);
 }
 
 template <int C, int CIN, int ACT>

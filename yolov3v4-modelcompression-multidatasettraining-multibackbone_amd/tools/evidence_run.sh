@@ -11,7 +11,7 @@ TAG=${1:-evidence}
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 if [ "$2" != "notests" ]; then
-( timeout 1800 python -m pytest tests -m gpu -q -s 2>&1 | grep -v "^Model Summary\|amdgpu.ids" | grep "passed\|failed\|FAILED\|Error\|int8 vs\|raw heads\|mAP\|608 b\|calm v\|sgd traj\|yolov3 320\|largest contrib\|drift\|pruned mobilenet\|calibration on\|cosine searches\|int8 engine vs" | grep -v "print(" | cut -c1-1200 | tail -120 ) > gpurun_out/${TAG}_tests.log 2>&1
+( timeout 1800 python -m pytest tests -m gpu -q -s 2>&1 | grep -v "^Model Summary\|amdgpu.ids" | grep "passed\|failed\|FAILED\|Error\|int8 vs\|raw heads\|mAP\|608 b\|calm v\|sgd traj\|three runs\|largest contrib\|drift\|pruned mobilenet\|calibration on\|cosine searches\|int8 engine vs" | grep -v "print(" | cut -c1-1200 | tail -120 ) > gpurun_out/${TAG}_tests.log 2>&1
 fi
 ( timeout 200 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | grep -v "^Model Summary\|amdgpu.ids" | tail -4 ) > gpurun_out/${TAG}_smoke.log 2>&1
 ( timeout 900 python bench.py 2>&1 | tail -1 ) > gpurun_out/${TAG}_bench_default.json 2>&1
@@ -48,4 +48,18 @@ timeout 300 python $T/profile_layers.py --batch 64 --size 608 --precision int8 >
 timeout 300 python $T/profile_layers.py --batch 32 --size 640 --precision int8 --cfg $PKG/cfg/yolov4/yolov4.cfg > gpurun_out/${TAG}_layers_v4_int8.txt 2>&1
 timeout 300 python $T/profile_layers.py --batch 32 --size 640 --cfg $PKG/cfg/yolov4/yolov4.cfg > gpurun_out/${TAG}_layers_v4_fp16.txt 2>&1
 timeout 600 python $T/pruned_finetune.py --bench > gpurun_out/${TAG}_pruned.txt 2>&1
+# the other training families: rider legs of the bench line (YOLOv3-Mobilenetv3-416 b64 = BASELINE configs[4], YOLOv4-608 b32) + their layer tables
+( timeout 900 python bench.py --families --no-v4 --no-cpu-baseline 2>&1 | tail -1 ) > gpurun_out/${TAG}_bench_families.json 2>&1
+timeout 300 python $T/profile_train.py --cfg $PKG/cfg/yolov3-mobilenet/yolov3-mobilenet-coco.cfg --size 416 --batch 64 > gpurun_out/${TAG}_train_layers_mobilenet.txt 2>&1
+timeout 300 python $T/profile_train.py --cfg $PKG/cfg/yolov4/yolov4.cfg --size 608 --batch 32 > gpurun_out/${TAG}_train_layers_v4.txt 2>&1
+python - <<PY
+import json
+try:
+    d = json.loads(open('gpurun_out/${TAG}_bench_families.json').read().strip().splitlines()[-1])
+    for k in ('train_mobilenet_416', 'train_v4_608'):
+        t = d.get(k) or {}
+        print(k, t.get('value'), 'images/s', t.get('ms_per_step'), 'ms/step', (t.get('roofline') or {}).get('gpu_ms_per_step'), 'ms of kernels', d.get(k + '_error', ''))
+except Exception as e:
+    print('families bench:', e)
+PY
 tail -14 gpurun_out/${TAG}_tests.log 2>/dev/null; cat gpurun_out/${TAG}_smoke.log; cut -c1-300 gpurun_out/${TAG}_bench_default.json; head -14 gpurun_out/${TAG}_rocprof_stats.txt; cat gpurun_out/${TAG}_traffic.log; tail -5 gpurun_out/${TAG}_pruned.txt
