@@ -1405,7 +1405,10 @@ static void wgrad_geometry(const yh_wgrad_desc* d, WgradArgs* pa, int* psplits, 
         // one resident wave of workgroups (3 per CU at 48 KB of LDS, 4 for the 64-row tiles; 256 CUs), rounded DOWN: a
         // partly filled second wave costs 10-20 % (measured: 1024 -> 768 workgroups, 76x76 128 -> 256: 0.324 -> 0.287 ms),
         // and every extra split costs a partial tile of traffic
-        int target = bm == 64 ? -1024 : (bm == 256 ? (a.bn == 256 ? -256 : -512) : -768);
+        // (round 6, profiles/r06_wgrad_split_sweep.txt: the 1x1 layers - 8 .. 32 tiles, a partial tile of traffic per split - are best at two
+        // workgroups per CU: 38^2 512 -> 256 0.064 -> 0.057 ms, 19^2 1024 -> 512 0.059 -> 0.053, 76^2 256 -> 128 0.083 -> 0.080; every other target
+        // between -384 and -1536 is slower on them, and -512 is slower on the 64-row 3x3 layers)
+        int target = d->kh * d->kw == 1 ? -512 : (bm == 64 ? -1024 : (bm == 256 ? (a.bn == 256 ? -256 : -512) : -768));
         { const char* e = getenv("YH_WGRAD_TARGET"); if (e) target = atoi(e); }
         splits = target > 0 ? (target + tiles - 1) / tiles : (-target) / tiles;   // negative: round down (one wave of workgroups)
         if (splits < 1) splits = 1;

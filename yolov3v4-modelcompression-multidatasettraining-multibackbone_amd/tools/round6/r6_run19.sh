@@ -4,7 +4,7 @@
 R="$GRAFT_REPO_ROOT"; cd "$R" || exit 1
 PKG=yolov3v4-modelcompression-multidatasettraining-multibackbone_amd
 O=gpurun_out/r6t; mkdir -p $O
-for t in default -256 -512 -1024 -1536; do
+for t in ${TARGETS:-default -256 -512 -1024 -1536}; do
   if [ "$t" = "default" ]; then unset YH_WGRAD_TARGET; else export YH_WGRAD_TARGET=$t; fi
   timeout 300 python $PKG/tools/profile_train.py --batch 64 --size 608 > $O/train_$t.txt 2>&1
   echo "== target $t: $(grep -E '^wgrad ' $O/train_$t.txt)"
@@ -12,7 +12,8 @@ done
 python - <<'PY'
 import re, collections
 rows = collections.OrderedDict()
-ts = ['default', '-256', '-512', '-1024', '-1536']
+import os
+ts = os.environ.get("TARGETS", "default -256 -512 -1024 -1536").split()
 for t in ts:
     for l in open('gpurun_out/r6t/train_%s.txt' % t):
         m = re.match(r'bwd\s+(wgrad\d+)\s+(\S+ \S+ k\d s\d)\s+([\d.]+)', l)
