@@ -807,7 +807,9 @@ static int pick_tile(int cout, long P, int cin_k, int vec, int taps = 1) {
     auto blocks = [&](int bm, int bn) { return (long)((c + bm - 1) / bm) * ((P + bn - 1) / bn); };
     if (w128 <= w64 && w128 <= w32) {
         if (w256 == w128 && blocks(256, 128) >= 256) return 26;
-        if (blocks(128, 256) >= 256) return 27;
+        // (one or two K steps - YOLOv4's 80^2 128 -> 128 1x1 layers - are all prologue and epilogue: the narrower tile's extra workgroups overlap
+        // them better, 0.037 -> 0.033 ms on eleven layers, profiles/r06_ring_tile_sweep.txt)
+        if (blocks(128, 256) >= 256) return (long)cin_k * taps <= 128 ? 21 : 27;
         if (blocks(128, 128) >= 256) return 21;
         return 25;
     }
@@ -1042,6 +1044,9 @@ extern "C" int yh_conv2d_tile(const yh_conv_desc* d) {
     if (pick_halo_tile(d)) return 41;
     if (const int pp = pick_pp_tile(d)) return pp;
     const int t = yh::pick_tile(d->cout, (long)d->n * d->ho * d->wo, d->cin_k, d->dtype == YH_F16 ? 8 : 4, d->kh * d->kw);
+    // a layer that stores its 2x upsampling (four stores per value) wants the small tile: more workgroups to overlap the store phase
+    // (round 6, profiles/r06_ring_tile_sweep.txt: 19^2 512 -> 256 0.040 -> 0.029 ms, 38^2 256 -> 128 0.059 -> 0.048, YOLOv4's 40^2 0.040 -> 0.029)
+    if (d->ups == 2 && d->dtype == YH_F16 && (t == 21 || t == 26 || t == 27 || t == 25)) return 24;
     return (d->dtype == YH_I8 && t == 3) ? 24 : t;
 }
 

@@ -30,6 +30,8 @@ def main():
     ap.add_argument('--iters', type=int, default=5)
     ap.add_argument('--tile', type=int, default=0, help='force one conv tile code for every layer (A/B runs)')
     args = ap.parse_args()
+    if args.tile:
+        os.environ['YOLO_HIP_TILE'] = str(args.tile)      # engine/plan.py reads it when the engine is created (generic ring tiles 21 - 35; 3x3: 41 - 43)
     dev = torch.device('cuda', 0)
     model = build_qmodel_synthetic(args.cfg, args.size, dev) if args.precision == 'int8' else \
         build_model(args.cfg, args.size, args.precision, dev)
