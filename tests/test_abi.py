@@ -103,7 +103,9 @@ def test_kernel_selection_on_the_headline_network():
               ((I8, 304, 32, 64, 3, 1, True), 72), ((I8, 304, 64, 128, 3, 2, False), 72), ((I8, 152, 64, 128, 3, 1, True), 72),
               ((F16, 304, 64, 32, 1, 1, False), 71), ((I8, 152, 128, 64, 1, 1, False), 71),
               ((F16, 76, 128, 256, 3, 1, True), 43), ((F16, 38, 256, 512, 3, 1, True), 43), ((F16, 19, 512, 1024, 3, 1, True), 43),
-              ((I8, 76, 128, 256, 3, 1, True), 43), ((F16, 152, 64, 128, 3, 1, True), 43)]
+              ((I8, 76, 128, 256, 3, 1, False), 43), ((I8, 38, 256, 512, 3, 1, True), 43), ((F16, 152, 64, 128, 3, 1, True), 43),
+              # round 6 (profiles/r06_ring_tile_sweep.txt): int8 with two channel chunks AND the fused quantised shortcut is ahead on the ring
+              ((I8, 76, 128, 256, 3, 1, True), 26)]
     for (dt, hw, cin, cout, k, s, res), want in expect:
         assert tile(_conv(dt, 64, hw, cin, cout, k, s, res)) == want, (dt, hw, cin, cout, k, s, res)
     # 1x1 layers of the deeper stages and the fp16 64 -> 128 stride-2 layer stay on the LDS-DMA ring / ping-pong kernels

@@ -965,6 +965,10 @@ static bool pick_hpp_tile(const yh_conv_desc* d) {
     // the 152 x 152 layers (64 -> 128, and the data gradient 128 -> 64 with a half-empty weight tile); behind only with a single
     // channel chunk (304 x 304 32 -> 64: 9 K steps do not amortise the halo prologue)
     if (d->cin_k % bk || d->cout < 64 || d->cin_k / bk < 2) return false;
+    // int8 with exactly two channel chunks (128 input channels: 18 K steps): the 128 x 256 ring tile is ahead when the layer carries the fused
+    // quantised shortcut (YOLOv3-608 b64 76^2 128 -> 256 +res: 0.188 against 0.170 ms on eight layers; without the shortcut 0.138 on this kernel) or is
+    // small (YOLOv4-640 b32 80^2: 0.075 / 0.092 against 0.068 / 0.086) - profiles/r06_ring_tile_sweep.txt
+    if (d->dtype == YH_I8 && d->cin_k / bk == 2 && (d->res || (long)d->n * d->ho * d->wo < 262144)) return false;
     const unsigned amask = d->dtype == YH_F16 ? 15u : 7u;     // 8-channel stores / residual loads
     if (d->cout % 8 || d->ldy % 8 || (((uintptr_t)d->y) & amask) || (d->res && (d->ldr % 8 || (((uintptr_t)d->res) & amask)))) return false;
     if ((long)(d->n + 1) * (d->h + 1) * (d->w_in + 1) + 4096 >= 0x7fffffffL) return false;
@@ -1046,7 +1050,13 @@ extern "C" int yh_conv2d_tile(const yh_conv_desc* d) {
     const int t = yh::pick_tile(d->cout, (long)d->n * d->ho * d->wo, d->cin_k, d->dtype == YH_F16 ? 8 : 4, d->kh * d->kw);
     // a layer that stores its 2x upsampling (four stores per value) wants the small tile: more workgroups to overlap the store phase
     // (round 6, profiles/r06_ring_tile_sweep.txt: 19^2 512 -> 256 0.040 -> 0.029 ms, 38^2 256 -> 128 0.059 -> 0.048, YOLOv4's 40^2 0.040 -> 0.029)
-    if (d->ups == 2 && d->dtype == YH_F16 && (t == 21 || t == 26 || t == 27 || t == 25)) return 24;
+    // (int8: 128 x 64 - 0.035 -> 0.024 and 0.045 -> 0.034 ms)
+    if (d->ups == 2 && (t == 21 || t == 26 || t == 27 || t == 25)) {
+        if (d->dtype == YH_F16) return 24;
+        if (d->dtype == YH_I8) return 25;
+    }
+    // int8 layers with at most four K steps (1x1 from <= 256 channels: YOLOv4's 80^2 128 -> 128 and 256 -> 128): 128 x 64 (0.035 / 0.040 -> 0.029 / 0.032 ms)
+    if (d->dtype == YH_I8 && (t == 21 || t == 27) && (long)d->cin_k * d->kh * d->kw <= 256) return 25;
     return (d->dtype == YH_I8 && t == 3) ? 24 : t;
 }
 
