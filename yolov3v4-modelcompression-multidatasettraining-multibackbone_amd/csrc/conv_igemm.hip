@@ -802,22 +802,24 @@ static int launch(const ConvArgs& a0, hipStream_t stream) {
 static int pick_tile(int cout, long P, int cin_k, int vec, int taps = 1) {
     (void)vec;
     const int c = cout;
-    const long w256 = ((c + 255) / 256) * 256, w128 = ((c + 127) / 128) * 128, w64 = ((c + 63) / 64) * 64,
-               w32 = ((c + 31) / 32) * 32;
+    const long w256 = ((c + 255) / 256) * 256, w128 = ((c + 127) / 128) * 128, w64 = ((c + 63) / 64) * 64;
     auto blocks = [&](int bm, int bn) { return (long)((c + bm - 1) / bm) * ((P + bn - 1) / bn); };
-    if (w128 <= w64 && w128 <= w32) {
-        if (w256 == w128 && blocks(256, 128) >= 256) return 26;
+    // Round 6 (profiles/r06_ring_tile_sweep.txt, sweeps on YOLOv3 / YOLOv4 / YOLOv3-Mobilenetv3 with the final kernels):
+    //  * the 32-row register-staged tile only for <= 32 outputs over a K of one step.  The round-1 rule also sent every width that pads least on
+    //    32 rows (72, 80, 160, 184, 200, 240, 480, 672, 960 ... : Mobilenetv3) there, where ANY ring tile is 1.3 - 2 x faster (26^2 112 -> 672:
+    //    0.052 -> 0.028 ms), and <= 32 outputs over 64 - 72 channels (104^2 64 -> 24: 0.046 -> 0.033 on the 64 x 128 ring tile)
+    //  * 256 x 128 / 128 x 256 only from two workgroups per CU on; below, 128 x 128 (38^2 256 -> 256 at batch 32: 0.0253 -> 0.0232 ms on nine
+    //    layers, the data gradients 0.0284 -> 0.0255; 19^2 1024 -> 512 at batch 64: 0.046 -> 0.044)
+    if (c <= 32) return (long)cin_k * taps >= 64 ? 24 : 3;
+    if (w128 <= w64) {
+        if (w256 == w128 && blocks(256, 128) >= 512) return 26;
         // (one or two K steps - YOLOv4's 80^2 128 -> 128 1x1 layers - are all prologue and epilogue: the narrower tile's extra workgroups overlap
-        // them better, 0.037 -> 0.033 ms on eleven layers, profiles/r06_ring_tile_sweep.txt)
-        if (blocks(128, 256) >= 256) return (long)cin_k * taps <= 128 ? 21 : 27;
+        // them better, 0.037 -> 0.033 ms on eleven layers)
+        if (blocks(128, 256) >= 512) return (long)cin_k * taps <= 128 ? 21 : 27;
         if (blocks(128, 128) >= 256) return 21;
         return 25;
     }
-    if (w64 <= w32) return blocks(64, 256) >= 2048 ? 24 : 24;
-    // <= 32 outputs: the 32-row register-staged tile, except for long K (3x3 over >= 64 channels: the data gradient of the
-    // early layers), where the LDS-DMA 64x128 tile wins despite its idle upper half (0.77 vs 0.98 ms at 304x304, 64 -> 32)
-    if ((long)cin_k * taps >= 512) return 24;
-    return 3;
+    return 24;      // 64-row tiles pad less
 }
 
 template <typename T, typename OutT> static int dispatch_tile(const ConvArgs& a, int tile, hipStream_t s) {
@@ -965,6 +967,9 @@ static bool pick_hpp_tile(const yh_conv_desc* d) {
     // the 152 x 152 layers (64 -> 128, and the data gradient 128 -> 64 with a half-empty weight tile); behind only with a single
     // channel chunk (304 x 304 32 -> 64: 9 K steps do not amortise the halo prologue)
     if (d->cin_k % bk || d->cout < 64 || d->cin_k / bk < 2) return false;
+    // fp16, a half-empty 128-row weight tile AND only two channel chunks (YOLOv4's 152^2 / 160^2 64 -> 64 layers): the 64 x 128 ring tile is ahead,
+    // 0.204 -> 0.147 ms in detection, 0.170 -> 0.119 in the training forward (128 -> 64, four chunks, stays: 5 - 13 % ahead here, round 3)
+    if (d->dtype == YH_F16 && d->cout <= 64 && d->cin_k / bk == 2) return false;
     // int8 with exactly two channel chunks (128 input channels: 18 K steps): the 128 x 256 ring tile is ahead when the layer carries the fused
     // quantised shortcut (YOLOv3-608 b64 76^2 128 -> 256 +res: 0.188 against 0.170 ms on eight layers; without the shortcut 0.138 on this kernel) or is
     // small (YOLOv4-640 b32 80^2: 0.075 / 0.092 against 0.068 / 0.086) - profiles/r06_ring_tile_sweep.txt

@@ -1408,7 +1408,9 @@ static void wgrad_geometry(const yh_wgrad_desc* d, WgradArgs* pa, int* psplits, 
         // (round 6, profiles/r06_wgrad_split_sweep.txt: the 1x1 layers - 8 .. 32 tiles, a partial tile of traffic per split - are best at two
         // workgroups per CU: 38^2 512 -> 256 0.064 -> 0.057 ms, 19^2 1024 -> 512 0.059 -> 0.053, 76^2 256 -> 128 0.083 -> 0.080; every other target
         // between -384 and -1536 is slower on them, and -512 is slower on the 64-row 3x3 layers)
-        int target = d->kh * d->kw == 1 ? -512 : (bm == 64 ? -1024 : (bm == 256 ? (a.bn == 256 ? -256 : -512) : -768));
+        // (a single tiny tile - Mobilenetv3's 208^2 16 -> 16 - keeps -1024: 0.088 against 0.113 ms)
+        const bool one_small_tile = d->cout <= 32 && a.ncols <= 32;
+        int target = d->kh * d->kw == 1 && !one_small_tile ? -512 : (bm == 64 ? -1024 : (bm == 256 ? (a.bn == 256 ? -256 : -512) : -768));
         { const char* e = getenv("YH_WGRAD_TARGET"); if (e) target = atoi(e); }
         splits = target > 0 ? (target + tiles - 1) / tiles : (-target) / tiles;   // negative: round down (one wave of workgroups)
         if (splits < 1) splits = 1;
